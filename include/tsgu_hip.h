@@ -1,0 +1,179 @@
+/*
+ * tsgu_hip.h — C ABI of the MI355X (gfx950) sparse hot path.
+ *
+ * This is the drop-in boundary of the build: every entry point replaces one ATen
+ * call site of the reference (cai4cai/torchsparsegradutils).  The reference has no
+ * native code, so there is no FFI to mirror; the functions below are what a binding
+ * for its hot path would call.  For every entry the replaced reference line is cited
+ * (paths relative to the reference checkout).
+ *
+ * Conventions
+ *   - plain pointers + sizes; no torch / C++ types; nothing throws across the ABI.
+ *   - all pointers are DEVICE pointers unless the name ends in `_host`.
+ *   - every launcher returns TSGU_OK (0) or a negative tsgu_status; it never syncs
+ *     the stream and never allocates device memory (workspaces are passed in), with
+ *     the single documented exception of the `*_analyse_host` helpers.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream);
+ *     `device` is the HIP ordinal the pointers live on.
+ *   - dense operands are row-major with an explicit leading dimension (elements).
+ *   - value dtype / index dtype are run-time enums (tsgu_vtype / tsgu_itype).
+ *   - CSR column indices inside a row need NOT be sorted or unique.
+ *   - batched CSR (torch layout): crow [batch][n_rows+1], col/val [batch][nnz_per_item];
+ *     every item's crow starts at 0.  batch == 1 for plain 2-D matrices.
+ */
+#ifndef TSGU_HIP_H
+#define TSGU_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TSGU_ABI_VERSION 1
+
+typedef enum {
+    TSGU_OK = 0,
+    TSGU_ERR_BAD_DTYPE = -1,     /* unsupported vtype/itype combination        */
+    TSGU_ERR_BAD_ARG = -2,       /* null pointer, negative size, bad leading dimension */
+    TSGU_ERR_TOO_LARGE = -3,     /* n_cols >= 2^31 or grid limit exceeded     */
+    TSGU_ERR_LAUNCH = -4,        /* hipLaunchKernel / hipGetLastError failed  */
+    TSGU_ERR_RUNTIME = -5,       /* other HIP runtime failure                 */
+    TSGU_ERR_NOT_TRIANGULAR = -6,/* zero/missing diagonal detected by analysis */
+    TSGU_ERR_TIMEOUT = -7        /* bounded device spin expired (sptrsm)       */
+} tsgu_status;
+
+typedef enum { TSGU_F32 = 0, TSGU_F64 = 1, TSGU_BF16 = 2 } tsgu_vtype;
+typedef enum { TSGU_I32 = 0, TSGU_I64 = 1 } tsgu_itype;
+
+/* Library / device introspection (no reference counterpart). */
+int tsgu_abi_version(void);
+const char* tsgu_status_string(int status);
+/* Fills name (<= cap bytes), compute-unit count and wavefront size of `device`. */
+int tsgu_device_info(int device, char* name, int cap, int* n_cu, int* wave_size);
+
+/*
+ * K1  C = A · B            (CSR × dense, optional fused column-dot epilogue)
+ * replaces: torch.sparse.mm(A, B)            torchsparsegradutils/sparse_matmul.py:155
+ *           A.matmul(p) in the Krylov loops  torchsparsegradutils/utils/linear_cg.py:322,
+ *                                            utils/bicgstab.py:196,221
+ *
+ * perm (optional, itype, [nnz]): value indirection — entry k uses val[perm[k]].  This is
+ * how Aᵀ·G (K2) runs on the cached transposed pattern without materialising Aᵀ's values:
+ * replaces: torch.sparse.mm(A.t(), grad)     torchsparsegradutils/sparse_matmul.py:229
+ *
+ * dot_w / dot_partial (optional): when non-NULL the kernel also writes, per thread block,
+ * partial[block][c] = sum_rows C[row,c] * W[row,c]  (fp32/fp64 accumulate), block-major,
+ * ld = p.  W has leading dimension ldw.  `tsgu_spmm_num_blocks` gives the row count of
+ * `dot_partial`.  Used for pᵀ(Ap) in CG (linear_cg.py:64-65).
+ */
+int tsgu_csr_spmm(int vtype, int itype,
+                  int64_t n_rows, int64_t n_cols, int64_t nnz_per_item,
+                  const void* crow, const void* col, const void* val, const void* perm,
+                  const void* B, int64_t ldb, int64_t b_batch_stride,
+                  void* C, int64_t ldc, int64_t c_batch_stride,
+                  int64_t p, int64_t batch,
+                  const void* dot_w, int64_t ldw, void* dot_partial,
+                  int device, void* stream);
+
+/* Number of thread blocks (per batch item) tsgu_csr_spmm uses for (n_rows, p, vtype). */
+int64_t tsgu_spmm_num_blocks(int vtype, int64_t n_rows, int64_t p);
+
+/*
+ * K3  out[k] = alpha * < G[row(k), :], B[col(k), :] >   for every stored entry k of A
+ * (sparsity-masked SDDMM; no row-index expansion, no nnz×p temporaries)
+ * replaces: repeat_interleave + 2×index_select + mul + sum
+ *           torchsparsegradutils/sparse_matmul.py:186-205      (alpha = +1)
+ *           torchsparsegradutils/sparse_solve.py:216-235       (alpha = -1, role swap when
+ *                                                               transpose: pass G/B swapped
+ *                                                               via `swap_roles`)
+ *           torchsparsegradutils/sparse_solve.py:487-504       (alpha = -1)
+ * swap_roles != 0 computes  alpha * < G[col(k), :], B[row(k), :] >  (sparse_solve.py:223-225).
+ * out has vtype, [batch][nnz_per_item].
+ */
+int tsgu_csr_sddmm(int vtype, int itype,
+                   int64_t n_rows, int64_t n_cols, int64_t nnz_per_item,
+                   const void* crow, const void* col,
+                   const void* G, int64_t ldg, int64_t g_batch_stride,
+                   const void* B, int64_t ldb, int64_t b_batch_stride,
+                   void* out, double alpha, int swap_roles,
+                   int64_t p, int64_t batch,
+                   int device, void* stream);
+
+/*
+ * COO flavour of K3 for un-coalesced COO inputs (explicit row indices, any order):
+ * out[k] = alpha * < G[row[k], :], B[col[k], :] >
+ * replaces: torchsparsegradutils/sparse_matmul.py:185,201-205 (COO branch)
+ */
+int tsgu_coo_sddmm(int vtype, int itype, int64_t nnz,
+                   const void* row, const void* col,
+                   const void* G, int64_t ldg, const void* B, int64_t ldb,
+                   void* out, double alpha, int64_t p,
+                   int device, void* stream);
+
+/*
+ * K4  X = op(A)^{-1} B   sparse triangular solve, sync-free (dependency-driven) CSR sweep.
+ * replaces: torch.triangular_solve(B, A, upper, transpose, unitriangular).solution
+ *           torchsparsegradutils/_compat.py:42-48  (from sparse_solve.py:181-183 and :202-204)
+ *
+ * The kernel walks a row-gather structure (ptr, idx, [perm], val) of the matrix M whose rows
+ * are solved in dependency order:  transpose == 0 → M = A (its CSR arrays, perm = NULL);
+ * transpose != 0 → the caller passes the cached transposed pattern of A (CSC arrays of A viewed
+ * as CSR of Aᵀ) with `perm` mapping into A's values, and `lower` already flipped.
+ * Entries on the wrong side of the diagonal are ignored; with unit != 0 stored diagonal entries
+ * are ignored too (same as the reference's backend).  X must NOT alias B.
+ * `work` : device scratch, tsgu_sptrsm_work_bytes() bytes, contents irrelevant on entry.
+ */
+int tsgu_csr_sptrsm(int vtype, int itype,
+                    int64_t n, int64_t nnz,
+                    const void* ptr, const void* idx, const void* perm, const void* val,
+                    int lower, int unit,
+                    const void* B, int64_t ldb, void* X, int64_t ldx, int64_t p,
+                    void* work, int device, void* stream);
+int64_t tsgu_sptrsm_work_bytes(int64_t n, int64_t p);
+
+/*
+ * K5  fused CG vector updates (no preconditioner), all per-column scalars stay on the device.
+ * replaces the ≈15-op chain  torchsparsegradutils/utils/linear_cg.py:64-95 (+ :27-47, :372-382)
+ *
+ * state layout (value type T = f32 or f64), all [p] unless noted:
+ *   scal + 0*p : rr        (residual_inner_prod, rᵀr of the current residual)
+ *   scal + 1*p : alpha
+ *   scal + 2*p : beta
+ *   scal + 3*p : rnorm     (‖r‖₂ per column, masked to 0 where rhs_is_zero)
+ *   flags (int32): [0] done (tolerance reached), [1] iterations executed, [2..2+p) has_converged,
+ *                  [2+p..2+2p) rhs_is_zero
+ *
+ * step 1  tsgu_cg_alpha:   alpha = safe(rr / Σ_blocks pAp_partial), 0 for converged columns
+ * step 2  tsgu_cg_update1: r -= alpha·Ap ; x += alpha·p ; partial rr_new per block
+ * step 3  tsgu_cg_beta:    rr_new = Σ partial ; beta = safe(rr_new / rr) ; rr = rr_new ;
+ *                          rnorm = sqrt(rr_new) (masked) ; has_converged ; done flag
+ * step 4  tsgu_cg_update2: pvec = r + beta·pvec
+ * Every step is a no-op once flags[0] != 0, so a host may enqueue iterations ahead and poll.
+ */
+int tsgu_cg_alpha(int vtype, const void* pap_partial, int64_t n_partial, void* scal, int* flags,
+                  double eps, int64_t p, int device, void* stream);
+int tsgu_cg_update1(int vtype, int64_t n, int64_t p,
+                    void* r, const void* Ap, void* x, const void* pvec,
+                    const void* scal, const int* flags, void* rr_partial,
+                    int device, void* stream);
+/* rows of rr_partial written by tsgu_cg_update1; r/Ap/x/pvec must be contiguous [n][p], 16-byte aligned */
+int64_t tsgu_cg_num_blocks(int vtype, int64_t n, int64_t p);
+int tsgu_cg_beta(int vtype, const void* rr_partial, int64_t n_partial, void* scal, int* flags,
+                 double eps, double stop_updating_after, double tolerance, int iter_index,
+                 int min_iter_index, int64_t p, int device, void* stream);
+int tsgu_cg_update2(int vtype, int64_t n, int64_t p, const void* r, void* pvec,
+                    const void* scal, const int* flags, int device, void* stream);
+
+/* Column-wise dot products  out[c] = Σ_i X[i,c]·Y[i,c]  (two-stage, deterministic).
+ * replaces: torch.dot / mul+sum in utils/bicgstab.py:168,199,222-224 and linear_cg.py:294 */
+/* `partial` needs tsgu_coldot_max_blocks(n, p) * p elements. */
+int64_t tsgu_coldot_max_blocks(int64_t n, int64_t p);
+int tsgu_coldot(int vtype, int64_t n, int64_t p, const void* X, int64_t ldx,
+                const void* Y, int64_t ldy, void* partial, void* out,
+                int device, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TSGU_HIP_H */

@@ -1,0 +1,255 @@
+"""CPU oracle for the sparse hot path — TEST INFRASTRUCTURE ONLY.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+this module; the product package never does.  It restates, in numpy on top of the plain-C
+loops of ``csr_oracle.c``, the algorithm of the reference's hot path:
+
+* ``sparse_mm`` forward/backward            reference sparse_matmul.py:141-234
+* ``sparse_triangular_solve`` fwd/bwd       reference sparse_solve.py:161-252, _compat.py:42-48
+* ``sparse_generic_solve`` backward rule    reference sparse_solve.py:455-519
+* ``linear_cg`` (no preconditioner/Lanczos) reference utils/linear_cg.py:213-430
+* ``bicgstab``                              reference utils/bicgstab.py:112-247
+
+The arithmetic itself lives in PyTorch ATen (third-party; the reference pins ``torch>=2.5``,
+pyproject.toml:23), so each kernel-level function restates the mathematical definition of the
+ATen call at the cited line.  PINNING: ``tests/test_oracle_golden.py`` checks every function
+here against outputs of the real reference captured by ``tests/golden/make_golden.py`` (run in
+the build container, where the reference is importable) — parity is pinned, not assumed.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "liboracle.so")
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "csr_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["gcc", "-O2", "-std=c99", "-fPIC", "-shared", "-ffp-contract=off", src, "-o", _SO, "-lm"])
+    return _SO
+
+
+def _load():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = ctypes.CDLL(_SO)
+    return _lib
+
+
+def _sfx(dtype) -> str:
+    dtype = np.dtype(dtype)
+    if dtype == np.float32:
+        return "f32"
+    if dtype == np.float64:
+        return "f64"
+    raise TypeError(f"oracle supports float32/float64, got {dtype}")
+
+
+def _i64(a):
+    return np.ascontiguousarray(a, dtype=np.int64)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _c(a, dtype):
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+I64 = ctypes.c_int64
+
+
+# ---- kernel-level restatements ---------------------------------------------------------------
+
+def csr_spmm(crow, col, val, B):
+    """C = A·B (reference sparse_matmul.py:155)."""
+    dt = val.dtype
+    crow, col, val, B = _i64(crow), _i64(col), _c(val, dt), _c(B, dt)
+    n, p = crow.size - 1, B.shape[1]
+    C = np.empty((n, p), dtype=dt)
+    fn = getattr(_load(), "oracle_csr_spmm_" + _sfx(dt))
+    fn(I64(n), _ptr(crow), _ptr(col), _ptr(val), _ptr(B), I64(p), _ptr(C), I64(p), I64(p))
+    return C
+
+
+def csr_spmm_t(crow, col, val, G, n_cols):
+    """D = Aᵀ·G (reference sparse_matmul.py:229)."""
+    dt = val.dtype
+    crow, col, val, G = _i64(crow), _i64(col), _c(val, dt), _c(G, dt)
+    n, p = crow.size - 1, G.shape[1]
+    D = np.empty((n_cols, p), dtype=dt)
+    fn = getattr(_load(), "oracle_csr_spmm_t_" + _sfx(dt))
+    fn(I64(n), I64(n_cols), _ptr(crow), _ptr(col), _ptr(val), _ptr(G), I64(p), _ptr(D), I64(p), I64(p))
+    return D
+
+
+def csr_sddmm(crow, col, R, Cm, alpha=1.0):
+    """out[k] = alpha·<R[row k], Cm[col k]> (reference sparse_matmul.py:186-205)."""
+    dt = R.dtype
+    crow, col, R, Cm = _i64(crow), _i64(col), _c(R, dt), _c(Cm, dt)
+    n, p = crow.size - 1, R.shape[1]
+    out = np.empty(col.size, dtype=dt)
+    ct = ctypes.c_float if dt == np.float32 else ctypes.c_double
+    fn = getattr(_load(), "oracle_csr_sddmm_" + _sfx(dt))
+    fn(I64(n), _ptr(crow), _ptr(col), _ptr(R), I64(p), _ptr(Cm), I64(p), ct(alpha), _ptr(out), I64(p))
+    return out
+
+
+def coo_sddmm(row, col, R, Cm, alpha=1.0):
+    """COO branch of the same rule (reference sparse_matmul.py:185,201-205)."""
+    dt = R.dtype
+    row, col, R, Cm = _i64(row), _i64(col), _c(R, dt), _c(Cm, dt)
+    out = np.empty(row.size, dtype=dt)
+    ct = ctypes.c_float if dt == np.float32 else ctypes.c_double
+    fn = getattr(_load(), "oracle_coo_sddmm_" + _sfx(dt))
+    fn(I64(row.size), _ptr(row), _ptr(col), _ptr(R), I64(R.shape[1]), _ptr(Cm), I64(R.shape[1]), ct(alpha),
+       _ptr(out), I64(R.shape[1]))
+    return out
+
+
+def csr_sptrsm(crow, col, val, B, upper, unit=False, transpose=False):
+    """X = op(A)^{-1}B (reference _compat.py:42-48)."""
+    dt = val.dtype
+    crow, col, val, B = _i64(crow), _i64(col), _c(val, dt), _c(B, dt)
+    n, p = crow.size - 1, B.shape[1]
+    X = np.empty((n, p), dtype=dt)
+    fn = getattr(_load(), "oracle_csr_sptrsm_" + _sfx(dt))
+    rc = fn(I64(n), _ptr(crow), _ptr(col), _ptr(val), int(upper), int(unit), int(transpose), _ptr(B), I64(p),
+            _ptr(X), I64(p), I64(p))
+    assert rc == 0
+    return X
+
+
+def expand_rows(crow):
+    """repeat_interleave(arange(n), diff(crow)) (reference sparse_matmul.py:190-192)."""
+    crow = _i64(crow)
+    return np.repeat(np.arange(crow.size - 1, dtype=np.int64), np.diff(crow))
+
+
+def block_diag_csr(crows, cols, vals, m):
+    """Batched CSR (b, ·) → one block-diagonal CSR (reference utils/utils.py:615-645)."""
+    b, nnz = cols.shape
+    crow = np.concatenate([[0]] + [crows[i, 1:].astype(np.int64) + i * nnz for i in range(b)])
+    col = np.concatenate([cols[i].astype(np.int64) + i * m for i in range(b)])
+    return crow, col, vals.reshape(-1)
+
+
+# ---- autograd-rule restatements ----------------------------------------------------------------
+
+def sparse_mm_fwd_bwd(crow, col, val, B, G, n_cols):
+    """forward C and backward (gradA values at A's pattern, gradB) — sparse_matmul.py:141-234."""
+    C = csr_spmm(crow, col, val, B)
+    gradA = csr_sddmm(crow, col, G, B, 1.0)
+    gradB = csr_spmm_t(crow, col, val, G, n_cols)
+    return C, gradA, gradB
+
+
+def triangular_solve_fwd_bwd(crow, col, val, B, G, upper, unit, transpose):
+    """x, gradA values, gradB — sparse_solve.py:161-252."""
+    x = csr_sptrsm(crow, col, val, B, upper, unit, transpose)
+    gradB = csr_sptrsm(crow, col, val, G, upper, unit, not transpose)  # :202-204
+    if transpose:  # :223-225  -gradB[col]·x[row]
+        gradA = csr_sddmm(crow, col, x, gradB, -1.0)
+    else:  # :226-228  -gradB[row]·x[col]
+        gradA = csr_sddmm(crow, col, gradB, x, -1.0)
+    return x, gradA, gradB
+
+
+def linear_cg(crow, col, val, rhs, tolerance, max_iter=1000, eps=1e-10, stop_updating_after=1e-10,
+              record_iters=()):
+    """Multi-RHS CG without preconditioner (reference utils/linear_cg.py:213-430, n_tridiag=0).
+
+    Returns (x, iterations, snapshots) where snapshots[k] is the un-normalised iterate after k
+    iterations for k in record_iters."""
+    dt = rhs.dtype
+    e = dt.type(eps)
+    rhs_norm = np.sqrt((rhs * rhs).sum(0, keepdims=True, dtype=dt))  # :257
+    rhs_is_zero = rhs_norm < e
+    rhs_norm = np.where(rhs_is_zero, dt.type(1), rhs_norm)
+    rhs = rhs / rhs_norm  # :262
+    x = np.zeros_like(rhs)
+    r = rhs - csr_spmm(crow, col, val, x)  # :266
+    rnorm = np.sqrt((r * r).sum(0, keepdims=True, dtype=dt))
+    has_conv = rnorm < dt.type(stop_updating_after)
+    snaps = {}
+    if has_conv.all():
+        return x * rhs_norm, 0, snaps
+    pvec = r.copy()
+    rr = (r * r).sum(0, keepdims=True, dtype=dt)  # :294
+    k_done = 0
+    for k in range(max_iter):
+        Ap = csr_spmm(crow, col, val, pvec)  # :322
+        pAp = (pvec * Ap).sum(0, keepdims=True, dtype=dt)  # :64-65
+        zero = pAp < e
+        alpha = np.where(zero, dt.type(0), rr / np.where(zero, dt.type(1), pAp))  # :68-71
+        alpha = np.where(has_conv, dt.type(0), alpha)  # :74
+        r = r - alpha * Ap  # :78
+        x = x + alpha * pvec  # :32
+        rr_old = rr
+        rr = (r * r).sum(0, keepdims=True, dtype=dt)  # :36-37
+        zero = rr_old < e
+        beta = np.where(zero, dt.type(0), rr / np.where(zero, dt.type(1), rr_old))  # :40-43
+        pvec = pvec * beta + r  # :47
+        rnorm = np.sqrt((r * r).sum(0, keepdims=True, dtype=dt))  # :372
+        rnorm = np.where(rhs_is_zero, dt.type(0), rnorm)
+        has_conv = rnorm < dt.type(stop_updating_after)  # :374
+        k_done = k + 1
+        if k_done in record_iters:
+            snaps[k_done] = (x * rhs_norm).copy()
+        if k >= min(10, max_iter - 1) and rnorm.mean() < tolerance:  # :376-382
+            break
+    return x * rhs_norm, k_done, snaps
+
+
+def bicgstab(crow, col, val, b, matvec_max=None, abstol=1e-8, reltol=1e-6):
+    """Single-vector BiCGSTAB, x0 = 0 (reference utils/bicgstab.py:126-247)."""
+    dt = b.dtype
+    n = b.shape[0]
+    mv = lambda v: csr_spmm(crow, col, val, v.reshape(-1, 1)).reshape(-1)
+    x = np.zeros(n, dtype=dt)
+    matvec_max = 2 * n if matvec_max is None else matvec_max
+    r0 = b - mv(x)
+    n_mv = 1
+    rho = alpha = omega = dt.type(1)
+    rho_next = np.dot(r0, r0)
+    resid = resid0 = np.abs(np.sqrt(rho_next))
+    thresh = max(abstol, reltol * resid0)
+    finished = resid <= thresh or n_mv >= matvec_max
+    if not finished:
+        r = r0.copy()
+        p = np.zeros(n, dtype=dt)
+        v = np.zeros(n, dtype=dt)
+    while not finished:
+        beta = rho_next / rho * alpha / omega
+        rho = rho_next
+        p = p * beta - beta * omega * v + r
+        v = mv(p)
+        n_mv += 1
+        alpha = rho / np.dot(r0, v)
+        s = r - alpha * v
+        resid = np.linalg.norm(s)
+        if resid <= thresh:
+            x = x + alpha * p
+            break
+        if n_mv >= matvec_max:
+            break
+        t = mv(s)
+        n_mv += 1
+        omega = np.dot(t, s) / np.dot(t, t)
+        rho_next = -omega * np.dot(r0, t)
+        r = s - omega * t
+        x = x + omega * s + alpha * p
+        resid = np.linalg.norm(r)
+        if resid <= thresh or n_mv >= matvec_max:
+            break
+    return x, n_mv

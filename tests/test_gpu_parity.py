@@ -1,0 +1,433 @@
+"""Parity of the HIP path (through the public API → C ABI) against the golden vectors of the real
+reference and against the CPU oracle on seeded inputs.  Needs an MI355X: `pytest -m gpu`.
+
+Tolerances (BASELINE north_star): indices bit-exact; values within 1e-5 relative fp32
+(normalised by the largest reference magnitude), 1e-11 fp64, 1e-3 bf16.
+"""
+
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+import _golden as G
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+TOL = {torch.float32: 1e-5, torch.float64: 1e-11}
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu_and_extension():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    from torchsparsegradutils_amd import _backend
+
+    _backend.load_library()  # no fallback: a missing extension is a failure, not a skip
+    name, n_cu, wave = _backend.device_info(0)
+    assert wave == 64
+    yield
+
+
+def tsgu():
+    import torchsparsegradutils_amd as m
+
+    return m
+
+
+def rel(a, b):
+    a = a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+    return G.rel_err(a, b)
+
+
+def shape_of(z, name):
+    B, Gd = z[name + "B"], z[name + "G"]
+    if B.ndim == 3:
+        return (B.shape[0], Gd.shape[1], B.shape[1])
+    return (Gd.shape[0], B.shape[0])
+
+
+# ---------------------------------------------------------------- sparse_mm -----------------
+def test_c1_config_coo_4096():
+    z = G.load("mm_c1_coo.npz")
+    idx = torch.from_numpy(np.stack([z["rows"].astype(np.int64), z["cols"].astype(np.int64)])).to(DEV)
+    A = torch.sparse_coo_tensor(idx, G.t(z["val"], DEV), (4096, 4096), is_coalesced=True).requires_grad_(True)
+    B = G.t(z["B"], DEV).requires_grad_(True)
+    C = tsgu().sparse_mm(A, B)
+    C.backward(G.t(z["G"], DEV))
+    assert A.grad.layout == torch.sparse_coo and A.grad._nnz() == 167772
+    assert torch.equal(A.grad._indices(), idx)
+    assert rel(C, z["C"]) < 1e-5
+    assert rel(A.grad._values(), z["gradA_val"]) < 1e-5
+    assert rel(B.grad, z["gradB"]) < 1e-5
+
+
+def test_mm_small_layouts_dtypes_batched():
+    z = G.load("mm_small.npz")
+    for name in z["names"]:
+        name = str(name)
+        shape = shape_of(z, name)
+        A = G.sparse_from(z, name + "A_", shape, DEV, requires_grad=True)
+        B = G.t(z[name + "B"], DEV).requires_grad_(True)
+        C = tsgu().sparse_mm(A, B)
+        C.backward(G.t(z[name + "G"], DEV))
+        tol = TOL[B.dtype]
+        assert rel(C, z[name + "C"]) < tol, name
+        assert rel(B.grad, z[name + "gradB"]) < tol, name
+        gA = A.grad
+        assert gA.layout == A.layout and gA.shape == A.shape, name
+        if gA.layout == torch.sparse_csr:
+            for mine, key in ((gA.crow_indices(), "crow"), (gA.col_indices(), "col")):
+                ref = z[name + "gradA_" + key]
+                assert mine.cpu().numpy().dtype == ref.dtype, name  # int32 stays int32
+                assert np.array_equal(mine.cpu().numpy(), ref), name
+            assert rel(gA.values(), z[name + "gradA_val"]) < tol, name
+        else:
+            assert np.array_equal(gA._indices().cpu().numpy(), z[name + "gradA_idx"]), name
+            assert rel(gA._values(), z[name + "gradA_val"]) < tol, name
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float64])
+def test_mm_stencil27_scaled_c2(dt):
+    from torchsparsegradutils_amd.utils import synthetic
+
+    z = G.load("mm_stencil27_12.npz")
+    vn = "f32" if dt == torch.float32 else "f64"
+    crow, col = synthetic.stencil27_periodic(12, 12, 12, torch.int32, device=DEV)
+    A = torch.sparse_csr_tensor(crow, col, G.t(z["val64"], DEV).to(dt), (1728, 1728)).requires_grad_(True)
+    B = G.t(z["B64"], DEV).to(dt).requires_grad_(True)
+    C = tsgu().sparse_mm(A, B)
+    C.backward(G.t(z["G64"], DEV).to(dt))
+    assert A.grad.crow_indices().dtype == torch.int32
+    assert torch.equal(A.grad.crow_indices(), crow) and torch.equal(A.grad.col_indices(), col)
+    assert rel(C, z[vn + "_C"]) < TOL[dt]
+    assert rel(A.grad.values(), z[vn + "_gradA_val"]) < TOL[dt]
+    assert rel(B.grad, z[vn + "_gradB"]) < TOL[dt]
+
+
+def test_mm_bf16_csr():
+    z = G.load("bf16_stencil.npz")
+    crow, col = G.t(z["crow"], DEV), G.t(z["col"], DEV)
+    A = torch.sparse_csr_tensor(crow, col, G.bf16(z["val_bf16"], DEV), (512, 512)).requires_grad_(True)
+    B = G.bf16(z["B_bf16"], DEV).requires_grad_(True)
+    C = tsgu().sparse_mm(A, B)
+    C.backward(G.bf16(z["G_bf16"], DEV))
+    assert C.dtype == torch.bfloat16 and A.grad.values().dtype == torch.bfloat16
+    # fp32 accumulation, one final rounding to bf16: within 1 bf16 ulp of the fp32 reference (≤ 2^-8 relative per
+    # element), i.e. 1e-3-class normwise
+    for mine, ref in ((C, z["C_f32"]), (A.grad.values(), z["gradA_f32"]), (B.grad, z["gradB_f32"])):
+        mine = mine.float().cpu().numpy()
+        assert np.all(np.abs(mine - ref) <= np.abs(ref) * 2.0 ** -8 + 1e-30)
+        assert np.linalg.norm(mine - ref) / np.linalg.norm(ref) < 3e-3
+
+
+def test_mm_one_sided_requires_grad_and_second_backward():
+    z = G.load("mm_small.npz")
+    name = "r2_csr_i32_f32_"
+    shape = shape_of(z, name)
+    A = G.sparse_from(z, name + "A_", shape, DEV, requires_grad=True)
+    B = G.t(z[name + "B"], DEV)
+    C = tsgu().sparse_mm(A, B)
+    C.sum().backward()
+    assert A.grad is not None and B.grad is None
+    A2 = G.sparse_from(z, name + "A_", shape, DEV)
+    B2 = G.t(z[name + "B"], DEV).requires_grad_(True)
+    C2 = tsgu().sparse_mm(A2, B2)
+    C2.sum().backward()
+    assert B2.grad is not None and A2.grad is None
+    with pytest.raises(RuntimeError):
+        C2.sum().backward()  # saved tensors were released (reference test_sparse_matmul.py:363-376)
+
+
+def test_mm_noncontiguous_rhs_and_wide_rhs():
+    """Transposed/strided B views (reference distributions/sparse_multivariate_normal.py:96-100) and
+    p > 256 (column tiling) against the oracle."""
+    from oracle import oracle
+    from torchsparsegradutils_amd.utils import synthetic
+
+    crow, col = synthetic.stencil27_periodic(6, 5, 4, torch.int64)
+    n = 120
+    val = torch.randn(col.numel(), dtype=torch.float64)
+    for p in (3, 300):
+        Bt = torch.randn(p, n, dtype=torch.float64)
+        A = torch.sparse_csr_tensor(crow.to(DEV), col.to(DEV), val.to(DEV), (n, n)).requires_grad_(True)
+        B = Bt.to(DEV).t().requires_grad_(True)  # (n, p) view with stride (1, n)
+        Gd = torch.randn(n, p, dtype=torch.float64)
+        C = tsgu().sparse_mm(A, B)
+        C.backward(Gd.to(DEV))
+        Co, gAo, gBo = oracle.sparse_mm_fwd_bwd(crow.numpy(), col.numpy(), val.numpy(), Bt.t().numpy(), Gd.numpy(), n)
+        assert rel(C, Co) < 1e-12 and rel(A.grad.values(), gAo) < 1e-12 and rel(B.grad, gBo) < 1e-12
+
+
+def test_mm_ragged_and_empty_rows_long_row():
+    """Empty rows, one very long row (> one LDS staging pass), empty matrix, against the oracle."""
+    from oracle import oracle
+
+    n, m, p = 70, 5000, 8
+    rng = np.random.default_rng(0)
+    counts = rng.integers(0, 6, size=n)
+    counts[3] = 0
+    counts[10] = 4500  # longer than the 2048-entry staging window
+    counts[69] = 0
+    crow = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    col = np.concatenate([rng.choice(m, size=c, replace=False) for c in counts]).astype(np.int64)
+    val = rng.standard_normal(col.size).astype(np.float32)
+    B = rng.standard_normal((m, p)).astype(np.float32)
+    Gd = rng.standard_normal((n, p)).astype(np.float32)
+    A = torch.sparse_csr_tensor(G.t(crow, DEV), G.t(col, DEV), G.t(val, DEV), (n, m)).requires_grad_(True)
+    Bd = G.t(B, DEV).requires_grad_(True)
+    C = tsgu().sparse_mm(A, Bd)
+    C.backward(G.t(Gd, DEV))
+    Co, gAo, gBo = oracle.sparse_mm_fwd_bwd(crow, col, val, B, Gd, m)
+    assert rel(C, Co) < 1e-5 and rel(A.grad.values(), gAo) < 1e-5 and rel(Bd.grad, gBo) < 1e-5
+    # all-empty matrix
+    E = torch.sparse_csr_tensor(torch.zeros(5, dtype=torch.int64, device=DEV), torch.zeros(0, dtype=torch.int64, device=DEV),
+                                torch.zeros(0, device=DEV), (4, 6))
+    out = tsgu().sparse_mm(E, torch.ones(6, 3, device=DEV))
+    assert torch.count_nonzero(out) == 0 and out.shape == (4, 3)
+
+
+# ---------------------------------------------------------- triangular solve ---------------
+def test_triangular_all_flags_layouts_batched():
+    z = G.load("tri_flags.npz")
+    for name in z["names"]:
+        name = str(name)
+        vn, kind, layout, u, d, t = name.rstrip("_").split("_")
+        Bn = z[name + "B"]
+        n = Bn.shape[-2]
+        shape = (Bn.shape[0], n, n) if kind == "b" else (n, n)
+        A = G.sparse_from(z, name + "A_", shape, DEV, requires_grad=True)
+        B = G.t(Bn, DEV).requires_grad_(True)
+        x = tsgu().sparse_triangular_solve(A, B, upper=u == "u1", unitriangular=d == "d1", transpose=t == "t1")
+        x.backward(G.t(z[name + "G"], DEV))
+        tol = 2e-5 if vn == "f32" else 1e-10
+        assert rel(x, z[name + "x"]) < tol, name
+        assert rel(B.grad, z[name + "gradB"]) < tol, name
+        gA = A.grad
+        assert gA.layout == A.layout, name
+        if layout == "csr":
+            assert np.array_equal(gA.crow_indices().cpu().numpy(), z[name + "gradA_crow"]), name
+            assert np.array_equal(gA.col_indices().cpu().numpy(), z[name + "gradA_col"]), name
+            assert rel(gA.values(), z[name + "gradA_val"]) < tol, name
+        else:
+            assert np.array_equal(gA._indices().cpu().numpy(), z[name + "gradA_idx"]), name
+            assert rel(gA._values(), z[name + "gradA_val"]) < tol, name
+
+
+def test_triangular_structured_lower_int32():
+    z = G.load("tri_stencil_lower.npz")
+    for tr in (0, 1):
+        A = torch.sparse_csr_tensor(G.t(z["crow"], DEV), G.t(z["col"], DEV), G.t(z["val"], DEV), (512, 512)).requires_grad_(True)
+        B = G.t(z["B"], DEV).requires_grad_(True)
+        x = tsgu().sparse_triangular_solve(A, B, upper=False, transpose=bool(tr))
+        x.backward(G.t(z["G"], DEV))
+        assert A.grad.crow_indices().dtype == torch.int32
+        assert rel(x, z[f"t{tr}_x"]) < 1e-5
+        assert rel(A.grad.values(), z[f"t{tr}_gradA_val"]) < 1e-5
+        assert rel(B.grad, z[f"t{tr}_gradB"]) < 1e-5
+
+
+def test_triangular_unit_with_stored_diagonal_raises_in_backward():
+    err = G.errors()["tri_unit_with_diag_backward"]
+    L = torch.tril(torch.ones(3, 3)).to_sparse_csr().to(DEV).requires_grad_(True)
+    B = torch.ones(3, 2, device=DEV, requires_grad=True)
+    x = tsgu().sparse_triangular_solve(L, B, upper=False, unitriangular=True)  # forward is fine
+    with pytest.raises(ValueError) as e:
+        x.sum().backward()
+    assert str(e.value) == err["msg"]
+
+
+def test_triangular_deep_dependency_chain_and_roundtrip():
+    """Bidiagonal factor = one dependency per row (n levels): the sync-free sweep must not deadlock;
+    plus a size-independent property on a larger banded factor: A·solve(A, B) == B."""
+    from oracle import oracle
+    from torchsparsegradutils_amd import _backend as be
+    from torchsparsegradutils_amd.utils import synthetic
+
+    n = 20000
+    crow = torch.arange(0, 2 * n, 2, dtype=torch.int64)
+    crow = torch.cat([torch.tensor([0]), crow[1:] - 1, torch.tensor([2 * n - 1])])
+    col = torch.stack([torch.arange(-1, n - 1), torch.arange(n)], 1).reshape(-1)[1:]
+    val = torch.stack([torch.full((n,), -0.5), torch.full((n,), 1.5)], 1).reshape(-1)[1:].double()
+    B = torch.randn(n, 3, dtype=torch.float64)
+    A = torch.sparse_csr_tensor(crow.to(DEV), col.to(DEV), val.to(DEV), (n, n))
+    for tr in (False, True):
+        x = tsgu().sparse_triangular_solve(A, B.to(DEV), upper=False, transpose=tr)
+        xo = oracle.csr_sptrsm(crow.numpy(), col.numpy(), val.numpy(), B.numpy(), upper=False, transpose=tr)
+        assert rel(x, xo) < 1e-12
+
+    lc, li, lv = synthetic.banded_lower(65536, per_row=18, band=4096, dtype=torch.float32, device=DEV)
+    Bd = torch.randn(65536, 8, device=DEV)
+    L = torch.sparse_csr_tensor(lc, li, lv, (65536, 65536))
+    x = tsgu().sparse_triangular_solve(L, Bd, upper=False)
+    back = be.csr_spmm(lc, li, lv, x, 65536, 65536)
+    assert float((back - Bd).abs().max() / Bd.abs().max()) < 1e-5
+
+
+# ---------------------------------------------------------- Krylov / generic solve ----------
+@pytest.mark.parametrize("dt", [torch.float32, torch.float64])
+def test_cg_iterates_match_reference(dt):
+    from torchsparsegradutils_amd.utils import LinearCGSettings, linear_cg
+
+    z = G.load("cg_lap16.npz")
+    vn = "f32" if dt == torch.float32 else "f64"
+    n = 4096
+    A = torch.sparse_csr_tensor(G.t(z["crow"], DEV), G.t(z["col"], DEV), G.t(z["val"], DEV).to(dt), (n, n))
+    B = G.t(z["B"], DEV).to(dt)
+    tol = 1e-5 if dt == torch.float32 else 1e-11
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for k in (1, 5, 11, 20):
+            x = linear_cg(A, B, max_tridiag_iter=min(k, 20), settings=LinearCGSettings(max_cg_iterations=k, cg_tolerance=1e-30))
+            assert rel(x, z[f"{vn}_iter{k}"]) < tol, k
+    with pytest.warns(UserWarning, match="CG terminated in 1000 iterations"):
+        x = linear_cg(A, B, settings=LinearCGSettings(max_cg_iterations=1000, cg_tolerance=1e-6))
+    assert rel(x, z[vn + "_final"]) < 10 * tol
+
+
+def test_cg_stops_on_tolerance_and_vector_rhs():
+    from torchsparsegradutils_amd.utils import LinearCGSettings, linear_cg
+    from oracle import oracle
+
+    z = G.load("cg_lap16.npz")
+    n = 4096
+    A = torch.sparse_csr_tensor(G.t(z["crow"], DEV), G.t(z["col"], DEV), G.t(z["val"], DEV).double(), (n, n))
+    b = G.t(z["B"], DEV).double()[:, 0].contiguous()
+    x = linear_cg(A, b, settings=LinearCGSettings(cg_tolerance=1e-3))
+    xo, iters, _ = oracle.linear_cg(z["crow"], z["col"], z["val"].astype(np.float64), z["B"].astype(np.float64)[:, :1], 1e-3)
+    assert x.shape == (n,) and iters < 1000
+    assert rel(x, xo[:, 0]) < 1e-10
+    # callable operator path (no fused dot epilogue) gives the same iterates
+    x2 = linear_cg(lambda v: A @ v, b, settings=LinearCGSettings(cg_tolerance=1e-3))
+    assert rel(x2, xo[:, 0]) < 1e-10
+
+
+def test_generic_solve_all_solvers_fwd_bwd():
+    from torchsparsegradutils_amd.utils import (BICGSTABSettings, LinearCGSettings, MINRESSettings, bicgstab,
+                                                linear_cg, minres)
+
+    z = G.load("generic_small.npz")
+    S = G.t(z["S"], DEV)
+    solvers = {
+        "cg": (linear_cg, {"settings": LinearCGSettings(cg_tolerance=1e-12)}, 2e-5),
+        "bicgstab": (bicgstab, {"settings": BICGSTABSettings(reltol=1e-12, abstol=1e-14)}, 1e-9),
+        "minres": (minres, {"settings": MINRESSettings(minres_tolerance=1e-12)}, 1e-9),
+        "default": (None, {}, 1e-8),
+    }
+    for name in z["names"]:
+        name = str(name)
+        layout, _, sname = name.rstrip("_").split("_")
+        solver, kw, tol = solvers[sname]
+        A = (S.to_sparse_coo() if layout == "coo" else S.to_sparse_csr()).requires_grad_(True)
+        B = G.t(z[name + "B"], DEV).requires_grad_(True)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            x = tsgu().sparse_generic_solve(A, B, solve=solver, **kw)
+            x.backward(G.t(z[name + "G"], DEV))
+        assert x.shape == B.shape, name
+        assert rel(x, z[name + "x"]) < tol, name
+        assert rel(B.grad, z[name + "gradB"]) < tol, name
+        gA = A.grad
+        assert gA.layout == A.layout, name
+        if layout == "csr":
+            assert np.array_equal(gA.crow_indices().cpu().numpy(), z[name + "gradA_crow"]), name
+            assert np.array_equal(gA.col_indices().cpu().numpy(), z[name + "gradA_col"]), name
+            assert rel(gA.values(), z[name + "gradA_val"]) < tol, name
+        else:
+            assert np.array_equal(gA._indices().cpu().numpy(), z[name + "gradA_idx"]), name
+            assert rel(gA._values(), z[name + "gradA_val"]) < tol, name
+
+
+def test_generic_solve_nonsymmetric_with_transpose_solver_and_bicgstab32():
+    from torchsparsegradutils_amd.utils import BICGSTABSettings, bicgstab
+
+    z = G.load("generic_small.npz")
+    T = G.t(z["nonsym_T"], DEV)
+    st = BICGSTABSettings(reltol=1e-13, abstol=1e-15)
+
+    def bic(A, b, **kw):
+        return bicgstab(A, b, settings=st)
+
+    def bic_t(A, b, **kw):
+        return bicgstab(A.to_dense().t().to_sparse_csr(), b, settings=st)
+
+    A = T.to_sparse_csr().requires_grad_(True)
+    B = G.t(z["nonsym_B"], DEV).requires_grad_(True)
+    x = tsgu().sparse_generic_solve(A, B, solve=bic, transpose_solve=bic_t)
+    x.backward(G.t(z["nonsym_G"], DEV))
+    assert rel(x, z["nonsym_x"]) < 1e-9 and rel(B.grad, z["nonsym_gradB"]) < 1e-9
+    assert rel(A.grad.values(), z["nonsym_gradA_val"]) < 1e-9
+    x32 = bicgstab(T.float().to_sparse_csr(), B.detach()[:, 0].float())
+    assert rel(x32, z["bicg32_x"]) < 2e-5
+
+
+def test_generic_solve_double_backward():
+    """create_graph=True then a Hessian-vector product vs dense autograd (reference test_sparse_solve.py:391-441)."""
+    from torchsparsegradutils_amd.utils import LinearCGSettings, linear_cg
+
+    z = G.load("generic_small.npz")
+    S = G.t(z["S"], DEV)
+    A = S.to_sparse_csr().requires_grad_(True)
+    B = torch.randn(12, 2, dtype=torch.float64, device=DEV, requires_grad=True)
+    kw = {"settings": LinearCGSettings(cg_tolerance=1e-14)}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        x = tsgu().sparse_generic_solve(A, B, solve=linear_cg, **kw)
+        (gB,) = torch.autograd.grad((x ** 2).sum(), B, create_graph=True)
+        (hv,) = torch.autograd.grad((gB ** 2).sum(), B)
+    Sd = S.clone()
+    Bd = B.detach().clone().requires_grad_(True)
+    xd = torch.linalg.solve(Sd, Bd)
+    (gBd,) = torch.autograd.grad((xd ** 2).sum(), Bd, create_graph=True)
+    (hvd,) = torch.autograd.grad((gBd ** 2).sum(), Bd)
+    assert rel(gB, gBd.detach().cpu().numpy()) < 1e-4
+    assert rel(hv, hvd.cpu().numpy()) < 1e-4
+
+
+# ---------------------------------------------------------- full-size properties -------------
+def test_full_size_c2_properties():
+    """BASELINE config C2 at full size (N=1e6, 27/row, 32 RHS): size-independent checks.
+    (a) linearity of SpMM in B, (b) adjoint identity <A·B, G> == <B, Aᵀ·G> == Σ vals·gradA,
+    (c) a sampled set of rows/entries against the oracle on the same inputs."""
+    from oracle import oracle
+    from torchsparsegradutils_amd.utils import synthetic
+
+    n, p = 10 ** 6, 32
+    crow, col = synthetic.stencil27_periodic(100, 100, 100, torch.int32, device=DEV)
+    val = torch.randn(col.numel(), device=DEV)
+    A = torch.sparse_csr_tensor(crow, col, val, (n, n)).requires_grad_(True)
+    B = torch.randn(n, p, device=DEV, requires_grad=True)
+    Gd = torch.randn(n, p, device=DEV)
+    C = tsgu().sparse_mm(A, B)
+    C.backward(Gd)
+    C2 = tsgu().sparse_mm(A.detach(), 2.0 * B.detach())
+    assert float((C2 - 2 * C.detach()).abs().max()) == 0.0  # scaling by 2 is exact in fp32
+    lhs = float((C.detach().double() * Gd.double()).sum())
+    mid = float((B.detach().double() * B.grad.double()).sum())
+    rhs = float((val.double() * A.grad.values().double()).sum())
+    scale = float((C.detach().double().abs() * Gd.double().abs()).sum())
+    assert abs(lhs - mid) / scale < 1e-6 and abs(lhs - rhs) / scale < 1e-6
+    # sampled rows against the oracle (gather the needed inputs to the host)
+    rows = torch.randint(0, n, (64,), device=DEV)
+    cr, cc = crow.cpu().numpy(), col.cpu().numpy()
+    Bh, Gh, vh = B.detach().cpu().numpy(), Gd.cpu().numpy(), val.cpu().numpy()
+    for r in rows.tolist():
+        s, e = cr[r], cr[r + 1]
+        crow1 = np.array([0, e - s])
+        c_ref = oracle.csr_spmm(crow1, cc[s:e], vh[s:e], Bh)
+        assert G.rel_err(C[r].detach().cpu().numpy(), c_ref[0]) < 1e-5
+        g_ref = oracle.csr_sddmm(crow1, cc[s:e], Gh[r : r + 1], Bh)
+        assert G.rel_err(A.grad.values()[s:e].cpu().numpy(), g_ref) < 1e-5
+    # gradB at sampled columns: Aᵀ·G restricted — use the symmetric pattern: column j's entries are the rows in col-list of row j
+    At_vals_ok = 0
+    for j in rows[:16].tolist():
+        acc = np.zeros(p, dtype=np.float64)
+        s, e = cr[j], cr[j + 1]
+        for i in cc[s:e]:  # pattern is structurally symmetric: row i contains column j
+            si, ei = cr[i], cr[i + 1]
+            k = si + int(np.nonzero(cc[si:ei] == j)[0][0])
+            acc += float(vh[k]) * Gh[i].astype(np.float64)
+        assert G.rel_err(B.grad[j].cpu().numpy(), acc) < 1e-5
+        At_vals_ok += 1
+    assert At_vals_ok == 16

@@ -1,0 +1,173 @@
+"""CPU-side checks: index helpers bit-exact vs the reference's golden outputs, validation messages,
+the C-ABI library exports every symbol the header declares, and the product refuses CPU tensors."""
+
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import _golden as G
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _same_sparse(S, z, prefix):
+    if S.layout == torch.sparse_csr:
+        assert np.array_equal(S.crow_indices().numpy(), z[prefix + "crow"])
+        assert np.array_equal(S.col_indices().numpy(), z[prefix + "col"])
+        assert np.array_equal(S.values().numpy(), z[prefix + "val"])
+    else:
+        assert np.array_equal(S._indices().numpy(), z[prefix + "idx"])
+        assert np.array_equal(S._values().numpy(), z[prefix + "val"])
+
+
+def test_convert_coo_to_csr_bit_exact():
+    from torchsparsegradutils_amd.utils import convert_coo_to_csr
+
+    z = G.load("utils_index.npz")
+    A = G.sparse_from(z, "c2c_in_", (9, 7))
+    _same_sparse(convert_coo_to_csr(A), z, "c2c_out_")
+    Ab = G.sparse_from(z, "c2cb_in_", (3, 5, 4))
+    _same_sparse(convert_coo_to_csr(Ab), z, "c2cb_out_")
+    with pytest.raises(ValueError, match="Unsupported layout"):
+        convert_coo_to_csr(torch.eye(3).to_sparse_csr())
+
+
+@pytest.mark.parametrize("layout", ["coo", "csr"])
+def test_block_diag_and_split_bit_exact(layout):
+    from torchsparsegradutils_amd.utils import sparse_block_diag, sparse_block_diag_split
+
+    z = G.load("utils_index.npz")
+    shapes = [(3, 4), (2, 2), (4, 3)]
+    blocks = [G.sparse_from(z, f"bd_{layout}_in{i}_", s) for i, s in enumerate(shapes)]
+    D = sparse_block_diag(*blocks)
+    assert D.shape == (9, 9)
+    _same_sparse(D, z, f"bd_{layout}_out_")
+    parts = sparse_block_diag_split(D, *shapes)
+    for i, part in enumerate(parts):
+        assert part.shape == shapes[i]
+        _same_sparse(part, z, f"bd_{layout}_split{i}_")
+    assert sparse_block_diag(blocks[0]) is blocks[0]  # single input returned unchanged (utils.py:566-567)
+    with pytest.raises(ValueError, match="At least one sparse tensor must be provided."):
+        sparse_block_diag()
+    with pytest.raises(TypeError):
+        sparse_block_diag(blocks[0], 3)
+    with pytest.raises(ValueError, match="does not match"):
+        sparse_block_diag_split(D, (3, 4), (2, 2))
+
+
+def test_stack_csr_sparse_eye_and_row_helpers():
+    from torchsparsegradutils_amd.utils import sparse_eye, stack_csr
+    from torchsparsegradutils_amd.utils.utils import _compress_row_indices, _demcompress_crow_indices, _sort_coo_indices
+
+    a = torch.tensor([[0.0, 1], [2, 0]]).to_sparse_csr()
+    b = torch.tensor([[3.0, 0], [0, 4]]).to_sparse_csr()
+    s = stack_csr([a, b])
+    assert s.shape == (2, 2, 2) and torch.equal(s.to_dense(), torch.stack([a.to_dense(), b.to_dense()]))
+    with pytest.raises(ValueError, match="Cannot stack empty list of tensors."):
+        stack_csr([])
+    with pytest.raises(TypeError):
+        stack_csr(a)
+    for layout in (torch.sparse_coo, torch.sparse_csr):
+        for idt in (torch.int32, torch.int64):
+            E = sparse_eye((3, 4, 4), layout=layout, values_dtype=torch.float32, indices_dtype=idt)
+            assert torch.equal(E.to_dense(), torch.eye(4).expand(3, 4, 4))
+    with pytest.raises(ValueError, match="square"):
+        sparse_eye((3, 4))
+    crow = torch.tensor([0, 2, 2, 5], dtype=torch.int32)
+    rows = _demcompress_crow_indices(crow, 3)
+    assert rows.dtype == torch.int32 and rows.tolist() == [0, 0, 2, 2, 2]
+    assert torch.equal(_compress_row_indices(rows, 3), crow)
+    idx = torch.tensor([[2, 0, 1, 0], [1, 3, 0, 1]])
+    srt, perm = _sort_coo_indices(idx)
+    ref = torch.sparse_coo_tensor(idx, torch.arange(4.0), (3, 4)).coalesce()
+    assert torch.equal(srt, ref.indices()) and torch.equal(perm.float(), ref.values())
+
+
+def test_validation_messages_match_reference():
+    import torchsparsegradutils_amd as m
+
+    E = G.errors()
+    A = torch.eye(3).to_sparse_coo()
+    B = torch.ones(3, 2)
+    cases = {
+        "mm_not_tensor": lambda: m.sparse_mm(A, 3),
+        "mm_low_dim": lambda: m.sparse_mm(A, torch.ones(3)),
+        "mm_dim_mismatch": lambda: m.sparse_mm(A, torch.ones(1, 3, 2)),
+        "mm_csc": lambda: m.sparse_mm(torch.eye(3).to_sparse_csc(), B),
+        "mm_dense_A": lambda: m.sparse_mm(torch.eye(3), B),
+        "mm_sparse_B": lambda: m.sparse_mm(A, B.to_sparse_coo()),
+        "mm_batch": lambda: m.sparse_mm(torch.stack([A, A]), torch.ones(3, 3, 2)),
+        "mm_inner": lambda: m.sparse_mm(A, torch.ones(4, 2)),
+        "tri_not_tensor": lambda: m.sparse_triangular_solve(A, None),
+        "tri_low_dim": lambda: m.sparse_triangular_solve(A, torch.ones(3)),
+        "tri_dim_mismatch": lambda: m.sparse_triangular_solve(A, torch.ones(1, 3, 2)),
+        "tri_csc": lambda: m.sparse_triangular_solve(torch.eye(3).to_sparse_csc(), B),
+        "tri_sparse_B": lambda: m.sparse_triangular_solve(A, B.to_sparse_coo()),
+        "tri_not_square": lambda: m.sparse_triangular_solve(torch.ones(3, 4).to_sparse_coo(), B),
+        "tri_inner": lambda: m.sparse_triangular_solve(A, torch.ones(4, 2)),
+        "tri_batch": lambda: m.sparse_triangular_solve(torch.stack([A, A]), torch.ones(3, 3, 2)),
+        "gs_not_tensor": lambda: m.sparse_generic_solve(A, 1.0),
+        "gs_layout": lambda: m.sparse_generic_solve(torch.eye(3), B),
+        "gs_dim": lambda: m.sparse_generic_solve(torch.stack([A, A]), B),
+        "gs_square": lambda: m.sparse_generic_solve(torch.ones(3, 4).to_sparse_coo(), B),
+        "gs_B_dim": lambda: m.sparse_generic_solve(A, torch.ones(3, 2, 2)),
+        "gs_incompatible": lambda: m.sparse_generic_solve(A, torch.ones(4, 2)),
+        "gs_B_sparse": lambda: m.sparse_generic_solve(A, B.to_sparse_coo()),
+    }
+    for name, fn in cases.items():
+        want = E[name]
+        assert want["type"] in ("ValueError", "TypeError"), name
+        with pytest.raises(Exception) as e:
+            fn()
+        assert type(e.value).__name__ == want["type"], name
+        assert str(e.value) == want["msg"], name
+    # dtype mismatch only warns (then the GPU-only product refuses the CPU operands)
+    with pytest.warns(UserWarning) as w:
+        with pytest.raises(RuntimeError, match="no CPU path"):
+            m.sparse_generic_solve(A, B.double())
+    assert E["gs_dtype_warning"]["warnings"] == [str(w[0].message)]
+
+
+def test_cpu_tensors_are_refused_not_silently_computed():
+    import torchsparsegradutils_amd as m
+    from torchsparsegradutils_amd.utils import bicgstab, linear_cg, minres
+
+    A = torch.eye(3).to_sparse_csr()
+    B = torch.ones(3, 2)
+    for fn in (lambda: m.sparse_mm(A, B), lambda: m.sparse_triangular_solve(A, B), lambda: linear_cg(A, B),
+               lambda: bicgstab(A, B), lambda: minres(A, B)):
+        with pytest.raises(RuntimeError, match="no CPU path"):
+            fn()
+
+
+def test_abi_library_exports_every_declared_symbol():
+    from torchsparsegradutils_amd import _backend
+
+    header = open(os.path.join(ROOT, "include", "tsgu_hip.h")).read()
+    declared = set(re.findall(r"\b(tsgu_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 15
+    lib = _backend.load_library()  # loads without a GPU; no compute call is made here
+    raw = ctypes.CDLL(_backend.LIB_PATH)
+    for name in declared:
+        assert hasattr(raw, name), f"{name} declared in include/tsgu_hip.h but not exported"
+        assert name in _backend.SIGNATURES, f"{name} has no ctypes signature"
+    assert set(_backend.SIGNATURES) <= declared
+    assert lib.tsgu_abi_version() == 1
+    assert lib.tsgu_status_string(-2).decode().startswith("bad argument")
+    # pure host-side helpers of the ABI
+    assert lib.tsgu_spmm_num_blocks(_backend.TSGU_F32, 10 ** 6, 32) == 31250
+    assert lib.tsgu_sptrsm_work_bytes(10, 1) >= 516
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "torchsparsegradutils_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f
+                assert "liboracle" not in src, f

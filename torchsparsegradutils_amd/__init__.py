@@ -1,0 +1,25 @@
+"""MI355X-native (gfx950) implementation of torchsparsegradutils' sparse hot path.
+
+Drop-in names for ``sparse_mm`` / ``sparse_triangular_solve`` / ``sparse_generic_solve``
+(reference ``torchsparsegradutils/__init__.py:1-16``); the arithmetic runs in hand-written HIP
+kernels behind the C ABI in ``include/tsgu_hip.h``.  GPU only — there is no CPU fallback.
+"""
+
+from .sparse_matmul import SparseMatMul, sparse_mm
+from .sparse_solve import (
+    SparseGenericSolve,
+    SparseTriangularSolve,
+    sparse_generic_solve,
+    sparse_triangular_solve,
+)
+
+__all__ = [
+    "sparse_mm",
+    "sparse_triangular_solve",
+    "sparse_generic_solve",
+    "SparseMatMul",
+    "SparseTriangularSolve",
+    "SparseGenericSolve",
+]
+
+__version__ = "0.1.0"

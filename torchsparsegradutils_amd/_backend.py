@@ -1,0 +1,297 @@
+"""ctypes binding of ``libtsgu_hip.so`` (C ABI in ``include/tsgu_hip.h``).
+
+PyTorch is used for device memory and streams only: every wrapper below takes
+tensors, checks them, and hands raw device pointers + the current HIP stream to
+the hand-written gfx950 kernels.  There is NO fallback: if the shared library is
+missing, or a tensor does not live on a HIP device, the call raises.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libtsgu_hip.so")
+
+TSGU_F32, TSGU_F64, TSGU_BF16 = 0, 1, 2
+TSGU_I32, TSGU_I64 = 0, 1
+
+_VTYPE = {torch.float32: TSGU_F32, torch.float64: TSGU_F64, torch.bfloat16: TSGU_BF16}
+_ITYPE = {torch.int32: TSGU_I32, torch.int64: TSGU_I64}
+
+_lib = None
+_lib_lock = threading.Lock()
+
+_i64 = ctypes.c_int64
+_int = ctypes.c_int
+_ptr = ctypes.c_void_p
+_dbl = ctypes.c_double
+
+# name -> (restype, argtypes); must list every symbol declared in include/tsgu_hip.h
+SIGNATURES = {
+    "tsgu_abi_version": (_int, []),
+    "tsgu_status_string": (ctypes.c_char_p, [_int]),
+    "tsgu_device_info": (_int, [_int, ctypes.c_char_p, _int, ctypes.POINTER(_int), ctypes.POINTER(_int)]),
+    "tsgu_csr_spmm": (
+        _int,
+        [_int, _int, _i64, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _ptr, _i64, _i64, _i64, _i64,
+         _ptr, _i64, _ptr, _int, _ptr],
+    ),
+    "tsgu_spmm_num_blocks": (_i64, [_int, _i64, _i64]),
+    "tsgu_csr_sddmm": (
+        _int,
+        [_int, _int, _i64, _i64, _i64, _ptr, _ptr, _ptr, _i64, _i64, _ptr, _i64, _i64, _ptr, _dbl, _int, _i64, _i64,
+         _int, _ptr],
+    ),
+    "tsgu_coo_sddmm": (_int, [_int, _int, _i64, _ptr, _ptr, _ptr, _i64, _ptr, _i64, _ptr, _dbl, _i64, _int, _ptr]),
+    "tsgu_csr_sptrsm": (
+        _int,
+        [_int, _int, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _int, _int, _ptr, _i64, _ptr, _i64, _i64, _ptr, _int, _ptr],
+    ),
+    "tsgu_sptrsm_work_bytes": (_i64, [_i64, _i64]),
+    "tsgu_cg_alpha": (_int, [_int, _ptr, _i64, _ptr, _ptr, _dbl, _i64, _int, _ptr]),
+    "tsgu_cg_update1": (_int, [_int, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _int, _ptr]),
+    "tsgu_cg_num_blocks": (_i64, [_int, _i64, _i64]),
+    "tsgu_cg_beta": (_int, [_int, _ptr, _i64, _ptr, _ptr, _dbl, _dbl, _dbl, _int, _int, _i64, _int, _ptr]),
+    "tsgu_cg_update2": (_int, [_int, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _int, _ptr]),
+    "tsgu_coldot_max_blocks": (_i64, [_i64, _i64]),
+    "tsgu_coldot": (_int, [_int, _i64, _i64, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _int, _ptr]),
+}
+
+
+class HipExtensionMissing(RuntimeError):
+    pass
+
+
+def load_library():
+    """Load (once) and return the ctypes handle; raises if the extension is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lib_lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise HipExtensionMissing(
+                f"{LIB_PATH} not found: build the gfx950 extension first "
+                "(python -c 'import __graft_entry__ as g; g.build()' or make -C torchsparsegradutils_amd/csrc). "
+                "torchsparsegradutils_amd has no CPU or eager fallback."
+            )
+        # torch has already loaded its libamdhip64.so (same SONAME), so the kernels register
+        # with the runtime that owns torch's streams and allocations.
+        lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError => header/library mismatch, fail loudly
+            fn.restype = res
+            fn.argtypes = args
+        if lib.tsgu_abi_version() != 1:
+            raise HipExtensionMissing("libtsgu_hip.so ABI version mismatch; rebuild the extension")
+        _lib = lib
+    return _lib
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        msg = load_library().tsgu_status_string(status).decode()
+        raise RuntimeError(f"{what} failed: {msg} (tsgu status {status})")
+
+
+def vtype_of(t: torch.Tensor) -> int:
+    try:
+        return _VTYPE[t.dtype]
+    except KeyError:
+        raise RuntimeError(f"torchsparsegradutils_amd: unsupported value dtype {t.dtype}") from None
+
+
+def itype_of(t: torch.Tensor) -> int:
+    try:
+        return _ITYPE[t.dtype]
+    except KeyError:
+        raise RuntimeError(f"torchsparsegradutils_amd: unsupported index dtype {t.dtype}") from None
+
+
+def require_device(*tensors: torch.Tensor) -> torch.device:
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError(
+                "torchsparsegradutils_amd runs on AMD MI355X (gfx950) only: got a tensor on "
+                f"'{t.device}'. There is no CPU path; move the operands to the GPU."
+            )
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError(f"all operands must be on the same device, got {dev} and {t.device}")
+    return dev
+
+
+def _stream(dev: torch.device) -> int:
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def rowmajor(t: torch.Tensor) -> torch.Tensor:
+    """Return `t` (2-D or 3-D) with unit stride in the last dim and a sane leading dimension."""
+    if t.stride(-1) != 1 and t.size(-1) != 1:
+        return t.contiguous()
+    if t.dim() >= 2 and t.size(-2) > 1 and t.stride(-2) < t.size(-1):
+        return t.contiguous()
+    if t.dim() == 3 and t.size(0) > 1 and t.stride(0) < t.size(1) * t.stride(1):
+        return t.contiguous()
+    if t.size(-1) == 1 and t.stride(-1) != 1:
+        return t.contiguous()
+    return t
+
+
+def _ld(t: torch.Tensor) -> int:
+    return t.stride(-2) if t.size(-2) > 1 else max(t.size(-1), 1)
+
+
+def _bs(t: torch.Tensor) -> int:
+    return t.stride(0) if (t.dim() == 3 and t.size(0) > 1) else 0
+
+
+def csr_spmm(crow, col, val, B, n_rows: int, n_cols: int, perm=None, out=None, dot_w=None):
+    """C = A·B for (batched) CSR arrays.  B: (m, p) or (b, m, p).  Returns C or (C, dot_partial)."""
+    lib = load_library()
+    dev = require_device(crow, col, val, B, perm, out, dot_w)
+    if val.dtype != B.dtype:
+        raise RuntimeError(f"expected A and B to have the same dtype, got {val.dtype} and {B.dtype}")
+    batched = B.dim() == 3
+    batch = B.size(0) if batched else 1
+    p = B.size(-1)
+    B = rowmajor(B)
+    nnz = col.size(-1)
+    crow, col, val = crow.contiguous(), col.contiguous(), val.contiguous()
+    if perm is not None:
+        perm = perm.contiguous()
+    shape = (batch, n_rows, p) if batched else (n_rows, p)
+    if out is None:
+        out = torch.empty(shape, dtype=B.dtype, device=dev)
+    partial = None
+    vt = vtype_of(val)
+    if dot_w is not None:
+        nblk = lib.tsgu_spmm_num_blocks(vt, n_rows, p)
+        partial = torch.empty((batch * nblk, p), dtype=B.dtype, device=dev)
+        dot_w = rowmajor(dot_w)
+    with torch.cuda.device(dev):
+        check(
+            lib.tsgu_csr_spmm(
+                vt, itype_of(crow), n_rows, n_cols, nnz, _p(crow), _p(col), _p(val), _p(perm),
+                _p(B), _ld(B), _bs(B), _p(out), _ld(out), _bs(out), p, batch,
+                _p(dot_w), _ld(dot_w) if dot_w is not None else 0, _p(partial), dev.index, _stream(dev),
+            ),
+            "tsgu_csr_spmm",
+        )
+    return out if dot_w is None else (out, partial)
+
+
+def csr_sddmm(crow, col, G, B, n_rows: int, n_cols: int, alpha: float = 1.0, swap_roles: bool = False):
+    """out[k] = alpha·<G[row k], B[col k]> (or roles swapped) for (batched) CSR patterns."""
+    lib = load_library()
+    dev = require_device(crow, col, G, B)
+    if G.dtype != B.dtype:
+        raise RuntimeError(f"expected both dense operands to have the same dtype, got {G.dtype} and {B.dtype}")
+    batched = G.dim() == 3
+    batch = G.size(0) if batched else 1
+    p = G.size(-1)
+    G, B = rowmajor(G), rowmajor(B)
+    crow, col = crow.contiguous(), col.contiguous()
+    nnz = col.size(-1)
+    out = torch.empty(col.shape, dtype=G.dtype, device=dev)
+    with torch.cuda.device(dev):
+        check(
+            lib.tsgu_csr_sddmm(
+                vtype_of(G), itype_of(crow), n_rows, n_cols, nnz, _p(crow), _p(col),
+                _p(G), _ld(G), _bs(G), _p(B), _ld(B), _bs(B), _p(out), float(alpha), int(bool(swap_roles)),
+                p, batch, dev.index, _stream(dev),
+            ),
+            "tsgu_csr_sddmm",
+        )
+    return out
+
+
+def coo_sddmm(row, col, G, B, alpha: float = 1.0):
+    lib = load_library()
+    dev = require_device(row, col, G, B)
+    if G.dtype != B.dtype:
+        raise RuntimeError(f"expected both dense operands to have the same dtype, got {G.dtype} and {B.dtype}")
+    G, B = rowmajor(G), rowmajor(B)
+    row, col = row.contiguous(), col.contiguous()
+    nnz = row.numel()
+    out = torch.empty((nnz,), dtype=G.dtype, device=dev)
+    with torch.cuda.device(dev):
+        check(
+            lib.tsgu_coo_sddmm(
+                vtype_of(G), itype_of(row), nnz, _p(row), _p(col), _p(G), _ld(G), _p(B), _ld(B), _p(out),
+                float(alpha), G.size(-1), dev.index, _stream(dev),
+            ),
+            "tsgu_coo_sddmm",
+        )
+    return out
+
+
+def csr_sptrsm(ptr, idx, val, B, n: int, lower: bool, unit: bool, perm=None):
+    """X = M^{-1} B for the row-gather structure (ptr, idx, [perm], val) of a triangular M."""
+    lib = load_library()
+    dev = require_device(ptr, idx, val, B, perm)
+    if val.dtype != B.dtype:
+        raise RuntimeError(f"expected A and B to have the same dtype, got {val.dtype} and {B.dtype}")
+    B = rowmajor(B)
+    p = B.size(-1)
+    ptr, idx, val = ptr.contiguous(), idx.contiguous(), val.contiguous()
+    if perm is not None:
+        perm = perm.contiguous()
+    X = torch.empty((n, p), dtype=B.dtype, device=dev)
+    work = torch.empty((lib.tsgu_sptrsm_work_bytes(n, p),), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        check(
+            lib.tsgu_csr_sptrsm(
+                vtype_of(val), itype_of(ptr), n, idx.numel(), _p(ptr), _p(idx), _p(perm), _p(val),
+                int(bool(lower)), int(bool(unit)), _p(B), _ld(B), _p(X), _ld(X), p, _p(work), dev.index, _stream(dev),
+            ),
+            "tsgu_csr_sptrsm",
+        )
+    # error word sits behind the 64 ticket counters (struct TrsmWork in csrc/sptrsm.hip)
+    err = int(work[512:516].view(torch.int32).item())
+    if err != 0:
+        check(-7, "tsgu_csr_sptrsm (dependency wait)")
+    return X
+
+
+def coldot(X, Y):
+    """Column-wise dot products of two (n, p) arrays -> (p,) tensor (deterministic)."""
+    lib = load_library()
+    dev = require_device(X, Y)
+    X, Y = rowmajor(X), rowmajor(Y)
+    n, p = X.shape
+    nb = lib.tsgu_coldot_max_blocks(n, p)
+    if nb < 0:
+        raise RuntimeError("tsgu_coldot: more than 256 right-hand sides are not supported by the fused path")
+    partial = torch.empty((nb, p), dtype=X.dtype, device=dev)
+    out = torch.empty((p,), dtype=X.dtype, device=dev)
+    with torch.cuda.device(dev):
+        check(
+            lib.tsgu_coldot(vtype_of(X), n, p, _p(X), _ld(X), _p(Y), _ld(Y), _p(partial), _p(out), dev.index,
+                            _stream(dev)),
+            "tsgu_coldot",
+        )
+    return out
+
+
+def device_info(index: int = 0):
+    lib = load_library()
+    name = ctypes.create_string_buffer(128)
+    ncu, wave = _int(0), _int(0)
+    check(lib.tsgu_device_info(index, name, 128, ctypes.byref(ncu), ctypes.byref(wave)), "tsgu_device_info")
+    return name.value.decode(), ncu.value, wave.value

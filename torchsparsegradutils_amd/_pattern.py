@@ -1,0 +1,165 @@
+"""Sparsity-pattern plans: the row-gather view of a sparse operand plus cached analyses.
+
+The reference re-derives structure on every call (``repeat_interleave`` of the row pointer,
+``A.t()`` → CSC→CSR conversion + sort inside ``torch.sparse.mm``; sparse_matmul.py:186-192,229).
+Here the structure work is done once per sparsity pattern and cached on the identity of the
+index tensors (the common training loop updates values, not the pattern):
+
+* ``RowGather``   – (crow, col[, perm]) arrays the HIP kernels walk, for CSR / COO / batched inputs
+* ``.transposed`` – the same for Aᵀ (CSC of A) with a permutation into A's value array, so that
+  Aᵀ·G and transposed triangular solves are gather kernels (no atomics, deterministic)
+* ``.has_diagonal`` – whether any stored entry sits on the diagonal (sparse_solve.py:230)
+"""
+
+from __future__ import annotations
+
+import threading
+from collections import OrderedDict
+from typing import Optional, Tuple
+
+import torch
+
+
+class RowGather:
+    """Row-gather structure of a (batched) sparse matrix on the device.
+
+    crow: (n_rows+1,) or (b, n_rows+1); col: (nnz,) or (b, nnz); perm: optional, same shape as
+    col, position of each entry in the owner's value array (None = identity).
+    """
+
+    __slots__ = ("crow", "col", "perm", "n_rows", "n_cols", "batch", "_t", "_has_diag", "_rows")
+
+    def __init__(self, crow, col, n_rows, n_cols, perm=None):
+        self.crow, self.col, self.perm = crow, col, perm
+        self.n_rows, self.n_cols = int(n_rows), int(n_cols)
+        self.batch = crow.size(0) if crow.dim() == 2 else None
+        self._t: Optional[RowGather] = None
+        self._has_diag: Optional[bool] = None
+        self._rows = None
+
+    @property
+    def nnz(self) -> int:
+        return self.col.size(-1)
+
+    def row_indices(self) -> torch.Tensor:
+        """Expanded row index per stored entry (same shape/dtype as col); cached."""
+        if self._rows is None:
+            n = self.n_rows
+            ar = torch.arange(n, dtype=self.col.dtype, device=self.col.device)
+            if self.batch is None:
+                self._rows = torch.repeat_interleave(ar, self.crow[1:] - self.crow[:-1], output_size=self.nnz)
+            else:
+                counts = (self.crow[:, 1:] - self.crow[:, :-1]).reshape(-1)
+                rows = torch.repeat_interleave(ar.repeat(self.batch), counts, output_size=self.batch * self.nnz)
+                self._rows = rows.view(self.batch, self.nnz)
+        return self._rows
+
+    @property
+    def transposed(self) -> "RowGather":
+        """Row-gather structure of Aᵀ whose ``perm`` indexes A's value array."""
+        if self._t is None:
+            self._t = _transpose(self)
+        return self._t
+
+    @property
+    def has_diagonal(self) -> bool:
+        if self._has_diag is None:
+            self._has_diag = bool(torch.any(self.row_indices() == self.col))
+        return self._has_diag
+
+
+def _transpose(g: RowGather) -> RowGather:
+    rows = g.row_indices()
+    idt = g.col.dtype
+    if g.batch is None:
+        order = torch.argsort(g.col, stable=True)
+        counts = torch.bincount(g.col, minlength=g.n_cols)
+        ptr = torch.zeros(g.n_cols + 1, dtype=idt, device=g.col.device)
+        ptr[1:] = torch.cumsum(counts, 0)
+        idx = rows[order]
+        perm = order if g.perm is None else g.perm[order]
+        return RowGather(ptr, idx.contiguous(), g.n_cols, g.n_rows, perm.to(idt).contiguous())
+    b, nnz = g.batch, g.nnz
+    item = torch.arange(b, device=g.col.device, dtype=torch.int64).unsqueeze(1)
+    key = (g.col.to(torch.int64) + item * g.n_cols).reshape(-1)
+    order = torch.argsort(key, stable=True)
+    counts = torch.bincount(key, minlength=b * g.n_cols).view(b, g.n_cols)
+    ptr = torch.zeros((b, g.n_cols + 1), dtype=idt, device=g.col.device)
+    ptr[:, 1:] = torch.cumsum(counts, 1)
+    idx = rows.reshape(-1)[order].view(b, nnz)
+    local = (order.view(b, nnz) - item * nnz)
+    perm = local if g.perm is None else torch.gather(g.perm.to(torch.int64), 1, local)
+    return RowGather(ptr, idx.contiguous(), g.n_cols, g.n_rows, perm.to(idt).contiguous())
+
+
+# ---- cache ---------------------------------------------------------------------------------
+
+_CACHE: "OrderedDict[tuple, Tuple[tuple, RowGather]]" = OrderedDict()
+_CACHE_LOCK = threading.Lock()  # backward runs on autograd threads
+_CACHE_MAX = 16
+
+
+def _key(kind: str, tensors, shape) -> tuple:
+    return (kind, tuple(shape)) + tuple((t.data_ptr(), t._version, tuple(t.shape), t.dtype, str(t.device)) for t in tensors)
+
+
+def _cached(kind, tensors, shape, build) -> RowGather:
+    key = _key(kind, tensors, shape)
+    with _CACHE_LOCK:
+        hit = _CACHE.get(key)
+        if hit is not None:
+            _CACHE.move_to_end(key)
+            return hit[1]
+    plan = build()
+    with _CACHE_LOCK:
+        # keep the index tensors alive with the entry so their addresses cannot be recycled
+        _CACHE[key] = (tuple(tensors), plan)
+        while len(_CACHE) > _CACHE_MAX:
+            _CACHE.popitem(last=False)
+    return plan
+
+
+def clear_cache() -> None:
+    with _CACHE_LOCK:
+        _CACHE.clear()
+
+
+def from_csr(A: torch.Tensor) -> RowGather:
+    """Plan for a CSR tensor, 2-D or batched 3-D (torch's batched CSR: equal nnz per item)."""
+    crow, col = A.crow_indices(), A.col_indices()
+    return _cached("csr", (crow, col), A.shape, lambda: RowGather(crow, col, A.size(-2), A.size(-1)))
+
+
+def from_coo_2d(indices: torch.Tensor, shape, coalesced: bool) -> RowGather:
+    """Plan for 2-D COO indices (2, nnz).  Coalesced input is already row-sorted; otherwise the
+    entries are visited in a stable row order through ``perm`` (duplicates stay separate)."""
+
+    def build():
+        n, m = int(shape[-2]), int(shape[-1])
+        rows, cols = indices[0], indices[1]
+        if coalesced:
+            crow = torch._convert_indices_from_coo_to_csr(rows, n, out_int32=False)
+            return RowGather(crow, cols.contiguous(), n, m)
+        order = torch.argsort(rows, stable=True)
+        crow = torch._convert_indices_from_coo_to_csr(rows[order].contiguous(), n, out_int32=False)
+        return RowGather(crow, cols[order].contiguous(), n, m, perm=order)
+
+    return _cached("coo" + ("c" if coalesced else "u"), (indices,), shape, build)
+
+
+def flat_block_diag(crow: torch.Tensor, col: torch.Tensor, n: int, m: int) -> RowGather:
+    """Batched CSR arrays (b, n+1)/(b, nnz) → the 2-D block-diagonal plan (b·n × b·m) the reference
+    assembles with ``sparse_block_diag`` (utils/utils.py:615-645): two vectorised adds, no sync."""
+
+    def build():
+        b, nnz = col.shape
+        idt = crow.dtype
+        if idt == torch.int32 and max(b * nnz, b * m) >= 2**31:
+            idt = torch.int64
+        item = torch.arange(b, device=col.device, dtype=idt).unsqueeze(1)
+        flat_crow = torch.cat(((crow[:, :-1].to(idt) + item * nnz).reshape(-1),
+                               torch.tensor([b * nnz], dtype=idt, device=col.device)))
+        flat_col = (col.to(idt) + item * m).reshape(-1)
+        return RowGather(flat_crow, flat_col, b * n, b * m)
+
+    return _cached("csrflat", (crow, col), (n, m), build)

@@ -1,0 +1,174 @@
+// extern "C" entry points for K1/K2/K3 (declared in include/tsgu_hip.h).
+// Argument validation lives here; the typed launchers are in spmm_*.hip / sddmm_*.hip.
+#include "sddmm_impl.h"
+#include "spmm_impl.h"
+
+#include <cstring>
+
+namespace tsgu {
+int spmm_dispatch_f32(int, const SpmmParams&, int64_t, hipStream_t);
+int spmm_dispatch_f64(int, const SpmmParams&, int64_t, hipStream_t);
+int spmm_dispatch_bf16(int, const SpmmParams&, int64_t, hipStream_t);
+int sddmm_dispatch_f32(int, const SddmmParams&, int64_t, hipStream_t);
+int sddmm_dispatch_f64(int, const SddmmParams&, int64_t, hipStream_t);
+int sddmm_dispatch_bf16(int, const SddmmParams&, int64_t, hipStream_t);
+int coo_sddmm_dispatch_f32(int, const CooSddmmParams&, hipStream_t);
+int coo_sddmm_dispatch_f64(int, const CooSddmmParams&, hipStream_t);
+int coo_sddmm_dispatch_bf16(int, const CooSddmmParams&, hipStream_t);
+}  // namespace tsgu
+
+using namespace tsgu;
+
+extern "C" {
+
+int tsgu_abi_version(void) { return TSGU_ABI_VERSION; }
+
+const char* tsgu_status_string(int status) {
+    switch (status) {
+        case TSGU_OK: return "ok";
+        case TSGU_ERR_BAD_DTYPE: return "unsupported value/index dtype";
+        case TSGU_ERR_BAD_ARG: return "bad argument (null pointer, negative size or leading dimension too small)";
+        case TSGU_ERR_TOO_LARGE: return "problem exceeds a kernel limit (n_cols >= 2^31, batch > 65535 or grid too large)";
+        case TSGU_ERR_LAUNCH: return "HIP kernel launch failed";
+        case TSGU_ERR_RUNTIME: return "HIP runtime call failed";
+        case TSGU_ERR_NOT_TRIANGULAR: return "matrix is not usable as a triangular factor (zero or missing diagonal)";
+        case TSGU_ERR_TIMEOUT: return "device-side dependency wait timed out";
+    }
+    return "unknown status";
+}
+
+int tsgu_device_info(int device, char* name, int cap, int* n_cu, int* wave_size) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return TSGU_ERR_RUNTIME;
+    if (name && cap > 0) {
+        std::strncpy(name, prop.gcnArchName, (size_t)cap - 1);
+        name[cap - 1] = 0;
+    }
+    if (n_cu) *n_cu = prop.multiProcessorCount;
+    if (wave_size) *wave_size = prop.warpSize;
+    return TSGU_OK;
+}
+
+int64_t tsgu_spmm_num_blocks(int vtype, int64_t n_rows, int64_t p) {
+    // mirrors spmm_geom(): the fused-dot path is only used with contiguous, 16-byte
+    // aligned operands, so "wide" depends on p alone.
+    const int wide = vtype == TSGU_F32 ? 4 : vtype == TSGU_F64 ? 2 : 8;
+    const RowGeom g = pick_geom(wide, p % wide == 0, p);
+    const int64_t rpb = kBlock / (g.cl * g.ep);
+    return (n_rows + rpb - 1) / rpb;
+}
+
+int tsgu_csr_spmm(int vtype, int itype, int64_t n_rows, int64_t n_cols, int64_t nnz_per_item,
+                  const void* crow, const void* col, const void* val, const void* perm,
+                  const void* B, int64_t ldb, int64_t b_batch_stride,
+                  void* C, int64_t ldc, int64_t c_batch_stride,
+                  int64_t p, int64_t batch,
+                  const void* dot_w, int64_t ldw, void* dot_partial,
+                  int device, void* stream) {
+    if (n_rows < 0 || n_cols < 0 || nnz_per_item < 0 || p < 0 || batch < 0) return TSGU_ERR_BAD_ARG;
+    if (n_rows == 0 || p == 0 || batch == 0) return TSGU_OK;
+    if (!crow || !C || (nnz_per_item > 0 && (!col || !val || !B))) return TSGU_ERR_BAD_ARG;
+    if (ldb < p || ldc < p) return TSGU_ERR_BAD_ARG;
+    if (n_cols > 0x7fffffffLL) return TSGU_ERR_TOO_LARGE;
+    if ((dot_partial != nullptr) != (dot_w != nullptr)) return TSGU_ERR_BAD_ARG;
+    if (dot_partial && (ldw < p || vtype == TSGU_BF16)) return TSGU_ERR_BAD_ARG;
+    if (const int rc = set_device(device)) return rc;
+    SpmmParams P{};
+    P.n_rows = n_rows;
+    P.nnz_per_item = nnz_per_item;
+    P.p = p;
+    P.crow = crow;
+    P.col = col;
+    P.val = val;
+    P.perm = perm;
+    P.B = B;
+    P.ldb = ldb;
+    P.b_bs = b_batch_stride;
+    P.C = C;
+    P.ldc = ldc;
+    P.c_bs = c_batch_stride;
+    P.W = dot_w;
+    P.ldw = ldw;
+    P.dot_partial = dot_partial;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    switch (vtype) {
+        case TSGU_F32: return spmm_dispatch_f32(itype, P, batch, s);
+        case TSGU_F64: return spmm_dispatch_f64(itype, P, batch, s);
+        case TSGU_BF16: return spmm_dispatch_bf16(itype, P, batch, s);
+    }
+    return TSGU_ERR_BAD_DTYPE;
+}
+
+int tsgu_csr_sddmm(int vtype, int itype, int64_t n_rows, int64_t n_cols, int64_t nnz_per_item,
+                   const void* crow, const void* col,
+                   const void* G, int64_t ldg, int64_t g_batch_stride,
+                   const void* B, int64_t ldb, int64_t b_batch_stride,
+                   void* out, double alpha, int swap_roles,
+                   int64_t p, int64_t batch, int device, void* stream) {
+    if (n_rows < 0 || n_cols < 0 || nnz_per_item < 0 || p < 0 || batch < 0) return TSGU_ERR_BAD_ARG;
+    if (n_rows == 0 || nnz_per_item == 0 || batch == 0) return TSGU_OK;
+    if (!crow || !col || !out || (p > 0 && (!G || !B))) return TSGU_ERR_BAD_ARG;
+    if (ldg < p || ldb < p) return TSGU_ERR_BAD_ARG;
+    if (n_cols > 0x7fffffffLL) return TSGU_ERR_TOO_LARGE;
+    if (const int rc = set_device(device)) return rc;
+    SddmmParams P{};
+    P.n_rows = n_rows;
+    P.nnz_per_item = nnz_per_item;
+    P.p = p;
+    P.crow = crow;
+    P.col = col;
+    if (!swap_roles) {
+        P.R = G;
+        P.ldr = ldg;
+        P.r_bs = g_batch_stride;
+        P.Cm = B;
+        P.ldc = ldb;
+        P.c_bs = b_batch_stride;
+    } else {
+        P.R = B;
+        P.ldr = ldb;
+        P.r_bs = b_batch_stride;
+        P.Cm = G;
+        P.ldc = ldg;
+        P.c_bs = g_batch_stride;
+    }
+    P.out = out;
+    P.alpha = alpha;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    switch (vtype) {
+        case TSGU_F32: return sddmm_dispatch_f32(itype, P, batch, s);
+        case TSGU_F64: return sddmm_dispatch_f64(itype, P, batch, s);
+        case TSGU_BF16: return sddmm_dispatch_bf16(itype, P, batch, s);
+    }
+    return TSGU_ERR_BAD_DTYPE;
+}
+
+int tsgu_coo_sddmm(int vtype, int itype, int64_t nnz, const void* row, const void* col,
+                   const void* G, int64_t ldg, const void* B, int64_t ldb,
+                   void* out, double alpha, int64_t p, int device, void* stream) {
+    if (nnz < 0 || p < 0) return TSGU_ERR_BAD_ARG;
+    if (nnz == 0) return TSGU_OK;
+    if (!row || !col || !out || (p > 0 && (!G || !B))) return TSGU_ERR_BAD_ARG;
+    if (ldg < p || ldb < p) return TSGU_ERR_BAD_ARG;
+    if (const int rc = set_device(device)) return rc;
+    CooSddmmParams P{};
+    P.nnz = nnz;
+    P.p = p;
+    P.row = row;
+    P.col = col;
+    P.R = G;
+    P.ldr = ldg;
+    P.Cm = B;
+    P.ldc = ldb;
+    P.out = out;
+    P.alpha = alpha;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    switch (vtype) {
+        case TSGU_F32: return coo_sddmm_dispatch_f32(itype, P, s);
+        case TSGU_F64: return coo_sddmm_dispatch_f64(itype, P, s);
+        case TSGU_BF16: return coo_sddmm_dispatch_bf16(itype, P, s);
+    }
+    return TSGU_ERR_BAD_DTYPE;
+}
+
+}  // extern "C"

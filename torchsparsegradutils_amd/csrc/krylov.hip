@@ -1,0 +1,390 @@
+// K5: fused vector updates of the Krylov loops (CG recurrences, column dots) on gfx950.
+// The reference runs ~15 elementwise/reduce ATen ops and a host sync per CG iteration
+// (utils/linear_cg.py:27-95, 372-382); here one iteration is
+//   K1(+pᵀAp epilogue) → cg_alpha → cg_update1 → cg_beta → cg_update2
+// with every per-column scalar and the convergence decision kept on the device.
+// All reductions are two-stage with a fixed summation order (no atomics): deterministic.
+#include "tsgu_common.h"
+
+namespace tsgu {
+
+constexpr int kPasses = 4;  // row passes per block in the elementwise kernels
+
+// Lane layout for a contiguous [n][p] array: lpr lanes per row, each VEC columns wide.
+struct VecGeom {
+    int vec;
+    int lpr;  // lanes per row = ceil(p / vec)
+    int rpp;  // rows per pass = 256 / lpr
+    int64_t blocks;
+};
+
+inline bool vec_geom(int wide, bool can_wide, int64_t n, int64_t p, VecGeom& g) {
+    g.vec = can_wide ? wide : 1;
+    const int64_t lpr = (p + g.vec - 1) / g.vec;
+    if (lpr > kBlock) return false;
+    g.lpr = (int)lpr;
+    g.rpp = kBlock / g.lpr;
+    const int64_t rows_per_block = (int64_t)g.rpp * kPasses;
+    g.blocks = (n + rows_per_block - 1) / rows_per_block;
+    return true;
+}
+
+// Sum partial[b][c] over b for the calling block's column window [c0, c0+w): result valid
+// in threads t < w (thread t owns column c0+t).  red: LDS scratch of kBlock Acc.
+template <typename Acc>
+__device__ __forceinline__ Acc block_colsum(const Acc* __restrict__ partial, int64_t n_partial, int64_t p,
+                                            int64_t c0, int w, Acc* red) {
+    const int t = threadIdx.x;
+    const int subs = kBlock / w;
+    const int sub = t / w, lc = t % w;
+    Acc s = 0;
+    if (sub < subs) {
+        for (int64_t b = sub; b < n_partial; b += subs) s += partial[b * p + c0 + lc];
+    }
+    red[t] = s;
+    __syncthreads();
+    Acc tot = 0;
+    if (t < w) {
+        for (int k = 0; k < subs; ++k) tot += red[k * w + t];
+    }
+    __syncthreads();
+    return tot;
+}
+
+// ---- generic column dot --------------------------------------------------------------
+template <typename V, int VEC>
+__global__ __launch_bounds__(kBlock) void coldot_partial_kernel(int64_t n, int64_t p, const V* __restrict__ X, int64_t ldx,
+                                                                const V* __restrict__ Y, int64_t ldy, int lpr, int rpp,
+                                                                V* __restrict__ partial) {
+    __shared__ V red[kBlock * VEC];
+    const int t = threadIdx.x;
+    const int cl = t % lpr, rs = t / lpr;
+    const int64_t c = (int64_t)cl * VEC;
+    const bool act = rs < rpp && c < p;
+    V acc[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) acc[v] = 0;
+    const int64_t r0 = (int64_t)blockIdx.x * rpp * kPasses;
+#pragma unroll
+    for (int ps = 0; ps < kPasses; ++ps) {
+        const int64_t r = r0 + (int64_t)ps * rpp + rs;
+        if (act && r < n) {
+            V x[VEC], y[VEC];
+            load_vec<V, VEC>(X + r * ldx + c, x);
+            load_vec<V, VEC>(Y + r * ldy + c, y);
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) acc[v] = fma(x[v], y[v], acc[v]);
+        }
+    }
+    if (rs < rpp) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) red[(rs * lpr + cl) * VEC + v] = acc[v];
+    }
+    __syncthreads();
+    for (int64_t cc = t; cc < p; cc += kBlock) {
+        V s = 0;
+        for (int k = 0; k < rpp; ++k) s += red[k * lpr * VEC + cc];
+        partial[(int64_t)blockIdx.x * p + cc] = s;
+    }
+}
+
+template <typename V>
+__global__ __launch_bounds__(kBlock) void colsum_finalize_kernel(const V* __restrict__ partial, int64_t n_partial, int64_t p,
+                                                                 V* __restrict__ out) {
+    __shared__ V red[kBlock];
+    const int64_t c0 = (int64_t)blockIdx.x * 64;
+    const int w = (int)(p - c0 < 64 ? p - c0 : 64);
+    const V tot = block_colsum<V>(partial, n_partial, p, c0, w, red);
+    if ((int)threadIdx.x < w) out[c0 + threadIdx.x] = tot;
+}
+
+// ---- CG ---------------------------------------------------------------------------------
+// scal: [rr | alpha | beta | rnorm] each [p];  flags: [done, iters, has_converged[p], rhs_is_zero[p]]
+template <typename V>
+__global__ __launch_bounds__(kBlock) void cg_alpha_kernel(const V* __restrict__ pap_partial, int64_t n_partial, int64_t p,
+                                                          V* __restrict__ scal, const int* __restrict__ flags, V eps) {
+    __shared__ V red[kBlock];
+    if (flags[0] != 0) return;
+    const int64_t c0 = (int64_t)blockIdx.x * 64;
+    const int w = (int)(p - c0 < 64 ? p - c0 : 64);
+    const V pap = block_colsum<V>(pap_partial, n_partial, p, c0, w, red);
+    if ((int)threadIdx.x < w) {
+        const int64_t c = c0 + threadIdx.x;
+        // safe division (linear_cg.py:67-71) then freeze converged columns (:74)
+        V alpha = pap < eps ? (V)0 : scal[c] / pap;
+        if (flags[2 + c] != 0) alpha = 0;
+        scal[p + c] = alpha;
+    }
+}
+
+template <typename V, int VEC>
+__global__ __launch_bounds__(kBlock) void cg_update1_kernel(int64_t n, int64_t p, V* __restrict__ r, const V* __restrict__ Ap,
+                                                            V* __restrict__ x, const V* __restrict__ pv,
+                                                            const V* __restrict__ scal, const int* __restrict__ flags,
+                                                            int lpr, int rpp, V* __restrict__ rr_partial) {
+    __shared__ V red[kBlock * VEC];
+    if (flags[0] != 0) return;
+    const int t = threadIdx.x;
+    const int cl = t % lpr, rs = t / lpr;
+    const int64_t c = (int64_t)cl * VEC;
+    const bool act = rs < rpp && c < p;
+    V alpha[VEC], acc[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+        acc[v] = 0;
+        alpha[v] = act ? scal[p + c + v] : (V)0;
+    }
+    const int64_t r0 = (int64_t)blockIdx.x * rpp * kPasses;
+#pragma unroll
+    for (int ps = 0; ps < kPasses; ++ps) {
+        const int64_t row = r0 + (int64_t)ps * rpp + rs;
+        if (act && row < n) {
+            const int64_t o = row * p + c;
+            V rv[VEC], av[VEC], xv[VEC], pvv[VEC];
+            load_vec<V, VEC>(r + o, rv);
+            load_vec<V, VEC>(Ap + o, av);
+            load_vec<V, VEC>(x + o, xv);
+            load_vec<V, VEC>(pv + o, pvv);
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                rv[v] = fma(-alpha[v], av[v], rv[v]);   // r -= alpha·Ap   (linear_cg.py:78)
+                xv[v] = fma(alpha[v], pvv[v], xv[v]);   // x += alpha·p    (linear_cg.py:32)
+                acc[v] = fma(rv[v], rv[v], acc[v]);     // rᵀr             (linear_cg.py:36-37)
+            }
+            store_vec<V, VEC>(r + o, rv);
+            store_vec<V, VEC>(x + o, xv);
+        }
+    }
+    if (rs < rpp) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) red[(rs * lpr + cl) * VEC + v] = acc[v];
+    }
+    __syncthreads();
+    for (int64_t cc = t; cc < p; cc += kBlock) {
+        V s = 0;
+        for (int k = 0; k < rpp; ++k) s += red[k * lpr * VEC + cc];
+        rr_partial[(int64_t)blockIdx.x * p + cc] = s;
+    }
+}
+
+template <typename V>
+__global__ __launch_bounds__(kBlock) void cg_beta_kernel(const V* __restrict__ rr_partial, int64_t n_partial, int64_t p,
+                                                         V* __restrict__ scal, int* __restrict__ flags, V eps, V stop_after,
+                                                         V tolerance, int iter_index, int min_iter_index) {
+    // single block: needs the mean of the residual norms over ALL columns for the stop test.
+    __shared__ V red[kBlock];
+    __shared__ V normsum[kBlock];
+    if (flags[0] != 0) return;
+    const int t = threadIdx.x;
+    V my_norm_sum = 0;
+    for (int64_t c0 = 0; c0 < p; c0 += 64) {
+        const int w = (int)(p - c0 < 64 ? p - c0 : 64);
+        const V rr_new = block_colsum<V>(rr_partial, n_partial, p, c0, w, red);
+        if (t < w) {
+            const int64_t c = c0 + t;
+            const V rr_old = scal[c];
+            // beta = rr_new / rr_old with the reference's safe division (linear_cg.py:35-43)
+            const V beta = rr_old < eps ? (V)0 : rr_new / rr_old;
+            scal[c] = rr_new;
+            scal[2 * p + c] = beta;
+            V nrm = sqrt(rr_new);                       // ‖r‖₂ (linear_cg.py:372)
+            if (flags[2 + p + c] != 0) nrm = 0;         // rhs_is_zero mask (:373)
+            scal[3 * p + c] = nrm;
+            flags[2 + c] = nrm < stop_after ? 1 : 0;    // has_converged (:374)
+            my_norm_sum += nrm;
+        }
+    }
+    normsum[t] = t < 64 ? my_norm_sum : (V)0;
+    __syncthreads();
+    if (t == 0) {
+        V s = 0;
+        const int lim = p < 64 ? (int)p : 64;
+        for (int k = 0; k < lim; ++k) s += normsum[k];
+        const V mean = s / (V)p;
+        flags[1] = iter_index + 1;
+        // stop rule (linear_cg.py:376-382): k >= min(10, max_iter-1) and mean‖r‖ < tol
+        if (iter_index >= min_iter_index && mean < tolerance) flags[0] = 1;
+    }
+}
+
+template <typename V, int VEC>
+__global__ __launch_bounds__(kBlock) void cg_update2_kernel(int64_t n, int64_t p, const V* __restrict__ r, V* __restrict__ pv,
+                                                            const V* __restrict__ scal, const int* __restrict__ flags,
+                                                            int lpr, int rpp) {
+    if (flags[0] != 0) return;
+    const int t = threadIdx.x;
+    const int cl = t % lpr, rs = t / lpr;
+    const int64_t c = (int64_t)cl * VEC;
+    if (!(rs < rpp && c < p)) return;
+    V beta[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) beta[v] = scal[2 * p + c + v];
+    const int64_t r0 = (int64_t)blockIdx.x * rpp * kPasses;
+#pragma unroll
+    for (int ps = 0; ps < kPasses; ++ps) {
+        const int64_t row = r0 + (int64_t)ps * rpp + rs;
+        if (row < n) {
+            const int64_t o = row * p + c;
+            V rv[VEC], pvv[VEC];
+            load_vec<V, VEC>(r + o, rv);
+            load_vec<V, VEC>(pv + o, pvv);
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) pvv[v] = fma(pvv[v], beta[v], rv[v]);  // p = r + beta·p (linear_cg.py:47)
+            store_vec<V, VEC>(pv + o, pvv);
+        }
+    }
+}
+
+template <typename V>
+inline bool geom_for(int64_t n, int64_t p, bool aligned, VecGeom& g) {
+    constexpr int wide = VT<V>::kWide;
+    return vec_geom(wide, aligned && (p % wide == 0), n, p, g);
+}
+
+}  // namespace tsgu
+
+using namespace tsgu;
+
+#define TSGU_VSWITCH(vtype, CALL_F32, CALL_F64) \
+    do {                                        \
+        if ((vtype) == TSGU_F32) {              \
+            using V = float;                    \
+            CALL_F32;                           \
+        } else if ((vtype) == TSGU_F64) {       \
+            using V = double;                   \
+            CALL_F64;                           \
+        } else {                                \
+            return TSGU_ERR_BAD_DTYPE;          \
+        }                                       \
+    } while (0)
+
+extern "C" {
+
+int64_t tsgu_cg_num_blocks(int vtype, int64_t n, int64_t p) {
+    // exact block count of tsgu_cg_update1 (operands must be 16-byte aligned, contiguous)
+    VecGeom g;
+    const bool ok = vtype == TSGU_F64 ? geom_for<double>(n, p, true, g) : geom_for<float>(n, p, true, g);
+    return ok ? g.blocks : -1;
+}
+
+int64_t tsgu_coldot_max_blocks(int64_t n, int64_t p) {
+    // upper bound on the partial rows tsgu_coldot writes (scalar-lane geometry)
+    VecGeom g;
+    if (!vec_geom(1, false, n, p, g)) return -1;
+    return g.blocks > 0 ? g.blocks : 1;
+}
+
+int tsgu_coldot(int vtype, int64_t n, int64_t p, const void* X, int64_t ldx, const void* Y, int64_t ldy,
+                void* partial, void* out, int device, void* stream) {
+    if (n < 0 || p <= 0 || !X || !Y || !partial || !out || ldx < p || ldy < p) return TSGU_ERR_BAD_ARG;
+    if (const int rc = set_device(device)) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+#define TSGU_COLDOT_BODY                                                                                          \
+    {                                                                                                             \
+        constexpr int wide = VT<V>::kWide;                                                                        \
+        VecGeom g;                                                                                                \
+        const bool can = aligned16(X) && aligned16(Y) && ldx % wide == 0 && ldy % wide == 0 && p % wide == 0;    \
+        if (!vec_geom(wide, can, n, p, g)) return TSGU_ERR_TOO_LARGE;                                             \
+        if (g.blocks == 0) g.blocks = 1;                                                                          \
+        if (g.vec == 1)                                                                                           \
+            hipLaunchKernelGGL((coldot_partial_kernel<V, 1>), dim3((unsigned)g.blocks), dim3(kBlock), 0, s, n, p, \
+                               (const V*)X, ldx, (const V*)Y, ldy, g.lpr, g.rpp, (V*)partial);                   \
+        else                                                                                                      \
+            hipLaunchKernelGGL((coldot_partial_kernel<V, wide>), dim3((unsigned)g.blocks), dim3(kBlock), 0, s, n, \
+                               p, (const V*)X, ldx, (const V*)Y, ldy, g.lpr, g.rpp, (V*)partial);                \
+        if (const int rc = check_launch()) return rc;                                                             \
+        hipLaunchKernelGGL((colsum_finalize_kernel<V>), dim3((unsigned)((p + 63) / 64)), dim3(kBlock), 0, s,      \
+                           (const V*)partial, g.blocks, p, (V*)out);                                              \
+        return check_launch();                                                                                    \
+    }
+    TSGU_VSWITCH(vtype, TSGU_COLDOT_BODY, TSGU_COLDOT_BODY);
+#undef TSGU_COLDOT_BODY
+    return TSGU_OK;
+}
+
+int tsgu_cg_alpha(int vtype, const void* pap_partial, int64_t n_partial, void* scal, int* flags, double eps,
+                  int64_t p, int device, void* stream) {
+    if (!pap_partial || !scal || !flags || p <= 0 || n_partial < 0) return TSGU_ERR_BAD_ARG;
+    if (const int rc = set_device(device)) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+#define TSGU_BODY                                                                                              \
+    {                                                                                                          \
+        hipLaunchKernelGGL((cg_alpha_kernel<V>), dim3((unsigned)((p + 63) / 64)), dim3(kBlock), 0, s,           \
+                           (const V*)pap_partial, n_partial, p, (V*)scal, (const int*)flags, (V)eps);          \
+        return check_launch();                                                                                 \
+    }
+    TSGU_VSWITCH(vtype, TSGU_BODY, TSGU_BODY);
+#undef TSGU_BODY
+    return TSGU_OK;
+}
+
+int tsgu_cg_update1(int vtype, int64_t n, int64_t p, void* r, const void* Ap, void* x, const void* pvec,
+                    const void* scal, const int* flags, void* rr_partial, int device, void* stream) {
+    if (n <= 0 || p <= 0 || !r || !Ap || !x || !pvec || !scal || !flags || !rr_partial) return TSGU_ERR_BAD_ARG;
+    if (const int rc = set_device(device)) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    // rr_partial has tsgu_cg_num_blocks(vtype, n, p) rows; that count assumes aligned operands.
+#define TSGU_BODY                                                                                               \
+    {                                                                                                           \
+        VecGeom g;                                                                                              \
+        constexpr int wide = VT<V>::kWide;                                                                      \
+        if (!(aligned16(r) && aligned16(Ap) && aligned16(x) && aligned16(pvec))) return TSGU_ERR_BAD_ARG;      \
+        if (!geom_for<V>(n, p, true, g)) return TSGU_ERR_TOO_LARGE;                                             \
+        if (g.vec == 1)                                                                                         \
+            hipLaunchKernelGGL((cg_update1_kernel<V, 1>), dim3((unsigned)g.blocks), dim3(kBlock), 0, s, n, p,   \
+                               (V*)r, (const V*)Ap, (V*)x, (const V*)pvec, (const V*)scal, flags, g.lpr, g.rpp, \
+                               (V*)rr_partial);                                                                 \
+        else                                                                                                    \
+            hipLaunchKernelGGL((cg_update1_kernel<V, wide>), dim3((unsigned)g.blocks), dim3(kBlock), 0, s, n,   \
+                               p, (V*)r, (const V*)Ap, (V*)x, (const V*)pvec, (const V*)scal, flags, g.lpr,     \
+                               g.rpp, (V*)rr_partial);                                                          \
+        return check_launch();                                                                                  \
+    }
+    TSGU_VSWITCH(vtype, TSGU_BODY, TSGU_BODY);
+#undef TSGU_BODY
+    return TSGU_OK;
+}
+
+int tsgu_cg_beta(int vtype, const void* rr_partial, int64_t n_partial, void* scal, int* flags, double eps,
+                 double stop_updating_after, double tolerance, int iter_index, int min_iter_index, int64_t p,
+                 int device, void* stream) {
+    if (!rr_partial || !scal || !flags || p <= 0 || n_partial < 0) return TSGU_ERR_BAD_ARG;
+    if (const int rc = set_device(device)) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+#define TSGU_BODY                                                                                             \
+    {                                                                                                         \
+        hipLaunchKernelGGL((cg_beta_kernel<V>), dim3(1), dim3(kBlock), 0, s, (const V*)rr_partial, n_partial, \
+                           p, (V*)scal, flags, (V)eps, (V)stop_updating_after, (V)tolerance, iter_index,      \
+                           min_iter_index);                                                                   \
+        return check_launch();                                                                                \
+    }
+    TSGU_VSWITCH(vtype, TSGU_BODY, TSGU_BODY);
+#undef TSGU_BODY
+    return TSGU_OK;
+}
+
+int tsgu_cg_update2(int vtype, int64_t n, int64_t p, const void* r, void* pvec, const void* scal,
+                    const int* flags, int device, void* stream) {
+    if (n <= 0 || p <= 0 || !r || !pvec || !scal || !flags) return TSGU_ERR_BAD_ARG;
+    if (const int rc = set_device(device)) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+#define TSGU_BODY                                                                                             \
+    {                                                                                                         \
+        constexpr int wide = VT<V>::kWide;                                                                    \
+        VecGeom g;                                                                                            \
+        if (!(aligned16(r) && aligned16(pvec))) return TSGU_ERR_BAD_ARG;                                      \
+        if (!geom_for<V>(n, p, true, g)) return TSGU_ERR_TOO_LARGE;                                           \
+        if (g.vec == 1)                                                                                       \
+            hipLaunchKernelGGL((cg_update2_kernel<V, 1>), dim3((unsigned)g.blocks), dim3(kBlock), 0, s, n, p, \
+                               (const V*)r, (V*)pvec, (const V*)scal, flags, g.lpr, g.rpp);                   \
+        else                                                                                                  \
+            hipLaunchKernelGGL((cg_update2_kernel<V, wide>), dim3((unsigned)g.blocks), dim3(kBlock), 0, s, n, \
+                               p, (const V*)r, (V*)pvec, (const V*)scal, flags, g.lpr, g.rpp);                \
+        return check_launch();                                                                                \
+    }
+    TSGU_VSWITCH(vtype, TSGU_BODY, TSGU_BODY);
+#undef TSGU_BODY
+    return TSGU_OK;
+}
+
+}  // extern "C"

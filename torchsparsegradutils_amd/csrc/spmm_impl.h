@@ -1,0 +1,234 @@
+// K1/K2: CSR × dense on gfx950.  One group of CL×EP lanes owns one row; a 256-thread
+// workgroup owns 256/(CL·EP) consecutive rows.  The workgroup's slice of the (col, val)
+// stream is contiguous in memory, so it is read once with fully coalesced loads into LDS
+// and then broadcast to the row groups from there; the dense RHS rows are gathered with
+// 16-byte loads (one 128-B line per fp32 row at p = 32) and accumulated in registers.
+// No atomics, fixed summation order (entry order inside a row) => run-to-run deterministic.
+#pragma once
+
+#include "tsgu_common.h"
+
+namespace tsgu {
+
+constexpr int kStageCap = 2048;  // staged entries per pass (16 KiB LDS for 4-byte values)
+
+template <typename V>
+struct StageBytes {
+    static constexpr int value = kStageCap * (int)(sizeof(int) + (sizeof(V) < 4 ? 4 : sizeof(V)));
+};
+
+struct SpmmParams {
+    int64_t n_rows, nnz_per_item, p;
+    const void* crow;
+    const void* col;
+    const void* val;
+    const void* perm;
+    const void* B;
+    int64_t ldb, b_bs;
+    void* C;
+    int64_t ldc, c_bs;
+    const void* W;
+    int64_t ldw;
+    void* dot_partial;
+    int64_t nblocks;  // row blocks per batch item
+};
+
+// LDS image of the staged entries.  4-byte-or-narrower values are packed with their
+// column into one 8-byte slot (one ds_read_b64 per entry); doubles use two arrays.
+template <typename V, bool PACK = (sizeof(V) <= 4)>
+struct Staged;
+
+template <typename V>
+struct Staged<V, true> {
+    using Acc = typename VT<V>::Acc;
+    uint2* slot;
+    __device__ __forceinline__ explicit Staged(unsigned char* base) : slot(reinterpret_cast<uint2*>(base)) {}
+    __device__ __forceinline__ void put(int i, int c, V v) const {
+        slot[i] = make_uint2((unsigned)c, __float_as_uint(VT<V>::up(v)));
+    }
+    __device__ __forceinline__ void get(int i, int& c, Acc& a) const {
+        const uint2 e = slot[i];
+        c = (int)e.x;
+        a = __uint_as_float(e.y);
+    }
+};
+
+template <typename V>
+struct Staged<V, false> {
+    using Acc = typename VT<V>::Acc;
+    double* vals;
+    int* cols;
+    __device__ __forceinline__ explicit Staged(unsigned char* base)
+        : vals(reinterpret_cast<double*>(base)), cols(reinterpret_cast<int*>(base + kStageCap * sizeof(double))) {}
+    __device__ __forceinline__ void put(int i, int c, V v) const {
+        cols[i] = c;
+        vals[i] = v;
+    }
+    __device__ __forceinline__ void get(int i, int& c, Acc& a) const {
+        c = cols[i];
+        a = vals[i];
+    }
+};
+
+template <typename V, typename I, int VEC, int CL, int EP, bool DOT>
+__global__ __launch_bounds__(kBlock) void csr_spmm_kernel(const SpmmParams P) {
+    using Acc = typename VT<V>::Acc;
+    constexpr int GROUP = CL * EP;
+    constexpr int RPB = kBlock / GROUP;
+    constexpr int U = 4;  // gathers issued back to back per lane
+
+    __shared__ __attribute__((aligned(16))) unsigned char smem[StageBytes<V>::value];
+    const Staged<V> stage(smem);
+
+    const int tid = threadIdx.x;
+    const int grp = tid / GROUP;
+    const int gl = tid % GROUP;
+    const int cl = gl % CL;
+    const int ep = gl / CL;
+
+    const int64_t vb = xcd_chunked_block(blockIdx.x, P.nblocks);
+    const int64_t item = blockIdx.y;
+    const int64_t cbase = ((int64_t)blockIdx.z * CL + cl) * VEC;  // first column of this lane
+    const bool col_ok = cbase < P.p;
+
+    const I* __restrict__ crow = static_cast<const I*>(P.crow) + item * (P.n_rows + 1);
+    const I* __restrict__ col = static_cast<const I*>(P.col) + item * P.nnz_per_item;
+    const V* __restrict__ val = static_cast<const V*>(P.val) + item * P.nnz_per_item;
+    const I* __restrict__ perm = static_cast<const I*>(P.perm);
+    const V* __restrict__ B = static_cast<const V*>(P.B) + item * P.b_bs + cbase;
+
+    const int64_t row0 = vb * RPB;
+    const int64_t row1 = row0 + RPB < P.n_rows ? row0 + RPB : P.n_rows;
+    const int64_t row = row0 + grp;
+    const bool row_ok = row < P.n_rows;
+
+    const int64_t blk_begin = (int64_t)crow[row0];
+    const int64_t blk_end = (int64_t)crow[row1];
+    const int64_t start = row_ok ? (int64_t)crow[row] : 0;
+    const int64_t end = row_ok ? (int64_t)crow[row + 1] : 0;
+
+    Acc acc[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) acc[v] = 0;
+
+    for (int64_t cs = blk_begin; cs < blk_end; cs += kStageCap) {
+        const int64_t ce = cs + kStageCap < blk_end ? cs + kStageCap : blk_end;
+        if (cs != blk_begin) __syncthreads();
+        for (int64_t k = cs + tid; k < ce; k += kBlock) {
+            const int64_t q = perm ? (int64_t)perm[item * P.nnz_per_item + k] : k;
+            stage.put((int)(k - cs), (int)col[k], val[q]);
+        }
+        __syncthreads();
+
+        const int64_t lo = start > cs ? start : cs;
+        const int64_t hi = end < ce ? end : ce;
+        int i = (int)(lo - cs) + ep;
+        const int iend = (int)(hi - cs);
+        if (col_ok) {
+            for (; i + (U - 1) * EP < iend; i += U * EP) {
+                int j[U];
+                Acc a[U];
+                Acc b[U][VEC];
+#pragma unroll
+                for (int u = 0; u < U; ++u) stage.get(i + u * EP, j[u], a[u]);
+#pragma unroll
+                for (int u = 0; u < U; ++u) load_vec<V, VEC>(B + (int64_t)j[u] * P.ldb, b[u]);
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) acc[v] = fma(a[u], b[u][v], acc[v]);
+                }
+            }
+            for (; i < iend; i += EP) {
+                int j;
+                Acc a;
+                Acc b[VEC];
+                stage.get(i, j, a);
+                load_vec<V, VEC>(B + (int64_t)j * P.ldb, b);
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) acc[v] = fma(a, b[v], acc[v]);
+            }
+        }
+    }
+
+    if constexpr (EP > 1) {
+#pragma unroll
+        for (int m = CL; m < GROUP; m <<= 1) {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) acc[v] += shfl_xor_acc(acc[v], m);
+        }
+    }
+
+    if (row_ok && col_ok && ep == 0) {
+        V* __restrict__ C = static_cast<V*>(P.C) + item * P.c_bs + row * P.ldc + cbase;
+        store_vec<V, VEC>(C, acc);
+    }
+
+    if constexpr (DOT) {
+        // partial[block][c] = Σ_rows C[row,c]·W[row,c]; rows summed in row order.
+        constexpr int TW = CL * VEC;  // columns covered by one column tile
+        __syncthreads();
+        Acc* red = reinterpret_cast<Acc*>(smem);
+        if (ep == 0) {
+            Acc w[VEC];
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) w[v] = 0;
+            if (row_ok && col_ok) {
+                load_vec<V, VEC>(static_cast<const V*>(P.W) + row * P.ldw + cbase, w);
+            }
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) red[grp * TW + cl * VEC + v] = (row_ok && col_ok) ? acc[v] * w[v] : (Acc)0;
+        }
+        __syncthreads();
+        if (tid < TW) {
+            Acc s = 0;
+            for (int r = 0; r < RPB; ++r) s += red[r * TW + tid];
+            const int64_t c = (int64_t)blockIdx.z * TW + tid;
+            if (c < P.p) {
+                static_cast<Acc*>(P.dot_partial)[(item * P.nblocks + vb) * P.p + c] = s;
+            }
+        }
+    }
+}
+
+inline int64_t spmm_rows_per_block(const RowGeom& g) { return kBlock / (g.cl * g.ep); }
+
+template <typename V>
+inline RowGeom spmm_geom(const SpmmParams& P, int64_t batch) {
+    constexpr int wide = VT<V>::kWide;
+    bool can = (P.p % wide == 0) && (P.ldb % wide == 0) && (P.ldc % wide == 0) && aligned16(P.B) && aligned16(P.C);
+    if (batch > 1) can = can && (P.b_bs % wide == 0) && (P.c_bs % wide == 0);
+    if (P.W) can = can && (P.ldw % wide == 0) && aligned16(P.W);
+    return pick_geom(wide, can, P.p);
+}
+
+template <typename V, typename I>
+int spmm_launch(SpmmParams P, int64_t batch, hipStream_t stream) {
+    const RowGeom g = spmm_geom<V>(P, batch);
+    const int64_t rpb = spmm_rows_per_block(g);
+    P.nblocks = (P.n_rows + rpb - 1) / rpb;
+    if (P.nblocks > 0x7fffffffLL || batch > 65535 || g.col_tiles > 65535) return TSGU_ERR_TOO_LARGE;
+    const dim3 grid((unsigned)P.nblocks, (unsigned)batch, (unsigned)g.col_tiles);
+    const bool dot = P.dot_partial != nullptr;
+    // the partial buffer is sized by tsgu_spmm_num_blocks(), which assumes the 16-byte geometry
+    // whenever p allows it: refuse operands that would silently fall back to scalar lanes.
+    if (dot && (P.p % VT<V>::kWide == 0) && g.vec == 1) return TSGU_ERR_BAD_ARG;
+    return dispatch_geom(g, [&](auto cl, auto ep) -> int {
+        constexpr int CL = decltype(cl)::value, EP = decltype(ep)::value;
+        constexpr int W = VT<V>::kWide;
+        if (g.vec == 1) {
+            if (dot)
+                hipLaunchKernelGGL((csr_spmm_kernel<V, I, 1, CL, EP, true>), grid, dim3(kBlock), 0, stream, P);
+            else
+                hipLaunchKernelGGL((csr_spmm_kernel<V, I, 1, CL, EP, false>), grid, dim3(kBlock), 0, stream, P);
+        } else {
+            if (dot)
+                hipLaunchKernelGGL((csr_spmm_kernel<V, I, W, CL, EP, true>), grid, dim3(kBlock), 0, stream, P);
+            else
+                hipLaunchKernelGGL((csr_spmm_kernel<V, I, W, CL, EP, false>), grid, dim3(kBlock), 0, stream, P);
+        }
+        return check_launch();
+    });
+}
+
+}  // namespace tsgu

@@ -1,0 +1,182 @@
+// Shared device/host helpers for the gfx950 kernels.  CDNA4 only: wave = 64 lanes,
+// 256-thread workgroups (one wave per SIMD), 8 XCDs with private L2s.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+
+#include "../../include/tsgu_hip.h"
+
+namespace tsgu {
+
+constexpr int kWave = 64;
+constexpr int kBlock = 256;
+constexpr int kXcd = 8;
+
+// bf16 is storage only: one 16-bit word, arithmetic in fp32.
+struct bf16_t {
+    uint16_t bits;
+};
+
+template <typename V>
+struct VT;
+template <>
+struct VT<float> {
+    using Acc = float;
+    static constexpr int kWide = 4;  // elements per 16-byte access
+    __device__ static __forceinline__ float up(float v) { return v; }
+    __device__ static __forceinline__ float down(float a) { return a; }
+};
+template <>
+struct VT<double> {
+    using Acc = double;
+    static constexpr int kWide = 2;
+    __device__ static __forceinline__ double up(double v) { return v; }
+    __device__ static __forceinline__ double down(double a) { return a; }
+};
+template <>
+struct VT<bf16_t> {
+    using Acc = float;
+    static constexpr int kWide = 8;
+    __device__ static __forceinline__ float up(bf16_t v) { return __uint_as_float(((uint32_t)v.bits) << 16); }
+    // round-to-nearest-even, NaN kept quiet
+    __device__ static __forceinline__ bf16_t down(float a) {
+        uint32_t u = __float_as_uint(a);
+        bf16_t r;
+        if ((u & 0x7fffffffu) > 0x7f800000u) {
+            r.bits = (uint16_t)((u >> 16) | 0x0040u);
+        } else {
+            u += 0x7fffu + ((u >> 16) & 1u);
+            r.bits = (uint16_t)(u >> 16);
+        }
+        return r;
+    }
+};
+
+// Workgroup b is observed to run on XCD (b % 8).  Give every XCD one contiguous run of
+// virtual blocks so that neighbouring row blocks (which gather overlapping RHS rows for
+// banded / stencil matrices) share one L2.  Bijective for any nblocks; speed only.
+__device__ __forceinline__ int64_t xcd_chunked_block(int64_t bid, int64_t nblocks) {
+    const int64_t q = nblocks / kXcd, r = nblocks % kXcd;
+    const int64_t x = bid % kXcd, l = bid / kXcd;
+    return x * q + (x < r ? x : r) + l;
+}
+
+// ---- VEC-element loads/stores of value type V into accumulator registers ------------
+template <typename V, int VEC>
+__device__ __forceinline__ void load_vec(const V* __restrict__ ptr, typename VT<V>::Acc (&out)[VEC]) {
+    if constexpr (VEC == 1) {
+        out[0] = VT<V>::up(*ptr);
+    } else {
+        static_assert(VEC == VT<V>::kWide, "vector width must be 1 or 16 bytes");
+        const uint4 raw = *reinterpret_cast<const uint4*>(ptr);
+        if constexpr (std::is_same<V, float>::value) {
+            out[0] = __uint_as_float(raw.x);
+            out[1] = __uint_as_float(raw.y);
+            out[2] = __uint_as_float(raw.z);
+            out[3] = __uint_as_float(raw.w);
+        } else if constexpr (std::is_same<V, double>::value) {
+            out[0] = __hiloint2double((int)raw.y, (int)raw.x);
+            out[1] = __hiloint2double((int)raw.w, (int)raw.z);
+        } else {
+            const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                out[2 * i] = __uint_as_float(w[i] << 16);
+                out[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+            }
+        }
+    }
+}
+
+template <typename V, int VEC>
+__device__ __forceinline__ void store_vec(V* __restrict__ ptr, const typename VT<V>::Acc (&in)[VEC]) {
+    if constexpr (VEC == 1) {
+        *ptr = VT<V>::down(in[0]);
+    } else {
+        uint4 raw;
+        if constexpr (std::is_same<V, float>::value) {
+            raw.x = __float_as_uint(in[0]);
+            raw.y = __float_as_uint(in[1]);
+            raw.z = __float_as_uint(in[2]);
+            raw.w = __float_as_uint(in[3]);
+        } else if constexpr (std::is_same<V, double>::value) {
+            raw.x = (uint32_t)__double2loint(in[0]);
+            raw.y = (uint32_t)__double2hiint(in[0]);
+            raw.z = (uint32_t)__double2loint(in[1]);
+            raw.w = (uint32_t)__double2hiint(in[1]);
+        } else {
+            uint32_t w[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                w[i] = (uint32_t)VT<V>::down(in[2 * i]).bits | ((uint32_t)VT<V>::down(in[2 * i + 1]).bits << 16);
+            }
+            raw.x = w[0];
+            raw.y = w[1];
+            raw.z = w[2];
+            raw.w = w[3];
+        }
+        *reinterpret_cast<uint4*>(ptr) = raw;
+    }
+}
+
+// xor-shuffle for float / double accumulators (all 64 lanes participate)
+__device__ __forceinline__ float shfl_xor_acc(float v, int mask) { return __shfl_xor(v, mask, kWave); }
+__device__ __forceinline__ double shfl_xor_acc(double v, int mask) { return __shfl_xor(v, mask, kWave); }
+
+// ---- host side -----------------------------------------------------------------------
+inline int check_launch() {
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? TSGU_OK : TSGU_ERR_LAUNCH;
+}
+
+inline int set_device(int device) {
+    if (device < 0) return TSGU_ERR_BAD_ARG;
+    return hipSetDevice(device) == hipSuccess ? TSGU_OK : TSGU_ERR_RUNTIME;
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+inline int next_pow2(int64_t x) {
+    int r = 1;
+    while (r < x) r <<= 1;
+    return r;
+}
+
+// Lane geometry for "a group of lanes owns a row":  CL column lanes × EP entry lanes,
+// every lane holding VEC consecutive columns.  Groups are at least 8 lanes wide so the
+// staged column/value stream is read by few distinct LDS addresses per wave.
+struct RowGeom {
+    int vec;      // 1 or kWide
+    int cl;       // column lanes per row (power of two, <= 64)
+    int ep;       // entry-parallel lanes per row
+    int64_t col_tiles;  // grid.z : tiles of cl*vec columns
+};
+
+inline RowGeom pick_geom(int wide, bool can_wide, int64_t p) {
+    RowGeom g;
+    g.vec = can_wide ? wide : 1;
+    const int64_t ncl = (p + g.vec - 1) / g.vec;
+    g.cl = ncl >= 64 ? 64 : next_pow2(ncl);
+    g.ep = g.cl >= 8 ? 1 : 8 / g.cl;
+    g.col_tiles = (ncl + g.cl - 1) / g.cl;
+    return g;
+}
+
+template <typename F>
+inline int dispatch_geom(const RowGeom& g, F&& f) {
+    // f.template operator()<CL, EP>()
+    switch (g.cl) {
+        case 1: return f(std::integral_constant<int, 1>{}, std::integral_constant<int, 8>{});
+        case 2: return f(std::integral_constant<int, 2>{}, std::integral_constant<int, 4>{});
+        case 4: return f(std::integral_constant<int, 4>{}, std::integral_constant<int, 2>{});
+        case 8: return f(std::integral_constant<int, 8>{}, std::integral_constant<int, 1>{});
+        case 16: return f(std::integral_constant<int, 16>{}, std::integral_constant<int, 1>{});
+        case 32: return f(std::integral_constant<int, 32>{}, std::integral_constant<int, 1>{});
+        case 64: return f(std::integral_constant<int, 64>{}, std::integral_constant<int, 1>{});
+    }
+    return TSGU_ERR_BAD_ARG;
+}
+
+}  // namespace tsgu

@@ -1,0 +1,82 @@
+"""Multi-GPU sharding of batched problems: one process per GPU, RCCL over xGMI.
+
+The reference has no distributed code; its only batching is algebraic (a batch of sparse matrices
+is a block-diagonal matrix, sparse_matmul.py:151-153), i.e. batch items are independent — no halo,
+no reduction.  So the path shards by contiguous runs of batch items: rank g owns items
+[g·b/G, (g+1)·b/G) of A and B, forward / SDDMM / Aᵀ·G all stay local, the sparse gradient stays
+sharded, and the only collective is ONE all-gather of the dense result (RCCL when the backend is
+"nccl"; gloo on CPU in the tests).  Un-batched operands are replicas — there is nothing to exchange.
+"""
+
+from __future__ import annotations
+
+from typing import Callable, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(batch: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous, balanced split of `batch` items over `world` ranks (first ranks get the remainder)."""
+    if batch < 0 or world <= 0 or not (0 <= rank < world):
+        raise ValueError(f"bad shard request: batch={batch}, world={world}, rank={rank}")
+    base, extra = divmod(batch, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def shard_batched_csr(A: torch.Tensor, rank: int, world: int) -> torch.Tensor:
+    """Rank-local items of a batched CSR tensor (views of the batched index/value arrays)."""
+    if A.layout != torch.sparse_csr or A.dim() != 3:
+        raise ValueError("expected a batched (3-D) CSR tensor")
+    lo, hi = shard_bounds(A.size(0), world, rank)
+    return torch.sparse_csr_tensor(
+        A.crow_indices()[lo:hi], A.col_indices()[lo:hi], A.values()[lo:hi], (hi - lo,) + tuple(A.shape[1:])
+    )
+
+
+def all_gather_batch(local: torch.Tensor, batch: int, group: Optional[dist.ProcessGroup] = None) -> torch.Tensor:
+    """Gather rank-local result shards (b_local, n, p) into the full (batch, n, p) tensor on every rank.
+
+    Equal shards use one `all_gather_into_tensor` (a single RCCL collective writing straight into the
+    output); ragged shards (batch not divisible by the world size) pad to the largest shard."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    sizes = [shard_bounds(batch, world, r) for r in range(world)]
+    assert local.size(0) == sizes[rank][1] - sizes[rank][0], "local shard does not match shard_bounds"
+    local = local.contiguous()
+    tail = tuple(local.shape[1:])
+    if batch % world == 0:
+        out = torch.empty((batch,) + tail, dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(out, local, group=group)
+        return out
+    biggest = max(hi - lo for lo, hi in sizes)
+    padded = torch.zeros((biggest,) + tail, dtype=local.dtype, device=local.device)
+    padded[: local.size(0)] = local
+    buf = torch.empty((world * biggest,) + tail, dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(buf, padded, group=group)
+    parts = [buf[r * biggest : r * biggest + (hi - lo)] for r, (lo, hi) in enumerate(sizes)]
+    return torch.cat(parts, dim=0)
+
+
+def sharded_batched_apply(
+    op: Callable[[torch.Tensor, torch.Tensor], torch.Tensor],
+    A: torch.Tensor,
+    B: torch.Tensor,
+    group: Optional[dist.ProcessGroup] = None,
+    gather: bool = True,
+) -> torch.Tensor:
+    """Apply a batched op (``sparse_mm`` / ``sparse_triangular_solve``) to this rank's slice of the
+    batch and (optionally) all-gather the dense results.
+
+    ``A``: batched CSR (b, n, m) and ``B``: dense (b, m, p), both holding the FULL batch on every
+    rank (or at least valid data in this rank's slice).  Gradients flow to the local slice only;
+    the gathered tensor is a detached copy, as a data-parallel step would consume it."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    lo, hi = shard_bounds(A.size(0), world, rank)
+    A_local = shard_batched_csr(A, rank, world)
+    local = op(A_local, B[lo:hi])
+    if not gather:
+        return local
+    return all_gather_batch(local.detach(), A.size(0), group)

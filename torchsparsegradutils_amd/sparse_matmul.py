@@ -1,0 +1,147 @@
+"""``sparse_mm`` / ``SparseMatMul`` — drop-in for reference ``torchsparsegradutils/sparse_matmul.py``.
+
+Same signature, validation order and messages (reference :114-127), same autograd contract
+(gradient of the sparse operand has A's layout, A's index tensors and A's index dtype;
+``needs_input_grad`` gating; saved tensors are released after the first backward).  The
+arithmetic runs in the hand-written gfx950 kernels:
+
+=============================  ================================  =====================
+reference (ATen)               here                              C ABI
+=============================  ================================  =====================
+``torch.sparse.mm(A, B)``      K1 CSR SpMM            (:155)     ``tsgu_csr_spmm``
+gathers + mul + sum  :186-205  K3 fused SDDMM                    ``tsgu_csr_sddmm``
+``torch.sparse.mm(A.t(), G)``  K2 gather SpMM on the cached      ``tsgu_csr_spmm``
+:229                           transposed pattern                (``perm`` argument)
+block-diag assembly  :151-153  none: batched CSR stays batched   ``batch`` argument
+=============================  ================================  =====================
+"""
+
+from __future__ import annotations
+
+from typing import cast
+
+import torch
+
+from . import _backend as _be
+from . import _pattern as _pt
+
+
+def sparse_mm(A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
+    r"""Sparse–dense matrix product :math:`C = A B` with sparsity-preserving gradients.
+
+    ``A``: sparse COO or CSR, ``(n, m)`` or ``(b, n, m)``; ``B``: dense ``(m, p)`` or ``(b, m, p)``.
+    Returns dense ``(n, p)`` / ``(b, n, p)``.  ``dL/dA`` is evaluated only at the stored entries
+    of ``A`` (:math:`[\partial A]_{ij} = \langle G_{i,:}, B_{j,:}\rangle`) and returned with A's
+    layout; ``dL/dB = A^\top G``.  Mirrors reference ``sparse_matmul.py:8-129``.
+    """
+    if not isinstance(A, torch.Tensor) or not isinstance(B, torch.Tensor):
+        raise ValueError("Both A and B should be instances of torch.Tensor")
+    if A.dim() < 2 or B.dim() < 2:
+        raise ValueError("Both A and B should be at least 2-dimensional tensors")
+    if A.dim() != B.dim() or A.dim() not in (2, 3):
+        raise ValueError("A and B must both be 2D or both be 3D tensors")
+    if A.layout not in {torch.sparse_coo, torch.sparse_csr}:
+        raise ValueError("A should be in either COO or CSR sparse format")
+    if B.layout != torch.strided:
+        raise ValueError("B must be a dense (strided) tensor")
+    if A.dim() == 3 and A.size(0) != B.size(0):
+        raise ValueError("If batched, A and B must have the same batch size")
+    if A.size(-1) != B.size(-2):
+        raise ValueError(f"Incompatible inner dimensions: A[..., {A.size(-1)}] vs B[..., {B.size(-2)}]")
+
+    return cast(torch.Tensor, SparseMatMul.apply(A, B))
+
+
+class _Operand:
+    """The sparse operand as the kernels see it: a row-gather plan + the value array, plus how
+    to hand a value-shaped gradient back in the caller's layout."""
+
+    __slots__ = ("plan", "values", "layout", "indices", "shape", "flat_batch")
+
+    def __init__(self, A: torch.Tensor):
+        self.layout = A.layout
+        self.shape = A.shape
+        self.flat_batch = None
+        if A.layout == torch.sparse_csr:
+            self.plan = _pt.from_csr(A)
+            self.values = A.values()
+            self.indices = None
+            return
+        # COO.  Batched COO is flattened to one block-diagonal 2-D pattern (what the reference
+        # does for every batched input, sparse_matmul.py:151-153); items may differ in nnz.
+        if A.dim() == 3:
+            A = A if A.is_coalesced() else A.coalesce()
+            idx = A._indices()
+            b, n, m = A.shape
+            flat = torch.stack((idx[0] * n + idx[1], idx[0] * m + idx[2]))
+            self.indices = idx
+            self.flat_batch = b
+            self.plan = _pt.from_coo_2d(flat, (b * n, b * m), coalesced=True)
+            self.values = A._values()
+            return
+        self.indices = A._indices()
+        self.values = A._values()
+        self.plan = _pt.from_coo_2d(self.indices, A.shape, coalesced=A.is_coalesced())
+
+    def rebuild(self, grad_values: torch.Tensor) -> torch.Tensor:
+        """Sparse gradient with A's own layout/indices (reference sparse_matmul.py:208-219)."""
+        if self.layout == torch.sparse_csr:
+            return torch.sparse_csr_tensor(self.plan.crow, self.plan.col, grad_values, self.shape)
+        return torch.sparse_coo_tensor(self.indices, grad_values, self.shape)
+
+
+class SparseMatMul(torch.autograd.Function):
+    """Autograd kernel behind :func:`sparse_mm` (mirrors reference ``sparse_matmul.py:132-234``)."""
+
+    @staticmethod
+    def forward(ctx, A, B):
+        ctx.batch_size = B.size()[0] if B.dim() == 3 else None
+        ctx.A_shape = A.size()
+        ctx.B_shape = B.size()
+        grad_flag = A.requires_grad or B.requires_grad
+
+        A, B = A.detach(), B.detach()
+        _be.require_device(B)
+        if A.device != B.device:
+            raise RuntimeError(f"A and B must be on the same device, got {A.device} and {B.device}")
+
+        op = _Operand(A)
+        plan = op.plan
+        if op.flat_batch is not None:  # batched COO → block-diagonal 2-D problem
+            Bk = B.reshape(-1, B.size(-1))
+        else:
+            Bk = B
+        x = _be.csr_spmm(plan.crow, plan.col, op.values, Bk, plan.n_rows, plan.n_cols, perm=plan.perm)
+        if op.flat_batch is not None:
+            x = x.view(ctx.batch_size, ctx.A_shape[-2], ctx.B_shape[-1])
+
+        ctx.op = op
+        ctx.save_for_backward(op.values, Bk)
+        x.requires_grad_(grad_flag)
+        return x
+
+    @staticmethod
+    def backward(ctx, grad):  # type: ignore[override]
+        values, B = ctx.saved_tensors
+        op: _Operand = ctx.op
+        plan = op.plan
+        gradA = gradB = None
+
+        G = grad.reshape(-1, grad.size(-1)) if op.flat_batch is not None else grad
+
+        if ctx.needs_input_grad[0]:
+            # gradA[k] = <G[row k,:], B[col k,:]> at A's stored entries only (reference :172-205)
+            if plan.perm is None:
+                gvals = _be.csr_sddmm(plan.crow, plan.col, G, B, plan.n_rows, plan.n_cols)
+            else:  # un-coalesced COO: one gradient entry per stored duplicate, in A's own order
+                gvals = _be.coo_sddmm(op.indices[0], op.indices[1], G, B)
+            gradA = op.rebuild(gvals)
+
+        if ctx.needs_input_grad[1]:
+            # gradB = Aᵀ·G as a gather over the cached transposed pattern (reference :229)
+            pt = plan.transposed
+            gradB = _be.csr_spmm(pt.crow, pt.col, values, G, pt.n_rows, pt.n_cols, perm=pt.perm)
+            if ctx.batch_size is not None:
+                gradB = gradB.view(ctx.B_shape)
+
+        return gradA, gradB

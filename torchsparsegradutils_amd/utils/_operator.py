@@ -1,0 +1,61 @@
+"""Matrix–vector closures for the Krylov loops.
+
+The reference passes ``A.matmul`` of a torch sparse tensor into its solvers
+(``utils/linear_cg.py:243-244``, ``utils/bicgstab.py:129-130``, ``utils/minres.py:149-150``), i.e.
+one ATen sparse addmm per iteration.  ``as_operator`` turns a sparse tensor into a closure over
+the K1 HIP kernel (optionally with the fused pᵀ(Ap) epilogue CG needs)."""
+
+from __future__ import annotations
+
+import torch
+
+from .. import _backend as _be
+from .. import _pattern as _pt
+
+
+class SparseOperator:
+    """y = A·v through ``tsgu_csr_spmm`` for a 2-D sparse COO/CSR tensor on the GPU."""
+
+    def __init__(self, A: torch.Tensor):
+        if A.dim() != 2:
+            raise RuntimeError("sparse operator must be a 2-D sparse tensor")
+        _be.require_device(A)
+        if A.layout == torch.sparse_csr:
+            self.plan = _pt.from_csr(A)
+            self.values = A.values()
+        elif A.layout == torch.sparse_coo:
+            A = A if A.is_coalesced() else A.coalesce()
+            self.plan = _pt.from_coo_2d(A.indices(), A.shape, coalesced=True)
+            self.values = A.values()
+        else:
+            raise RuntimeError(f"unsupported sparse layout {A.layout}")
+        self.shape = A.shape
+        self.dtype = self.values.dtype
+
+    def _cast(self, v):
+        return v if v.dtype == self.dtype else v.to(self.dtype)
+
+    def __call__(self, v: torch.Tensor) -> torch.Tensor:
+        v = self._cast(v)
+        p = self.plan
+        if v.dim() == 1:
+            return _be.csr_spmm(p.crow, p.col, self.values, v.unsqueeze(-1), p.n_rows, p.n_cols, perm=p.perm).squeeze(-1)
+        return _be.csr_spmm(p.crow, p.col, self.values, v, p.n_rows, p.n_cols, perm=p.perm)
+
+    matmul = __call__
+
+    def matmul_with_dot(self, v: torch.Tensor):
+        """(A·v, per-block partial sums of vᵀ(A·v) per column) — K1 with the fused dot epilogue."""
+        p = self.plan
+        return _be.csr_spmm(p.crow, p.col, self.values, v, p.n_rows, p.n_cols, perm=p.perm, dot_w=v)
+
+
+def as_operator(matmul_closure):
+    """tensor-or-callable → callable, keeping the reference's error for anything else."""
+    if torch.is_tensor(matmul_closure):
+        if matmul_closure.layout in (torch.sparse_csr, torch.sparse_coo):
+            return SparseOperator(matmul_closure)
+        return matmul_closure.matmul
+    if callable(matmul_closure):
+        return matmul_closure
+    raise RuntimeError("matmul_closure must be a tensor, or a callable object!")

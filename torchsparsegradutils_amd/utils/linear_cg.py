@@ -1,0 +1,246 @@
+"""``linear_cg`` — drop-in for reference ``torchsparsegradutils/utils/linear_cg.py`` (batched
+multi-RHS conjugate gradients, port of ``linear_operator``'s CG).
+
+Same signature, settings tuple, quirks and messages: right-hand sides are normalised per column
+(:257-263), convergence is the *mean* normalised residual over columns tested from iteration
+``min(10, max_iter-1)`` on (:376-382), converged columns are frozen (:74), divisions are guarded
+by ``eps`` (:39-43, :67-71), and a ``UserWarning`` is raised when the cap is hit (:411-421).
+
+What changes is where the work happens.  The reference issues one sparse addmm plus ≈15 small
+ATen ops and one device→host sync per iteration; here one iteration of the un-preconditioned
+loop is five launches with all per-column scalars resident on the GPU:
+
+    K1 SpMM (+ fused pᵀAp block partials) → cg_alpha → cg_update1 (r, x, rᵀr partials)
+      → cg_beta (β, ‖r‖, has_converged, stop flag) → cg_update2 (p = r + βp)
+
+and the host only polls the 4-byte stop flag every ``_POLL`` iterations (kernels turn into
+no-ops once it is set, so running ahead is harmless).
+"""
+
+from __future__ import annotations
+
+import warnings
+from typing import Callable, NamedTuple, Optional, Union
+
+import torch
+
+from .. import _backend as _be
+from ._operator import SparseOperator, as_operator
+
+_POLL = 8  # iterations enqueued between two reads of the device stop flag
+
+
+class LinearCGSettings(NamedTuple):
+    """Mirrors reference ``utils/linear_cg.py:10-20`` (note the default ``cg_tolerance`` of 1)."""
+
+    max_cg_iterations: int = 1000
+    max_lanczos_quadrature_iterations: int = 20
+    cg_tolerance: float = 1
+    terminate_cg_by_size: bool = False
+    verbose_linalg: bool = False
+
+
+def _default_preconditioner(x):
+    return x.clone()
+
+
+def _colnorm(v: torch.Tensor) -> torch.Tensor:
+    """‖v‖₂ per column as a (1, p) tensor (HIP two-stage reduction)."""
+    return _be.coldot(v, v).sqrt_().unsqueeze(0)
+
+
+def linear_cg(
+    matmul_closure: Union[torch.Tensor, Callable[[torch.Tensor], torch.Tensor]],
+    rhs: torch.Tensor,
+    n_tridiag: int = 0,
+    tolerance: Optional[float] = None,
+    eps: float = 1e-10,
+    stop_updating_after: float = 1e-10,
+    max_iter: Optional[int] = None,
+    max_tridiag_iter: Optional[int] = None,
+    initial_guess: Optional[torch.Tensor] = None,
+    preconditioner: Optional[Callable[[torch.Tensor], torch.Tensor]] = None,
+    settings: LinearCGSettings = LinearCGSettings(),
+) -> torch.Tensor:
+    r"""Solve SPD systems :math:`A x = b` for one or many right-hand sides with conjugate gradients.
+
+    ``matmul_closure`` is a tensor (dense, or sparse COO/CSR → HIP SpMM) or a callable ``v -> A v``;
+    ``rhs`` is ``(n,)`` or ``(n, k)`` on the GPU.  Arguments and defaults mirror the reference; the
+    Lanczos tridiagonalisation output (``n_tridiag > 0``, reference :303-310, :385-406) is not
+    provided by this build and raises ``NotImplementedError``.
+    """
+    _be.require_device(rhs)
+    is_vector = rhs.ndimension() == 1
+    if is_vector:
+        rhs = rhs.unsqueeze(-1)
+    if rhs.ndimension() != 2:
+        raise NotImplementedError("linear_cg on gfx950 supports (n,) and (n, k) right-hand sides (no batch dims)")
+
+    if max_iter is None:
+        max_iter = settings.max_cg_iterations
+    if max_tridiag_iter is None:
+        max_tridiag_iter = settings.max_lanczos_quadrature_iterations
+    if initial_guess is None:
+        x0 = None
+    else:
+        is_vector = initial_guess.ndimension() == 1
+        x0 = initial_guess.unsqueeze(-1) if is_vector else initial_guess
+    if tolerance is None:
+        tolerance = settings.cg_tolerance
+    if max_tridiag_iter > max_iter:
+        raise RuntimeError("Getting a tridiagonalization larger than the number of CG iterations run is not possible!")
+    if n_tridiag:
+        raise NotImplementedError("Lanczos tridiagonalisation (n_tridiag > 0) is outside the gfx950 hot path")
+
+    op = as_operator(matmul_closure)
+
+    num_rows, p = rhs.shape
+    n_iter = min(max_iter, num_rows) if settings.terminate_cg_by_size else max_iter
+    dtype, dev = rhs.dtype, rhs.device
+    if dtype not in (torch.float32, torch.float64):
+        raise RuntimeError(f"linear_cg: unsupported dtype {dtype}")
+
+    # normalise the right-hand sides (reference :257-263)
+    rhs_norm = _colnorm(rhs)
+    rhs_is_zero = rhs_norm.lt(eps)
+    rhs_norm = rhs_norm.masked_fill_(rhs_is_zero, 1)
+    rhs = rhs.div(rhs_norm)
+
+    if x0 is None:
+        result = torch.zeros_like(rhs)
+        residual = rhs - op(result)  # reference :266 (kept: it is also the NaN probe of :278)
+    else:
+        result = x0.div(rhs_norm).expand_as(rhs).contiguous()
+        residual = rhs - op(result)
+    residual = residual.contiguous()
+
+    if settings.verbose_linalg:
+        print(f"Running CG on a {rhs.shape} RHS for {n_iter} iterations (tol={tolerance}). Output: {result.shape}.")
+
+    if not torch.equal(residual, residual):
+        raise RuntimeError("NaNs encountered when trying to perform matrix-vector multiplication")
+
+    residual_norm = _colnorm(residual)
+    has_converged = torch.lt(residual_norm, stop_updating_after)
+    if bool(has_converged.all()):
+        n_iter = 0
+
+    tolerance_reached = False
+    k_done = 0
+    if n_iter > 0:
+        if preconditioner is not None:
+            result, residual_norm, k_done, tolerance_reached = _pcg_loop(
+                op, preconditioner, rhs_is_zero, result, residual, has_converged, n_iter, max_iter, tolerance, eps,
+                stop_updating_after,
+            )
+        else:
+            result, residual_norm, k_done, tolerance_reached = _fused_loop(
+                op, rhs_is_zero, result, residual, has_converged, n_iter, max_iter, tolerance, eps,
+                stop_updating_after,
+            )
+
+    result = result.mul(rhs_norm)
+
+    if not tolerance_reached and n_iter > 0:
+        warnings.warn(
+            "CG terminated in {} iterations with average residual norm {}"
+            " which is larger than the tolerance of {} specified by"
+            " linear_operator.settings.cg_tolerance."
+            " If performance is affected, consider raising the maximum number of CG iterations by running code in"
+            " a linear_operator.settings.max_cg_iterations(value) context.".format(
+                k_done, residual_norm.mean(), tolerance
+            ),
+            UserWarning,
+        )
+
+    if is_vector:
+        result = result.squeeze(-1)
+    return result
+
+
+def _fused_loop(op, rhs_is_zero, x, r, has_converged, n_iter, max_iter, tolerance, eps, stop_after):
+    """Un-preconditioned CG iterations on the fused gfx950 kernels (reference :319-382, :50-95)."""
+    lib = _be.load_library()
+    n, p = r.shape
+    dev, dtype = r.device, r.dtype
+    vt = _be.vtype_of(r)
+    nb_upd = lib.tsgu_cg_num_blocks(vt, n, p)
+    if nb_upd < 0:
+        raise RuntimeError("linear_cg: more than 1024 simultaneous right-hand sides are not supported")
+
+    # device state: scal = [rr | alpha | beta | rnorm], flags = [done, iters, has_converged[p], rhs_is_zero[p]]
+    scal = torch.zeros(4 * p, dtype=dtype, device=dev)
+    scal[:p] = _be.coldot(r, r)  # residual_inner_prod (reference :294)
+    flags = torch.zeros(2 + 2 * p, dtype=torch.int32, device=dev)
+    flags[2 : 2 + p] = has_converged.reshape(-1).to(torch.int32)
+    flags[2 + p :] = rhs_is_zero.reshape(-1).to(torch.int32)
+    rr_partial = torch.empty((nb_upd, p), dtype=dtype, device=dev)
+    pvec = r.clone()  # curr_conjugate_vec (reference :293)
+    fused_dot = isinstance(op, SparseOperator) and op.dtype == dtype
+    stream = lambda: torch.cuda.current_stream(dev).cuda_stream  # noqa: E731
+    min_iter_index = min(10, max_iter - 1)
+
+    done = False
+    k = 0
+    with torch.cuda.device(dev):
+        while k < n_iter and not done:
+            upto = min(n_iter, max(k + _POLL, min_iter_index + 1) if k <= min_iter_index else k + _POLL)
+            for kk in range(k, upto):
+                if fused_dot:
+                    Ap, pap = op.matmul_with_dot(pvec)  # K1 + pᵀAp partials (reference :322, :64-65)
+                    n_partial = pap.shape[0]
+                else:
+                    Ap = op(pvec).contiguous()
+                    pap = _be.coldot(pvec, Ap).unsqueeze(0)
+                    n_partial = 1
+                s = stream()
+                _be.check(lib.tsgu_cg_alpha(vt, pap.data_ptr(), n_partial, scal.data_ptr(), flags.data_ptr(), eps, p,
+                                            dev.index, s), "tsgu_cg_alpha")
+                _be.check(lib.tsgu_cg_update1(vt, n, p, r.data_ptr(), Ap.data_ptr(), x.data_ptr(), pvec.data_ptr(),
+                                              scal.data_ptr(), flags.data_ptr(), rr_partial.data_ptr(), dev.index, s),
+                          "tsgu_cg_update1")
+                _be.check(lib.tsgu_cg_beta(vt, rr_partial.data_ptr(), nb_upd, scal.data_ptr(), flags.data_ptr(), eps,
+                                           stop_after, float(tolerance), kk, min_iter_index, p, dev.index, s),
+                          "tsgu_cg_beta")
+                _be.check(lib.tsgu_cg_update2(vt, n, p, r.data_ptr(), pvec.data_ptr(), scal.data_ptr(),
+                                              flags.data_ptr(), dev.index, s), "tsgu_cg_update2")
+            k = upto
+            head = flags[:2].tolist()  # the only device→host read: [done, iterations executed]
+            done = head[0] != 0
+    k_done = int(flags[1].item())
+    rnorm = scal[3 * p : 4 * p].unsqueeze(0)
+    return x, rnorm, k_done, done
+
+
+def _pcg_loop(op, preconditioner, rhs_is_zero, x, r, has_converged, n_iter, max_iter, tolerance, eps, stop_after):
+    """Preconditioned iterations (reference :323-355).  The user's preconditioner is an opaque
+    callable, so the recurrences run as device tensor ops around it; SpMM and dots stay on the HIP kernels."""
+    dtype = r.dtype
+    z = preconditioner(r)
+    pvec = z.clone() if z is r else z
+    rz = _be.coldot(z.contiguous(), r).unsqueeze(0)
+    rnorm = _colnorm(r)
+    done = False
+    k_done = 0
+    eps_t = torch.tensor(eps, dtype=dtype, device=r.device)
+    for k in range(n_iter):
+        Ap = op(pvec).contiguous()
+        pap = _be.coldot(pvec.contiguous(), Ap).unsqueeze(0)
+        zero = pap < eps_t
+        alpha = torch.where(zero, torch.zeros_like(pap), rz / torch.where(zero, torch.ones_like(pap), pap))
+        alpha = alpha.masked_fill(has_converged, 0)
+        r = torch.addcmul(r, alpha, Ap, value=-1)
+        z = preconditioner(r)
+        x = torch.addcmul(x, alpha, pvec)
+        rz_old = rz
+        rz = _be.coldot(z.contiguous(), r.contiguous()).unsqueeze(0)
+        zero = rz_old < eps_t
+        beta = torch.where(zero, torch.zeros_like(rz), rz / torch.where(zero, torch.ones_like(rz), rz_old))
+        pvec = pvec * beta + z
+        rnorm = _colnorm(r.contiguous()).masked_fill_(rhs_is_zero, 0)
+        has_converged = rnorm < stop_after
+        k_done = k + 1
+        if k >= min(10, max_iter - 1) and bool(rnorm.mean() < tolerance):
+            done = True
+            break
+    return x, rnorm, k_done, done

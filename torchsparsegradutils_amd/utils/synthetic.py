@@ -1,0 +1,109 @@
+"""Vectorised synthetic CSR generators for the benchmark / parity configurations.
+
+The reference's generators (``utils/random_sparse.py``) sample indices with a Python ``set``
+rejection loop (:306-311) and cannot produce 27e6 entries; these build the same kind of
+matrices (neighbourhood stencils like ``encoders/pairwise_encoder.py`` produces, banded random
+triangular factors like ``benchmarks/sparse_triangular_solve_rand.py:131-142``) with tensor ops.
+All generators are deterministic given ``seed`` and run on any device.
+"""
+
+from __future__ import annotations
+
+from typing import Tuple
+
+import torch
+
+
+def _grid(nx: int, ny: int, nz: int, device):
+    idx = torch.arange(nx * ny * nz, device=device, dtype=torch.int64)
+    return idx // (ny * nz), (idx // nz) % ny, idx % nz
+
+
+def stencil27_periodic(nx: int, ny: int, nz: int, index_dtype=torch.int32, device="cpu") -> Tuple[torch.Tensor, torch.Tensor]:
+    """Pattern of the periodic 3-D 27-point stencil on an nx×ny×nz grid: exactly 27 entries per
+    row, column indices sorted inside each row.  Returns (crow, col)."""
+    if min(nx, ny, nz) < 3:
+        raise ValueError("periodic 27-point stencil needs every grid dimension >= 3")
+    x, y, z = _grid(nx, ny, nz, device)
+    cols = []
+    for dx in (-1, 0, 1):
+        for dy in (-1, 0, 1):
+            for dz in (-1, 0, 1):
+                cols.append((((x + dx) % nx) * ny + (y + dy) % ny) * nz + (z + dz) % nz)
+    col = torch.sort(torch.stack(cols, dim=1), dim=1).values.reshape(-1).to(index_dtype)
+    n = nx * ny * nz
+    crow = (torch.arange(n + 1, device=device, dtype=torch.int64) * 27).to(index_dtype)
+    return crow, col
+
+
+def stencil7_periodic(nx: int, ny: int, nz: int, index_dtype=torch.int32, device="cpu"):
+    """Periodic 7-point stencil pattern (7 entries per row, sorted columns)."""
+    if min(nx, ny, nz) < 3:
+        raise ValueError("periodic 7-point stencil needs every grid dimension >= 3")
+    x, y, z = _grid(nx, ny, nz, device)
+    cols = [(x * ny + y) * nz + z]
+    for d in (-1, 1):
+        cols.append((((x + d) % nx) * ny + y) * nz + z)
+        cols.append((x * ny + (y + d) % ny) * nz + z)
+        cols.append((x * ny + y) * nz + (z + d) % nz)
+    col = torch.sort(torch.stack(cols, dim=1), dim=1).values.reshape(-1).to(index_dtype)
+    n = nx * ny * nz
+    crow = (torch.arange(n + 1, device=device, dtype=torch.int64) * 7).to(index_dtype)
+    return crow, col
+
+
+def laplacian7(nx: int, ny: int, nz: int, index_dtype=torch.int32, dtype=torch.float32, device="cpu", shift: float = 0.0):
+    """SPD 7-point Laplacian (Dirichlet, non-periodic): diagonal 6 (+shift), off-diagonals -1.
+    Returns (crow, col, val) with sorted columns."""
+    n = nx * ny * nz
+    x, y, z = _grid(nx, ny, nz, device)
+    me = torch.arange(n, device=device, dtype=torch.int64)
+    cand = [
+        (me - ny * nz, x > 0),
+        (me - nz, y > 0),
+        (me - 1, z > 0),
+        (me, torch.ones_like(x, dtype=torch.bool)),
+        (me + 1, z < nz - 1),
+        (me + nz, y < ny - 1),
+        (me + ny * nz, x < nx - 1),
+    ]
+    cols = torch.stack([c for c, _ in cand], dim=1)
+    keep = torch.stack([k for _, k in cand], dim=1)
+    vals = torch.full((n, 7), -1.0, dtype=dtype, device=device)
+    vals[:, 3] = 6.0 + shift
+    counts = keep.sum(dim=1)
+    crow = torch.zeros(n + 1, dtype=torch.int64, device=device)
+    crow[1:] = torch.cumsum(counts, 0)
+    return crow.to(index_dtype), cols[keep].to(index_dtype), vals[keep]
+
+
+def banded_lower(n: int, per_row: int = 18, band: int = 4096, index_dtype=torch.int32, dtype=torch.float32,
+                 device="cpu", seed: int = 0):
+    """Well-conditioned random lower-triangular CSR: diagonal ~U(1,2) plus up to `per_row` distinct
+    off-diagonal columns drawn from [i-band, i-1], values ~U(0,0.1); sorted, duplicate-free rows.
+    (n=262144, per_row=18, band=4096, seed=0 gives the ~4.94M-entry matrix of config C3.)"""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    i = torch.arange(n, dtype=torch.int64).unsqueeze(1)
+    off = torch.randint(1, band + 1, (n, per_row), generator=g, dtype=torch.int64)
+    cand = i - off
+    cand = torch.sort(cand, dim=1).values
+    ok = cand >= 0
+    ok[:, 1:] &= cand[:, 1:] != cand[:, :-1]
+    cols = torch.cat([cand, i], dim=1)
+    keep = torch.cat([ok, torch.ones((n, 1), dtype=torch.bool)], dim=1)
+    vals = torch.rand((n, per_row + 1), generator=g, dtype=torch.float64) * 0.1
+    vals[:, -1] = 1.0 + torch.rand((n,), generator=g, dtype=torch.float64)
+    crow = torch.zeros(n + 1, dtype=torch.int64)
+    crow[1:] = torch.cumsum(keep.sum(dim=1), 0)
+    return (crow.to(index_dtype).to(device), cols[keep].to(index_dtype).to(device), vals[keep].to(dtype).to(device))
+
+
+def lower_of(crow: torch.Tensor, col: torch.Tensor, val: torch.Tensor):
+    """Keep the lower triangle (incl. diagonal) of a CSR matrix given as arrays."""
+    n = crow.numel() - 1
+    rows = torch.repeat_interleave(torch.arange(n, device=col.device, dtype=col.dtype), (crow[1:] - crow[:-1]))
+    keep = col <= rows
+    counts = torch.bincount(rows[keep].to(torch.int64), minlength=n)
+    new_crow = torch.zeros(n + 1, dtype=torch.int64, device=col.device)
+    new_crow[1:] = torch.cumsum(counts, 0)
+    return new_crow.to(crow.dtype), col[keep], val[keep]
