@@ -117,7 +117,7 @@ def test_mm_bf16_csr():
     # fp32 accumulation, one final rounding to bf16: within 1 bf16 ulp of the fp32 reference (≤ 2^-8 relative per
     # element), i.e. 1e-3-class normwise
     for mine, ref in ((C, z["C_f32"]), (A.grad.values(), z["gradA_f32"]), (B.grad, z["gradB_f32"])):
-        mine = mine.float().cpu().numpy()
+        mine = mine.detach().float().cpu().numpy()
         assert np.all(np.abs(mine - ref) <= np.abs(ref) * 2.0 ** -8 + 1e-30)
         assert np.linalg.norm(mine - ref) / np.linalg.norm(ref) < 3e-3
 
