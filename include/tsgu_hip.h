@@ -112,6 +112,50 @@ int tsgu_coo_sddmm(int vtype, int itype, int64_t nnz,
                    int device, void* stream);
 
 /*
+ * K2+K3 fused: the whole backward of C = A·B in one pass over the cached transposed pattern
+ * (t_ptr[n_cols+1], t_idx[nnz] = row in A, t_perm[nnz] = position in A's value array):
+ *   gradB[j,:]          = Σ_k∈col j  val[t_perm[k]] · G[t_idx[k],:]          (sparse_matmul.py:229)
+ *   gradA_vals[t_perm[k]] = < G[t_idx[k],:], B[j,:] >                          (sparse_matmul.py:186-205)
+ * Every upstream row G[i,:] is gathered once and used for both gradients (K2 and K3 run separately
+ * gather 2·nnz dense rows).  fp32 / bf16, p <= 64·(16 bytes / element size); batched like K1.
+ * Results are identical to K2 (same order) and to K3 up to the order-independent per-entry dot.
+ */
+int tsgu_csr_mm_backward(int vtype, int itype, int64_t n_rows, int64_t n_cols, int64_t nnz_per_item,
+                         const void* t_ptr, const void* t_idx, const void* t_perm, const void* val,
+                         const void* G, int64_t ldg, int64_t g_batch_stride,
+                         const void* B, int64_t ldb, int64_t b_batch_stride,
+                         void* gradA_vals, void* gradB, int64_t ldgb, int64_t gb_batch_stride,
+                         int64_t p, int64_t batch, int device, void* stream);
+
+/*
+ * Wave-pipelined, LDS-tiled variants of K1/K2/K3 ("wavetile") for patterns whose neighbouring rows
+ * share columns (stencils, banded matrices).  They replace the same reference lines as
+ * tsgu_csr_spmm / tsgu_csr_sddmm and produce bit-identical results; the operand rows a wave needs
+ * for its `rows_per_task` consecutive matrix rows are fetched once into a wave-private LDS tile.
+ * They need a per-pattern plan (built once by the caller with index ops, cached with the pattern):
+ *   tmeta [ntask]               int32x2 {first entry, entry count}, ntask = ceil(n_rows / rows_per_task)
+ *   tcols [ntask][max_distinct] int32   distinct column indices of the task's rows, padded by
+ *                                       repeating the last one (16-byte aligned rows)
+ *   lidx  [ntask][max_entries]  uint8   for each entry (in task order) the position of its column
+ *                                       in the task's tcols row, zero padded
+ * Every task must have <= max_distinct distinct columns and <= max_entries entries
+ * (tsgu_wavetile_geometry reports the limits for (vtype, p)); otherwise use the gather kernels.
+ * Dense operands must be 16-byte aligned with 16-byte-aligned rows whenever p is a multiple of the
+ * 16-byte vector width.  fp32 and bf16 values; 2-D operands only; 4 <= nnz < 2^31.
+ */
+int tsgu_wavetile_geometry(int vtype, int64_t p, int* rows_per_task, int* max_distinct, int* max_entries);
+int tsgu_csr_spmm_wavetile(int vtype, int itype, int64_t n_rows, int64_t n_cols, int64_t nnz,
+                           const void* crow, const void* val, const void* perm,
+                           const void* tmeta, const void* tcols, const void* lidx,
+                           const void* B, int64_t ldb, void* C, int64_t ldc, int64_t p,
+                           int device, void* stream);
+int tsgu_csr_sddmm_wavetile(int vtype, int itype, int64_t n_rows, int64_t n_cols, int64_t nnz,
+                            const void* crow, const void* tmeta, const void* tcols, const void* lidx,
+                            const void* G, int64_t ldg, const void* B, int64_t ldb,
+                            void* out, double alpha, int swap_roles, int64_t p,
+                            int device, void* stream);
+
+/*
  * K4  X = op(A)^{-1} B   sparse triangular solve, sync-free (dependency-driven) CSR sweep.
  * replaces: torch.triangular_solve(B, A, upper, transpose, unitriangular).solution
  *           torchsparsegradutils/_compat.py:42-48  (from sparse_solve.py:181-183 and :202-204)

@@ -1,0 +1,103 @@
+#!/usr/bin/env python3
+"""Developer micro-benchmark: per-kernel HIP-event timings at C2 (or a given grid) + quick self-checks.
+Not part of the product or the test-suite; used to iterate on kernels between gpurun calls.
+
+    python tools/kbench.py [--grid 100 100 100] [--rhs 32] [--reps 50] [--only spmm,sddmm,spmmt]
+"""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from torchsparsegradutils_amd import _backend as be  # noqa: E402
+from torchsparsegradutils_amd import _pattern  # noqa: E402
+from torchsparsegradutils_amd.utils import synthetic  # noqa: E402
+
+
+def ev(fn, reps):
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record()
+    b.synchronize()
+    return a.elapsed_time(b) / reps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--grid", type=int, nargs=3, default=[100, 100, 100])
+    ap.add_argument("--rhs", type=int, default=32)
+    ap.add_argument("--reps", type=int, default=50)
+    ap.add_argument("--only", default="spmm,sddmm,spmmt,bwd_fused,spmm_tiled,sddmm_tiled,spmmt_tiled")
+    ap.add_argument("--check", action="store_true")
+    ap.add_argument("--pattern", default="stencil27", help="stencil27 | diag27 (27 copies of own row) | band27 (cols = row-13..row+13)")
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    nx, ny, nz = a.grid
+    n, p = nx * ny * nz, a.rhs
+    crow, col = synthetic.stencil27_periodic(nx, ny, nz, torch.int32, device=dev)
+    if a.pattern == "diag27":
+        col = torch.arange(n, device=dev, dtype=torch.int32).repeat_interleave(27)
+    elif a.pattern == "band27":
+        col = ((torch.arange(n, device=dev).unsqueeze(1) + torch.arange(-13, 14, device=dev).unsqueeze(0)) % n).reshape(-1).to(torch.int32)
+    nnz = col.numel()
+    val = torch.randn(nnz, device=dev)
+    B = torch.randn(n, p, device=dev)
+    G = torch.randn(n, p, device=dev)
+    A = torch.sparse_csr_tensor(crow, col, val, (n, n))
+    plan = _pattern.from_csr(A)
+    pt = plan.transposed
+    I, V = 4, 4
+    by = {"spmm": (n + 1) * I + nnz * (I + V) + 2 * n * p * V, "sddmm": (n + 1) * I + nnz * I + 2 * n * p * V + nnz * V}
+    by["spmmt"] = by["spmm"]
+    fns = {
+        "spmm": lambda: be.csr_spmm(crow, col, val, B, n, n),
+        "sddmm": lambda: be.csr_sddmm(crow, col, G, B, n, n),
+        "spmmt": lambda: be.csr_spmm(pt.crow, pt.col, val, G, n, n, perm=pt.perm),
+    }
+    by["bwd_fused"] = (n + 1) * I + nnz * (I + V) + 2 * n * p * V + nnz * V + n * p * V
+    fns["bwd_fused"] = lambda: be.csr_mm_backward(pt, val, G, B, n, n)
+    geo = be.tiled_geometry(torch.float32, p)
+    tl, tlt = plan.tiles(*geo), pt.tiles(*geo)
+    if tl is not None:
+        print(f"tile plan: geo={geo} max_distinct={tl.max_distinct} max_entries={tl.max_entries} reuse={tl.reuse:.2f}; transposed ok={tlt is not None}")
+        by.update({"spmm_tiled": by["spmm"], "sddmm_tiled": by["sddmm"], "spmmt_tiled": by["spmm"]})
+        fns["spmm_tiled"] = lambda: be.csr_spmm_tiled(crow, val, tl, B, n, n)
+        fns["sddmm_tiled"] = lambda: be.csr_sddmm_tiled(crow, tl, G, B, n, n)
+        if tlt is not None:
+            fns["spmmt_tiled"] = lambda: be.csr_spmm_tiled(pt.crow, val, tlt, G, n, n, perm=pt.perm)
+    for k in a.only.split(","):
+        if k not in fns:
+            continue
+        ms = ev(fns[k], a.reps)
+        print(f"{k:12s} {ms*1e3:8.1f} us  {by[k]/ms/1e6:8.1f} GB/s  ({by[k]/ms/1e6/8000*100:.1f}% of 8 TB/s)", flush=True)
+    if a.check and tl is not None:
+        for base in ("spmm", "sddmm", "spmmt"):
+            if base + "_tiled" in fns:
+                x, y = fns[base](), fns[base + "_tiled"]()
+                print(f"{base}: tiled vs gather max abs diff = {float((x - y).abs().max())}")
+    if a.check:
+        gA, gB = fns["bwd_fused"]()
+        print("fused bwd vs K3/K2: gradA max abs diff", float((gA - fns["sddmm"]()).abs().max()), " gradB max abs diff", float((gB - fns["spmmt"]()).abs().max()))
+        C = fns["spmm"]()
+        Cr = torch.sparse.mm(A, B)
+        print("spmm  max rel err vs hipSPARSE:", float((C - Cr).abs().max() / Cr.abs().max()))
+        Dt = fns["spmmt"]()
+        Dr = torch.sparse.mm(A.t().to_sparse_csr(), G) if n <= 200000 else None
+        if Dr is not None:
+            print("spmmt max rel err:", float((Dt - Dr).abs().max() / Dr.abs().max()))
+        gv = fns["sddmm"]()
+        rows = plan.row_indices().long()
+        sel = torch.randint(0, nnz, (100000,), device=dev)
+        ref = (G[rows[sel]] * B[col[sel].long()]).sum(1)
+        print("sddmm max rel err (sampled):", float((gv[sel] - ref).abs().max() / ref.abs().max()))
+
+
+if __name__ == "__main__":
+    main()

@@ -16,7 +16,7 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libtsgu_hip.so")
+LIB_PATH = os.environ.get("TSGU_LIB_PATH") or os.path.join(_HERE, "csrc", "libtsgu_hip.so")  # env override: kernel A/B builds
 
 TSGU_F32, TSGU_F64, TSGU_BF16 = 0, 1, 2
 TSGU_I32, TSGU_I64 = 0, 1
@@ -49,6 +49,21 @@ SIGNATURES = {
          _int, _ptr],
     ),
     "tsgu_coo_sddmm": (_int, [_int, _int, _i64, _ptr, _ptr, _ptr, _i64, _ptr, _i64, _ptr, _dbl, _i64, _int, _ptr]),
+    "tsgu_csr_mm_backward": (
+        _int,
+        [_int, _int, _i64, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _ptr, _i64, _i64, _ptr, _ptr, _i64,
+         _i64, _i64, _i64, _int, _ptr],
+    ),
+    "tsgu_wavetile_geometry": (_int, [_int, _i64, ctypes.POINTER(_int), ctypes.POINTER(_int), ctypes.POINTER(_int)]),
+    "tsgu_csr_spmm_wavetile": (
+        _int,
+        [_int, _int, _i64, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _ptr, _i64, _i64, _int, _ptr],
+    ),
+    "tsgu_csr_sddmm_wavetile": (
+        _int,
+        [_int, _int, _i64, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _ptr, _i64, _ptr, _dbl, _int, _i64,
+         _int, _ptr],
+    ),
     "tsgu_csr_sptrsm": (
         _int,
         [_int, _int, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _int, _int, _ptr, _i64, _ptr, _i64, _i64, _ptr, _int, _ptr],
@@ -217,6 +232,92 @@ def csr_sddmm(crow, col, G, B, n_rows: int, n_cols: int, alpha: float = 1.0, swa
                 p, batch, dev.index, _stream(dev),
             ),
             "tsgu_csr_sddmm",
+        )
+    return out
+
+
+def csr_mm_backward(tplan, val, G, B, n_rows: int, n_cols: int):
+    """(gradA values in A's order, gradB) in one pass over the transposed plan `tplan` of A."""
+    lib = load_library()
+    dev = require_device(tplan.crow, val, G, B)
+    if not (val.dtype == G.dtype == B.dtype):
+        raise RuntimeError("expected A, B and the upstream gradient to have the same dtype")
+    batched = G.dim() == 3
+    batch = G.size(0) if batched else 1
+    p = G.size(-1)
+    G, B = rowmajor(G), rowmajor(B)
+    val = val.contiguous()
+    gradA = torch.empty(val.shape, dtype=val.dtype, device=dev)
+    gradB = torch.empty(B.shape, dtype=B.dtype, device=dev)
+    with torch.cuda.device(dev):
+        check(
+            lib.tsgu_csr_mm_backward(
+                vtype_of(val), itype_of(tplan.crow), n_rows, n_cols, tplan.col.size(-1),
+                _p(tplan.crow), _p(tplan.col), _p(tplan.perm), _p(val),
+                _p(G), _ld(G), _bs(G), _p(B), _ld(B), _bs(B), _p(gradA), _p(gradB), _ld(gradB), _bs(gradB),
+                p, batch, dev.index, _stream(dev),
+            ),
+            "tsgu_csr_mm_backward",
+        )
+    return gradA, gradB
+
+
+def fused_backward_supported(dtype: torch.dtype, p: int) -> bool:
+    wide = {torch.float32: 4, torch.bfloat16: 8}.get(dtype)
+    if wide is None or p <= 0:
+        return False
+    vec = wide if p % wide == 0 else 1
+    return (p + vec - 1) // vec <= 64
+
+
+def tiled_geometry(dtype: torch.dtype, p: int):
+    """(rows_per_task, max_distinct, max_entries) of the wave-pipelined tiled kernels, or None."""
+    if dtype not in (torch.float32, torch.bfloat16) or p <= 0:
+        return None
+    lib = load_library()
+    rpt, mx, me = _int(0), _int(0), _int(0)
+    if lib.tsgu_wavetile_geometry(_VTYPE[dtype], p, ctypes.byref(rpt), ctypes.byref(mx), ctypes.byref(me)) != 0:
+        return None
+    return rpt.value, mx.value, me.value
+
+
+def _tiled_ok(*dense) -> bool:
+    return all(t.dim() == 2 and t.data_ptr() % 16 == 0 and (_ld(t) * t.element_size()) % 16 == 0 for t in dense)
+
+
+def csr_spmm_tiled(crow, val, tiles, B, n_rows: int, n_cols: int, perm=None):
+    """C = A·B through the wave-pipelined LDS-tiled kernel; `tiles` is a _pattern.TilePlan."""
+    lib = load_library()
+    dev = require_device(crow, val, B, perm)
+    B = rowmajor(B)
+    p = B.size(-1)
+    out = torch.empty((n_rows, p), dtype=B.dtype, device=dev)
+    with torch.cuda.device(dev):
+        check(
+            lib.tsgu_csr_spmm_wavetile(
+                vtype_of(val), itype_of(crow), n_rows, n_cols, tiles.nnz, _p(crow), _p(val), _p(perm),
+                _p(tiles.tmeta), _p(tiles.tile_cols), _p(tiles.lidx),
+                _p(B), _ld(B), _p(out), _ld(out), p, dev.index, _stream(dev),
+            ),
+            "tsgu_csr_spmm_wavetile",
+        )
+    return out
+
+
+def csr_sddmm_tiled(crow, tiles, G, B, n_rows: int, n_cols: int, alpha: float = 1.0, swap_roles: bool = False):
+    lib = load_library()
+    dev = require_device(crow, G, B)
+    G, B = rowmajor(G), rowmajor(B)
+    out = torch.empty((tiles.nnz,), dtype=G.dtype, device=dev)
+    with torch.cuda.device(dev):
+        check(
+            lib.tsgu_csr_sddmm_wavetile(
+                vtype_of(G), itype_of(crow), n_rows, n_cols, tiles.nnz, _p(crow),
+                _p(tiles.tmeta), _p(tiles.tile_cols), _p(tiles.lidx),
+                _p(G), _ld(G), _p(B), _ld(B), _p(out), float(alpha), int(bool(swap_roles)), G.size(-1),
+                dev.index, _stream(dev),
+            ),
+            "tsgu_csr_sddmm_wavetile",
         )
     return out
 

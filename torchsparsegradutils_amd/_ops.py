@@ -1,0 +1,41 @@
+"""Kernel selection for one sparse operand: LDS-tiled kernels when the pattern has column reuse
+inside row blocks (stencils, banded factors) and the operands qualify, plain gather kernels otherwise.
+Both produce the same values (same summation order); the choice is speed only."""
+
+from __future__ import annotations
+
+import torch
+
+from . import _backend as _be
+from ._pattern import RowGather
+
+
+ENABLE_TILED = False  # the single-buffered tiled kernels are slower than the gather kernels on gfx950
+
+
+def _tiles_for(plan: RowGather, dense: torch.Tensor, *others: torch.Tensor):
+    if not ENABLE_TILED or plan.batch is not None or dense.dim() != 2:
+        return None
+    geo = _be.tiled_geometry(dense.dtype, dense.size(-1))
+    if geo is None:
+        return None
+    if not _be._tiled_ok(*(_be.rowmajor(t) for t in (dense,) + others)):
+        return None
+    return plan.tiles(*geo)
+
+
+def spmm(plan: RowGather, values: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
+    """A·B for the operand described by (plan, values); perm-aware (transposed / un-coalesced plans)."""
+    tiles = _tiles_for(plan, B) if values.dtype == B.dtype else None
+    if tiles is not None:
+        return _be.csr_spmm_tiled(plan.crow, values, tiles, B, plan.n_rows, plan.n_cols, perm=plan.perm)
+    return _be.csr_spmm(plan.crow, plan.col, values, B, plan.n_rows, plan.n_cols, perm=plan.perm)
+
+
+def sddmm(plan: RowGather, G: torch.Tensor, B: torch.Tensor, alpha: float = 1.0, swap_roles: bool = False) -> torch.Tensor:
+    """alpha·<G[row k], B[col k]> (or roles swapped) at the plan's stored entries, in plan order."""
+    gathered = G if swap_roles else B
+    tiles = _tiles_for(plan, gathered, B if swap_roles else G) if G.dtype == B.dtype else None
+    if tiles is not None:
+        return _be.csr_sddmm_tiled(plan.crow, tiles, G, B, plan.n_rows, plan.n_cols, alpha=alpha, swap_roles=swap_roles)
+    return _be.csr_sddmm(plan.crow, plan.col, G, B, plan.n_rows, plan.n_cols, alpha=alpha, swap_roles=swap_roles)

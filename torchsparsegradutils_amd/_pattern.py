@@ -27,7 +27,7 @@ class RowGather:
     col, position of each entry in the owner's value array (None = identity).
     """
 
-    __slots__ = ("crow", "col", "perm", "n_rows", "n_cols", "batch", "_t", "_has_diag", "_rows")
+    __slots__ = ("crow", "col", "perm", "n_rows", "n_cols", "batch", "_t", "_has_diag", "_rows", "_tiles")
 
     def __init__(self, crow, col, n_rows, n_cols, perm=None):
         self.crow, self.col, self.perm = crow, col, perm
@@ -36,6 +36,15 @@ class RowGather:
         self._t: Optional[RowGather] = None
         self._has_diag: Optional[bool] = None
         self._rows = None
+        self._tiles = {}
+
+    def tiles(self, rows_per_task: int, max_distinct: int, max_entries: int):
+        """Plan for the wave-pipelined LDS-tiled kernels (None when the pattern does not qualify or
+        profit); cached per task height.  See `build_tile_plan`."""
+        key = (rows_per_task, max_distinct, max_entries)
+        if key not in self._tiles:
+            self._tiles[key] = build_tile_plan(self, rows_per_task, max_distinct, max_entries)
+        return self._tiles[key]
 
     @property
     def nnz(self) -> int:
@@ -66,6 +75,63 @@ class RowGather:
         if self._has_diag is None:
             self._has_diag = bool(torch.any(self.row_indices() == self.col))
         return self._has_diag
+
+
+class TilePlan:
+    """Per-task column dictionary consumed by tsgu_csr_*_wavetile (layout: include/tsgu_hip.h)."""
+
+    __slots__ = ("tmeta", "tile_cols", "lidx", "reuse", "max_distinct", "max_entries", "nnz")
+
+    def __init__(self, tmeta, tile_cols, lidx, reuse, max_distinct, max_entries, nnz):
+        self.tmeta, self.tile_cols, self.lidx = tmeta, tile_cols, lidx
+        self.reuse, self.max_distinct, self.max_entries, self.nnz = reuse, max_distinct, max_entries, nnz
+
+
+_TILE_MIN_REUSE = 1.5   # average entries per distinct column inside a task
+_TILE_MAX_PADDING = 2.0  # padded / real size of the per-task tables
+
+
+def build_tile_plan(g: RowGather, rows_per_task: int, cap_distinct: int, cap_entries: int):
+    """Distinct columns per task of `rows_per_task` consecutive rows + 8-bit local indices, in the
+    fixed-stride, 16-byte aligned layout the wave-pipelined kernels load with wide accesses.
+
+    One sort of (task, column) keys per pattern (tens of ms at 27e6 entries), amortised over every
+    later forward/backward on the same pattern.  Returns None when a task exceeds the kernel limits,
+    the pattern has too little column reuse, or padding would waste memory (ragged patterns)."""
+    if g.batch is not None or g.n_rows == 0 or not (4 <= g.nnz < 2**31):
+        return None
+    n, m, nnz = g.n_rows, g.n_cols, g.nnz
+    dev = g.crow.device
+    ntask = (n + rows_per_task - 1) // rows_per_task
+    e0 = g.crow[torch.arange(0, n, rows_per_task, device=dev)].to(torch.int64)
+    ne = torch.cat((e0[1:], g.crow[-1:].to(torch.int64))) - e0
+    if int(ne.max()) > cap_entries or ntask * cap_entries > _TILE_MAX_PADDING * nnz:
+        return None
+    task = g.row_indices().to(torch.int64) // rows_per_task
+    key = task * m + g.col.to(torch.int64)
+    uniq, inv = torch.unique(key, return_inverse=True)
+    total = uniq.numel()
+    reuse = nnz / max(total, 1)
+    if reuse < _TILE_MIN_REUSE:
+        return None
+    utask = uniq // m
+    cnt = torch.bincount(utask, minlength=ntask)
+    top = int(cnt.max())
+    if top > cap_distinct or top > 256 or ntask * cap_distinct > _TILE_MAX_PADDING * total:
+        return None
+    first = torch.cumsum(cnt, 0) - cnt                       # start of each task's run in `uniq`
+    # padded column table: position d of task t reads uniq[first[t] + min(d, cnt[t]-1)]
+    d = torch.arange(cap_distinct, device=dev).unsqueeze(0)
+    src = first.unsqueeze(1) + torch.minimum(d, (cnt - 1).clamp_min(0).unsqueeze(1))
+    cols = (uniq - utask * m).to(torch.int32)
+    tile_cols = cols[src.clamp_max(total - 1)].contiguous()  # (ntask, cap_distinct)
+    # padded local-index table: entry e of task t (task order) -> position inside the task's run
+    local = (inv - first[task]).to(torch.uint8)
+    pos = torch.arange(nnz, device=dev, dtype=torch.int64) - e0[task]
+    lidx = torch.zeros((ntask, cap_entries), dtype=torch.uint8, device=dev)
+    lidx[task, pos] = local
+    tmeta = torch.stack((e0, ne), dim=1).to(torch.int32).contiguous()
+    return TilePlan(tmeta, tile_cols, lidx, reuse, top, int(ne.max()), nnz)
 
 
 def _transpose(g: RowGather) -> RowGather:

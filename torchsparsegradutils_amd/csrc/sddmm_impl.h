@@ -29,9 +29,7 @@ struct SddmmParams {
 
 template <typename Acc, int CL>
 __device__ __forceinline__ Acc reduce_cl(Acc x) {
-#pragma unroll
-    for (int m = 1; m < CL; m <<= 1) x += shfl_xor_acc(x, m);
-    return x;
+    return group_sum<Acc, CL>(x);
 }
 
 template <typename V, typename I, int VEC, int CL, int EP>
@@ -80,11 +78,24 @@ __global__ __launch_bounds__(kBlock) void csr_sddmm_kernel(const SddmmParams P) 
     if (row_ok && lane_ok0) load_vec<V, VEC>(R + row * P.ldr + c0, r0);
 
     const Acc alpha = (Acc)P.alpha;
+    const uint32_t ldc = (uint32_t)P.ldc;
 
     for (int64_t cs = blk_begin; cs < blk_end; cs += kSddmmCap) {
         const int64_t ce = cs + kSddmmCap < blk_end ? cs + kSddmmCap : blk_end;
         if (cs != blk_begin) __syncthreads();
-        for (int64_t k = cs + tid; k < ce; k += kBlock) s_col[k - cs] = (int)col[k];
+        for (int64_t base = cs + tid; base < ce; base += (int64_t)kBlock * 4) {
+            I cj[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t k = base + (int64_t)u * kBlock;
+                cj[u] = k < ce ? col[k] : (I)0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t k = base + (int64_t)u * kBlock;
+                if (k < ce) s_col[k - cs] = (int)cj[u];
+            }
+        }
         __syncthreads();
 
         const int64_t lo = start > cs ? start : cs;
@@ -93,21 +104,24 @@ __global__ __launch_bounds__(kBlock) void csr_sddmm_kernel(const SddmmParams P) 
         const int iend = (int)(hi - cs);
 
         if (single_tile) {
+            // Lanes whose columns lie beyond p (p not a multiple of CL·VEC) read columns 0.. instead
+            // and their partial is discarded: every load stays unconditional, so the U gathers of a
+            // pass are all in flight together.
+            const int64_t cc = lane_ok0 ? c0 : 0;
             for (; i + (U - 1) * EP < iend; i += U * EP) {
                 Acc b[U][VEC];
                 Acc d[U];
+                int j[U];
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int j = s_col[i + u * EP];
+                for (int u = 0; u < U; ++u) j[u] = s_col[i + u * EP];
 #pragma unroll
-                    for (int v = 0; v < VEC; ++v) b[u][v] = 0;
-                    if (lane_ok0) load_vec<V, VEC>(Cm + (int64_t)j * P.ldc + c0, b[u]);
-                }
+                for (int u = 0; u < U; ++u) load_vec<V, VEC>(Cm + row_off(j[u], ldc) + cc, b[u]);
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     d[u] = 0;
 #pragma unroll
                     for (int v = 0; v < VEC; ++v) d[u] = fma(r0[v], b[u][v], d[u]);
+                    d[u] = lane_ok0 ? d[u] : (Acc)0;
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u) d[u] = reduce_cl<Acc, CL>(d[u]);
@@ -118,13 +132,12 @@ __global__ __launch_bounds__(kBlock) void csr_sddmm_kernel(const SddmmParams P) 
             }
             for (; i < iend; i += EP) {
                 Acc b[VEC];
-#pragma unroll
-                for (int v = 0; v < VEC; ++v) b[v] = 0;
                 const int j = s_col[i];
-                if (lane_ok0) load_vec<V, VEC>(Cm + (int64_t)j * P.ldc + c0, b);
+                load_vec<V, VEC>(Cm + row_off(j, ldc) + cc, b);
                 Acc d = 0;
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) d = fma(r0[v], b[v], d);
+                d = lane_ok0 ? d : (Acc)0;
                 d = reduce_cl<Acc, CL>(d);
                 if (cl == 0) s_out[i] = d;
             }
@@ -139,7 +152,7 @@ __global__ __launch_bounds__(kBlock) void csr_sddmm_kernel(const SddmmParams P) 
                     if (c < P.p) {
                         Acc rr[VEC], b[VEC];
                         load_vec<V, VEC>(R + row * P.ldr + c, rr);
-                        load_vec<V, VEC>(Cm + (int64_t)j * P.ldc + c, b);
+                        load_vec<V, VEC>(Cm + row_off(j, ldc) + c, b);
 #pragma unroll
                         for (int v = 0; v < VEC; ++v) d = fma(rr[v], b[v], d);
                     }
@@ -211,7 +224,7 @@ int sddmm_launch(SddmmParams P, int64_t batch, hipStream_t stream) {
     const int64_t rpb = kBlock / (g.cl * g.ep);
     P.nblocks = (P.n_rows + rpb - 1) / rpb;
     P.col_tiles = g.col_tiles;
-    if (P.nblocks > 0x7fffffffLL || batch > 65535) return TSGU_ERR_TOO_LARGE;
+    if (P.nblocks > 0x7fffffffLL || batch > 65535 || P.ldc > 0xffffffffLL) return TSGU_ERR_TOO_LARGE;
     const dim3 grid((unsigned)P.nblocks, (unsigned)batch, 1);
     return dispatch_geom(g, [&](auto cl, auto ep) -> int {
         constexpr int CL = decltype(cl)::value, EP = decltype(ep)::value;

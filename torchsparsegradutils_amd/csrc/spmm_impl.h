@@ -70,12 +70,16 @@ struct Staged<V, false> {
     }
 };
 
-template <typename V, typename I, int VEC, int CL, int EP, bool DOT>
+template <typename V, typename I, int VEC, int CL, int EP, bool DOT, bool PERM>
 __global__ __launch_bounds__(kBlock) void csr_spmm_kernel(const SpmmParams P) {
     using Acc = typename VT<V>::Acc;
     constexpr int GROUP = CL * EP;
     constexpr int RPB = kBlock / GROUP;
-    constexpr int U = 4;  // gathers issued back to back per lane
+#ifndef TSGU_SPMM_U
+#define TSGU_SPMM_U 4
+#endif
+    constexpr int U = TSGU_SPMM_U;  // gathers issued back to back per lane
+    constexpr int SU = 4;  // staging loads issued back to back per thread
 
     __shared__ __attribute__((aligned(16))) unsigned char smem[StageBytes<V>::value];
     const Staged<V> stage(smem);
@@ -96,6 +100,7 @@ __global__ __launch_bounds__(kBlock) void csr_spmm_kernel(const SpmmParams P) {
     const V* __restrict__ val = static_cast<const V*>(P.val) + item * P.nnz_per_item;
     const I* __restrict__ perm = static_cast<const I*>(P.perm);
     const V* __restrict__ B = static_cast<const V*>(P.B) + item * P.b_bs + cbase;
+    const uint32_t ldb = (uint32_t)P.ldb;
 
     const int64_t row0 = vb * RPB;
     const int64_t row1 = row0 + RPB < P.n_rows ? row0 + RPB : P.n_rows;
@@ -114,9 +119,30 @@ __global__ __launch_bounds__(kBlock) void csr_spmm_kernel(const SpmmParams P) {
     for (int64_t cs = blk_begin; cs < blk_end; cs += kStageCap) {
         const int64_t ce = cs + kStageCap < blk_end ? cs + kStageCap : blk_end;
         if (cs != blk_begin) __syncthreads();
-        for (int64_t k = cs + tid; k < ce; k += kBlock) {
-            const int64_t q = perm ? (int64_t)perm[item * P.nnz_per_item + k] : k;
-            stage.put((int)(k - cs), (int)col[k], val[q]);
+        // stage the (col, val) slice: all loads of a pass are issued before the first LDS write, so a
+        // workgroup pays one memory round trip per SU·256 entries (two with the value indirection).
+        for (int64_t base = cs + tid; base < ce; base += (int64_t)kBlock * SU) {
+            I cj[SU];
+            V vv[SU];
+            int64_t q[SU];
+#pragma unroll
+            for (int u = 0; u < SU; ++u) {
+                const int64_t k = base + (int64_t)u * kBlock;
+                const bool ok = k < ce;
+                cj[u] = ok ? stream_load(col + k) : (I)0;
+                if constexpr (PERM) q[u] = ok ? (int64_t)stream_load(perm + item * P.nnz_per_item + k) : 0;
+                else q[u] = ok ? k : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < SU; ++u) {
+                if constexpr (PERM) vv[u] = val[q[u]];  // gathered: keep cacheable
+                else vv[u] = stream_load(val + q[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < SU; ++u) {
+                const int64_t k = base + (int64_t)u * kBlock;
+                if (k < ce) stage.put((int)(k - cs), (int)cj[u], vv[u]);
+            }
         }
         __syncthreads();
 
@@ -132,7 +158,7 @@ __global__ __launch_bounds__(kBlock) void csr_spmm_kernel(const SpmmParams P) {
 #pragma unroll
                 for (int u = 0; u < U; ++u) stage.get(i + u * EP, j[u], a[u]);
 #pragma unroll
-                for (int u = 0; u < U; ++u) load_vec<V, VEC>(B + (int64_t)j[u] * P.ldb, b[u]);
+                for (int u = 0; u < U; ++u) load_vec<V, VEC>(B + row_off(j[u], ldb), b[u]);
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
 #pragma unroll
@@ -144,7 +170,7 @@ __global__ __launch_bounds__(kBlock) void csr_spmm_kernel(const SpmmParams P) {
                 Acc a;
                 Acc b[VEC];
                 stage.get(i, j, a);
-                load_vec<V, VEC>(B + (int64_t)j * P.ldb, b);
+                load_vec<V, VEC>(B + row_off(j, ldb), b);
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) acc[v] = fma(a, b[v], acc[v]);
             }
@@ -161,7 +187,7 @@ __global__ __launch_bounds__(kBlock) void csr_spmm_kernel(const SpmmParams P) {
 
     if (row_ok && col_ok && ep == 0) {
         V* __restrict__ C = static_cast<V*>(P.C) + item * P.c_bs + row * P.ldc + cbase;
-        store_vec<V, VEC>(C, acc);
+        store_vec<V, VEC, true>(C, acc);
     }
 
     if constexpr (DOT) {
@@ -213,20 +239,24 @@ int spmm_launch(SpmmParams P, int64_t batch, hipStream_t stream) {
     // the partial buffer is sized by tsgu_spmm_num_blocks(), which assumes the 16-byte geometry
     // whenever p allows it: refuse operands that would silently fall back to scalar lanes.
     if (dot && (P.p % VT<V>::kWide == 0) && g.vec == 1) return TSGU_ERR_BAD_ARG;
+    const bool has_perm = P.perm != nullptr;
+    if (dot && has_perm) return TSGU_ERR_BAD_ARG;
+    if (P.ldb > 0xffffffffLL) return TSGU_ERR_TOO_LARGE;
     return dispatch_geom(g, [&](auto cl, auto ep) -> int {
         constexpr int CL = decltype(cl)::value, EP = decltype(ep)::value;
         constexpr int W = VT<V>::kWide;
+#define TSGU_SPMM_GO(VECW, DOTF, PERMF) \
+    hipLaunchKernelGGL((csr_spmm_kernel<V, I, VECW, CL, EP, DOTF, PERMF>), grid, dim3(kBlock), 0, stream, P)
         if (g.vec == 1) {
-            if (dot)
-                hipLaunchKernelGGL((csr_spmm_kernel<V, I, 1, CL, EP, true>), grid, dim3(kBlock), 0, stream, P);
-            else
-                hipLaunchKernelGGL((csr_spmm_kernel<V, I, 1, CL, EP, false>), grid, dim3(kBlock), 0, stream, P);
+            if (dot) TSGU_SPMM_GO(1, true, false);
+            else if (has_perm) TSGU_SPMM_GO(1, false, true);
+            else TSGU_SPMM_GO(1, false, false);
         } else {
-            if (dot)
-                hipLaunchKernelGGL((csr_spmm_kernel<V, I, W, CL, EP, true>), grid, dim3(kBlock), 0, stream, P);
-            else
-                hipLaunchKernelGGL((csr_spmm_kernel<V, I, W, CL, EP, false>), grid, dim3(kBlock), 0, stream, P);
+            if (dot) TSGU_SPMM_GO(W, true, false);
+            else if (has_perm) TSGU_SPMM_GO(W, false, true);
+            else TSGU_SPMM_GO(W, false, false);
         }
+#undef TSGU_SPMM_GO
         return check_launch();
     });
 }

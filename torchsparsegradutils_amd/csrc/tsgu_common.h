@@ -63,6 +63,43 @@ __device__ __forceinline__ int64_t xcd_chunked_block(int64_t bid, int64_t nblock
     return x * q + (x < r ? x : r) + l;
 }
 
+// ---- streaming (non-temporal) accesses --------------------------------------------------
+// Data that is touched exactly once (the col/val stream, the output rows) is loaded/stored with
+// the `nt` policy so that it does not evict the gathered RHS rows, which are the only operand
+// with reuse, from the 4 MiB per-XCD L2.
+#ifndef TSGU_NT_STAGE
+#define TSGU_NT_STAGE 1
+#endif
+#ifndef TSGU_NT_STORE
+#define TSGU_NT_STORE 1
+#endif
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+
+template <typename T>
+__device__ __forceinline__ T stream_load(const T* p) {
+#if TSGU_NT_STAGE
+    if constexpr (sizeof(T) == 2) {
+        const unsigned short b = __builtin_nontemporal_load(reinterpret_cast<const unsigned short*>(p));
+        T r;
+        __builtin_memcpy(&r, &b, 2);
+        return r;
+    } else {
+        return __builtin_nontemporal_load(p);
+    }
+#else
+    return *p;
+#endif
+}
+
+__device__ __forceinline__ void stream_store16(void* ptr, uint4 raw) {
+#if TSGU_NT_STORE
+    u32x4_t v = {raw.x, raw.y, raw.z, raw.w};
+    __builtin_nontemporal_store(v, reinterpret_cast<u32x4_t*>(ptr));
+#else
+    *reinterpret_cast<uint4*>(ptr) = raw;
+#endif
+}
+
 // ---- VEC-element loads/stores of value type V into accumulator registers ------------
 template <typename V, int VEC>
 __device__ __forceinline__ void load_vec(const V* __restrict__ ptr, typename VT<V>::Acc (&out)[VEC]) {
@@ -90,7 +127,7 @@ __device__ __forceinline__ void load_vec(const V* __restrict__ ptr, typename VT<
     }
 }
 
-template <typename V, int VEC>
+template <typename V, int VEC, bool STREAM = false>
 __device__ __forceinline__ void store_vec(V* __restrict__ ptr, const typename VT<V>::Acc (&in)[VEC]) {
     if constexpr (VEC == 1) {
         *ptr = VT<V>::down(in[0]);
@@ -117,8 +154,43 @@ __device__ __forceinline__ void store_vec(V* __restrict__ ptr, const typename VT
             raw.z = w[2];
             raw.w = w[3];
         }
-        *reinterpret_cast<uint4*>(ptr) = raw;
+        if constexpr (STREAM) stream_store16(ptr, raw);
+        else *reinterpret_cast<uint4*>(ptr) = raw;
     }
+}
+
+// Offset (in elements) of dense row j with a leading dimension < 2^32: one v_mad_u64_u32.
+__device__ __forceinline__ uint64_t row_off(int j, uint32_t ld) { return (uint64_t)(uint32_t)j * ld; }
+
+// ---- cross-lane sums inside an aligned group of CL lanes (CL <= 16: DPP, no LDS traffic) ----
+// DPP controls: quad_perm [1,0,3,2] = 0xB1, quad_perm [2,3,0,1] = 0x4E, row_half_mirror = 0x141
+// (lane i <-> 7-i of each 8), row_mirror = 0x140 (lane i <-> 15-i of each 16).  After each step
+// both partners hold the same partial sum, so the sequence is an all-reduce over the group.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double x) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float x) { return dpp_f32<CTRL>(x); }
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double x) { return dpp_f64<CTRL>(x); }
+
+template <typename Acc, int CL>
+__device__ __forceinline__ Acc group_sum(Acc x) {
+    static_assert(CL >= 1 && CL <= 64 && (CL & (CL - 1)) == 0, "CL must be a power of two");
+    if constexpr (CL >= 2) x += dpp_move<0xB1>(x);
+    if constexpr (CL >= 4) x += dpp_move<0x4E>(x);
+    if constexpr (CL >= 8) x += dpp_move<0x141>(x);
+    if constexpr (CL >= 16) x += dpp_move<0x140>(x);
+    if constexpr (CL >= 32) x += __shfl_xor(x, 16, 64);
+    if constexpr (CL >= 64) x += __shfl_xor(x, 32, 64);
+    return x;
 }
 
 // xor-shuffle for float / double accumulators (all 64 lanes participate)

@@ -23,6 +23,7 @@ from typing import cast
 import torch
 
 from . import _backend as _be
+from . import _ops
 from . import _pattern as _pt
 
 
@@ -111,7 +112,9 @@ class SparseMatMul(torch.autograd.Function):
             Bk = B.reshape(-1, B.size(-1))
         else:
             Bk = B
-        x = _be.csr_spmm(plan.crow, plan.col, op.values, Bk, plan.n_rows, plan.n_cols, perm=plan.perm)
+        if A.dtype != B.dtype:
+            raise RuntimeError(f"expected A and B to have the same dtype, got {A.dtype} and {B.dtype}")
+        x = _ops.spmm(plan, op.values, Bk)
         if op.flat_batch is not None:
             x = x.view(ctx.batch_size, ctx.A_shape[-2], ctx.B_shape[-1])
 
@@ -129,18 +132,27 @@ class SparseMatMul(torch.autograd.Function):
 
         G = grad.reshape(-1, grad.size(-1)) if op.flat_batch is not None else grad
 
-        if ctx.needs_input_grad[0]:
+        need_a, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        if (need_a and need_b and plan.perm is None and G.dtype == B.dtype == values.dtype
+                and _be.fused_backward_supported(G.dtype, G.size(-1))):
+            # both gradients in one pass: each upstream row G[i,:] is gathered once (reference :172-229)
+            gvals, gradB = _be.csr_mm_backward(plan.transposed, values, G, B, plan.n_rows, plan.n_cols)
+            gradA = op.rebuild(gvals)
+            if ctx.batch_size is not None:
+                gradB = gradB.view(ctx.B_shape)
+            return gradA, gradB
+
+        if need_a:
             # gradA[k] = <G[row k,:], B[col k,:]> at A's stored entries only (reference :172-205)
             if plan.perm is None:
-                gvals = _be.csr_sddmm(plan.crow, plan.col, G, B, plan.n_rows, plan.n_cols)
+                gvals = _ops.sddmm(plan, G, B)
             else:  # un-coalesced COO: one gradient entry per stored duplicate, in A's own order
                 gvals = _be.coo_sddmm(op.indices[0], op.indices[1], G, B)
             gradA = op.rebuild(gvals)
 
-        if ctx.needs_input_grad[1]:
+        if need_b:
             # gradB = Aᵀ·G as a gather over the cached transposed pattern (reference :229)
-            pt = plan.transposed
-            gradB = _be.csr_spmm(pt.crow, pt.col, values, G, pt.n_rows, pt.n_cols, perm=pt.perm)
+            gradB = _ops.spmm(plan.transposed, values, G)
             if ctx.batch_size is not None:
                 gradB = gradB.view(ctx.B_shape)
 

@@ -19,6 +19,7 @@ from typing import Callable, Optional, cast
 import torch
 
 from . import _backend as _be
+from . import _ops
 from . import _pattern as _pt
 from .utils.utils import convert_coo_to_csr  # noqa: F401  (re-export parity with the reference module)
 
@@ -150,9 +151,7 @@ class SparseTriangularSolve(torch.autograd.Function):
             raise ValueError("First input should be strictly triangular (i.e. unit diagonals is implicit)")
 
         # gradA[k] = -<gradB[i,:], x[j,:]>, roles swapped for the transposed solve (reference :223-235)
-        gvals = _be.csr_sddmm(
-            plan.crow, plan.col, gradB, x, plan.n_rows, plan.n_cols, alpha=-1.0, swap_roles=bool(ctx.transpose)
-        )
+        gvals = _ops.sddmm(plan, gradB, x, alpha=-1.0, swap_roles=bool(ctx.transpose))
         if plan.perm is not None:  # cannot happen for coalesced inputs; kept for safety
             out = torch.empty_like(gvals)
             out[plan.perm] = gvals
@@ -223,7 +222,7 @@ class _MaskedOuter(torch.autograd.Function):
     def forward(ctx, G, X, plan, alpha):
         ctx.plan, ctx.alpha = plan, alpha
         ctx.save_for_backward(G, X)
-        return _be.csr_sddmm(plan.crow, plan.col, G.detach(), X.detach(), plan.n_rows, plan.n_cols, alpha=alpha)
+        return _ops.sddmm(plan, G.detach(), X.detach(), alpha=alpha)
 
     @staticmethod
     def backward(ctx, gout):  # type: ignore[override]
@@ -232,10 +231,9 @@ class _MaskedOuter(torch.autograd.Function):
         w = (gout * ctx.alpha).contiguous()
         dG = dX = None
         if ctx.needs_input_grad[0]:  # dG[i,:] = Σ_k∈row i w[k]·X[col k,:]
-            dG = _be.csr_spmm(plan.crow, plan.col, w, X.detach(), plan.n_rows, plan.n_cols)
+            dG = _ops.spmm(plan, w, X.detach())
         if ctx.needs_input_grad[1]:  # dX[j,:] = Σ_k: col k = j  w[k]·G[row k,:]
-            pt = plan.transposed
-            dX = _be.csr_spmm(pt.crow, pt.col, w, G.detach(), pt.n_rows, pt.n_cols, perm=pt.perm)
+            dX = _ops.spmm(plan.transposed, w, G.detach())
         return dG, dX, None, None
 
 

@@ -10,6 +10,7 @@ from __future__ import annotations
 import torch
 
 from .. import _backend as _be
+from .. import _ops
 from .. import _pattern as _pt
 
 
@@ -39,8 +40,8 @@ class SparseOperator:
         v = self._cast(v)
         p = self.plan
         if v.dim() == 1:
-            return _be.csr_spmm(p.crow, p.col, self.values, v.unsqueeze(-1), p.n_rows, p.n_cols, perm=p.perm).squeeze(-1)
-        return _be.csr_spmm(p.crow, p.col, self.values, v, p.n_rows, p.n_cols, perm=p.perm)
+            return _ops.spmm(p, self.values, v.unsqueeze(-1)).squeeze(-1)
+        return _ops.spmm(p, self.values, v)
 
     matmul = __call__
 
