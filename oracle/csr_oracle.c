@@ -137,4 +137,25 @@
 DEFINE_ALL(float, f32)
 DEFINE_ALL(double, f64)
 
+/* Number of dependency levels of a lower (upper=0) or upper (upper=1) triangular CSR pattern:
+   level(i) = 1 + max level of the rows it depends on.  Used to characterise K4 test/bench matrices
+   (a level-scheduled solver would need this many grid barriers). */
+int64_t oracle_csr_levels(int64_t n, const int64_t* crow, const int64_t* col, int upper) {
+    int64_t* lvl = (int64_t*)calloc((size_t)(n > 0 ? n : 1), sizeof(int64_t));
+    int64_t top = 0;
+    if (!lvl) return -1;
+    for (int64_t s = 0; s < n; ++s) {
+        const int64_t i = upper ? n - 1 - s : s;
+        int64_t l = 0;
+        for (int64_t k = crow[i]; k < crow[i + 1]; ++k) {
+            const int64_t j = col[k];
+            if ((upper ? j > i : j < i) && lvl[j] > l) l = lvl[j];
+        }
+        lvl[i] = l + 1;
+        if (lvl[i] > top) top = lvl[i];
+    }
+    free(lvl);
+    return top;
+}
+
 int oracle_abi_version(void) { return 1; }

@@ -130,6 +130,14 @@ def csr_sptrsm(crow, col, val, B, upper, unit=False, transpose=False):
     return X
 
 
+def csr_levels(crow, col, upper=False):
+    """Dependency levels of a triangular pattern (what a level-scheduled solve would barrier on)."""
+    crow, col = _i64(crow), _i64(col)
+    fn = _load().oracle_csr_levels
+    fn.restype = ctypes.c_int64
+    return int(fn(I64(crow.size - 1), _ptr(crow), _ptr(col), int(upper)))
+
+
 def expand_rows(crow):
     """repeat_interleave(arange(n), diff(crow)) (reference sparse_matmul.py:190-192)."""
     crow = _i64(crow)
