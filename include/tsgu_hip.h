@@ -195,7 +195,10 @@ int64_t tsgu_sptrsm_work_bytes(int64_t n, int64_t p);
  * step 4  tsgu_cg_update2: pvec = r + beta·pvec
  * Every step is a no-op once flags[0] != 0, so a host may enqueue iterations ahead and poll.
  */
-int tsgu_cg_alpha(int vtype, const void* pap_partial, int64_t n_partial, void* scal, int* flags,
+/* `fold` (optional): scratch of tsgu_cg_fold_rows() * p elements; when given and n_partial is large the
+ * partial rows are first folded (deterministically) to that many rows by a wide launch. */
+int64_t tsgu_cg_fold_rows(void);
+int tsgu_cg_alpha(int vtype, const void* pap_partial, int64_t n_partial, void* fold, void* scal, int* flags,
                   double eps, int64_t p, int device, void* stream);
 int tsgu_cg_update1(int vtype, int64_t n, int64_t p,
                     void* r, const void* Ap, void* x, const void* pvec,

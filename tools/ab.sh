@@ -1,1 +1,2 @@
-python bench.py --steps 30 --warmup 5 --no-cpu-baseline 2>&1 | tail -1
+python -m pytest tests -m gpu -x -q --timeout 300 2>&1 | tail -3
+python bench_configs.py --only c4,c5 --no-cpu 2>&1 | grep -vE "Warn|warn|amdgpu.ids|sparse_csr_tensor"

@@ -69,7 +69,8 @@ SIGNATURES = {
         [_int, _int, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _int, _int, _ptr, _i64, _ptr, _i64, _i64, _ptr, _int, _ptr],
     ),
     "tsgu_sptrsm_work_bytes": (_i64, [_i64, _i64]),
-    "tsgu_cg_alpha": (_int, [_int, _ptr, _i64, _ptr, _ptr, _dbl, _i64, _int, _ptr]),
+    "tsgu_cg_fold_rows": (_i64, []),
+    "tsgu_cg_alpha": (_int, [_int, _ptr, _i64, _ptr, _ptr, _ptr, _dbl, _i64, _int, _ptr]),
     "tsgu_cg_update1": (_int, [_int, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _int, _ptr]),
     "tsgu_cg_num_blocks": (_i64, [_int, _i64, _i64]),
     "tsgu_cg_beta": (_int, [_int, _ptr, _i64, _ptr, _ptr, _dbl, _dbl, _dbl, _int, _int, _i64, _int, _ptr]),

@@ -156,10 +156,7 @@ __global__ __launch_bounds__(kBlock) void csr_mm_backward_kernel(const BwdParams
 
     if constexpr (EP > 1) {
 #pragma unroll
-        for (int m = CL; m < GROUP; m <<= 1) {
-#pragma unroll
-            for (int v = 0; v < VEC; ++v) acc[v] += shfl_xor_acc(acc[v], m);
-        }
+        for (int v = 0; v < VEC; ++v) acc[v] = ep_sum<Acc, CL, EP>(acc[v]);
     }
     if (row_ok && col_ok && ep == 0) {
         V* __restrict__ O = static_cast<V*>(P.gradB) + item * P.o_bs + row * P.ldo + c0;

@@ -98,6 +98,26 @@ __global__ __launch_bounds__(kBlock) void colsum_finalize_kernel(const V* __rest
     if ((int)threadIdx.x < w) out[c0 + threadIdx.x] = tot;
 }
 
+// First level of a three-stage column sum: `rows` partial rows -> kFoldRows rows (block b sums the
+// contiguous slice of rows [b*chunk, (b+1)*chunk) in row order).  Keeps the single-block finalisers
+// (which need all columns at once) short when a kernel produced tens of thousands of partials.
+constexpr int kFoldRows = 256;
+
+template <typename V>
+__global__ __launch_bounds__(kBlock) void colsum_fold_kernel(const V* __restrict__ partial, int64_t rows, int64_t p,
+                                                             int64_t chunk, V* __restrict__ out, const int* __restrict__ flags) {
+    __shared__ V red[kBlock];
+    if (flags && flags[0] != 0) return;
+    const int64_t r0 = (int64_t)blockIdx.x * chunk;
+    int64_t r1 = r0 + chunk;
+    r1 = r1 < rows ? r1 : rows;
+    for (int64_t c0 = 0; c0 < p; c0 += 64) {
+        const int w = (int)(p - c0 < 64 ? p - c0 : 64);
+        const V tot = r0 < r1 ? block_colsum<V>(partial + r0 * p, r1 - r0, p, c0, w, red) : (V)0;
+        if ((int)threadIdx.x < w) out[(int64_t)blockIdx.x * p + c0 + threadIdx.x] = tot;
+    }
+}
+
 // ---- CG ---------------------------------------------------------------------------------
 // scal: [rr | alpha | beta | rnorm] each [p];  flags: [done, iters, has_converged[p], rhs_is_zero[p]]
 template <typename V>
@@ -260,6 +280,8 @@ using namespace tsgu;
 
 extern "C" {
 
+int64_t tsgu_cg_fold_rows(void) { return kFoldRows; }
+
 int64_t tsgu_cg_num_blocks(int vtype, int64_t n, int64_t p) {
     // exact block count of tsgu_cg_update1 (operands must be 16-byte aligned, contiguous)
     VecGeom g;
@@ -302,15 +324,27 @@ int tsgu_coldot(int vtype, int64_t n, int64_t p, const void* X, int64_t ldx, con
     return TSGU_OK;
 }
 
-int tsgu_cg_alpha(int vtype, const void* pap_partial, int64_t n_partial, void* scal, int* flags, double eps,
-                  int64_t p, int device, void* stream) {
+int tsgu_cg_alpha(int vtype, const void* pap_partial, int64_t n_partial, void* fold, void* scal, int* flags,
+                  double eps, int64_t p, int device, void* stream) {
     if (!pap_partial || !scal || !flags || p <= 0 || n_partial < 0) return TSGU_ERR_BAD_ARG;
     if (const int rc = set_device(device)) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    // many partial rows (one per K1 workgroup): fold them to kFoldRows rows first (needs `fold`)
+    const bool do_fold = fold != nullptr && n_partial > 4 * kFoldRows;
+    const int64_t chunk = (n_partial + kFoldRows - 1) / kFoldRows;
 #define TSGU_BODY                                                                                              \
     {                                                                                                          \
-        hipLaunchKernelGGL((cg_alpha_kernel<V>), dim3((unsigned)((p + 63) / 64)), dim3(kBlock), 0, s,           \
-                           (const V*)pap_partial, n_partial, p, (V*)scal, (const int*)flags, (V)eps);          \
+        const V* src = (const V*)pap_partial;                                                                  \
+        int64_t rows = n_partial;                                                                              \
+        if (do_fold) {                                                                                         \
+            hipLaunchKernelGGL((colsum_fold_kernel<V>), dim3(kFoldRows), dim3(kBlock), 0, s, src, n_partial, p, \
+                               chunk, (V*)fold, (const int*)flags);                                            \
+            if (const int rc = check_launch()) return rc;                                                      \
+            src = (const V*)fold;                                                                              \
+            rows = kFoldRows;                                                                                  \
+        }                                                                                                      \
+        hipLaunchKernelGGL((cg_alpha_kernel<V>), dim3((unsigned)((p + 63) / 64)), dim3(kBlock), 0, s, src,      \
+                           rows, p, (V*)scal, (const int*)flags, (V)eps);                                      \
         return check_launch();                                                                                 \
     }
     TSGU_VSWITCH(vtype, TSGU_BODY, TSGU_BODY);

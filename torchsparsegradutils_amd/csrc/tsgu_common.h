@@ -193,6 +193,25 @@ __device__ __forceinline__ Acc group_sum(Acc x) {
     return x;
 }
 
+// Sum over the EP entry-lanes of a row group (lanes cl + CL*e, e < EP): xor strides CL, 2CL, ... below
+// CL*EP.  The geometries in use have 8-lane groups ((CL,EP) = (1,8), (2,4), (4,2)): strides 1 and 2 are
+// quad permutes, stride 4 is half-mirror followed by a quad reversal (i -> 7-i -> i^4); no LDS traffic.
+template <typename Acc, int CL, int EP>
+__device__ __forceinline__ Acc ep_sum(Acc x) {
+    if constexpr (EP == 1) {
+        return x;
+    } else if constexpr (CL * EP == 8) {
+        if constexpr (CL == 1) x += dpp_move<0xB1>(x);
+        if constexpr (CL <= 2) x += dpp_move<0x4E>(x);
+        x += dpp_move<0x1B>(dpp_move<0x141>(x));
+        return x;
+    } else {
+#pragma unroll
+        for (int m = CL; m < CL * EP; m <<= 1) x += __shfl_xor(x, m, 64);
+        return x;
+    }
+}
+
 // xor-shuffle for float / double accumulators (all 64 lanes participate)
 __device__ __forceinline__ float shfl_xor_acc(float v, int mask) { return __shfl_xor(v, mask, kWave); }
 __device__ __forceinline__ double shfl_xor_acc(double v, int mask) { return __shfl_xor(v, mask, kWave); }

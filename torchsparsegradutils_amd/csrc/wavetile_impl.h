@@ -281,10 +281,7 @@ struct WtCtx {
         } else {
             if constexpr (EP > 1) {
 #pragma unroll
-                for (int m = CL; m < GROUP; m <<= 1) {
-#pragma unroll
-                    for (int v = 0; v < VEC; ++v) acc[v] += shfl_xor_acc(acc[v], m);
-                }
+                for (int v = 0; v < VEC; ++v) acc[v] = ep_sum<float, CL, EP>(acc[v]);
             }
             const int64_t row = task * RPT + grp;
             if (row < P.n_rows && col_ok && ep == 0) {

@@ -175,6 +175,7 @@ def _fused_loop(op, rhs_is_zero, x, r, has_converged, n_iter, max_iter, toleranc
     flags[2 : 2 + p] = has_converged.reshape(-1).to(torch.int32)
     flags[2 + p :] = rhs_is_zero.reshape(-1).to(torch.int32)
     rr_partial = torch.empty((nb_upd, p), dtype=dtype, device=dev)
+    fold = torch.empty((lib.tsgu_cg_fold_rows(), p), dtype=dtype, device=dev)
     pvec = r.clone()  # curr_conjugate_vec (reference :293)
     fused_dot = isinstance(op, SparseOperator) and op.dtype == dtype
     stream = lambda: torch.cuda.current_stream(dev).cuda_stream  # noqa: E731
@@ -194,7 +195,7 @@ def _fused_loop(op, rhs_is_zero, x, r, has_converged, n_iter, max_iter, toleranc
                     pap = _be.coldot(pvec, Ap).unsqueeze(0)
                     n_partial = 1
                 s = stream()
-                _be.check(lib.tsgu_cg_alpha(vt, pap.data_ptr(), n_partial, scal.data_ptr(), flags.data_ptr(), eps, p,
+                _be.check(lib.tsgu_cg_alpha(vt, pap.data_ptr(), n_partial, fold.data_ptr(), scal.data_ptr(), flags.data_ptr(), eps, p,
                                             dev.index, s), "tsgu_cg_alpha")
                 _be.check(lib.tsgu_cg_update1(vt, n, p, r.data_ptr(), Ap.data_ptr(), x.data_ptr(), pvec.data_ptr(),
                                               scal.data_ptr(), flags.data_ptr(), rr_partial.data_ptr(), dev.index, s),
