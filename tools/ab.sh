@@ -1,2 +1,1 @@
-python -m pytest tests -m gpu -x -q --timeout 300 2>&1 | tail -3
-python bench_configs.py --only c4,c5 --no-cpu 2>&1 | grep -vE "Warn|warn|amdgpu.ids|sparse_csr_tensor"
+python -m pytest tests/test_gpu_reference_style.py -m gpu -x -q --timeout 600 2>&1 | tail -12
