@@ -76,8 +76,8 @@ int tsgu_csr_spmm(int vtype, int itype,
                   const void* dot_w, int64_t ldw, void* dot_partial,
                   int device, void* stream);
 
-/* Number of thread blocks (per batch item) tsgu_csr_spmm uses for (n_rows, p, vtype). */
-int64_t tsgu_spmm_num_blocks(int vtype, int64_t n_rows, int64_t p);
+/* Number of thread blocks (per batch item) tsgu_csr_spmm uses for (n_rows, nnz_per_item, p, vtype). */
+int64_t tsgu_spmm_num_blocks(int vtype, int64_t n_rows, int64_t nnz_per_item, int64_t p);
 
 /*
  * K3  out[k] = alpha * < G[row(k), :], B[col(k), :] >   for every stored entry k of A

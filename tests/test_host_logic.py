@@ -159,7 +159,8 @@ def test_abi_library_exports_every_declared_symbol():
     assert lib.tsgu_abi_version() == 1
     assert lib.tsgu_status_string(-2).decode().startswith("bad argument")
     # pure host-side helpers of the ABI
-    assert lib.tsgu_spmm_num_blocks(_backend.TSGU_F32, 10 ** 6, 32) == 31250
+    assert lib.tsgu_spmm_num_blocks(_backend.TSGU_F32, 10 ** 6, 27 * 10 ** 6, 32) == 31250
+    assert lib.tsgu_spmm_num_blocks(_backend.TSGU_F32, 2000376, 13907376, 4) == 10419  # short rows: 6 runs of 32 rows
     assert lib.tsgu_sptrsm_work_bytes(10, 1) >= 516
 
 

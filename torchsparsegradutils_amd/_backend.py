@@ -42,7 +42,7 @@ SIGNATURES = {
         [_int, _int, _i64, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _ptr, _i64, _i64, _i64, _i64,
          _ptr, _i64, _ptr, _int, _ptr],
     ),
-    "tsgu_spmm_num_blocks": (_i64, [_int, _i64, _i64]),
+    "tsgu_spmm_num_blocks": (_i64, [_int, _i64, _i64, _i64]),
     "tsgu_csr_sddmm": (
         _int,
         [_int, _int, _i64, _i64, _i64, _ptr, _ptr, _ptr, _i64, _i64, _ptr, _i64, _i64, _ptr, _dbl, _int, _i64, _i64,
@@ -197,7 +197,7 @@ def csr_spmm(crow, col, val, B, n_rows: int, n_cols: int, perm=None, out=None, d
     partial = None
     vt = vtype_of(val)
     if dot_w is not None:
-        nblk = lib.tsgu_spmm_num_blocks(vt, n_rows, p)
+        nblk = lib.tsgu_spmm_num_blocks(vt, n_rows, nnz, p)
         partial = torch.empty((batch * nblk, p), dtype=B.dtype, device=dev)
         dot_w = rowmajor(dot_w)
     with torch.cuda.device(dev):

@@ -49,13 +49,14 @@ int tsgu_device_info(int device, char* name, int cap, int* n_cu, int* wave_size)
     return TSGU_OK;
 }
 
-int64_t tsgu_spmm_num_blocks(int vtype, int64_t n_rows, int64_t p) {
+int64_t tsgu_spmm_num_blocks(int vtype, int64_t n_rows, int64_t nnz_per_item, int64_t p) {
     // mirrors spmm_geom(): the fused-dot path is only used with contiguous, 16-byte
     // aligned operands, so "wide" depends on p alone.
     const int wide = vtype == TSGU_F32 ? 4 : vtype == TSGU_F64 ? 2 : 8;
     const RowGeom g = pick_geom(wide, p % wide == 0, p);
     const int64_t rpb = kBlock / (g.cl * g.ep);
-    return (n_rows + rpb - 1) / rpb;
+    const int64_t rows = rpb * spmm_row_mult(n_rows, nnz_per_item, rpb);
+    return (n_rows + rows - 1) / rows;
 }
 
 int tsgu_csr_spmm(int vtype, int itype, int64_t n_rows, int64_t n_cols, int64_t nnz_per_item,

@@ -11,6 +11,7 @@
 namespace tsgu {
 
 constexpr int kStageCap = 2048;  // staged entries per pass (16 KiB LDS for 4-byte values)
+constexpr int kMaxRowMult = 8;   // runs of RPB rows one workgroup may own
 
 template <typename V>
 struct StageBytes {
@@ -31,6 +32,7 @@ struct SpmmParams {
     int64_t ldw;
     void* dot_partial;
     int64_t nblocks;  // row blocks per batch item
+    int rmul;         // runs of RPB rows per workgroup
 };
 
 // LDS image of the staged entries.  4-byte-or-narrower values are packed with their
@@ -70,7 +72,7 @@ struct Staged<V, false> {
     }
 };
 
-template <typename V, typename I, int VEC, int CL, int EP, bool DOT, bool PERM>
+template <typename V, typename I, int VEC, int CL, int EP, bool DOT, bool PERM, bool MULTI>
 __global__ __launch_bounds__(kBlock) void csr_spmm_kernel(const SpmmParams P) {
     using Acc = typename VT<V>::Acc;
     constexpr int GROUP = CL * EP;
@@ -102,25 +104,19 @@ __global__ __launch_bounds__(kBlock) void csr_spmm_kernel(const SpmmParams P) {
     const V* __restrict__ B = static_cast<const V*>(P.B) + item * P.b_bs + cbase;
     const uint32_t ldb = (uint32_t)P.ldb;
 
-    const int64_t row0 = vb * RPB;
-    const int64_t row1 = row0 + RPB < P.n_rows ? row0 + RPB : P.n_rows;
-    const int64_t row = row0 + grp;
-    const bool row_ok = row < P.n_rows;
-
+    // A workgroup owns RPB·rmul consecutive rows (rmul > 1 for short rows, so that the dependent
+    // crow -> (col,val) -> gather round trips are amortised over more work); row group `grp` handles
+    // rows row0 + grp + m·RPB, m < rmul.
+    const int rmul = MULTI ? P.rmul : 1;
+    constexpr int MM = MULTI ? kMaxRowMult : 1;  // compile-time bound of the row-run loops
+    const int64_t row0 = vb * RPB * rmul;
+    const int64_t row1 = row0 + (int64_t)RPB * rmul < P.n_rows ? row0 + (int64_t)RPB * rmul : P.n_rows;
     const int64_t blk_begin = (int64_t)crow[row0];
     const int64_t blk_end = (int64_t)crow[row1];
-    const int64_t start = row_ok ? (int64_t)crow[row] : 0;
-    const int64_t end = row_ok ? (int64_t)crow[row + 1] : 0;
 
-    Acc acc[VEC];
-#pragma unroll
-    for (int v = 0; v < VEC; ++v) acc[v] = 0;
-
-    for (int64_t cs = blk_begin; cs < blk_end; cs += kStageCap) {
-        const int64_t ce = cs + kStageCap < blk_end ? cs + kStageCap : blk_end;
-        if (cs != blk_begin) __syncthreads();
-        // stage the (col, val) slice: all loads of a pass are issued before the first LDS write, so a
-        // workgroup pays one memory round trip per SU·256 entries (two with the value indirection).
+    // stage entries [cs, ce) of the (col, val) stream: all loads of a pass are issued before the first
+    // LDS write, so a pass costs one memory round trip (two with the value indirection).
+    auto stage_pass = [&](int64_t cs, int64_t ce) {
         for (int64_t base = cs + tid; base < ce; base += (int64_t)kBlock * SU) {
             I cj[SU];
             V vv[SU];
@@ -144,10 +140,10 @@ __global__ __launch_bounds__(kBlock) void csr_spmm_kernel(const SpmmParams P) {
                 if (k < ce) stage.put((int)(k - cs), (int)cj[u], vv[u]);
             }
         }
-        __syncthreads();
+    };
 
-        const int64_t lo = start > cs ? start : cs;
-        const int64_t hi = end < ce ? end : ce;
+    // accumulate the staged entries [lo, hi) (absolute positions inside the pass starting at cs)
+    auto consume = [&](int64_t cs, int64_t lo, int64_t hi, Acc(&acc)[VEC]) {
         int i = (int)(lo - cs) + ep;
         const int iend = (int)(hi - cs);
         if (col_ok) {
@@ -175,32 +171,89 @@ __global__ __launch_bounds__(kBlock) void csr_spmm_kernel(const SpmmParams P) {
                 for (int v = 0; v < VEC; ++v) acc[v] = fma(a, b[v], acc[v]);
             }
         }
-    }
+    };
 
-    if constexpr (EP > 1) {
+    Acc dotp[VEC];  // DOT: Σ over this lane's rows of C[row,c]·W[row,c]
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) acc[v] = ep_sum<Acc, CL, EP>(acc[v]);
-    }
+    for (int v = 0; v < VEC; ++v) dotp[v] = 0;
 
-    if (row_ok && col_ok && ep == 0) {
-        V* __restrict__ C = static_cast<V*>(P.C) + item * P.c_bs + row * P.ldc + cbase;
-        store_vec<V, VEC, true>(C, acc);
+    auto finish_row = [&](int64_t row, bool row_ok, Acc(&acc)[VEC]) {
+        if constexpr (EP > 1) {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) acc[v] = ep_sum<Acc, CL, EP>(acc[v]);
+        }
+        if (row_ok && col_ok && ep == 0) {
+            V* __restrict__ C = static_cast<V*>(P.C) + item * P.c_bs + row * P.ldc + cbase;
+            store_vec<V, VEC, true>(C, acc);
+            if constexpr (DOT) {
+                Acc w[VEC];
+                load_vec<V, VEC>(static_cast<const V*>(P.W) + row * P.ldw + cbase, w);
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) dotp[v] = fma(acc[v], w[v], dotp[v]);
+            }
+        }
+    };
+
+    const bool fits = blk_end - blk_begin <= kStageCap;
+    if (fits) {
+        // common case: the whole workgroup slice is staged once, then every row is consumed from LDS.
+        // The row bounds are fetched before the staging pass so that they share its round trip.
+        I rb[MM], re_[MM];
+#pragma unroll
+        for (int m = 0; m < MM; ++m) {
+            const int64_t row = row0 + grp + (int64_t)m * RPB;
+            const bool ok = m < rmul && row < row1;
+            rb[m] = ok ? crow[row] : (I)0;
+            re_[m] = ok ? crow[row + 1] : (I)0;
+        }
+        stage_pass(blk_begin, blk_end);
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < MM; ++m) {
+            if (m >= rmul) break;
+            const int64_t row = row0 + grp + (int64_t)m * RPB;
+            const bool row_ok = row < row1;
+            const int64_t start = (int64_t)rb[m];
+            const int64_t end = (int64_t)re_[m];
+            Acc acc[VEC];
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) acc[v] = 0;
+            consume(blk_begin, start, end, acc);
+            finish_row(row, row_ok, acc);
+        }
+    } else {
+        // long rows: each run of RPB rows streams its entries through the staging window in passes
+        for (int m = 0; m < rmul; ++m) {
+            const int64_t s0 = row0 + (int64_t)m * RPB;
+            if (s0 >= row1) break;
+            const int64_t s1 = s0 + RPB < row1 ? s0 + RPB : row1;
+            const int64_t sb = (int64_t)crow[s0], se = (int64_t)crow[s1];
+            const int64_t row = s0 + grp;
+            const bool row_ok = row < s1;
+            const int64_t start = row_ok ? (int64_t)crow[row] : 0;
+            const int64_t end = row_ok ? (int64_t)crow[row + 1] : 0;
+            Acc acc[VEC];
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) acc[v] = 0;
+            for (int64_t cs = sb; cs < se; cs += kStageCap) {
+                const int64_t ce = cs + kStageCap < se ? cs + kStageCap : se;
+                __syncthreads();
+                stage_pass(cs, ce);
+                __syncthreads();
+                consume(cs, start > cs ? start : cs, end < ce ? end : ce, acc);
+            }
+            finish_row(row, row_ok, acc);
+        }
     }
 
     if constexpr (DOT) {
-        // partial[block][c] = Σ_rows C[row,c]·W[row,c]; rows summed in row order.
+        // partial[block][c] = Σ_rows C[row,c]·W[row,c], reduced over the row groups in a fixed order
         constexpr int TW = CL * VEC;  // columns covered by one column tile
         __syncthreads();
         Acc* red = reinterpret_cast<Acc*>(smem);
         if (ep == 0) {
-            Acc w[VEC];
 #pragma unroll
-            for (int v = 0; v < VEC; ++v) w[v] = 0;
-            if (row_ok && col_ok) {
-                load_vec<V, VEC>(static_cast<const V*>(P.W) + row * P.ldw + cbase, w);
-            }
-#pragma unroll
-            for (int v = 0; v < VEC; ++v) red[grp * TW + cl * VEC + v] = (row_ok && col_ok) ? acc[v] * w[v] : (Acc)0;
+            for (int v = 0; v < VEC; ++v) red[grp * TW + cl * VEC + v] = dotp[v];
         }
         __syncthreads();
         if (tid < TW) {
@@ -212,6 +265,16 @@ __global__ __launch_bounds__(kBlock) void csr_spmm_kernel(const SpmmParams P) {
             }
         }
     }
+}
+
+// rows-per-workgroup multiplier: aim at ~1.5k staged entries per workgroup, at most 8 runs of RPB rows
+inline int spmm_row_mult(int64_t n_rows, int64_t nnz, int64_t rpb) {
+    if (n_rows <= 0) return 1;
+    const double per_run = (double)nnz / (double)n_rows * (double)rpb;
+    int k = per_run > 0 ? (int)(1536.0 / per_run) : 8;
+    if (k < 1) k = 1;
+    if (k > kMaxRowMult) k = kMaxRowMult;
+    return k;
 }
 
 inline int64_t spmm_rows_per_block(const RowGeom& g) { return kBlock / (g.cl * g.ep); }
@@ -229,7 +292,8 @@ template <typename V, typename I>
 int spmm_launch(SpmmParams P, int64_t batch, hipStream_t stream) {
     const RowGeom g = spmm_geom<V>(P, batch);
     const int64_t rpb = spmm_rows_per_block(g);
-    P.nblocks = (P.n_rows + rpb - 1) / rpb;
+    P.rmul = spmm_row_mult(P.n_rows, P.nnz_per_item, rpb);
+    P.nblocks = (P.n_rows + rpb * P.rmul - 1) / (rpb * P.rmul);
     if (P.nblocks > 0x7fffffffLL || batch > 65535 || g.col_tiles > 65535) return TSGU_ERR_TOO_LARGE;
     const dim3 grid((unsigned)P.nblocks, (unsigned)batch, (unsigned)g.col_tiles);
     const bool dot = P.dot_partial != nullptr;
@@ -242,8 +306,13 @@ int spmm_launch(SpmmParams P, int64_t batch, hipStream_t stream) {
     return dispatch_geom(g, [&](auto cl, auto ep) -> int {
         constexpr int CL = decltype(cl)::value, EP = decltype(ep)::value;
         constexpr int W = VT<V>::kWide;
-#define TSGU_SPMM_GO(VECW, DOTF, PERMF) \
-    hipLaunchKernelGGL((csr_spmm_kernel<V, I, VECW, CL, EP, DOTF, PERMF>), grid, dim3(kBlock), 0, stream, P)
+#define TSGU_SPMM_GO(VECW, DOTF, PERMF)                                                                              \
+    do {                                                                                                             \
+        if (P.rmul > 1)                                                                                              \
+            hipLaunchKernelGGL((csr_spmm_kernel<V, I, VECW, CL, EP, DOTF, PERMF, true>), grid, dim3(kBlock), 0, stream, P);  \
+        else                                                                                                         \
+            hipLaunchKernelGGL((csr_spmm_kernel<V, I, VECW, CL, EP, DOTF, PERMF, false>), grid, dim3(kBlock), 0, stream, P); \
+    } while (0)
         if (g.vec == 1) {
             if (dot) TSGU_SPMM_GO(1, true, false);
             else if (has_perm) TSGU_SPMM_GO(1, false, true);

@@ -77,7 +77,7 @@ struct WtStage {
     int q[kWtEnt];            // perm positions (SpmmPerm)
     int rs, re;               // entry range of this lane's row (absolute)
     bool row_ok;
-    float own[VEC];           // sddmm row operand
+    float own[2 * VEC];       // sddmm row operand (compute geometry: up to 2 vectors per lane)
 };
 
 template <typename V, typename I, int VEC, int CL, int EP, int MODE>
@@ -88,6 +88,12 @@ struct WtCtx {
     static constexpr int TW = CL * VEC;
     static constexpr int NT4 = (G::LT + 3) / 4;
     static constexpr unsigned kRowBytes = TW * sizeof(V);
+    // Compute geometry: half as many column lanes as the loader geometry, each covering NV vectors, and
+    // twice the entry lanes.  The per-entry overhead (slot read, address, masks) is paid by half as many
+    // lanes per entry -> ~1/3 fewer instructions per task, which is what bounds this kernel.
+    static constexpr int CC = CL >= 2 ? CL / 2 : CL;
+    static constexpr int NV = CL / CC;
+    static constexpr int EC = EP * NV;
     static_assert(G::LT * G::NG == G::CAP || true, "");
 
     const WtParams& P;
@@ -100,6 +106,7 @@ struct WtCtx {
     uint2* slots;         // {tile row byte offset, value bits}
     float* dots;
     int lane, cl, ep, grp, lg;
+    int clc, epc;  // compute-geometry lane coordinates inside the row group
     int64_t c0;
     int64_t t_base, t_stride, k_last;  // this wave's tasks: t_base + k*t_stride, k = 0..k_last
     int nnz_m4;                        // nnz - 4 (clamp for the 4-wide entry loads)
@@ -154,8 +161,14 @@ struct WtCtx {
         st.re = (int)crow[row + 1];
         st.row_ok = ok;
         if constexpr (MODE == kWtSddmm) {
-            const int64_t cc = c0 < P.p ? c0 : 0;
-            load_vec<V, VEC>(static_cast<const V*>(P.R) + row * P.ldr + cc, st.own);  // masked when consumed
+#pragma unroll
+            for (int nv = 0; nv < NV; ++nv) {
+                const int64_t cb = (int64_t)(clc * NV + nv) * VEC;
+                float o[VEC];
+                load_vec<V, VEC>(static_cast<const V*>(P.R) + row * P.ldr + (cb < P.p ? cb : 0), o);  // masked when consumed
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) st.own[nv * VEC + v] = o[v];
+            }
         }
     }
 
@@ -208,68 +221,79 @@ struct WtCtx {
         sl[1] = hi;
     }
 
-    // consume task from LDS.  The slot reads of batch k+1 are issued before the tile reads of batch k
-    // are consumed, so a row costs ~one LDS round trip per U entries instead of two; entries beyond
-    // the row's end are clamped to its last slot and contribute with a zero weight.
-    __device__ __forceinline__ void compute(int64_t task, int eb, int ne, int rs, int re, const float (&own)[VEC]) const {
-#ifndef TSGU_WT_U
-#define TSGU_WT_U 8
-#endif
-        constexpr int U = TSGU_WT_U;
-        const bool col_ok = c0 < P.p;
-        float acc[VEC];
+    // one batch of up to U entries of this lane (MASKED: clamp slot indices to the row's last entry and
+    // zero-weight the padding)
+    template <bool MASKED, int U>
+    __device__ __forceinline__ void batch(int i, int iend, const unsigned char* trow, const float (&own)[2 * VEC],
+                                          float (&acc)[2 * VEC], const bool (&vok)[2]) const {
+        uint2 e[U];
+        float b[U][NV][VEC];
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) acc[v] = 0;
-        int i = rs - eb + ep;
-        const int iend = re - eb;
-        const unsigned char* trow = tile + (col_ok ? c0 : 0) * sizeof(V);
-        if (i < iend) {
-            const int ilast = iend - 1;
-            uint2 en[U];
+        for (int u = 0; u < U; ++u) {
+            int k = i + u * EC;
+            if constexpr (MASKED) k = k < iend ? k : iend - 1;
+            e[u] = slots[k];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int nv = 0; nv < NV; ++nv)
+                load_vec<V, VEC>(reinterpret_cast<const V*>(trow + e[u].x + nv * VEC * sizeof(V)), b[u][nv]);
+        }
+        if constexpr (MODE == kWtSddmm) {
+            float d[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int k = i + u * EP;
-                en[u] = slots[k < ilast ? k : ilast];
+                d[u] = 0;
+#pragma unroll
+                for (int nv = 0; nv < NV; ++nv) {
+                    float t = 0;
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) t = fma(own[nv * VEC + v], b[u][nv][v], t);
+                    d[u] += vok[nv] ? t : 0.f;
+                }
             }
-            for (; i < iend; i += U * EP) {
-                uint2 e[U];
-                float b[U][VEC];
 #pragma unroll
-                for (int u = 0; u < U; ++u) e[u] = en[u];
-#pragma unroll
-                for (int u = 0; u < U; ++u) load_vec<V, VEC>(reinterpret_cast<const V*>(trow + e[u].x), b[u]);
+            for (int u = 0; u < U; ++u) d[u] = group_sum<float, CC>(d[u]);
+            if (clc == 0) {
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    const int k = i + (U + u) * EP;
-                    en[u] = slots[k < ilast ? k : ilast];
+                    if (!MASKED || i + u * EC < iend) dots[i + u * EC] = d[u];
                 }
-                if constexpr (MODE == kWtSddmm) {
-                    float d[U];
+            }
+        } else {
 #pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        d[u] = 0;
+            for (int u = 0; u < U; ++u) {
+                float a = __uint_as_float(e[u].y);
+                if constexpr (MASKED) a = (i + u * EC < iend) ? a : 0.f;
 #pragma unroll
-                        for (int v = 0; v < VEC; ++v) d[u] = fma(own[v], b[u][v], d[u]);
-                        d[u] = col_ok ? d[u] : 0.f;
-                    }
+                for (int nv = 0; nv < NV; ++nv) {
 #pragma unroll
-                    for (int u = 0; u < U; ++u) d[u] = group_sum<float, CL>(d[u]);
-                    if (cl == 0) {
-#pragma unroll
-                        for (int u = 0; u < U; ++u) {
-                            if (i + u * EP < iend) dots[i + u * EP] = d[u];
-                        }
-                    }
-                } else {
-#pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        const float a = (i + u * EP < iend) ? __uint_as_float(e[u].y) : 0.f;
-#pragma unroll
-                        for (int v = 0; v < VEC; ++v) acc[v] = fma(a, b[u][v], acc[v]);
-                    }
+                    for (int v = 0; v < VEC; ++v) acc[nv * VEC + v] = fma(a, b[u][nv][v], acc[nv * VEC + v]);
                 }
             }
         }
+    }
+
+    // consume task from LDS (compute geometry CC x EC lanes per row).  Full batches run without clamps
+    // or masks; at most one masked batch finishes the row.
+    __device__ __forceinline__ void compute(int64_t task, int eb, int ne, int rs, int re, const float (&own)[2 * VEC]) const {
+#ifndef TSGU_WT_U
+#define TSGU_WT_U 4
+#endif
+        constexpr int U = TSGU_WT_U;
+        const int64_t cb0 = (int64_t)clc * NV * VEC;
+        bool vok[2];
+        vok[0] = cb0 < P.p;
+        vok[1] = NV > 1 && cb0 + VEC < P.p;
+        float acc[2 * VEC];
+#pragma unroll
+        for (int v = 0; v < 2 * VEC; ++v) acc[v] = 0;
+        int i = rs - eb + epc;
+        const int iend = re - eb;
+        const unsigned char* trow = tile + (vok[0] ? cb0 : 0) * sizeof(V);
+        for (; i + (U - 1) * EC < iend; i += U * EC) batch<false, U>(i, iend, trow, own, acc, vok);
+        if (i < iend) batch<true, U>(i, iend, trow, own, acc, vok);
         if constexpr (MODE == kWtSddmm) {
             V* __restrict__ outv = static_cast<V*>(P.out);
             const float alpha = (float)P.alpha;
@@ -279,13 +303,21 @@ struct WtCtx {
                 if (e < ne) outv[(int64_t)eb + e] = VT<V>::down(alpha * dots[e]);
             }
         } else {
-            if constexpr (EP > 1) {
+            if constexpr (EC > 1) {
 #pragma unroll
-                for (int v = 0; v < VEC; ++v) acc[v] = ep_sum<float, CL, EP>(acc[v]);
+                for (int v = 0; v < NV * VEC; ++v) acc[v] = ep_sum<float, CC, EC>(acc[v]);
             }
             const int64_t row = task * RPT + grp;
-            if (row < P.n_rows && col_ok && ep == 0) {
-                store_vec<V, VEC, true>(static_cast<V*>(P.out) + row * P.ldo + c0, acc);
+            if (row < P.n_rows && epc == 0) {
+#pragma unroll
+                for (int nv = 0; nv < NV; ++nv) {
+                    if (vok[nv]) {
+                        float o[VEC];
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) o[v] = acc[nv * VEC + v];
+                        store_vec<V, VEC, true>(static_cast<V*>(P.out) + row * P.ldo + cb0 + nv * VEC, o);
+                    }
+                }
             }
         }
     }
@@ -300,9 +332,9 @@ struct WtCtx {
         const int eb = __builtin_amdgcn_readfirstlane(st.cur.x);
         const int ne = __builtin_amdgcn_readfirstlane(st.cur.y);
         const int rs = st.row_ok ? st.rs : 0, re = st.row_ok ? st.re : 0;
-        float own[VEC];
+        float own[2 * VEC];
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) own[v] = (MODE == kWtSddmm && st.row_ok && c0 < P.p) ? st.own[v] : 0.f;
+        for (int v = 0; v < 2 * VEC; ++v) own[v] = (MODE == kWtSddmm && st.row_ok && v < NV * VEC) ? st.own[v] : 0.f;
         issue_rows(st);                                      // step t+2 (st.tcs were loaded two steps ago)
         issue_entries(st, clamp_task(t + 2), st.ent);        // step t+2 (st.q were loaded two steps ago)
         issue_index(st, clamp_task(t + 4), st.idx);          // step t+4
@@ -361,6 +393,8 @@ __global__ __launch_bounds__(kWave* kWtWaves, 2) void csr_wavetile_kernel(const 
     c.lg = lane / CL;
     c.ep = (lane % Ctx::GROUP) / CL;
     c.grp = lane / Ctx::GROUP;
+    c.clc = (lane % Ctx::GROUP) % Ctx::CC;
+    c.epc = (lane % Ctx::GROUP) / Ctx::CC;
     c.c0 = (int64_t)c.cl * VEC;
     c.X = static_cast<const V*>(P.X) + (c.c0 < P.p ? c.c0 : 0);
     c.ldx = (uint32_t)P.ldx;
