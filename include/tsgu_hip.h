@@ -155,6 +155,14 @@ int tsgu_csr_sddmm_wavetile(int vtype, int itype, int64_t n_rows, int64_t n_cols
                             void* out, double alpha, int swap_roles, int64_t p,
                             int device, void* stream);
 
+/* Fused backward (same contract as tsgu_csr_mm_backward) on the wavetile plan of the TRANSPOSED pattern. */
+int tsgu_csr_mm_backward_wavetile(int vtype, int itype, int64_t n_rows, int64_t n_cols, int64_t nnz,
+                                  const void* t_ptr, const void* t_perm, const void* val,
+                                  const void* tmeta, const void* tcols, const void* lidx,
+                                  const void* G, int64_t ldg, const void* B, int64_t ldb,
+                                  void* gradA_vals, void* gradB, int64_t ldgb, int64_t p,
+                                  int device, void* stream);
+
 /*
  * K4  X = op(A)^{-1} B   sparse triangular solve, sync-free (dependency-driven) CSR sweep.
  * replaces: torch.triangular_solve(B, A, upper, transpose, unitriangular).solution

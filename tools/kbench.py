@@ -34,7 +34,7 @@ def main():
     ap.add_argument("--grid", type=int, nargs=3, default=[100, 100, 100])
     ap.add_argument("--rhs", type=int, default=32)
     ap.add_argument("--reps", type=int, default=50)
-    ap.add_argument("--only", default="spmm,sddmm,spmmt,bwd_fused,spmm_tiled,sddmm_tiled,spmmt_tiled")
+    ap.add_argument("--only", default="spmm,sddmm,spmmt,bwd_fused,spmm_tiled,sddmm_tiled,spmmt_tiled,bwd_tiled")
     ap.add_argument("--check", action="store_true")
     ap.add_argument("--pattern", default="stencil27", help="stencil27 | diag27 (27 copies of own row) | band27 (cols = row-13..row+13)")
     a = ap.parse_args()
@@ -72,6 +72,8 @@ def main():
         fns["sddmm_tiled"] = lambda: be.csr_sddmm_tiled(crow, tl, G, B, n, n)
         if tlt is not None:
             fns["spmmt_tiled"] = lambda: be.csr_spmm_tiled(pt.crow, val, tlt, G, n, n, perm=pt.perm)
+            by["bwd_tiled"] = by["bwd_fused"]
+            fns["bwd_tiled"] = lambda: be.csr_mm_backward_tiled(pt, tlt, val, G, B, n, n)
     for k in a.only.split(","):
         if k not in fns:
             continue
@@ -83,6 +85,10 @@ def main():
                 x, y = fns[base](), fns[base + "_tiled"]()
                 print(f"{base}: tiled vs gather max abs diff = {float((x - y).abs().max())}")
     if a.check:
+        if "bwd_tiled" in fns:
+            gA2, gB2 = fns["bwd_tiled"]()
+            gA1, gB1 = fns["bwd_fused"]()
+            print("bwd_tiled vs bwd_fused: gradA max abs diff", float((gA1 - gA2).abs().max()), " gradB max abs diff", float((gB1 - gB2).abs().max()), " scale", float(gB1.abs().max()))
         gA, gB = fns["bwd_fused"]()
         print("fused bwd vs K3/K2: gradA max abs diff", float((gA - fns["sddmm"]()).abs().max()), " gradB max abs diff", float((gB - fns["spmmt"]()).abs().max()))
         C = fns["spmm"]()

@@ -64,6 +64,11 @@ SIGNATURES = {
         [_int, _int, _i64, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _ptr, _i64, _ptr, _dbl, _int, _i64,
          _int, _ptr],
     ),
+    "tsgu_csr_mm_backward_wavetile": (
+        _int,
+        [_int, _int, _i64, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _i64,
+         _int, _ptr],
+    ),
     "tsgu_csr_sptrsm": (
         _int,
         [_int, _int, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _int, _int, _ptr, _i64, _ptr, _i64, _i64, _ptr, _int, _ptr],
@@ -321,6 +326,25 @@ def csr_sddmm_tiled(crow, tiles, G, B, n_rows: int, n_cols: int, alpha: float = 
             "tsgu_csr_sddmm_wavetile",
         )
     return out
+
+
+def csr_mm_backward_tiled(tplan, tiles, val, G, B, n_rows: int, n_cols: int):
+    """Fused backward on the wavetile plan `tiles` of the transposed pattern `tplan` (2-D operands)."""
+    lib = load_library()
+    dev = require_device(tplan.crow, val, G, B)
+    G, B = rowmajor(G), rowmajor(B)
+    gradA = torch.empty(val.shape, dtype=val.dtype, device=dev)
+    gradB = torch.empty(B.shape, dtype=B.dtype, device=dev)
+    with torch.cuda.device(dev):
+        check(
+            lib.tsgu_csr_mm_backward_wavetile(
+                vtype_of(val), itype_of(tplan.crow), n_rows, n_cols, tiles.nnz, _p(tplan.crow), _p(tplan.perm), _p(val),
+                _p(tiles.tmeta), _p(tiles.tile_cols), _p(tiles.lidx), _p(G), _ld(G), _p(B), _ld(B),
+                _p(gradA), _p(gradB), _ld(gradB), G.size(-1), dev.index, _stream(dev),
+            ),
+            "tsgu_csr_mm_backward_wavetile",
+        )
+    return gradA, gradB
 
 
 def coo_sddmm(row, col, G, B, alpha: float = 1.0):

@@ -39,7 +39,17 @@ __device__ __forceinline__ Acc block_colsum(const Acc* __restrict__ partial, int
     const int sub = t / w, lc = t % w;
     Acc s = 0;
     if (sub < subs) {
-        for (int64_t b = sub; b < n_partial; b += subs) s += partial[b * p + c0 + lc];
+        // four independent chains keep four loads in flight per thread (fixed order => deterministic)
+        Acc s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+        int64_t b = sub;
+        for (; b + 3 * (int64_t)subs < n_partial; b += 4 * (int64_t)subs) {
+            s0 += partial[b * p + c0 + lc];
+            s1 += partial[(b + subs) * p + c0 + lc];
+            s2 += partial[(b + 2 * (int64_t)subs) * p + c0 + lc];
+            s3 += partial[(b + 3 * (int64_t)subs) * p + c0 + lc];
+        }
+        for (; b < n_partial; b += subs) s0 += partial[b * p + c0 + lc];
+        s = (s0 + s1) + (s2 + s3);
     }
     red[t] = s;
     __syncthreads();

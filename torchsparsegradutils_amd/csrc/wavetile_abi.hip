@@ -98,4 +98,39 @@ int tsgu_csr_sddmm_wavetile(int vtype, int itype, int64_t n_rows, int64_t n_cols
     return wt_go(vtype, itype, kWtSddmm, P, can, device, static_cast<hipStream_t>(stream));
 }
 
+int tsgu_csr_mm_backward_wavetile(int vtype, int itype, int64_t n_rows, int64_t n_cols, int64_t nnz,
+                                  const void* t_ptr, const void* t_perm, const void* val,
+                                  const void* tmeta, const void* tcols, const void* lidx,
+                                  const void* G, int64_t ldg, const void* B, int64_t ldb,
+                                  void* gradA_vals, void* gradB, int64_t ldgb, int64_t p,
+                                  int device, void* stream) {
+    if (n_rows <= 0 || n_cols <= 0 || nnz <= 0 || p <= 0) return TSGU_ERR_BAD_ARG;
+    if (!t_ptr || !t_perm || !val || !tmeta || !tcols || !lidx || !G || !B || !gradA_vals || !gradB) return TSGU_ERR_BAD_ARG;
+    if (ldg < p || ldb < p || ldgb < p || n_rows > 0x7fffffffLL) return TSGU_ERR_BAD_ARG;
+    const int wide = wide_of(vtype);
+    const bool wide_p = p % wide == 0;
+    const bool can = wide_p && ldb % wide == 0 && ldg % wide == 0 && ldgb % wide == 0 && aligned16(B) && aligned16(G) &&
+                     aligned16(gradB);
+    if (wide_p && !can) return TSGU_ERR_BAD_ARG;
+    if (const int rc = set_device(device)) return rc;
+    WtParams P{};
+    P.n_rows = n_cols;  // rows of Aᵀ
+    P.nnz = nnz;
+    P.p = p;
+    P.crow = t_ptr;
+    P.val = val;
+    P.perm = t_perm;
+    P.tmeta = static_cast<const int2*>(tmeta);
+    P.tcols = static_cast<const int*>(tcols);
+    P.lidx = static_cast<const unsigned char*>(lidx);
+    P.X = G;
+    P.ldx = ldg;
+    P.R = B;
+    P.ldr = ldb;
+    P.out = gradB;
+    P.ldo = ldgb;
+    P.out2 = gradA_vals;
+    return wt_go(vtype, itype, kWtBwd, P, can, device, static_cast<hipStream_t>(stream));
+}
+
 }  // extern "C"

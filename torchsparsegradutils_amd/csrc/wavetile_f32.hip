@@ -8,6 +8,7 @@ int wavetile_dispatch_f32(int itype, int mode, const WtParams& P, bool can_wide,
         case kWtSpmm: return wavetile_launch<float, I, kWtSpmm>(P, can_wide, n_cu, stream);         \
         case kWtSpmmPerm: return wavetile_launch<float, I, kWtSpmmPerm>(P, can_wide, n_cu, stream); \
         case kWtSddmm: return wavetile_launch<float, I, kWtSddmm>(P, can_wide, n_cu, stream);       \
+        case kWtBwd: return wavetile_launch<float, I, kWtBwd>(P, can_wide, n_cu, stream);           \
     }                                                                                            \
     return TSGU_ERR_BAD_ARG;
     if (itype == TSGU_I32) { GO(int32_t) }

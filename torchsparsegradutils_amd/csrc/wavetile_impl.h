@@ -28,7 +28,11 @@
 
 namespace tsgu {
 
-enum WtMode { kWtSpmm = 0, kWtSpmmPerm = 1, kWtSddmm = 2 };
+enum WtMode { kWtSpmm = 0, kWtSpmmPerm = 1, kWtSddmm = 2, kWtBwd = 3 };
+
+constexpr bool wt_has_perm(int mode) { return mode == kWtSpmmPerm || mode == kWtBwd; }
+constexpr bool wt_has_dots(int mode) { return mode == kWtSddmm || mode == kWtBwd; }
+constexpr bool wt_has_acc(int mode) { return mode != kWtSddmm; }
 
 constexpr int kWtLT = 12;        // tile rows per loader group (16-byte loads a lane keeps in flight per task)
 constexpr int kWtEnt = 4;        // entries per lane per task  -> 256 entries per task
@@ -46,7 +50,8 @@ struct WtParams {
     int64_t ldx;
     const void* R;               // sddmm row operand
     int64_t ldr;
-    void* out;                   // spmm: C [n_rows][ldo]; sddmm: values [nnz]
+    void* out;                   // spmm / bwd: dense rows [n_rows][ldo]; sddmm: values [nnz]
+    void* out2;                  // bwd: gradA values [nnz], addressed through perm
     int64_t ldo;
     double alpha;
     int64_t nblocks;             // workgroups launched
@@ -74,11 +79,29 @@ struct WtStage {
     i32x4_t tcs[(WtGeom<CL>::LT + 3) / 4];
     unsigned lid4;            // 4 local indices
     float ent_v[kWtEnt];
-    int q[kWtEnt];            // perm positions (SpmmPerm)
+    int q[kWtEnt];            // perm positions (SpmmPerm / Bwd)
+    int qs[kWtEnt];           // perm positions of the task whose entries are in flight (Bwd scatter)
+    int shift;                // entries the 4-wide loads were shifted back to stay inside the arrays
     int rs, re;               // entry range of this lane's row (absolute)
     bool row_ok;
     float own[2 * VEC];       // sddmm row operand (compute geometry: up to 2 vectors per lane)
 };
+
+// The 4-wide entry loads of a lane are clamped to start at nnz-4; when that moved the window back by d
+// elements (only the tail lanes of the very last task), element u of the lane is w[u+d].
+template <typename T>
+__device__ __forceinline__ void wt_unshift(T (&w)[4], int d) {
+    if (d > 0) {
+        T r[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int s = u + d;
+            r[u] = s == 1 ? w[1] : s == 2 ? w[2] : w[3];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) w[u] = r[u];
+    }
+}
 
 template <typename V, typename I, int VEC, int CL, int EP, int MODE>
 struct WtCtx {
@@ -133,14 +156,22 @@ struct WtCtx {
         }
     }
 
-    // entry loads (4 consecutive entries per lane), row bounds and the sddmm row operand of `task`
+    // first entry index of this lane's 4-wide window for a task starting at e0, and how far it was shifted
+    __device__ __forceinline__ int entry_window(int e0, int& shift) const {
+        int k = e0 + lane * 4;
+        const int kc = k < nnz_m4 ? k : nnz_m4;
+        shift = k - kc;
+        return kc > 0 ? kc : 0;
+    }
+
+    // entry loads (4 consecutive entries per lane), row bounds and the row operand of `task`
     __device__ __forceinline__ void issue_entries(WtStage<V, VEC, CL, MODE>& st, int64_t task, int2 m) const {
         const int e0 = __builtin_amdgcn_readfirstlane(m.x);
         st.lid4 = *reinterpret_cast<const unsigned*>(P.lidx + task * 256 + lane * 4);
-        int k = e0 + lane * 4;
-        k = k < nnz_m4 ? k : nnz_m4;
-        k = k > 0 ? k : 0;
+        int shift;
+        const int k = entry_window(e0, shift);
         if constexpr (MODE == kWtSpmm) {
+            st.shift = shift;  // applied to the values when they are drained
             if constexpr (sizeof(V) == 4) {
                 const WtU4 raw = *reinterpret_cast<const WtU4*>(val + k);
 #pragma unroll
@@ -150,9 +181,21 @@ struct WtCtx {
                 for (int u = 0; u < kWtEnt; ++u) st.ent_v[u] = VT<V>::up(val[k + u]);
             }
         }
-        if constexpr (MODE == kWtSpmmPerm) {
+        if constexpr (wt_has_perm(MODE)) {
+            // st.q (loaded two steps ago for this task) arrived long ago: undo its window shift, then gather
+            wt_unshift(st.q, st.shift);
+            st.shift = 0;
 #pragma unroll
-            for (int u = 0; u < kWtEnt; ++u) st.ent_v[u] = VT<V>::up(val[st.q[u]]);
+            for (int u = 0; u < kWtEnt; ++u) {
+                int qq = st.q[u];
+                qq = qq < 0 ? 0 : (qq < (int)P.nnz ? qq : (int)P.nnz - 1);
+                st.q[u] = qq;
+                st.ent_v[u] = VT<V>::up(val[qq]);
+            }
+            if constexpr (MODE == kWtBwd) {
+#pragma unroll
+                for (int u = 0; u < kWtEnt; ++u) st.qs[u] = st.q[u];
+            }
         }
         int64_t row = task * RPT + grp;
         const bool ok = row < P.n_rows;
@@ -160,7 +203,7 @@ struct WtCtx {
         st.rs = (int)crow[row];  // unconditional (row is clamped); masked with row_ok when consumed
         st.re = (int)crow[row + 1];
         st.row_ok = ok;
-        if constexpr (MODE == kWtSddmm) {
+        if constexpr (wt_has_dots(MODE)) {
 #pragma unroll
             for (int nv = 0; nv < NV; ++nv) {
                 const int64_t cb = (int64_t)(clc * NV + nv) * VEC;
@@ -184,19 +227,23 @@ struct WtCtx {
                 for (int w = 0; w < 4; ++w) st.tcs[i][w] = (4 * i + w < G::LT) ? src[4 * i + w] : 0;
             }
         }
-        if constexpr (MODE == kWtSpmmPerm) {
+        if constexpr (wt_has_perm(MODE)) {
             const int e0 = __builtin_amdgcn_readfirstlane(m.x);
-            int k = e0 + lane * 4;
-            k = k < nnz_m4 ? k : nnz_m4;
-            k = k > 0 ? k : 0;
+            const int k = entry_window(e0, st.shift);
+            if constexpr (sizeof(I) == 4) {
+                const WtU4 raw = *reinterpret_cast<const WtU4*>(perm + k);
 #pragma unroll
-            for (int u = 0; u < kWtEnt; ++u) st.q[u] = (int)perm[k + u];
+                for (int u = 0; u < kWtEnt; ++u) st.q[u] = (int)raw.w[u];
+            } else {
+#pragma unroll
+                for (int u = 0; u < kWtEnt; ++u) st.q[u] = (int)perm[k + u];
+            }
         }
     }
 
     // registers -> wave-private LDS (tile rows + entry slots).  Branch-free: rows / slots beyond the
     // task's counts hold padding and land in tile rows / slots that are never read.
-    __device__ __forceinline__ void drain(const WtStage<V, VEC, CL, MODE>& st) const {
+    __device__ __forceinline__ void drain(WtStage<V, VEC, CL, MODE>& st) const {
         unsigned char* dst = tile + (size_t)(lg * G::LT) * kRowBytes + (c0 < P.p ? c0 : 0) * sizeof(V);
 #pragma unroll
         for (int i = 0; i < G::LT; ++i) {
@@ -207,15 +254,19 @@ struct WtCtx {
                 *reinterpret_cast<u32x4_t*>(dst + (size_t)i * kRowBytes) = st.rows[i];
             }
         }
+        float ev[kWtEnt];
+#pragma unroll
+        for (int u = 0; u < kWtEnt; ++u) ev[u] = st.ent_v[u];
+        if constexpr (MODE == kWtSpmm) wt_unshift(ev, st.shift);
         u32x4_t lo, hi;
         lo.x = (st.lid4 & 0xffu) * kRowBytes;
-        lo.y = __float_as_uint(st.ent_v[0]);
+        lo.y = __float_as_uint(ev[0]);
         lo.z = ((st.lid4 >> 8) & 0xffu) * kRowBytes;
-        lo.w = __float_as_uint(st.ent_v[1]);
+        lo.w = __float_as_uint(ev[1]);
         hi.x = ((st.lid4 >> 16) & 0xffu) * kRowBytes;
-        hi.y = __float_as_uint(st.ent_v[2]);
+        hi.y = __float_as_uint(ev[2]);
         hi.z = (st.lid4 >> 24) * kRowBytes;
-        hi.w = __float_as_uint(st.ent_v[3]);
+        hi.w = __float_as_uint(ev[3]);
         u32x4_t* sl = reinterpret_cast<u32x4_t*>(slots + lane * 4);
         sl[0] = lo;
         sl[1] = hi;
@@ -240,7 +291,7 @@ struct WtCtx {
             for (int nv = 0; nv < NV; ++nv)
                 load_vec<V, VEC>(reinterpret_cast<const V*>(trow + e[u].x + nv * VEC * sizeof(V)), b[u][nv]);
         }
-        if constexpr (MODE == kWtSddmm) {
+        if constexpr (wt_has_dots(MODE)) {
             float d[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -261,7 +312,8 @@ struct WtCtx {
                     if (!MASKED || i + u * EC < iend) dots[i + u * EC] = d[u];
                 }
             }
-        } else {
+        }
+        if constexpr (wt_has_acc(MODE)) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 float a = __uint_as_float(e[u].y);
@@ -277,11 +329,12 @@ struct WtCtx {
 
     // consume task from LDS (compute geometry CC x EC lanes per row).  Full batches run without clamps
     // or masks; at most one masked batch finishes the row.
-    __device__ __forceinline__ void compute(int64_t task, int eb, int ne, int rs, int re, const float (&own)[2 * VEC]) const {
+    __device__ __forceinline__ void compute(int64_t task, int eb, int ne, int rs, int re, const float (&own)[2 * VEC],
+                                            const int (&qcur)[kWtEnt]) const {
 #ifndef TSGU_WT_U
 #define TSGU_WT_U 4
 #endif
-        constexpr int U = TSGU_WT_U;
+        constexpr int U = MODE == kWtBwd ? 2 : TSGU_WT_U;  // the fused mode is at the register limit
         const int64_t cb0 = (int64_t)clc * NV * VEC;
         bool vok[2];
         vok[0] = cb0 < P.p;
@@ -302,7 +355,17 @@ struct WtCtx {
                 const int e = lane + u * kWave;
                 if (e < ne) outv[(int64_t)eb + e] = VT<V>::down(alpha * dots[e]);
             }
-        } else {
+        }
+        if constexpr (MODE == kWtBwd) {
+            // gradA[perm[k]] = <G[i,:], B[j,:]>: this lane owns entries 4·lane .. 4·lane+3 of the task
+            V* __restrict__ ga = static_cast<V*>(P.out2);
+#pragma unroll
+            for (int u = 0; u < kWtEnt; ++u) {
+                const int e = lane * 4 + u;
+                if (e < ne) ga[qcur[u]] = VT<V>::down(dots[e]);
+            }
+        }
+        if constexpr (wt_has_acc(MODE)) {
             if constexpr (EC > 1) {
 #pragma unroll
                 for (int v = 0; v < NV * VEC; ++v) acc[v] = ep_sum<float, CC, EC>(acc[v]);
@@ -334,11 +397,14 @@ struct WtCtx {
         const int rs = st.row_ok ? st.rs : 0, re = st.row_ok ? st.re : 0;
         float own[2 * VEC];
 #pragma unroll
-        for (int v = 0; v < 2 * VEC; ++v) own[v] = (MODE == kWtSddmm && st.row_ok && v < NV * VEC) ? st.own[v] : 0.f;
+        for (int v = 0; v < 2 * VEC; ++v) own[v] = (wt_has_dots(MODE) && st.row_ok && v < NV * VEC) ? st.own[v] : 0.f;
+        int qcur[kWtEnt];
+#pragma unroll
+        for (int u = 0; u < kWtEnt; ++u) qcur[u] = (MODE == kWtBwd) ? st.qs[u] : 0;
         issue_rows(st);                                      // step t+2 (st.tcs were loaded two steps ago)
         issue_entries(st, clamp_task(t + 2), st.ent);        // step t+2 (st.q were loaded two steps ago)
         issue_index(st, clamp_task(t + 4), st.idx);          // step t+4
-        compute(clamp_task(t), eb, ne, rs, re, own);
+        compute(clamp_task(t), eb, ne, rs, re, own, qcur);
     }
 
     // fill stage `st` for the tasks tA, tA+2, tA+4 it will process first
@@ -359,7 +425,7 @@ __global__ __launch_bounds__(kWave* kWtWaves, 2) void csr_wavetile_kernel(const 
     using G = WtGeom<CL>;
     constexpr int TW = CL * VEC;
     constexpr size_t kTileBytes = (size_t)G::CAP * TW * sizeof(V);
-    constexpr size_t kWaveLds = kTileBytes + 256 * sizeof(uint2) + (MODE == kWtSddmm ? 256 * sizeof(float) : 0);
+    constexpr size_t kWaveLds = kTileBytes + 256 * sizeof(uint2) + (wt_has_dots(MODE) ? 256 * sizeof(float) : 0);
 
     extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
@@ -445,7 +511,7 @@ int wavetile_launch(WtParams P, bool can_wide, int n_cu, hipStream_t stream) {
     const int rpt = kWave / (g.cl * g.ep);
     P.ntask = (P.n_rows + rpt - 1) / rpt;
     if (P.ldx > 0xffffffffLL || P.nnz > 0x7fffffffLL || P.nnz < 4) return TSGU_ERR_TOO_LARGE;
-    const size_t lds = wavetile_lds_bytes<V>(g.cl, g.vec, MODE == kWtSddmm);
+    const size_t lds = wavetile_lds_bytes<V>(g.cl, g.vec, wt_has_dots(MODE));
     if (lds > 80 * 1024) return TSGU_ERR_TOO_LARGE;
     // persistent grid: 2 workgroups (8 independent wave pipelines) per CU
     int64_t blocks = (int64_t)n_cu * 2;
