@@ -123,17 +123,27 @@ __global__ __launch_bounds__(kBlock) void sptrsm_syncfree_kernel(const TrsmParam
                 }
             }
             Bits xb = S::kTag;
-            const long long t0 = wall_clock64();
-            for (;;) {
+            // poll: back-to-back agent-scope loads (the hop latency of the solve's critical path is the
+            // time between the producer's store and the first poll that sees it); the wall clock and the
+            // error word are only consulted every 256 spins.
+#ifndef TSGU_TRSM_SLEEP
+#define TSGU_TRSM_SLEEP 4
+#endif
+            long long t0 = 0;
+            for (unsigned spin = 0;; ++spin) {
                 if (need && xb == S::kTag) {
                     xb = __hip_atomic_load(X + j * P.ldx + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 if (!__any(need && xb == S::kTag)) break;
-                __builtin_amdgcn_s_sleep(2);
-                if (wall_clock64() - t0 > P.timeout_ticks ||
-                    __hip_atomic_load(&work->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-                    dead = true;
-                    break;
+                if (TSGU_TRSM_SLEEP > 0) __builtin_amdgcn_s_sleep(TSGU_TRSM_SLEEP);
+                if ((spin & 255u) == 255u) {
+                    const long long now = wall_clock64();
+                    if (t0 == 0) t0 = now;
+                    if (now - t0 > P.timeout_ticks ||
+                        __hip_atomic_load(&work->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                        dead = true;
+                        break;
+                    }
                 }
             }
             if (dead) break;
@@ -171,8 +181,13 @@ int sptrsm_launch(const TrsmParams& P, int n_cu, hipStream_t stream) {
     const int cl = P.p >= 64 ? 64 : next_pow2(P.p);
     const int64_t tiles = (P.p + cl - 1) / cl;
     if (tiles > 64) return TSGU_ERR_TOO_LARGE;
-    // persistent grid: up to 8 workgroups (32 waves) per CU; never more waves than rows.
-    int64_t blocks = (int64_t)n_cu * 8;
+    // persistent grid: ONE workgroup (4 waves) per CU.  Every resident wave polls, and the hop latency is
+    // paid in the consumer CU's memory queue: 32 polling waves per CU measured 1.46 us per dependency
+    // level at C3, 4 per CU 1.21 us.  Never more waves than rows.
+#ifndef TSGU_TRSM_BLOCKS_PER_CU
+#define TSGU_TRSM_BLOCKS_PER_CU 1
+#endif
+    int64_t blocks = (int64_t)n_cu * TSGU_TRSM_BLOCKS_PER_CU;
     const int64_t need = (P.n + 3) / 4;
     if (blocks > need) blocks = need;
     if (tiles > 1) {
