@@ -4,13 +4,16 @@ Both produce the same values (same summation order); the choice is speed only.""
 
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import _backend as _be
 from ._pattern import RowGather
 
-
-ENABLE_TILED = False  # the single-buffered tiled kernels are slower than the gather kernels on gfx950
+# The wave-pipelined LDS-tiled kernels are parity-clean but only on par with / slightly ahead of the gather
+# kernels: off by default; TSGU_ENABLE_TILED=1 selects them where the pattern qualifies.
+ENABLE_TILED = os.environ.get("TSGU_ENABLE_TILED", "0") == "1"
 
 
 def _tiles_for(plan: RowGather, dense: torch.Tensor, *others: torch.Tensor):
