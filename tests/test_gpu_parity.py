@@ -188,6 +188,33 @@ def test_mm_ragged_and_empty_rows_long_row():
     assert torch.count_nonzero(out) == 0 and out.shape == (4, 3)
 
 
+def test_mm_short_rows_multi_run_workgroups_and_cg_dot_epilogue():
+    """Short rows (several runs of rows per workgroup), with one row longer than the staging window inside
+    such a workgroup, for p in {1, 4, 5}; plus the fused pᵀ(Ap) epilogue against a plain column dot."""
+    from oracle import oracle
+    from torchsparsegradutils_amd import _backend as be
+
+    rng = np.random.default_rng(5)
+    n = m = 3000
+    counts = rng.integers(0, 6, size=n)
+    counts[1500] = 2600
+    crow = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    col = np.concatenate([np.sort(rng.choice(m, size=c, replace=False)) for c in counts]).astype(np.int64)
+    val = rng.standard_normal(col.size)
+    for p in (1, 4, 5):
+        B = rng.standard_normal((m, p))
+        Gd = rng.standard_normal((n, p))
+        A = torch.sparse_csr_tensor(G.t(crow, DEV), G.t(col, DEV), G.t(val, DEV), (n, m)).requires_grad_(True)
+        Bd = G.t(B, DEV).requires_grad_(True)
+        C = tsgu().sparse_mm(A, Bd)
+        C.backward(G.t(Gd, DEV))
+        Co, gAo, gBo = oracle.sparse_mm_fwd_bwd(crow, col, val, B, Gd, m)
+        assert rel(C, Co) < 1e-12 and rel(A.grad.values(), gAo) < 1e-12 and rel(Bd.grad, gBo) < 1e-12, p
+        Cd, partial = be.csr_spmm(G.t(crow, DEV), G.t(col, DEV), G.t(val, DEV), Bd.detach(), n, m, dot_w=Bd.detach())
+        assert rel(Cd, Co) < 1e-12
+        assert rel(partial.sum(0), (Co * B).sum(0)) < 1e-11, p
+
+
 # ---------------------------------------------------------- triangular solve ---------------
 def test_triangular_all_flags_layouts_batched():
     z = G.load("tri_flags.npz")

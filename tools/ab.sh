@@ -1,1 +1,1 @@
-TSGU_ENABLE_TILED=1 python -m pytest tests -m gpu -x -q --timeout 300 2>&1 | tail -4
+python -m pytest tests -m gpu -x -q --timeout 300 2>&1 | tail -3

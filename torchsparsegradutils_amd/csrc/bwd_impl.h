@@ -82,9 +82,9 @@ __global__ __launch_bounds__(kBlock) void csr_mm_backward_kernel(const BwdParams
     for (int64_t cs = blk_begin; cs < blk_end; cs += kBwdCap) {
         const int64_t ce = cs + kBwdCap < blk_end ? cs + kBwdCap : blk_end;
         if (cs != blk_begin) __syncthreads();
+        // phase A: coalesced loads of (row index, perm) -> LDS
         for (int64_t base = cs + tid; base < ce; base += (int64_t)kBlock * 4) {
             I ri[4], q[4];
-            V vv[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int64_t k = base + (int64_t)u * kBlock;
@@ -93,14 +93,37 @@ __global__ __launch_bounds__(kBlock) void csr_mm_backward_kernel(const BwdParams
                 q[u] = ok ? stream_load(tperm + k) : (I)0;
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) vv[u] = val[(int64_t)q[u]];
-#pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int64_t k = base + (int64_t)u * kBlock;
                 if (k < ce) {
-                    s_ia[k - cs] = make_uint2((unsigned)ri[u], __float_as_uint(VT<V>::up(vv[u])));
+                    s_ia[k - cs].x = (unsigned)ri[u];
                     s_q[k - cs] = (int)q[u];
                 }
+            }
+        }
+        __syncthreads();
+        // phase B: A's values through perm, "row-transposed" lane order: consecutive lanes take the same
+        // local entry index t of consecutive rows.  Neighbouring rows of Aᵀ reference neighbouring entries
+        // of the same row of A (adjacent positions of val), so the TA merges them into one L1 access instead
+        // of one 64-byte access per 4-byte value.
+        {
+            const int xr = tid % RPB, xt = tid / RPB;
+            const int64_t xrow = row0 + xr;
+            int xlo = 0, xhi = 0;
+            if (xrow < row1) {
+                const int64_t a = (int64_t)tptr[xrow], b = (int64_t)tptr[xrow + 1];
+                xlo = (int)((a > cs ? a : cs) - cs);
+                xhi = (int)((b < ce ? b : ce) - cs);
+            }
+            constexpr int XT = kBlock / RPB;
+            for (int kk = xlo + xt; kk < xhi; kk += XT * 2) {
+                const int k2 = kk + XT;
+                const int q0 = s_q[kk];
+                const int q1 = k2 < xhi ? s_q[k2] : q0;
+                const V v0 = val[q0];
+                const V v1 = val[q1];
+                s_ia[kk].y = __float_as_uint(VT<V>::up(v0));
+                if (k2 < xhi) s_ia[k2].y = __float_as_uint(VT<V>::up(v1));
             }
         }
         __syncthreads();
@@ -150,8 +173,17 @@ __global__ __launch_bounds__(kBlock) void csr_mm_backward_kernel(const BwdParams
             if (cl == 0) s_dot[i] = d;
         }
         __syncthreads();
-        // gradA[perm[k]] = <G[i,:], B[j,:]> : 4-byte scatter, one entry per lane
-        for (int64_t k = cs + tid; k < ce; k += kBlock) gradA[s_q[k - cs]] = VT<V>::down(s_dot[k - cs]);
+        // gradA[perm[k]] = <G[i,:], B[j,:]> : 4-byte scatter in the same row-transposed lane order
+        {
+            const int xr = tid % RPB, xt = tid / RPB;
+            const int64_t xrow = row0 + xr;
+            if (xrow < row1) {
+                const int64_t a = (int64_t)tptr[xrow], b = (int64_t)tptr[xrow + 1];
+                const int xlo = (int)((a > cs ? a : cs) - cs);
+                const int xhi = (int)((b < ce ? b : ce) - cs);
+                for (int kk = xlo + xt; kk < xhi; kk += kBlock / RPB) gradA[s_q[kk]] = VT<V>::down(s_dot[kk]);
+            }
+        }
     }
 
     if constexpr (EP > 1) {
