@@ -220,6 +220,27 @@ int tsgu_cg_beta(int vtype, const void* rr_partial, int64_t n_partial, void* sca
 int tsgu_cg_update2(int vtype, int64_t n, int64_t p, const void* r, void* pvec,
                     const void* scal, const int* flags, int device, void* stream);
 
+/*
+ * K6  fused BiCGSTAB recurrences (no preconditioner), all right-hand sides in lock-step, scalars on the device.
+ * replaces the per-column Python loop and its ~12 ATen ops + 2 host reads per iteration
+ *           torchsparsegradutils/utils/bicgstab.py:113-124, 163-241
+ * scal  [8][p]: rho | alpha | omega | rho_next | threshold | beta | resid | resid0
+ * flags int32 : [0] all columns finished, [1] iterations, [2..2+p) finished, [2+p..2+2p) finishing after the half
+ *               step, [2+2p..2+3p) matvecs used.
+ * tsgu_bicg_scalar(phase): 0 init (partial = <r0,r0>) | 1 beta | 2 alpha (partial = <r0,v>) | 3 half (|s|^2)
+ *                          | 4 omega (partial = 3 sets <t,s>,<t,t>,<r0,t>, `set_stride` apart) | 5 end (|r|^2)
+ * tsgu_bicg_vector(which): 0 p=(p*beta-(beta*omega)*v)+r (a0=p,a1=r,a2=v) | 1 s=r-alpha*v (a0=s,a1=r,a2=v)
+ *                          | 2 three dot partials (a0=t,a1=s,a2=r0) | 3 x/r update (a0=x,a1=r,a2=s,a3=t,a4=p)
+ * Vector operands are contiguous [n][p], 16-byte aligned; partial buffers have tsgu_cg_num_blocks() rows per set.
+ * Every step is a no-op once flags[0] != 0.
+ */
+int tsgu_bicg_scalar(int vtype, int phase, const void* partial, int64_t n_partial, int64_t set_stride, void* fold,
+                     void* scal, int* flags, double abstol, double reltol, int matvec_max, int nmv0, int64_t p,
+                     int device, void* stream);
+int tsgu_bicg_vector(int vtype, int which, int64_t n, int64_t p, void* a0, void* a1, const void* a2, const void* a3,
+                     const void* a4, const void* scal, const int* flags, void* partial, int64_t set_stride,
+                     int device, void* stream);
+
 /* Column-wise dot products  out[c] = Σ_i X[i,c]·Y[i,c]  (two-stage, deterministic).
  * replaces: torch.dot / mul+sum in utils/bicgstab.py:168,199,222-224 and linear_cg.py:294 */
 /* `partial` needs tsgu_coldot_max_blocks(n, p) * p elements. */

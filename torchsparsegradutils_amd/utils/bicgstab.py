@@ -17,7 +17,9 @@ from typing import Callable, NamedTuple, Optional, Union
 import torch
 
 from .. import _backend as _be
-from ._operator import as_operator
+from ._operator import SparseOperator, as_operator
+
+_POLL = 4  # iterations enqueued between two reads of the device "all columns finished" word
 
 _null_log = logging.getLogger("bicgstab")
 _null_log.disabled = True
@@ -49,6 +51,9 @@ def bicgstab(
     ``matmul_closure``: tensor (dense or sparse COO/CSR) or callable; ``rhs``: ``(n,)`` or ``(n, k)``
     on the GPU.  Returns the solution with the shape of ``rhs``."""
     _be.require_device(rhs)
+    if settings.precon is None and rhs.dtype in (torch.float32, torch.float64) and rhs.dim() in (1, 2) \
+            and rhs.shape[-1 if rhs.dim() == 2 else 0] > 0 and (rhs.dim() == 1 or rhs.shape[1] <= 1024):
+        return _bicgstab_fused(matmul_closure, rhs, initial_guess, settings)
     if rhs.dim() > 1:
         # column-by-column, exactly like the reference (each column has its own stopping point)
         sols = [
@@ -127,3 +132,75 @@ def bicgstab(
             break
 
     return x
+
+
+def _bicgstab_fused(matmul_closure, rhs, initial_guess, settings: BICGSTABSettings) -> torch.Tensor:
+    """All columns in lock-step on the K6 kernels (csrc/bicgstab.hip); same per-column arithmetic and stopping
+    rules as the reference's column loop (utils/bicgstab.py:126-247)."""
+    lib = _be.load_library()
+    is_vector = rhs.dim() == 1
+    B = (rhs.unsqueeze(-1) if is_vector else rhs).contiguous()
+    n, p = B.shape
+    dev, dtype = B.device, B.dtype
+    vt = _be.vtype_of(B)
+    op = as_operator(matmul_closure)
+    fused_dot = isinstance(op, SparseOperator) and op.dtype == dtype
+    matvec_max = 2 * n if settings.matvec_max is None else int(settings.matvec_max)
+    matvec_max = min(matvec_max, 2**31 - 1)
+
+    if initial_guess is None:
+        x = torch.zeros_like(B)
+        r0 = (B - op(x)).contiguous()  # one matvec on A·0, as the reference (bicgstab.py:159-161)
+        nmv0 = 1
+    else:
+        x = (initial_guess.unsqueeze(-1) if initial_guess.dim() == 1 else initial_guess).clone().contiguous()
+        r0 = B.clone()  # the reference does not subtract A·x0 (bicgstab.py:158)
+        nmv0 = 0
+
+    nb = lib.tsgu_cg_num_blocks(vt, n, p)
+    if nb < 0:
+        raise RuntimeError("bicgstab: more than 1024 simultaneous right-hand sides are not supported")
+    scal = torch.zeros(8 * p, dtype=dtype, device=dev)
+    flags = torch.zeros(2 + 3 * p, dtype=torch.int32, device=dev)
+    part = torch.empty((3, nb, p), dtype=dtype, device=dev)
+    fold = torch.empty((lib.tsgu_cg_fold_rows(), p), dtype=dtype, device=dev)
+    stream = lambda: torch.cuda.current_stream(dev).cuda_stream  # noqa: E731
+
+    def scalar(phase, partial, rows, set_stride=0):
+        _be.check(lib.tsgu_bicg_scalar(vt, phase, None if partial is None else partial.data_ptr(), rows, set_stride,
+                                       fold.data_ptr(), scal.data_ptr(), flags.data_ptr(), float(settings.abstol),
+                                       float(settings.reltol), matvec_max, nmv0, p, dev.index, stream()), "tsgu_bicg_scalar")
+
+    def vector(which, a0, a1, a2, a3=None, a4=None, partial=None, set_stride=0):
+        _be.check(lib.tsgu_bicg_vector(vt, which, n, p, a0.data_ptr(), a1.data_ptr(), a2.data_ptr(),
+                                       None if a3 is None else a3.data_ptr(), None if a4 is None else a4.data_ptr(),
+                                       scal.data_ptr(), flags.data_ptr(), None if partial is None else partial.data_ptr(),
+                                       set_stride, dev.index, stream()), "tsgu_bicg_vector")
+
+    with torch.cuda.device(dev):
+        rr0 = _be.coldot(r0, r0).unsqueeze(0).contiguous()
+        scalar(0, rr0, 1)
+        r = r0.clone()
+        pv = torch.zeros_like(B)
+        v = torch.zeros_like(B)
+        s = torch.zeros_like(B)
+        done = bool(flags[0].item())
+        while not done:
+            for _ in range(_POLL):
+                scalar(1, None, 0)                      # beta, rho (bicgstab.py:183-184)
+                vector(0, pv, r, v)                     # p update (:187-189)
+                if fused_dot:
+                    v, pr0v = op.matmul_with_dot(pv, r0)  # v = A p with <r0, v> partials (:196-199)
+                    scalar(2, pr0v, pr0v.shape[0])
+                else:
+                    v = op(pv).contiguous()
+                    scalar(2, _be.coldot(r0, v).unsqueeze(0).contiguous(), 1)
+                vector(1, s, r, v, partial=part[0])     # s = r - alpha v, |s|^2 (:200-203)
+                scalar(3, part[0], nb)                  # early exit / matvec budget (:207-214)
+                t = op(s).contiguous()                  # t = A s (:221)
+                vector(2, t, s, r0, partial=part, set_stride=nb * p)
+                scalar(4, part, nb, nb * p)             # omega, rho_next (:223-224)
+                vector(3, x, r, s, t, pv, partial=part[0])  # r, x updates, |r|^2 (:227-235)
+                scalar(5, part[0], nb)                  # stop tests (:239-241)
+            done = bool(flags[0].item())
+    return x.squeeze(-1) if is_vector else x
