@@ -421,6 +421,47 @@ def test_bicgstab_fused_multi_rhs_matches_columnwise_oracle():
     assert x1.shape == (n,) and rel(x1, x2.cpu().numpy()) < 1e-10
 
 
+def test_krylov_hipgraph_replay_is_bitwise_identical_to_eager_launches(monkeypatch):
+    """Long solves replay a recorded chunk of iterations as a hipGraph (device-side iteration counter and stop
+    flags); the iterates must be bit-identical to launching every kernel eagerly."""
+    from torchsparsegradutils_amd.utils import BICGSTABSettings, LinearCGSettings, _graph, bicgstab, linear_cg
+
+    z = G.load("cg_lap16.npz")
+    n = 4096
+    A = torch.sparse_csr_tensor(G.t(z["crow"], DEV), G.t(z["col"], DEV), G.t(z["val"], DEV).double(), (n, n))
+    B = G.t(z["B"], DEV).double()
+    st = LinearCGSettings(max_cg_iterations=203, cg_tolerance=1e-30)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        before = dict(_graph.STATS)
+        xg = linear_cg(A, B, settings=st)
+        assert _graph.STATS["captures"] == before["captures"] + 1, _graph.STATS
+        assert _graph.STATS["replays"] >= before["replays"] + 20
+        monkeypatch.setattr(_graph, "MIN_ITERS", 0)
+        xe = linear_cg(A, B, settings=st)
+    assert torch.equal(xg, xe)
+
+    # BiCGSTAB on a convection-diffusion operator (non-symmetric, ~100 iterations)
+    g = 64
+    idx = np.arange(g * g).reshape(g, g)
+    rows, cols, vals = [idx.ravel()], [idx.ravel()], [np.full(g * g, 4.0)]
+    for sl_a, sl_b, w in ((idx[1:, :], idx[:-1, :], -1.3), (idx[:-1, :], idx[1:, :], -0.7),
+                          (idx[:, 1:], idx[:, :-1], -1.2), (idx[:, :-1], idx[:, 1:], -0.8)):
+        rows.append(sl_a.ravel()); cols.append(sl_b.ravel()); vals.append(np.full(sl_a.size, w))
+    coo = torch.sparse_coo_tensor(np.stack([np.concatenate(rows), np.concatenate(cols)]), np.concatenate(vals),
+                                  (g * g, g * g)).coalesce().to(DEV)
+    Ac = coo.to_sparse_csr()
+    rhs = torch.randn(g * g, 3, dtype=torch.float64, device=DEV)
+    sb = BICGSTABSettings(reltol=1e-12, abstol=1e-14)
+    xe = bicgstab(Ac, rhs, settings=sb)
+    monkeypatch.setattr(_graph, "MIN_ITERS", 64)
+    before = dict(_graph.STATS)
+    xg = bicgstab(Ac, rhs, settings=sb)
+    assert _graph.STATS["captures"] == before["captures"] + 1, _graph.STATS
+    assert torch.equal(xg, xe)
+    assert float((Ac @ xg - rhs).norm() / rhs.norm()) < 1e-10
+
+
 def test_generic_solve_double_backward():
     """create_graph=True then a Hessian-vector product vs dense autograd (reference test_sparse_solve.py:391-441)."""
     from torchsparsegradutils_amd.utils import LinearCGSettings, linear_cg

@@ -158,9 +158,12 @@ __global__ __launch_bounds__(kBlock) void cg_beta_kernel(const V* __restrict__ r
         const int lim = p < 64 ? (int)p : 64;
         for (int k = 0; k < lim; ++k) s += normsum[k];
         const V mean = s / (V)p;
-        flags[1] = iter_index + 1;
+        // iter_index < 0: the iteration counter lives on the device (flags[1]), so that every iteration is the
+        // same launch and a chunk of iterations can be replayed as one hipGraph.
+        const int it = iter_index < 0 ? flags[1] : iter_index;
+        flags[1] = it + 1;
         // stop rule (linear_cg.py:376-382): k >= min(10, max_iter-1) and mean‖r‖ < tol
-        if (iter_index >= min_iter_index && mean < tolerance) flags[0] = 1;
+        if (it >= min_iter_index && mean < tolerance) flags[0] = 1;
     }
 }
 

@@ -45,10 +45,12 @@ class SparseOperator:
 
     matmul = __call__
 
-    def matmul_with_dot(self, v: torch.Tensor, w: torch.Tensor = None):
-        """(A·v, per-block partial sums of <w, A·v> per column; w defaults to v) — K1 with the fused dot epilogue."""
+    def matmul_with_dot(self, v: torch.Tensor, w: torch.Tensor = None, out: torch.Tensor = None):
+        """(A·v, per-block partial sums of <w, A·v> per column; w defaults to v) — K1 with the fused dot epilogue.
+        ``out`` (optional, must not alias ``v``) receives A·v in place."""
         p = self.plan
-        return _be.csr_spmm(p.crow, p.col, self.values, v, p.n_rows, p.n_cols, perm=p.perm, dot_w=v if w is None else w)
+        return _be.csr_spmm(p.crow, p.col, self.values, v, p.n_rows, p.n_cols, perm=p.perm, out=out,
+                            dot_w=v if w is None else w)
 
 
 def as_operator(matmul_closure):

@@ -17,9 +17,11 @@ from typing import Callable, NamedTuple, Optional, Union
 import torch
 
 from .. import _backend as _be
+from . import _graph
 from ._operator import SparseOperator, as_operator
 
 _POLL = 4  # iterations enqueued between two reads of the device "all columns finished" word
+_GRAPH_AFTER = 16  # iterations run eagerly before a chunk is recorded as a hipGraph
 
 _null_log = logging.getLogger("bicgstab")
 _null_log.disabled = True
@@ -184,23 +186,38 @@ def _bicgstab_fused(matmul_closure, rhs, initial_guess, settings: BICGSTABSettin
         pv = torch.zeros_like(B)
         v = torch.zeros_like(B)
         s = torch.zeros_like(B)
+
+        def iteration():
+            scalar(1, None, 0)                      # beta, rho (bicgstab.py:183-184)
+            vector(0, pv, r, v)                     # p update (:187-189)
+            if fused_dot:
+                _, pr0v = op.matmul_with_dot(pv, r0, out=v)  # v = A p with <r0, v> partials (:196-199)
+                scalar(2, pr0v, pr0v.shape[0])
+            else:
+                v.copy_(op(pv))
+                scalar(2, _be.coldot(r0, v).unsqueeze(0).contiguous(), 1)
+            vector(1, s, r, v, partial=part[0])     # s = r - alpha v, |s|^2 (:200-203)
+            scalar(3, part[0], nb)                  # early exit / matvec budget (:207-214)
+            t = op(s).contiguous()                  # t = A s (:221)
+            vector(2, t, s, r0, partial=part, set_stride=nb * p)
+            scalar(4, part, nb, nb * p)             # omega, rho_next (:223-224)
+            vector(3, x, r, s, t, pv, partial=part[0])  # r, x updates, |r|^2 (:227-235)
+            scalar(5, part[0], nb)                  # stop tests (:239-241)
+
         done = bool(flags[0].item())
+        k = 0
+        graph = None
+        try_graph = fused_dot and _graph.enabled()  # user callables are opaque (may synchronise): never captured
         while not done:
-            for _ in range(_POLL):
-                scalar(1, None, 0)                      # beta, rho (bicgstab.py:183-184)
-                vector(0, pv, r, v)                     # p update (:187-189)
-                if fused_dot:
-                    v, pr0v = op.matmul_with_dot(pv, r0)  # v = A p with <r0, v> partials (:196-199)
-                    scalar(2, pr0v, pr0v.shape[0])
-                else:
-                    v = op(pv).contiguous()
-                    scalar(2, _be.coldot(r0, v).unsqueeze(0).contiguous(), 1)
-                vector(1, s, r, v, partial=part[0])     # s = r - alpha v, |s|^2 (:200-203)
-                scalar(3, part[0], nb)                  # early exit / matvec budget (:207-214)
-                t = op(s).contiguous()                  # t = A s (:221)
-                vector(2, t, s, r0, partial=part, set_stride=nb * p)
-                scalar(4, part, nb, nb * p)             # omega, rho_next (:223-224)
-                vector(3, x, r, s, t, pv, partial=part[0])  # r, x updates, |r|^2 (:227-235)
-                scalar(5, part[0], nb)                  # stop tests (:239-241)
+            if try_graph and graph is None and k >= _GRAPH_AFTER and (matvec_max - nmv0) // 2 - k >= _graph.MIN_ITERS:
+                # still running after _GRAPH_AFTER iterations: record one chunk as a hipGraph and replay it
+                graph = _graph.capture(iteration, _POLL)
+                try_graph = graph is not None
+            if graph is not None:
+                _graph.replay(graph)
+            else:
+                for _ in range(_POLL):
+                    iteration()
+            k += _POLL
             done = bool(flags[0].item())
     return x.squeeze(-1) if is_vector else x

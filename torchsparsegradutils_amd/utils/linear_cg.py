@@ -25,6 +25,7 @@ from typing import Callable, NamedTuple, Optional, Union
 import torch
 
 from .. import _backend as _be
+from . import _graph
 from ._operator import SparseOperator, as_operator
 
 _POLL = 8  # iterations enqueued between two reads of the device stop flag
@@ -181,31 +182,46 @@ def _fused_loop(op, rhs_is_zero, x, r, has_converged, n_iter, max_iter, toleranc
     stream = lambda: torch.cuda.current_stream(dev).cuda_stream  # noqa: E731
     min_iter_index = min(10, max_iter - 1)
 
+    def iteration():
+        if fused_dot:
+            Ap, pap = op.matmul_with_dot(pvec)  # K1 + pᵀAp partials (reference :322, :64-65)
+            n_partial = pap.shape[0]
+        else:
+            Ap = op(pvec).contiguous()
+            pap = _be.coldot(pvec, Ap).unsqueeze(0)
+            n_partial = 1
+        s = stream()
+        _be.check(lib.tsgu_cg_alpha(vt, pap.data_ptr(), n_partial, fold.data_ptr(), scal.data_ptr(), flags.data_ptr(), eps, p,
+                                    dev.index, s), "tsgu_cg_alpha")
+        _be.check(lib.tsgu_cg_update1(vt, n, p, r.data_ptr(), Ap.data_ptr(), x.data_ptr(), pvec.data_ptr(),
+                                      scal.data_ptr(), flags.data_ptr(), rr_partial.data_ptr(), dev.index, s),
+                  "tsgu_cg_update1")
+        # iteration index -1: the counter is flags[1] on the device, every iteration is the same launch
+        _be.check(lib.tsgu_cg_beta(vt, rr_partial.data_ptr(), nb_upd, scal.data_ptr(), flags.data_ptr(), eps,
+                                   stop_after, float(tolerance), -1, min_iter_index, p, dev.index, s),
+                  "tsgu_cg_beta")
+        _be.check(lib.tsgu_cg_update2(vt, n, p, r.data_ptr(), pvec.data_ptr(), scal.data_ptr(),
+                                      flags.data_ptr(), dev.index, s), "tsgu_cg_update2")
+
     done = False
     k = 0
+    graph = None
+    try_graph = fused_dot and _graph.enabled()  # user callables are opaque (may synchronise): never captured
     with torch.cuda.device(dev):
         while k < n_iter and not done:
-            upto = min(n_iter, max(k + _POLL, min_iter_index + 1) if k <= min_iter_index else k + _POLL)
-            for kk in range(k, upto):
-                if fused_dot:
-                    Ap, pap = op.matmul_with_dot(pvec)  # K1 + pᵀAp partials (reference :322, :64-65)
-                    n_partial = pap.shape[0]
-                else:
-                    Ap = op(pvec).contiguous()
-                    pap = _be.coldot(pvec, Ap).unsqueeze(0)
-                    n_partial = 1
-                s = stream()
-                _be.check(lib.tsgu_cg_alpha(vt, pap.data_ptr(), n_partial, fold.data_ptr(), scal.data_ptr(), flags.data_ptr(), eps, p,
-                                            dev.index, s), "tsgu_cg_alpha")
-                _be.check(lib.tsgu_cg_update1(vt, n, p, r.data_ptr(), Ap.data_ptr(), x.data_ptr(), pvec.data_ptr(),
-                                              scal.data_ptr(), flags.data_ptr(), rr_partial.data_ptr(), dev.index, s),
-                          "tsgu_cg_update1")
-                _be.check(lib.tsgu_cg_beta(vt, rr_partial.data_ptr(), nb_upd, scal.data_ptr(), flags.data_ptr(), eps,
-                                           stop_after, float(tolerance), kk, min_iter_index, p, dev.index, s),
-                          "tsgu_cg_beta")
-                _be.check(lib.tsgu_cg_update2(vt, n, p, r.data_ptr(), pvec.data_ptr(), scal.data_ptr(),
-                                              flags.data_ptr(), dev.index, s), "tsgu_cg_update2")
-            k = upto
+            if try_graph and graph is None and k > min_iter_index and n_iter - k >= _graph.MIN_ITERS:
+                # long solves: capture _POLL iterations once as a hipGraph and replay it (one host call per
+                # chunk instead of 6 launches per iteration; finished iterations are device-side no-ops)
+                graph = _graph.capture(iteration, _POLL)
+                try_graph = graph is not None
+            if graph is not None and k + _POLL <= n_iter:
+                _graph.replay(graph)
+                k += _POLL
+            else:
+                upto = min(n_iter, max(k + _POLL, min_iter_index + 1) if k <= min_iter_index else k + _POLL)
+                for _ in range(k, upto):
+                    iteration()
+                k = upto
             head = flags[:2].tolist()  # the only device→host read: [done, iterations executed]
             done = head[0] != 0
     k_done = int(flags[1].item())
