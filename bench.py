@@ -107,7 +107,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
 
     from torchsparsegradutils_amd import _backend as be
-    from torchsparsegradutils_amd import _pattern, sparse_mm
+    from torchsparsegradutils_amd import _ops, _pattern, sparse_mm
     from torchsparsegradutils_amd.utils import synthetic
 
     be.load_library()  # fail loudly if the HIP extension is missing
@@ -159,17 +159,25 @@ def main():
     pt = plan.transposed
     Bd, vd = B.detach(), val
     reps = max(args.steps, 20)
+    # the fused backward the step really runs: block-dictionary kernel when the pattern qualifies (C2 does)
+    uses_block = _ops._block_for(pt, G, Bd) is not None
+    bwd_name = ("csr_blocktile_kernel (K2+K3 fused bwd, block dictionary)" if uses_block
+                else "csr_mm_backward_kernel (K2+K3 fused bwd)")
     kern = {
         "csr_spmm_kernel (K1 fwd)": time_events(lambda: be.csr_spmm(plan.crow, plan.col, vd, Bd, n, n), reps, dev),
-        "csr_mm_backward_kernel (K2+K3 fused bwd)": time_events(lambda: be.csr_mm_backward(pt, vd, G, Bd, n, n), reps, dev),
+        bwd_name: time_events(lambda: _ops.mm_backward(plan, vd, G, Bd), reps, dev),
     }
-    # the two kernels the fused backward replaces, for reference (not part of the step)
+    # kernels the fused backward replaces, for reference (not part of the step)
     kern_alt = {
         "csr_sddmm_kernel (K3 alone)": time_events(lambda: be.csr_sddmm(plan.crow, plan.col, G, Bd, n, n), reps, dev),
         "csr_spmm_kernel perm (K2 alone)": time_events(lambda: be.csr_spmm(pt.crow, pt.col, vd, G, n, n, perm=pt.perm), reps, dev),
     }
     ab = alg_bytes(n, nnz, p)
-    kbytes = {"csr_spmm_kernel (K1 fwd)": ab["spmm"], "csr_mm_backward_kernel (K2+K3 fused bwd)": ab["fwd_bwd"] - ab["spmm"],
+    if uses_block:
+        kern_alt["csr_mm_backward_kernel (K2+K3 fused bwd, plain gather)"] = time_events(
+            lambda: be.csr_mm_backward(pt, vd, G, Bd, n, n), reps, dev)
+    kbytes = {"csr_spmm_kernel (K1 fwd)": ab["spmm"], bwd_name: ab["fwd_bwd"] - ab["spmm"],
+              "csr_mm_backward_kernel (K2+K3 fused bwd, plain gather)": ab["fwd_bwd"] - ab["spmm"],
               "csr_sddmm_kernel (K3 alone)": ab["sddmm"], "csr_spmm_kernel perm (K2 alone)": ab["spmm_t"]}
     dominant = max(kern, key=kern.get)
     traffic = None
@@ -222,7 +230,7 @@ def main():
                 "workload": f"C2: CSR SpMM+backward, periodic 27-pt stencil {nx}x{ny}x{nz} (N={n}, nnz={nnz}), {p} RHS, "
                             "fp32 values / int32 indices, sparse_mm fwd + backward through the autograd API; one such item per GPU",
                 "algorithmic_bytes_per_step_per_gpu": ab["fwd_bwd"],
-                "pattern_plan": "transposed pattern cached per sparsity pattern (built in warm-up, "
+                "pattern_plan": "transposed pattern + block dictionary cached per sparsity pattern (built in warm-up, "
                                 f"first step incl. build: {cold_ms:.1f} ms)",
             },
             "gflops": round(flops / (ms_per_step * 1e-3) / 1e9, 1),

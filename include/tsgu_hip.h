@@ -128,6 +128,43 @@ int tsgu_csr_mm_backward(int vtype, int itype, int64_t n_rows, int64_t n_cols, i
                          int64_t p, int64_t batch, int device, void* stream);
 
 /*
+ * Workgroup-tiled variants of K1/K2 and of the fused backward ("blocktile"): same reference lines as
+ * tsgu_csr_spmm (sparse_matmul.py:169,229) and tsgu_csr_mm_backward (sparse_matmul.py:186-205,229).
+ * The distinct dense rows a block of `rpb` consecutive sparse rows references are DMA-ed into LDS once
+ * and every stored entry reads its dense row from there (2.8x less L1 traffic at the 27-point stencil);
+ * the 4-byte column index is replaced by a 16-bit local index.  Plan, built once per pattern:
+ *   ndist [nblocks]        int32   distinct dense rows of block b, nblocks = ceil(n_rows / rpb)
+ *   trow  [nblocks][capd]  int32   their indices, padded by repeating the last one
+ *   ent   [nnz]            uint32  per entry, in the walked pattern's order: local index | slot << 16
+ *   sperm [nnz]            int32   (walked pattern addresses the values through a permutation, e.g. the
+ *                                   transposed pattern) positions in the value array, ascending inside each
+ *                                   block; `slot` = where the entry's value sits in that order.  NULL when
+ *                                   the values are in the walked order (slot unused).
+ * `tile` = 1: dense rows staged in LDS as described; `tile` = 0: only the dictionary (trow) is staged and the
+ * dense rows are gathered from global memory — same plan, keeps the sorted-permutation value / gradA accesses
+ * (3x fewer scattered L1 accesses at the stencil) at full occupancy; measured faster than both the LDS-tile
+ * variant and tsgu_csr_mm_backward at C2 (351 vs 393 vs 412 us).
+ * Limits (tsgu_blocktile_limits, per `tile`): capd a multiple of `distinct_multiple`, <= max_distinct; entries
+ * per block <= ecap <= max_entries, ecap a multiple of 256; (tile ? capd·p·4 : capd·4) + ecap·8 <=
+ * lds_budget_bytes.  fp32, p in {16, 32, 64}, 16-byte aligned dense operands with ld % 4 == 0, 2-D operands;
+ * anything else: gather kernels.  rpb·(p/4) must divide 256 (rows_per_block reports the preferred value).
+ * Summation order per output row is the stored entry order (as K1).
+ */
+int tsgu_blocktile_limits(int vtype, int64_t p, int tile, int* rows_per_block, int* distinct_multiple, int* max_distinct,
+                          int* max_entries, int* lds_budget_bytes);
+int tsgu_csr_spmm_blocktile(int vtype, int itype, int64_t n_rows, int64_t nnz, const void* ptr,
+                            const void* ndist, const void* trow, int capd, int ecap, int rpb, int tile,
+                            const void* ent, const void* sperm, const void* val,
+                            const void* B, int64_t ldb, void* C, int64_t ldc, int64_t p,
+                            int device, void* stream);
+int tsgu_csr_mm_backward_blocktile(int vtype, int itype, int64_t n_rows_t, int64_t nnz, const void* t_ptr,
+                                   const void* ndist, const void* trow, int capd, int ecap, int rpb, int tile,
+                                   const void* ent, const void* sperm, const void* val,
+                                   const void* G, int64_t ldg, const void* B, int64_t ldb,
+                                   void* gradA_vals, void* gradB, int64_t ldgb, int64_t p,
+                                   int device, void* stream);
+
+/*
  * Wave-pipelined, LDS-tiled variants of K1/K2/K3 ("wavetile") for patterns whose neighbouring rows
  * share columns (stencils, banded matrices).  They replace the same reference lines as
  * tsgu_csr_spmm / tsgu_csr_sddmm and produce bit-identical results; the operand rows a wave needs

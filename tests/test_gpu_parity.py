@@ -188,6 +188,58 @@ def test_mm_ragged_and_empty_rows_long_row():
     assert torch.count_nonzero(out) == 0 and out.shape == (4, 3)
 
 
+@pytest.mark.parametrize("p", [16, 32, 64])
+@pytest.mark.parametrize("itype", [torch.int32, torch.int64])
+def test_block_dictionary_kernels_match_oracle(p, itype, monkeypatch):
+    """csrc/blocktile_impl.h through the C ABI, both flavours (LDS tile / gather from global), forward and
+    transposed walks and the fused backward, on a ragged rectangular banded pattern (empty rows, a tail block,
+    rows of 0..40 entries) against the CPU oracle; then the same through sparse_mm with the selection forced."""
+    from oracle import oracle
+    from torchsparsegradutils_amd import _backend as be, _ops, _pattern
+
+    rng = np.random.default_rng(10 + p)
+    n, m = 2051, 1900
+    rows = rng.integers(0, n, 40000)
+    cols = np.clip(rows * m // n + rng.integers(-9, 10, 40000), 0, m - 1)
+    rows[rows % 13 == 0] += 1
+    A = torch.sparse_coo_tensor(np.stack([rows, cols]), rng.standard_normal(40000), (n, m)).coalesce()
+    Ac = A.to_sparse_csr()
+    crow, col, val = (x.numpy() for x in (Ac.crow_indices(), Ac.col_indices(), Ac.values()))
+    val = val.astype(np.float32)
+    B = rng.standard_normal((m, p)).astype(np.float32)
+    Gd = rng.standard_normal((n, p)).astype(np.float32)
+    C_o, gA_o, gB_o = oracle.sparse_mm_fwd_bwd(crow, col, val, B, Gd, m)
+
+    g = _pattern.RowGather(G.t(crow, DEV).to(itype), G.t(col, DEV).to(itype), n, m)
+    gt = g.transposed
+    vd, Bd, Gdev = G.t(val, DEV), G.t(B, DEV), G.t(Gd, DEV)
+    for tile in (True, False):
+        geo = be.blocktile_limits(torch.float32, p, tile=tile)
+        assert geo is not None
+        bp, bpt = g.block_plan(*geo), gt.block_plan(*geo)
+        assert bp is not None and bpt is not None and bp.sperm is None and bpt.sperm is not None
+        assert rel(be.csr_spmm_blocktile(g.crow, vd, bp, Bd, n, tile=tile), C_o) < 1e-5
+        assert rel(be.csr_spmm_blocktile(gt.crow, vd, bpt, Gdev, m, tile=tile), gB_o) < 1e-5
+        gA, gB = be.csr_mm_backward_blocktile(gt.crow, bpt, vd, Gdev, Bd, m, tile=tile)
+        assert rel(gA, gA_o) < 1e-5 and rel(gB, gB_o) < 1e-5
+        # p >= 32: one lane group per row in both kernel families, i.e. the same order of summation as K2
+        if p >= 32:
+            assert torch.equal(gB, be.csr_spmm(gt.crow, gt.col, vd, Gdev, m, n, perm=gt.perm))
+
+    # public API with the selection forced for this (small) pattern
+    monkeypatch.setattr(_ops, "BLOCK_MIN_NNZ", 0)
+    Ad = torch.sparse_csr_tensor(g.crow, g.col, vd, (n, m)).requires_grad_(True)
+    Bq = Bd.clone().requires_grad_(True)
+    Cq = tsgu().sparse_mm(Ad, Bq)
+    Cq.backward(Gdev)
+    assert rel(Cq, C_o) < 1e-5 and rel(Ad.grad.values(), gA_o) < 1e-5 and rel(Bq.grad, gB_o) < 1e-5
+    assert _pattern.from_csr(Ad).transposed._blocks, "the block-dictionary plan was not used"
+    # only B needs a gradient: transposed SpMM through the dictionary
+    Bq2 = Bd.clone().requires_grad_(True)
+    tsgu().sparse_mm(Ad.detach(), Bq2).backward(Gdev)
+    assert torch.equal(Bq2.grad, Bq.grad)
+
+
 def test_mm_short_rows_multi_run_workgroups_and_cg_dot_epilogue():
     """Short rows (several runs of rows per workgroup), with one row longer than the staging window inside
     such a workgroup, for p in {1, 4, 5}; plus the fused pᵀ(Ap) epilogue against a plain column dot."""

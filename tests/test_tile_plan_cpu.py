@@ -49,3 +49,66 @@ def test_plan_refused_when_limits_or_reuse_fail():
     A = torch.sparse_coo_tensor(torch.stack((idx // 4000, idx % 4000)), torch.ones(12000), (4000, 4000)).coalesce().to_sparse_csr()
     gr = P.RowGather(A.crow_indices(), A.col_indices(), 4000, 4000)
     assert P.build_tile_plan(gr, 8, 128, 256) is None
+
+
+# ------------------------------------------------------------------ block-dictionary plan (blocktile kernels) ----
+def _check_block(g, rpb, row_bytes, limits):
+    bp = P.build_block_plan(g, rpb, row_bytes, limits)
+    assert bp is not None
+    n, nnz = g.n_rows, g.nnz
+    nb = (n + rpb - 1) // rpb
+    assert bp.ndist.shape == (nb,) and bp.trow.shape == (nb, bp.capd) and bp.ent.shape == (nnz,)
+    assert bp.ndist.dtype == bp.trow.dtype == bp.ent.dtype == torch.int32
+    assert bp.capd % limits[0] == 0 and bp.ecap % 256 == 0
+    blk = g.row_indices().long() // rpb
+    e0 = g.crow[torch.arange(0, n, rpb)].long()
+    ent = bp.ent.long() & 0xFFFFFFFF
+    lidx, slot = ent & 0xFFFF, ent >> 16
+    # every entry finds its column through the block's dictionary
+    assert torch.equal(bp.trow[blk, lidx].long(), g.col.long())
+    assert bool((lidx < bp.ndist[blk]).all())
+    # dictionary rows are distinct, padding repeats the last valid one
+    for b in (0, nb // 2, nb - 1):
+        c = int(bp.ndist[b])
+        assert len(set(bp.trow[b, :c].tolist())) == c and torch.all(bp.trow[b, c:] == bp.trow[b, c - 1])
+    if g.perm is None:
+        assert bp.sperm is None and bool((slot == 0).all())
+    else:
+        assert bp.sperm.dtype == torch.int32
+        # the sorted permutation holds each block's positions ascending, and slot points at the entry's own value
+        assert torch.equal(bp.sperm[(e0[blk] + slot)].long(), g.perm.long())
+        ends = torch.cat((e0[1:], g.crow[-1:].long()))
+        for b in (0, nb // 3, nb - 1):
+            seg = bp.sperm[int(e0[b]) : int(ends[b])]
+            assert bool((seg[1:] > seg[:-1]).all())
+            assert sorted(seg.tolist()) == sorted(g.perm[int(e0[b]) : int(ends[b])].tolist())
+    return bp
+
+
+def test_block_plan_forward_and_transposed_and_limits():
+    crow, col = synthetic.stencil27_periodic(12, 10, 9, torch.int32)
+    g = P.RowGather(crow, col, 1080, 1080)
+    lim_tile, lim_gather = (8, 512, 2048, 65536), (4, 1024, 2048, 65536)
+    bp = _check_block(g, 32, 128, lim_tile)
+    assert bp.reuse > 2.0 and bp.rpb == 32
+    bpt = _check_block(g.transposed, 32, 4, lim_gather)
+    assert bpt.sperm is not None
+    _check_block(g.transposed, 16, 128, lim_tile)
+    # cached per (rows per block, row size, limits)
+    assert g.block_plan(32, 128, lim_tile) is g.block_plan(32, 128, lim_tile)
+    # limits: distinct rows, entries per block, LDS budget
+    assert P.build_block_plan(g, 32, 128, (8, 64, 2048, 65536)) is None
+    assert P.build_block_plan(g, 32, 128, (8, 512, 512, 65536)) is None
+    assert P.build_block_plan(g, 32, 128, (8, 512, 2048, 16384)) is None
+
+
+def test_block_plan_ragged_rows_and_tail_block():
+    gen = torch.Generator().manual_seed(4)
+    n, m = 1003, 900   # n not a multiple of the block height, empty rows, rectangular
+    rows = torch.randint(0, n, (9000,), generator=gen)
+    cols = (rows * m // n + torch.randint(-6, 7, (9000,), generator=gen)).clamp(0, m - 1)
+    rows[rows % 17 == 0] += 1  # every 17th row is empty, its neighbour twice as long
+    A = torch.sparse_coo_tensor(torch.stack((rows, cols)), torch.ones(9000), (n, m)).coalesce().to_sparse_csr()
+    g = P.RowGather(A.crow_indices(), A.col_indices(), n, m)
+    _check_block(g, 32, 128, (8, 512, 2048, 65536))
+    _check_block(g.transposed, 64, 4, (4, 1024, 2048, 65536))

@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--reps", type=int, default=50)
     ap.add_argument("--only", default="spmm,sddmm,spmmt,bwd_fused,spmm_tiled,sddmm_tiled,spmmt_tiled,bwd_tiled")
     ap.add_argument("--check", action="store_true")
+    ap.add_argument("--rpb", type=int, nargs="*", default=[8, 16, 32], help="block heights for the workgroup-tiled kernels")
     ap.add_argument("--pattern", default="stencil27", help="stencil27 | diag27 (27 copies of own row) | band27 (cols = row-13..row+13)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -74,7 +75,42 @@ def main():
             fns["spmmt_tiled"] = lambda: be.csr_spmm_tiled(pt.crow, val, tlt, G, n, n, perm=pt.perm)
             by["bwd_tiled"] = by["bwd_fused"]
             fns["bwd_tiled"] = lambda: be.csr_mm_backward_tiled(pt, tlt, val, G, B, n, n)
-    for k in a.only.split(","):
+    lim = be.blocktile_limits(torch.float32, p, tile=True)
+    if lim is not None:
+        lim = lim[2]
+        import time as _t
+        for rpb in a.rpb:
+            t0 = _t.perf_counter()
+            bp, bpt = plan.block_plan(rpb, p * 4, lim), pt.block_plan(rpb, p * 4, lim)
+            torch.cuda.synchronize()
+            if bp is None or bpt is None:
+                print(f"block plan rpb={rpb}: not available (fwd {bp is not None}, transposed {bpt is not None})")
+                continue
+            print(f"block plan rpb={rpb}: capd={bp.capd}/{bpt.capd} ecap={bp.ecap}/{bpt.ecap} reuse={bp.reuse:.2f} build {(_t.perf_counter()-t0)*1e3:.0f} ms")
+            by[f"spmm_bt{rpb}"] = by["spmm"]; by[f"spmmt_bt{rpb}"] = by["spmm"]; by[f"bwd_bt{rpb}"] = by["bwd_fused"]
+            fns[f"spmm_bt{rpb}"] = (lambda bp=bp: be.csr_spmm_blocktile(crow, val, bp, B, n))
+            fns[f"spmmt_bt{rpb}"] = (lambda bpt=bpt: be.csr_spmm_blocktile(pt.crow, val, bpt, G, n))
+            fns[f"bwd_bt{rpb}"] = (lambda bpt=bpt: be.csr_mm_backward_blocktile(pt.crow, bpt, val, G, B, n))
+            by[f"spmm_bg{rpb}"] = by["spmm"]; by[f"spmmt_bg{rpb}"] = by["spmm"]; by[f"bwd_bg{rpb}"] = by["bwd_fused"]
+            fns[f"spmm_bg{rpb}"] = (lambda bp=bp: be.csr_spmm_blocktile(crow, val, bp, B, n, tile=False))
+            fns[f"spmmt_bg{rpb}"] = (lambda bpt=bpt: be.csr_spmm_blocktile(pt.crow, val, bpt, G, n, tile=False))
+            fns[f"bwd_bg{rpb}"] = (lambda bpt=bpt: be.csr_mm_backward_blocktile(pt.crow, bpt, val, G, B, n, tile=False))
+            if a.check:
+                C0 = fns["spmm"](); C1 = fns[f"spmm_bg{rpb}"]()
+                D0 = fns["spmmt"](); D1 = fns[f"spmmt_bg{rpb}"]()
+                gA0, gB0 = fns["bwd_fused"](); gA1, gB1 = fns[f"bwd_bg{rpb}"]()
+                print(f"  *_bg{rpb} vs gather: spmm {float((C0 - C1).abs().max())} spmmt {float((D0 - D1).abs().max())} gradA {float((gA0 - gA1).abs().max())} gradB {float((gB0 - gB1).abs().max())}")
+            if a.check:
+                C0 = fns["spmm"](); C1 = fns[f"spmm_bt{rpb}"]()
+                print(f"  spmm_bt{rpb} vs gather: max abs diff {float((C0 - C1).abs().max())}")
+                D0 = fns["spmmt"](); D1 = fns[f"spmmt_bt{rpb}"]()
+                print(f"  spmmt_bt{rpb} vs gather: max abs diff {float((D0 - D1).abs().max())}")
+                gA0, gB0 = fns["bwd_fused"](); gA1, gB1 = fns[f"bwd_bt{rpb}"]()
+                print(f"  bwd_bt{rpb} vs fused gather: gradA {float((gA0 - gA1).abs().max())} gradB {float((gB0 - gB1).abs().max())}")
+    only = a.only.split(",")
+    if "bt" in only:
+        only += [k for k in fns if "_bt" in k or "_bg" in k]
+    for k in only:
         if k not in fns:
             continue
         ms = ev(fns[k], a.reps)

@@ -54,6 +54,21 @@ SIGNATURES = {
         [_int, _int, _i64, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _ptr, _i64, _i64, _ptr, _ptr, _i64,
          _i64, _i64, _i64, _int, _ptr],
     ),
+    "tsgu_blocktile_limits": (
+        _int,
+        [_int, _i64, _int, ctypes.POINTER(_int), ctypes.POINTER(_int), ctypes.POINTER(_int), ctypes.POINTER(_int),
+         ctypes.POINTER(_int)],
+    ),
+    "tsgu_csr_spmm_blocktile": (
+        _int,
+        [_int, _int, _i64, _i64, _ptr, _ptr, _ptr, _int, _int, _int, _int, _ptr, _ptr, _ptr, _ptr, _i64, _ptr, _i64,
+         _i64, _int, _ptr],
+    ),
+    "tsgu_csr_mm_backward_blocktile": (
+        _int,
+        [_int, _int, _i64, _i64, _ptr, _ptr, _ptr, _int, _int, _int, _int, _ptr, _ptr, _ptr, _ptr, _i64, _ptr, _i64,
+         _ptr, _ptr, _i64, _i64, _int, _ptr],
+    ),
     "tsgu_wavetile_geometry": (_int, [_int, _i64, ctypes.POINTER(_int), ctypes.POINTER(_int), ctypes.POINTER(_int)]),
     "tsgu_csr_spmm_wavetile": (
         _int,
@@ -287,6 +302,59 @@ def tiled_geometry(dtype: torch.dtype, p: int):
     if lib.tsgu_wavetile_geometry(_VTYPE[dtype], p, ctypes.byref(rpt), ctypes.byref(mx), ctypes.byref(me)) != 0:
         return None
     return rpt.value, mx.value, me.value
+
+
+def blocktile_limits(dtype: torch.dtype, p: int, tile: bool = False):
+    """(rows_per_block, row_bytes, (distinct_multiple, max_distinct, max_entries, lds_budget_bytes)) of the
+    block-dictionary kernels (LDS-tiled or gather-from-global flavour), or None when (dtype, p) is not covered."""
+    if dtype != torch.float32 or p <= 0:
+        return None
+    lib = load_library()
+    r, a, b, c, d = _int(0), _int(0), _int(0), _int(0), _int(0)
+    if lib.tsgu_blocktile_limits(_VTYPE[dtype], p, int(tile), ctypes.byref(r), ctypes.byref(a), ctypes.byref(b),
+                                 ctypes.byref(c), ctypes.byref(d)) != 0:
+        return None
+    return r.value, (p * 4 if tile else 4), (a.value, b.value, c.value, d.value)
+
+
+def csr_spmm_blocktile(crow, val, bp, B, n_rows: int, tile: bool = True):
+    """C = A·B through the workgroup-tiled kernel; `bp` is a _pattern.BlockPlan of the walked pattern."""
+    lib = load_library()
+    dev = require_device(crow, val, B)
+    B = rowmajor(B)
+    p = B.size(-1)
+    out = torch.empty((n_rows, p), dtype=B.dtype, device=dev)
+    with torch.cuda.device(dev):
+        check(
+            lib.tsgu_csr_spmm_blocktile(
+                vtype_of(val), itype_of(crow), n_rows, bp.nnz, _p(crow), _p(bp.ndist), _p(bp.trow), bp.capd, bp.ecap,
+                bp.rpb, int(tile), _p(bp.ent), _p(bp.sperm), _p(val.contiguous()), _p(B), _ld(B), _p(out), _ld(out), p,
+                dev.index, _stream(dev),
+            ),
+            "tsgu_csr_spmm_blocktile",
+        )
+    return out
+
+
+def csr_mm_backward_blocktile(tcrow, bp, val, G, B, n_rows_t: int, tile: bool = True):
+    """(gradA values in A's order, gradB) in one pass over the transposed pattern's BlockPlan."""
+    lib = load_library()
+    dev = require_device(tcrow, val, G, B)
+    G, B = rowmajor(G), rowmajor(B)
+    p = G.size(-1)
+    val = val.contiguous()
+    grad_a = torch.empty_like(val)
+    grad_b = torch.empty((n_rows_t, p), dtype=G.dtype, device=dev)
+    with torch.cuda.device(dev):
+        check(
+            lib.tsgu_csr_mm_backward_blocktile(
+                vtype_of(val), itype_of(tcrow), n_rows_t, bp.nnz, _p(tcrow), _p(bp.ndist), _p(bp.trow), bp.capd,
+                bp.ecap, bp.rpb, int(tile), _p(bp.ent), _p(bp.sperm), _p(val), _p(G), _ld(G), _p(B), _ld(B),
+                _p(grad_a), _p(grad_b), _ld(grad_b), p, dev.index, _stream(dev),
+            ),
+            "tsgu_csr_mm_backward_blocktile",
+        )
+    return grad_a, grad_b
 
 
 def _tiled_ok(*dense) -> bool:

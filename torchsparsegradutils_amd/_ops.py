@@ -16,6 +16,33 @@ from ._pattern import RowGather
 ENABLE_TILED = os.environ.get("TSGU_ENABLE_TILED", "0") == "1"
 
 
+# Block-dictionary kernels (csrc/blocktile_impl.h, gather-from-global flavour): used for operands addressed through
+# a permutation (transposed patterns: gradB = Aᵀ·G and the fused backward), where the per-block sorted permutation
+# turns the 4-byte scattered value / gradA accesses into short runs.  TSGU_ENABLE_BLOCK=0 falls back to K2 / the
+# plain fused backward.  Patterns below the size threshold stay on the plan-free kernels (launch-bound anyway).
+ENABLE_BLOCK = os.environ.get("TSGU_ENABLE_BLOCK", "1") == "1"
+BLOCK_MIN_NNZ = 1 << 16
+
+
+def _block_for(plan: RowGather, dense: torch.Tensor, *others: torch.Tensor):
+    if (not ENABLE_BLOCK or plan.batch is not None or plan.perm is None or dense.dim() != 2
+            or plan.nnz < BLOCK_MIN_NNZ or plan.crow.dtype not in (torch.int32, torch.int64)):
+        return None
+    geo = _be.blocktile_limits(dense.dtype, dense.size(-1), tile=False)
+    if geo is None or not _be._tiled_ok(*(_be.rowmajor(t) for t in (dense,) + others)):
+        return None
+    return plan.block_plan(*geo)
+
+
+def mm_backward(plan: RowGather, values: torch.Tensor, G: torch.Tensor, B: torch.Tensor):
+    """(gradA values in A's order, gradB) of C = A·B in one pass over the transposed pattern."""
+    t = plan.transposed
+    bp = _block_for(t, G, B) if values.dtype == G.dtype == B.dtype else None
+    if bp is not None:
+        return _be.csr_mm_backward_blocktile(t.crow, bp, values, G, B, t.n_rows, tile=False)
+    return _be.csr_mm_backward(t, values, G, B, plan.n_rows, plan.n_cols)
+
+
 def _tiles_for(plan: RowGather, dense: torch.Tensor, *others: torch.Tensor):
     if not ENABLE_TILED or plan.batch is not None or dense.dim() != 2:
         return None
@@ -29,6 +56,9 @@ def _tiles_for(plan: RowGather, dense: torch.Tensor, *others: torch.Tensor):
 
 def spmm(plan: RowGather, values: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
     """A·B for the operand described by (plan, values); perm-aware (transposed / un-coalesced plans)."""
+    bp = _block_for(plan, B) if values.dtype == B.dtype else None
+    if bp is not None:
+        return _be.csr_spmm_blocktile(plan.crow, values, bp, B, plan.n_rows, tile=False)
     tiles = _tiles_for(plan, B) if values.dtype == B.dtype else None
     if tiles is not None:
         return _be.csr_spmm_tiled(plan.crow, values, tiles, B, plan.n_rows, plan.n_cols, perm=plan.perm)

@@ -27,7 +27,7 @@ class RowGather:
     col, position of each entry in the owner's value array (None = identity).
     """
 
-    __slots__ = ("crow", "col", "perm", "n_rows", "n_cols", "batch", "_t", "_has_diag", "_rows", "_tiles")
+    __slots__ = ("crow", "col", "perm", "n_rows", "n_cols", "batch", "_t", "_has_diag", "_rows", "_tiles", "_blocks")
 
     def __init__(self, crow, col, n_rows, n_cols, perm=None):
         self.crow, self.col, self.perm = crow, col, perm
@@ -37,6 +37,15 @@ class RowGather:
         self._has_diag: Optional[bool] = None
         self._rows = None
         self._tiles = {}
+        self._blocks = {}
+
+    def block_plan(self, rows_per_block: int, row_bytes: int, limits):
+        """Plan for the workgroup-tiled kernels (csrc/blocktile_impl.h), None when the pattern does not
+        qualify or profit; cached per block height / dense row size.  See `build_block_plan`."""
+        key = (rows_per_block, row_bytes, tuple(limits))
+        if key not in self._blocks:
+            self._blocks[key] = build_block_plan(self, rows_per_block, row_bytes, limits)
+        return self._blocks[key]
 
     def tiles(self, rows_per_task: int, max_distinct: int, max_entries: int):
         """Plan for the wave-pipelined LDS-tiled kernels (None when the pattern does not qualify or
@@ -132,6 +141,62 @@ def build_tile_plan(g: RowGather, rows_per_task: int, cap_distinct: int, cap_ent
     lidx[task, pos] = local
     tmeta = torch.stack((e0, ne), dim=1).to(torch.int32).contiguous()
     return TilePlan(tmeta, tile_cols, lidx, reuse, top, int(ne.max()), nnz)
+
+
+class BlockPlan:
+    """Per-block dictionary of distinct dense rows + packed entry words for tsgu_csr_*_blocktile
+    (layout: include/tsgu_hip.h)."""
+
+    __slots__ = ("ndist", "trow", "ent", "sperm", "capd", "ecap", "rpb", "reuse", "nnz")
+
+    def __init__(self, ndist, trow, ent, sperm, capd, ecap, rpb, reuse, nnz):
+        self.ndist, self.trow, self.ent, self.sperm = ndist, trow, ent, sperm
+        self.capd, self.ecap, self.rpb, self.reuse, self.nnz = capd, ecap, rpb, reuse, nnz
+
+
+def build_block_plan(g: RowGather, rpb: int, row_bytes: int, limits):
+    """Blocks of `rpb` consecutive rows: distinct column indices per block (`trow`, padded to `capd`), a 16-bit
+    local index per stored entry and — for plans that address the owner's values through `perm`
+    (transposed / un-coalesced) — the permutation sorted inside each block (`sperm`) with each entry's slot in
+    that order (`ent = lidx | slot << 16`).  Two device sorts per pattern, amortised over every later call.
+    `limits` = (distinct_multiple, max_distinct, max_entries, lds_budget_bytes) from tsgu_blocktile_limits."""
+    mult, max_distinct, max_entries, lds_budget = limits
+    if g.batch is not None or g.n_rows == 0 or not (1 <= g.nnz < 2**31):
+        return None
+    n, m, nnz = g.n_rows, g.n_cols, g.nnz
+    dev = g.crow.device
+    nb = (n + rpb - 1) // rpb
+    e0 = g.crow[torch.arange(0, n, rpb, device=dev)].to(torch.int64)
+    ne = torch.cat((e0[1:], g.crow[-1:].to(torch.int64))) - e0
+    ecap = (int(ne.max()) + 255) // 256 * 256
+    if ecap == 0 or ecap > max_entries:
+        return None
+    blk = g.row_indices().to(torch.int64) // rpb
+    uniq, inv = torch.unique(blk * m + g.col.to(torch.int64), return_inverse=True)
+    total = uniq.numel()
+    reuse = nnz / max(total, 1)
+    if reuse < _TILE_MIN_REUSE:
+        return None
+    ublk = uniq // m
+    cnt = torch.bincount(ublk, minlength=nb)
+    capd = (int(cnt.max()) + mult - 1) // mult * mult
+    if capd > max_distinct or capd * row_bytes + ecap * 8 > lds_budget or nb * capd > _TILE_MAX_PADDING * total + 4096:
+        return None
+    first = torch.cumsum(cnt, 0) - cnt
+    d = torch.arange(capd, device=dev).unsqueeze(0)
+    src = first.unsqueeze(1) + torch.minimum(d, (cnt - 1).clamp_min(0).unsqueeze(1))
+    trow = (uniq - ublk * m).to(torch.int32)[src.clamp_max(total - 1)].contiguous()
+    ent = (inv - first[blk]).to(torch.int64)
+    sperm = None
+    if g.perm is not None:
+        # entries are stored block after block, so sorting (block, perm) permutes inside each block only
+        order = torch.argsort(blk * nnz + g.perm.to(torch.int64))
+        sperm = g.perm[order].to(torch.int32).contiguous()
+        slot = torch.empty(nnz, dtype=torch.int64, device=dev)
+        slot[order] = torch.arange(nnz, device=dev, dtype=torch.int64) - e0[blk[order]]
+        ent = ent | (slot << 16)
+    ent = ent.to(torch.int32).contiguous()  # bit pattern of the uint32 word (slot < 2048)
+    return BlockPlan(cnt.to(torch.int32).contiguous(), trow, ent, sperm, capd, ecap, rpb, reuse, nnz)
 
 
 def _transpose(g: RowGather) -> RowGather:

@@ -136,7 +136,7 @@ class SparseMatMul(torch.autograd.Function):
         if (need_a and need_b and plan.perm is None and G.dtype == B.dtype == values.dtype
                 and _be.fused_backward_supported(G.dtype, G.size(-1))):
             # both gradients in one pass: each upstream row G[i,:] is gathered once (reference :172-229)
-            gvals, gradB = _be.csr_mm_backward(plan.transposed, values, G, B, plan.n_rows, plan.n_cols)
+            gvals, gradB = _ops.mm_backward(plan, values, G, B)
             gradA = op.rebuild(gvals)
             if ctx.batch_size is not None:
                 gradB = gradB.view(ctx.B_shape)
