@@ -160,11 +160,14 @@ def main():
     Bd, vd = B.detach(), val
     reps = max(args.steps, 20)
     # the fused backward the step really runs: block-dictionary kernel when the pattern qualifies (C2 does)
-    uses_block = _ops._block_for(pt, G, Bd) is not None
-    bwd_name = ("csr_blocktile_kernel (K2+K3 fused bwd, block dictionary)" if uses_block
+    uses_pack = _ops._pack_for(pt, G, Bd) is not None
+    uses_block = uses_pack or _ops._block_for(pt, G, Bd) is not None
+    bwd_name = ("csr_rowpack_kernel (K2+K3 fused bwd, row pairs)" if uses_pack
+                else "csr_blocktile_kernel (K2+K3 fused bwd, block dictionary)" if uses_block
                 else "csr_mm_backward_kernel (K2+K3 fused bwd)")
+    fwd_name = "csr_rowpack_kernel (K1 fwd, row pairs)" if _ops._pack_for(plan, Bd) is not None else "csr_spmm_kernel (K1 fwd)"
     kern = {
-        "csr_spmm_kernel (K1 fwd)": time_events(lambda: be.csr_spmm(plan.crow, plan.col, vd, Bd, n, n), reps, dev),
+        fwd_name: time_events(lambda: _ops.spmm(plan, vd, Bd), reps, dev),
         bwd_name: time_events(lambda: _ops.mm_backward(plan, vd, G, Bd), reps, dev),
     }
     # kernels the fused backward replaces, for reference (not part of the step)
@@ -176,7 +179,9 @@ def main():
     if uses_block:
         kern_alt["csr_mm_backward_kernel (K2+K3 fused bwd, plain gather)"] = time_events(
             lambda: be.csr_mm_backward(pt, vd, G, Bd, n, n), reps, dev)
-    kbytes = {"csr_spmm_kernel (K1 fwd)": ab["spmm"], bwd_name: ab["fwd_bwd"] - ab["spmm"],
+    if fwd_name != "csr_spmm_kernel (K1 fwd)":
+        kern_alt["csr_spmm_kernel (K1 fwd)"] = time_events(lambda: be.csr_spmm(plan.crow, plan.col, vd, Bd, n, n), reps, dev)
+    kbytes = {"csr_spmm_kernel (K1 fwd)": ab["spmm"], fwd_name: ab["spmm"], bwd_name: ab["fwd_bwd"] - ab["spmm"],
               "csr_mm_backward_kernel (K2+K3 fused bwd, plain gather)": ab["fwd_bwd"] - ab["spmm"],
               "csr_sddmm_kernel (K3 alone)": ab["sddmm"], "csr_spmm_kernel perm (K2 alone)": ab["spmm_t"]}
     dominant = max(kern, key=kern.get)
@@ -230,7 +235,7 @@ def main():
                 "workload": f"C2: CSR SpMM+backward, periodic 27-pt stencil {nx}x{ny}x{nz} (N={n}, nnz={nnz}), {p} RHS, "
                             "fp32 values / int32 indices, sparse_mm fwd + backward through the autograd API; one such item per GPU",
                 "algorithmic_bytes_per_step_per_gpu": ab["fwd_bwd"],
-                "pattern_plan": "transposed pattern + block dictionary cached per sparsity pattern (built in warm-up, "
+                "pattern_plan": "transposed pattern + row-pair union plans cached per sparsity pattern (built in warm-up, "
                                 f"first step incl. build: {cold_ms:.1f} ms)",
             },
             "gflops": round(flops / (ms_per_step * 1e-3) / 1e9, 1),

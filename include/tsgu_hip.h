@@ -165,6 +165,35 @@ int tsgu_csr_mm_backward_blocktile(int vtype, int itype, int64_t n_rows_t, int64
                                    int device, void* stream);
 
 /*
+ * Row-pair gather kernels ("rowpack"): same reference lines as tsgu_csr_spmm (sparse_matmul.py:169,229) and
+ * tsgu_csr_mm_backward (sparse_matmul.py:186-205,229).  One lane group owns rows 2q and 2q+1 and walks the sorted
+ * UNION of their column sets, so a dense row both rows reference is gathered once (27-point stencil: 36 gathers
+ * per pair instead of 54).  Plan, built once per pattern:
+ *   uptr [ceil(n_rows/2)+1] int32   union-entry offsets per row pair
+ *   ucol [nu]               int32   dense-row index of each union entry (ascending inside a pair)
+ *   upos [nu]               uint32  two 16-bit halves (low: row 2q, high: row 2q+1): slot of that row's value in
+ *                                   the workgroup's staged value slice; bit 15 set = no entry in this column
+ *   sperm[nnz]              int32   (walked pattern addresses the values through a permutation) positions in the
+ *                                   value array, ascending inside each workgroup's entry range; slots index that
+ *                                   order.  NULL: values are in walked order, slot = entry offset in the workgroup.
+ * A workgroup covers rows_per_block = 2·256/(p/4) consecutive rows; ecap / ucap = capacity of the staged value slice
+ * / union records (multiples of 256, <= the limits, ucap·8 + ecap·4 <= lds_budget_bytes).  fp32, p in {16, 32, 64},
+ * 16-byte aligned dense operands with ld % 4 == 0, 2-D operands.  Each row's sum runs over its own entries in
+ * ascending stored order (bit-identical to the one-group-per-row kernels); a row never touches a dense row it does
+ * not reference (predicated update, no multiply by zero).
+ */
+int tsgu_rowpack_limits(int vtype, int64_t p, int* rows_per_block, int* max_entries, int* max_union, int* lds_budget_bytes);
+int tsgu_csr_spmm_rowpack(int vtype, int itype, int64_t n_rows, int64_t nnz, const void* ptr,
+                          const void* uptr, const void* ucol, const void* upos, int ecap, int ucap,
+                          const void* sperm, const void* val,
+                          const void* B, int64_t ldb, void* C, int64_t ldc, int64_t p, int device, void* stream);
+int tsgu_csr_mm_backward_rowpack(int vtype, int itype, int64_t n_rows_t, int64_t nnz, const void* t_ptr,
+                                 const void* uptr, const void* ucol, const void* upos, int ecap, int ucap,
+                                 const void* sperm, const void* val,
+                                 const void* G, int64_t ldg, const void* B, int64_t ldb,
+                                 void* gradA_vals, void* gradB, int64_t ldgb, int64_t p, int device, void* stream);
+
+/*
  * Wave-pipelined, LDS-tiled variants of K1/K2/K3 ("wavetile") for patterns whose neighbouring rows
  * share columns (stencils, banded matrices).  They replace the same reference lines as
  * tsgu_csr_spmm / tsgu_csr_sddmm and produce bit-identical results; the operand rows a wave needs

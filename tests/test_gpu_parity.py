@@ -226,7 +226,45 @@ def test_block_dictionary_kernels_match_oracle(p, itype, monkeypatch):
         if p >= 32:
             assert torch.equal(gB, be.csr_spmm(gt.crow, gt.col, vd, Gdev, m, n, perm=gt.perm))
 
-    # public API with the selection forced for this (small) pattern
+    # row-pair union kernels on the same operands (forward, transposed, fused backward)
+    geo = be.rowpack_limits(torch.float32, p)
+    assert geo is not None
+    rp, rpt = g.rowpack_plan(*geo), gt.rowpack_plan(*geo)
+    assert rp is not None and rpt is not None and rp.sperm is None and rpt.sperm is not None
+    assert rel(be.csr_spmm_rowpack(g.crow, vd, rp, Bd, n), C_o) < 1e-5
+    gB2 = be.csr_spmm_rowpack(gt.crow, vd, rpt, Gdev, m)
+    gA3, gB3 = be.csr_mm_backward_rowpack(gt.crow, rpt, vd, Gdev, Bd, m)
+    assert rel(gB2, gB_o) < 1e-5 and rel(gA3, gA_o) < 1e-5 and torch.equal(gB2, gB3)
+    if p >= 32:
+        assert torch.equal(gB3, be.csr_spmm(gt.crow, gt.col, vd, Gdev, m, n, perm=gt.perm))
+    # a row must never touch a dense row it does not reference: poison one row of B that only ONE row of a pair uses
+    rows_of = lambda c: set(np.nonzero(col == c)[0].tolist())  # noqa: E731
+    rowidx = np.repeat(np.arange(n), np.diff(crow))
+    poisoned = None
+    for cand in range(m):
+        users = set(rowidx[col == cand].tolist())
+        if len(users) >= 1 and any(((r ^ 1) not in users) and ((r ^ 1) < n) for r in users):
+            poisoned = cand
+            break
+    assert poisoned is not None
+    Bp = Bd.clone()
+    Bp[poisoned] = float("inf")
+    Cp = be.csr_spmm_rowpack(g.crow, vd, rp, Bp, n)
+    users = torch.from_numpy(np.unique(rowidx[col == poisoned])).to(DEV)
+    clean = torch.ones(n, dtype=torch.bool, device=DEV)
+    clean[users] = False
+    assert bool(torch.isfinite(Cp[clean]).all()) and not bool(torch.isfinite(Cp[users]).all())
+
+    # public API with the selection forced for this (small) pattern: row pairs first, then the block dictionary
+    monkeypatch.setattr(_ops, "PACK_MIN_NNZ", 0)
+    Ad = torch.sparse_csr_tensor(g.crow, g.col, vd, (n, m)).requires_grad_(True)
+    Bq = Bd.clone().requires_grad_(True)
+    Cq = tsgu().sparse_mm(Ad, Bq)
+    Cq.backward(Gdev)
+    assert rel(Cq, C_o) < 1e-5 and rel(Ad.grad.values(), gA_o) < 1e-5 and rel(Bq.grad, gB_o) < 1e-5
+    assert _pattern.from_csr(Ad)._packs and _pattern.from_csr(Ad).transposed._packs, "the row-pair plan was not used"
+    _pattern.clear_cache()
+    monkeypatch.setattr(_ops, "ENABLE_PACK", False)
     monkeypatch.setattr(_ops, "BLOCK_MIN_NNZ", 0)
     Ad = torch.sparse_csr_tensor(g.crow, g.col, vd, (n, m)).requires_grad_(True)
     Bq = Bd.clone().requires_grad_(True)

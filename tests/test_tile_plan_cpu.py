@@ -112,3 +112,75 @@ def test_block_plan_ragged_rows_and_tail_block():
     g = P.RowGather(A.crow_indices(), A.col_indices(), n, m)
     _check_block(g, 32, 128, (8, 512, 2048, 65536))
     _check_block(g.transposed, 64, 4, (4, 1024, 2048, 65536))
+
+
+# ------------------------------------------------------------------ row-pair union plan (rowpack kernels) ----
+def _check_rowpack(g, rpb, limits):
+    rp = P.build_rowpack_plan(g, rpb, limits)
+    assert rp is not None
+    n, nnz = g.n_rows, g.nnz
+    npairs = (n + 1) // 2
+    assert rp.uptr.shape == (npairs + 1,) and rp.uptr.dtype == rp.ucol.dtype == rp.upos.dtype == torch.int32
+    nu = int(rp.uptr[-1])
+    assert rp.ucol.shape == (nu,) and rp.upos.shape == (nu,) and rp.ecap % 256 == 0 and rp.ucap % 256 == 0
+    word = rp.upos.long() & 0xFFFFFFFF
+    halves = torch.stack((word & 0xFFFF, word >> 16))
+    upair = torch.repeat_interleave(torch.arange(npairs), (rp.uptr[1:] - rp.uptr[:-1]).long())
+    # union columns ascend strictly inside a pair
+    same = upair[1:] == upair[:-1]
+    assert bool((rp.ucol[1:][same] > rp.ucol[:-1][same]).all())
+    rows = g.row_indices().long()
+    e0 = g.crow[torch.arange(0, n, rpb)].long()
+    ends = torch.cat((e0[1:], g.crow[-1:].long()))
+    present = (halves & 0x8000) == 0
+    assert int(present.sum()) == nnz
+    # every present half points at the value of the entry (row 2q+r, ucol) inside the workgroup's staged slice
+    for r in (0, 1):
+        u = torch.nonzero(present[r]).flatten()
+        row = 2 * upair[u] + r
+        blk = row // rpb
+        slot = halves[r][u]
+        assert bool((slot < (ends - e0)[blk]).all())
+        pos = e0[blk] + slot                       # index into the staged order
+        src = pos if g.perm is None else None
+        if g.perm is None:
+            assert torch.equal(g.col[src].long(), rp.ucol[u].long()) and torch.equal(rows[src], row)
+        else:
+            val_index = rp.sperm[pos].long()        # position in the owner's value array
+            # the entry of the walked pattern with that perm value must be (row, ucol)
+            inv = torch.empty(nnz, dtype=torch.long)
+            inv[g.perm.long()] = torch.arange(nnz)
+            k = inv[val_index]
+            assert torch.equal(g.col[k].long(), rp.ucol[u].long()) and torch.equal(rows[k], row)
+    if g.perm is not None:
+        for b in (0, len(e0) // 2, len(e0) - 1):
+            seg = rp.sperm[int(e0[b]) : int(ends[b])]
+            assert bool((seg[1:] > seg[:-1]).all())
+    return rp
+
+
+def test_rowpack_plan_stencil_ragged_and_limits():
+    crow, col = synthetic.stencil27_periodic(12, 10, 9, torch.int32)
+    g = P.RowGather(crow, col, 1080, 1080)
+    lim = (2048, 3072, 65536)
+    rp = _check_rowpack(g, 64, lim)
+    assert 1.4 < rp.reuse <= 2.0
+    _check_rowpack(g.transposed, 64, lim)
+    assert g.rowpack_plan(64, lim) is g.rowpack_plan(64, lim)
+    assert P.build_rowpack_plan(g, 64, (1024, 3072, 65536)) is None   # entries per workgroup
+    assert P.build_rowpack_plan(g, 64, (2048, 1024, 65536)) is None   # union records per workgroup
+    assert P.build_rowpack_plan(g, 64, (2048, 3072, 8192)) is None    # LDS budget
+    # odd row count, empty rows, rectangular
+    gen = torch.Generator().manual_seed(5)
+    n, m = 1003, 900
+    rows = torch.randint(0, n, (9000,), generator=gen)
+    cols = (rows * m // n + torch.randint(-3, 4, (9000,), generator=gen)).clamp(0, m - 1)
+    rows[rows % 17 == 0] += 1
+    A = torch.sparse_coo_tensor(torch.stack((rows, cols)), torch.ones(9000), (n, m)).coalesce().to_sparse_csr()
+    gr = P.RowGather(A.crow_indices(), A.col_indices(), n, m)
+    _check_rowpack(gr, 64, lim)
+    _check_rowpack(gr.transposed, 128, lim)
+    # no shared columns between the rows of a pair: refused
+    idx = torch.randperm(4000 * 4000, generator=gen)[:12000]
+    R = torch.sparse_coo_tensor(torch.stack((idx // 4000, idx % 4000)), torch.ones(12000), (4000, 4000)).coalesce().to_sparse_csr()
+    assert P.build_rowpack_plan(P.RowGather(R.crow_indices(), R.col_indices(), 4000, 4000), 64, lim) is None

@@ -107,7 +107,28 @@ def main():
                 print(f"  spmmt_bt{rpb} vs gather: max abs diff {float((D0 - D1).abs().max())}")
                 gA0, gB0 = fns["bwd_fused"](); gA1, gB1 = fns[f"bwd_bt{rpb}"]()
                 print(f"  bwd_bt{rpb} vs fused gather: gradA {float((gA0 - gA1).abs().max())} gradB {float((gB0 - gB1).abs().max())}")
+    rl = be.rowpack_limits(torch.float32, p)
+    if rl is not None:
+        import time as _t
+        t0 = _t.perf_counter()
+        rp, rpt = plan.rowpack_plan(*rl), pt.rowpack_plan(*rl)
+        torch.cuda.synchronize()
+        if rp is None or rpt is None:
+            print(f"rowpack plan: not available (fwd {rp is not None}, transposed {rpt is not None})")
+        else:
+            print(f"rowpack plan: rpb={rp.rpb} ecap={rp.ecap}/{rpt.ecap} ucap={rp.ucap}/{rpt.ucap} reuse={rp.reuse:.2f} build {(_t.perf_counter()-t0)*1e3:.0f} ms")
+            by["spmm_rp"] = by["spmm"]; by["spmmt_rp"] = by["spmm"]; by["bwd_rp"] = by["bwd_fused"]
+            fns["spmm_rp"] = lambda: be.csr_spmm_rowpack(crow, val, rp, B, n)
+            fns["spmmt_rp"] = lambda: be.csr_spmm_rowpack(pt.crow, val, rpt, G, n)
+            fns["bwd_rp"] = lambda: be.csr_mm_backward_rowpack(pt.crow, rpt, val, G, B, n)
+            if a.check:
+                C0 = fns["spmm"](); C1 = fns["spmm_rp"]()
+                D0 = fns["spmmt"](); D1 = fns["spmmt_rp"]()
+                gA0, gB0 = fns["bwd_fused"](); gA1, gB1 = fns["bwd_rp"]()
+                print(f"  rowpack vs gather: spmm {float((C0 - C1).abs().max())} spmmt {float((D0 - D1).abs().max())} gradA {float((gA0 - gA1).abs().max())} gradB {float((gB0 - gB1).abs().max())}")
     only = a.only.split(",")
+    if "rp" in only:
+        only += [k for k in fns if k.endswith("_rp")]
     if "bt" in only:
         only += [k for k in fns if "_bt" in k or "_bg" in k]
     for k in only:

@@ -9,7 +9,7 @@ mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
 for pass in "fetch FETCH_SIZE" "write WRITE_SIZE"; do
   set -- $pass
-  timeout 600 rocprofv3 --kernel-trace --pmc $2 --kernel-include-regex "tsgu::csr_(spmm|blocktile|mm_backward)" --output-format csv \
+  timeout 600 rocprofv3 --kernel-trace --pmc $2 --kernel-include-regex "tsgu::csr_(spmm|blocktile|rowpack|mm_backward)" --output-format csv \
      -d $OUT/$1 -o p -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/$1.log 2>&1
 done
 find $OUT -name "*counter_collection.csv" | head

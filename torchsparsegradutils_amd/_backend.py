@@ -69,6 +69,19 @@ SIGNATURES = {
         [_int, _int, _i64, _i64, _ptr, _ptr, _ptr, _int, _int, _int, _int, _ptr, _ptr, _ptr, _ptr, _i64, _ptr, _i64,
          _ptr, _ptr, _i64, _i64, _int, _ptr],
     ),
+    "tsgu_rowpack_limits": (
+        _int,
+        [_int, _i64, ctypes.POINTER(_int), ctypes.POINTER(_int), ctypes.POINTER(_int), ctypes.POINTER(_int)],
+    ),
+    "tsgu_csr_spmm_rowpack": (
+        _int,
+        [_int, _int, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _int, _int, _ptr, _ptr, _ptr, _i64, _ptr, _i64, _i64, _int, _ptr],
+    ),
+    "tsgu_csr_mm_backward_rowpack": (
+        _int,
+        [_int, _int, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _int, _int, _ptr, _ptr, _ptr, _i64, _ptr, _i64, _ptr, _ptr,
+         _i64, _i64, _int, _ptr],
+    ),
     "tsgu_wavetile_geometry": (_int, [_int, _i64, ctypes.POINTER(_int), ctypes.POINTER(_int), ctypes.POINTER(_int)]),
     "tsgu_csr_spmm_wavetile": (
         _int,
@@ -353,6 +366,57 @@ def csr_mm_backward_blocktile(tcrow, bp, val, G, B, n_rows_t: int, tile: bool = 
                 _p(grad_a), _p(grad_b), _ld(grad_b), p, dev.index, _stream(dev),
             ),
             "tsgu_csr_mm_backward_blocktile",
+        )
+    return grad_a, grad_b
+
+
+def rowpack_limits(dtype: torch.dtype, p: int):
+    """(rows_per_block, (max_entries, max_union, lds_budget_bytes)) of the row-pair gather kernels, or None."""
+    if dtype != torch.float32 or p <= 0:
+        return None
+    lib = load_library()
+    r, a, b, c = _int(0), _int(0), _int(0), _int(0)
+    if lib.tsgu_rowpack_limits(_VTYPE[dtype], p, ctypes.byref(r), ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)) != 0:
+        return None
+    return r.value, (a.value, b.value, c.value)
+
+
+def csr_spmm_rowpack(crow, val, rp, B, n_rows: int):
+    """C = A·B through the row-pair union walk; `rp` is a _pattern.RowPackPlan of the walked pattern."""
+    lib = load_library()
+    dev = require_device(crow, val, B)
+    B = rowmajor(B)
+    p = B.size(-1)
+    out = torch.empty((n_rows, p), dtype=B.dtype, device=dev)
+    with torch.cuda.device(dev):
+        check(
+            lib.tsgu_csr_spmm_rowpack(
+                vtype_of(val), itype_of(crow), n_rows, rp.nnz, _p(crow), _p(rp.uptr), _p(rp.ucol), _p(rp.upos),
+                rp.ecap, rp.ucap, _p(rp.sperm), _p(val.contiguous()), _p(B), _ld(B), _p(out), _ld(out), p,
+                dev.index, _stream(dev),
+            ),
+            "tsgu_csr_spmm_rowpack",
+        )
+    return out
+
+
+def csr_mm_backward_rowpack(tcrow, rp, val, G, B, n_rows_t: int):
+    """(gradA values in A's order, gradB) in one pass over the transposed pattern's RowPackPlan."""
+    lib = load_library()
+    dev = require_device(tcrow, val, G, B)
+    G, B = rowmajor(G), rowmajor(B)
+    p = G.size(-1)
+    val = val.contiguous()
+    grad_a = torch.empty_like(val)
+    grad_b = torch.empty((n_rows_t, p), dtype=G.dtype, device=dev)
+    with torch.cuda.device(dev):
+        check(
+            lib.tsgu_csr_mm_backward_rowpack(
+                vtype_of(val), itype_of(tcrow), n_rows_t, rp.nnz, _p(tcrow), _p(rp.uptr), _p(rp.ucol), _p(rp.upos),
+                rp.ecap, rp.ucap, _p(rp.sperm), _p(val), _p(G), _ld(G), _p(B), _ld(B),
+                _p(grad_a), _p(grad_b), _ld(grad_b), p, dev.index, _stream(dev),
+            ),
+            "tsgu_csr_mm_backward_rowpack",
         )
     return grad_a, grad_b
 

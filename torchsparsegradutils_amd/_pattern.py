@@ -27,7 +27,8 @@ class RowGather:
     col, position of each entry in the owner's value array (None = identity).
     """
 
-    __slots__ = ("crow", "col", "perm", "n_rows", "n_cols", "batch", "_t", "_has_diag", "_rows", "_tiles", "_blocks")
+    __slots__ = ("crow", "col", "perm", "n_rows", "n_cols", "batch", "_t", "_has_diag", "_rows", "_tiles", "_blocks",
+                 "_packs")
 
     def __init__(self, crow, col, n_rows, n_cols, perm=None):
         self.crow, self.col, self.perm = crow, col, perm
@@ -38,6 +39,15 @@ class RowGather:
         self._rows = None
         self._tiles = {}
         self._blocks = {}
+        self._packs = {}
+
+    def rowpack_plan(self, rows_per_block: int, limits):
+        """Plan for the row-pair gather kernels (csrc/rowpack_impl.h), None when the pattern does not qualify or
+        profit; cached per workgroup height.  See `build_rowpack_plan`."""
+        key = (rows_per_block, tuple(limits))
+        if key not in self._packs:
+            self._packs[key] = build_rowpack_plan(self, rows_per_block, limits)
+        return self._packs[key]
 
     def block_plan(self, rows_per_block: int, row_bytes: int, limits):
         """Plan for the workgroup-tiled kernels (csrc/blocktile_impl.h), None when the pattern does not
@@ -197,6 +207,71 @@ def build_block_plan(g: RowGather, rpb: int, row_bytes: int, limits):
         ent = ent | (slot << 16)
     ent = ent.to(torch.int32).contiguous()  # bit pattern of the uint32 word (slot < 2048)
     return BlockPlan(cnt.to(torch.int32).contiguous(), trow, ent, sperm, capd, ecap, rpb, reuse, nnz)
+
+
+class RowPackPlan:
+    """Union-of-columns walk for pairs of consecutive rows, consumed by tsgu_csr_*_rowpack (layout: include/tsgu_hip.h)."""
+
+    __slots__ = ("uptr", "ucol", "upos", "sperm", "ecap", "ucap", "rpb", "reuse", "nnz")
+
+    def __init__(self, uptr, ucol, upos, sperm, ecap, ucap, rpb, reuse, nnz):
+        self.uptr, self.ucol, self.upos, self.sperm = uptr, ucol, upos, sperm
+        self.ecap, self.ucap, self.rpb, self.reuse, self.nnz = ecap, ucap, rpb, reuse, nnz
+
+
+_PACK_MIN_REUSE = 1.2   # stored entries per union entry (2.0 = both rows of every pair share all columns)
+_PACK_ABSENT = 0x8000
+
+
+def build_rowpack_plan(g: RowGather, rpb: int, limits):
+    """Rows 2q and 2q+1 walk the sorted union of their column sets: `ucol` per union entry, `upos` = two 16-bit slots
+    (one per row; bit 15 = this row has no entry there) into the value slice a workgroup of `rpb` rows stages.  For
+    plans addressed through `perm` the slice is staged in the order of the permutation sorted inside the workgroup
+    (`sperm`), otherwise in stored order.  `limits` = (max_entries, max_union, lds_budget_bytes)."""
+    max_entries, max_union, lds_budget = limits
+    if g.batch is not None or g.n_rows == 0 or not (1 <= g.nnz < 2**31):
+        return None
+    n, m, nnz = g.n_rows, g.n_cols, g.nnz
+    dev = g.crow.device
+    gpb = rpb // 2
+    npairs = (n + 1) // 2
+    e0 = g.crow[torch.arange(0, n, rpb, device=dev)].to(torch.int64)
+    ne = torch.cat((e0[1:], g.crow[-1:].to(torch.int64))) - e0
+    ecap = max((int(ne.max()) + 255) // 256 * 256, 256)
+    if ecap > max_entries or ecap >= _PACK_ABSENT:
+        return None
+    rows = g.row_indices().to(torch.int64)
+    pair = rows // 2
+    uniq, inv = torch.unique(pair * m + g.col.to(torch.int64), return_inverse=True)  # sorted: (pair, column) ascending
+    nu = uniq.numel()
+    reuse = nnz / max(nu, 1)
+    if reuse < _PACK_MIN_REUSE:
+        return None
+    upair = uniq // m
+    cnt = torch.bincount(upair, minlength=npairs)
+    uptr = torch.zeros(npairs + 1, dtype=torch.int64, device=dev)
+    uptr[1:] = torch.cumsum(cnt, 0)
+    u0 = uptr[torch.arange(0, npairs, gpb, device=dev)]
+    nub = torch.cat((u0[1:], uptr[-1:])) - u0
+    ucap = max((int(nub.max()) + 255) // 256 * 256, 256)
+    if ucap > max_union or ucap * 8 + ecap * 4 > lds_budget:
+        return None
+    blk = rows // rpb
+    k = torch.arange(nnz, device=dev, dtype=torch.int64)
+    sperm = None
+    if g.perm is None:
+        slot = k - e0[blk]
+    else:
+        order = torch.argsort(blk * nnz + g.perm.to(torch.int64))  # entries are stored block after block
+        sperm = g.perm[order].to(torch.int32).contiguous()
+        slot = torch.empty(nnz, dtype=torch.int64, device=dev)
+        slot[order] = k - e0[blk[order]]
+    half = torch.full((2, nu), _PACK_ABSENT, dtype=torch.int64, device=dev)
+    half[rows % 2, inv] = slot
+    word = half[0] | (half[1] << 16)
+    word = torch.where(word >= 2**31, word - 2**32, word).to(torch.int32).contiguous()  # bit pattern of the uint32
+    ucol = (uniq - upair * m).to(torch.int32).contiguous()
+    return RowPackPlan(uptr.to(torch.int32).contiguous(), ucol, word, sperm, ecap, ucap, rpb, reuse, nnz)
 
 
 def _transpose(g: RowGather) -> RowGather:
