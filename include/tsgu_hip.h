@@ -176,6 +176,8 @@ int tsgu_csr_mm_backward_blocktile(int vtype, int itype, int64_t n_rows_t, int64
  *   sperm[nnz]              int32   (walked pattern addresses the values through a permutation) positions in the
  *                                   value array, ascending inside each workgroup's entry range; slots index that
  *                                   order.  NULL: values are in walked order, slot = entry offset in the workgroup.
+ *   order[nblocks]          int32   optional (NULL = natural): workgroup b processes row block order[b]; any
+ *                                   permutation is valid, it only changes which blocks are L2-resident together.
  * A workgroup covers rows_per_block = 2·256/(p/4) consecutive rows; ecap / ucap = capacity of the staged value slice
  * / union records (multiples of 256, <= the limits, ucap·8 + ecap·4 <= lds_budget_bytes).  fp32, p in {16, 32, 64},
  * 16-byte aligned dense operands with ld % 4 == 0, 2-D operands.  Each row's sum runs over its own entries in
@@ -185,11 +187,11 @@ int tsgu_csr_mm_backward_blocktile(int vtype, int itype, int64_t n_rows_t, int64
 int tsgu_rowpack_limits(int vtype, int64_t p, int* rows_per_block, int* max_entries, int* max_union, int* lds_budget_bytes);
 int tsgu_csr_spmm_rowpack(int vtype, int itype, int64_t n_rows, int64_t nnz, const void* ptr,
                           const void* uptr, const void* ucol, const void* upos, int ecap, int ucap,
-                          const void* sperm, const void* val,
+                          const void* sperm, const void* order, const void* val,
                           const void* B, int64_t ldb, void* C, int64_t ldc, int64_t p, int device, void* stream);
 int tsgu_csr_mm_backward_rowpack(int vtype, int itype, int64_t n_rows_t, int64_t nnz, const void* t_ptr,
                                  const void* uptr, const void* ucol, const void* upos, int ecap, int ucap,
-                                 const void* sperm, const void* val,
+                                 const void* sperm, const void* order, const void* val,
                                  const void* G, int64_t ldg, const void* B, int64_t ldb,
                                  void* gradA_vals, void* gradB, int64_t ldgb, int64_t p, int device, void* stream);
 

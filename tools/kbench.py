@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--reps", type=int, default=50)
     ap.add_argument("--only", default="spmm,sddmm,spmmt,bwd_fused,spmm_tiled,sddmm_tiled,spmmt_tiled,bwd_tiled")
     ap.add_argument("--check", action="store_true")
+    ap.add_argument("--tile-order", type=int, default=0, help="experiment: blocks per yz tile for the rowpack processing order")
     ap.add_argument("--rpb", type=int, nargs="*", default=[8, 16, 32], help="block heights for the workgroup-tiled kernels")
     ap.add_argument("--pattern", default="stencil27", help="stencil27 | diag27 (27 copies of own row) | band27 (cols = row-13..row+13)")
     a = ap.parse_args()
@@ -121,6 +122,17 @@ def main():
             fns["spmm_rp"] = lambda: be.csr_spmm_rowpack(crow, val, rp, B, n)
             fns["spmmt_rp"] = lambda: be.csr_spmm_rowpack(pt.crow, val, rpt, G, n)
             fns["bwd_rp"] = lambda: be.csr_mm_backward_rowpack(pt.crow, rpt, val, G, B, n)
+            if a.tile_order:
+                # experiment: (x-plane, yz-tile) loop interchange inside each XCD chunk of 64-row blocks
+                nb = (n + rp.rpb - 1) // rp.rpb
+                b = torch.arange(nb, device=dev)
+                r0 = b * rp.rpb
+                plane, inpl = r0 // (ny * nz), (r0 % (ny * nz)) // (a.tile_order * rp.rpb)
+                chunk = b * 8 // nb
+                key = (chunk * 4096 + inpl) * 4096 + plane
+                order = torch.argsort(key * nb + b).to(torch.int32)
+                rp.order = order; rpt.order = order
+                print("  tile order on:", a.tile_order, "blocks per tile")
             if a.check:
                 C0 = fns["spmm"](); C1 = fns["spmm_rp"]()
                 D0 = fns["spmmt"](); D1 = fns["spmmt_rp"]()

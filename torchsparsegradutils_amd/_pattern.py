@@ -212,10 +212,10 @@ def build_block_plan(g: RowGather, rpb: int, row_bytes: int, limits):
 class RowPackPlan:
     """Union-of-columns walk for pairs of consecutive rows, consumed by tsgu_csr_*_rowpack (layout: include/tsgu_hip.h)."""
 
-    __slots__ = ("uptr", "ucol", "upos", "sperm", "ecap", "ucap", "rpb", "reuse", "nnz")
+    __slots__ = ("uptr", "ucol", "upos", "sperm", "order", "ecap", "ucap", "rpb", "reuse", "nnz")
 
-    def __init__(self, uptr, ucol, upos, sperm, ecap, ucap, rpb, reuse, nnz):
-        self.uptr, self.ucol, self.upos, self.sperm = uptr, ucol, upos, sperm
+    def __init__(self, uptr, ucol, upos, sperm, ecap, ucap, rpb, reuse, nnz, order=None):
+        self.uptr, self.ucol, self.upos, self.sperm, self.order = uptr, ucol, upos, sperm, order
         self.ecap, self.ucap, self.rpb, self.reuse, self.nnz = ecap, ucap, rpb, reuse, nnz
 
 

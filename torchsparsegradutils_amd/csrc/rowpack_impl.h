@@ -34,6 +34,7 @@ struct RpParams {
     const int* ucol;        // [nu]
     const uint32_t* upos;   // [nu]
     const int* sperm;       // [nnz] or null
+    const int* order;       // [nblocks] or null: workgroup b processes row block order[b] (a permutation; speed only)
     const float* val;
     const float* S;         // gathered dense operand (B for SpMM, G for the backward)
     int64_t lds_;
@@ -58,7 +59,10 @@ __global__ __launch_bounds__(kBlock) void csr_rowpack_kernel(const RpParams P) {
     constexpr int VEC = 4;
     constexpr int GPB = kBlock / CL;  // lane groups (row pairs) per workgroup
     constexpr int RPB = 2 * GPB;      // rows per workgroup
-    constexpr int U = 4;
+#ifndef TSGU_RP_U
+#define TSGU_RP_U 4
+#endif
+    constexpr int U = TSGU_RP_U;  // gathers in flight per lane
     static_assert(MODE == kRpSpmm || PERM, "the backward always walks the transposed pattern");
 
     extern __shared__ uint4 rp_smem[];
@@ -71,7 +75,8 @@ __global__ __launch_bounds__(kBlock) void csr_rowpack_kernel(const RpParams P) {
     const int grp = tid / CL;
     const int cl = tid % CL;
 
-    const int64_t vb = xcd_chunked_block(blockIdx.x, P.nblocks);
+    int64_t vb = xcd_chunked_block(blockIdx.x, P.nblocks);
+    if (P.order) vb = P.order[vb];
     const I* __restrict__ ptr = static_cast<const I*>(P.ptr);
     const int64_t row0 = vb * RPB;
     const int64_t row1 = row0 + RPB < P.n_rows ? row0 + RPB : P.n_rows;
