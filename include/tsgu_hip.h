@@ -176,6 +176,12 @@ int tsgu_csr_mm_backward_blocktile(int vtype, int itype, int64_t n_rows_t, int64
  *   sperm[nnz]              int32   (walked pattern addresses the values through a permutation) positions in the
  *                                   value array, ascending inside each workgroup's entry range; slots index that
  *                                   order.  NULL: values are in walked order, slot = entry offset in the workgroup.
+ *   vpair[nblocks·G]        int32   optional, with eptr[nblocks+1] and sperm (G = 256/(p/4) lane groups per workgroup):
+ *                                   the row pair each lane-group slot owns (-1 = none), so that a workgroup can own
+ *                                   any set of pairs — e.g. a 3-D brick of a lattice, whose entries form long runs in
+ *                                   the value array — instead of G consecutive ones.  uptr/ucol/upos are then laid
+ *                                   out in slot order and eptr gives each workgroup's range in sperm.  NULL = natural
+ *                                   (nblocks is ignored and derived from n_rows).
  *   order[nblocks]          int32   optional (NULL = natural): workgroup b processes row block order[b]; any
  *                                   permutation is valid, it only changes which blocks are L2-resident together.
  * A workgroup covers rows_per_block = 2·256/(p/4) consecutive rows; ecap / ucap = capacity of the staged value slice
@@ -187,12 +193,12 @@ int tsgu_csr_mm_backward_blocktile(int vtype, int itype, int64_t n_rows_t, int64
 int tsgu_rowpack_limits(int vtype, int64_t p, int* rows_per_block, int* max_entries, int* max_union, int* lds_budget_bytes);
 int tsgu_csr_spmm_rowpack(int vtype, int itype, int64_t n_rows, int64_t nnz, const void* ptr,
                           const void* uptr, const void* ucol, const void* upos, int ecap, int ucap,
-                          const void* sperm, const void* order, const void* val,
-                          const void* B, int64_t ldb, void* C, int64_t ldc, int64_t p, int device, void* stream);
+                          const void* sperm, const void* order, const void* vpair, const void* eptr, int64_t nblocks,
+                          const void* val, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t p, int device, void* stream);
 int tsgu_csr_mm_backward_rowpack(int vtype, int itype, int64_t n_rows_t, int64_t nnz, const void* t_ptr,
                                  const void* uptr, const void* ucol, const void* upos, int ecap, int ucap,
-                                 const void* sperm, const void* order, const void* val,
-                                 const void* G, int64_t ldg, const void* B, int64_t ldb,
+                                 const void* sperm, const void* order, const void* vpair, const void* eptr, int64_t nblocks,
+                                 const void* val, const void* G, int64_t ldg, const void* B, int64_t ldb,
                                  void* gradA_vals, void* gradB, int64_t ldgb, int64_t p, int device, void* stream);
 
 /*

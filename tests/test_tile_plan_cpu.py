@@ -115,30 +115,45 @@ def test_block_plan_ragged_rows_and_tail_block():
 
 
 # ------------------------------------------------------------------ row-pair union plan (rowpack kernels) ----
-def _check_rowpack(g, rpb, limits):
-    rp = P.build_rowpack_plan(g, rpb, limits)
+def _check_rowpack(g, rpb, limits, pair_order=None):
+    rp = P.build_rowpack_plan(g, rpb, limits, pair_order=pair_order)
     assert rp is not None
     n, nnz = g.n_rows, g.nnz
     npairs = (n + 1) // 2
-    assert rp.uptr.shape == (npairs + 1,) and rp.uptr.dtype == rp.ucol.dtype == rp.upos.dtype == torch.int32
+    gpb = rpb // 2
+    if pair_order is None:
+        nslots = (npairs + gpb - 1) // gpb * gpb
+        slot_pair = torch.full((nslots,), -1, dtype=torch.long)
+        slot_pair[:npairs] = torch.arange(npairs)
+        assert rp.vpair is None and rp.eptr is None
+    else:
+        nslots = pair_order.numel()
+        slot_pair = pair_order.long()
+        assert torch.equal(rp.vpair.long(), slot_pair) and rp.nblocks == nslots // gpb and rp.eptr.shape == (rp.nblocks + 1,)
+    assert rp.uptr.shape == (nslots + 1,) and rp.uptr.dtype == rp.ucol.dtype == rp.upos.dtype == torch.int32
     nu = int(rp.uptr[-1])
     assert rp.ucol.shape == (nu,) and rp.upos.shape == (nu,) and rp.ecap % 256 == 0 and rp.ucap % 256 == 0
     word = rp.upos.long() & 0xFFFFFFFF
     halves = torch.stack((word & 0xFFFF, word >> 16))
-    upair = torch.repeat_interleave(torch.arange(npairs), (rp.uptr[1:] - rp.uptr[:-1]).long())
+    uslot = torch.repeat_interleave(torch.arange(nslots), (rp.uptr[1:] - rp.uptr[:-1]).long())
+    upair = slot_pair[uslot]
+    assert bool((upair >= 0).all())
     # union columns ascend strictly inside a pair
     same = upair[1:] == upair[:-1]
     assert bool((rp.ucol[1:][same] > rp.ucol[:-1][same]).all())
     rows = g.row_indices().long()
-    e0 = g.crow[torch.arange(0, n, rpb)].long()
-    ends = torch.cat((e0[1:], g.crow[-1:].long()))
+    if pair_order is None:
+        e0 = g.crow[torch.arange(0, n, rpb)].long()
+        ends = torch.cat((e0[1:], g.crow[-1:].long()))
+    else:
+        e0, ends = rp.eptr[:-1].long(), rp.eptr[1:].long()
     present = (halves & 0x8000) == 0
     assert int(present.sum()) == nnz
     # every present half points at the value of the entry (row 2q+r, ucol) inside the workgroup's staged slice
     for r in (0, 1):
         u = torch.nonzero(present[r]).flatten()
         row = 2 * upair[u] + r
-        blk = row // rpb
+        blk = uslot[u] // gpb
         slot = halves[r][u]
         assert bool((slot < (ends - e0)[blk]).all())
         pos = e0[blk] + slot                       # index into the staged order
@@ -184,3 +199,32 @@ def test_rowpack_plan_stencil_ragged_and_limits():
     idx = torch.randperm(4000 * 4000, generator=gen)[:12000]
     R = torch.sparse_coo_tensor(torch.stack((idx // 4000, idx % 4000)), torch.ones(12000), (4000, 4000)).coalesce().to_sparse_csr()
     assert P.build_rowpack_plan(P.RowGather(R.crow_indices(), R.col_indices(), 4000, 4000), 64, lim) is None
+
+
+def test_lattice_detection_and_brick_ownership():
+    lim = (2048, 3072, 65536)
+    for dims, expect in (((12, 10, 8), (8, 80)), ((9, 7, 6), (6, 42))):
+        crow, col = synthetic.stencil27_periodic(*dims, torch.int32)
+        n = dims[0] * dims[1] * dims[2]
+        g = P.RowGather(crow, col, n, n)
+        assert P.detect_lattice(g) == expect and P.detect_lattice(g.transposed) == expect
+        po = P.brick_pair_order(n, expect, 32, "cpu")
+        assert po.numel() % 32 == 0 and sorted(po[po >= 0].tolist()) == list(range(n // 2))
+        _check_rowpack(g.transposed, 64, lim, pair_order=po)
+        # the automatic choice for a permuted plan on a lattice is the brick plan; forward plans stay natural
+        auto = g.transposed.rowpack_plan(64, lim)
+        assert auto.vpair is not None and auto.lattice == expect
+        assert g.rowpack_plan(64, lim).vpair is None
+    c7 = synthetic.laplacian7(6, 8, 10)
+    assert P.detect_lattice(P.RowGather(c7[0], c7[1], 480, 480)) == (10, 80)
+    # not lattices: a band, a random pattern, an odd z extent
+    n = 600
+    band = ((torch.arange(n).unsqueeze(1) + torch.arange(-5, 6).unsqueeze(0)) % n).reshape(-1)
+    gb = P.RowGather((torch.arange(n + 1) * 11).int(), band.int(), n, n)
+    assert P.detect_lattice(gb) is None
+    crow, col = synthetic.stencil27_periodic(6, 6, 5, torch.int32)
+    assert P.detect_lattice(P.RowGather(crow, col, 180, 180)) is None
+    gen = torch.Generator().manual_seed(1)
+    idx = torch.randperm(500 * 500, generator=gen)[:5000]
+    R = torch.sparse_coo_tensor(torch.stack((idx // 500, idx % 500)), torch.ones(5000), (500, 500)).coalesce().to_sparse_csr()
+    assert P.detect_lattice(P.RowGather(R.crow_indices(), R.col_indices(), 500, 500)) is None

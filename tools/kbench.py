@@ -36,6 +36,8 @@ def main():
     ap.add_argument("--reps", type=int, default=50)
     ap.add_argument("--only", default="spmm,sddmm,spmmt,bwd_fused,spmm_tiled,sddmm_tiled,spmmt_tiled,bwd_tiled")
     ap.add_argument("--check", action="store_true")
+    ap.add_argument("--brick", type=int, nargs=3, default=None, help="experiment: (z pairs, y, x) brick of the transposed rowpack plan")
+    ap.add_argument("--no-bricks", action="store_true")
     ap.add_argument("--tile-order", type=int, default=0, help="experiment: blocks per yz tile for the rowpack processing order")
     ap.add_argument("--rpb", type=int, nargs="*", default=[8, 16, 32], help="block heights for the workgroup-tiled kernels")
     ap.add_argument("--pattern", default="stencil27", help="stencil27 | diag27 (27 copies of own row) | band27 (cols = row-13..row+13)")
@@ -112,7 +114,14 @@ def main():
     if rl is not None:
         import time as _t
         t0 = _t.perf_counter()
-        rp, rpt = plan.rowpack_plan(*rl), pt.rowpack_plan(*rl)
+        if a.brick:
+            lat = _pattern.detect_lattice(pt)
+            print("  lattice:", lat, "brick", a.brick)
+            po = _pattern.brick_pair_order(n, lat, rl[0] // 2, dev, shape=tuple(a.brick))
+            rp, rpt = plan.rowpack_plan(*rl), _pattern.build_rowpack_plan(pt, rl[0], rl[1], pair_order=po, lattice=lat)
+        else:
+            _pattern.ENABLE_BRICKS = not a.no_bricks
+            rp, rpt = plan.rowpack_plan(*rl), pt.rowpack_plan(*rl)
         torch.cuda.synchronize()
         if rp is None or rpt is None:
             print(f"rowpack plan: not available (fwd {rp is not None}, transposed {rpt is not None})")

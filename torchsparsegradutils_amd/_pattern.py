@@ -46,7 +46,13 @@ class RowGather:
         profit; cached per workgroup height.  See `build_rowpack_plan`."""
         key = (rows_per_block, tuple(limits))
         if key not in self._packs:
-            self._packs[key] = build_rowpack_plan(self, rows_per_block, limits)
+            plan = None
+            if ENABLE_BRICKS and self.perm is not None:
+                lat = detect_lattice(self)
+                order = brick_pair_order(self.n_rows, lat, rows_per_block // 2, self.crow.device) if lat else None
+                if order is not None:
+                    plan = build_rowpack_plan(self, rows_per_block, limits, pair_order=order, lattice=lat)
+            self._packs[key] = plan if plan is not None else build_rowpack_plan(self, rows_per_block, limits)
         return self._packs[key]
 
     def block_plan(self, rows_per_block: int, row_bytes: int, limits):
@@ -212,22 +218,96 @@ def build_block_plan(g: RowGather, rpb: int, row_bytes: int, limits):
 class RowPackPlan:
     """Union-of-columns walk for pairs of consecutive rows, consumed by tsgu_csr_*_rowpack (layout: include/tsgu_hip.h)."""
 
-    __slots__ = ("uptr", "ucol", "upos", "sperm", "order", "ecap", "ucap", "rpb", "reuse", "nnz")
+    __slots__ = ("uptr", "ucol", "upos", "sperm", "order", "vpair", "eptr", "nblocks", "ecap", "ucap", "rpb", "reuse",
+                 "nnz", "lattice")
 
-    def __init__(self, uptr, ucol, upos, sperm, ecap, ucap, rpb, reuse, nnz, order=None):
+    def __init__(self, uptr, ucol, upos, sperm, ecap, ucap, rpb, reuse, nnz, order=None, vpair=None, eptr=None,
+                 nblocks=0, lattice=None):
         self.uptr, self.ucol, self.upos, self.sperm, self.order = uptr, ucol, upos, sperm, order
+        self.vpair, self.eptr, self.nblocks, self.lattice = vpair, eptr, nblocks, lattice
         self.ecap, self.ucap, self.rpb, self.reuse, self.nnz = ecap, ucap, rpb, reuse, nnz
 
 
 _PACK_MIN_REUSE = 1.2   # stored entries per union entry (2.0 = both rows of every pair share all columns)
 _PACK_ABSENT = 0x8000
+ENABLE_BRICKS = True    # lattice patterns: permuted walks own 3-D bricks of row pairs (see brick_pair_order)
 
 
-def build_rowpack_plan(g: RowGather, rpb: int, limits):
+def detect_lattice(g: RowGather):
+    """Strides (d1,) or (d1, d2) of a row-major 2-D / 3-D lattice whose stencil this square pattern is (row =
+    x·d2 + y·d1 + z), or None.  Heuristic on the histogram of col − row: the offsets present in at least half of
+    the rows form clusters {±1}, {d1 − r … d1 + r}, {d2 − r' … d2 + r'}; the cluster centres are the strides.
+    Wrap-around offsets of periodic stencils are rare and ignored.  Anything irregular returns None."""
+    if g.batch is not None or g.n_rows != g.n_cols or g.n_rows < 64 or g.nnz == 0:
+        return None
+    n = g.n_rows
+    off = g.col.to(torch.int64) - g.row_indices().to(torch.int64)
+    uniq, cnt = torch.unique(off, return_counts=True)
+    if uniq.numel() > 4096:
+        return None
+    pos = uniq[(cnt >= n // 2) & (uniq > 0)].tolist()  # few values: host side
+    if not pos or pos[0] != 1:
+        return None
+    clusters, reach = [[pos[0]]], 1
+    for o in pos[1:]:
+        if o - clusters[-1][-1] <= reach:
+            clusters[-1].append(o)
+        else:
+            reach = clusters[-1][-1]
+            clusters.append([o])
+    if len(clusters) not in (2, 3) or clusters[0][-1] != 1:
+        return None
+    strides = []
+    for c in clusters[1:]:
+        centre2 = c[0] + c[-1]
+        if centre2 % 2:
+            return None
+        strides.append(centre2 // 2)
+    d1 = strides[0]
+    if d1 < 4 or d1 % 2 or n % d1:
+        return None
+    if len(strides) == 2:
+        d2 = strides[1]
+        if d2 % d1 or n % d2 or d2 // d1 < 2 or n // d2 < 2:
+            return None
+        return (d1, d2)
+    return (d1,) if n // d1 >= 2 else None
+
+
+def brick_pair_order(n: int, lattice, gpb: int, device, shape=None):
+    """Lane-group slot → row pair so that a workgroup of `gpb` slots owns a brick of the lattice (pairs run along z).
+    A brick's entries form long runs in the transposed operand's value array (all 27 neighbours of an interior
+    point belong to it), instead of the 3-word runs a block of consecutive rows gives.  Returns an int64 tensor of
+    nblocks·gpb pair indices, -1 where a brick sticks out of the lattice."""
+    d1 = lattice[0]
+    nzp = d1 // 2
+    if len(lattice) == 2:
+        d2 = lattice[1]
+        ny, nx = d2 // d1, n // d2
+        if shape is None:
+            shape = {16: (4, 2, 2), 32: (4, 2, 4), 64: (4, 4, 4)}.get(gpb)  # (z pairs, y, x); C2: 312 -> 250-263 us
+    else:
+        d2, ny, nx = n, n // d1, 1
+        if shape is None:
+            shape = {16: (4, 4, 1), 32: (8, 4, 1), 64: (8, 8, 1)}.get(gpb)
+    if shape is None or shape[0] * shape[1] * shape[2] != gpb:
+        return None
+    pz, by, bx = shape
+    ar = lambda k: torch.arange(k, device=device, dtype=torch.int64)  # noqa: E731
+    Xb, Yb, Zb = -(-nx // bx), -(-ny // by), -(-nzp // pz)
+    X, Y, Z, ix, iy, ip = torch.meshgrid(ar(Xb), ar(Yb), ar(Zb), ar(bx), ar(by), ar(pz), indexing="ij")
+    x, y, zp = X * bx + ix, Y * by + iy, Z * pz + ip
+    ok = (x < nx) & (y < ny) & (zp < nzp)
+    pair = (x * d2 + y * d1) // 2 + zp
+    return torch.where(ok, pair, torch.full_like(pair, -1)).reshape(-1)
+
+
+def build_rowpack_plan(g: RowGather, rpb: int, limits, pair_order=None, lattice=None):
     """Rows 2q and 2q+1 walk the sorted union of their column sets: `ucol` per union entry, `upos` = two 16-bit slots
     (one per row; bit 15 = this row has no entry there) into the value slice a workgroup of `rpb` rows stages.  For
     plans addressed through `perm` the slice is staged in the order of the permutation sorted inside the workgroup
-    (`sperm`), otherwise in stored order.  `limits` = (max_entries, max_union, lds_budget_bytes)."""
+    (`sperm`), otherwise in stored order.  `pair_order` (permuted plans only) assigns row pairs to lane-group slots
+    (see brick_pair_order); None = consecutive.  `limits` = (max_entries, max_union, lds_budget_bytes)."""
     max_entries, max_union, lds_budget = limits
     if g.batch is not None or g.n_rows == 0 or not (1 <= g.nnz < 2**31):
         return None
@@ -235,43 +315,62 @@ def build_rowpack_plan(g: RowGather, rpb: int, limits):
     dev = g.crow.device
     gpb = rpb // 2
     npairs = (n + 1) // 2
-    e0 = g.crow[torch.arange(0, n, rpb, device=dev)].to(torch.int64)
-    ne = torch.cat((e0[1:], g.crow[-1:].to(torch.int64))) - e0
+    natural = pair_order is None
+    if natural:
+        nb = (npairs + gpb - 1) // gpb
+        pair_order = torch.full((nb * gpb,), -1, dtype=torch.int64, device=dev)
+        pair_order[:npairs] = torch.arange(npairs, device=dev)
+    elif g.perm is None or pair_order.numel() % gpb:
+        return None
+    nslots = pair_order.numel()
+    nb = nslots // gpb
+    valid = pair_order >= 0
+    slot_of = torch.full((npairs,), -1, dtype=torch.int64, device=dev)
+    slot_of[pair_order[valid]] = torch.nonzero(valid).flatten()
+    if int(valid.sum()) != npairs or bool((slot_of < 0).any()):
+        return None  # not a permutation of the pairs
+    rows = g.row_indices().to(torch.int64)
+    vp = slot_of[rows // 2]                       # lane-group slot of every stored entry
+    blk = vp // gpb
+    ne = torch.bincount(blk, minlength=nb)
     ecap = max((int(ne.max()) + 255) // 256 * 256, 256)
     if ecap > max_entries or ecap >= _PACK_ABSENT:
         return None
-    rows = g.row_indices().to(torch.int64)
-    pair = rows // 2
-    uniq, inv = torch.unique(pair * m + g.col.to(torch.int64), return_inverse=True)  # sorted: (pair, column) ascending
+    eptr = torch.zeros(nb + 1, dtype=torch.int64, device=dev)
+    eptr[1:] = torch.cumsum(ne, 0)
+    uniq, inv = torch.unique(vp * m + g.col.to(torch.int64), return_inverse=True)  # sorted: (slot, column) ascending
     nu = uniq.numel()
     reuse = nnz / max(nu, 1)
     if reuse < _PACK_MIN_REUSE:
         return None
-    upair = uniq // m
-    cnt = torch.bincount(upair, minlength=npairs)
-    uptr = torch.zeros(npairs + 1, dtype=torch.int64, device=dev)
-    uptr[1:] = torch.cumsum(cnt, 0)
-    u0 = uptr[torch.arange(0, npairs, gpb, device=dev)]
-    nub = torch.cat((u0[1:], uptr[-1:])) - u0
-    ucap = max((int(nub.max()) + 255) // 256 * 256, 256)
+    uslot = uniq // m
+    uptr = torch.zeros(nslots + 1, dtype=torch.int64, device=dev)
+    uptr[1:] = torch.cumsum(torch.bincount(uslot, minlength=nslots), 0)
+    ub = uptr[torch.arange(0, nslots + 1, gpb, device=dev)]
+    ucap = max((int((ub[1:] - ub[:-1]).max()) + 255) // 256 * 256, 256)
     if ucap > max_union or ucap * 8 + ecap * 4 > lds_budget:
         return None
-    blk = rows // rpb
     k = torch.arange(nnz, device=dev, dtype=torch.int64)
     sperm = None
     if g.perm is None:
-        slot = k - e0[blk]
+        slot = k - eptr[blk]                      # natural order: a workgroup's entries are one contiguous range
     else:
-        order = torch.argsort(blk * nnz + g.perm.to(torch.int64))  # entries are stored block after block
+        order = torch.argsort(blk * nnz + g.perm.to(torch.int64))
         sperm = g.perm[order].to(torch.int32).contiguous()
         slot = torch.empty(nnz, dtype=torch.int64, device=dev)
-        slot[order] = k - e0[blk[order]]
+        slot[order] = k - eptr[blk[order]]
     half = torch.full((2, nu), _PACK_ABSENT, dtype=torch.int64, device=dev)
     half[rows % 2, inv] = slot
     word = half[0] | (half[1] << 16)
     word = torch.where(word >= 2**31, word - 2**32, word).to(torch.int32).contiguous()  # bit pattern of the uint32
-    ucol = (uniq - upair * m).to(torch.int32).contiguous()
-    return RowPackPlan(uptr.to(torch.int32).contiguous(), ucol, word, sperm, ecap, ucap, rpb, reuse, nnz)
+    ucol = (uniq - uslot * m).to(torch.int32).contiguous()
+    plan = RowPackPlan(uptr.to(torch.int32).contiguous(), ucol, word, sperm, ecap, ucap, rpb, reuse, nnz)
+    if not natural:
+        plan.vpair = pair_order.to(torch.int32).contiguous()
+        plan.eptr = eptr.to(torch.int32).contiguous()
+        plan.nblocks = nb
+        plan.lattice = lattice
+    return plan
 
 
 def _transpose(g: RowGather) -> RowGather:

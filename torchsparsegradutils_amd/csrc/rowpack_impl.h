@@ -35,6 +35,9 @@ struct RpParams {
     const uint32_t* upos;   // [nu]
     const int* sperm;       // [nnz] or null
     const int* order;       // [nblocks] or null: workgroup b processes row block order[b] (a permutation; speed only)
+    const int* vpair;       // [nblocks*GPB] or null: row pair owned by each lane-group slot (-1 = none): lets a workgroup own
+                            // any set of pairs (e.g. a 3-D brick of a lattice) instead of consecutive ones; needs eptr + sperm
+    const int* eptr;        // [nblocks+1] with vpair: start of each workgroup's entries in sperm
     const float* val;
     const float* S;         // gathered dense operand (B for SpMM, G for the backward)
     int64_t lds_;
@@ -54,15 +57,27 @@ constexpr int kRpMaxQ = 8;    // staged values per workgroup <= 8 * 256
 constexpr int kRpMaxU = 12;   // union records per workgroup <= 12 * 256
 constexpr int kRpAbsent = 0x8000;
 
+#ifndef TSGU_RP_WAVES
+#define TSGU_RP_WAVES 0
+#endif
+#if TSGU_RP_WAVES > 0
+#define TSGU_RP_OCC __attribute__((amdgpu_waves_per_eu(TSGU_RP_WAVES, TSGU_RP_WAVES)))
+#else
+#define TSGU_RP_OCC
+#endif
+
 template <typename I, int CL, int MODE, bool PERM>
-__global__ __launch_bounds__(kBlock) void csr_rowpack_kernel(const RpParams P) {
+__global__ __launch_bounds__(kBlock) TSGU_RP_OCC void csr_rowpack_kernel(const RpParams P) {
     constexpr int VEC = 4;
     constexpr int GPB = kBlock / CL;  // lane groups (row pairs) per workgroup
     constexpr int RPB = 2 * GPB;      // rows per workgroup
 #ifndef TSGU_RP_U
 #define TSGU_RP_U 4
 #endif
-    constexpr int U = TSGU_RP_U;  // gathers in flight per lane
+#ifndef TSGU_RP_UB
+#define TSGU_RP_UB 0
+#endif
+    constexpr int U = (MODE == kRpBwd && TSGU_RP_UB > 0) ? TSGU_RP_UB : TSGU_RP_U;  // gathers in flight per lane
     static_assert(MODE == kRpSpmm || PERM, "the backward always walks the transposed pattern");
 
     extern __shared__ uint4 rp_smem[];
@@ -78,22 +93,32 @@ __global__ __launch_bounds__(kBlock) void csr_rowpack_kernel(const RpParams P) {
     int64_t vb = xcd_chunked_block(blockIdx.x, P.nblocks);
     if (P.order) vb = P.order[vb];
     const I* __restrict__ ptr = static_cast<const I*>(P.ptr);
-    const int64_t row0 = vb * RPB;
-    const int64_t row1 = row0 + RPB < P.n_rows ? row0 + RPB : P.n_rows;
     const int64_t npairs = (P.n_rows + 1) / 2;
+    const int64_t nslots = P.nblocks * GPB;  // uptr is indexed by lane-group slot (= pair index when vpair is null)
     const int64_t pair0 = vb * GPB;
-    const int64_t pair1 = pair0 + GPB < npairs ? pair0 + GPB : npairs;
-    const int64_t pair = pair0 + grp;
-    const bool pair_ok = pair < npairs;
+    const int64_t pair1 = P.vpair ? pair0 + GPB : (pair0 + GPB < npairs ? pair0 + GPB : npairs);
+    const int64_t slot_id = pair0 + grp;
+    int64_t pair = slot_id;
+    if (P.vpair) pair = slot_id < nslots ? (int64_t)P.vpair[slot_id] : -1;
+    const bool pair_ok = pair >= 0 && pair < npairs;
     const int64_t ra = 2 * pair, rb = 2 * pair + 1;
     const bool b_ok = rb < P.n_rows;
 
-    const int64_t e0 = (int64_t)ptr[row0];
-    const int ne = (int)((int64_t)ptr[row1] - e0);
+    int64_t e0;
+    int ne;
+    if (P.vpair) {
+        e0 = (int64_t)P.eptr[vb];
+        ne = (int)((int64_t)P.eptr[vb + 1] - e0);
+    } else {
+        const int64_t row0 = vb * RPB;
+        const int64_t row1 = row0 + RPB < P.n_rows ? row0 + RPB : P.n_rows;
+        e0 = (int64_t)ptr[row0];
+        ne = (int)((int64_t)ptr[row1] - e0);
+    }
     const int64_t u0 = (int64_t)P.uptr[pair0];
     const int nu = (int)((int64_t)P.uptr[pair1] - u0);
-    const int lo = pair_ok ? (int)((int64_t)P.uptr[pair] - u0) : 0;
-    const int hi = pair_ok ? (int)((int64_t)P.uptr[pair + 1] - u0) : 0;
+    const int lo = pair_ok ? (int)((int64_t)P.uptr[slot_id] - u0) : 0;
+    const int hi = pair_ok ? (int)((int64_t)P.uptr[slot_id + 1] - u0) : 0;
 
     // ---- phase A: union records and values of the workgroup's rows -> LDS (DMA, no VGPR round trip) ----
     int qv[kRpMaxQ];
@@ -120,7 +145,11 @@ __global__ __launch_bounds__(kBlock) void csr_rowpack_kernel(const RpParams P) {
         const int t = q * kBlock + tid;
         if (q * kBlock < ne) {
             if (t < ne) {
+#ifdef TSGU_RP_DEBUG_CONTIG_VAL  // timing probe only
+                const float* vsrc = P.val + e0 + t;
+#else
                 const float* vsrc = PERM ? P.val + qv[q] : P.val + e0 + t;
+#endif
                 __builtin_amdgcn_global_load_lds((rp_glb_ptr)vsrc, (rp_lds_ptr)(s_val + q * kBlock + wave * kWave), 4, 0, PERM ? 0 : 2);
             }
         }
@@ -154,6 +183,9 @@ __global__ __launch_bounds__(kBlock) void csr_rowpack_kernel(const RpParams P) {
     };
 
     int i = lo;
+#ifdef TSGU_RP_DEBUG_SKIP_B  // timing probe only
+    i = hi;
+#endif
     for (; i + U <= hi; i += U) {
         int c[U];
         uint32_t w[U];
@@ -192,7 +224,11 @@ __global__ __launch_bounds__(kBlock) void csr_rowpack_kernel(const RpParams P) {
         for (int q = 0; q < kRpMaxQ; ++q) {
             const int t = q * kBlock + tid;
             if (q * kBlock < ne) {
+#ifndef TSGU_RP_DEBUG_SKIP_SCATTER
                 if (t < ne) P.gradA[qv[q]] = s_val[t];
+#else
+                if (t < ne) P.gradA[e0 + t] = s_val[t];  // timing probe only: contiguous
+#endif
             }
         }
     }
@@ -208,7 +244,11 @@ int rp_launch(RpParams P, hipStream_t stream) {
         P.ucap % 4 != 0 || P.lds_ > 0xffffffffLL)
         return TSGU_ERR_BAD_ARG;
     const int64_t rpb = 2 * (kBlock / cl);
-    P.nblocks = (P.n_rows + rpb - 1) / rpb;
+    if (P.vpair) {
+        if (!PERM || !P.eptr || P.nblocks <= 0) return TSGU_ERR_BAD_ARG;  // nblocks comes with the plan
+    } else {
+        P.nblocks = (P.n_rows + rpb - 1) / rpb;
+    }
     if (P.nblocks > 0x7fffffffLL) return TSGU_ERR_TOO_LARGE;
     if (P.nblocks == 0) return TSGU_OK;
     const size_t lds = (size_t)P.ucap * 8 + (size_t)P.ecap * 4;
