@@ -186,16 +186,17 @@ int tsgu_csr_mm_backward_blocktile(int vtype, int itype, int64_t n_rows_t, int64
  *                                   permutation is valid, it only changes which blocks are L2-resident together.
  * A workgroup covers rows_per_block = 2·256/(p/4) consecutive rows; ecap / ucap = capacity of the staged value slice
  * / union records (multiples of 256, <= the limits, ucap·8 + ecap·4 <= lds_budget_bytes).  fp32, p in {16, 32, 64},
- * 16-byte aligned dense operands with ld % 4 == 0, 2-D operands.  Each row's sum runs over its own entries in
+ * 16-byte aligned dense operands with ld % 4 == 0, 2-D operands.  n_cols (n_cols_t) = rows of the gathered dense
+ * operand; below 2^24 rows and 4 GiB the kernels use 32-bit gather offsets.  Each row's sum runs over its own entries in
  * ascending stored order (bit-identical to the one-group-per-row kernels); a row never touches a dense row it does
  * not reference (predicated update, no multiply by zero).
  */
 int tsgu_rowpack_limits(int vtype, int64_t p, int* rows_per_block, int* max_entries, int* max_union, int* lds_budget_bytes);
-int tsgu_csr_spmm_rowpack(int vtype, int itype, int64_t n_rows, int64_t nnz, const void* ptr,
+int tsgu_csr_spmm_rowpack(int vtype, int itype, int64_t n_rows, int64_t n_cols, int64_t nnz, const void* ptr,
                           const void* uptr, const void* ucol, const void* upos, int ecap, int ucap,
                           const void* sperm, const void* order, const void* vpair, const void* eptr, int64_t nblocks,
                           const void* val, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t p, int device, void* stream);
-int tsgu_csr_mm_backward_rowpack(int vtype, int itype, int64_t n_rows_t, int64_t nnz, const void* t_ptr,
+int tsgu_csr_mm_backward_rowpack(int vtype, int itype, int64_t n_rows_t, int64_t n_cols_t, int64_t nnz, const void* t_ptr,
                                  const void* uptr, const void* ucol, const void* upos, int ecap, int ucap,
                                  const void* sperm, const void* order, const void* vpair, const void* eptr, int64_t nblocks,
                                  const void* val, const void* G, int64_t ldg, const void* B, int64_t ldb,

@@ -75,12 +75,12 @@ SIGNATURES = {
     ),
     "tsgu_csr_spmm_rowpack": (
         _int,
-        [_int, _int, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _int, _int, _ptr, _ptr, _ptr, _ptr, _i64, _ptr, _ptr, _i64, _ptr,
+        [_int, _int, _i64, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _int, _int, _ptr, _ptr, _ptr, _ptr, _i64, _ptr, _ptr, _i64, _ptr,
          _i64, _i64, _int, _ptr],
     ),
     "tsgu_csr_mm_backward_rowpack": (
         _int,
-        [_int, _int, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _int, _int, _ptr, _ptr, _ptr, _ptr, _i64, _ptr, _ptr, _i64, _ptr,
+        [_int, _int, _i64, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _int, _int, _ptr, _ptr, _ptr, _ptr, _i64, _ptr, _ptr, _i64, _ptr,
          _i64, _ptr, _ptr, _i64, _i64, _int, _ptr],
     ),
     "tsgu_wavetile_geometry": (_int, [_int, _i64, ctypes.POINTER(_int), ctypes.POINTER(_int), ctypes.POINTER(_int)]),
@@ -392,7 +392,7 @@ def csr_spmm_rowpack(crow, val, rp, B, n_rows: int):
     with torch.cuda.device(dev):
         check(
             lib.tsgu_csr_spmm_rowpack(
-                vtype_of(val), itype_of(crow), n_rows, rp.nnz, _p(crow), _p(rp.uptr), _p(rp.ucol), _p(rp.upos),
+                vtype_of(val), itype_of(crow), n_rows, B.size(0), rp.nnz, _p(crow), _p(rp.uptr), _p(rp.ucol), _p(rp.upos),
                 rp.ecap, rp.ucap, _p(rp.sperm), _p(rp.order), _p(rp.vpair), _p(rp.eptr), rp.nblocks, _p(val.contiguous()),
                 _p(B), _ld(B), _p(out), _ld(out), p,
                 dev.index, _stream(dev),
@@ -414,7 +414,7 @@ def csr_mm_backward_rowpack(tcrow, rp, val, G, B, n_rows_t: int):
     with torch.cuda.device(dev):
         check(
             lib.tsgu_csr_mm_backward_rowpack(
-                vtype_of(val), itype_of(tcrow), n_rows_t, rp.nnz, _p(tcrow), _p(rp.uptr), _p(rp.ucol), _p(rp.upos),
+                vtype_of(val), itype_of(tcrow), n_rows_t, G.size(0), rp.nnz, _p(tcrow), _p(rp.uptr), _p(rp.ucol), _p(rp.upos),
                 rp.ecap, rp.ucap, _p(rp.sperm), _p(rp.order), _p(rp.vpair), _p(rp.eptr), rp.nblocks, _p(val), _p(G), _ld(G),
                 _p(B), _ld(B),
                 _p(grad_a), _p(grad_b), _ld(grad_b), p, dev.index, _stream(dev),

@@ -5,13 +5,14 @@ using namespace tsgu;
 
 namespace {
 
-int fill(RpParams& P, int64_t n_rows, int64_t nnz, int64_t p, const void* ptr, const void* uptr, const void* ucol,
+int fill(RpParams& P, int64_t n_rows, int64_t n_src, int64_t nnz, int64_t p, const void* ptr, const void* uptr, const void* ucol,
          const void* upos, int ecap, int ucap, const void* sperm, const void* order, const void* vpair, const void* eptr,
          int64_t nblocks, const void* val) {
-    if (n_rows < 0 || nnz < 0 || p <= 0) return TSGU_ERR_BAD_ARG;
+    if (n_rows < 0 || n_src < 0 || nnz < 0 || p <= 0) return TSGU_ERR_BAD_ARG;
     if (!ptr || !uptr || (nnz > 0 && (!ucol || !upos || !val))) return TSGU_ERR_BAD_ARG;
     if (n_rows > 0x7fffffffLL || nnz > 0x7fffffffLL) return TSGU_ERR_TOO_LARGE;
     P.n_rows = n_rows;
+    P.n_src = n_src;
     P.nnz = nnz;
     P.p = p;
     P.ptr = ptr;
@@ -43,13 +44,13 @@ int tsgu_rowpack_limits(int vtype, int64_t p, int* rows_per_block, int* max_entr
     return TSGU_OK;
 }
 
-int tsgu_csr_spmm_rowpack(int vtype, int itype, int64_t n_rows, int64_t nnz, const void* ptr,
+int tsgu_csr_spmm_rowpack(int vtype, int itype, int64_t n_rows, int64_t n_cols, int64_t nnz, const void* ptr,
                           const void* uptr, const void* ucol, const void* upos, int ecap, int ucap,
                           const void* sperm, const void* order, const void* vpair, const void* eptr, int64_t nblocks,
                           const void* val, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t p, int device, void* stream) {
     if (vtype != TSGU_F32) return TSGU_ERR_BAD_DTYPE;
     RpParams P{};
-    if (const int rc = fill(P, n_rows, nnz, p, ptr, uptr, ucol, upos, ecap, ucap, sperm, order, vpair, eptr, nblocks, val)) return rc;
+    if (const int rc = fill(P, n_rows, n_cols, nnz, p, ptr, uptr, ucol, upos, ecap, ucap, sperm, order, vpair, eptr, nblocks, val)) return rc;
     if (n_rows == 0) return TSGU_OK;
     if (!B || !C || ldb < p || ldc < p) return TSGU_ERR_BAD_ARG;
     if (const int rc = set_device(device)) return rc;
@@ -63,14 +64,14 @@ int tsgu_csr_spmm_rowpack(int vtype, int itype, int64_t n_rows, int64_t nnz, con
     return TSGU_ERR_BAD_DTYPE;
 }
 
-int tsgu_csr_mm_backward_rowpack(int vtype, int itype, int64_t n_rows_t, int64_t nnz, const void* t_ptr,
+int tsgu_csr_mm_backward_rowpack(int vtype, int itype, int64_t n_rows_t, int64_t n_cols_t, int64_t nnz, const void* t_ptr,
                                  const void* uptr, const void* ucol, const void* upos, int ecap, int ucap,
                                  const void* sperm, const void* order, const void* vpair, const void* eptr, int64_t nblocks,
                                  const void* val, const void* G, int64_t ldg, const void* B, int64_t ldb,
                                  void* gradA_vals, void* gradB, int64_t ldgb, int64_t p, int device, void* stream) {
     if (vtype != TSGU_F32) return TSGU_ERR_BAD_DTYPE;
     RpParams P{};
-    if (const int rc = fill(P, n_rows_t, nnz, p, t_ptr, uptr, ucol, upos, ecap, ucap, sperm, order, vpair, eptr, nblocks, val)) return rc;
+    if (const int rc = fill(P, n_rows_t, n_cols_t, nnz, p, t_ptr, uptr, ucol, upos, ecap, ucap, sperm, order, vpair, eptr, nblocks, val)) return rc;
     if (n_rows_t == 0) return TSGU_OK;
     if (!sperm || !B || !gradB || (nnz > 0 && (!G || !gradA_vals)) || ldg < p || ldb < p || ldgb < p) return TSGU_ERR_BAD_ARG;
     if (const int rc = set_device(device)) return rc;

@@ -29,6 +29,7 @@ enum RpMode { kRpSpmm = 0, kRpBwd = 1 };
 
 struct RpParams {
     int64_t n_rows, nnz, p;
+    int64_t n_src;          // rows of the gathered dense operand (= columns of the walked pattern)
     const void* ptr;        // [n_rows+1] entry offsets of the walked pattern
     const int* uptr;        // [npairs+1]
     const int* ucol;        // [nu]
@@ -66,7 +67,7 @@ constexpr int kRpAbsent = 0x8000;
 #define TSGU_RP_OCC
 #endif
 
-template <typename I, int CL, int MODE, bool PERM>
+template <typename I, int CL, int MODE, bool PERM, bool SMALL>
 __global__ __launch_bounds__(kBlock) TSGU_RP_OCC void csr_rowpack_kernel(const RpParams P) {
     constexpr int VEC = 4;
     constexpr int GPB = kBlock / CL;  // lane groups (row pairs) per workgroup
@@ -77,6 +78,7 @@ __global__ __launch_bounds__(kBlock) TSGU_RP_OCC void csr_rowpack_kernel(const R
 #ifndef TSGU_RP_UB
 #define TSGU_RP_UB 0
 #endif
+
     constexpr int U = (MODE == kRpBwd && TSGU_RP_UB > 0) ? TSGU_RP_UB : TSGU_RP_U;  // gathers in flight per lane
     static_assert(MODE == kRpSpmm || PERM, "the backward always walks the transposed pattern");
 
@@ -164,8 +166,19 @@ __global__ __launch_bounds__(kBlock) TSGU_RP_OCC void csr_rowpack_kernel(const R
     __syncthreads();
 
     // ---- phase B: walk the union of the pair's columns; one gather serves both rows ----
-    const float* __restrict__ Sg = P.S + cl * VEC;
-    const uint32_t ld = (uint32_t)P.lds_;
+    // dense row c starts at byte c·ld·4 of a wave-uniform base: when the operand is smaller than 4 GiB and the factors
+    // fit 24 bits (launcher checks) the offset is ONE full-rate v_mad_u32_u24 and the load uses the SGPR-base form,
+    // instead of a quarter-rate 64-bit multiply-add + 64-bit shift-add per gather (the phase is VALU-issue-bound)
+    const char* __restrict__ Sbase = reinterpret_cast<const char*>(P.S);
+    const uint32_t ldb4 = (uint32_t)P.lds_ * 4u, cl16 = (uint32_t)cl * 16u;
+    auto gather = [&](int c, float (&g)[VEC]) {
+        if constexpr (SMALL) {
+            const uint32_t boff = __umul24((uint32_t)c, ldb4) + cl16;
+            load_vec<float, VEC>(reinterpret_cast<const float*>(Sbase + boff), g);
+        } else {
+            load_vec<float, VEC>(P.S + cl * VEC + row_off(c, (uint32_t)P.lds_), g);
+        }
+    };
 
     auto use = [&](const float (&g)[VEC], uint32_t half, float (&acc)[VEC], const float (&own)[VEC]) {
         if (!(half & kRpAbsent)) {  // uniform inside the lane group, divergent across the wave: exec-masked
@@ -196,7 +209,7 @@ __global__ __launch_bounds__(kBlock) TSGU_RP_OCC void csr_rowpack_kernel(const R
             w[u] = s_upos[i + u];
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) load_vec<float, VEC>(Sg + row_off(c[u], ld), g[u]);
+        for (int u = 0; u < U; ++u) gather(c[u], g[u]);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             use(g[u], w[u] & 0xffffu, acc_a, own_a);
@@ -207,7 +220,7 @@ __global__ __launch_bounds__(kBlock) TSGU_RP_OCC void csr_rowpack_kernel(const R
         const int c = s_ucol[i];
         const uint32_t w = s_upos[i];
         float g[VEC];
-        load_vec<float, VEC>(Sg + row_off(c, ld), g);
+        gather(c, g);
         use(g, w & 0xffffu, acc_a, own_a);
         use(g, w >> 16, acc_b, own_b);
     }
@@ -254,11 +267,17 @@ int rp_launch(RpParams P, hipStream_t stream) {
     const size_t lds = (size_t)P.ucap * 8 + (size_t)P.ecap * 4;
     if (lds > 64 * 1024) return TSGU_ERR_TOO_LARGE;
     const dim3 grid((unsigned)P.nblocks), block(kBlock);
+    // 32-bit byte offsets into the gathered operand: rows < 2^24, row pitch < 2^24 bytes, whole operand < 4 GiB
+    const bool small = P.n_src < (1ll << 24) && P.lds_ * 4 < (1ll << 24) && P.n_src * P.lds_ * 4 < (1ll << 32);
+#define TSGU_RP_GO(CLV)                                                                                           \
+    if (small) hipLaunchKernelGGL((csr_rowpack_kernel<I, CLV, MODE, PERM, true>), grid, block, lds, stream, P);   \
+    else hipLaunchKernelGGL((csr_rowpack_kernel<I, CLV, MODE, PERM, false>), grid, block, lds, stream, P);
     switch (cl) {
-        case 4: hipLaunchKernelGGL((csr_rowpack_kernel<I, 4, MODE, PERM>), grid, block, lds, stream, P); break;
-        case 8: hipLaunchKernelGGL((csr_rowpack_kernel<I, 8, MODE, PERM>), grid, block, lds, stream, P); break;
-        case 16: hipLaunchKernelGGL((csr_rowpack_kernel<I, 16, MODE, PERM>), grid, block, lds, stream, P); break;
+        case 4: TSGU_RP_GO(4) break;
+        case 8: TSGU_RP_GO(8) break;
+        case 16: TSGU_RP_GO(16) break;
     }
+#undef TSGU_RP_GO
     return check_launch();
 }
 
