@@ -79,6 +79,7 @@ __global__ __launch_bounds__(kBlock) TSGU_RP_OCC void csr_rowpack_kernel(const R
 #define TSGU_RP_UB 0
 #endif
 
+
     constexpr int U = (MODE == kRpBwd && TSGU_RP_UB > 0) ? TSGU_RP_UB : TSGU_RP_U;  // gathers in flight per lane
     static_assert(MODE == kRpSpmm || PERM, "the backward always walks the transposed pattern");
 

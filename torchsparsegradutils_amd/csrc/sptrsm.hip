@@ -77,6 +77,7 @@ __global__ __launch_bounds__(kBlock) void sptrsm_fill_kernel(void* X, int64_t ld
 
 template <typename V, typename I, int CL>
 __global__ __launch_bounds__(kBlock) void sptrsm_syncfree_kernel(const TrsmParams P) {
+
     using S = Sentinel<V>;
     using Bits = typename S::Bits;
     constexpr int EP = kWave / CL;
@@ -109,11 +110,14 @@ __global__ __launch_bounds__(kBlock) void sptrsm_syncfree_kernel(const TrsmParam
         V diag = 0;
         bool dead = false;
         for (int64_t base = s; base < e; base += EP) {
-            const int64_t k = base + ep;
+            // entries are visited farthest-dependency first: ascending columns for a lower sweep, descending for an
+            // upper one.  The nearest rows are the ones solved last (the critical path), so everything else of the row
+            // is already accumulated when they arrive (upper sweeps walked ascending cost 5.1 instead of 3.2 ms at C3).
+            const int64_t k = P.lower ? base + ep : (e - 1) - (base - s) - ep;
             bool need = false;
             int64_t j = 0;
             V a = 0;
-            if (k < e) {
+            if (k >= s && k < e) {
                 j = (int64_t)idx[k];
                 a = val[perm ? (int64_t)perm[k] : k];
                 if (j == row) {
@@ -188,6 +192,7 @@ int sptrsm_launch(const TrsmParams& P, int n_cu, hipStream_t stream) {
 #define TSGU_TRSM_BLOCKS_PER_CU 1
 #endif
     int64_t blocks = (int64_t)n_cu * TSGU_TRSM_BLOCKS_PER_CU;
+
     const int64_t need = (P.n + 3) / 4;
     if (blocks > need) blocks = need;
     if (tiles > 1) {
