@@ -171,11 +171,13 @@ int tsgu_csr_mm_backward_blocktile(int vtype, int itype, int64_t n_rows_t, int64
  * per pair instead of 54).  Plan, built once per pattern:
  *   uptr [ceil(n_rows/2)+1] int32   union-entry offsets per row pair
  *   ucol [nu]               int32   dense-row index of each union entry (ascending inside a pair)
- *   upos [nu]               uint32  two 16-bit halves (low: row 2q, high: row 2q+1): slot of that row's value in
+ *   upos [nu]               uint32  (only with sperm) two 16-bit halves (low: row 2q, high: row 2q+1): slot of that row's value in
  *                                   the workgroup's staged value slice; bit 15 set = no entry in this column
  *   sperm[nnz]              int32   (walked pattern addresses the values through a permutation) positions in the
  *                                   value array, ascending inside each workgroup's entry range; slots index that
- *                                   order.  NULL: values are in walked order, slot = entry offset in the workgroup.
+ *                                   order.  NULL: values are in walked order; upos is then NULL too and bits 30 / 31
+ *                                   of ucol say whether row 2q / 2q+1 owns the column (n_cols < 2^30), the slots of
+ *                                   a row being consecutive.
  *   vpair[nblocks·G]        int32   optional, with eptr[nblocks+1] and sperm (G = 256/(p/4) lane groups per workgroup):
  *                                   the row pair each lane-group slot owns (-1 = none), so that a workgroup can own
  *                                   any set of pairs — e.g. a 3-D brick of a lattice, whose entries form long runs in
@@ -185,7 +187,7 @@ int tsgu_csr_mm_backward_blocktile(int vtype, int itype, int64_t n_rows_t, int64
  *   order[nblocks]          int32   optional (NULL = natural): workgroup b processes row block order[b]; any
  *                                   permutation is valid, it only changes which blocks are L2-resident together.
  * A workgroup covers rows_per_block = 2·256/(p/4) consecutive rows; ecap / ucap = capacity of the staged value slice
- * / union records (multiples of 256, <= the limits, ucap·8 + ecap·4 <= lds_budget_bytes).  fp32, p in {16, 32, 64},
+ * / union records (multiples of 256, <= the limits, ucap·8 (ucap·4 without upos) + ecap·4 <= lds_budget_bytes).  fp32, p in {16, 32, 64},
  * 16-byte aligned dense operands with ld % 4 == 0, 2-D operands.  n_cols (n_cols_t) = rows of the gathered dense
  * operand; below 2^24 rows and 4 GiB the kernels use 32-bit gather offsets.  Each row's sum runs over its own entries in
  * ascending stored order (bit-identical to the one-group-per-row kernels); a row never touches a dense row it does

@@ -130,43 +130,54 @@ def _check_rowpack(g, rpb, limits, pair_order=None):
         nslots = pair_order.numel()
         slot_pair = pair_order.long()
         assert torch.equal(rp.vpair.long(), slot_pair) and rp.nblocks == nslots // gpb and rp.eptr.shape == (rp.nblocks + 1,)
-    assert rp.uptr.shape == (nslots + 1,) and rp.uptr.dtype == rp.ucol.dtype == rp.upos.dtype == torch.int32
+    assert rp.uptr.shape == (nslots + 1,) and rp.uptr.dtype == rp.ucol.dtype == torch.int32
+    assert rp.upos is None or rp.upos.dtype == torch.int32
     nu = int(rp.uptr[-1])
-    assert rp.ucol.shape == (nu,) and rp.upos.shape == (nu,) and rp.ecap % 256 == 0 and rp.ucap % 256 == 0
-    word = rp.upos.long() & 0xFFFFFFFF
-    halves = torch.stack((word & 0xFFFF, word >> 16))
+    assert rp.ucol.shape == (nu,) and rp.ecap % 256 == 0 and rp.ucap % 256 == 0
     uslot = torch.repeat_interleave(torch.arange(nslots), (rp.uptr[1:] - rp.uptr[:-1]).long())
     upair = slot_pair[uslot]
     assert bool((upair >= 0).all())
-    # union columns ascend strictly inside a pair
-    same = upair[1:] == upair[:-1]
-    assert bool((rp.ucol[1:][same] > rp.ucol[:-1][same]).all())
     rows = g.row_indices().long()
-    if pair_order is None:
-        e0 = g.crow[torch.arange(0, n, rpb)].long()
-        ends = torch.cat((e0[1:], g.crow[-1:].long()))
+    ucol = rp.ucol.long() & 0xFFFFFFFF
+    if g.perm is None:
+        # stored order: no slot words, bits 30 / 31 of ucol = "row 2q / 2q+1 owns this column", slots run consecutively
+        assert rp.upos is None and rp.sperm is None
+        own = torch.stack(((ucol >> 30) & 1, ucol >> 31)).bool()
+        ucol = ucol & 0x3FFFFFFF
+        assert int(own.sum()) == nnz
+        for r in (0, 1):
+            u = torch.nonzero(own[r]).flatten()
+            row = 2 * upair[u] + r
+            first = torch.ones_like(u, dtype=torch.bool)
+            first[1:] = row[1:] != row[:-1]
+            start = torch.nonzero(first).flatten()
+            rank = torch.arange(u.numel()) - torch.repeat_interleave(start, torch.diff(torch.cat((start, torch.tensor([u.numel()])))))
+            k = g.crow[row].long() + rank          # the rank-th stored entry of that row
+            assert torch.equal(g.col[k].long(), ucol[u]) and torch.equal(rows[k], row)
     else:
-        e0, ends = rp.eptr[:-1].long(), rp.eptr[1:].long()
-    present = (halves & 0x8000) == 0
-    assert int(present.sum()) == nnz
-    # every present half points at the value of the entry (row 2q+r, ucol) inside the workgroup's staged slice
-    for r in (0, 1):
-        u = torch.nonzero(present[r]).flatten()
-        row = 2 * upair[u] + r
-        blk = uslot[u] // gpb
-        slot = halves[r][u]
-        assert bool((slot < (ends - e0)[blk]).all())
-        pos = e0[blk] + slot                       # index into the staged order
-        src = pos if g.perm is None else None
-        if g.perm is None:
-            assert torch.equal(g.col[src].long(), rp.ucol[u].long()) and torch.equal(rows[src], row)
+        assert rp.upos.shape == (nu,)
+    same = upair[1:] == upair[:-1]
+    assert bool((ucol[1:][same] > ucol[:-1][same]).all())
+    if g.perm is not None:
+        word = rp.upos.long() & 0xFFFFFFFF
+        halves = torch.stack((word & 0xFFFF, word >> 16))
+        if pair_order is None:
+            e0 = g.crow[torch.arange(0, n, rpb)].long()
+            ends = torch.cat((e0[1:], g.crow[-1:].long()))
         else:
-            val_index = rp.sperm[pos].long()        # position in the owner's value array
-            # the entry of the walked pattern with that perm value must be (row, ucol)
-            inv = torch.empty(nnz, dtype=torch.long)
-            inv[g.perm.long()] = torch.arange(nnz)
-            k = inv[val_index]
-            assert torch.equal(g.col[k].long(), rp.ucol[u].long()) and torch.equal(rows[k], row)
+            e0, ends = rp.eptr[:-1].long(), rp.eptr[1:].long()
+        present = (halves & 0x8000) == 0
+        assert int(present.sum()) == nnz
+        inv = torch.empty(nnz, dtype=torch.long)
+        inv[g.perm.long()] = torch.arange(nnz)
+        for r in (0, 1):
+            u = torch.nonzero(present[r]).flatten()
+            row = 2 * upair[u] + r
+            blk = uslot[u] // gpb
+            slot = halves[r][u]
+            assert bool((slot < (ends - e0)[blk]).all())
+            k = inv[rp.sperm[e0[blk] + slot].long()]   # entry of the walked pattern whose value sits in that slot
+            assert torch.equal(g.col[k].long(), ucol[u]) and torch.equal(rows[k], row)
     if g.perm is not None:
         for b in (0, len(e0) // 2, len(e0) - 1):
             seg = rp.sperm[int(e0[b]) : int(ends[b])]
@@ -228,3 +239,18 @@ def test_lattice_detection_and_brick_ownership():
     idx = torch.randperm(500 * 500, generator=gen)[:5000]
     R = torch.sparse_coo_tensor(torch.stack((idx // 500, idx % 500)), torch.ones(5000), (500, 500)).coalesce().to_sparse_csr()
     assert P.detect_lattice(P.RowGather(R.crow_indices(), R.col_indices(), 500, 500)) is None
+
+
+def test_rowpack_plan_refuses_unsorted_or_duplicate_columns():
+    """The union walk visits a row's entries in ascending column order; torch accepts unsorted / duplicate CSR columns
+    when invariants are not checked, and such patterns must stay on the order-agnostic gather kernels."""
+    lim = (2048, 3072, 65536)
+    crow, col = synthetic.stencil27_periodic(6, 6, 6, torch.int32)
+    ok = P.RowGather(crow, col, 216, 216)
+    assert P.build_rowpack_plan(ok, 64, lim) is not None
+    swapped = col.clone()
+    swapped[[3, 4]] = col[[4, 3]]
+    assert P.build_rowpack_plan(P.RowGather(crow, swapped, 216, 216), 64, lim) is None
+    dup = col.clone()
+    dup[28] = dup[27]
+    assert P.build_rowpack_plan(P.RowGather(crow, dup, 216, 216), 64, lim) is None

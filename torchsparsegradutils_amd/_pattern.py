@@ -330,6 +330,11 @@ def build_rowpack_plan(g: RowGather, rpb: int, limits, pair_order=None, lattice=
     if int(valid.sum()) != npairs or bool((slot_of < 0).any()):
         return None  # not a permutation of the pairs
     rows = g.row_indices().to(torch.int64)
+    if nnz > 1:
+        # the union walk visits a row's entries in ascending column order: stored rows must be sorted and duplicate-free
+        c64 = g.col.to(torch.int64)
+        if bool(((c64[1:] <= c64[:-1]) & (rows[1:] == rows[:-1])).any()):
+            return None
     vp = slot_of[rows // 2]                       # lane-group slot of every stored entry
     blk = vp // gpb
     ne = torch.bincount(blk, minlength=nb)
@@ -348,7 +353,7 @@ def build_rowpack_plan(g: RowGather, rpb: int, limits, pair_order=None, lattice=
     uptr[1:] = torch.cumsum(torch.bincount(uslot, minlength=nslots), 0)
     ub = uptr[torch.arange(0, nslots + 1, gpb, device=dev)]
     ucap = max((int((ub[1:] - ub[:-1]).max()) + 255) // 256 * 256, 256)
-    if ucap > max_union or ucap * 8 + ecap * 4 > lds_budget:
+    if ucap > max_union or ucap * (4 if g.perm is None else 8) + ecap * 4 > lds_budget or (g.perm is None and m >= 2**30):
         return None
     k = torch.arange(nnz, device=dev, dtype=torch.int64)
     sperm = None
@@ -359,11 +364,19 @@ def build_rowpack_plan(g: RowGather, rpb: int, limits, pair_order=None, lattice=
         sperm = g.perm[order].to(torch.int32).contiguous()
         slot = torch.empty(nnz, dtype=torch.int64, device=dev)
         slot[order] = k - eptr[blk[order]]
-    half = torch.full((2, nu), _PACK_ABSENT, dtype=torch.int64, device=dev)
-    half[rows % 2, inv] = slot
-    word = half[0] | (half[1] << 16)
-    word = torch.where(word >= 2**31, word - 2**32, word).to(torch.int32).contiguous()  # bit pattern of the uint32
-    ucol = (uniq - uslot * m).to(torch.int32).contiguous()
+    to_i32 = lambda w: torch.where(w >= 2**31, w - 2**32, w).to(torch.int32).contiguous()  # noqa: E731  (uint32 bit pattern)
+    ucol64 = uniq - uslot * m
+    if g.perm is None:
+        # stored order: a row's slots are consecutive, the record only carries the ownership bits (30: row 2q, 31: 2q+1)
+        own = torch.zeros((2, nu), dtype=torch.int64, device=dev)
+        own[rows % 2, inv] = 1
+        ucol = to_i32(ucol64 | (own[0] << 30) | (own[1] << 31))
+        word = None
+    else:
+        half = torch.full((2, nu), _PACK_ABSENT, dtype=torch.int64, device=dev)
+        half[rows % 2, inv] = slot
+        word = to_i32(half[0] | (half[1] << 16))
+        ucol = ucol64.to(torch.int32).contiguous()
     plan = RowPackPlan(uptr.to(torch.int32).contiguous(), ucol, word, sperm, ecap, ucap, rpb, reuse, nnz)
     if not natural:
         plan.vpair = pair_order.to(torch.int32).contiguous()

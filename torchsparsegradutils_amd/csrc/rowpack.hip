@@ -9,7 +9,7 @@ int fill(RpParams& P, int64_t n_rows, int64_t n_src, int64_t nnz, int64_t p, con
          const void* upos, int ecap, int ucap, const void* sperm, const void* order, const void* vpair, const void* eptr,
          int64_t nblocks, const void* val) {
     if (n_rows < 0 || n_src < 0 || nnz < 0 || p <= 0) return TSGU_ERR_BAD_ARG;
-    if (!ptr || !uptr || (nnz > 0 && (!ucol || !upos || !val))) return TSGU_ERR_BAD_ARG;
+    if (!ptr || !uptr || (nnz > 0 && (!ucol || !val)) || (nnz > 0 && sperm && !upos)) return TSGU_ERR_BAD_ARG;
     if (n_rows > 0x7fffffffLL || nnz > 0x7fffffffLL) return TSGU_ERR_TOO_LARGE;
     P.n_rows = n_rows;
     P.n_src = n_src;

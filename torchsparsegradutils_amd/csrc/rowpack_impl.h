@@ -9,8 +9,10 @@
 // Plan (built once per sparsity pattern by _pattern.build_rowpack_plan):
 //   uptr [npairs+1]  int32   union-entry offsets per row pair, npairs = ceil(n_rows / 2)
 //   ucol [nu]        int32   dense-row index of each union entry (ascending inside a pair)
-//   upos [nu]        uint32  two 16-bit halves, one per row of the pair: slot of that row's value inside the
+//   upos [nu]        uint32  (permuted walks) two 16-bit halves, one per row of the pair: slot of that row's value inside the
 //                            workgroup's staged value slice, bit 15 set = the row has no entry in this column
+//                            Walks in stored order carry no upos: bits 30 / 31 of ucol say which rows own the column
+//                            and the slots are consecutive per row.
 //   sperm[nnz]       int32   (patterns walked through a permutation) positions in the value array, ascending
 //                            inside each workgroup's entry range; the slots of `upos` index this order.  NULL
 //                            when the values are in the walked order (slot = entry offset inside the workgroup).
@@ -85,8 +87,8 @@ __global__ __launch_bounds__(kBlock) TSGU_RP_OCC void csr_rowpack_kernel(const R
 
     extern __shared__ uint4 rp_smem[];
     int* s_ucol = reinterpret_cast<int*>(rp_smem);
-    uint32_t* s_upos = reinterpret_cast<uint32_t*>(s_ucol + P.ucap);
-    float* s_val = reinterpret_cast<float*>(s_upos + P.ucap);
+    uint32_t* s_upos = reinterpret_cast<uint32_t*>(s_ucol + P.ucap);           // permuted walks only
+    float* s_val = reinterpret_cast<float*>(s_ucol + (PERM ? 2 : 1) * (size_t)P.ucap);
 
     const int tid = threadIdx.x;
     const int wave = tid / kWave;
@@ -139,7 +141,8 @@ __global__ __launch_bounds__(kBlock) TSGU_RP_OCC void csr_rowpack_kernel(const R
         if (q * kBlock < nu) {
             if (t < nu) {
                 __builtin_amdgcn_global_load_lds((rp_glb_ptr)(P.ucol + u0 + t), (rp_lds_ptr)(s_ucol + q * kBlock + wave * kWave), 4, 0, 2);
-                __builtin_amdgcn_global_load_lds((rp_glb_ptr)(P.upos + u0 + t), (rp_lds_ptr)(s_upos + q * kBlock + wave * kWave), 4, 0, 2);
+                if constexpr (PERM)
+                    __builtin_amdgcn_global_load_lds((rp_glb_ptr)(P.upos + u0 + t), (rp_lds_ptr)(s_upos + q * kBlock + wave * kWave), 4, 0, 2);
             }
         }
     }
@@ -200,30 +203,65 @@ __global__ __launch_bounds__(kBlock) TSGU_RP_OCC void csr_rowpack_kernel(const R
 #ifdef TSGU_RP_DEBUG_SKIP_B  // timing probe only
     i = hi;
 #endif
-    for (; i + U <= hi; i += U) {
-        int c[U];
-        uint32_t w[U];
-        float g[U][VEC];
+    if constexpr (PERM) {
+        for (; i + U <= hi; i += U) {
+            int c[U];
+            uint32_t w[U];
+            float g[U][VEC];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            c[u] = s_ucol[i + u];
-            w[u] = s_upos[i + u];
+            for (int u = 0; u < U; ++u) {
+                c[u] = s_ucol[i + u];
+                w[u] = s_upos[i + u];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) gather(c[u], g[u]);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                use(g[u], w[u] & 0xffffu, acc_a, own_a);
+                use(g[u], w[u] >> 16, acc_b, own_b);
+            }
         }
-#pragma unroll
-        for (int u = 0; u < U; ++u) gather(c[u], g[u]);
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            use(g[u], w[u] & 0xffffu, acc_a, own_a);
-            use(g[u], w[u] >> 16, acc_b, own_b);
+        for (; i < hi; ++i) {
+            const int c = s_ucol[i];
+            const uint32_t w = s_upos[i];
+            float g[VEC];
+            gather(c, g);
+            use(g, w & 0xffffu, acc_a, own_a);
+            use(g, w >> 16, acc_b, own_b);
         }
-    }
-    for (; i < hi; ++i) {
-        const int c = s_ucol[i];
-        const uint32_t w = s_upos[i];
-        float g[VEC];
-        gather(c, g);
-        use(g, w & 0xffffu, acc_a, own_a);
-        use(g, w >> 16, acc_b, own_b);
+    } else {
+        // values in walked order: the slots of a row are consecutive, so the record only says WHICH rows own the column
+        // (bits 30 / 31 of ucol) and two running counters replace the slot words (no upos stream, half the record LDS)
+        int ka = pair_ok ? (int)((int64_t)ptr[ra] - e0) : 0;
+        int kb = (pair_ok && b_ok) ? (int)((int64_t)ptr[rb] - e0) : 0;
+        auto use_seq = [&](const float (&g)[VEC], bool present, int& k, float (&acc)[VEC]) {
+            if (present) {
+                const float a = s_val[k];
+                ++k;
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) acc[v] = fma(a, g[v], acc[v]);
+            }
+        };
+        for (; i + U <= hi; i += U) {
+            uint32_t w[U];
+            float g[U][VEC];
+#pragma unroll
+            for (int u = 0; u < U; ++u) w[u] = (uint32_t)s_ucol[i + u];
+#pragma unroll
+            for (int u = 0; u < U; ++u) gather((int)(w[u] & 0x3fffffffu), g[u]);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                use_seq(g[u], (w[u] >> 30) & 1u, ka, acc_a);
+                use_seq(g[u], w[u] >> 31, kb, acc_b);
+            }
+        }
+        for (; i < hi; ++i) {
+            const uint32_t w = (uint32_t)s_ucol[i];
+            float g[VEC];
+            gather((int)(w & 0x3fffffffu), g);
+            use_seq(g, (w >> 30) & 1u, ka, acc_a);
+            use_seq(g, w >> 31, kb, acc_b);
+        }
     }
 
     if (pair_ok) {
@@ -265,7 +303,8 @@ int rp_launch(RpParams P, hipStream_t stream) {
     }
     if (P.nblocks > 0x7fffffffLL) return TSGU_ERR_TOO_LARGE;
     if (P.nblocks == 0) return TSGU_OK;
-    const size_t lds = (size_t)P.ucap * 8 + (size_t)P.ecap * 4;
+    const size_t lds = (size_t)P.ucap * (PERM ? 8 : 4) + (size_t)P.ecap * 4;
+    if (!PERM && P.n_src >= (1ll << 30)) return TSGU_ERR_TOO_LARGE;  // ownership bits live in bits 30 / 31 of ucol
     if (lds > 64 * 1024) return TSGU_ERR_TOO_LARGE;
     const dim3 grid((unsigned)P.nblocks), block(kBlock);
     // 32-bit byte offsets into the gathered operand: rows < 2^24, row pitch < 2^24 bytes, whole operand < 4 GiB
