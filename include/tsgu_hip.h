@@ -318,6 +318,25 @@ int tsgu_bicg_vector(int vtype, int which, int64_t n, int64_t p, void* a0, void*
                      const void* a4, const void* scal, const int* flags, void* partial, int64_t set_stride,
                      int device, void* stream);
 
+/*
+ * K7: fused MINRES recurrences (no preconditioner, one shift), all right-hand sides at once — replaces the per-iteration
+ * ATen op chain of reference utils/minres.py:259-296 (Lanczos step, Givens QR, solution update) and its
+ * every-10-iterations stopping test (:299-305).  One iteration = tsgu_csr_spmm(+ <z, A z> partials) ->
+ * tsgu_minres_scalar(0: alpha) -> tsgu_minres_vector(0: z_c = (A z - alpha z) - beta z_prev2 over z_prev2, |z_c|^2
+ * partials) -> tsgu_minres_scalar(1: beta_c and the rotations) -> tsgu_minres_vector(1: z_c /= beta_c, w_c over w_prev2,
+ * sol += w_c·scale, optionally |update|^2 and |sol|^2 partials) [-> tsgu_minres_scalar(2: stop test into flags[0])].
+ * scal: [12][p] values — 0 alpha | 1 beta | 2,3 c,s two steps back | 4,5 c,s one step back | 6 scale | 7 sub | 8 subsub |
+ * 9 diag | 10 scale of this update | 11 beta of the previous step; flags: int32 [0] stop, [1] iterations.  The caller
+ * initialises rows 1, 6, 11 with the initial beta and rows 2, 4 with ones.  Arrays are contiguous [n][p], 16-byte
+ * aligned; partial sets are `set_stride` elements apart with tsgu_cg_num_blocks(vtype, n, p) rows each; `fold`
+ * (tsgu_cg_fold_rows() x p) is scratch for long partial lists.  fp32 / fp64, p <= 1024.
+ */
+int tsgu_minres_scalar(int vtype, int phase, const void* partial, int64_t n_partial, int64_t set_stride, void* fold,
+                       void* scal, int* flags, double eps, double tol, double shift, int64_t p, int device, void* stream);
+int tsgu_minres_vector(int vtype, int which, int64_t n, int64_t p, void* a0, const void* a1, void* a2, const void* a3,
+                       void* a4, const void* scal, const int* flags, void* partial, int64_t set_stride, int with_norms,
+                       int device, void* stream);
+
 /* Column-wise dot products  out[c] = Σ_i X[i,c]·Y[i,c]  (two-stage, deterministic).
  * replaces: torch.dot / mul+sum in utils/bicgstab.py:168,199,222-224 and linear_cg.py:294 */
 /* `partial` needs tsgu_coldot_max_blocks(n, p) * p elements. */

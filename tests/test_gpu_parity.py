@@ -614,6 +614,45 @@ def test_krylov_hipgraph_replay_is_bitwise_identical_to_eager_launches(monkeypat
     assert float((Ac @ xg - rhs).norm() / rhs.norm()) < 1e-10
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.float64])
+def test_minres_fused_matches_reference_op_chain(dt, monkeypatch):
+    """K7: the fused single-shift MINRES against the line-by-line op chain of the reference (same module, reached with
+    `value=1.0`): multi-RHS incl. a zero column, a vector RHS, a shift, an iteration cap that is not a multiple of 10,
+    an indefinite matrix; then hipGraph replay of 10-iteration chunks is bit-identical to eager launches."""
+    from torchsparsegradutils_amd.utils import MINRESSettings, _graph, minres
+
+    z = G.load("cg_lap16.npz")
+    n = 4096
+    val = G.t(z["val"], DEV).to(dt)
+    A = torch.sparse_csr_tensor(G.t(z["crow"], DEV), G.t(z["col"], DEV), val, (n, n))
+    B = G.t(z["B"], DEV).to(dt).clone()
+    B[:, 1] = 0
+    tol = 2e-4 if dt == torch.float32 else 1e-9
+    for kw in ({"settings": MINRESSettings(minres_tolerance=1e-6)}, {"max_iter": 37, "settings": MINRESSettings(minres_tolerance=0.0)},
+               {"shifts": torch.tensor([0.75], dtype=dt, device=DEV), "settings": MINRESSettings(minres_tolerance=1e-7)}):
+        x = minres(A, B, **kw)
+        x_ref = minres(A, B, value=1.0, **kw)          # tensor-op path (reference op chain)
+        assert x.shape == x_ref.shape == B.shape
+        assert float(x[:, 1].abs().max()) == 0.0
+        assert rel(x, x_ref.cpu().numpy()) < tol, kw
+    xv = minres(A, B[:, 0].contiguous(), settings=MINRESSettings(minres_tolerance=1e-6))
+    assert xv.shape == (n,) and rel(xv, minres(A, B[:, 0].contiguous(), value=1.0, settings=MINRESSettings(minres_tolerance=1e-6)).cpu().numpy()) < tol
+    # symmetric indefinite operator: the Laplacian shifted into the middle of its spectrum
+    Ai = torch.sparse_csr_tensor(G.t(z["crow"], DEV), G.t(z["col"], DEV), val, (n, n))
+    sh = torch.tensor([-3.1], dtype=dt, device=DEV)
+    xi = minres(Ai, B[:, :1].contiguous(), shifts=sh, max_iter=60, settings=MINRESSettings(minres_tolerance=0.0))
+    xr = minres(Ai, B[:, :1].contiguous(), shifts=sh, max_iter=60, value=1.0, settings=MINRESSettings(minres_tolerance=0.0))
+    assert rel(xi, xr.cpu().numpy()) < (5e-3 if dt == torch.float32 else 1e-8)
+    # graph replay vs eager
+    st = MINRESSettings(minres_tolerance=0.0)
+    before = dict(_graph.STATS)
+    xg = minres(A, B, max_iter=150, settings=st)
+    assert _graph.STATS["captures"] == before["captures"] + 1 and _graph.STATS["replays"] > before["replays"]
+    monkeypatch.setattr(_graph, "MIN_ITERS", 0)
+    xe = minres(A, B, max_iter=150, settings=st)
+    assert torch.equal(xg, xe)
+
+
 def test_generic_solve_double_backward():
     """create_graph=True then a Hessian-vector product vs dense autograd (reference test_sparse_solve.py:391-441)."""
     from torchsparsegradutils_amd.utils import LinearCGSettings, linear_cg

@@ -69,6 +69,14 @@ SIGNATURES = {
         [_int, _int, _i64, _i64, _ptr, _ptr, _ptr, _int, _int, _int, _int, _ptr, _ptr, _ptr, _ptr, _i64, _ptr, _i64,
          _ptr, _ptr, _i64, _i64, _int, _ptr],
     ),
+    "tsgu_minres_scalar": (
+        _int,
+        [_int, _int, _ptr, _i64, _i64, _ptr, _ptr, _ptr, _dbl, _dbl, _dbl, _i64, _int, _ptr],
+    ),
+    "tsgu_minres_vector": (
+        _int,
+        [_int, _int, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _int, _int, _ptr],
+    ),
     "tsgu_rowpack_limits": (
         _int,
         [_int, _i64, ctypes.POINTER(_int), ctypes.POINTER(_int), ctypes.POINTER(_int), ctypes.POINTER(_int)],

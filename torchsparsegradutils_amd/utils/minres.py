@@ -1,12 +1,14 @@
 """``minres`` — drop-in for reference ``torchsparsegradutils/utils/minres.py`` (the default solver of
 ``sparse_generic_solve``, reference sparse_solve.py:406-410).
 
-MINRES is not a kernel target of this build: the Lanczos + Givens
-recurrences below are the same mathematics as the reference, expressed as device tensor ops; what
-runs on the hand-written HIP path is the matvec (K1 SpMM when ``matmul_closure`` is a sparse
-tensor).  Signature, settings, the rhs normalisation, the ``max_iter = min(max_iter, n+1)`` cap,
-the every-10-iterations relative-update stopping test and the shifted-system output layout follow
-reference ``utils/minres.py:140-311``.
+Without a preconditioner and with a single shift (the ``sparse_generic_solve`` default path) the
+Lanczos + Givens recurrences run on the fused K7 kernels (``csrc/minres.hip``): five launches per
+iteration around the K1 SpMM, all per-column scalars on the device, one host read every 10
+iterations — where the reference synchronises for its stopping test — and hipGraph replay of
+10-iteration chunks for long solves.  A preconditioner, several shifts or a ``value`` factor use
+the same mathematics as device tensor ops around the K1 matvec.  Signature, settings, the rhs
+normalisation, the ``max_iter = min(max_iter, n+1)`` cap, the every-10-iterations relative-update
+stopping test and the shifted-system output layout follow reference ``utils/minres.py:140-311``.
 """
 
 from __future__ import annotations
@@ -16,7 +18,8 @@ from typing import Callable, NamedTuple, Optional, Union
 import torch
 
 from .. import _backend as _be
-from ._operator import as_operator
+from . import _graph
+from ._operator import SparseOperator, as_operator
 
 
 class MINRESSettings(NamedTuple):
@@ -61,6 +64,15 @@ def minres(
     def apply(v):
         out = mm(v)
         return out.mul(value) if value is not None else out
+
+    if (preconditioner is None and value is None and shifts.numel() == 1 and rhs.dim() == 2
+            and rhs.dtype in (torch.float32, torch.float64) and 0 < rhs.size(-1) <= 1024 and rhs.size(-2) > 0):
+        sol = _minres_fused(mm, rhs.contiguous(), float(shifts), eps, max_iter, settings).unsqueeze(0)
+        sol = sol.masked_fill(rhs_is_zero, 0)
+        if squeeze:
+            sol = sol.squeeze(-1)
+            rhs_norm = rhs_norm.squeeze(-1)
+        return sol.squeeze(0).mul(rhs_norm)
 
     probe = apply(rhs)
     shifts = shifts.reshape(shifts.shape + (1,) * (probe.dim() - shifts.dim() + 1))
@@ -139,3 +151,84 @@ def minres(
     if shifts.numel() == 1:
         sol = sol.squeeze(0)
     return sol.mul(rhs_norm)
+
+
+def _minres_fused(op, rhs: torch.Tensor, shift: float, eps: float, max_iter: int, settings: MINRESSettings) -> torch.Tensor:
+    """Un-preconditioned single-shift MINRES on the K7 kernels; `rhs` is the normalised (n, p) right-hand side
+    (reference utils/minres.py:241-311; without a preconditioner q == z)."""
+    lib = _be.load_library()
+    n, p = rhs.shape
+    dev, dtype = rhs.device, rhs.dtype
+    vt = _be.vtype_of(rhs)
+    fused_dot = isinstance(op, SparseOperator) and op.dtype == dtype
+    nb = lib.tsgu_cg_num_blocks(vt, n, p)
+    if nb < 0:
+        raise RuntimeError("minres: more than 1024 simultaneous right-hand sides are not supported")
+
+    z = [torch.zeros_like(rhs), rhs.clone()]                     # [z two steps back, z one step back]
+    beta0 = (z[1] * z[1]).sum(dim=-2).sqrt()                    # (minres.py:246-248)
+    z[1] = z[1] / beta0
+    w = [torch.zeros_like(rhs), torch.zeros_like(rhs)]
+    sol = torch.zeros_like(rhs)
+    scal = torch.zeros(12 * p, dtype=dtype, device=dev)
+    scal[p : 2 * p] = beta0
+    scal[11 * p :] = beta0
+    scal[6 * p : 7 * p] = beta0                                  # scale_prev (minres.py:255)
+    scal[2 * p : 3 * p] = 1
+    scal[4 * p : 5 * p] = 1
+    flags = torch.zeros(2, dtype=torch.int32, device=dev)
+    part = torch.empty((2, nb, p), dtype=dtype, device=dev)
+    fold = torch.empty((lib.tsgu_cg_fold_rows(), p), dtype=dtype, device=dev)
+    stream = lambda: torch.cuda.current_stream(dev).cuda_stream  # noqa: E731
+
+    def scalar(phase, partial, rows, set_stride=0):
+        _be.check(lib.tsgu_minres_scalar(vt, phase, partial.data_ptr(), rows, set_stride, fold.data_ptr(), scal.data_ptr(),
+                                         flags.data_ptr(), float(eps), float(settings.minres_tolerance), shift, p,
+                                         dev.index, stream()), "tsgu_minres_scalar")
+
+    def iteration(check: bool):
+        if fused_dot:
+            prod, pzz = op.matmul_with_dot(z[1])                # A z with <z, A z> partials (minres.py:261-262)
+        else:
+            prod = op(z[1]).contiguous()
+            pzz = _be.coldot(prod, z[1]).unsqueeze(0).contiguous()
+        scalar(0, pzz, pzz.shape[0])
+        _be.check(lib.tsgu_minres_vector(vt, 0, n, p, z[0].data_ptr(), z[1].data_ptr(), prod.data_ptr(), None, None,
+                                         scal.data_ptr(), flags.data_ptr(), part.data_ptr(), 0, 0, dev.index, stream()),
+                  "tsgu_minres_vector")
+        scalar(1, part[0], nb)
+        _be.check(lib.tsgu_minres_vector(vt, 1, n, p, z[0].data_ptr(), z[1].data_ptr(), w[0].data_ptr(), w[1].data_ptr(),
+                                         sol.data_ptr(), scal.data_ptr(), flags.data_ptr(), part.data_ptr(), nb * p,
+                                         int(check), dev.index, stream()), "tsgu_minres_vector")
+        if check:
+            scalar(2, part, nb, nb * p)                          # every 10th iteration (minres.py:299-305)
+        z.reverse()                                              # the buffer that held z two steps back now holds z_c
+        w.reverse()
+
+    def chunk10():
+        for k in range(10):
+            iteration(k == 9)
+
+    total = max_iter + 2                                         # (minres.py:259)
+    i = 0
+    graph = None
+    try_graph = fused_dot and _graph.enabled()
+    with torch.cuda.device(dev):
+        while i < total:
+            if i % 10 == 0 and total - i >= 10:
+                if try_graph and graph is None and i >= 10 and total - i >= _graph.MIN_ITERS:
+                    graph = _graph.capture(chunk10, 1)           # buffer roles return after an even number of steps
+                    try_graph = graph is not None
+                if graph is not None:
+                    _graph.replay(graph)
+                else:
+                    chunk10()
+                i += 10
+                if bool(flags[0].item()):
+                    break
+            else:
+                iteration((i + 1) % 10 == 0)
+                i += 1
+                if i % 10 == 0 and bool(flags[0].item()):
+                    break
+    return sol
