@@ -9,6 +9,7 @@ missing, or a tensor does not live on a HIP device, the call raises.
 from __future__ import annotations
 
 import ctypes
+import functools
 import os
 import threading
 from typing import Optional
@@ -326,6 +327,7 @@ def tiled_geometry(dtype: torch.dtype, p: int):
     return rpt.value, mx.value, me.value
 
 
+@functools.lru_cache(maxsize=None)
 def blocktile_limits(dtype: torch.dtype, p: int, tile: bool = False):
     """(rows_per_block, row_bytes, (distinct_multiple, max_distinct, max_entries, lds_budget_bytes)) of the
     block-dictionary kernels (LDS-tiled or gather-from-global flavour), or None when (dtype, p) is not covered."""
@@ -379,6 +381,7 @@ def csr_mm_backward_blocktile(tcrow, bp, val, G, B, n_rows_t: int, tile: bool = 
     return grad_a, grad_b
 
 
+@functools.lru_cache(maxsize=None)
 def rowpack_limits(dtype: torch.dtype, p: int):
     """(rows_per_block, (max_entries, max_union, lds_budget_bytes)) of the row-pair gather kernels, or None."""
     if dtype != torch.float32 or p <= 0:
