@@ -340,6 +340,40 @@ def test_rowpack_brick_ownership_on_lattices(kind, monkeypatch):
     assert used and used[0].vpair is not None
 
 
+def test_rowpack_strided_operands_beyond_4GiB_use_64bit_offsets():
+    """Dense operands handed over as column slices of wider arrays (leading dimension 1024): the gathered operand then
+    spans more than 4 GiB and the row-pair kernels must take their 64-bit-offset instantiation; results must equal the
+    contiguous (32-bit-offset) run bit for bit."""
+    from torchsparsegradutils_amd import _backend as be, _pattern
+    from torchsparsegradutils_amd.utils import synthetic
+
+    dims = (104, 104, 104)
+    n, p, ld = dims[0] * dims[1] * dims[2], 32, 1024
+    assert n * ld * 4 > 2**32
+    crow, col = synthetic.stencil27_periodic(*dims, torch.int32, device=DEV)
+    g = _pattern.RowGather(crow, col, n, n)
+    gt = g.transposed
+    geo = be.rowpack_limits(torch.float32, p)
+    rp, rpt = g.rowpack_plan(*geo), gt.rowpack_plan(*geo)
+    assert rp is not None and rpt is not None
+    gen = torch.Generator(device=DEV).manual_seed(7)
+    val = torch.randn(col.numel(), device=DEV, generator=gen)
+    wideB = torch.empty((n, ld), device=DEV)
+    wideG = torch.empty((n, ld), device=DEV)
+    Bs, Gs = wideB[:, 64 : 64 + p], wideG[:, 128 : 128 + p]
+    Bs.copy_(torch.randn(n, p, device=DEV, generator=gen))
+    Gs.copy_(torch.randn(n, p, device=DEV, generator=gen))
+    assert be.rowmajor(Bs) is Bs and Bs.stride(0) == ld
+    Bc, Gc = Bs.contiguous(), Gs.contiguous()
+    assert torch.equal(be.csr_spmm_rowpack(g.crow, val, rp, Bs, n), be.csr_spmm_rowpack(g.crow, val, rp, Bc, n))
+    gA1, gB1 = be.csr_mm_backward_rowpack(gt.crow, rpt, val, Gs, Bs, n)
+    gA0, gB0 = be.csr_mm_backward_rowpack(gt.crow, rpt, val, Gc, Bc, n)
+    assert torch.equal(gA1, gA0) and torch.equal(gB1, gB0)
+    # and the contiguous run agrees with the plain gather kernels on sampled rows
+    ref = be.csr_spmm(g.crow, g.col, val, Bc, n, n)
+    assert torch.equal(be.csr_spmm_rowpack(g.crow, val, rp, Bc, n), ref)
+
+
 def test_mm_short_rows_multi_run_workgroups_and_cg_dot_epilogue():
     """Short rows (several runs of rows per workgroup), with one row longer than the staging window inside
     such a workgroup, for p in {1, 4, 5}; plus the fused pᵀ(Ap) epilogue against a plain column dot."""

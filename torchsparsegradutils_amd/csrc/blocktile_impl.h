@@ -87,19 +87,11 @@ __global__ __launch_bounds__(kBlock) void csr_blocktile_kernel(const BtParams P)
     const int64_t row1 = row0 + RPB < P.n_rows ? row0 + RPB : P.n_rows;
     const int64_t row = row0 + grp;
     const bool row_ok = row < P.n_rows;
-#ifdef TSGU_BT_DEBUG_CONST  // timing probe only: uniform 27 entries per row, no header loads
-    const int64_t e0 = row0 * 27;
-    const int ne = (int)((row1 - row0) * 27);
-    const int nd = P.capd - 8;
-    const int lo = row_ok ? (int)((row - row0) * 27) : 0;
-    const int hi = row_ok ? lo + 27 : 0;
-#else
     const int64_t e0 = (int64_t)ptr[row0];
     const int ne = (int)((int64_t)ptr[row1] - e0);
     const int nd = P.ndist[vb];
     const int lo = row_ok ? (int)((int64_t)ptr[row] - e0) : 0;
     const int hi = row_ok ? (int)((int64_t)ptr[row + 1] - e0) : 0;
-#endif
     const int* __restrict__ trow = P.trow + vb * P.capd;
 
     // ---- phase A: everything the block needs goes to LDS by DMA --------------------------------
@@ -112,11 +104,7 @@ __global__ __launch_bounds__(kBlock) void csr_blocktile_kernel(const BtParams P)
             src[t] = 0;
             if (d0 < nd) {
                 const int d = d0 + lane / CL;
-#ifdef TSGU_BT_DEBUG_CONST  // timing probe only (wrong results): every block loads the same L1-resident rows
-                src[t] = d;
-#else
                 src[t] = stream_load(trow + (d < nd ? d : nd - 1));
-#endif
             }
         }
     }

@@ -151,11 +151,7 @@ __global__ __launch_bounds__(kBlock) TSGU_RP_OCC void csr_rowpack_kernel(const R
         const int t = q * kBlock + tid;
         if (q * kBlock < ne) {
             if (t < ne) {
-#ifdef TSGU_RP_DEBUG_CONTIG_VAL  // timing probe only
-                const float* vsrc = P.val + e0 + t;
-#else
                 const float* vsrc = PERM ? P.val + qv[q] : P.val + e0 + t;
-#endif
                 __builtin_amdgcn_global_load_lds((rp_glb_ptr)vsrc, (rp_lds_ptr)(s_val + q * kBlock + wave * kWave), 4, 0, PERM ? 0 : 2);
             }
         }
@@ -200,9 +196,6 @@ __global__ __launch_bounds__(kBlock) TSGU_RP_OCC void csr_rowpack_kernel(const R
     };
 
     int i = lo;
-#ifdef TSGU_RP_DEBUG_SKIP_B  // timing probe only
-    i = hi;
-#endif
     if constexpr (PERM) {
         for (; i + U <= hi; i += U) {
             int c[U];
@@ -276,11 +269,7 @@ __global__ __launch_bounds__(kBlock) TSGU_RP_OCC void csr_rowpack_kernel(const R
         for (int q = 0; q < kRpMaxQ; ++q) {
             const int t = q * kBlock + tid;
             if (q * kBlock < ne) {
-#ifndef TSGU_RP_DEBUG_SKIP_SCATTER
                 if (t < ne) P.gradA[qv[q]] = s_val[t];
-#else
-                if (t < ne) P.gradA[e0 + t] = s_val[t];  // timing probe only: contiguous
-#endif
             }
         }
     }
