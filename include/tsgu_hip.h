@@ -203,6 +203,14 @@ int tsgu_csr_mm_backward_rowpack(int vtype, int itype, int64_t n_rows_t, int64_t
                                  const void* sperm, const void* order, const void* vpair, const void* eptr, int64_t nblocks,
                                  const void* val, const void* G, int64_t ldg, const void* B, int64_t ldb,
                                  void* gradA_vals, void* gradB, int64_t ldgb, int64_t p, int device, void* stream);
+/* Row-pair SDDMM (same plan as tsgu_csr_spmm_rowpack for a pattern walked in stored order; replaces tsgu_csr_sddmm,
+ * reference sparse_matmul.py:186-205, sparse_solve.py:223-235): out_vals[k] = alpha·<R[row k,:], Cm[col k,:]>.  The dense
+ * rows of Cm that both rows of a pair reference are gathered once; the gradients leave in stored order with one
+ * coalesced write per workgroup.  The G/B role swap of the solves is expressed by exchanging R and Cm. */
+int tsgu_csr_sddmm_rowpack(int vtype, int itype, int64_t n_rows, int64_t n_cols, int64_t nnz, const void* ptr,
+                           const void* uptr, const void* ucol, int ecap, int ucap, const void* order,
+                           const void* R, int64_t ldr, const void* Cm, int64_t ldc, void* out_vals, double alpha,
+                           int64_t p, int device, void* stream);
 
 /*
  * Wave-pipelined, LDS-tiled variants of K1/K2/K3 ("wavetile") for patterns whose neighbouring rows

@@ -237,6 +237,12 @@ def test_block_dictionary_kernels_match_oracle(p, itype, monkeypatch):
     assert rel(gB2, gB_o) < 1e-5 and rel(gA3, gA_o) < 1e-5 and torch.equal(gB2, gB3)
     if p >= 32:
         assert torch.equal(gB3, be.csr_spmm(gt.crow, gt.col, vd, Gdev, m, n, perm=gt.perm))
+    # SDDMM through the union walk (stored order), plain and with the scale / role swap the solves use
+    assert rel(be.csr_sddmm_rowpack(g.crow, rp, Gdev, Bd, n), gA_o) < 1e-5
+    Xs = torch.randn(n, p, device=DEV)
+    Ys = torch.randn(m, p, device=DEV) if m != n else torch.randn(n, p, device=DEV)
+    want = be.csr_sddmm(g.crow, g.col, Xs, Ys, n, m, alpha=-1.0)
+    assert rel(be.csr_sddmm_rowpack(g.crow, rp, Xs, Ys, n, alpha=-1.0), want.cpu().numpy()) < 1e-5
     # a row must never touch a dense row it does not reference: poison one row of B that only ONE row of a pair uses
     rows_of = lambda c: set(np.nonzero(col == c)[0].tolist())  # noqa: E731
     rowidx = np.repeat(np.arange(n), np.diff(crow))

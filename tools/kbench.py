@@ -131,6 +131,10 @@ def main():
             fns["spmm_rp"] = lambda: be.csr_spmm_rowpack(crow, val, rp, B, n)
             fns["spmmt_rp"] = lambda: be.csr_spmm_rowpack(pt.crow, val, rpt, G, n)
             fns["bwd_rp"] = lambda: be.csr_mm_backward_rowpack(pt.crow, rpt, val, G, B, n)
+            by["sddmm_rp"] = by["sddmm"]
+            fns["sddmm_rp"] = lambda: be.csr_sddmm_rowpack(crow, rp, G, B, n)
+            if a.check:
+                print("  sddmm_rp vs sddmm:", float((fns["sddmm"]() - fns["sddmm_rp"]()).abs().max()))
             if a.tile_order:
                 # experiment: (x-plane, yz-tile) loop interchange inside each XCD chunk of 64-row blocks
                 nb = (n + rp.rpb - 1) // rp.rpb

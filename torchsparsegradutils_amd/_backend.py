@@ -87,6 +87,11 @@ SIGNATURES = {
         [_int, _int, _i64, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _int, _int, _ptr, _ptr, _ptr, _ptr, _i64, _ptr, _ptr, _i64, _ptr,
          _i64, _i64, _int, _ptr],
     ),
+    "tsgu_csr_sddmm_rowpack": (
+        _int,
+        [_int, _int, _i64, _i64, _i64, _ptr, _ptr, _ptr, _int, _int, _ptr, _ptr, _i64, _ptr, _i64, _ptr, _dbl, _i64, _int,
+         _ptr],
+    ),
     "tsgu_csr_mm_backward_rowpack": (
         _int,
         [_int, _int, _i64, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _int, _int, _ptr, _ptr, _ptr, _ptr, _i64, _ptr, _ptr, _i64, _ptr,
@@ -409,6 +414,24 @@ def csr_spmm_rowpack(crow, val, rp, B, n_rows: int):
                 dev.index, _stream(dev),
             ),
             "tsgu_csr_spmm_rowpack",
+        )
+    return out
+
+
+def csr_sddmm_rowpack(crow, rp, R, Cm, n_rows: int, alpha: float = 1.0):
+    """out[k] = alpha·<R[row k], Cm[col k]> in stored order through the row-pair union walk (plan of a stored-order pattern)."""
+    lib = load_library()
+    dev = require_device(crow, R, Cm)
+    R, Cm = rowmajor(R), rowmajor(Cm)
+    p = R.size(-1)
+    out = torch.empty((rp.nnz,), dtype=R.dtype, device=dev)
+    with torch.cuda.device(dev):
+        check(
+            lib.tsgu_csr_sddmm_rowpack(
+                vtype_of(R), itype_of(crow), n_rows, Cm.size(0), rp.nnz, _p(crow), _p(rp.uptr), _p(rp.ucol), rp.ecap,
+                rp.ucap, _p(rp.order), _p(R), _ld(R), _p(Cm), _ld(Cm), _p(out), float(alpha), p, dev.index, _stream(dev),
+            ),
+            "tsgu_csr_sddmm_rowpack",
         )
     return out
 

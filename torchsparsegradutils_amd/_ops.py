@@ -92,6 +92,11 @@ def spmm(plan: RowGather, values: torch.Tensor, B: torch.Tensor) -> torch.Tensor
 def sddmm(plan: RowGather, G: torch.Tensor, B: torch.Tensor, alpha: float = 1.0, swap_roles: bool = False) -> torch.Tensor:
     """alpha·<G[row k], B[col k]> (or roles swapped) at the plan's stored entries, in plan order."""
     gathered = G if swap_roles else B
+    rowop = B if swap_roles else G
+    if plan.perm is None and G.dtype == B.dtype:
+        rp = _pack_for(plan, gathered, rowop)
+        if rp is not None:
+            return _be.csr_sddmm_rowpack(plan.crow, rp, rowop, gathered, plan.n_rows, alpha=alpha)
     tiles = _tiles_for(plan, gathered, B if swap_roles else G) if G.dtype == B.dtype else None
     if tiles is not None:
         return _be.csr_sddmm_tiled(plan.crow, tiles, G, B, plan.n_rows, plan.n_cols, alpha=alpha, swap_roles=swap_roles)

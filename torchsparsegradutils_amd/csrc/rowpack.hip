@@ -88,4 +88,30 @@ int tsgu_csr_mm_backward_rowpack(int vtype, int itype, int64_t n_rows_t, int64_t
     return TSGU_ERR_BAD_DTYPE;
 }
 
+int tsgu_csr_sddmm_rowpack(int vtype, int itype, int64_t n_rows, int64_t n_cols, int64_t nnz, const void* ptr,
+                           const void* uptr, const void* ucol, int ecap, int ucap, const void* order,
+                           const void* R, int64_t ldr, const void* Cm, int64_t ldc, void* out_vals, double alpha,
+                           int64_t p, int device, void* stream) {
+    if (vtype != TSGU_F32) return TSGU_ERR_BAD_DTYPE;
+    RpParams P{};
+    // the value array is not read: pass the output as a placeholder for the non-null check
+    if (const int rc = fill(P, n_rows, n_cols, nnz, p, ptr, uptr, ucol, nullptr, ecap, ucap, nullptr, order, nullptr, nullptr, 0,
+                            out_vals))
+        return rc;
+    if (n_rows == 0 || nnz == 0) return TSGU_OK;
+    if (!R || !Cm || !out_vals || ldr < p || ldc < p) return TSGU_ERR_BAD_ARG;
+    if (const int rc = set_device(device)) return rc;
+    P.val = nullptr;
+    P.Own = static_cast<const float*>(R);
+    P.ldown = ldr;
+    P.S = static_cast<const float*>(Cm);
+    P.lds_ = ldc;
+    P.gradA = static_cast<float*>(out_vals);
+    P.alpha = (float)alpha;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (itype == TSGU_I32) return rp_launch<int32_t, kRpSddmm, false>(P, s);
+    if (itype == TSGU_I64) return rp_launch<int64_t, kRpSddmm, false>(P, s);
+    return TSGU_ERR_BAD_DTYPE;
+}
+
 }  // extern "C"

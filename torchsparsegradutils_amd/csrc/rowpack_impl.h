@@ -27,7 +27,7 @@
 
 namespace tsgu {
 
-enum RpMode { kRpSpmm = 0, kRpBwd = 1 };
+enum RpMode { kRpSpmm = 0, kRpBwd = 1, kRpSddmm = 2 };
 
 struct RpParams {
     int64_t n_rows, nnz, p;
@@ -48,7 +48,8 @@ struct RpParams {
     int64_t ldown;
     float* out;             // C / gradB
     int64_t ldo;
-    float* gradA;           // backward: [nnz] in A's order
+    float* gradA;           // backward: [nnz] in A's order; SDDMM: [nnz] output in walked order
+    float alpha;            // SDDMM scale
     int ecap, ucap;         // LDS capacities: staged values / union records per workgroup
     int64_t nblocks;
 };
@@ -83,7 +84,8 @@ __global__ __launch_bounds__(kBlock) TSGU_RP_OCC void csr_rowpack_kernel(const R
 
 
     constexpr int U = (MODE == kRpBwd && TSGU_RP_UB > 0) ? TSGU_RP_UB : TSGU_RP_U;  // gathers in flight per lane
-    static_assert(MODE == kRpSpmm || PERM, "the backward always walks the transposed pattern");
+    static_assert(MODE != kRpBwd || PERM, "the backward always walks the transposed pattern");
+    static_assert(MODE != kRpSddmm || !PERM, "SDDMM walks the pattern in stored order");
 
     extern __shared__ uint4 rp_smem[];
     int* s_ucol = reinterpret_cast<int*>(rp_smem);
@@ -146,6 +148,7 @@ __global__ __launch_bounds__(kBlock) TSGU_RP_OCC void csr_rowpack_kernel(const R
             }
         }
     }
+    if constexpr (MODE != kRpSddmm) {  // SDDMM reads no values
 #pragma unroll
     for (int q = 0; q < kRpMaxQ; ++q) {
         const int t = q * kBlock + tid;
@@ -156,10 +159,11 @@ __global__ __launch_bounds__(kBlock) TSGU_RP_OCC void csr_rowpack_kernel(const R
             }
         }
     }
+    }
     float own_a[VEC], own_b[VEC], acc_a[VEC], acc_b[VEC];
 #pragma unroll
     for (int v = 0; v < VEC; ++v) own_a[v] = own_b[v] = acc_a[v] = acc_b[v] = 0.f;
-    if constexpr (MODE == kRpBwd) {
+    if constexpr (MODE != kRpSpmm) {
         if (pair_ok) load_vec<float, VEC>(P.Own + ra * P.ldown + cl * VEC, own_a);
         if (pair_ok && b_ok) load_vec<float, VEC>(P.Own + rb * P.ldown + cl * VEC, own_b);
     }
@@ -227,12 +231,21 @@ __global__ __launch_bounds__(kBlock) TSGU_RP_OCC void csr_rowpack_kernel(const R
         // (bits 30 / 31 of ucol) and two running counters replace the slot words (no upos stream, half the record LDS)
         int ka = pair_ok ? (int)((int64_t)ptr[ra] - e0) : 0;
         int kb = (pair_ok && b_ok) ? (int)((int64_t)ptr[rb] - e0) : 0;
-        auto use_seq = [&](const float (&g)[VEC], bool present, int& k, float (&acc)[VEC]) {
+        auto use_seq = [&](const float (&g)[VEC], bool present, int& k, float (&acc)[VEC], const float (&own)[VEC]) {
             if (present) {
-                const float a = s_val[k];
-                ++k;
+                if constexpr (MODE == kRpSddmm) {
+                    // gradient of the stored entry: <row operand, gathered column operand>, into the entry's slot
+                    float d = own[0] * g[0];
 #pragma unroll
-                for (int v = 0; v < VEC; ++v) acc[v] = fma(a, g[v], acc[v]);
+                    for (int v = 1; v < VEC; ++v) d = fma(own[v], g[v], d);
+                    d = group_sum<float, CL>(d);
+                    if (cl == 0) s_val[k] = d;
+                } else {
+                    const float a = s_val[k];
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) acc[v] = fma(a, g[v], acc[v]);
+                }
+                ++k;
             }
         };
         for (; i + U <= hi; i += U) {
@@ -244,22 +257,34 @@ __global__ __launch_bounds__(kBlock) TSGU_RP_OCC void csr_rowpack_kernel(const R
             for (int u = 0; u < U; ++u) gather((int)(w[u] & 0x3fffffffu), g[u]);
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                use_seq(g[u], (w[u] >> 30) & 1u, ka, acc_a);
-                use_seq(g[u], w[u] >> 31, kb, acc_b);
+                use_seq(g[u], (w[u] >> 30) & 1u, ka, acc_a, own_a);
+                use_seq(g[u], w[u] >> 31, kb, acc_b, own_b);
             }
         }
         for (; i < hi; ++i) {
             const uint32_t w = (uint32_t)s_ucol[i];
             float g[VEC];
             gather((int)(w & 0x3fffffffu), g);
-            use_seq(g, (w >> 30) & 1u, ka, acc_a);
-            use_seq(g, w >> 31, kb, acc_b);
+            use_seq(g, (w >> 30) & 1u, ka, acc_a, own_a);
+            use_seq(g, w >> 31, kb, acc_b, own_b);
         }
     }
 
-    if (pair_ok) {
-        store_vec<float, VEC, true>(P.out + ra * P.ldo + cl * VEC, acc_a);
-        if (b_ok) store_vec<float, VEC, true>(P.out + rb * P.ldo + cl * VEC, acc_b);
+    if constexpr (MODE != kRpSddmm) {
+        if (pair_ok) {
+            store_vec<float, VEC, true>(P.out + ra * P.ldo + cl * VEC, acc_a);
+            if (b_ok) store_vec<float, VEC, true>(P.out + rb * P.ldo + cl * VEC, acc_b);
+        }
+    } else {
+        // the block's gradients sit in stored order in LDS: one coalesced, streaming write
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < kRpMaxQ; ++q) {
+            const int t = q * kBlock + tid;
+            if (q * kBlock < ne) {
+                if (t < ne) __builtin_nontemporal_store(P.alpha * s_val[t], P.gradA + e0 + t);
+            }
+        }
     }
 
     if constexpr (MODE == kRpBwd) {
@@ -277,8 +302,9 @@ __global__ __launch_bounds__(kBlock) TSGU_RP_OCC void csr_rowpack_kernel(const R
 
 template <typename I, int MODE, bool PERM>
 int rp_launch(RpParams P, hipStream_t stream) {
-    if (P.p % 4 != 0 || P.lds_ % 4 != 0 || P.ldo % 4 != 0 || !aligned16(P.S) || !aligned16(P.out)) return TSGU_ERR_BAD_ARG;
-    if (MODE == kRpBwd && (P.ldown % 4 != 0 || !aligned16(P.Own))) return TSGU_ERR_BAD_ARG;
+    if (P.p % 4 != 0 || P.lds_ % 4 != 0 || !aligned16(P.S)) return TSGU_ERR_BAD_ARG;
+    if (MODE != kRpSddmm && (P.ldo % 4 != 0 || !aligned16(P.out))) return TSGU_ERR_BAD_ARG;
+    if (MODE != kRpSpmm && (P.ldown % 4 != 0 || !aligned16(P.Own))) return TSGU_ERR_BAD_ARG;
     const int64_t cl = P.p / 4;
     if (cl != 4 && cl != 8 && cl != 16) return TSGU_ERR_BAD_ARG;
     if (P.ecap <= 0 || P.ucap <= 0 || P.ecap > kRpMaxQ * kBlock || P.ucap > kRpMaxU * kBlock || P.ecap >= kRpAbsent ||
