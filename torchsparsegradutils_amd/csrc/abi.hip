@@ -53,7 +53,8 @@ int64_t tsgu_spmm_num_blocks(int vtype, int64_t n_rows, int64_t nnz_per_item, in
     // mirrors spmm_geom(): the fused-dot path is only used with contiguous, 16-byte
     // aligned operands, so "wide" depends on p alone.
     const int wide = vtype == TSGU_F32 ? 4 : vtype == TSGU_F64 ? 2 : 8;
-    const RowGeom g = pick_geom(wide, p % wide == 0, p);
+    RowGeom g = pick_geom(wide, p % wide == 0, p);
+    prefer_row_per_lane(g, n_rows, nnz_per_item);  // the fused-dot path never walks a permutation
     const int64_t rpb = kBlock / (g.cl * g.ep);
     const int64_t rows = rpb * spmm_row_mult(n_rows, nnz_per_item, rpb);
     return (n_rows + rows - 1) / rows;

@@ -285,7 +285,9 @@ inline RowGeom spmm_geom(const SpmmParams& P, int64_t batch) {
     bool can = (P.p % wide == 0) && (P.ldb % wide == 0) && (P.ldc % wide == 0) && aligned16(P.B) && aligned16(P.C);
     if (batch > 1) can = can && (P.b_bs % wide == 0) && (P.c_bs % wide == 0);
     if (P.W) can = can && (P.ldw % wide == 0) && aligned16(P.W);
-    return pick_geom(wide, can, P.p);
+    RowGeom g = pick_geom(wide, can, P.p);
+    if (!P.perm) prefer_row_per_lane(g, P.n_rows, P.nnz_per_item);
+    return g;
 }
 
 template <typename V, typename I>

@@ -255,11 +255,21 @@ inline RowGeom pick_geom(int wide, bool can_wide, int64_t p) {
     return g;
 }
 
+// One lane per row (CL = EP = 1) for operands whose dense row is a single 16-byte access and whose sparse rows are
+// short: consecutive lanes own consecutive rows, so for banded / stencil patterns the k-th gathers of a wave fall on
+// consecutive dense rows — one contiguous kilobyte instead of 64 separate lines through L1 (C4's 7-point Laplacian
+// with 4 right-hand sides: K1 85 -> ... us).  Longer or ragged rows keep 8 entry lanes per row.
+inline void prefer_row_per_lane(RowGeom& g, int64_t n_rows, int64_t nnz) {
+    if (g.cl == 1 && g.vec > 1 && n_rows > 0 && nnz <= 16 * n_rows) g.ep = 1;
+}
+
 template <typename F>
 inline int dispatch_geom(const RowGeom& g, F&& f) {
     // f.template operator()<CL, EP>()
     switch (g.cl) {
-        case 1: return f(std::integral_constant<int, 1>{}, std::integral_constant<int, 8>{});
+        case 1:
+            if (g.ep == 1) return f(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+            return f(std::integral_constant<int, 1>{}, std::integral_constant<int, 8>{});
         case 2: return f(std::integral_constant<int, 2>{}, std::integral_constant<int, 4>{});
         case 4: return f(std::integral_constant<int, 4>{}, std::integral_constant<int, 2>{});
         case 8: return f(std::integral_constant<int, 8>{}, std::integral_constant<int, 1>{});
