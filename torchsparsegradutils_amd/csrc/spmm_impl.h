@@ -286,7 +286,7 @@ inline RowGeom spmm_geom(const SpmmParams& P, int64_t batch) {
     if (batch > 1) can = can && (P.b_bs % wide == 0) && (P.c_bs % wide == 0);
     if (P.W) can = can && (P.ldw % wide == 0) && aligned16(P.W);
     RowGeom g = pick_geom(wide, can, P.p);
-    if (!P.perm) prefer_row_per_lane(g, P.n_rows, P.nnz_per_item);
+    prefer_row_per_lane(g, P.n_rows, P.nnz_per_item);
     return g;
 }
 
