@@ -53,9 +53,13 @@ def _worker(rank, world, port, batch, q):
         want = torch.stack([items[i].to_dense() @ B[i] for i in range(batch)])
         lo, hi = parallel.shard_bounds(batch, world, rank)
         local = parallel.sharded_batched_apply(_oracle_batched_mm, A, B, gather=False)
+        # run-by-run compute with asynchronous gathers (falls back to the single gather for ragged shards)
+        piped = parallel.sharded_batched_apply(_oracle_batched_mm, A, B, overlap_chunks=2)
         ok = (
             full.shape == want.shape
             and torch.allclose(full, want, atol=1e-12)
+            and piped.shape == want.shape
+            and torch.equal(piped, full)
             and local.shape[0] == hi - lo
             and torch.allclose(local, want[lo:hi], atol=1e-12)
         )
