@@ -247,18 +247,29 @@ __global__ __launch_bounds__(kBlock) void csr_spmm_kernel(const SpmmParams P) {
     }
 
     if constexpr (DOT) {
-        // partial[block][c] = Σ_rows C[row,c]·W[row,c], reduced over the row groups in a fixed order
+        // partial[block][c] = Σ_rows C[row,c]·W[row,c]: the lanes of a wave that own the same columns are summed with
+        // xor-shuffles (fixed tree), then the four waves through LDS — a serial sum over the row groups costs
+        // 256 dependent LDS reads per workgroup with one lane per row (10 us at C4).
         constexpr int TW = CL * VEC;  // columns covered by one column tile
+        const int lane = tid & (kWave - 1), wave = tid / kWave;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            Acc x = ep == 0 ? dotp[v] : (Acc)0;
+#pragma unroll
+            for (int m = CL; m < kWave; m <<= 1) x += shfl_xor_acc(x, m);
+            dotp[v] = x;
+        }
         __syncthreads();
         Acc* red = reinterpret_cast<Acc*>(smem);
-        if (ep == 0) {
+        constexpr int NW = kBlock / kWave;
+        if (lane < CL) {
 #pragma unroll
-            for (int v = 0; v < VEC; ++v) red[grp * TW + cl * VEC + v] = dotp[v];
+            for (int v = 0; v < VEC; ++v) red[wave * TW + lane * VEC + v] = dotp[v];
         }
         __syncthreads();
         if (tid < TW) {
             Acc s = 0;
-            for (int r = 0; r < RPB; ++r) s += red[r * TW + tid];
+            for (int r = 0; r < NW; ++r) s += red[r * TW + tid];
             const int64_t c = (int64_t)blockIdx.z * TW + tid;
             if (c < P.p) {
                 static_cast<Acc*>(P.dot_partial)[(item * P.nblocks + vb) * P.p + c] = s;
