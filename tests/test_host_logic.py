@@ -160,7 +160,10 @@ def test_abi_library_exports_every_declared_symbol():
     assert lib.tsgu_status_string(-2).decode().startswith("bad argument")
     # pure host-side helpers of the ABI
     assert lib.tsgu_spmm_num_blocks(_backend.TSGU_F32, 10 ** 6, 27 * 10 ** 6, 32) == 31250
-    assert lib.tsgu_spmm_num_blocks(_backend.TSGU_F32, 2000376, 13907376, 4) == 10419  # short rows: 6 runs of 32 rows
+    # 16-byte dense rows + short sparse rows: one lane per row, 256 rows per workgroup
+    assert lib.tsgu_spmm_num_blocks(_backend.TSGU_F32, 2000376, 13907376, 4) == 7814
+    # the same operand with long rows keeps 8 entry lanes per row (32 rows per workgroup)
+    assert lib.tsgu_spmm_num_blocks(_backend.TSGU_F32, 2000376, 40 * 2000376, 4) == 62512
     assert lib.tsgu_sptrsm_work_bytes(10, 1) >= 516
 
 
