@@ -258,7 +258,7 @@ inline RowGeom pick_geom(int wide, bool can_wide, int64_t p) {
 // One lane per row (CL = EP = 1) for operands whose dense row is a single 16-byte access and whose sparse rows are
 // short: consecutive lanes own consecutive rows, so for banded / stencil patterns the k-th gathers of a wave fall on
 // consecutive dense rows — one contiguous kilobyte instead of 64 separate lines through L1 (C4's 7-point Laplacian
-// with 4 right-hand sides: K1 85 -> ... us).  Longer or ragged rows keep 8 entry lanes per row.
+// with 4 right-hand sides: K1 with the dot epilogue 85 -> 43 us).  Longer or ragged rows keep 8 entry lanes per row.
 inline void prefer_row_per_lane(RowGeom& g, int64_t n_rows, int64_t nnz) {
     if (g.cl == 1 && g.vec > 1 && n_rows > 0 && nnz <= 16 * n_rows) g.ep = 1;
 }
