@@ -13,12 +13,17 @@ RCCL all-gather of the forward result is timed separately and reported in `allga
 
 value = algorithmic GB/s of the whole job = N · 1188 MB / max-over-ranks step time
 (476 MB forward + 712 MB minimum fused backward).  One JSON line on rank 0.
+
+The line also carries `c5`: BASELINE.json configs[4] (batched CSR, 64 items of N=131072, 27 nnz/row, 16 RHS, bf16)
+sharded over the N ranks through `torchsparsegradutils_amd.parallel` — compute-only and end-to-end (with the RCCL
+all-gather of the result) reported separately.  `--no-c5` skips it.
 """
 
 import argparse
 import json
 import os
 import statistics
+import subprocess
 import sys
 import time
 
@@ -30,11 +35,11 @@ import torch  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
 
-def alg_bytes(n, nnz, p, I=4, V=4):
+def alg_bytes(n, nnz, p, I=4, V=4, items=1):
     spmm = (n + 1) * I + nnz * (I + V) + 2 * n * p * V
     sddmm = (n + 1) * I + nnz * I + 2 * n * p * V + nnz * V
     fused_bwd = (n + 1) * I + nnz * (I + V) + 2 * n * p * V + nnz * V + n * p * V  # crow,col,val,G,B in; gradA,gradB out
-    return {"spmm": spmm, "sddmm": sddmm, "spmm_t": spmm, "fwd_bwd": spmm + fused_bwd}
+    return {k: v * items for k, v in {"spmm": spmm, "sddmm": sddmm, "spmm_t": spmm, "bwd": fused_bwd, "fwd_bwd": spmm + fused_bwd}.items()}
 
 
 def time_events(fn, reps, dev):
@@ -50,12 +55,21 @@ def time_events(fn, reps, dev):
     return start.elapsed_time(stop) / reps
 
 
-def cpu_baseline_leg(p):
-    """Reference op sequence (oracle/aten_port.py) on the host cores, bounded sample of C2."""
+def host_cores():
+    try:
+        out = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout
+        keep = [ln.strip() for ln in out.splitlines() if ln.split(":")[0].strip() in ("Model name", "CPU(s)", "Socket(s)", "Core(s) per socket", "Thread(s) per core")]
+        return "; ".join(" ".join(k.split()) for k in keep)
+    except Exception:  # noqa: BLE001
+        return f"{os.cpu_count()} CPUs"
+
+
+def cpu_baseline_leg(nx, ny, nz, p):
+    """Reference op sequence (oracle/aten_port.py) on the host cores, on the FULL C2 input (same generator as the GPU
+    run), 3 timed repeats after 1 warm-up."""
     from oracle import aten_port
     from torchsparsegradutils_amd.utils import synthetic
 
-    nx, ny, nz = 100, 50, 50  # quarter of the C2 grid: 250 000 rows × 27
     n = nx * ny * nz
     crow, col = synthetic.stencil27_periodic(nx, ny, nz, torch.int32)
     g = torch.Generator().manual_seed(0)
@@ -64,21 +78,96 @@ def cpu_baseline_leg(p):
     B = torch.randn(n, p, generator=g)
     G = torch.randn(n, p, generator=g)
     times = []
-    for it in range(3):
+    budget = time.perf_counter() + 90.0  # never let the baseline dominate the run
+    for it in range(4):
         t0 = time.perf_counter()
         aten_port.mm_forward(A, B)
         aten_port.mm_backward(A, B, G)
         times.append(time.perf_counter() - t0)
-    t = statistics.median(times[1:]) if len(times) > 1 else times[0]
+        if time.perf_counter() > budget and len(times) >= 2:
+            break
+    timed = times[1:]
+    t = statistics.median(timed)
     b = alg_bytes(n, col.numel(), p)["fwd_bwd"]
     return {
         "value": round(b / t / 1e9, 3),
         "unit": "GB/s",
         "cores": torch.get_num_threads(),
         "kind": "port",
-        "sample": f"N={n} rows ({nx}x{ny}x{nz} periodic 27-pt, nnz={col.numel()}), {p} RHS, fp32/int32, fwd+bwd via the "
-                  f"reference's ATen op chain, median of 2 after 1 warm-up: {t * 1e3:.0f} ms/step; host has {os.cpu_count()} CPUs",
+        "sample": f"full workload: N={n} rows ({nx}x{ny}x{nz} periodic 27-pt, nnz={col.numel()}), {p} RHS, fp32/int32, fwd+bwd via "
+                  f"the reference's ATen op chain (oracle/aten_port.py), median of {len(timed)} after 1 warm-up: {t * 1e3:.0f} ms/step "
+                  f"(all: {[round(x * 1e3) for x in times]} ms); host: {host_cores()}",
     }
+
+
+def c5_leg(dev, world, rank, steps, warmup, barrier):
+    """BASELINE configs[4]: 64 independent periodic 27-pt stencils on 64x64x32 (N=131072), bf16, 16 RHS, sharded over
+    the ranks by `parallel.sharded_batched_apply` (contiguous batch split, local kernels, one all-gather of the result)."""
+    import torch.distributed as dist
+
+    from torchsparsegradutils_amd import parallel, sparse_mm
+    from torchsparsegradutils_amd.utils import synthetic
+
+    nx, ny, nz, p, batch = 64, 64, 32, 16, 64
+    n = nx * ny * nz
+    crow1, col1 = synthetic.stencil27_periodic(nx, ny, nz, torch.int32, device=dev)
+    nnz = col1.numel()
+    lo, hi = parallel.shard_bounds(batch, world, rank)
+    g = torch.Generator(device=dev).manual_seed(1234)  # same full batch on every rank (only the local slice is used)
+    val = torch.randn((batch, nnz), device=dev, generator=g).to(torch.bfloat16)
+    B = torch.randn((batch, n, p), device=dev, generator=g).to(torch.bfloat16)
+    A = torch.sparse_csr_tensor(crow1.unsqueeze(0).repeat(batch, 1), col1.unsqueeze(0).repeat(batch, 1), val, (batch, n, n))
+    A_loc = parallel.shard_batched_csr(A, rank, world).requires_grad_(True)
+    B_loc = B[lo:hi].clone().requires_grad_(True)
+    G_loc = torch.randn((hi - lo, n, p), device=dev, generator=g).to(torch.bfloat16)
+
+    def fwd_local():
+        return sparse_mm(A_loc, B_loc)
+
+    def fwd_bwd_local():
+        C = sparse_mm(A_loc, B_loc)
+        torch.autograd.grad(C, (A_loc, B_loc), G_loc)
+
+    def fwd_gathered():
+        return parallel.sharded_batched_apply(sparse_mm, A, B, gather=True)
+
+    def fwd_gathered_overlap():
+        return parallel.sharded_batched_apply(sparse_mm, A, B, gather=True, overlap_chunks=min(4, hi - lo))
+
+    def timed(fn):
+        for _ in range(max(warmup, 2)):
+            fn()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        return el / steps * 1e3
+
+    ab = alg_bytes(n, nnz, p, I=4, V=2, items=batch)  # whole job
+    ms_fwd = timed(fwd_local)
+    ms_fb = timed(fwd_bwd_local)
+    out = {
+        "workload": f"C5: batched CSR SpMM, {batch} items of periodic 27-pt {nx}x{ny}x{nz} (N={n}, nnz={nnz}), {p} RHS, bf16 values / "
+                    f"int32 indices, {world} rank(s) x {hi - lo} items, sharded by parallel.sharded_batched_apply",
+        "algorithmic_bytes_fwd_whole_job": ab["spmm"],
+        "fwd_compute_only": {"ms": round(ms_fwd, 4), "GBps_whole_job": round(ab["spmm"] / (ms_fwd * 1e-3) / 1e9, 1),
+                             "frac_of_hbm_peak_per_gpu": round(ab["spmm"] / world / (ms_fwd * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+        "fwd_bwd_compute_only": {"ms": round(ms_fb, 4), "GBps_whole_job": round(ab["fwd_bwd"] / (ms_fb * 1e-3) / 1e9, 1),
+                                 "frac_of_hbm_peak_per_gpu": round(ab["fwd_bwd"] / world / (ms_fb * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+    }
+    if world > 1:
+        ms_e2e = timed(fwd_gathered)
+        ms_ovl = timed(fwd_gathered_overlap)
+        out["fwd_end_to_end_with_allgather"] = {"ms": round(ms_e2e, 4), "GBps_whole_job": round(ab["spmm"] / (ms_e2e * 1e-3) / 1e9, 1),
+                                                "gathered_bytes_per_rank": (hi - lo) * n * p * 2}
+        out["fwd_end_to_end_overlapped_chunks"] = {"ms": round(ms_ovl, 4), "GBps_whole_job": round(ab["spmm"] / (ms_ovl * 1e-3) / 1e9, 1)}
+    return out
 
 
 def main():
@@ -89,6 +178,7 @@ def main():
     ap.add_argument("--grid", type=int, nargs=3, default=[100, 100, 100], help="stencil grid (default = C2)")
     ap.add_argument("--rhs", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-c5", action="store_true")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -123,11 +213,18 @@ def main():
     A = torch.sparse_csr_tensor(crow, col, val, (n, n)).requires_grad_(True)
 
     def step():
-        # forward + backward through the autograd engine.  torch.autograd.grad hands the gradients back
-        # directly; `.backward()` would additionally deep-copy the sparse CSR gradient (crow, col, values:
-        # 220 MB of device copies per step inside torch's AccumulateGrad), which is not part of the hot path.
+        # forward + backward through the autograd engine; torch.autograd.grad hands the gradients back directly
         C = sparse_mm(A, B)
         gA, gB = torch.autograd.grad(C, (A, B), G)
+        return C
+
+    def step_backward_call():
+        # the reference harness' form (benchmarks/benchmark_utils.py:194-198): `.backward()` accumulates into .grad —
+        # torch's AccumulateGrad deep-copies the sparse CSR gradient (crow, col, values) on the first accumulation
+        A.grad = None
+        B.grad = None
+        C = sparse_mm(A, B)
+        C.backward(G)
         return C
 
     def barrier():
@@ -135,62 +232,85 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    t_cold0 = time.perf_counter()
-    step()
-    torch.cuda.synchronize(dev)
-    cold_ms = (time.perf_counter() - t_cold0) * 1e3  # includes the one-off transposed-pattern build
-    for _ in range(max(args.warmup - 1, 0)):
+    def sync_time(fn):
+        t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t0) * 1e3
+
+    # first steps, one by one: the first sight of a pattern runs on the plan-free kernels (+ builds the transposed
+    # pattern), the row-pair plans are built when the pattern comes back (`_ops.PLAN_AFTER_USES`)
+    first_ms = [sync_time(step) for _ in range(3)]
+    for _ in range(max(args.warmup - 3, 0)):
         step()
 
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    ms_per_step = elapsed / args.steps * 1e3
+    def timed_loop(fn):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            fn()
+        barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        return el / args.steps * 1e3
+
+    ms_per_step = timed_loop(step)
+    step_backward_call()
+    ms_backward_call = timed_loop(step_backward_call)
+    A.grad = None
+    B.grad = None
 
     # ---- per-kernel durations (HIP events on the launch stream), same resident operands ----
     plan = _pattern.from_csr(A.detach())
     pt = plan.transposed
     Bd, vd = B.detach(), val
     reps = max(args.steps, 20)
-    # the fused backward the step really runs: block-dictionary kernel when the pattern qualifies (C2 does)
-    uses_pack = _ops._pack_for(pt, G, Bd) is not None
-    uses_block = uses_pack or _ops._block_for(pt, G, Bd) is not None
-    bwd_name = ("csr_rowpack_kernel (K2+K3 fused bwd, row pairs)" if uses_pack
-                else "csr_blocktile_kernel (K2+K3 fused bwd, block dictionary)" if uses_block
+    rp_t = _ops._pack_for(pt, G, Bd)
+    rp_f = _ops._pack_for(plan, Bd)
+    rp_s = _ops._pack_for(plan, Bd, G, need_plain_slots=True)
+
+    def form(rp):
+        return "class dictionary, %d classes" % rp.nclasses if rp.nclasses else "per-workgroup streams"
+
+    bwd_name = (f"csr_rowpack_kernel (K2+K3 fused bwd, row pairs, {form(rp_t)})" if rp_t is not None
                 else "csr_mm_backward_kernel (K2+K3 fused bwd)")
-    fwd_name = "csr_rowpack_kernel (K1 fwd, row pairs)" if _ops._pack_for(plan, Bd) is not None else "csr_spmm_kernel (K1 fwd)"
+    fwd_name = f"csr_rowpack_kernel (K1 fwd, row pairs, {form(rp_f)})" if rp_f is not None else "csr_spmm_kernel (K1 fwd)"
     kern = {
         fwd_name: time_events(lambda: _ops.spmm(plan, vd, Bd), reps, dev),
         bwd_name: time_events(lambda: _ops.mm_backward(plan, vd, G, Bd), reps, dev),
     }
-    # kernels the fused backward replaces, for reference (not part of the step)
-    kern_alt = {
-        "csr_sddmm_kernel (K3 alone)": time_events(lambda: be.csr_sddmm(plan.crow, plan.col, G, Bd, n, n), reps, dev),
-        "csr_spmm_kernel perm (K2 alone)": time_events(lambda: be.csr_spmm(pt.crow, pt.col, vd, G, n, n, perm=pt.perm), reps, dev),
-    }
     ab = alg_bytes(n, nnz, p)
-    if uses_block:
-        kern_alt["csr_mm_backward_kernel (K2+K3 fused bwd, plain gather)"] = time_events(
-            lambda: be.csr_mm_backward(pt, vd, G, Bd, n, n), reps, dev)
-    if fwd_name != "csr_spmm_kernel (K1 fwd)":
-        kern_alt["csr_spmm_kernel (K1 fwd)"] = time_events(lambda: be.csr_spmm(plan.crow, plan.col, vd, Bd, n, n), reps, dev)
-    kbytes = {"csr_spmm_kernel (K1 fwd)": ab["spmm"], fwd_name: ab["spmm"], bwd_name: ab["fwd_bwd"] - ab["spmm"],
-              "csr_mm_backward_kernel (K2+K3 fused bwd, plain gather)": ab["fwd_bwd"] - ab["spmm"],
-              "csr_sddmm_kernel (K3 alone)": ab["sddmm"], "csr_spmm_kernel perm (K2 alone)": ab["spmm_t"]}
+    kbytes = {fwd_name: ab["spmm"], bwd_name: ab["bwd"]}
+    # kernels the step does not run (one-sided gradients, plan-free first sight), for reference
+    kern_alt = {}
+
+    def alt(name, nbytes, fn):
+        kern_alt[name] = time_events(fn, reps, dev)
+        kbytes[name] = nbytes
+
+    if rp_s is not None:
+        alt("csr_rowpack_kernel (K3 alone, row-pair SDDMM: A-only gradients)", ab["sddmm"], lambda: _ops.sddmm(plan, G, Bd))
+    if rp_t is not None:
+        alt("csr_rowpack_kernel (K2 alone, row pairs: B-only gradients)", ab["spmm_t"], lambda: _ops.spmm(pt, vd, G))
+        alt("csr_mm_backward_kernel (K2+K3 fused bwd, plan-free first sight)", ab["bwd"], lambda: be.csr_mm_backward(pt, vd, G, Bd, n, n))
+    if rp_f is not None:
+        alt("csr_spmm_kernel (K1 fwd, plan-free first sight)", ab["spmm"], lambda: be.csr_spmm(plan.crow, plan.col, vd, Bd, n, n))
+    alt("csr_sddmm_kernel (K3 alone, plan-free)", ab["sddmm"], lambda: be.csr_sddmm(plan.crow, plan.col, G, Bd, n, n))
+    alt("csr_spmm_kernel perm (K2 alone, plan-free)", ab["spmm_t"], lambda: be.csr_spmm(pt.crow, pt.col, vd, G, n, n, perm=pt.perm))
     dominant = max(kern, key=kern.get)
-    traffic = None
+    traffic = traffic_source = None
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.exists(tpath) and [nx, ny, nz, p] == [100, 100, 100, 32]:
         try:
-            traffic = json.load(open(tpath)).get(dominant)
-        except Exception:
+            tj = json.load(open(tpath))
+            key = "fused_backward" if dominant == bwd_name else "forward"
+            if tj.get("plan_form") == (form(rp_t) if dominant == bwd_name else form(rp_f)).split(",")[0]:
+                traffic = tj.get(key)
+                traffic_source = f"{tj.get('source')}@{tj.get('commit')} (rocprofv3 PMC passes; not measured in this run)"
+        except Exception:  # noqa: BLE001
             traffic = None
     achieved = kbytes[dominant] / (kern[dominant] * 1e-3) / 1e9
     # device copy ceiling for context
@@ -209,10 +329,22 @@ def main():
         ag_ms = time_events(lambda: dist.all_gather_into_tensor(out, C), 10, dev)
         allgather = {"ms": round(ag_ms, 4), "bytes_per_rank": C.numel() * 4,
                      "algbw_GB/s": round(world * C.numel() * 4 / (ag_ms * 1e-3) / 1e9, 1)}
+        del out, C
+
+    plan_stats = {"cache_entries": _pattern.cache_stats()[0], "plan_bytes_resident": _pattern.cache_stats()[1]}
+    c5 = None
+    if not args.no_c5:
+        del A, B, G, val, crow, col, plan, pt, rp_t, rp_f, rp_s, Bd, vd
+        _pattern.clear_cache()
+        torch.cuda.empty_cache()
+        try:
+            c5 = c5_leg(dev, world, rank, args.steps, args.warmup, barrier)
+        except Exception as exc:  # noqa: BLE001  (never lose the headline line to the secondary leg)
+            c5 = {"error": repr(exc)}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline_leg(p)
+        cpu = cpu_baseline_leg(nx, ny, nz, p)
 
     if rank == 0:
         total_bytes = ab["fwd_bwd"] * world
@@ -226,6 +358,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 5),
+            "ms_per_step_backward_call": round(ms_backward_call, 5),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -235,8 +368,12 @@ def main():
                 "workload": f"C2: CSR SpMM+backward, periodic 27-pt stencil {nx}x{ny}x{nz} (N={n}, nnz={nnz}), {p} RHS, "
                             "fp32 values / int32 indices, sparse_mm fwd + backward through the autograd API; one such item per GPU",
                 "algorithmic_bytes_per_step_per_gpu": ab["fwd_bwd"],
-                "pattern_plan": "transposed pattern + row-pair union plans cached per sparsity pattern (built in warm-up, "
-                                f"first step incl. build: {cold_ms:.1f} ms)",
+                "timed_step": "sparse_mm + torch.autograd.grad (ms_per_step); the same step with C.backward(G) into .grad "
+                              "(reference harness form, includes torch's AccumulateGrad copies of the sparse gradient) is ms_per_step_backward_call",
+                "first_steps_ms": [round(x, 2) for x in first_ms],
+                "plan_policy": f"first sight of a pattern: plan-free gather kernels + transposed pattern; row-pair plans built at use "
+                               f"{_ops.PLAN_AFTER_USES + 1} (first_steps_ms[{_ops.PLAN_AFTER_USES}] includes plan_build)",
+                "plans": plan_stats,
             },
             "gflops": round(flops / (ms_per_step * 1e-3) / 1e9, 1),
             "frac_of_hbm_peak": round(value / world / HBM_PEAK_GBS, 4),
@@ -248,6 +385,7 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic,
+                "traffic_source": traffic_source,
                 "avg_launch_ms": round(kern[dominant], 5),
                 "algorithmic_bytes_per_launch": kbytes[dominant],
             },
@@ -255,6 +393,7 @@ def main():
             "kernels_GBps": {k: round(kbytes[k] / (v * 1e-3) / 1e9, 1) for k, v in {**kern, **kern_alt}.items()},
             "device_copy_GBps": round(copy_gbs, 1),
             "cpu_baseline": cpu,
+            "c5": c5,
         }
         if allgather is not None:
             line["allgather"] = allgather

@@ -11,8 +11,7 @@
  *   - plain pointers + sizes; no torch / C++ types; nothing throws across the ABI.
  *   - all pointers are DEVICE pointers unless the name ends in `_host`.
  *   - every launcher returns TSGU_OK (0) or a negative tsgu_status; it never syncs
- *     the stream and never allocates device memory (workspaces are passed in), with
- *     the single documented exception of the `*_analyse_host` helpers.
+ *     the stream and never allocates device memory (workspaces and plans are passed in).
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream);
  *     `device` is the HIP ordinal the pointers live on.
  *   - dense operands are row-major with an explicit leading dimension (elements).
@@ -30,7 +29,7 @@
 extern "C" {
 #endif
 
-#define TSGU_ABI_VERSION 1
+#define TSGU_ABI_VERSION 2
 
 typedef enum {
     TSGU_OK = 0,
@@ -39,7 +38,7 @@ typedef enum {
     TSGU_ERR_TOO_LARGE = -3,     /* n_cols >= 2^31 or grid limit exceeded     */
     TSGU_ERR_LAUNCH = -4,        /* hipLaunchKernel / hipGetLastError failed  */
     TSGU_ERR_RUNTIME = -5,       /* other HIP runtime failure                 */
-    TSGU_ERR_NOT_TRIANGULAR = -6,/* zero/missing diagonal detected by analysis */
+    TSGU_ERR_RESERVED_6 = -6,    /* (unused; kept so that the numbering of -7 is stable) */
     TSGU_ERR_TIMEOUT = -7        /* bounded device spin expired (sptrsm)       */
 } tsgu_status;
 
@@ -128,125 +127,81 @@ int tsgu_csr_mm_backward(int vtype, int itype, int64_t n_rows, int64_t n_cols, i
                          int64_t p, int64_t batch, int device, void* stream);
 
 /*
- * Workgroup-tiled variants of K1/K2 and of the fused backward ("blocktile"): same reference lines as
- * tsgu_csr_spmm (sparse_matmul.py:169,229) and tsgu_csr_mm_backward (sparse_matmul.py:186-205,229).
- * The distinct dense rows a block of `rpb` consecutive sparse rows references are DMA-ed into LDS once
- * and every stored entry reads its dense row from there (2.8x less L1 traffic at the 27-point stencil);
- * the 4-byte column index is replaced by a 16-bit local index.  Plan, built once per pattern:
- *   ndist [nblocks]        int32   distinct dense rows of block b, nblocks = ceil(n_rows / rpb)
- *   trow  [nblocks][capd]  int32   their indices, padded by repeating the last one
- *   ent   [nnz]            uint32  per entry, in the walked pattern's order: local index | slot << 16
- *   sperm [nnz]            int32   (walked pattern addresses the values through a permutation, e.g. the
- *                                   transposed pattern) positions in the value array, ascending inside each
- *                                   block; `slot` = where the entry's value sits in that order.  NULL when
- *                                   the values are in the walked order (slot unused).
- * `tile` = 1: dense rows staged in LDS as described; `tile` = 0: only the dictionary (trow) is staged and the
- * dense rows are gathered from global memory — same plan, keeps the sorted-permutation value / gradA accesses
- * (3x fewer scattered L1 accesses at the stencil) at full occupancy; measured faster than both the LDS-tile
- * variant and tsgu_csr_mm_backward at C2 (351 vs 393 vs 412 us).
- * Limits (tsgu_blocktile_limits, per `tile`): capd a multiple of `distinct_multiple`, <= max_distinct; entries
- * per block <= ecap <= max_entries, ecap a multiple of 256; (tile ? capd·p·4 : capd·4) + ecap·8 <=
- * lds_budget_bytes.  fp32, p in {16, 32, 64}, 16-byte aligned dense operands with ld % 4 == 0, 2-D operands;
- * anything else: gather kernels.  rpb·(p/4) must divide 256 (rows_per_block reports the preferred value).
- * Summation order per output row is the stored entry order (as K1).
- */
-int tsgu_blocktile_limits(int vtype, int64_t p, int tile, int* rows_per_block, int* distinct_multiple, int* max_distinct,
-                          int* max_entries, int* lds_budget_bytes);
-int tsgu_csr_spmm_blocktile(int vtype, int itype, int64_t n_rows, int64_t nnz, const void* ptr,
-                            const void* ndist, const void* trow, int capd, int ecap, int rpb, int tile,
-                            const void* ent, const void* sperm, const void* val,
-                            const void* B, int64_t ldb, void* C, int64_t ldc, int64_t p,
-                            int device, void* stream);
-int tsgu_csr_mm_backward_blocktile(int vtype, int itype, int64_t n_rows_t, int64_t nnz, const void* t_ptr,
-                                   const void* ndist, const void* trow, int capd, int ecap, int rpb, int tile,
-                                   const void* ent, const void* sperm, const void* val,
-                                   const void* G, int64_t ldg, const void* B, int64_t ldb,
-                                   void* gradA_vals, void* gradB, int64_t ldgb, int64_t p,
-                                   int device, void* stream);
-
-/*
- * Row-pair gather kernels ("rowpack"): same reference lines as tsgu_csr_spmm (sparse_matmul.py:169,229) and
+ * Row-pair gather kernels ("rowpack"): same reference lines as tsgu_csr_spmm (sparse_matmul.py:155,229) and
  * tsgu_csr_mm_backward (sparse_matmul.py:186-205,229).  One lane group owns rows 2q and 2q+1 and walks the sorted
  * UNION of their column sets, so a dense row both rows reference is gathered once (27-point stencil: 36 gathers
- * per pair instead of 54).  Plan, built once per pattern:
- *   uptr [ceil(n_rows/2)+1] int32   union-entry offsets per row pair
- *   ucol [nu]               int32   dense-row index of each union entry (ascending inside a pair)
- *   upos [nu]               uint32  (only with sperm) two 16-bit halves (low: row 2q, high: row 2q+1): slot of that row's value in
- *                                   the workgroup's staged value slice; bit 15 set = no entry in this column
- *   sperm[nnz]              int32   (walked pattern addresses the values through a permutation) positions in the
- *                                   value array, ascending inside each workgroup's entry range; slots index that
- *                                   order.  NULL: values are in walked order; upos is then NULL too and bits 30 / 31
- *                                   of ucol say whether row 2q / 2q+1 owns the column (n_cols < 2^30), the slots of
- *                                   a row being consecutive.
- *   vpair[nblocks·G]        int32   optional, with eptr[nblocks+1] and sperm (G = 256/(p/4) lane groups per workgroup):
- *                                   the row pair each lane-group slot owns (-1 = none), so that a workgroup can own
- *                                   any set of pairs — e.g. a 3-D brick of a lattice, whose entries form long runs in
- *                                   the value array — instead of G consecutive ones.  uptr/ucol/upos are then laid
- *                                   out in slot order and eptr gives each workgroup's range in sperm.  NULL = natural
- *                                   (nblocks is ignored and derived from n_rows).
- *   order[nblocks]          int32   optional (NULL = natural): workgroup b processes row block order[b]; any
- *                                   permutation is valid, it only changes which blocks are L2-resident together.
- * A workgroup covers rows_per_block = 2·256/(p/4) consecutive rows; ecap / ucap = capacity of the staged value slice
- * / union records (multiples of 256, <= the limits, ucap·8 (ucap·4 without upos) + ecap·4 <= lds_budget_bytes).  fp32, p in {16, 32, 64},
- * 16-byte aligned dense operands with ld % 4 == 0, 2-D operands.  n_cols (n_cols_t) = rows of the gathered dense
- * operand; below 2^24 rows and 4 GiB the kernels use 32-bit gather offsets.  Each row's sum runs over its own entries in
- * ascending stored order (bit-identical to the one-group-per-row kernels); a row never touches a dense row it does
+ * per pair instead of 54).  A workgroup of 256 threads = G lane groups (G = rows_per_block/2 from
+ * tsgu_rowpack_geometry) owns G row pairs.  The plan is built once per sparsity pattern by the caller with index ops
+ * and handed over as a struct of device pointers (all int32 / uint32 arrays):
+ *
+ * STREAM FORM (nclasses == 0) — one record per union entry / stored entry of the whole matrix
+ *   uptr [nblocks·G+1]   union-entry offsets per lane-group slot (slot s of workgroup b = b·G + s)
+ *   ucol [nu]            dense-row index of each union entry (ascending inside a pair).  Without upos, bits 30 / 31
+ *                        say whether row 2q / 2q+1 owns the column (n_cols < 2^30) and the value slots of a row are
+ *                        consecutive in the workgroup's staged value slice.
+ *   upos [nu]            optional: two 16-bit halves (low: row 2q, high: row 2q+1) = slot of that row's value in the
+ *                        workgroup's staged value slice; bit 15 set = the row has no entry in this column.  Required
+ *                        with sperm and whenever entry_lanes > 1.
+ *   sperm[nnz]           optional (the walked pattern addresses the values through a permutation, e.g. the transposed
+ *                        pattern): positions in the value array, ascending inside each workgroup's entry range; the
+ *                        slots of upos index that order.  NULL: values are read in walked order.
+ *   vpair[nblocks·G]     optional, with eptr[nblocks+1] and sperm: the row pair each lane-group slot owns (-1 = none),
+ *                        so that a workgroup can own any set of pairs — e.g. a 3-D brick of a lattice, whose entries
+ *                        form long runs in the value array — instead of G consecutive ones; eptr gives each
+ *                        workgroup's range in sperm.  NULL = consecutive pairs.
+ * CLASS-DICTIONARY FORM (nclasses > 0) — workgroups whose records are translations of each other share one copy.
+ *   wcls [nblocks]       class of each workgroup
+ *   wbase[nblocks][3]    {base pair, base column, base value position} added to the class's relative records
+ *   uptr [nclasses][G+1] relative union offsets (first = 0, last = union entries of the class)
+ *   ucol / upos [nclasses][ucap], sperm [nclasses][ecap], vpair [nclasses][G] (relative, -1 = none), cne[nclasses] =
+ *                        stored entries per workgroup (with sperm).  eptr is unused.
+ *   On lattice stencils (dozens of classes for millions of rows) the index streams — a third of the HBM traffic of
+ *   the stream form — shrink to a few KB that stay in L2; results are bit-identical to the stream form.
+ * order[nblocks]         optional (NULL = natural): workgroup b processes block order[b]; any permutation is valid.
+ * ecap / ucap = capacity of the staged value slice / union records per workgroup (multiples of 256, within the limits
+ * of tsgu_rowpack_geometry; ucap·(upos ? 8 : 4) + ecap·4 <= lds_budget_bytes).
+ * fp32 and bf16 values (bf16: fp32 accumulation); p·sizeof(value)/16 in {2, 4, 8, 16} column lanes; 16-byte aligned
+ * dense operands with 16-byte aligned rows; 2-D operands (batched problems are passed as their block-diagonal 2-D
+ * form).  n_cols (n_cols_t) = rows of the gathered dense operand; below 2^24 rows and 4 GiB the kernels use 32-bit
+ * gather offsets.  With entry_lanes == 1 each row's sum runs over its own entries in ascending stored order
+ * (bit-identical to the one-group-per-row kernels); with entry_lanes > 1 (narrow dense rows) the entries of a pair
+ * are dealt round-robin to the entry lanes and combined by a fixed xor tree.  A row never touches a dense row it does
  * not reference (predicated update, no multiply by zero).
  */
-int tsgu_rowpack_limits(int vtype, int64_t p, int* rows_per_block, int* max_entries, int* max_union, int* lds_budget_bytes);
+typedef struct tsgu_rowpack_plan {
+    int64_t nblocks;          /* workgroups */
+    int32_t ecap, ucap;       /* LDS capacities (entries) */
+    int32_t nclasses;         /* 0 = stream form */
+    int32_t reserved;
+    const void* uptr;
+    const void* ucol;
+    const void* upos;
+    const void* sperm;
+    const void* order;
+    const void* vpair;
+    const void* eptr;
+    const void* wcls;
+    const void* wbase;
+    const void* cne;
+} tsgu_rowpack_plan;
+
+/* Geometry for (vtype, p): rows per workgroup, entry lanes per pair (> 1: plans need upos), plan limits. */
+int tsgu_rowpack_geometry(int vtype, int64_t p, int* rows_per_block, int* entry_lanes, int* max_entries, int* max_union,
+                          int* lds_budget_bytes);
 int tsgu_csr_spmm_rowpack(int vtype, int itype, int64_t n_rows, int64_t n_cols, int64_t nnz, const void* ptr,
-                          const void* uptr, const void* ucol, const void* upos, int ecap, int ucap,
-                          const void* sperm, const void* order, const void* vpair, const void* eptr, int64_t nblocks,
-                          const void* val, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t p, int device, void* stream);
+                          const tsgu_rowpack_plan* plan, const void* val, const void* B, int64_t ldb, void* C, int64_t ldc,
+                          int64_t p, int device, void* stream);
+/* (gradA values in A's order, gradB) in one walk over the transposed pattern's plan (needs sperm). */
 int tsgu_csr_mm_backward_rowpack(int vtype, int itype, int64_t n_rows_t, int64_t n_cols_t, int64_t nnz, const void* t_ptr,
-                                 const void* uptr, const void* ucol, const void* upos, int ecap, int ucap,
-                                 const void* sperm, const void* order, const void* vpair, const void* eptr, int64_t nblocks,
-                                 const void* val, const void* G, int64_t ldg, const void* B, int64_t ldb,
-                                 void* gradA_vals, void* gradB, int64_t ldgb, int64_t p, int device, void* stream);
-/* Row-pair SDDMM (same plan as tsgu_csr_spmm_rowpack for a pattern walked in stored order; replaces tsgu_csr_sddmm,
- * reference sparse_matmul.py:186-205, sparse_solve.py:223-235): out_vals[k] = alpha·<R[row k,:], Cm[col k,:]>.  The dense
+                                 const tsgu_rowpack_plan* plan, const void* val, const void* G, int64_t ldg, const void* B,
+                                 int64_t ldb, void* gradA_vals, void* gradB, int64_t ldgb, int64_t p, int device, void* stream);
+/* Row-pair SDDMM (plan of a pattern walked in stored order, without upos; replaces tsgu_csr_sddmm, reference
+ * sparse_matmul.py:186-205, sparse_solve.py:223-235): out_vals[k] = alpha·<R[row k,:], Cm[col k,:]>.  The dense
  * rows of Cm that both rows of a pair reference are gathered once; the gradients leave in stored order with one
  * coalesced write per workgroup.  The G/B role swap of the solves is expressed by exchanging R and Cm. */
 int tsgu_csr_sddmm_rowpack(int vtype, int itype, int64_t n_rows, int64_t n_cols, int64_t nnz, const void* ptr,
-                           const void* uptr, const void* ucol, int ecap, int ucap, const void* order,
-                           const void* R, int64_t ldr, const void* Cm, int64_t ldc, void* out_vals, double alpha,
-                           int64_t p, int device, void* stream);
-
-/*
- * Wave-pipelined, LDS-tiled variants of K1/K2/K3 ("wavetile") for patterns whose neighbouring rows
- * share columns (stencils, banded matrices).  They replace the same reference lines as
- * tsgu_csr_spmm / tsgu_csr_sddmm and produce bit-identical results; the operand rows a wave needs
- * for its `rows_per_task` consecutive matrix rows are fetched once into a wave-private LDS tile.
- * They need a per-pattern plan (built once by the caller with index ops, cached with the pattern):
- *   tmeta [ntask]               int32x2 {first entry, entry count}, ntask = ceil(n_rows / rows_per_task)
- *   tcols [ntask][max_distinct] int32   distinct column indices of the task's rows, padded by
- *                                       repeating the last one (16-byte aligned rows)
- *   lidx  [ntask][max_entries]  uint8   for each entry (in task order) the position of its column
- *                                       in the task's tcols row, zero padded
- * Every task must have <= max_distinct distinct columns and <= max_entries entries
- * (tsgu_wavetile_geometry reports the limits for (vtype, p)); otherwise use the gather kernels.
- * Dense operands must be 16-byte aligned with 16-byte-aligned rows whenever p is a multiple of the
- * 16-byte vector width.  fp32 and bf16 values; 2-D operands only; 4 <= nnz < 2^31.
- */
-int tsgu_wavetile_geometry(int vtype, int64_t p, int* rows_per_task, int* max_distinct, int* max_entries);
-int tsgu_csr_spmm_wavetile(int vtype, int itype, int64_t n_rows, int64_t n_cols, int64_t nnz,
-                           const void* crow, const void* val, const void* perm,
-                           const void* tmeta, const void* tcols, const void* lidx,
-                           const void* B, int64_t ldb, void* C, int64_t ldc, int64_t p,
-                           int device, void* stream);
-int tsgu_csr_sddmm_wavetile(int vtype, int itype, int64_t n_rows, int64_t n_cols, int64_t nnz,
-                            const void* crow, const void* tmeta, const void* tcols, const void* lidx,
-                            const void* G, int64_t ldg, const void* B, int64_t ldb,
-                            void* out, double alpha, int swap_roles, int64_t p,
-                            int device, void* stream);
-
-/* Fused backward (same contract as tsgu_csr_mm_backward) on the wavetile plan of the TRANSPOSED pattern. */
-int tsgu_csr_mm_backward_wavetile(int vtype, int itype, int64_t n_rows, int64_t n_cols, int64_t nnz,
-                                  const void* t_ptr, const void* t_perm, const void* val,
-                                  const void* tmeta, const void* tcols, const void* lidx,
-                                  const void* G, int64_t ldg, const void* B, int64_t ldb,
-                                  void* gradA_vals, void* gradB, int64_t ldgb, int64_t p,
-                                  int device, void* stream);
+                           const tsgu_rowpack_plan* plan, const void* R, int64_t ldr, const void* Cm, int64_t ldc,
+                           void* out_vals, double alpha, int64_t p, int device, void* stream);
 
 /*
  * K4  X = op(A)^{-1} B   sparse triangular solve, sync-free (dependency-driven) CSR sweep.

@@ -30,6 +30,16 @@ def _need_gpu_and_extension():
     yield
 
 
+@pytest.fixture(autouse=True)
+def _plans_at_first_sight(monkeypatch):
+    """The product builds row-pair plans when a pattern comes back (`_ops.PLAN_AFTER_USES`); the parity tests
+    use every pattern once, so they ask for the plans at first sight.  test_plan_policy_* covers the default."""
+    from torchsparsegradutils_amd import _ops
+
+    monkeypatch.setattr(_ops, "PLAN_AFTER_USES", 0)
+    yield
+
+
 def tsgu():
     import torchsparsegradutils_amd as m
 
@@ -188,15 +198,36 @@ def test_mm_ragged_and_empty_rows_long_row():
     assert torch.count_nonzero(out) == 0 and out.shape == (4, 3)
 
 
-@pytest.mark.parametrize("p", [16, 32, 64])
+def _bf16_round(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(torch.bfloat16).float().numpy()
+
+
+def _close(mine, ref, dt):
+    """fp32: 1e-5 normwise; bf16 (fp32 accumulation, one final rounding): every element within one bf16 ulp
+    (2^-8 relative) of the fp32 result — plus the accumulation-order slack of a few fp32 ulps of the row's
+    magnitude for entries that cancel — and 3e-3 normwise."""
+    mine = mine.detach().float().cpu().numpy() if torch.is_tensor(mine) else np.asarray(mine, dtype=np.float32)
+    ref = np.asarray(ref, dtype=np.float64)
+    if dt == torch.float32:
+        return G.rel_err(mine, ref) < 1e-5
+    scale = np.abs(ref).max()
+    return bool(np.all(np.abs(mine - ref) <= np.abs(ref) * 2.0 ** -8 + scale * 2e-6 + 1e-30)) and \
+        np.linalg.norm(mine - ref) / np.linalg.norm(ref) < 3e-3
+
+
+@pytest.mark.parametrize("form", ["stream", "dictionary"])
+@pytest.mark.parametrize("dt,p", [(torch.float32, 8), (torch.float32, 16), (torch.float32, 32), (torch.float32, 64),
+                                  (torch.bfloat16, 16), (torch.bfloat16, 32), (torch.bfloat16, 64), (torch.bfloat16, 128)])
 @pytest.mark.parametrize("itype", [torch.int32, torch.int64])
-def test_block_dictionary_kernels_match_oracle(p, itype, monkeypatch):
-    """csrc/blocktile_impl.h through the C ABI, both flavours (LDS tile / gather from global), forward and
-    transposed walks and the fused backward, on a ragged rectangular banded pattern (empty rows, a tail block,
-    rows of 0..40 entries) against the CPU oracle; then the same through sparse_mm with the selection forced."""
+def test_rowpack_kernels_match_oracle(dt, p, itype, form, monkeypatch):
+    """csrc/rowpack_impl.h through the C ABI: every lane geometry (2x4, 4x2, 8x1, 16x1 column x entry lanes), fp32 and
+    bf16, both plan forms (per-workgroup streams / class dictionary), forward and transposed walks, the fused
+    backward and the row-pair SDDMM, on a ragged rectangular banded pattern (empty rows, a tail block, rows of 0..40
+    entries) against the CPU oracle; then the same through sparse_mm with the selection forced."""
     from oracle import oracle
     from torchsparsegradutils_amd import _backend as be, _ops, _pattern
 
+    monkeypatch.setattr(_pattern, "DEDUP_MODE", "force" if form == "dictionary" else "off")
     rng = np.random.default_rng(10 + p)
     n, m = 2051, 1900
     rows = rng.integers(0, n, 40000)
@@ -208,43 +239,36 @@ def test_block_dictionary_kernels_match_oracle(p, itype, monkeypatch):
     val = val.astype(np.float32)
     B = rng.standard_normal((m, p)).astype(np.float32)
     Gd = rng.standard_normal((n, p)).astype(np.float32)
+    if dt == torch.bfloat16:
+        val, B, Gd = _bf16_round(val), _bf16_round(B), _bf16_round(Gd)
     C_o, gA_o, gB_o = oracle.sparse_mm_fwd_bwd(crow, col, val, B, Gd, m)
 
     g = _pattern.RowGather(G.t(crow, DEV).to(itype), G.t(col, DEV).to(itype), n, m)
     gt = g.transposed
-    vd, Bd, Gdev = G.t(val, DEV), G.t(B, DEV), G.t(Gd, DEV)
-    for tile in (True, False):
-        geo = be.blocktile_limits(torch.float32, p, tile=tile)
-        assert geo is not None
-        bp, bpt = g.block_plan(*geo), gt.block_plan(*geo)
-        assert bp is not None and bpt is not None and bp.sperm is None and bpt.sperm is not None
-        assert rel(be.csr_spmm_blocktile(g.crow, vd, bp, Bd, n, tile=tile), C_o) < 1e-5
-        assert rel(be.csr_spmm_blocktile(gt.crow, vd, bpt, Gdev, m, tile=tile), gB_o) < 1e-5
-        gA, gB = be.csr_mm_backward_blocktile(gt.crow, bpt, vd, Gdev, Bd, m, tile=tile)
-        assert rel(gA, gA_o) < 1e-5 and rel(gB, gB_o) < 1e-5
-        # p >= 32: one lane group per row in both kernel families, i.e. the same order of summation as K2
-        if p >= 32:
-            assert torch.equal(gB, be.csr_spmm(gt.crow, gt.col, vd, Gdev, m, n, perm=gt.perm))
-
-    # row-pair union kernels on the same operands (forward, transposed, fused backward)
-    geo = be.rowpack_limits(torch.float32, p)
+    vd, Bd, Gdev = G.t(val, DEV).to(dt), G.t(B, DEV).to(dt), G.t(Gd, DEV).to(dt)
+    geo = be.rowpack_geometry(dt, p)
     assert geo is not None
-    rp, rpt = g.rowpack_plan(*geo), gt.rowpack_plan(*geo)
+    rpb, limits, ep = geo
+    assert rpb == 2 * 256 // max(p * vd.element_size() // 16, 8)
+    rp, rpt = g.rowpack_plan(rpb, limits, explicit_slots=ep > 1), gt.rowpack_plan(rpb, limits)
     assert rp is not None and rpt is not None and rp.sperm is None and rpt.sperm is not None
-    assert rel(be.csr_spmm_rowpack(g.crow, vd, rp, Bd, n), C_o) < 1e-5
+    assert (rp.nclasses > 0) == (form == "dictionary") and (rpt.nclasses > 0) == (form == "dictionary")
+    assert (rp.upos is not None) == (ep > 1)
+    assert _close(be.csr_spmm_rowpack(g.crow, vd, rp, Bd, n), C_o, dt)
     gB2 = be.csr_spmm_rowpack(gt.crow, vd, rpt, Gdev, m)
     gA3, gB3 = be.csr_mm_backward_rowpack(gt.crow, rpt, vd, Gdev, Bd, m)
-    assert rel(gB2, gB_o) < 1e-5 and rel(gA3, gA_o) < 1e-5 and torch.equal(gB2, gB3)
-    if p >= 32:
+    assert _close(gB2, gB_o, dt) and _close(gA3, gA_o, dt) and torch.equal(gB2, gB3)
+    if ep == 1:
+        # one lane group per row in both kernel families, i.e. the same order of summation as K1 / K2
         assert torch.equal(gB3, be.csr_spmm(gt.crow, gt.col, vd, Gdev, m, n, perm=gt.perm))
-    # SDDMM through the union walk (stored order), plain and with the scale / role swap the solves use
-    assert rel(be.csr_sddmm_rowpack(g.crow, rp, Gdev, Bd, n), gA_o) < 1e-5
-    Xs = torch.randn(n, p, device=DEV)
-    Ys = torch.randn(m, p, device=DEV) if m != n else torch.randn(n, p, device=DEV)
-    want = be.csr_sddmm(g.crow, g.col, Xs, Ys, n, m, alpha=-1.0)
-    assert rel(be.csr_sddmm_rowpack(g.crow, rp, Xs, Ys, n, alpha=-1.0), want.cpu().numpy()) < 1e-5
+        assert torch.equal(be.csr_spmm_rowpack(g.crow, vd, rp, Bd, n), be.csr_spmm(g.crow, g.col, vd, Bd, n, m))
+        # SDDMM through the union walk (stored order), plain and with the scale / role swap the solves use
+        assert _close(be.csr_sddmm_rowpack(g.crow, rp, Gdev, Bd, n), gA_o, dt)
+        Xs = torch.randn(n, p, device=DEV).to(dt)
+        Ys = torch.randn(m, p, device=DEV).to(dt)
+        want = be.csr_sddmm(g.crow, g.col, Xs, Ys, n, m, alpha=-1.0)
+        assert _close(be.csr_sddmm_rowpack(g.crow, rp, Xs, Ys, n, alpha=-1.0), want.float().cpu().numpy(), dt)
     # a row must never touch a dense row it does not reference: poison one row of B that only ONE row of a pair uses
-    rows_of = lambda c: set(np.nonzero(col == c)[0].tolist())  # noqa: E731
     rowidx = np.repeat(np.arange(n), np.diff(crow))
     poisoned = None
     for cand in range(m):
@@ -259,29 +283,31 @@ def test_block_dictionary_kernels_match_oracle(p, itype, monkeypatch):
     users = torch.from_numpy(np.unique(rowidx[col == poisoned])).to(DEV)
     clean = torch.ones(n, dtype=torch.bool, device=DEV)
     clean[users] = False
-    assert bool(torch.isfinite(Cp[clean]).all()) and not bool(torch.isfinite(Cp[users]).all())
+    assert bool(torch.isfinite(Cp[clean].float()).all()) and not bool(torch.isfinite(Cp[users].float()).all())
 
-    # public API with the selection forced for this (small) pattern: row pairs first, then the block dictionary
+    # public API with the selection forced for this (small) pattern
     monkeypatch.setattr(_ops, "PACK_MIN_NNZ", 0)
     Ad = torch.sparse_csr_tensor(g.crow, g.col, vd, (n, m)).requires_grad_(True)
     Bq = Bd.clone().requires_grad_(True)
     Cq = tsgu().sparse_mm(Ad, Bq)
     Cq.backward(Gdev)
-    assert rel(Cq, C_o) < 1e-5 and rel(Ad.grad.values(), gA_o) < 1e-5 and rel(Bq.grad, gB_o) < 1e-5
+    assert _close(Cq, C_o, dt) and _close(Ad.grad.values(), gA_o, dt) and _close(Bq.grad, gB_o, dt)
     assert _pattern.from_csr(Ad)._packs and _pattern.from_csr(Ad).transposed._packs, "the row-pair plan was not used"
-    _pattern.clear_cache()
-    monkeypatch.setattr(_ops, "ENABLE_PACK", False)
-    monkeypatch.setattr(_ops, "BLOCK_MIN_NNZ", 0)
-    Ad = torch.sparse_csr_tensor(g.crow, g.col, vd, (n, m)).requires_grad_(True)
-    Bq = Bd.clone().requires_grad_(True)
-    Cq = tsgu().sparse_mm(Ad, Bq)
-    Cq.backward(Gdev)
-    assert rel(Cq, C_o) < 1e-5 and rel(Ad.grad.values(), gA_o) < 1e-5 and rel(Bq.grad, gB_o) < 1e-5
-    assert _pattern.from_csr(Ad).transposed._blocks, "the block-dictionary plan was not used"
-    # only B needs a gradient: transposed SpMM through the dictionary
+    # only B needs a gradient: transposed SpMM through the row-pair plan
     Bq2 = Bd.clone().requires_grad_(True)
     tsgu().sparse_mm(Ad.detach(), Bq2).backward(Gdev)
     assert torch.equal(Bq2.grad, Bq.grad)
+    # selection off: the plain gather kernels give the same numbers (bit-identical with one entry lane per pair)
+    _pattern.clear_cache()
+    monkeypatch.setattr(_ops, "ENABLE_PACK", False)
+    Ad0 = torch.sparse_csr_tensor(g.crow, g.col, vd, (n, m)).requires_grad_(True)
+    Bq0 = Bd.clone().requires_grad_(True)
+    Cq0 = tsgu().sparse_mm(Ad0, Bq0)
+    Cq0.backward(Gdev)
+    assert not _pattern.from_csr(Ad0)._packs
+    assert _close(Cq0, C_o, dt) and _close(Ad0.grad.values(), gA_o, dt) and _close(Bq0.grad, gB_o, dt)
+    if ep == 1 and dt == torch.float32:
+        assert torch.equal(Cq0, Cq) and torch.equal(Bq0.grad, Bq.grad)
 
 
 @pytest.mark.parametrize("kind", ["stencil27", "stencil27_odd", "laplacian7", "grid2d"])
@@ -312,15 +338,14 @@ def test_rowpack_brick_ownership_on_lattices(kind, monkeypatch):
 
     g = _pattern.RowGather(crow, col, n, n)
     gt = g.transposed
-    geo = be.rowpack_limits(torch.float32, p)
-    brick = gt.rowpack_plan(*geo)
+    rpb, limits, _ep = be.rowpack_geometry(torch.float32, p)
+    brick = gt.rowpack_plan(rpb, limits)
     assert len(_pattern.detect_lattice(gt)) == (1 if kind == "grid2d" else 2)
     if kind == "laplacian7":
         # 7-point stencil: neighbouring rows share too few columns (12 union entries for 14: reuse < 1.2) — no row-pair
-        # plan at all; the lattice is still recognised and the API falls back to the block-dictionary / gather kernels
+        # plan at all; the lattice is still recognised and the API falls back to the plain gather kernels
         assert brick is None
         monkeypatch.setattr(_ops, "PACK_MIN_NNZ", 0)
-        monkeypatch.setattr(_ops, "BLOCK_MIN_NNZ", 0)
         Ad = torch.sparse_csr_tensor(crow, col, G.t(val, DEV), (n, n)).requires_grad_(True)
         Bq = G.t(B, DEV).requires_grad_(True)
         Cq = tsgu().sparse_mm(Ad, Bq)
@@ -328,13 +353,23 @@ def test_rowpack_brick_ownership_on_lattices(kind, monkeypatch):
         assert rel(Cq, C_o) < 1e-5 and rel(Ad.grad.values(), gA_o) < 1e-5 and rel(Bq.grad, gB_o) < 1e-5
         return
     assert brick is not None and brick.vpair is not None and len(brick.lattice) == (1 if kind == "grid2d" else 2)
-    natural = _pattern.build_rowpack_plan(gt, *geo)
+    natural = _pattern.build_rowpack_plan(gt, rpb, limits, dedup="off")
     vd, Bd, Gdev = G.t(val, DEV), G.t(B, DEV), G.t(Gd, DEV)
     gA1, gB1 = be.csr_mm_backward_rowpack(gt.crow, brick, vd, Gdev, Bd, n)
     gA0, gB0 = be.csr_mm_backward_rowpack(gt.crow, natural, vd, Gdev, Bd, n)
     assert rel(gA1, gA_o) < 1e-5 and rel(gB1, gB_o) < 1e-5
     assert torch.equal(gA1, gA0) and torch.equal(gB1, gB0)
     assert torch.equal(be.csr_spmm_rowpack(gt.crow, vd, brick, Gdev, n), gB0)
+    # the class-dictionary form of the same brick plan and of the natural plan: bit-identical results
+    po = _pattern.brick_pair_order(n, brick.lattice, rpb // 2, DEV)
+    for other in (_pattern.build_rowpack_plan(gt, rpb, limits, pair_order=po, lattice=brick.lattice, dedup="force"),
+                  _pattern.build_rowpack_plan(gt, rpb, limits, dedup="force"),
+                  _pattern.build_rowpack_plan(gt, rpb, limits, pair_order=po, lattice=brick.lattice, dedup="off")):
+        gA2, gB2 = be.csr_mm_backward_rowpack(gt.crow, other, vd, Gdev, Bd, n)
+        assert torch.equal(gA2, gA0) and torch.equal(gB2, gB0)
+    fwd_s = be.csr_spmm_rowpack(g.crow, vd, _pattern.build_rowpack_plan(g, rpb, limits, dedup="off"), Bd, n)
+    fwd_d = be.csr_spmm_rowpack(g.crow, vd, _pattern.build_rowpack_plan(g, rpb, limits, dedup="force"), Bd, n)
+    assert torch.equal(fwd_s, fwd_d) and rel(fwd_d, C_o) < 1e-5
 
     monkeypatch.setattr(_ops, "PACK_MIN_NNZ", 0)
     Ad = torch.sparse_csr_tensor(crow, col, vd, (n, n)).requires_grad_(True)
@@ -359,9 +394,9 @@ def test_rowpack_strided_operands_beyond_4GiB_use_64bit_offsets():
     crow, col = synthetic.stencil27_periodic(*dims, torch.int32, device=DEV)
     g = _pattern.RowGather(crow, col, n, n)
     gt = g.transposed
-    geo = be.rowpack_limits(torch.float32, p)
-    rp, rpt = g.rowpack_plan(*geo), gt.rowpack_plan(*geo)
-    assert rp is not None and rpt is not None
+    rpb, limits, _ep = be.rowpack_geometry(torch.float32, p)
+    rp, rpt = g.rowpack_plan(rpb, limits), gt.rowpack_plan(rpb, limits)
+    assert rp is not None and rpt is not None and rp.nclasses > 0 and rpt.nclasses > 0   # lattice: dictionary form
     gen = torch.Generator(device=DEV).manual_seed(7)
     val = torch.randn(col.numel(), device=DEV, generator=gen)
     wideB = torch.empty((n, ld), device=DEV)

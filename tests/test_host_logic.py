@@ -156,7 +156,15 @@ def test_abi_library_exports_every_declared_symbol():
         assert hasattr(raw, name), f"{name} declared in include/tsgu_hip.h but not exported"
         assert name in _backend.SIGNATURES, f"{name} has no ctypes signature"
     assert set(_backend.SIGNATURES) <= declared
-    assert lib.tsgu_abi_version() == 1
+    assert lib.tsgu_abi_version() == 2
+    # row-pair geometry: (rows per workgroup, entry lanes) per (value type, p); unsupported shapes are refused
+    r, e = ctypes.c_int(0), ctypes.c_int(0)
+    for vt, p_, want in ((_backend.TSGU_F32, 32, (64, 1)), (_backend.TSGU_F32, 64, (32, 1)), (_backend.TSGU_F32, 16, (64, 2)),
+                         (_backend.TSGU_F32, 8, (64, 4)), (_backend.TSGU_BF16, 16, (64, 4)), (_backend.TSGU_BF16, 128, (32, 1))):
+        assert lib.tsgu_rowpack_geometry(vt, p_, ctypes.byref(r), ctypes.byref(e), None, None, None) == 0
+        assert (r.value, e.value) == want, (vt, p_, r.value, e.value)
+    assert lib.tsgu_rowpack_geometry(_backend.TSGU_F64, 32, None, None, None, None, None) != 0
+    assert lib.tsgu_rowpack_geometry(_backend.TSGU_F32, 12, None, None, None, None, None) != 0
     assert lib.tsgu_status_string(-2).decode().startswith("bad argument")
     # pure host-side helpers of the ABI
     assert lib.tsgu_spmm_num_blocks(_backend.TSGU_F32, 10 ** 6, 27 * 10 ** 6, 32) == 31250

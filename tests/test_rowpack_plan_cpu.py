@@ -1,5 +1,6 @@
-"""CPU checks of the wave-tile plan builder (pure index arithmetic; the kernels that consume it run in the
-GPU suite): every entry must be recoverable from (tile_cols, lidx), padding must follow the documented layout."""
+"""CPU checks of the row-pair plan builder (pure index arithmetic; the kernels that consume it run in the GPU
+suite): every stored entry must be recoverable from the union records, and the class-dictionary form must expand to
+exactly the stream form."""
 
 import torch
 
@@ -7,117 +8,38 @@ from torchsparsegradutils_amd import _pattern as P
 from torchsparsegradutils_amd.utils import synthetic
 
 
-def _check(g, rpt, cap_d, cap_e):
-    t = P.build_tile_plan(g, rpt, cap_d, cap_e)
-    assert t is not None
-    n, nnz = g.n_rows, g.nnz
-    ntask = (n + rpt - 1) // rpt
-    assert t.tmeta.shape == (ntask, 2) and t.tile_cols.shape == (ntask, cap_d) and t.lidx.shape == (ntask, cap_e)
-    assert t.tmeta.dtype == torch.int32 and t.tile_cols.dtype == torch.int32 and t.lidx.dtype == torch.uint8
-    rows = g.row_indices().long()
-    task = rows // rpt
-    e0 = t.tmeta[:, 0].long()
-    assert torch.equal(e0, g.crow[torch.arange(0, n, rpt)].long())
-    assert int(t.tmeta[:, 1].sum()) == nnz
-    pos = torch.arange(nnz) - e0[task]
-    assert torch.equal(t.tile_cols[task, t.lidx[task, pos].long()].long(), g.col.long())
-    # padding of the column table repeats the last valid column of the task
-    cnt = torch.tensor([len(set(g.col[int(e0[k]) : int(e0[k]) + int(t.tmeta[k, 1])].tolist())) for k in range(ntask)])
-    for k in (0, ntask // 2, ntask - 1):
-        c = int(cnt[k])
-        assert c <= t.max_distinct
-        assert torch.all(t.tile_cols[k, c:] == t.tile_cols[k, c - 1])
-    return t
-
-
-def test_stencil_plan_and_transposed_plan():
-    crow, col = synthetic.stencil27_periodic(12, 10, 9, torch.int32)
-    g = P.RowGather(crow, col, 1080, 1080)
-    t = _check(g, 8, 128, 256)
-    assert t.reuse > 1.5
-    _check(g.transposed, 8, 128, 256)
-
-
-def test_plan_refused_when_limits_or_reuse_fail():
-    crow, col = synthetic.stencil27_periodic(12, 10, 9, torch.int32)
-    g = P.RowGather(crow, col, 1080, 1080)
-    assert P.build_tile_plan(g, 8, 16, 256) is None      # too many distinct columns per task
-    assert P.build_tile_plan(g, 8, 128, 64) is None      # too many entries per task
-    # random pattern: (almost) no column shared between the rows of a task
-    gen = torch.Generator().manual_seed(0)
-    idx = torch.randperm(4000 * 4000, generator=gen)[:12000]
-    A = torch.sparse_coo_tensor(torch.stack((idx // 4000, idx % 4000)), torch.ones(12000), (4000, 4000)).coalesce().to_sparse_csr()
-    gr = P.RowGather(A.crow_indices(), A.col_indices(), 4000, 4000)
-    assert P.build_tile_plan(gr, 8, 128, 256) is None
-
-
-# ------------------------------------------------------------------ block-dictionary plan (blocktile kernels) ----
-def _check_block(g, rpb, row_bytes, limits):
-    bp = P.build_block_plan(g, rpb, row_bytes, limits)
-    assert bp is not None
-    n, nnz = g.n_rows, g.nnz
-    nb = (n + rpb - 1) // rpb
-    assert bp.ndist.shape == (nb,) and bp.trow.shape == (nb, bp.capd) and bp.ent.shape == (nnz,)
-    assert bp.ndist.dtype == bp.trow.dtype == bp.ent.dtype == torch.int32
-    assert bp.capd % limits[0] == 0 and bp.ecap % 256 == 0
-    blk = g.row_indices().long() // rpb
-    e0 = g.crow[torch.arange(0, n, rpb)].long()
-    ent = bp.ent.long() & 0xFFFFFFFF
-    lidx, slot = ent & 0xFFFF, ent >> 16
-    # every entry finds its column through the block's dictionary
-    assert torch.equal(bp.trow[blk, lidx].long(), g.col.long())
-    assert bool((lidx < bp.ndist[blk]).all())
-    # dictionary rows are distinct, padding repeats the last valid one
-    for b in (0, nb // 2, nb - 1):
-        c = int(bp.ndist[b])
-        assert len(set(bp.trow[b, :c].tolist())) == c and torch.all(bp.trow[b, c:] == bp.trow[b, c - 1])
-    if g.perm is None:
-        assert bp.sperm is None and bool((slot == 0).all())
-    else:
-        assert bp.sperm.dtype == torch.int32
-        # the sorted permutation holds each block's positions ascending, and slot points at the entry's own value
-        assert torch.equal(bp.sperm[(e0[blk] + slot)].long(), g.perm.long())
-        ends = torch.cat((e0[1:], g.crow[-1:].long()))
-        for b in (0, nb // 3, nb - 1):
-            seg = bp.sperm[int(e0[b]) : int(ends[b])]
-            assert bool((seg[1:] > seg[:-1]).all())
-            assert sorted(seg.tolist()) == sorted(g.perm[int(e0[b]) : int(ends[b])].tolist())
-    return bp
-
-
-def test_block_plan_forward_and_transposed_and_limits():
-    crow, col = synthetic.stencil27_periodic(12, 10, 9, torch.int32)
-    g = P.RowGather(crow, col, 1080, 1080)
-    lim_tile, lim_gather = (8, 512, 2048, 65536), (4, 1024, 2048, 65536)
-    bp = _check_block(g, 32, 128, lim_tile)
-    assert bp.reuse > 2.0 and bp.rpb == 32
-    bpt = _check_block(g.transposed, 32, 4, lim_gather)
-    assert bpt.sperm is not None
-    _check_block(g.transposed, 16, 128, lim_tile)
-    # cached per (rows per block, row size, limits)
-    assert g.block_plan(32, 128, lim_tile) is g.block_plan(32, 128, lim_tile)
-    # limits: distinct rows, entries per block, LDS budget
-    assert P.build_block_plan(g, 32, 128, (8, 64, 2048, 65536)) is None
-    assert P.build_block_plan(g, 32, 128, (8, 512, 512, 65536)) is None
-    assert P.build_block_plan(g, 32, 128, (8, 512, 2048, 16384)) is None
-
-
-def test_block_plan_ragged_rows_and_tail_block():
-    gen = torch.Generator().manual_seed(4)
-    n, m = 1003, 900   # n not a multiple of the block height, empty rows, rectangular
-    rows = torch.randint(0, n, (9000,), generator=gen)
-    cols = (rows * m // n + torch.randint(-6, 7, (9000,), generator=gen)).clamp(0, m - 1)
-    rows[rows % 17 == 0] += 1  # every 17th row is empty, its neighbour twice as long
-    A = torch.sparse_coo_tensor(torch.stack((rows, cols)), torch.ones(9000), (n, m)).coalesce().to_sparse_csr()
-    g = P.RowGather(A.crow_indices(), A.col_indices(), n, m)
-    _check_block(g, 32, 128, (8, 512, 2048, 65536))
-    _check_block(g.transposed, 64, 4, (4, 1024, 2048, 65536))
-
-
 # ------------------------------------------------------------------ row-pair union plan (rowpack kernels) ----
-def _check_rowpack(g, rpb, limits, pair_order=None):
-    rp = P.build_rowpack_plan(g, rpb, limits, pair_order=pair_order)
-    assert rp is not None
+def _check_dictionary_form(g, rpb, limits, pair_order, explicit_slots, stream):
+    """The class-dictionary form must expand to exactly the stream form (same walk, same slots, same positions)."""
+    d = P.build_rowpack_plan(g, rpb, limits, pair_order=pair_order, explicit_slots=explicit_slots, dedup="force")
+    assert d is not None and d.nclasses >= 1 and d.wcls.shape == (d.nblocks,) and d.wbase.shape == (d.nblocks, 3)
+    assert d.ecap == stream.ecap and d.ucap == stream.ucap and d.nblocks == stream.nblocks and d.eptr is None
+    gpb = rpb // 2
+    assert d.uptr.shape == (d.nclasses * (gpb + 1),) and d.ucol.shape == (d.nclasses * d.ucap,)
+    uptr, ucol, upos, sperm, vpair, eptr = P.expand_classes(d)
+    assert torch.equal(uptr, stream.uptr.long())
+    assert torch.equal(ucol & 0xFFFFFFFF, stream.ucol.long() & 0xFFFFFFFF)
+    assert (upos is None) == (stream.upos is None)
+    if upos is not None:
+        assert torch.equal(upos, stream.upos.long() & 0xFFFFFFFF)
+    assert (sperm is None) == (stream.sperm is None)
+    if sperm is not None:
+        assert torch.equal(sperm, stream.sperm.long())
+        if stream.eptr is not None:
+            assert torch.equal(eptr, stream.eptr.long())
+    if stream.vpair is not None:
+        assert torch.equal(vpair, stream.vpair.long())
+    else:
+        n_pairs = (g.n_rows + 1) // 2
+        assert d.vpair is None and torch.equal(vpair[:n_pairs], torch.arange(n_pairs))
+    assert bool((d.ucol.view(-1, d.ucap).long() & 0x3FFFFFFF >= 0).all())
+    return d
+
+
+def _check_rowpack(g, rpb, limits, pair_order=None, explicit_slots=False):
+    rp = P.build_rowpack_plan(g, rpb, limits, pair_order=pair_order, explicit_slots=explicit_slots, dedup="off")
+    assert rp is not None and rp.nclasses == 0
+    _check_dictionary_form(g, rpb, limits, pair_order, explicit_slots, rp)
     n, nnz = g.n_rows, g.nnz
     npairs = (n + 1) // 2
     gpb = rpb // 2
@@ -139,7 +61,7 @@ def _check_rowpack(g, rpb, limits, pair_order=None):
     assert bool((upair >= 0).all())
     rows = g.row_indices().long()
     ucol = rp.ucol.long() & 0xFFFFFFFF
-    if g.perm is None:
+    if g.perm is None and not explicit_slots:
         # stored order: no slot words, bits 30 / 31 of ucol = "row 2q / 2q+1 owns this column", slots run consecutively
         assert rp.upos is None and rp.sperm is None
         own = torch.stack(((ucol >> 30) & 1, ucol >> 31)).bool()
@@ -155,10 +77,10 @@ def _check_rowpack(g, rpb, limits, pair_order=None):
             k = g.crow[row].long() + rank          # the rank-th stored entry of that row
             assert torch.equal(g.col[k].long(), ucol[u]) and torch.equal(rows[k], row)
     else:
-        assert rp.upos.shape == (nu,)
+        assert rp.upos.shape == (nu,) and (rp.sperm is None) == (g.perm is None)
     same = upair[1:] == upair[:-1]
     assert bool((ucol[1:][same] > ucol[:-1][same]).all())
-    if g.perm is not None:
+    if rp.upos is not None:
         word = rp.upos.long() & 0xFFFFFFFF
         halves = torch.stack((word & 0xFFFF, word >> 16))
         if pair_order is None:
@@ -169,14 +91,17 @@ def _check_rowpack(g, rpb, limits, pair_order=None):
         present = (halves & 0x8000) == 0
         assert int(present.sum()) == nnz
         inv = torch.empty(nnz, dtype=torch.long)
-        inv[g.perm.long()] = torch.arange(nnz)
+        perm = g.perm.long() if g.perm is not None else torch.arange(nnz)
+        inv[perm] = torch.arange(nnz)
+        sperm = rp.sperm.long() if rp.sperm is not None else None
         for r in (0, 1):
             u = torch.nonzero(present[r]).flatten()
             row = 2 * upair[u] + r
             blk = uslot[u] // gpb
             slot = halves[r][u]
             assert bool((slot < (ends - e0)[blk]).all())
-            k = inv[rp.sperm[e0[blk] + slot].long()]   # entry of the walked pattern whose value sits in that slot
+            pos = sperm[e0[blk] + slot] if sperm is not None else e0[blk] + slot   # position in the value array
+            k = inv[pos]                                   # entry of the walked pattern whose value sits in that slot
             assert torch.equal(g.col[k].long(), ucol[u]) and torch.equal(rows[k], row)
     if g.perm is not None:
         for b in (0, len(e0) // 2, len(e0) - 1):
@@ -254,3 +179,75 @@ def test_rowpack_plan_refuses_unsorted_or_duplicate_columns():
     dup = col.clone()
     dup[28] = dup[27]
     assert P.build_rowpack_plan(P.RowGather(crow, dup, 216, 216), 64, lim) is None
+
+
+def test_explicit_slots_for_stored_order_plans():
+    """Kernels with several entry lanes per pair (narrow dense rows) need slot words also in stored order."""
+    crow, col = synthetic.stencil27_periodic(8, 6, 6, torch.int32)
+    g = P.RowGather(crow, col, 288, 288)
+    rp = _check_rowpack(g, 64, (2048, 3072, 65536), explicit_slots=True)
+    assert rp.upos is not None and rp.sperm is None
+    assert g.rowpack_plan(64, (2048, 3072, 65536), explicit_slots=True) is not g.rowpack_plan(64, (2048, 3072, 65536))
+
+
+def test_dictionary_form_on_lattices_and_batches():
+    """Translation dedup: a periodic lattice needs few classes; a block-diagonal batch of equal patterns shares them;
+    an irregular pattern has (almost) one class per workgroup and keeps the stream form in auto mode."""
+    lim = (2048, 3072, 65536)
+    crow, col = synthetic.stencil27_periodic(32, 32, 32, torch.int32)
+    n = 32768
+    g = P.RowGather(crow, col, n, n)
+    auto = P.build_rowpack_plan(g, 64, lim, dedup="auto")
+    assert auto.nclasses > 0 and auto.nclasses <= auto.nblocks // 4, (auto.nclasses, auto.nblocks)
+    lat = P.detect_lattice(g.transposed)
+    po = P.brick_pair_order(n, lat, 32, "cpu")
+    brick = P.build_rowpack_plan(g.transposed, 64, lim, pair_order=po, lattice=lat, dedup="auto")
+    assert 0 < brick.nclasses <= 27, brick.nclasses
+    assert brick.plan_bytes() < 0.1 * (4 * g.nnz * 2)   # stream form: > 8 bytes per stored entry
+    # four items with the same pattern, flattened to a block-diagonal problem: no new classes
+    b = 3
+    bc = crow.unsqueeze(0).repeat(b, 1)
+    bcol = col.unsqueeze(0).repeat(b, 1)
+    flat = P.flat_of(P.RowGather(bc, bcol, n, n))
+    assert flat.n_rows == b * n and flat.nnz == b * g.nnz
+    fauto = P.build_rowpack_plan(flat, 64, lim, dedup="auto")
+    assert fauto.nclasses == auto.nclasses and fauto.nblocks == b * auto.nblocks
+    _check_rowpack(flat, 64, lim)
+    # irregular pattern (banded random): stream form in auto mode, still expandable when forced
+    gen = torch.Generator().manual_seed(7)
+    m = 3000
+    rows = torch.arange(m).repeat_interleave(6)
+    cols = (rows + torch.randint(-4, 5, (rows.numel(),), generator=gen)).clamp(0, m - 1)
+    A = torch.sparse_coo_tensor(torch.stack((rows, cols)), torch.ones(rows.numel()), (m, m)).coalesce().to_sparse_csr()
+    gi = P.RowGather(A.crow_indices(), A.col_indices(), m, m)
+    irr = P.build_rowpack_plan(gi, 64, lim, dedup="auto")
+    assert irr is not None and irr.nclasses == 0
+    _check_rowpack(gi, 64, lim)
+    _check_rowpack(gi.transposed, 64, lim)
+
+
+def test_plan_cache_is_released_with_the_sparse_tensor():
+    """Cache entries hold derived data only; dropping the sparse tensor evicts them (weakref on the index storage)."""
+    import gc
+
+    P.clear_cache()
+    crow, col = synthetic.stencil27_periodic(6, 6, 6, torch.int32)
+    A = torch.sparse_csr_tensor(crow, col, torch.ones(col.numel()), (216, 216))
+    del crow, col
+    g = P.from_csr(A)
+    g.transposed  # noqa: B018  (derived data now lives in the cache)
+    assert P.from_csr(A).core is g.core and P.cache_stats()[0] == 1 and P.cache_stats()[1] > 0
+    del g
+    gc.collect()
+    assert P.cache_stats()[0] == 1, "the cache must not depend on views being alive"
+    del A
+    gc.collect()
+    assert P.cache_stats() == (0, 0)
+    # batched COO: the flattened indices are derived data, cached on the caller's index tensor
+    idx = torch.tensor([[0, 0, 1, 1], [0, 1, 0, 1], [1, 0, 0, 1]])
+    C = torch.sparse_coo_tensor(idx, torch.ones(4), (2, 2, 2)).coalesce()
+    g1, g2 = P.from_coo_batched(C._indices(), C.shape), P.from_coo_batched(C._indices(), C.shape)
+    assert g1.core is g2.core and g1.n_rows == 4 and g1.crow.tolist() == [0, 1, 2, 3, 4] and g1.col.tolist() == [1, 0, 2, 3]
+    del C, idx, g1, g2
+    gc.collect()
+    assert P.cache_stats()[0] == 0

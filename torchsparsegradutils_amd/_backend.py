@@ -55,21 +55,6 @@ SIGNATURES = {
         [_int, _int, _i64, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _ptr, _i64, _i64, _ptr, _ptr, _i64,
          _i64, _i64, _i64, _int, _ptr],
     ),
-    "tsgu_blocktile_limits": (
-        _int,
-        [_int, _i64, _int, ctypes.POINTER(_int), ctypes.POINTER(_int), ctypes.POINTER(_int), ctypes.POINTER(_int),
-         ctypes.POINTER(_int)],
-    ),
-    "tsgu_csr_spmm_blocktile": (
-        _int,
-        [_int, _int, _i64, _i64, _ptr, _ptr, _ptr, _int, _int, _int, _int, _ptr, _ptr, _ptr, _ptr, _i64, _ptr, _i64,
-         _i64, _int, _ptr],
-    ),
-    "tsgu_csr_mm_backward_blocktile": (
-        _int,
-        [_int, _int, _i64, _i64, _ptr, _ptr, _ptr, _int, _int, _int, _int, _ptr, _ptr, _ptr, _ptr, _i64, _ptr, _i64,
-         _ptr, _ptr, _i64, _i64, _int, _ptr],
-    ),
     "tsgu_minres_scalar": (
         _int,
         [_int, _int, _ptr, _i64, _i64, _ptr, _ptr, _ptr, _dbl, _dbl, _dbl, _i64, _int, _ptr],
@@ -78,40 +63,16 @@ SIGNATURES = {
         _int,
         [_int, _int, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _int, _int, _ptr],
     ),
-    "tsgu_rowpack_limits": (
+    "tsgu_rowpack_geometry": (
         _int,
-        [_int, _i64, ctypes.POINTER(_int), ctypes.POINTER(_int), ctypes.POINTER(_int), ctypes.POINTER(_int)],
+        [_int, _i64, ctypes.POINTER(_int), ctypes.POINTER(_int), ctypes.POINTER(_int), ctypes.POINTER(_int),
+         ctypes.POINTER(_int)],
     ),
-    "tsgu_csr_spmm_rowpack": (
-        _int,
-        [_int, _int, _i64, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _int, _int, _ptr, _ptr, _ptr, _ptr, _i64, _ptr, _ptr, _i64, _ptr,
-         _i64, _i64, _int, _ptr],
-    ),
-    "tsgu_csr_sddmm_rowpack": (
-        _int,
-        [_int, _int, _i64, _i64, _i64, _ptr, _ptr, _ptr, _int, _int, _ptr, _ptr, _i64, _ptr, _i64, _ptr, _dbl, _i64, _int,
-         _ptr],
-    ),
+    "tsgu_csr_spmm_rowpack": (_int, [_int, _int, _i64, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _i64, _ptr, _i64, _i64, _int, _ptr]),
     "tsgu_csr_mm_backward_rowpack": (
-        _int,
-        [_int, _int, _i64, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _int, _int, _ptr, _ptr, _ptr, _ptr, _i64, _ptr, _ptr, _i64, _ptr,
-         _i64, _ptr, _ptr, _i64, _i64, _int, _ptr],
-    ),
-    "tsgu_wavetile_geometry": (_int, [_int, _i64, ctypes.POINTER(_int), ctypes.POINTER(_int), ctypes.POINTER(_int)]),
-    "tsgu_csr_spmm_wavetile": (
-        _int,
-        [_int, _int, _i64, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _ptr, _i64, _i64, _int, _ptr],
-    ),
-    "tsgu_csr_sddmm_wavetile": (
-        _int,
-        [_int, _int, _i64, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _ptr, _i64, _ptr, _dbl, _int, _i64,
-         _int, _ptr],
-    ),
-    "tsgu_csr_mm_backward_wavetile": (
-        _int,
-        [_int, _int, _i64, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _i64,
-         _int, _ptr],
-    ),
+        _int, [_int, _int, _i64, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _i64, _int, _ptr]),
+    "tsgu_csr_sddmm_rowpack": (
+        _int, [_int, _int, _i64, _i64, _i64, _ptr, _ptr, _ptr, _i64, _ptr, _i64, _ptr, _dbl, _i64, _int, _ptr]),
     "tsgu_csr_sptrsm": (
         _int,
         [_int, _int, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _int, _int, _ptr, _i64, _ptr, _i64, _i64, _ptr, _int, _ptr],
@@ -155,7 +116,7 @@ def load_library():
             fn = getattr(lib, name)  # AttributeError => header/library mismatch, fail loudly
             fn.restype = res
             fn.argtypes = args
-        if lib.tsgu_abi_version() != 1:
+        if lib.tsgu_abi_version() != 2:
             raise HipExtensionMissing("libtsgu_hip.so ABI version mismatch; rebuild the extension")
         _lib = lib
     return _lib
@@ -321,81 +282,35 @@ def fused_backward_supported(dtype: torch.dtype, p: int) -> bool:
     return (p + vec - 1) // vec <= 64
 
 
-def tiled_geometry(dtype: torch.dtype, p: int):
-    """(rows_per_task, max_distinct, max_entries) of the wave-pipelined tiled kernels, or None."""
+class _RowpackPlanStruct(ctypes.Structure):
+    """``tsgu_rowpack_plan`` of include/tsgu_hip.h."""
+
+    _fields_ = [("nblocks", _i64), ("ecap", ctypes.c_int32), ("ucap", ctypes.c_int32), ("nclasses", ctypes.c_int32),
+                ("reserved", ctypes.c_int32)] + [(k, _ptr) for k in ("uptr", "ucol", "upos", "sperm", "order", "vpair", "eptr",
+                                                                     "wcls", "wbase", "cne")]
+
+
+def _plan_struct(rp):
+    """ctypes image of a _pattern.RowPackPlan (cached on the plan; the plan keeps the tensors alive)."""
+    st = rp._cstruct
+    if st is None:
+        st = _RowpackPlanStruct(rp.nblocks, rp.ecap, rp.ucap, rp.nclasses, 0, _p(rp.uptr), _p(rp.ucol), _p(rp.upos), _p(rp.sperm),
+                                _p(rp.order), _p(rp.vpair), _p(rp.eptr), _p(rp.wcls), _p(rp.wbase), _p(rp.cne))
+        rp._cstruct = st
+    return ctypes.addressof(st)
+
+
+@functools.lru_cache(maxsize=None)
+def rowpack_geometry(dtype: torch.dtype, p: int):
+    """(rows_per_block, (max_entries, max_union, lds_budget_bytes), entry_lanes) of the row-pair gather kernels, or None."""
     if dtype not in (torch.float32, torch.bfloat16) or p <= 0:
         return None
     lib = load_library()
-    rpt, mx, me = _int(0), _int(0), _int(0)
-    if lib.tsgu_wavetile_geometry(_VTYPE[dtype], p, ctypes.byref(rpt), ctypes.byref(mx), ctypes.byref(me)) != 0:
+    r, e, a, b, c = _int(0), _int(0), _int(0), _int(0), _int(0)
+    if lib.tsgu_rowpack_geometry(_VTYPE[dtype], p, ctypes.byref(r), ctypes.byref(e), ctypes.byref(a), ctypes.byref(b),
+                                 ctypes.byref(c)) != 0:
         return None
-    return rpt.value, mx.value, me.value
-
-
-@functools.lru_cache(maxsize=None)
-def blocktile_limits(dtype: torch.dtype, p: int, tile: bool = False):
-    """(rows_per_block, row_bytes, (distinct_multiple, max_distinct, max_entries, lds_budget_bytes)) of the
-    block-dictionary kernels (LDS-tiled or gather-from-global flavour), or None when (dtype, p) is not covered."""
-    if dtype != torch.float32 or p <= 0:
-        return None
-    lib = load_library()
-    r, a, b, c, d = _int(0), _int(0), _int(0), _int(0), _int(0)
-    if lib.tsgu_blocktile_limits(_VTYPE[dtype], p, int(tile), ctypes.byref(r), ctypes.byref(a), ctypes.byref(b),
-                                 ctypes.byref(c), ctypes.byref(d)) != 0:
-        return None
-    return r.value, (p * 4 if tile else 4), (a.value, b.value, c.value, d.value)
-
-
-def csr_spmm_blocktile(crow, val, bp, B, n_rows: int, tile: bool = True):
-    """C = A·B through the workgroup-tiled kernel; `bp` is a _pattern.BlockPlan of the walked pattern."""
-    lib = load_library()
-    dev = require_device(crow, val, B)
-    B = rowmajor(B)
-    p = B.size(-1)
-    out = torch.empty((n_rows, p), dtype=B.dtype, device=dev)
-    with torch.cuda.device(dev):
-        check(
-            lib.tsgu_csr_spmm_blocktile(
-                vtype_of(val), itype_of(crow), n_rows, bp.nnz, _p(crow), _p(bp.ndist), _p(bp.trow), bp.capd, bp.ecap,
-                bp.rpb, int(tile), _p(bp.ent), _p(bp.sperm), _p(val.contiguous()), _p(B), _ld(B), _p(out), _ld(out), p,
-                dev.index, _stream(dev),
-            ),
-            "tsgu_csr_spmm_blocktile",
-        )
-    return out
-
-
-def csr_mm_backward_blocktile(tcrow, bp, val, G, B, n_rows_t: int, tile: bool = True):
-    """(gradA values in A's order, gradB) in one pass over the transposed pattern's BlockPlan."""
-    lib = load_library()
-    dev = require_device(tcrow, val, G, B)
-    G, B = rowmajor(G), rowmajor(B)
-    p = G.size(-1)
-    val = val.contiguous()
-    grad_a = torch.empty_like(val)
-    grad_b = torch.empty((n_rows_t, p), dtype=G.dtype, device=dev)
-    with torch.cuda.device(dev):
-        check(
-            lib.tsgu_csr_mm_backward_blocktile(
-                vtype_of(val), itype_of(tcrow), n_rows_t, bp.nnz, _p(tcrow), _p(bp.ndist), _p(bp.trow), bp.capd,
-                bp.ecap, bp.rpb, int(tile), _p(bp.ent), _p(bp.sperm), _p(val), _p(G), _ld(G), _p(B), _ld(B),
-                _p(grad_a), _p(grad_b), _ld(grad_b), p, dev.index, _stream(dev),
-            ),
-            "tsgu_csr_mm_backward_blocktile",
-        )
-    return grad_a, grad_b
-
-
-@functools.lru_cache(maxsize=None)
-def rowpack_limits(dtype: torch.dtype, p: int):
-    """(rows_per_block, (max_entries, max_union, lds_budget_bytes)) of the row-pair gather kernels, or None."""
-    if dtype != torch.float32 or p <= 0:
-        return None
-    lib = load_library()
-    r, a, b, c = _int(0), _int(0), _int(0), _int(0)
-    if lib.tsgu_rowpack_limits(_VTYPE[dtype], p, ctypes.byref(r), ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)) != 0:
-        return None
-    return r.value, (a.value, b.value, c.value)
+    return r.value, (a.value, b.value, c.value), e.value
 
 
 def csr_spmm_rowpack(crow, val, rp, B, n_rows: int):
@@ -408,10 +323,8 @@ def csr_spmm_rowpack(crow, val, rp, B, n_rows: int):
     with torch.cuda.device(dev):
         check(
             lib.tsgu_csr_spmm_rowpack(
-                vtype_of(val), itype_of(crow), n_rows, B.size(0), rp.nnz, _p(crow), _p(rp.uptr), _p(rp.ucol), _p(rp.upos),
-                rp.ecap, rp.ucap, _p(rp.sperm), _p(rp.order), _p(rp.vpair), _p(rp.eptr), rp.nblocks, _p(val.contiguous()),
-                _p(B), _ld(B), _p(out), _ld(out), p,
-                dev.index, _stream(dev),
+                vtype_of(val), itype_of(crow), n_rows, B.size(0), rp.nnz, _p(crow), _plan_struct(rp), _p(val.contiguous()),
+                _p(B), _ld(B), _p(out), _ld(out), p, dev.index, _stream(dev),
             ),
             "tsgu_csr_spmm_rowpack",
         )
@@ -428,8 +341,8 @@ def csr_sddmm_rowpack(crow, rp, R, Cm, n_rows: int, alpha: float = 1.0):
     with torch.cuda.device(dev):
         check(
             lib.tsgu_csr_sddmm_rowpack(
-                vtype_of(R), itype_of(crow), n_rows, Cm.size(0), rp.nnz, _p(crow), _p(rp.uptr), _p(rp.ucol), rp.ecap,
-                rp.ucap, _p(rp.order), _p(R), _ld(R), _p(Cm), _ld(Cm), _p(out), float(alpha), p, dev.index, _stream(dev),
+                vtype_of(R), itype_of(crow), n_rows, Cm.size(0), rp.nnz, _p(crow), _plan_struct(rp), _p(R), _ld(R), _p(Cm),
+                _ld(Cm), _p(out), float(alpha), p, dev.index, _stream(dev),
             ),
             "tsgu_csr_sddmm_rowpack",
         )
@@ -448,10 +361,8 @@ def csr_mm_backward_rowpack(tcrow, rp, val, G, B, n_rows_t: int):
     with torch.cuda.device(dev):
         check(
             lib.tsgu_csr_mm_backward_rowpack(
-                vtype_of(val), itype_of(tcrow), n_rows_t, G.size(0), rp.nnz, _p(tcrow), _p(rp.uptr), _p(rp.ucol), _p(rp.upos),
-                rp.ecap, rp.ucap, _p(rp.sperm), _p(rp.order), _p(rp.vpair), _p(rp.eptr), rp.nblocks, _p(val), _p(G), _ld(G),
-                _p(B), _ld(B),
-                _p(grad_a), _p(grad_b), _ld(grad_b), p, dev.index, _stream(dev),
+                vtype_of(val), itype_of(tcrow), n_rows_t, G.size(0), rp.nnz, _p(tcrow), _plan_struct(rp), _p(val), _p(G), _ld(G),
+                _p(B), _ld(B), _p(grad_a), _p(grad_b), _ld(grad_b), p, dev.index, _stream(dev),
             ),
             "tsgu_csr_mm_backward_rowpack",
         )
@@ -460,62 +371,6 @@ def csr_mm_backward_rowpack(tcrow, rp, val, G, B, n_rows_t: int):
 
 def _tiled_ok(*dense) -> bool:
     return all(t.dim() == 2 and t.data_ptr() % 16 == 0 and (_ld(t) * t.element_size()) % 16 == 0 for t in dense)
-
-
-def csr_spmm_tiled(crow, val, tiles, B, n_rows: int, n_cols: int, perm=None):
-    """C = A·B through the wave-pipelined LDS-tiled kernel; `tiles` is a _pattern.TilePlan."""
-    lib = load_library()
-    dev = require_device(crow, val, B, perm)
-    B = rowmajor(B)
-    p = B.size(-1)
-    out = torch.empty((n_rows, p), dtype=B.dtype, device=dev)
-    with torch.cuda.device(dev):
-        check(
-            lib.tsgu_csr_spmm_wavetile(
-                vtype_of(val), itype_of(crow), n_rows, n_cols, tiles.nnz, _p(crow), _p(val), _p(perm),
-                _p(tiles.tmeta), _p(tiles.tile_cols), _p(tiles.lidx),
-                _p(B), _ld(B), _p(out), _ld(out), p, dev.index, _stream(dev),
-            ),
-            "tsgu_csr_spmm_wavetile",
-        )
-    return out
-
-
-def csr_sddmm_tiled(crow, tiles, G, B, n_rows: int, n_cols: int, alpha: float = 1.0, swap_roles: bool = False):
-    lib = load_library()
-    dev = require_device(crow, G, B)
-    G, B = rowmajor(G), rowmajor(B)
-    out = torch.empty((tiles.nnz,), dtype=G.dtype, device=dev)
-    with torch.cuda.device(dev):
-        check(
-            lib.tsgu_csr_sddmm_wavetile(
-                vtype_of(G), itype_of(crow), n_rows, n_cols, tiles.nnz, _p(crow),
-                _p(tiles.tmeta), _p(tiles.tile_cols), _p(tiles.lidx),
-                _p(G), _ld(G), _p(B), _ld(B), _p(out), float(alpha), int(bool(swap_roles)), G.size(-1),
-                dev.index, _stream(dev),
-            ),
-            "tsgu_csr_sddmm_wavetile",
-        )
-    return out
-
-
-def csr_mm_backward_tiled(tplan, tiles, val, G, B, n_rows: int, n_cols: int):
-    """Fused backward on the wavetile plan `tiles` of the transposed pattern `tplan` (2-D operands)."""
-    lib = load_library()
-    dev = require_device(tplan.crow, val, G, B)
-    G, B = rowmajor(G), rowmajor(B)
-    gradA = torch.empty(val.shape, dtype=val.dtype, device=dev)
-    gradB = torch.empty(B.shape, dtype=B.dtype, device=dev)
-    with torch.cuda.device(dev):
-        check(
-            lib.tsgu_csr_mm_backward_wavetile(
-                vtype_of(val), itype_of(tplan.crow), n_rows, n_cols, tiles.nnz, _p(tplan.crow), _p(tplan.perm), _p(val),
-                _p(tiles.tmeta), _p(tiles.tile_cols), _p(tiles.lidx), _p(G), _ld(G), _p(B), _ld(B),
-                _p(gradA), _p(gradB), _ld(gradB), G.size(-1), dev.index, _stream(dev),
-            ),
-            "tsgu_csr_mm_backward_wavetile",
-        )
-    return gradA, gradB
 
 
 def coo_sddmm(row, col, G, B, alpha: float = 1.0):

@@ -1,6 +1,10 @@
-"""Kernel selection for one sparse operand: LDS-tiled kernels when the pattern has column reuse
-inside row blocks (stencils, banded factors) and the operands qualify, plain gather kernels otherwise.
-Both produce the same values (same summation order); the choice is speed only."""
+"""Kernel selection for one sparse operand: row-pair union kernels when neighbouring rows share columns (stencils,
+banded factors, meshes) and the operands qualify, plain gather kernels otherwise.  Both produce the same values
+(same per-row summation order when a pair has one entry lane); the choice is speed only.
+
+Batched CSR operands (torch layout, equal nnz per item) that qualify for the row-pair kernels are handed to them as
+ONE block-diagonal 2-D problem (`_pattern.flat_of`: two vectorised adds on the index arrays, values untouched):
+the row-pair plans are translation-deduplicated, so items that share a pattern also share their plan records."""
 
 from __future__ import annotations
 
@@ -9,83 +13,85 @@ import os
 import torch
 
 from . import _backend as _be
+from . import _pattern as _pt
 from ._pattern import RowGather
-
-# The wave-pipelined LDS-tiled kernels are parity-clean but only on par with / slightly ahead of the gather
-# kernels: off by default; TSGU_ENABLE_TILED=1 selects them where the pattern qualifies.
-ENABLE_TILED = os.environ.get("TSGU_ENABLE_TILED", "0") == "1"
-
-
-# Block-dictionary kernels (csrc/blocktile_impl.h, gather-from-global flavour): used for operands addressed through
-# a permutation (transposed patterns: gradB = Aᵀ·G and the fused backward), where the per-block sorted permutation
-# turns the 4-byte scattered value / gradA accesses into short runs.  TSGU_ENABLE_BLOCK=0 falls back to K2 / the
-# plain fused backward.  Patterns below the size threshold stay on the plan-free kernels (launch-bound anyway).
-ENABLE_BLOCK = os.environ.get("TSGU_ENABLE_BLOCK", "1") == "1"
-BLOCK_MIN_NNZ = 1 << 16
-
-
-def _block_for(plan: RowGather, dense: torch.Tensor, *others: torch.Tensor):
-    if (not ENABLE_BLOCK or plan.batch is not None or plan.perm is None or dense.dim() != 2
-            or plan.nnz < BLOCK_MIN_NNZ or plan.crow.dtype not in (torch.int32, torch.int64)):
-        return None
-    geo = _be.blocktile_limits(dense.dtype, dense.size(-1), tile=False)
-    if geo is None or not _be._tiled_ok(*(_be.rowmajor(t) for t in (dense,) + others)):
-        return None
-    return plan.block_plan(*geo)
-
 
 # Row-pair kernels (csrc/rowpack_impl.h): rows 2q, 2q+1 walk the union of their columns, a shared dense row is
 # gathered once.  First choice for forward, transposed and fused-backward walks when neighbouring rows share columns
-# (stencil / banded / mesh patterns: C2 K1 151 -> 131 us, fused backward 412 -> 312 us); TSGU_ENABLE_PACK=0 disables.
+# (stencil / banded / mesh patterns); TSGU_ENABLE_PACK=0 disables.  Small patterns stay on the plan-free kernels
+# (launch-bound anyway).
 ENABLE_PACK = os.environ.get("TSGU_ENABLE_PACK", "1") == "1"
 PACK_MIN_NNZ = 1 << 16
+# A row-pair plan costs a few device sorts: it is built when a pattern is seen for the PLAN_AFTER_USES-th time (the
+# first use runs on the plan-free kernels), so that one-off patterns never pay for it.  0 = build at first sight.
+PLAN_AFTER_USES = int(os.environ.get("TSGU_PLAN_AFTER_USES", "1"))
 
 
-def _pack_for(plan: RowGather, dense: torch.Tensor, *others: torch.Tensor):
+def _pack_for(plan: RowGather, dense: torch.Tensor, *others: torch.Tensor, need_plain_slots: bool = False):
+    """RowPackPlan of the 2-D `plan` for these dense operands, or None (disabled / not supported / not profitable /
+    pattern not seen often enough yet)."""
     if (not ENABLE_PACK or plan.batch is not None or dense.dim() != 2 or plan.nnz < PACK_MIN_NNZ
             or plan.crow.dtype not in (torch.int32, torch.int64)):
         return None
-    geo = _be.rowpack_limits(dense.dtype, dense.size(-1))
+    geo = _be.rowpack_geometry(dense.dtype, dense.size(-1))
     if geo is None or not _be._tiled_ok(*(_be.rowmajor(t) for t in (dense,) + others)):
         return None
-    return plan.rowpack_plan(*geo)
+    rpb, limits, entry_lanes = geo
+    if need_plain_slots and entry_lanes > 1:
+        return None  # SDDMM walks ownership-bit records (one entry lane per pair)
+    if not plan.seen_enough(PLAN_AFTER_USES):
+        return None
+    return plan.rowpack_plan(rpb, limits, explicit_slots=entry_lanes > 1)
+
+
+def _flat(plan: RowGather, *dense: torch.Tensor):
+    """(block-diagonal 2-D plan, flattened dense operands) of a batched problem, or None when the operands are not
+    batch-contiguous (the plain kernels then take the batch as gridDim.y)."""
+    if plan.batch is None or any(t.dim() != 3 for t in dense):
+        return None
+    flat = []
+    for t in dense:
+        t = _be.rowmajor(t)
+        if t.size(0) > 1 and t.stride(0) != t.size(1) * t.stride(1):
+            return None
+        if t.size(1) > 1 and t.stride(1) != t.size(2):
+            return None
+        flat.append(t.reshape(-1, t.size(-1)))
+    return _pt.flat_of(plan), flat
 
 
 def mm_backward(plan: RowGather, values: torch.Tensor, G: torch.Tensor, B: torch.Tensor):
     """(gradA values in A's order, gradB) of C = A·B in one pass over the transposed pattern."""
-    t = plan.transposed
     same = values.dtype == G.dtype == B.dtype
+    if same and plan.batch is not None and ENABLE_PACK:
+        fl = _flat(plan, G, B)
+        if fl is not None:
+            fplan, (Gf, Bf) = fl
+            rp = _pack_for(fplan.transposed, Gf, Bf)
+            if rp is not None:
+                ga, gb = _be.csr_mm_backward_rowpack(fplan.transposed.crow, rp, values.reshape(-1), Gf, Bf, fplan.n_cols)
+                return ga.view(values.shape), gb.view(B.shape)
+    t = plan.transposed
     rp = _pack_for(t, G, B) if same else None
     if rp is not None:
         return _be.csr_mm_backward_rowpack(t.crow, rp, values, G, B, t.n_rows)
-    bp = _block_for(t, G, B) if same else None
-    if bp is not None:
-        return _be.csr_mm_backward_blocktile(t.crow, bp, values, G, B, t.n_rows, tile=False)
     return _be.csr_mm_backward(t, values, G, B, plan.n_rows, plan.n_cols)
-
-
-def _tiles_for(plan: RowGather, dense: torch.Tensor, *others: torch.Tensor):
-    if not ENABLE_TILED or plan.batch is not None or dense.dim() != 2:
-        return None
-    geo = _be.tiled_geometry(dense.dtype, dense.size(-1))
-    if geo is None:
-        return None
-    if not _be._tiled_ok(*(_be.rowmajor(t) for t in (dense,) + others)):
-        return None
-    return plan.tiles(*geo)
 
 
 def spmm(plan: RowGather, values: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
     """A·B for the operand described by (plan, values); perm-aware (transposed / un-coalesced plans)."""
-    rp = _pack_for(plan, B) if values.dtype == B.dtype else None
-    if rp is not None:
-        return _be.csr_spmm_rowpack(plan.crow, values, rp, B, plan.n_rows)
-    bp = _block_for(plan, B) if values.dtype == B.dtype else None
-    if bp is not None:
-        return _be.csr_spmm_blocktile(plan.crow, values, bp, B, plan.n_rows, tile=False)
-    tiles = _tiles_for(plan, B) if values.dtype == B.dtype else None
-    if tiles is not None:
-        return _be.csr_spmm_tiled(plan.crow, values, tiles, B, plan.n_rows, plan.n_cols, perm=plan.perm)
+    if values.dtype == B.dtype:
+        if plan.batch is not None and ENABLE_PACK:
+            fl = _flat(plan, B)
+            if fl is not None:
+                fplan, (Bf,) = fl
+                rp = _pack_for(fplan, Bf)
+                if rp is not None:
+                    out = _be.csr_spmm_rowpack(fplan.crow, values.reshape(-1), rp, Bf, fplan.n_rows)
+                    return out.view(B.size(0), plan.n_rows, B.size(-1))
+        rp = _pack_for(plan, B)
+        if rp is not None:
+            return _be.csr_spmm_rowpack(plan.crow, values, rp, B, plan.n_rows)
     return _be.csr_spmm(plan.crow, plan.col, values, B, plan.n_rows, plan.n_cols, perm=plan.perm)
 
 
@@ -94,10 +100,7 @@ def sddmm(plan: RowGather, G: torch.Tensor, B: torch.Tensor, alpha: float = 1.0,
     gathered = G if swap_roles else B
     rowop = B if swap_roles else G
     if plan.perm is None and G.dtype == B.dtype:
-        rp = _pack_for(plan, gathered, rowop)
-        if rp is not None:
+        rp = _pack_for(plan, gathered, rowop, need_plain_slots=True)
+        if rp is not None and rp.upos is None:
             return _be.csr_sddmm_rowpack(plan.crow, rp, rowop, gathered, plan.n_rows, alpha=alpha)
-    tiles = _tiles_for(plan, gathered, B if swap_roles else G) if G.dtype == B.dtype else None
-    if tiles is not None:
-        return _be.csr_sddmm_tiled(plan.crow, tiles, G, B, plan.n_rows, plan.n_cols, alpha=alpha, swap_roles=swap_roles)
     return _be.csr_sddmm(plan.crow, plan.col, G, B, plan.n_rows, plan.n_cols, alpha=alpha, swap_roles=swap_roles)

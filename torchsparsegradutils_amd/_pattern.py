@@ -13,63 +13,96 @@ index tensors (the common training loop updates values, not the pattern):
 
 from __future__ import annotations
 
+import os as _os
 import threading
+import weakref
 from collections import OrderedDict
 from typing import Optional, Tuple
 
 import torch
 
 
+class _Core:
+    """Everything derived from one sparsity pattern (shared by all RowGather views of it, owned by the cache).
+    Holds only tensors this module allocated — never the caller's index tensors — so that dropping the sparse
+    tensor releases its plans (the cache entry is evicted by a finalizer on the index storage)."""
+
+    __slots__ = ("t", "has_diag", "rows", "packs", "uses", "flat", "own", "__weakref__")
+
+    def __init__(self):
+        self.t: Optional[RowGather] = None
+        self.has_diag: Optional[bool] = None
+        self.rows = None
+        self.packs = {}
+        self.uses = 0
+        self.flat: Optional[RowGather] = None
+        self.own = {}   # derived index arrays of the pattern itself (COO → crow, stable row order, ...)
+
+    def nbytes(self) -> int:
+        seen, total = set(), 0
+
+        def add(t):
+            nonlocal total
+            if torch.is_tensor(t) and t.data_ptr() not in seen:
+                seen.add(t.data_ptr())
+                total += t.numel() * t.element_size()
+
+        add(self.rows)
+        for t in self.own.values():
+            add(t)
+        for rp in self.packs.values():
+            if rp is not None:
+                total += rp.plan_bytes()
+        for sub in (self.t, self.flat):
+            if sub is not None:
+                add(sub.crow), add(sub.col), add(sub.perm)
+                total += sub.core.nbytes()
+        return total
+
+
 class RowGather:
     """Row-gather structure of a (batched) sparse matrix on the device.
 
     crow: (n_rows+1,) or (b, n_rows+1); col: (nnz,) or (b, nnz); perm: optional, same shape as
-    col, position of each entry in the owner's value array (None = identity).
+    col, position of each entry in the owner's value array (None = identity).  Derived analyses
+    live in ``core`` (shared between views of the same pattern through the module cache).
     """
 
-    __slots__ = ("crow", "col", "perm", "n_rows", "n_cols", "batch", "_t", "_has_diag", "_rows", "_tiles", "_blocks",
-                 "_packs")
+    __slots__ = ("crow", "col", "perm", "n_rows", "n_cols", "batch", "core")
 
-    def __init__(self, crow, col, n_rows, n_cols, perm=None):
+    def __init__(self, crow, col, n_rows, n_cols, perm=None, core: Optional[_Core] = None):
         self.crow, self.col, self.perm = crow, col, perm
         self.n_rows, self.n_cols = int(n_rows), int(n_cols)
         self.batch = crow.size(0) if crow.dim() == 2 else None
-        self._t: Optional[RowGather] = None
-        self._has_diag: Optional[bool] = None
-        self._rows = None
-        self._tiles = {}
-        self._blocks = {}
-        self._packs = {}
+        self.core = _Core() if core is None else core
 
-    def rowpack_plan(self, rows_per_block: int, limits):
+    # kept as attributes of the view for the tests / tools that look at them
+    @property
+    def _packs(self):
+        return self.core.packs
+
+    def seen_enough(self, after: int) -> bool:
+        """Count one use of this pattern; True once it has been used more than `after` times (plan policy:
+        expensive plans are only built for patterns that come back)."""
+        self.core.uses += 1
+        return self.core.uses > after
+
+    def rowpack_plan(self, rows_per_block: int, limits, explicit_slots: bool = False):
         """Plan for the row-pair gather kernels (csrc/rowpack_impl.h), None when the pattern does not qualify or
         profit; cached per workgroup height.  See `build_rowpack_plan`."""
-        key = (rows_per_block, tuple(limits))
-        if key not in self._packs:
+        key = (rows_per_block, tuple(limits), bool(explicit_slots) or self.perm is not None)
+        packs = self.core.packs
+        if key not in packs:
             plan = None
             if ENABLE_BRICKS and self.perm is not None:
                 lat = detect_lattice(self)
                 order = brick_pair_order(self.n_rows, lat, rows_per_block // 2, self.crow.device) if lat else None
                 if order is not None:
                     plan = build_rowpack_plan(self, rows_per_block, limits, pair_order=order, lattice=lat)
-            self._packs[key] = plan if plan is not None else build_rowpack_plan(self, rows_per_block, limits)
-        return self._packs[key]
-
-    def block_plan(self, rows_per_block: int, row_bytes: int, limits):
-        """Plan for the workgroup-tiled kernels (csrc/blocktile_impl.h), None when the pattern does not
-        qualify or profit; cached per block height / dense row size.  See `build_block_plan`."""
-        key = (rows_per_block, row_bytes, tuple(limits))
-        if key not in self._blocks:
-            self._blocks[key] = build_block_plan(self, rows_per_block, row_bytes, limits)
-        return self._blocks[key]
-
-    def tiles(self, rows_per_task: int, max_distinct: int, max_entries: int):
-        """Plan for the wave-pipelined LDS-tiled kernels (None when the pattern does not qualify or
-        profit); cached per task height.  See `build_tile_plan`."""
-        key = (rows_per_task, max_distinct, max_entries)
-        if key not in self._tiles:
-            self._tiles[key] = build_tile_plan(self, rows_per_task, max_distinct, max_entries)
-        return self._tiles[key]
+            if plan is None:
+                plan = build_rowpack_plan(self, rows_per_block, limits, explicit_slots=explicit_slots)
+            packs[key] = plan
+        return packs[key]
 
     @property
     def nnz(self) -> int:
@@ -77,155 +110,58 @@ class RowGather:
 
     def row_indices(self) -> torch.Tensor:
         """Expanded row index per stored entry (same shape/dtype as col); cached."""
-        if self._rows is None:
+        if self.core.rows is None:
             n = self.n_rows
             ar = torch.arange(n, dtype=self.col.dtype, device=self.col.device)
             if self.batch is None:
-                self._rows = torch.repeat_interleave(ar, self.crow[1:] - self.crow[:-1], output_size=self.nnz)
+                self.core.rows = torch.repeat_interleave(ar, self.crow[1:] - self.crow[:-1], output_size=self.nnz)
             else:
                 counts = (self.crow[:, 1:] - self.crow[:, :-1]).reshape(-1)
                 rows = torch.repeat_interleave(ar.repeat(self.batch), counts, output_size=self.batch * self.nnz)
-                self._rows = rows.view(self.batch, self.nnz)
-        return self._rows
+                self.core.rows = rows.view(self.batch, self.nnz)
+        return self.core.rows
 
     @property
     def transposed(self) -> "RowGather":
         """Row-gather structure of Aᵀ whose ``perm`` indexes A's value array."""
-        if self._t is None:
-            self._t = _transpose(self)
-        return self._t
+        if self.core.t is None:
+            self.core.t = _transpose(self)
+        return self.core.t
 
     @property
     def has_diagonal(self) -> bool:
-        if self._has_diag is None:
-            self._has_diag = bool(torch.any(self.row_indices() == self.col))
-        return self._has_diag
-
-
-class TilePlan:
-    """Per-task column dictionary consumed by tsgu_csr_*_wavetile (layout: include/tsgu_hip.h)."""
-
-    __slots__ = ("tmeta", "tile_cols", "lidx", "reuse", "max_distinct", "max_entries", "nnz")
-
-    def __init__(self, tmeta, tile_cols, lidx, reuse, max_distinct, max_entries, nnz):
-        self.tmeta, self.tile_cols, self.lidx = tmeta, tile_cols, lidx
-        self.reuse, self.max_distinct, self.max_entries, self.nnz = reuse, max_distinct, max_entries, nnz
-
-
-_TILE_MIN_REUSE = 1.5   # average entries per distinct column inside a task
-_TILE_MAX_PADDING = 2.0  # padded / real size of the per-task tables
-
-
-def build_tile_plan(g: RowGather, rows_per_task: int, cap_distinct: int, cap_entries: int):
-    """Distinct columns per task of `rows_per_task` consecutive rows + 8-bit local indices, in the
-    fixed-stride, 16-byte aligned layout the wave-pipelined kernels load with wide accesses.
-
-    One sort of (task, column) keys per pattern (tens of ms at 27e6 entries), amortised over every
-    later forward/backward on the same pattern.  Returns None when a task exceeds the kernel limits,
-    the pattern has too little column reuse, or padding would waste memory (ragged patterns)."""
-    if g.batch is not None or g.n_rows == 0 or not (4 <= g.nnz < 2**31):
-        return None
-    n, m, nnz = g.n_rows, g.n_cols, g.nnz
-    dev = g.crow.device
-    ntask = (n + rows_per_task - 1) // rows_per_task
-    e0 = g.crow[torch.arange(0, n, rows_per_task, device=dev)].to(torch.int64)
-    ne = torch.cat((e0[1:], g.crow[-1:].to(torch.int64))) - e0
-    if int(ne.max()) > cap_entries or ntask * cap_entries > _TILE_MAX_PADDING * nnz:
-        return None
-    task = g.row_indices().to(torch.int64) // rows_per_task
-    key = task * m + g.col.to(torch.int64)
-    uniq, inv = torch.unique(key, return_inverse=True)
-    total = uniq.numel()
-    reuse = nnz / max(total, 1)
-    if reuse < _TILE_MIN_REUSE:
-        return None
-    utask = uniq // m
-    cnt = torch.bincount(utask, minlength=ntask)
-    top = int(cnt.max())
-    if top > cap_distinct or top > 256 or ntask * cap_distinct > _TILE_MAX_PADDING * total:
-        return None
-    first = torch.cumsum(cnt, 0) - cnt                       # start of each task's run in `uniq`
-    # padded column table: position d of task t reads uniq[first[t] + min(d, cnt[t]-1)]
-    d = torch.arange(cap_distinct, device=dev).unsqueeze(0)
-    src = first.unsqueeze(1) + torch.minimum(d, (cnt - 1).clamp_min(0).unsqueeze(1))
-    cols = (uniq - utask * m).to(torch.int32)
-    tile_cols = cols[src.clamp_max(total - 1)].contiguous()  # (ntask, cap_distinct)
-    # padded local-index table: entry e of task t (task order) -> position inside the task's run
-    local = (inv - first[task]).to(torch.uint8)
-    pos = torch.arange(nnz, device=dev, dtype=torch.int64) - e0[task]
-    lidx = torch.zeros((ntask, cap_entries), dtype=torch.uint8, device=dev)
-    lidx[task, pos] = local
-    tmeta = torch.stack((e0, ne), dim=1).to(torch.int32).contiguous()
-    return TilePlan(tmeta, tile_cols, lidx, reuse, top, int(ne.max()), nnz)
-
-
-class BlockPlan:
-    """Per-block dictionary of distinct dense rows + packed entry words for tsgu_csr_*_blocktile
-    (layout: include/tsgu_hip.h)."""
-
-    __slots__ = ("ndist", "trow", "ent", "sperm", "capd", "ecap", "rpb", "reuse", "nnz")
-
-    def __init__(self, ndist, trow, ent, sperm, capd, ecap, rpb, reuse, nnz):
-        self.ndist, self.trow, self.ent, self.sperm = ndist, trow, ent, sperm
-        self.capd, self.ecap, self.rpb, self.reuse, self.nnz = capd, ecap, rpb, reuse, nnz
-
-
-def build_block_plan(g: RowGather, rpb: int, row_bytes: int, limits):
-    """Blocks of `rpb` consecutive rows: distinct column indices per block (`trow`, padded to `capd`), a 16-bit
-    local index per stored entry and — for plans that address the owner's values through `perm`
-    (transposed / un-coalesced) — the permutation sorted inside each block (`sperm`) with each entry's slot in
-    that order (`ent = lidx | slot << 16`).  Two device sorts per pattern, amortised over every later call.
-    `limits` = (distinct_multiple, max_distinct, max_entries, lds_budget_bytes) from tsgu_blocktile_limits."""
-    mult, max_distinct, max_entries, lds_budget = limits
-    if g.batch is not None or g.n_rows == 0 or not (1 <= g.nnz < 2**31):
-        return None
-    n, m, nnz = g.n_rows, g.n_cols, g.nnz
-    dev = g.crow.device
-    nb = (n + rpb - 1) // rpb
-    e0 = g.crow[torch.arange(0, n, rpb, device=dev)].to(torch.int64)
-    ne = torch.cat((e0[1:], g.crow[-1:].to(torch.int64))) - e0
-    ecap = (int(ne.max()) + 255) // 256 * 256
-    if ecap == 0 or ecap > max_entries:
-        return None
-    blk = g.row_indices().to(torch.int64) // rpb
-    uniq, inv = torch.unique(blk * m + g.col.to(torch.int64), return_inverse=True)
-    total = uniq.numel()
-    reuse = nnz / max(total, 1)
-    if reuse < _TILE_MIN_REUSE:
-        return None
-    ublk = uniq // m
-    cnt = torch.bincount(ublk, minlength=nb)
-    capd = (int(cnt.max()) + mult - 1) // mult * mult
-    if capd > max_distinct or capd * row_bytes + ecap * 8 > lds_budget or nb * capd > _TILE_MAX_PADDING * total + 4096:
-        return None
-    first = torch.cumsum(cnt, 0) - cnt
-    d = torch.arange(capd, device=dev).unsqueeze(0)
-    src = first.unsqueeze(1) + torch.minimum(d, (cnt - 1).clamp_min(0).unsqueeze(1))
-    trow = (uniq - ublk * m).to(torch.int32)[src.clamp_max(total - 1)].contiguous()
-    ent = (inv - first[blk]).to(torch.int64)
-    sperm = None
-    if g.perm is not None:
-        # entries are stored block after block, so sorting (block, perm) permutes inside each block only
-        order = torch.argsort(blk * nnz + g.perm.to(torch.int64))
-        sperm = g.perm[order].to(torch.int32).contiguous()
-        slot = torch.empty(nnz, dtype=torch.int64, device=dev)
-        slot[order] = torch.arange(nnz, device=dev, dtype=torch.int64) - e0[blk[order]]
-        ent = ent | (slot << 16)
-    ent = ent.to(torch.int32).contiguous()  # bit pattern of the uint32 word (slot < 2048)
-    return BlockPlan(cnt.to(torch.int32).contiguous(), trow, ent, sperm, capd, ecap, rpb, reuse, nnz)
+        if self.core.has_diag is None:
+            self.core.has_diag = bool(torch.any(self.row_indices() == self.col))
+        return self.core.has_diag
 
 
 class RowPackPlan:
-    """Union-of-columns walk for pairs of consecutive rows, consumed by tsgu_csr_*_rowpack (layout: include/tsgu_hip.h)."""
+    """Union-of-columns walk for pairs of consecutive rows, consumed by tsgu_csr_*_rowpack (layout: include/tsgu_hip.h).
+
+    Two storage forms of the same walk:
+    * stream form — ``uptr / ucol / upos / sperm`` hold one record per union entry / stored entry of the whole matrix;
+    * class-dictionary form (``nclasses > 0``) — workgroups whose records are translations of each other (equal after
+      subtracting the workgroup's base pair / base column / base value position) share ONE copy of the records:
+      ``uptr / ucol / upos / sperm / vpair`` are then per-class tables with fixed strides and ``wcls`` / ``wbase`` give
+      every workgroup its class and its three bases.  On lattice stencils (a few dozen classes for millions of rows)
+      the index streams — a third of the kernels' HBM traffic — become L2-resident."""
 
     __slots__ = ("uptr", "ucol", "upos", "sperm", "order", "vpair", "eptr", "nblocks", "ecap", "ucap", "rpb", "reuse",
-                 "nnz", "lattice")
+                 "nnz", "lattice", "wcls", "wbase", "cne", "nclasses", "gpb", "_cstruct")
 
     def __init__(self, uptr, ucol, upos, sperm, ecap, ucap, rpb, reuse, nnz, order=None, vpair=None, eptr=None,
-                 nblocks=0, lattice=None):
+                 nblocks=0, lattice=None, gpb=None):
         self.uptr, self.ucol, self.upos, self.sperm, self.order = uptr, ucol, upos, sperm, order
         self.vpair, self.eptr, self.nblocks, self.lattice = vpair, eptr, nblocks, lattice
         self.ecap, self.ucap, self.rpb, self.reuse, self.nnz = ecap, ucap, rpb, reuse, nnz
+        self.gpb = rpb // 2 if gpb is None else gpb
+        self.wcls = self.wbase = self.cne = None
+        self.nclasses = 0
+        self._cstruct = None
+
+    def plan_bytes(self) -> int:
+        return sum(t.numel() * t.element_size() for t in (self.uptr, self.ucol, self.upos, self.sperm, self.order, self.vpair,
+                                                          self.eptr, self.wcls, self.wbase, self.cne) if t is not None)
 
 
 _PACK_MIN_REUSE = 1.2   # stored entries per union entry (2.0 = both rows of every pair share all columns)
@@ -302,12 +238,19 @@ def brick_pair_order(n: int, lattice, gpb: int, device, shape=None):
     return torch.where(ok, pair, torch.full_like(pair, -1)).reshape(-1)
 
 
-def build_rowpack_plan(g: RowGather, rpb: int, limits, pair_order=None, lattice=None):
+DEDUP_MODE = _os.environ.get("TSGU_DEDUP", "auto")   # "auto" | "off" | "force" (tests: small matrices have few workgroups)
+DEDUP_MAX_FRACTION = 0.25    # dictionary form when the classes are at most this fraction of the workgroups ...
+DEDUP_MAX_BYTES = 8 << 20    # ... and the class tables stay cache-sized
+
+
+def build_rowpack_plan(g: RowGather, rpb: int, limits, pair_order=None, lattice=None, explicit_slots=False, dedup=None):
     """Rows 2q and 2q+1 walk the sorted union of their column sets: `ucol` per union entry, `upos` = two 16-bit slots
     (one per row; bit 15 = this row has no entry there) into the value slice a workgroup of `rpb` rows stages.  For
     plans addressed through `perm` the slice is staged in the order of the permutation sorted inside the workgroup
-    (`sperm`), otherwise in stored order.  `pair_order` (permuted plans only) assigns row pairs to lane-group slots
-    (see brick_pair_order); None = consecutive.  `limits` = (max_entries, max_union, lds_budget_bytes)."""
+    (`sperm`), otherwise in stored order — and then, unless `explicit_slots` (kernels with several entry lanes per
+    pair), the record only carries two ownership bits (30 / 31 of ucol) because a row's slots are consecutive.
+    `pair_order` (permuted plans only) assigns row pairs to lane-group slots (see brick_pair_order); None =
+    consecutive.  `limits` = (max_entries, max_union, lds_budget_bytes).  `dedup` overrides DEDUP_MODE."""
     max_entries, max_union, lds_budget = limits
     if g.batch is not None or g.n_rows == 0 or not (1 <= g.nnz < 2**31):
         return None
@@ -316,6 +259,7 @@ def build_rowpack_plan(g: RowGather, rpb: int, limits, pair_order=None, lattice=
     gpb = rpb // 2
     npairs = (n + 1) // 2
     natural = pair_order is None
+    slots = explicit_slots or g.perm is not None
     if natural:
         nb = (npairs + gpb - 1) // gpb
         pair_order = torch.full((nb * gpb,), -1, dtype=torch.int64, device=dev)
@@ -353,37 +297,178 @@ def build_rowpack_plan(g: RowGather, rpb: int, limits, pair_order=None, lattice=
     uptr[1:] = torch.cumsum(torch.bincount(uslot, minlength=nslots), 0)
     ub = uptr[torch.arange(0, nslots + 1, gpb, device=dev)]
     ucap = max((int((ub[1:] - ub[:-1]).max()) + 255) // 256 * 256, 256)
-    if ucap > max_union or ucap * (4 if g.perm is None else 8) + ecap * 4 > lds_budget or (g.perm is None and m >= 2**30):
+    if ucap > max_union or ucap * (8 if slots else 4) + ecap * 4 > lds_budget or (not slots and m >= 2**30):
         return None
     k = torch.arange(nnz, device=dev, dtype=torch.int64)
-    sperm = None
+    sperm64 = None
     if g.perm is None:
         slot = k - eptr[blk]                      # natural order: a workgroup's entries are one contiguous range
     else:
         order = torch.argsort(blk * nnz + g.perm.to(torch.int64))
-        sperm = g.perm[order].to(torch.int32).contiguous()
+        sperm64 = g.perm[order].to(torch.int64)
         slot = torch.empty(nnz, dtype=torch.int64, device=dev)
         slot[order] = k - eptr[blk[order]]
-    to_i32 = lambda w: torch.where(w >= 2**31, w - 2**32, w).to(torch.int32).contiguous()  # noqa: E731  (uint32 bit pattern)
     ucol64 = uniq - uslot * m
-    if g.perm is None:
+    own = word64 = None
+    if not slots:
         # stored order: a row's slots are consecutive, the record only carries the ownership bits (30: row 2q, 31: 2q+1)
         own = torch.zeros((2, nu), dtype=torch.int64, device=dev)
         own[rows % 2, inv] = 1
-        ucol = to_i32(ucol64 | (own[0] << 30) | (own[1] << 31))
-        word = None
+        own = (own[0] << 30) | (own[1] << 31)
     else:
         half = torch.full((2, nu), _PACK_ABSENT, dtype=torch.int64, device=dev)
         half[rows % 2, inv] = slot
-        word = to_i32(half[0] | (half[1] << 16))
-        ucol = ucol64.to(torch.int32).contiguous()
-    plan = RowPackPlan(uptr.to(torch.int32).contiguous(), ucol, word, sperm, ecap, ucap, rpb, reuse, nnz)
+        word64 = half[0] | (half[1] << 16)
+    plan = RowPackPlan(None, None, None, None, ecap, ucap, rpb, reuse, nnz, nblocks=nb, lattice=lattice)
+    mode = DEDUP_MODE if dedup is None else dedup
+    if mode != "off" and _dedup_classes(plan, mode == "force", natural, uptr, ub, ucol64, own, word64, sperm64, pair_order,
+                                        eptr, nb, gpb):
+        return plan
+    plan.uptr = uptr.to(torch.int32).contiguous()
+    plan.ucol = _to_i32(ucol64 | own if own is not None else ucol64)
+    plan.upos = None if word64 is None else _to_i32(word64)
+    plan.sperm = None if sperm64 is None else sperm64.to(torch.int32).contiguous()
     if not natural:
         plan.vpair = pair_order.to(torch.int32).contiguous()
         plan.eptr = eptr.to(torch.int32).contiguous()
-        plan.nblocks = nb
-        plan.lattice = lattice
     return plan
+
+
+def _to_i32(w: torch.Tensor) -> torch.Tensor:
+    """int64 holding a uint32 bit pattern -> int32 tensor with the same bits."""
+    return torch.where(w >= 2**31, w - 2**32, w).to(torch.int32).contiguous()
+
+
+def _mix(a: torch.Tensor, b, pos) -> torch.Tensor:
+    """64-bit mixing of (a, b, position) with wrap-around integer arithmetic (collisions are caught by the exact
+    comparison in _dedup_classes, so this only has to be well spread)."""
+    if not torch.is_tensor(pos):
+        pos = torch.tensor(pos, dtype=torch.int64, device=a.device)
+    x = a * -7046029254386353131 + b * -4417276706812531889 + 1609587929392839161
+    x = x ^ (pos * 2870177450012600261 + 7046029254386353131)
+    return x * -49064778989728563
+
+
+def _dedup_classes(plan: RowPackPlan, force: bool, natural: bool, uptr, ub, ucol64, own, word64, sperm64, pair_order, eptr,
+                   nb: int, gpb: int) -> bool:
+    """Translation-deduplicate the per-workgroup records of a row-pair plan (see RowPackPlan).  Fills the
+    class-dictionary fields of `plan` and returns True when the dictionary form is used."""
+    dev = uptr.device
+    i64 = torch.int64
+    big = torch.iinfo(i64).max
+    ar_nb = torch.arange(nb, device=dev)
+    nu_b = ub[1:] - ub[:-1]
+    nu = int(ub[-1])
+    ne_b = eptr[1:] - eptr[:-1]
+    nnz = int(eptr[-1])
+    wg_u = torch.repeat_interleave(ar_nb, nu_b, output_size=nu)
+    pos_u = torch.arange(nu, device=dev) - ub[wg_u]
+    base_col = torch.full((nb,), big, dtype=i64, device=dev).scatter_reduce_(0, wg_u, ucol64, "amin")
+    base_col = torch.where(nu_b > 0, base_col, torch.zeros_like(base_col))
+    rel_col = ucol64 - base_col[wg_u]
+    po = pair_order.view(nb, gpb)
+    valid = po >= 0
+    base_pair = torch.where(valid, po, torch.full_like(po, big)).amin(1)
+    base_pair = torch.where(valid.any(1), base_pair, torch.zeros_like(base_pair))
+    rel_pair = torch.where(valid, po - base_pair[:, None], torch.full_like(po, -1))
+    rel_uptr = uptr[:-1].view(nb, gpb) - ub[:-1, None]
+    rec = word64 if word64 is not None else own
+    h = torch.zeros(nb, dtype=i64, device=dev)
+    h.index_add_(0, wg_u, _mix(rel_col, rec, pos_u))
+    h += _mix(rel_pair, rel_uptr, torch.arange(gpb, device=dev)[None, :] + 1000003).sum(1)
+    h += _mix(nu_b, ne_b, 7)
+    rel_perm = base_perm = None
+    if sperm64 is not None:
+        wg_e = torch.repeat_interleave(ar_nb, ne_b, output_size=nnz)
+        pos_e = torch.arange(nnz, device=dev) - eptr[wg_e]
+        base_perm = torch.zeros(nb, dtype=i64, device=dev)
+        has = ne_b > 0
+        base_perm[has] = sperm64[eptr[:-1][has]]   # sorted ascending inside a workgroup: the first is the smallest
+        rel_perm = sperm64 - base_perm[wg_e]
+        h.index_add_(0, wg_e, _mix(rel_perm, pos_e, 3))
+    uniq, inv = torch.unique(h, return_inverse=True)
+    ncls = uniq.numel()
+    slots = word64 is not None
+    table_bytes = ncls * ((gpb + 1) * 4 + plan.ucap * (8 if slots else 4) + (plan.ecap * 4 if sperm64 is not None else 0) + gpb * 4)
+    if not force and (ncls > DEDUP_MAX_FRACTION * nb or table_bytes > DEDUP_MAX_BYTES):
+        return False
+    rep = torch.full((ncls,), nb, dtype=i64, device=dev).scatter_reduce_(0, inv, ar_nb, "amin")
+    r_b = rep[inv]
+    # exact check against the class representative (a hash collision falls back to the stream form)
+    ok = (torch.equal(nu_b, nu_b[r_b]) and torch.equal(ne_b, ne_b[r_b]) and torch.equal(rel_pair, rel_pair[r_b])
+          and torch.equal(rel_uptr, rel_uptr[r_b]))
+    if ok:
+        idx = ub[r_b][wg_u] + pos_u
+        ok = torch.equal(rel_col, rel_col[idx]) and torch.equal(rec, rec[idx])
+    if ok and sperm64 is not None:
+        idx_e = eptr[r_b][wg_e] + pos_e
+        ok = torch.equal(rel_perm, rel_perm[idx_e])
+    if not ok:
+        return False
+    cuptr = torch.zeros((ncls, gpb + 1), dtype=i64, device=dev)
+    cuptr[:, :gpb] = rel_uptr[rep]
+    cuptr[:, gpb] = nu_b[rep]
+    is_rep = r_b == ar_nb
+    mu = is_rep[wg_u]
+    cu, pu = inv[wg_u[mu]], pos_u[mu]
+    cucol = torch.zeros((ncls, plan.ucap), dtype=i64, device=dev)
+    cucol[cu, pu] = rel_col[mu] | own[mu] if own is not None else rel_col[mu]
+    plan.uptr = cuptr.to(torch.int32).reshape(-1).contiguous()
+    plan.ucol = _to_i32(cucol.reshape(-1))
+    if slots:
+        cupos = torch.full((ncls, plan.ucap), _PACK_ABSENT | (_PACK_ABSENT << 16), dtype=i64, device=dev)
+        cupos[cu, pu] = word64[mu]
+        plan.upos = _to_i32(cupos.reshape(-1))
+    if sperm64 is not None:
+        me = is_rep[wg_e]
+        csperm = torch.zeros((ncls, plan.ecap), dtype=i64, device=dev)
+        csperm[inv[wg_e[me]], pos_e[me]] = rel_perm[me]
+        plan.sperm = csperm.to(torch.int32).reshape(-1).contiguous()
+        plan.cne = ne_b[rep].to(torch.int32).contiguous()
+    if not natural:
+        plan.vpair = rel_pair[rep].to(torch.int32).reshape(-1).contiguous()
+    wbase = torch.stack((base_pair, base_col, base_perm if base_perm is not None else torch.zeros_like(base_pair)), 1)
+    plan.wbase = wbase.to(torch.int32).contiguous()
+    plan.wcls = inv.to(torch.int32).contiguous()
+    plan.nclasses = ncls
+    return True
+
+
+def expand_classes(plan: RowPackPlan):
+    """Stream-form arrays (uptr, ucol, upos, sperm, vpair, eptr) of a class-dictionary plan — what the kernels see
+    after adding every workgroup's bases.  Test / debugging helper."""
+    assert plan.nclasses > 0
+    gpb, nb = plan.gpb, plan.nblocks
+    cls = plan.wcls.long()
+    wb = plan.wbase.long()
+    cuptr = plan.uptr.view(-1, gpb + 1).long()[cls]                     # (nb, gpb+1) relative
+    nu_b = cuptr[:, gpb]
+    ub = torch.zeros(nb + 1, dtype=torch.int64, device=cls.device)
+    ub[1:] = torch.cumsum(nu_b, 0)
+    uptr = torch.cat(((cuptr[:, :gpb] + ub[:-1, None]).reshape(-1), ub[-1:]))
+    ar = torch.arange(plan.ucap, device=cls.device)[None, :]
+    mu = ar < nu_b[:, None]
+    slots = plan.upos is not None
+    words = plan.ucol.view(-1, plan.ucap).long()[cls] & 0xFFFFFFFF
+    if slots:
+        ucol = (words + wb[:, 1:2])[mu]
+        upos = (plan.upos.view(-1, plan.ucap).long()[cls] & 0xFFFFFFFF)[mu]
+    else:
+        ucol = (((words & 0x3FFFFFFF) + wb[:, 1:2]) | (words & 0xC0000000))[mu]
+        upos = None
+    sperm = eptr = None
+    if plan.sperm is not None:
+        ne_b = plan.cne.long()[cls]
+        eptr = torch.zeros(nb + 1, dtype=torch.int64, device=cls.device)
+        eptr[1:] = torch.cumsum(ne_b, 0)
+        me = torch.arange(plan.ecap, device=cls.device)[None, :] < ne_b[:, None]
+        sperm = (plan.sperm.view(-1, plan.ecap).long()[cls] + wb[:, 2:3])[me]
+    if plan.vpair is not None:
+        rel = plan.vpair.view(-1, gpb).long()[cls]
+        vpair = torch.where(rel >= 0, rel + wb[:, 0:1], rel).reshape(-1)
+    else:
+        vpair = (wb[:, 0:1] + torch.arange(gpb, device=cls.device)[None, :]).reshape(-1)
+    return uptr, ucol, upos, sperm, vpair, eptr
 
 
 def _transpose(g: RowGather) -> RowGather:
@@ -411,30 +496,45 @@ def _transpose(g: RowGather) -> RowGather:
 
 
 # ---- cache ---------------------------------------------------------------------------------
+# key -> _Core.  The key identifies the caller's index tensors by storage identity + view geometry + version; the
+# entry is evicted when any of those storages dies (weakref finalizer: torch keeps one Python object per live
+# storage), when the LRU count is exceeded, or when the derived bytes exceed the budget.  Cores never reference
+# the caller's tensors, so `del A` really frees the plans.
 
-_CACHE: "OrderedDict[tuple, Tuple[tuple, RowGather]]" = OrderedDict()
-_CACHE_LOCK = threading.Lock()  # backward runs on autograd threads
+_CACHE: "OrderedDict[tuple, _Core]" = OrderedDict()
+_CACHE_LOCK = threading.RLock()  # backward runs on autograd threads; finalizers may run inside a locked region
 _CACHE_MAX = 16
+_CACHE_MAX_BYTES = int(_os.environ.get("TSGU_PLAN_CACHE_BYTES", str(8 << 30)))
 
 
 def _key(kind: str, tensors, shape) -> tuple:
-    return (kind, tuple(shape)) + tuple((t.data_ptr(), t._version, tuple(t.shape), t.dtype, str(t.device)) for t in tensors)
+    return (kind, tuple(shape)) + tuple(
+        (t.untyped_storage()._cdata, t.storage_offset(), tuple(t.shape), tuple(t.stride()), t.dtype, t._version, str(t.device))
+        for t in tensors)
 
 
-def _cached(kind, tensors, shape, build) -> RowGather:
+def _evict(key) -> None:
+    with _CACHE_LOCK:
+        _CACHE.pop(key, None)
+
+
+def _core_for(kind: str, tensors, shape) -> _Core:
     key = _key(kind, tensors, shape)
     with _CACHE_LOCK:
-        hit = _CACHE.get(key)
-        if hit is not None:
+        core = _CACHE.get(key)
+        if core is not None:
             _CACHE.move_to_end(key)
-            return hit[1]
-    plan = build()
-    with _CACHE_LOCK:
-        # keep the index tensors alive with the entry so their addresses cannot be recycled
-        _CACHE[key] = (tuple(tensors), plan)
+            return core
+        core = _Core()
+        _CACHE[key] = core
+        for t in tensors:
+            weakref.finalize(t.untyped_storage(), _evict, key)
         while len(_CACHE) > _CACHE_MAX:
             _CACHE.popitem(last=False)
-    return plan
+        if len(_CACHE) > 1 and sum(c.nbytes() for c in _CACHE.values()) > _CACHE_MAX_BYTES:
+            while len(_CACHE) > 1 and sum(c.nbytes() for c in _CACHE.values()) > _CACHE_MAX_BYTES:
+                _CACHE.popitem(last=False)
+    return core
 
 
 def clear_cache() -> None:
@@ -442,42 +542,72 @@ def clear_cache() -> None:
         _CACHE.clear()
 
 
+def cache_stats():
+    """(entries, derived bytes) held by the pattern cache."""
+    with _CACHE_LOCK:
+        return len(_CACHE), sum(c.nbytes() for c in _CACHE.values())
+
+
 def from_csr(A: torch.Tensor) -> RowGather:
     """Plan for a CSR tensor, 2-D or batched 3-D (torch's batched CSR: equal nnz per item)."""
     crow, col = A.crow_indices(), A.col_indices()
-    return _cached("csr", (crow, col), A.shape, lambda: RowGather(crow, col, A.size(-2), A.size(-1)))
+    return RowGather(crow, col, A.size(-2), A.size(-1), core=_core_for("csr", (crow, col), A.shape))
 
 
 def from_coo_2d(indices: torch.Tensor, shape, coalesced: bool) -> RowGather:
     """Plan for 2-D COO indices (2, nnz).  Coalesced input is already row-sorted; otherwise the
     entries are visited in a stable row order through ``perm`` (duplicates stay separate)."""
-
-    def build():
-        n, m = int(shape[-2]), int(shape[-1])
-        rows, cols = indices[0], indices[1]
+    n, m = int(shape[-2]), int(shape[-1])
+    core = _core_for("coo" + ("c" if coalesced else "u"), (indices,), shape)
+    own = core.own
+    if "crow" not in own:
+        rows = indices[0]
         if coalesced:
-            crow = torch._convert_indices_from_coo_to_csr(rows, n, out_int32=False)
-            return RowGather(crow, cols.contiguous(), n, m)
-        order = torch.argsort(rows, stable=True)
-        crow = torch._convert_indices_from_coo_to_csr(rows[order].contiguous(), n, out_int32=False)
-        return RowGather(crow, cols[order].contiguous(), n, m, perm=order)
+            own["crow"] = torch._convert_indices_from_coo_to_csr(rows, n, out_int32=False)
+        else:
+            order = torch.argsort(rows, stable=True)
+            own["crow"] = torch._convert_indices_from_coo_to_csr(rows[order].contiguous(), n, out_int32=False)
+            own["col"] = indices[1][order].contiguous()
+            own["perm"] = order
+    if coalesced:
+        return RowGather(own["crow"], indices[1].contiguous(), n, m, core=core)
+    return RowGather(own["crow"], own["col"], n, m, perm=own["perm"], core=core)
 
-    return _cached("coo" + ("c" if coalesced else "u"), (indices,), shape, build)
+
+def from_coo_batched(indices: torch.Tensor, shape) -> RowGather:
+    """Plan for coalesced 3-D COO indices (3, nnz) as ONE block-diagonal 2-D pattern (b·n × b·m) — what the reference
+    assembles for every batched input (sparse_matmul.py:151-153); items may differ in nnz.  Cached on the caller's
+    index tensor (the flattened indices are derived data)."""
+    b, n, m = (int(v) for v in shape)
+    core = _core_for("coo3", (indices,), shape)
+    own = core.own
+    if "crow" not in own:
+        own["crow"] = torch._convert_indices_from_coo_to_csr(indices[0] * n + indices[1], b * n, out_int32=False)
+        own["col"] = (indices[0] * m + indices[2]).contiguous()
+    return RowGather(own["crow"], own["col"], b * n, b * m, core=core)
 
 
-def flat_block_diag(crow: torch.Tensor, col: torch.Tensor, n: int, m: int) -> RowGather:
-    """Batched CSR arrays (b, n+1)/(b, nnz) → the 2-D block-diagonal plan (b·n × b·m) the reference
-    assembles with ``sparse_block_diag`` (utils/utils.py:615-645): two vectorised adds, no sync."""
-
-    def build():
+def flat_of(g: RowGather) -> RowGather:
+    """Batched CSR plan (b, n+1)/(b, nnz) → the 2-D block-diagonal plan (b·n × b·m) the reference assembles with
+    ``sparse_block_diag`` (utils/utils.py:615-645): two vectorised adds, no sync; cached with the pattern."""
+    if g.batch is None:
+        return g
+    if g.core.flat is None:
+        crow, col, n, m = g.crow, g.col, g.n_rows, g.n_cols
         b, nnz = col.shape
         idt = crow.dtype
-        if idt == torch.int32 and max(b * nnz, b * m) >= 2**31:
+        if idt == torch.int32 and max(b * nnz, b * m, b * n) >= 2**31:
             idt = torch.int64
         item = torch.arange(b, device=col.device, dtype=idt).unsqueeze(1)
         flat_crow = torch.cat(((crow[:, :-1].to(idt) + item * nnz).reshape(-1),
                                torch.tensor([b * nnz], dtype=idt, device=col.device)))
         flat_col = (col.to(idt) + item * m).reshape(-1)
-        return RowGather(flat_crow, flat_col, b * n, b * m)
+        g.core.flat = RowGather(flat_crow, flat_col, b * n, b * m)
+    return g.core.flat
 
-    return _cached("csrflat", (crow, col), (n, m), build)
+
+def flat_block_diag(crow: torch.Tensor, col: torch.Tensor, n: int, m: int) -> RowGather:
+    """Block-diagonal 2-D plan of batched CSR index arrays (see flat_of)."""
+    b = col.size(0)
+    g = RowGather(crow, col, n, m, core=_core_for("csr", (crow, col), (b, n, m)))
+    return flat_of(g)

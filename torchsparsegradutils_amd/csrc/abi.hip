@@ -31,7 +31,6 @@ const char* tsgu_status_string(int status) {
         case TSGU_ERR_TOO_LARGE: return "problem exceeds a kernel limit (n_cols >= 2^31, batch > 65535 or grid too large)";
         case TSGU_ERR_LAUNCH: return "HIP kernel launch failed";
         case TSGU_ERR_RUNTIME: return "HIP runtime call failed";
-        case TSGU_ERR_NOT_TRIANGULAR: return "matrix is not usable as a triangular factor (zero or missing diagonal)";
         case TSGU_ERR_TIMEOUT: return "device-side dependency wait timed out";
     }
     return "unknown status";

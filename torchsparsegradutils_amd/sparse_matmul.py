@@ -73,11 +73,9 @@ class _Operand:
         if A.dim() == 3:
             A = A if A.is_coalesced() else A.coalesce()
             idx = A._indices()
-            b, n, m = A.shape
-            flat = torch.stack((idx[0] * n + idx[1], idx[0] * m + idx[2]))
             self.indices = idx
-            self.flat_batch = b
-            self.plan = _pt.from_coo_2d(flat, (b * n, b * m), coalesced=True)
+            self.flat_batch = A.size(0)
+            self.plan = _pt.from_coo_batched(idx, A.shape)
             self.values = A._values()
             return
         self.indices = A._indices()

@@ -83,9 +83,7 @@ class _TriOperand:
         if self.batch is None:
             self.plan = _pt.from_coo_2d(idx, A.shape, coalesced=True)
         else:
-            b, n, m = A.shape
-            flat = torch.stack((idx[0] * n + idx[1], idx[0] * m + idx[2]))
-            self.plan = _pt.from_coo_2d(flat, (b * n, b * m), coalesced=True)
+            self.plan = _pt.from_coo_batched(idx, A.shape)
 
     def rebuild(self, grad_values: torch.Tensor) -> torch.Tensor:
         """Gradient in the caller's layout (reference sparse_solve.py:237-250)."""
