@@ -5,6 +5,7 @@ Tolerances (BASELINE north_star): indices bit-exact; values within 1e-5 relative
 (normalised by the largest reference magnitude), 1e-11 fp64, 1e-3 bf16.
 """
 
+import os
 import warnings
 
 import numpy as np
@@ -308,6 +309,117 @@ def test_rowpack_kernels_match_oracle(dt, p, itype, form, monkeypatch):
     assert _close(Cq0, C_o, dt) and _close(Ad0.grad.values(), gA_o, dt) and _close(Bq0.grad, gB_o, dt)
     if ep == 1 and dt == torch.float32:
         assert torch.equal(Cq0, Cq) and torch.equal(Bq0.grad, Bq.grad)
+
+
+def _c5_operands():
+    z = G.load("c5_batched_bf16.npz")
+    b, n = z["crow"].shape[0], z["crow"].shape[1] - 1
+    A = torch.sparse_csr_tensor(G.t(z["crow"], DEV), G.t(z["col"], DEV), G.bf16(z["val_bf16"], DEV), (b, n, n))
+    return z, A, G.bf16(z["B_bf16"], DEV), G.bf16(z["G_bf16"], DEV)
+
+
+@pytest.mark.parametrize("packed", [True, False])
+def test_c5_batched_bf16_csr_fwd_bwd(packed, monkeypatch):
+    """BASELINE configs[4] scaled down: batched CSR (3 items sharing the 27-pt pattern + 1 item with another
+    pattern), 16 RHS (32-byte dense rows: 2 column lanes x 4 entry lanes per pair), bf16, against the reference's
+    batched fp32 result on the bf16-rounded inputs.  `packed`: the batch runs as one block-diagonal problem on the
+    row-pair kernels (class-dictionary plan shared between the items); otherwise on the plain kernels (gridDim.y)."""
+    from torchsparsegradutils_amd import _ops, _pattern
+
+    monkeypatch.setattr(_ops, "ENABLE_PACK", packed)
+    z, A, B, Gd = _c5_operands()
+    A.requires_grad_(True)
+    B.requires_grad_(True)
+    C = tsgu().sparse_mm(A, B)
+    C.backward(Gd)
+    assert C.dtype == torch.bfloat16 and C.shape == B.shape
+    gA = A.grad
+    assert gA.layout == torch.sparse_csr and gA.values().dtype == torch.bfloat16 and gA.shape == A.shape
+    assert gA.crow_indices().dtype == torch.int32 and torch.equal(gA.crow_indices(), A.crow_indices())
+    assert torch.equal(gA.col_indices(), A.col_indices())
+    for mine, ref in ((C, z["C_f32"]), (gA.values(), z["gradA_f32"]), (B.grad, z["gradB_f32"])):
+        assert _close(mine, ref, torch.bfloat16)
+    flat = _pattern.from_csr(A).core.flat
+    if packed:
+        rp = list(flat.core.packs.values())
+        rpt = list(flat.transposed.core.packs.values())
+        assert rp and rp[0] is not None and rpt and rpt[0] is not None, "the row-pair kernels were not used"
+        # three of the four items share one pattern: their workgroups share the classes
+        assert rp[0].nclasses == 0 or rp[0].nclasses < rp[0].nblocks
+    else:
+        assert flat is None
+    # one-sided gradients take the un-fused kernels
+    A2 = A.detach().clone().requires_grad_(True)
+    C2 = tsgu().sparse_mm(A2, B.detach())
+    C2.backward(Gd)
+    assert _close(A2.grad.values(), z["gradA_f32"], torch.bfloat16)
+    B3 = B.detach().clone().requires_grad_(True)
+    tsgu().sparse_mm(A.detach(), B3).backward(Gd)
+    assert _close(B3.grad, z["gradB_f32"], torch.bfloat16)
+
+
+def test_c5_sharded_batched_apply_on_rccl_world_of_one():
+    """`parallel.sharded_batched_apply` with the HIP op on a real `nccl` (RCCL) process group — world size 1 on this
+    one-GPU box: shard → local kernels → all-gather (plain and chunk-overlapped) must reproduce the golden result; the
+    gloo world-size-2 tests cover the >1-rank bookkeeping on CPU."""
+    import torch.distributed as dist
+
+    from torchsparsegradutils_amd import parallel
+
+    z, A, B, Gd = _c5_operands()
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29531")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        out = parallel.sharded_batched_apply(tsgu().sparse_mm, A, B)
+        out_c = parallel.sharded_batched_apply(tsgu().sparse_mm, A, B, overlap_chunks=2)
+        local = parallel.sharded_batched_apply(tsgu().sparse_mm, A, B, gather=False)
+        assert out.shape == B.shape and torch.equal(out, out_c) and torch.equal(out, local)
+        assert _close(out, z["C_f32"], torch.bfloat16)
+        # gradients flow to the local shard
+        Ar = parallel.shard_batched_csr(A, 0, 1).requires_grad_(True)
+        Br = B.clone().requires_grad_(True)
+        tsgu().sparse_mm(Ar, Br).backward(Gd)
+        assert _close(Ar.grad.values(), z["gradA_f32"], torch.bfloat16) and _close(Br.grad, z["gradB_f32"], torch.bfloat16)
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
+def test_plan_policy_first_sight_runs_plan_free_then_builds_and_releases(monkeypatch):
+    """Default policy: the first use of a pattern runs on the plan-free kernels, the row-pair plans are built when
+    the pattern comes back, results are identical (fp32, one entry lane), and dropping the tensor frees the plans."""
+    import gc
+
+    from torchsparsegradutils_amd import _ops, _pattern
+    from torchsparsegradutils_amd.utils import synthetic
+
+    monkeypatch.setattr(_ops, "PLAN_AFTER_USES", 1)
+    monkeypatch.setattr(_ops, "PACK_MIN_NNZ", 0)
+    _pattern.clear_cache()
+    crow, col = synthetic.stencil27_periodic(12, 10, 8, torch.int32, device=DEV)
+    n = 960
+    A = torch.sparse_csr_tensor(crow, col, torch.randn(col.numel(), device=DEV), (n, n)).requires_grad_(True)
+    del crow, col
+    B = torch.randn(n, 32, device=DEV, requires_grad=True)
+    Gd = torch.randn(n, 32, device=DEV)
+    outs = []
+    for it in range(3):
+        C = tsgu().sparse_mm(A, B)
+        gA, gB = torch.autograd.grad(C, (A, B), Gd)
+        outs.append((C.detach(), gA.values().detach(), gB.detach()))
+        core = _pattern.from_csr(A.detach()).core
+        built = bool(core.packs) and core.t is not None and bool(core.t.core.packs)
+        assert built == (it >= 1), (it, core.packs)
+    for a, b_ in zip(outs[0], outs[2]):
+        assert torch.equal(a, b_)
+    entries, nbytes = _pattern.cache_stats()
+    assert entries == 1 and nbytes > 0
+    del A, C, gA, gB, outs, core
+    gc.collect()
+    assert _pattern.cache_stats() == (0, 0)
 
 
 @pytest.mark.parametrize("kind", ["stencil27", "stencil27_odd", "laplacian7", "grid2d"])

@@ -155,3 +155,16 @@ def test_generic_solve_gradient_rule():
         assert G.rel_err(x, z[name + "x"]) < tol, name
         assert G.rel_err(gB, z[name + "gradB"]) < tol, name
         assert G.rel_err(gA, z[name + "gradA_val"]) < tol, name
+
+
+def test_c5_batched_bf16_inputs():
+    """C5 scaled down (round 2): the reference's batched fp32 path on bf16-rounded inputs, item by item."""
+    z = G.load("c5_batched_bf16.npz")
+    val = G.bf16(z["val_bf16"]).float().numpy()
+    B = G.bf16(z["B_bf16"]).float().numpy()
+    Gd = G.bf16(z["G_bf16"]).float().numpy()
+    for k in range(val.shape[0]):
+        C, gA, gB = oracle.sparse_mm_fwd_bwd(z["crow"][k], z["col"][k], val[k], B[k], Gd[k], B.shape[1])
+        assert G.rel_err(C, z["C_f32"][k]) < 3e-6
+        assert G.rel_err(gA, z["gradA_f32"][k]) < 3e-6
+        assert G.rel_err(gB, z["gradB_f32"][k]) < 3e-6

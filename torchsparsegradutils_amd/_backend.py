@@ -405,6 +405,8 @@ def csr_sptrsm(ptr, idx, val, B, n: int, lower: bool, unit: bool, perm=None):
     if perm is not None:
         perm = perm.contiguous()
     X = torch.empty((n, p), dtype=B.dtype, device=dev)
+    if n == 0 or p == 0:
+        return X  # nothing to solve (the kernel would not even initialise its error word)
     work = torch.empty((lib.tsgu_sptrsm_work_bytes(n, p),), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
         check(
@@ -425,6 +427,8 @@ def coldot(X, Y):
     """Column-wise dot products of two (n, p) arrays -> (p,) tensor (deterministic)."""
     lib = load_library()
     dev = require_device(X, Y)
+    if X.dtype != Y.dtype:
+        raise RuntimeError(f"tsgu_coldot: expected both operands to have the same dtype, got {X.dtype} and {Y.dtype}")
     X, Y = rowmajor(X), rowmajor(Y)
     n, p = X.shape
     nb = lib.tsgu_coldot_max_blocks(n, p)

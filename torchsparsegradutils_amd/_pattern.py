@@ -602,7 +602,8 @@ def flat_of(g: RowGather) -> RowGather:
         flat_crow = torch.cat(((crow[:, :-1].to(idt) + item * nnz).reshape(-1),
                                torch.tensor([b * nnz], dtype=idt, device=col.device)))
         flat_col = (col.to(idt) + item * m).reshape(-1)
-        g.core.flat = RowGather(flat_crow, flat_col, b * n, b * m)
+        flat_perm = None if g.perm is None else (g.perm.to(idt) + item * nnz).reshape(-1)
+        g.core.flat = RowGather(flat_crow, flat_col, b * n, b * m, perm=flat_perm)
     return g.core.flat
 
 

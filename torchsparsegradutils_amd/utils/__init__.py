@@ -26,3 +26,13 @@ __all__ = [
     "stack_csr",
     "sparse_eye",
 ]
+
+
+def last_solve_info(solver: str = "linear_cg"):
+    """Iteration count / stopping outcome / final residual of the calling thread's most recent solve with
+    ``solver`` in {"linear_cg", "minres", "bicgstab"} (build extension: the reference only prints, see
+    utils/linear_cg.py:273-275)."""
+    import sys as _sys
+
+    mod = _sys.modules[__name__ + "." + solver]
+    return mod.last_solve_info()

@@ -34,7 +34,12 @@ class SparseOperator:
         self.dtype = self.values.dtype
 
     def _cast(self, v):
-        return v if v.dtype == self.dtype else v.to(self.dtype)
+        # mixed dtypes: the reference's ``A.matmul(v)`` raises torch's dtype error (sparse_generic_solve only warns
+        # beforehand, sparse_solve.py:398-403); the raw-pointer kernels must never see operands of two widths
+        if v.dtype != self.dtype:
+            names = {torch.float64: "Double", torch.float32: "Float", torch.bfloat16: "BFloat16", torch.float16: "Half"}
+            raise RuntimeError(f"expected scalar type {names.get(self.dtype, self.dtype)} but found {names.get(v.dtype, v.dtype)}")
+        return v
 
     def __call__(self, v: torch.Tensor) -> torch.Tensor:
         v = self._cast(v)
@@ -49,8 +54,18 @@ class SparseOperator:
         """(A·v, per-block partial sums of <w, A·v> per column; w defaults to v) — K1 with the fused dot epilogue.
         ``out`` (optional, must not alias ``v``) receives A·v in place."""
         p = self.plan
+        v = self._cast(v)
         return _be.csr_spmm(p.crow, p.col, self.values, v, p.n_rows, p.n_cols, perm=p.perm, out=out,
                             dot_w=v if w is None else w)
+
+
+def checked(out: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """Output of a matrix–vector closure inside a fused solver loop: the raw-pointer kernels work in ONE dtype, so a
+    closure that promotes (e.g. a float64 operator applied to float32 vectors) is an error, as it is — with torch's
+    own message — in the reference's op chain."""
+    if out.dtype != dtype:
+        raise RuntimeError(f"matmul_closure returned {out.dtype} for {dtype} vectors: expected one working dtype")
+    return out
 
 
 def as_operator(matmul_closure):

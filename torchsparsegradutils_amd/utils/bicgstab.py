@@ -14,11 +14,13 @@ from __future__ import annotations
 import logging
 from typing import Callable, NamedTuple, Optional, Union
 
+import threading
+
 import torch
 
 from .. import _backend as _be
 from . import _graph
-from ._operator import SparseOperator, as_operator
+from ._operator import SparseOperator, as_operator, checked
 
 _POLL = 4  # iterations enqueued between two reads of the device "all columns finished" word
 _GRAPH_AFTER = 16  # iterations run eagerly before a chunk is recorded as a hipGraph
@@ -152,7 +154,7 @@ def _bicgstab_fused(matmul_closure, rhs, initial_guess, settings: BICGSTABSettin
 
     if initial_guess is None:
         x = torch.zeros_like(B)
-        r0 = (B - op(x)).contiguous()  # one matvec on A·0, as the reference (bicgstab.py:159-161)
+        r0 = (B - checked(op(x), dtype)).contiguous()  # one matvec on A·0, as the reference (bicgstab.py:159-161)
         nmv0 = 1
     else:
         x = (initial_guess.unsqueeze(-1) if initial_guess.dim() == 1 else initial_guess).clone().contiguous()
@@ -194,11 +196,11 @@ def _bicgstab_fused(matmul_closure, rhs, initial_guess, settings: BICGSTABSettin
                 _, pr0v = op.matmul_with_dot(pv, r0, out=v)  # v = A p with <r0, v> partials (:196-199)
                 scalar(2, pr0v, pr0v.shape[0])
             else:
-                v.copy_(op(pv))
+                v.copy_(checked(op(pv), dtype))
                 scalar(2, _be.coldot(r0, v).unsqueeze(0).contiguous(), 1)
             vector(1, s, r, v, partial=part[0])     # s = r - alpha v, |s|^2 (:200-203)
             scalar(3, part[0], nb)                  # early exit / matvec budget (:207-214)
-            t = op(s).contiguous()                  # t = A s (:221)
+            t = checked(op(s), dtype).contiguous()                  # t = A s (:221)
             vector(2, t, s, r0, partial=part, set_stride=nb * p)
             scalar(4, part, nb, nb * p)             # omega, rho_next (:223-224)
             vector(3, x, r, s, t, pv, partial=part[0])  # r, x updates, |r|^2 (:227-235)
@@ -220,4 +222,17 @@ def _bicgstab_fused(matmul_closure, rhs, initial_guess, settings: BICGSTABSettin
                     iteration()
             k += _POLL
             done = bool(flags[0].item())
+    _INFO.last = {"solver": "bicgstab", "iterations_enqueued": k, "finished": True}
     return x.squeeze(-1) if is_vector else x
+
+
+class _Info(threading.local):
+    last = None
+
+
+_INFO = _Info()
+
+
+def last_solve_info():
+    """Diagnostics of this thread's most recent fused ``bicgstab`` call."""
+    return _INFO.last

@@ -19,6 +19,7 @@ no-ops once it is set, so running ahead is harmless).
 
 from __future__ import annotations
 
+import threading
 import warnings
 from typing import Callable, NamedTuple, Optional, Union
 
@@ -26,7 +27,7 @@ import torch
 
 from .. import _backend as _be
 from . import _graph
-from ._operator import SparseOperator, as_operator
+from ._operator import SparseOperator, as_operator, checked
 
 _POLL = 8  # iterations enqueued between two reads of the device stop flag
 
@@ -71,11 +72,12 @@ def linear_cg(
     provided by this build and raises ``NotImplementedError``.
     """
     _be.require_device(rhs)
+    if rhs.ndimension() > 2:
+        return _batched_rhs(matmul_closure, rhs, n_tridiag, tolerance, eps, stop_updating_after, max_iter, max_tridiag_iter,
+                            initial_guess, preconditioner, settings)
     is_vector = rhs.ndimension() == 1
     if is_vector:
         rhs = rhs.unsqueeze(-1)
-    if rhs.ndimension() != 2:
-        raise NotImplementedError("linear_cg on gfx950 supports (n,) and (n, k) right-hand sides (no batch dims)")
 
     if max_iter is None:
         max_iter = settings.max_cg_iterations
@@ -109,10 +111,10 @@ def linear_cg(
 
     if x0 is None:
         result = torch.zeros_like(rhs)
-        residual = rhs - op(result)  # reference :266 (kept: it is also the NaN probe of :278)
+        residual = rhs - checked(op(result), rhs.dtype)  # reference :266 (kept: it is also the NaN probe of :278)
     else:
         result = x0.div(rhs_norm).expand_as(rhs).contiguous()
-        residual = rhs - op(result)
+        residual = rhs - checked(op(result), rhs.dtype)
     residual = residual.contiguous()
 
     if settings.verbose_linalg:
@@ -154,9 +156,62 @@ def linear_cg(
             UserWarning,
         )
 
+    _INFO.last = {"solver": "linear_cg", "iterations": int(k_done), "tolerance_reached": bool(tolerance_reached) or n_iter == 0,
+                  "residual_norm": residual_norm.detach().reshape(-1).clone(), "tolerance": float(tolerance)}
+    if settings.verbose_linalg:
+        print(f"CG finished after {k_done} iterations; mean normalised residual {float(residual_norm.mean()):.3e} "
+              f"(tolerance {tolerance}, reached={bool(tolerance_reached) or n_iter == 0}).")
+
     if is_vector:
         result = result.squeeze(-1)
     return result
+
+
+class _Info(threading.local):
+    last = None
+
+
+_INFO = _Info()
+
+
+def last_solve_info():
+    """Diagnostics of this thread's most recent ``linear_cg`` call: iterations executed, whether the tolerance
+    was reached and the final rhs-normalised residual norm per column (the device already holds them; the
+    reference only offers ``verbose_linalg`` printing, utils/linear_cg.py:273-275)."""
+    return _INFO.last
+
+
+def _batched_rhs(matmul_closure, rhs, n_tridiag, tolerance, eps, stop_updating_after, max_iter, max_tridiag_iter,
+                 initial_guess, preconditioner, settings):
+    """Right-hand sides with batch dimensions ``(*batch, n, k)`` (reference utils/linear_cg.py:257-263, :378: norms
+    and convergence are per (batch, column), the stop rule is their mean): the batch is folded into the columns,
+    ``(n, batch·k)``, and solved by the 2-D path.  A 2-D sparse operator applies to every column alike; any other
+    closure sees its own ``(*batch, n, k)`` layout through a reshaping wrapper."""
+    if n_tridiag:
+        raise NotImplementedError("Lanczos tridiagonalisation (n_tridiag > 0) is outside the gfx950 hot path")
+    batch_shape = tuple(rhs.shape[:-2])
+    n, k = rhs.shape[-2:]
+    nb = 1
+    for d in batch_shape:
+        nb *= d
+
+    def fold(t):      # (*batch, n, k) -> (n, batch*k)
+        return t.reshape(nb, n, k).permute(1, 0, 2).reshape(n, nb * k)
+
+    def unfold(t):    # (n, batch*k) -> (*batch, n, k)
+        return t.reshape(n, nb, k).permute(1, 0, 2).reshape(batch_shape + (n, k))
+
+    def wrap(fn):
+        return lambda v: fold(fn(unfold(v)))
+
+    if torch.is_tensor(matmul_closure) and matmul_closure.layout in (torch.sparse_csr, torch.sparse_coo):
+        op = matmul_closure
+    else:
+        op = wrap(as_operator(matmul_closure))
+    x0 = None if initial_guess is None else fold(initial_guess.expand(rhs.shape))
+    pre = None if preconditioner is None else wrap(preconditioner)
+    out = linear_cg(op, fold(rhs).contiguous(), 0, tolerance, eps, stop_updating_after, max_iter, max_tridiag_iter, x0, pre, settings)
+    return unfold(out)
 
 
 def _fused_loop(op, rhs_is_zero, x, r, has_converged, n_iter, max_iter, tolerance, eps, stop_after):
@@ -187,7 +242,7 @@ def _fused_loop(op, rhs_is_zero, x, r, has_converged, n_iter, max_iter, toleranc
             Ap, pap = op.matmul_with_dot(pvec)  # K1 + pᵀAp partials (reference :322, :64-65)
             n_partial = pap.shape[0]
         else:
-            Ap = op(pvec).contiguous()
+            Ap = checked(op(pvec), dtype).contiguous()
             pap = _be.coldot(pvec, Ap).unsqueeze(0)
             n_partial = 1
         s = stream()
@@ -241,7 +296,7 @@ def _pcg_loop(op, preconditioner, rhs_is_zero, x, r, has_converged, n_iter, max_
     k_done = 0
     eps_t = torch.tensor(eps, dtype=dtype, device=r.device)
     for k in range(n_iter):
-        Ap = op(pvec).contiguous()
+        Ap = checked(op(pvec), dtype).contiguous()
         pap = _be.coldot(pvec.contiguous(), Ap).unsqueeze(0)
         zero = pap < eps_t
         alpha = torch.where(zero, torch.zeros_like(pap), rz / torch.where(zero, torch.ones_like(pap), pap))

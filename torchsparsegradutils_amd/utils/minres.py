@@ -13,13 +13,14 @@ stopping test and the shifted-system output layout follow reference ``utils/minr
 
 from __future__ import annotations
 
+import threading
 from typing import Callable, NamedTuple, Optional, Union
 
 import torch
 
 from .. import _backend as _be
 from . import _graph
-from ._operator import SparseOperator, as_operator
+from ._operator import SparseOperator, as_operator, checked
 
 
 class MINRESSettings(NamedTuple):
@@ -190,7 +191,7 @@ def _minres_fused(op, rhs: torch.Tensor, shift: float, eps: float, max_iter: int
         if fused_dot:
             prod, pzz = op.matmul_with_dot(z[1])                # A z with <z, A z> partials (minres.py:261-262)
         else:
-            prod = op(z[1]).contiguous()
+            prod = checked(op(z[1]), dtype).contiguous()
             pzz = _be.coldot(prod, z[1]).unsqueeze(0).contiguous()
         scalar(0, pzz, pzz.shape[0])
         _be.check(lib.tsgu_minres_vector(vt, 0, n, p, z[0].data_ptr(), z[1].data_ptr(), prod.data_ptr(), None, None,
@@ -217,8 +218,11 @@ def _minres_fused(op, rhs: torch.Tensor, shift: float, eps: float, max_iter: int
         while i < total:
             if i % 10 == 0 and total - i >= 10:
                 if try_graph and graph is None and i >= 10 and total - i >= _graph.MIN_ITERS:
+                    roles = (z[:], w[:])
                     graph = _graph.capture(chunk10, 1)           # buffer roles return after an even number of steps
                     try_graph = graph is not None
+                    if graph is None:
+                        z[:], w[:] = roles                       # nothing executed: undo the recorded role swaps
                 if graph is not None:
                     _graph.replay(graph)
                 else:
@@ -231,4 +235,18 @@ def _minres_fused(op, rhs: torch.Tensor, shift: float, eps: float, max_iter: int
                 i += 1
                 if i % 10 == 0 and bool(flags[0].item()):
                     break
+    _INFO.last = {"solver": "minres", "iterations": i, "tolerance_reached": bool(flags[0].item()),
+                  "tolerance": float(settings.minres_tolerance)}
     return sol
+
+
+class _Info(threading.local):
+    last = None
+
+
+_INFO = _Info()
+
+
+def last_solve_info():
+    """Diagnostics of this thread's most recent fused ``minres`` call (iterations, stopping test outcome)."""
+    return _INFO.last
