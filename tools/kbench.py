@@ -39,7 +39,7 @@ def main():
     ap.add_argument("--reps", type=int, default=50)
     ap.add_argument("--only", default="")
     ap.add_argument("--check", action="store_true")
-    ap.add_argument("--brick", type=int, nargs=3, default=None, help="experiment: (z pairs, y, x) brick of the transposed rowpack plan")
+    ap.add_argument("--brick", type=int, nargs=3, action="append", default=None, help="experiment: extra (z pairs, y, x) brick shapes of the transposed rowpack plan")
     ap.add_argument("--fwd-brick", action="store_true", help="experiment: forward through an identity-permutation brick plan")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -79,13 +79,17 @@ def main():
         lat = _pattern.detect_lattice(pt) if b == 1 else None
         po = None
         if lat is not None:
-            po = _pattern.brick_pair_order(n, lat, rpb // 2, dev, shape=tuple(a.brick) if a.brick else None)
+            po = _pattern.brick_pair_order(n, lat, rpb // 2, dev)
         plans = {}
         for tag, dd in (("s", "off"), ("d", "force")):
             plans["rp_fwd_" + tag] = _pattern.build_rowpack_plan(plan, rpb, lim, explicit_slots=ep > 1, dedup=dd)
             plans["rp_t_nat_" + tag] = _pattern.build_rowpack_plan(pt, rpb, lim, dedup=dd)
             if po is not None:
                 plans["rp_t_brick_" + tag] = _pattern.build_rowpack_plan(pt, rpb, lim, pair_order=po, lattice=lat, dedup=dd)
+        for shp in (a.brick or []):
+            pox = _pattern.brick_pair_order(n, lat, rpb // 2, dev, shape=tuple(shp)) if lat is not None else None
+            if pox is not None:
+                plans["rp_t_brick%d.%d.%d_d" % tuple(shp)] = _pattern.build_rowpack_plan(pt, rpb, lim, pair_order=pox, lattice=lat, dedup="force")
         if a.fwd_brick and po is not None:
             ident = _pattern.RowGather(crow, col, n, n, perm=torch.arange(nnz, device=dev, dtype=torch.int32))
             plans["rp_fwdbrick_d"] = _pattern.build_rowpack_plan(ident, rpb, lim, pair_order=po, lattice=lat, dedup="force")

@@ -96,7 +96,7 @@ __global__ __launch_bounds__(kBlock) TSGU_RP_OCC void csr_rowpack_kernel(const R
     float* s_val = reinterpret_cast<float*>(s_ucol + (SLOTS ? 2 : 1) * (size_t)P.ucap);
 
     const int tid = threadIdx.x;
-    const int wave = tid / kWave;
+    const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);  // provably wave-uniform: no waterfall loop around the LDS-DMA
     const int grp = tid / GROUP;
     const int gl = tid % GROUP;
     const int cl = gl % CL;
