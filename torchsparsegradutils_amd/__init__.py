@@ -5,6 +5,7 @@ Drop-in names for ``sparse_mm`` / ``sparse_triangular_solve`` / ``sparse_generic
 kernels behind the C ABI in ``include/tsgu_hip.h``.  GPU only — there is no CPU fallback.
 """
 
+from .sparse_lstsq import SparseGenericLstsq, sparse_generic_lstsq
 from .sparse_matmul import SparseMatMul, sparse_mm
 from .sparse_solve import (
     SparseGenericSolve,
@@ -17,6 +18,8 @@ __all__ = [
     "sparse_mm",
     "sparse_triangular_solve",
     "sparse_generic_solve",
+    "sparse_generic_lstsq",
+    "SparseGenericLstsq",
     "SparseMatMul",
     "SparseTriangularSolve",
     "SparseGenericSolve",

@@ -2,6 +2,7 @@
 
 from .bicgstab import BICGSTABSettings, bicgstab
 from .linear_cg import LinearCGSettings, linear_cg
+from .lsmr import lsmr
 from .minres import MINRESSettings, minres
 from .utils import (
     convert_coo_to_csr,
@@ -19,6 +20,7 @@ __all__ = [
     "MINRESSettings",
     "bicgstab",
     "BICGSTABSettings",
+    "lsmr",
     "convert_coo_to_csr_indices_values",
     "convert_coo_to_csr",
     "sparse_block_diag",

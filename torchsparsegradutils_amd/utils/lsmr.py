@@ -1,0 +1,245 @@
+"""``lsmr`` — drop-in for reference ``torchsparsegradutils/utils/lsmr.py`` (LSMR of Fong & Saunders, SIAM J. Sci.
+Comput. 33(5), 2011: Golub–Kahan bidiagonalisation + two QR sweeps; the reference adapts scipy's implementation).
+
+Same signature and stopping rules (``atol`` / ``btol`` / ``conlim`` tests of the paper, §6; reference :339-383).  What
+differs is where the work happens: the two products per iteration, ``A·v`` and ``Aᵀ·u``, run on the K1 HIP kernel
+(``Aᵀ`` through the cached transposed pattern — the reference converts CSC→CSR inside ATen at every call), the vector
+recurrences are device tensor ops, and all right-hand sides advance in LOCK-STEP: the reference's default least-squares
+solver loops over the columns in Python (sparse_lstsq.py:124-147), here a column that has met its stopping test is
+frozen while the others continue.  The O(1)-per-column scalars (rotations, norm estimates) live on the host in
+float64; two small device→host reads per iteration (the norms β, α) replace the reference's two syncs
+(``beta > 0`` and ``if stop``, :272, :381).
+"""
+
+from __future__ import annotations
+
+from typing import Callable, Optional, Tuple, Union
+
+import numpy as np
+import torch
+
+from .. import _backend as _be
+from ._operator import SparseOperator
+
+
+def _rotation(a: np.ndarray, b: np.ndarray):
+    """Stable plane rotation (c, s, r) with r = hypot(a, b), elementwise; r == 0 gives c = s = 0."""
+    r = np.hypot(a, b)
+    safe = np.where(r > 0, r, 1.0)
+    return a / safe, b / safe, r
+
+
+def _transposed_operator(A: torch.Tensor):
+    """v -> Aᵀ v for a 2-D sparse tensor on the GPU, as a gather over the cached transposed pattern."""
+    from .. import _ops
+
+    op = SparseOperator(A)
+    plan_t = op.plan.transposed
+
+    def rmatvec(u):
+        u = op._cast(u)
+        if u.dim() == 1:
+            return _ops.spmm(plan_t, op.values, u.unsqueeze(-1)).squeeze(-1)
+        return _ops.spmm(plan_t, op.values, u)
+
+    return op, rmatvec
+
+
+def _as_pair(A, Armat, n):
+    """(matvec, rmatvec, n) from the reference's accepted argument forms (reference :150-165)."""
+    if torch.is_tensor(A):
+        if n is None:
+            n = A.shape[1]
+        if A.layout in (torch.sparse_csr, torch.sparse_coo) and A.dim() == 2:
+            op, rmat = _transposed_operator(A)
+            mat = op
+            if Armat is None:
+                Armat = rmat
+        else:
+            mat = A.matmul
+            if Armat is None:
+                Armat = torch.adjoint(A).matmul
+    elif callable(A):
+        mat = A
+    else:
+        raise RuntimeError("matmul_closure must be a tensor, or a callable object!")
+    if n is None:
+        raise RuntimeError("n needs to be provided or computed from A given as a tensor")
+    if torch.is_tensor(Armat):
+        if Armat.layout in (torch.sparse_csr, torch.sparse_coo) and Armat.dim() == 2:
+            Armat = SparseOperator(Armat)
+        else:
+            Armat = Armat.matmul
+    elif not callable(Armat):
+        raise RuntimeError("matmul_closure must be a tensor, or a callable object!")
+    return mat, Armat, int(n)
+
+
+def _colnorm_host(v: torch.Tensor) -> np.ndarray:
+    """‖v[:, j]‖₂ per column → float64 numpy (HIP two-stage reduction + one small device→host read)."""
+    return np.sqrt(np.maximum(_be.coldot(v, v).double().cpu().numpy(), 0.0))
+
+
+@torch.no_grad()
+def lsmr(
+    A: Union[torch.Tensor, Callable[[torch.Tensor], torch.Tensor]],
+    b: torch.Tensor,
+    Armat: Optional[Union[torch.Tensor, Callable[[torch.Tensor], torch.Tensor]]] = None,
+    n: Optional[int] = None,
+    damp: float = 0.0,
+    atol: float = 1e-6,
+    btol: float = 1e-6,
+    conlim: float = 1e8,
+    maxiter: Optional[int] = None,
+    x0: Optional[torch.Tensor] = None,
+    check_nonzero: bool = True,
+) -> Tuple[torch.Tensor, int]:
+    r"""Iterative least squares :math:`\min_x \|A x - b\|_2` (damped: :math:`\|(A; \text{damp}\,I)x - (b; 0)\|_2`).
+
+    ``A``: tensor (dense, or sparse COO/CSR → HIP SpMM for ``A·`` and ``Aᵀ·``) or callable ``v -> A v`` (then ``Armat``
+    and ``n`` are required, as in the reference).  ``b``: ``(m,)`` on the GPU; ``(m, k)`` is accepted as an extension —
+    the k systems are solved in lock-step, each with its own stopping point.  Returns ``(x, iterations)`` where
+    ``iterations`` is the largest iteration count over the right-hand sides.  ``check_nonzero`` is accepted for
+    signature parity (the β > 0 test costs nothing here: β is needed on the host anyway)."""
+    _be.require_device(b)
+    user_mat, user_rmat = callable(A) and not torch.is_tensor(A), callable(Armat) and not torch.is_tensor(Armat)
+    mat, rmat, n = _as_pair(A, Armat, n)
+    if torch.atleast_1d(b).dim() == 1:
+        # user closures see the 1-D vectors the reference hands them; the kernels work on (·, 1) columns
+        if user_mat:
+            mat = (lambda f: (lambda v: f(v[:, 0]).unsqueeze(1)))(mat)
+        if user_rmat:
+            rmat = (lambda f: (lambda v: f(v[:, 0]).unsqueeze(1)))(rmat)
+    if b.dtype not in (torch.float32, torch.float64):
+        raise RuntimeError(f"lsmr: unsupported dtype {b.dtype}")
+    b = torch.atleast_1d(b)
+    vector = b.dim() == 1 or (b.dim() == 2 and b.shape[1] == 1)  # the reference squeezes (m, 1) to a vector (:172-174)
+    B = b.reshape(b.shape[0], -1).contiguous()
+    m, k = B.shape
+    dt, dev = B.dtype, B.device
+    eps = float(torch.finfo(dt).eps)
+    ctol = 1.0 / conlim if conlim > 0 else 0.0
+    if maxiter is None:
+        maxiter = min(m, n)
+
+    def row(a: np.ndarray) -> torch.Tensor:  # per-column coefficients as a (1, k) device tensor
+        return torch.as_tensor(a, dtype=dt, device=dev).unsqueeze(0)
+
+    normb = _colnorm_host(B)
+    u = B.clone()
+    if x0 is None:
+        x = torch.zeros((n, k), dtype=dt, device=dev)
+        beta = normb.copy()
+    else:
+        x = torch.atleast_1d(x0).reshape(n, -1).to(dt).clone().contiguous()
+        u = (u - mat(x)).contiguous()
+        beta = _colnorm_host(u)
+    u = u / row(np.where(beta > 0, beta, 1.0))
+    v = rmat(u).contiguous()
+    alpha = np.where(beta > 0, _colnorm_host(v), 0.0)
+    v = torch.where(row(beta) > 0, v, torch.zeros_like(v)) / row(np.where(alpha > 0, alpha, 1.0))
+
+    # rotation state and recurrences (paper §3, notation of its Algorithm LSMR)
+    zetabar = alpha * beta
+    alphabar = alpha.copy()
+    rho = np.ones(k)
+    rhobar = np.ones(k)
+    cbar = np.ones(k)
+    sbar = np.zeros(k)
+    h = v.clone()
+    hbar = torch.zeros_like(v)
+    # ‖r‖ estimate (§5)
+    betadd = beta.copy()
+    betad = np.zeros(k)
+    rhodold = np.ones(k)
+    tautildeold = np.zeros(k)
+    thetatilde = np.zeros(k)
+    zeta = np.zeros(k)
+    d = np.zeros(k)
+    # ‖A‖, cond(A) estimates
+    norm_a2 = alpha ** 2
+    maxrbar = np.zeros(k)
+    minrbar = np.full(k, 0.99 * float(torch.finfo(dt).max))
+
+    # columns that are already solved: ‖Aᵀ r₀‖ = 0, or b = 0 (then x = 0) (reference :237-243)
+    done = (alpha * beta == 0) | (normb == 0)
+    if x0 is not None and bool((normb == 0).any()):
+        x[:, torch.as_tensor(normb == 0, device=dev)] = 0
+    its = np.zeros(k, dtype=np.int64)
+    normb_safe = np.where(normb > 0, normb, 1.0)
+
+    itn = 0
+    while itn < maxiter and not bool(done.all()):
+        itn += 1
+        live = ~done
+        # next bidiagonalisation step: β u = A v − α u ;  α v = Aᵀ u − β v
+        u = (mat(v) - u * row(alpha)).contiguous()
+        beta = _colnorm_host(u)
+        pos = beta > 0
+        u = u / row(np.where(pos, beta, 1.0))
+        v_new = (rmat(u) - v * row(beta)).contiguous()
+        alpha_new = _colnorm_host(v_new)
+        v_new = v_new / row(np.where(alpha_new > 0, alpha_new, 1.0))
+        keep = row(pos.astype(np.float64)) > 0
+        v = torch.where(keep, v_new, v)
+        alpha = np.where(pos, alpha_new, alpha)
+
+        # rotation for the damping term, then Q_k on the bidiagonal
+        chat, shat, alphahat = _rotation(alphabar, np.full(k, float(damp)))
+        rhoold = rho
+        c, s, rho = _rotation(alphahat, beta)
+        thetanew = s * alpha
+        alphabar = c * alpha
+        # Q̄_k on R_kᵀ
+        rhobarold, zetaold = rhobar, zeta
+        thetabar = sbar * rho
+        rhotemp = cbar * rho
+        cbar, sbar, rhobar = _rotation(cbar * rho, thetanew)
+        zeta = cbar * zetabar
+        zetabar = -sbar * zetabar
+
+        # h̄, x, h (finished columns keep their x)
+        den1 = rhoold * rhobarold
+        hbar = h - hbar * row(np.where(den1 != 0, thetabar * rho / np.where(den1 != 0, den1, 1.0), 0.0))
+        den2 = rho * rhobar
+        step = np.where(live & (den2 != 0), zeta / np.where(den2 != 0, den2, 1.0), 0.0)
+        x = x + hbar * row(step)
+        h = v - h * row(np.where(rho != 0, thetanew / np.where(rho != 0, rho, 1.0), 0.0))
+
+        # estimate of ‖r‖: rotations Q̂_{k,2k+1}, Q_{k,k+1}, Q̃_{k-1}
+        betaacute = chat * betadd
+        betacheck = -shat * betadd
+        betahat = c * betaacute
+        betadd = -s * betaacute
+        thetatildeold = thetatilde
+        ctildeold, stildeold, rhotildeold = _rotation(rhodold, thetabar)
+        thetatilde = stildeold * rhobar
+        rhodold = ctildeold * rhobar
+        betad = -stildeold * betad + ctildeold * betahat
+        tautildeold = (zetaold - thetatildeold * tautildeold) / np.where(rhotildeold != 0, rhotildeold, 1.0)
+        taud = (zeta - thetatilde * tautildeold) / np.where(rhodold != 0, rhodold, 1.0)
+        d = d + betacheck ** 2
+        normr = np.sqrt(d + (betad - taud) ** 2 + betadd ** 2)
+        # estimates of ‖A‖ and cond(A)
+        norm_a2 = norm_a2 + beta ** 2
+        norm_a = np.sqrt(norm_a2)
+        norm_a2 = norm_a2 + alpha ** 2
+        maxrbar = np.maximum(maxrbar, rhobarold)
+        if itn > 1:
+            minrbar = np.minimum(minrbar, rhobarold)
+
+        # stopping tests (paper §6; the first three guard against tolerances below machine precision)
+        normar = np.abs(zetabar)
+        normx = _colnorm_host(x)
+        cond_a = np.maximum(maxrbar, rhotemp) / np.minimum(minrbar, rhotemp)
+        test1 = normr / normb_safe
+        test2 = normar / (norm_a * normr + eps)
+        test3 = 1.0 / (cond_a + eps)
+        t1 = test1 / (1.0 + norm_a * normx / normb_safe)
+        rtol = btol + atol * norm_a * normx / normb_safe
+        stop = (1 + test3 <= 1) | (1 + test2 <= 1) | (1 + t1 <= 1) | (test3 <= ctol) | (test2 <= atol) | (test1 <= rtol)
+        its = np.where(live, itn, its)
+        done = done | stop
+
+    out = x[:, 0] if vector else x
+    return out, int(its.max()) if k else 0
