@@ -61,6 +61,11 @@ int tsgu_device_info(int device, char* name, int cap, int* n_cu, int* wave_size)
  * how Aᵀ·G (K2) runs on the cached transposed pattern without materialising Aᵀ's values:
  * replaces: torch.sparse.mm(A.t(), grad)     torchsparsegradutils/sparse_matmul.py:229
  *
+ * b_col_stride / c_col_stride: element (i, c) of B / C sits at i·ld + c·col_stride.  1 = row-major.  Other values
+ * serve the TRANSPOSED VIEWS the reference's sparse multivariate normal passes (`bvec.t()` / `permute`,
+ * distributions/sparse_multivariate_normal.py:96,100: ld = 1, col_stride = n) without a copy: the kernel then takes
+ * one column per grid.z slice with lanes along the rows.
+ *
  * dot_w / dot_partial (optional): when non-NULL the kernel also writes, per thread block,
  * partial[block][c] = sum_rows C[row,c] * W[row,c]  (fp32/fp64 accumulate), block-major,
  * ld = p.  W has leading dimension ldw.  `tsgu_spmm_num_blocks` gives the row count of
@@ -69,8 +74,8 @@ int tsgu_device_info(int device, char* name, int cap, int* n_cu, int* wave_size)
 int tsgu_csr_spmm(int vtype, int itype,
                   int64_t n_rows, int64_t n_cols, int64_t nnz_per_item,
                   const void* crow, const void* col, const void* val, const void* perm,
-                  const void* B, int64_t ldb, int64_t b_batch_stride,
-                  void* C, int64_t ldc, int64_t c_batch_stride,
+                  const void* B, int64_t ldb, int64_t b_col_stride, int64_t b_batch_stride,
+                  void* C, int64_t ldc, int64_t c_col_stride, int64_t c_batch_stride,
                   int64_t p, int64_t batch,
                   const void* dot_w, int64_t ldw, void* dot_partial,
                   int device, void* stream);
@@ -213,14 +218,15 @@ int tsgu_csr_sddmm_rowpack(int vtype, int itype, int64_t n_rows, int64_t n_cols,
  * transpose != 0 → the caller passes the cached transposed pattern of A (CSC arrays of A viewed
  * as CSR of Aᵀ) with `perm` mapping into A's values, and `lower` already flipped.
  * Entries on the wrong side of the diagonal are ignored; with unit != 0 stored diagonal entries
- * are ignored too (same as the reference's backend).  X must NOT alias B.
+ * are ignored too (same as the reference's backend).  X must NOT alias B.  B(i, c) = B[i·ldb + c·b_col_stride]
+ * (b_col_stride = 1: row-major; transposed views are read in place), X is row-major.
  * `work` : device scratch, tsgu_sptrsm_work_bytes() bytes, contents irrelevant on entry.
  */
 int tsgu_csr_sptrsm(int vtype, int itype,
                     int64_t n, int64_t nnz,
                     const void* ptr, const void* idx, const void* perm, const void* val,
                     int lower, int unit,
-                    const void* B, int64_t ldb, void* X, int64_t ldx, int64_t p,
+                    const void* B, int64_t ldb, int64_t b_col_stride, void* X, int64_t ldx, int64_t p,
                     void* work, int device, void* stream);
 int64_t tsgu_sptrsm_work_bytes(int64_t n, int64_t p);
 

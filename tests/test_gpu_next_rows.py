@@ -119,3 +119,128 @@ def test_lsmr_iterations_damping_closures_and_wide_backward_error():
     xw = sparse_generic_lstsq(Aw, torch.randn(10, dtype=torch.float64, device=DEV))
     with pytest.raises(ValueError, match="tall full-rank"):
         xw.sum().backward()
+
+
+# --------------------------------------------------------------------------- f-4: PairwiseEncoder
+_ENC = {"full": dict(diag=True, upper=None, channel_voxel_relation="inter"),
+        "low": dict(diag=False, upper=False, channel_voxel_relation="intra")}
+_SHAPE, _RADIUS = (2, 5, 4, 6), 1.5
+
+
+@pytest.mark.parametrize("tag", ["full", "low"])
+@pytest.mark.parametrize("lay", ["csr", "coo"])
+@pytest.mark.parametrize("iname", ["i32", "i64"])
+def test_pairwise_encoder_output_and_gradients_through_sparse_mm(tag, lay, iname):
+    """The encoder on the GPU: indices bit-exact with the reference (CSR: crow/col/permutation; COO: coalesced
+    indices), values exact, then `sparse_mm` on its output with the gradient flowing back to the encoder's INPUT
+    volumes (reference README.md:610-626: the CSR + encoder backward that blows up memory there is one fused SDDMM +
+    one index_add here)."""
+    from torchsparsegradutils_amd import sparse_mm
+    from torchsparsegradutils_amd.encoders import PairwiseEncoder
+
+    z = G.load("encoder_mvn.npz")
+    key = f"{tag}_{lay}_{iname}_"
+    idt = torch.int32 if iname == "i32" else torch.int64
+    enc = PairwiseEncoder(_RADIUS, _SHAPE, layout=torch.sparse_csr if lay == "csr" else torch.sparse_coo,
+                          indices_dtype=idt, device=DEV, **_ENC[tag])
+    if tag == "full":
+        assert np.array_equal(np.array(enc.offsets), z["full_offsets"])
+    assert enc.device.type == "cuda"
+    vals = G.t(z[key + "in"], DEV).requires_grad_(True)
+    A = enc(vals)
+    if lay == "csr":
+        assert A.layout == torch.sparse_csr and A.crow_indices().dtype == idt
+        assert np.array_equal(A.crow_indices().cpu().numpy(), z[key + "crow"])
+        assert np.array_equal(A.col_indices().cpu().numpy(), z[key + "col"])
+        assert np.array_equal(enc.csr_permutation.cpu().numpy(), z[key + "perm"])
+        assert np.array_equal(A.values().detach().cpu().numpy(), z[key + "val"])
+    else:
+        assert A.layout == torch.sparse_coo and A.is_coalesced()   # torch stores COO indices as int64 whatever was asked
+        assert np.array_equal(A.indices().cpu().numpy(), z[key + "idx"])
+        assert np.array_equal(A.values().detach().cpu().numpy(), z[key + "val"])
+    B = G.t(z[key + "B"], DEV)
+    C = sparse_mm(A, B)
+    C.backward(G.t(z[key + "G"], DEV))
+    assert rel(C, z[key + "C"]) < 1e-11
+    assert rel(vals.grad, z[key + "grad_in"]) < 1e-11
+    if lay == "csr" and iname == "i32":
+        vb = G.t(z[tag + "_batched_in"], DEV)
+        Ab = enc(vb)
+        assert Ab.shape == (3, 240, 240) and np.array_equal(Ab.crow_indices().cpu().numpy(), z[tag + "_batched_crow"])
+        assert np.array_equal(Ab.values().cpu().numpy(), z[tag + "_batched_val"])
+    # CPU construction + .to(device) moves the cached index tensors (reference `_apply`, :714-722)
+    enc2 = PairwiseEncoder(_RADIUS, _SHAPE, layout=torch.sparse_csr, indices_dtype=idt, **_ENC[tag]).to(DEV)
+    assert enc2.device.type == "cuda" and torch.equal(enc2(vals.detach()).values(), enc(vals.detach()).to_sparse_csr().values()
+                                                       if lay == "coo" else A.values().detach())
+    with pytest.raises(ValueError, match="must match number of offsets"):
+        enc(vals.detach()[1:])
+    with pytest.raises(ValueError, match="Spatial dimensions do not match"):
+        enc(vals.detach()[..., :-1])
+
+
+# --------------------------------------------------------------------------- f-1: the multivariate normal's call pattern
+def _mvn_inputs(z, vn):
+    from torchsparsegradutils_amd.encoders import PairwiseEncoder
+
+    dt = torch.float32 if vn == "f32" else torch.float64
+    enc = PairwiseEncoder(_RADIUS, _SHAPE, diag=False, upper=False, channel_voxel_relation="intra", layout=torch.sparse_csr,
+                          device=DEV)
+    Ls = enc(G.t(z[vn + "_w"], DEV))
+    Lfull = torch.sparse_csr_tensor(G.t(z[vn + "_Lfull_crow"], DEV), G.t(z[vn + "_Lfull_col"], DEV), G.t(z[vn + "_Lfull_val"], DEV),
+                                    (240, 240))
+    return dt, enc, Ls, Lfull, G.t(z[vn + "_diag"], DEV), G.t(z[vn + "_loc"], DEV), G.t(z[vn + "_eps"], DEV)
+
+
+@pytest.mark.parametrize("vn", ["f32", "f64"])
+def test_sparse_multivariate_normal_rsample_all_parameterisations(vn):
+    """`SparseMultivariateNormal.rsample` (reference :354-389) for fixed noise: covariance / precision factor x LLᵀ /
+    LDLᵀ, 7 samples — i.e. `sparse_mm` and `sparse_triangular_solve(upper=False, transpose=True[, unitriangular=True])`
+    fed with TRANSPOSED VIEWS of the noise; plus the batched precision-LDLᵀ form (permuted 3-D views)."""
+    from torchsparsegradutils_amd.distributions import SparseMultivariateNormal
+
+    z = G.load("encoder_mvn.npz")
+    dt, enc, Ls, Lfull, diag, loc, eps = _mvn_inputs(z, vn)
+    tol = 1e-5 if dt == torch.float32 else 1e-12
+    for name, kw in (("scale_ldlt", dict(diagonal=diag, scale_tril=Ls)), ("scale_llt", dict(scale_tril=Lfull)),
+                     ("prec_ldlt", dict(diagonal=diag, precision_tril=Ls)), ("prec_llt", dict(precision_tril=Lfull))):
+        dist = SparseMultivariateNormal(loc, **kw)
+        x = dist._transform(eps)
+        assert x.shape == (7, 240) and rel(x, z[f"{vn}_{name}_x"]) < tol, (name, rel(x, z[f"{vn}_{name}_x"]))
+        assert dist.rsample((3,)).shape == (3, 240) and dist.rsample().shape == (240,)
+    Lb = enc(G.t(z[vn + "_wb"], DEV))
+    distb = SparseMultivariateNormal(G.t(z[vn + "_locb"], DEV), diagonal=G.t(z[vn + "_diagb"], DEV), precision_tril=Lb)
+    xb = distb._transform(G.t(z[vn + "_epsb"], DEV))
+    assert xb.shape == (5, 2, 240) and rel(xb, z[vn + "_prec_ldlt_batched_x"]) < tol
+    # gradients reach the factor's values and the encoder input through the transposed-view path
+    w = G.t(z[vn + "_w"], DEV).requires_grad_(True)
+    d2 = SparseMultivariateNormal(loc, diagonal=diag, precision_tril=enc(w))
+    d2._transform(eps).square().sum().backward()
+    assert w.grad is not None and bool(torch.isfinite(w.grad).all()) and float(w.grad.abs().max()) > 0
+
+
+def test_rsample_sequence_makes_no_device_copies_of_the_noise():
+    """SURVEY f-1: `sparse_triangular_solve(L, eps.t(), upper=False, unitriangular=True, transpose=True)` and
+    `sparse_mm(L, eta.t())` consume the transposed views in place — the peak allocation of the sequence is the
+    result (plus K4's small work area), not result + a row-major copy of the operand."""
+    from torchsparsegradutils_amd import _backend as be, sparse_mm, sparse_triangular_solve
+    from torchsparsegradutils_amd.utils import synthetic
+
+    n, k = 65536, 16
+    crow, col, val = synthetic.banded_lower(n, per_row=6, band=64, device=DEV)
+    L = torch.sparse_csr_tensor(crow, col, val, (n, n))
+    eps = torch.randn(k, n, device=DEV)
+    view = eps.t()
+    assert be.is_transposed_view(view)
+    for op, kw in ((sparse_triangular_solve, dict(upper=False, unitriangular=False, transpose=True)), (sparse_mm, {})):
+        op(L, view, **kw)                                # warm-up: cached transposed pattern, library load
+        want = op(L, view.contiguous(), **kw)
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats()
+        base = torch.cuda.memory_allocated()
+        out = op(L, view, **kw)
+        torch.cuda.synchronize()
+        extra = torch.cuda.max_memory_allocated() - base
+        result_bytes = n * k * 4
+        assert extra < 1.25 * result_bytes, (op.__name__, extra, result_bytes)   # a copy of the operand would double it
+        assert out.shape == (n, k) and rel(out, want.cpu().numpy()) < 1e-6
+    be.poll_errors(block=True)

@@ -80,7 +80,7 @@ def mm_backward(plan: RowGather, values: torch.Tensor, G: torch.Tensor, B: torch
 
 def spmm(plan: RowGather, values: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
     """A·B for the operand described by (plan, values); perm-aware (transposed / un-coalesced plans)."""
-    if values.dtype == B.dtype:
+    if values.dtype == B.dtype and not _be.is_transposed_view(B):  # transposed views: zero-copy column-strided K1
         if plan.batch is not None and ENABLE_PACK:
             fl = _flat(plan, B)
             if fl is not None:

@@ -61,17 +61,19 @@ int64_t tsgu_spmm_num_blocks(int vtype, int64_t n_rows, int64_t nnz_per_item, in
 
 int tsgu_csr_spmm(int vtype, int itype, int64_t n_rows, int64_t n_cols, int64_t nnz_per_item,
                   const void* crow, const void* col, const void* val, const void* perm,
-                  const void* B, int64_t ldb, int64_t b_batch_stride,
-                  void* C, int64_t ldc, int64_t c_batch_stride,
+                  const void* B, int64_t ldb, int64_t b_col_stride, int64_t b_batch_stride,
+                  void* C, int64_t ldc, int64_t c_col_stride, int64_t c_batch_stride,
                   int64_t p, int64_t batch,
                   const void* dot_w, int64_t ldw, void* dot_partial,
                   int device, void* stream) {
     if (n_rows < 0 || n_cols < 0 || nnz_per_item < 0 || p < 0 || batch < 0) return TSGU_ERR_BAD_ARG;
     if (n_rows == 0 || p == 0 || batch == 0) return TSGU_OK;
     if (!crow || !C || (nnz_per_item > 0 && (!col || !val || !B))) return TSGU_ERR_BAD_ARG;
-    if (ldb < p || ldc < p) return TSGU_ERR_BAD_ARG;
+    if (b_col_stride < 1 || c_col_stride < 1) return TSGU_ERR_BAD_ARG;
+    if ((b_col_stride == 1 && ldb < p) || (c_col_stride == 1 && ldc < p) || ldb < 1 || ldc < 1) return TSGU_ERR_BAD_ARG;
     if (n_cols > 0x7fffffffLL) return TSGU_ERR_TOO_LARGE;
     if ((dot_partial != nullptr) != (dot_w != nullptr)) return TSGU_ERR_BAD_ARG;
+    if (dot_partial && (b_col_stride != 1 || c_col_stride != 1)) return TSGU_ERR_BAD_ARG;
     if (dot_partial && (ldw < p || vtype == TSGU_BF16)) return TSGU_ERR_BAD_ARG;
     if (const int rc = set_device(device)) return rc;
     SpmmParams P{};
@@ -85,6 +87,8 @@ int tsgu_csr_spmm(int vtype, int itype, int64_t n_rows, int64_t n_cols, int64_t 
     P.B = B;
     P.ldb = ldb;
     P.b_bs = b_batch_stride;
+    P.b_cs = b_col_stride;
+    P.c_cs = c_col_stride;
     P.C = C;
     P.ldc = ldc;
     P.c_bs = c_batch_stride;

@@ -26,6 +26,7 @@ struct SpmmParams {
     const void* perm;
     const void* B;
     int64_t ldb, b_bs;
+    int64_t b_cs, c_cs;  // column strides (elements) of B and C: 1 = row-major; != 1 (transposed views) => one column per grid.z slice
     void* C;
     int64_t ldc, c_bs;
     const void* W;
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(kBlock) void csr_spmm_kernel(const SpmmParams P) {
     const I* __restrict__ col = static_cast<const I*>(P.col) + item * P.nnz_per_item;
     const V* __restrict__ val = static_cast<const V*>(P.val) + item * P.nnz_per_item;
     const I* __restrict__ perm = static_cast<const I*>(P.perm);
-    const V* __restrict__ B = static_cast<const V*>(P.B) + item * P.b_bs + cbase;
+    const V* __restrict__ B = static_cast<const V*>(P.B) + item * P.b_bs + cbase * P.b_cs;
     const uint32_t ldb = (uint32_t)P.ldb;
 
     // A workgroup owns RPB·rmul consecutive rows (rmul > 1 for short rows, so that the dependent
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(kBlock) void csr_spmm_kernel(const SpmmParams P) {
             for (int v = 0; v < VEC; ++v) acc[v] = ep_sum<Acc, CL, EP>(acc[v]);
         }
         if (row_ok && col_ok && ep == 0) {
-            V* __restrict__ C = static_cast<V*>(P.C) + item * P.c_bs + row * P.ldc + cbase;
+            V* __restrict__ C = static_cast<V*>(P.C) + item * P.c_bs + row * P.ldc + cbase * P.c_cs;
             store_vec<V, VEC, true>(C, acc);
             if constexpr (DOT) {
                 Acc w[VEC];
@@ -297,6 +298,15 @@ inline RowGeom spmm_geom(const SpmmParams& P, int64_t batch) {
     if (batch > 1) can = can && (P.b_bs % wide == 0) && (P.c_bs % wide == 0);
     if (P.W) can = can && (P.ldw % wide == 0) && aligned16(P.W);
     RowGeom g = pick_geom(wide, can, P.p);
+    if (P.b_cs != 1 || P.c_cs != 1) {
+        // column-strided operands (e.g. the .t() views the sparse multivariate normal passes): one column per grid.z
+        // slice and lanes along ROWS — with unit row stride consecutive lanes then touch consecutive addresses
+        g.vec = 1;
+        g.cl = 1;
+        g.ep = (P.n_rows > 0 && P.nnz_per_item <= 16 * P.n_rows) ? 1 : 8;
+        g.col_tiles = P.p;
+        return g;
+    }
     prefer_row_per_lane(g, P.n_rows, P.nnz_per_item);
     return g;
 }

@@ -32,7 +32,7 @@ struct TrsmParams {
     const void* perm;
     const void* val;
     const void* B;
-    int64_t ldb;
+    int64_t ldb, bcs;  // row / column stride of B (elements)
     void* X;
     int64_t ldx;
     TrsmWork* work;
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(kBlock) void sptrsm_syncfree_kernel(const TrsmParam
             diag += shfl_xor_acc(diag, m);
         }
         if (ep == 0 && col_ok) {
-            const V rhs = B[row * P.ldb + c];
+            const V rhs = B[row * P.ldb + c * P.bcs];
             V x = rhs - acc;
             if (!P.unit) x = x / diag;
             Bits xb = S::bits(x);
@@ -228,15 +228,20 @@ int64_t tsgu_sptrsm_work_bytes(int64_t, int64_t) { return (int64_t)sizeof(TrsmWo
 int tsgu_csr_sptrsm(int vtype, int itype, int64_t n, int64_t nnz,
                     const void* ptr, const void* idx, const void* perm, const void* val,
                     int lower, int unit,
-                    const void* B, int64_t ldb, void* X, int64_t ldx, int64_t p,
+                    const void* B, int64_t ldb, int64_t b_col_stride, void* X, int64_t ldx, int64_t p,
                     void* work, int device, void* stream) {
     if (n < 0 || nnz < 0 || p < 0) return TSGU_ERR_BAD_ARG;
     if (n == 0 || p == 0) return TSGU_OK;
     if (!ptr || !B || !X || !work || (nnz > 0 && (!idx || !val))) return TSGU_ERR_BAD_ARG;
-    if (ldb < p || ldx < p || B == X) return TSGU_ERR_BAD_ARG;
+    if (b_col_stride < 1 || ldb < 1 || (b_col_stride == 1 && ldb < p) || ldx < p || B == X) return TSGU_ERR_BAD_ARG;
     if (const int rc = set_device(device)) return rc;
-    int n_cu = 0;
-    if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) return TSGU_ERR_RUNTIME;
+    // compute-unit count per device ordinal: queried once (hipDeviceGetAttribute costs microseconds on every solve)
+    static int cu_cache[64] = {0};
+    int n_cu = device < 64 ? cu_cache[device] : 0;
+    if (n_cu == 0) {
+        if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) return TSGU_ERR_RUNTIME;
+        if (device < 64) cu_cache[device] = n_cu;
+    }
     TrsmParams P{};
     P.n = n;
     P.p = p;
@@ -246,6 +251,7 @@ int tsgu_csr_sptrsm(int vtype, int itype, int64_t n, int64_t nnz,
     P.val = val;
     P.B = B;
     P.ldb = ldb;
+    P.bcs = b_col_stride;
     P.X = X;
     P.ldx = ldx;
     P.work = static_cast<TrsmWork*>(work);

@@ -1,0 +1,200 @@
+"""``PairwiseEncoder`` — drop-in for reference ``torchsparsegradutils/encoders/pairwise_encoder.py``:
+turns per-offset value volumes ``[(B), N, C, *S]`` into the sparse neighbourhood (stencil) matrix ``[(B), V, V]``,
+``V = C·prod(S)``, whose entry ``(v, v − o)`` carries ``values[n(o), v]`` for every offset ``o`` inside the radius —
+the matrices `sparse_mm` / the sparse multivariate normal consume.
+
+Same constructor, attributes (``offsets`` in the reference's order, ``indices`` / ``crow_indices`` / ``col_indices`` /
+``csr_permutation``), validation messages and outputs (bit-exact indices).  What differs is the work per call:
+
+* the reference loops over the offsets in Python, trims and flattens each value volume, concatenates them and — for
+  CSR — applies a permutation (``:731-749``, ``:832``); COO outputs are re-sorted by ``coalesce()`` on every call
+  (``:821-823``).  Here the whole chain is composed ONCE at construction into a single gather index into the flattened
+  input, so a call is one ``index_select`` (and its backward one ``index_add``), in CSR order for both layouts — the
+  COO output is built already coalesced, no per-call sort;
+* index construction is one vectorised validity mask over (offset, voxel) instead of 2·N trimmed views.
+"""
+
+from __future__ import annotations
+
+from functools import reduce
+from operator import mul
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+
+def _ball_offsets(radius: float, spatial_dims: int) -> List[Tuple[int, ...]]:
+    """Non-zero integer vectors of the closed N-ball of the given radius."""
+    r = int(np.floor(radius))
+    axes = [np.arange(-r, r + 1)] * spatial_dims
+    grid = np.stack(np.meshgrid(*axes, indexing="ij"), axis=-1).reshape(-1, spatial_dims)
+    keep = ((grid ** 2).sum(1) <= radius ** 2) & (np.abs(grid).sum(1) > 0)
+    return [tuple(int(c) for c in row) for row in grid[keep]]
+
+
+def gen_offsets_nd(radius: float, spatial_dims: int, upper: Optional[bool] = None, num_channels: int = 1,
+                   channel_voxel_relation: str = "indep") -> List[Tuple[int, ...]]:
+    """Ordered (channel, *spatial) offsets, same set and same order as the reference's ``_gen_offsets_nd``
+    (:198-321): spatial offsets in the ball; with ``'intra'`` the pure channel offsets, with ``'inter'`` also every
+    channel × spatial combination; ``upper`` keeps the offsets whose first non-zero entry is negative (True) /
+    positive (False); sorted by squared length with the channel step weighted 10, then by absolute values, then
+    negative before positive."""
+    ball = _ball_offsets(radius, spatial_dims)
+    offs = [(0,) + s for s in ball]
+    zero = (0,) * spatial_dims
+    if channel_voxel_relation != "indep":
+        offs += [(c,) + zero for c in range(1, num_channels)]
+    if channel_voxel_relation == "inter":
+        offs += [(c,) + s for c in range(1, num_channels) for s in ball]
+
+    def lead(o):
+        return next((c for c in o if c != 0), 0)
+
+    if upper is False:
+        offs = [o for o in offs if lead(o) > 0]
+    elif upper is True:
+        offs = [o for o in offs if lead(o) < 0]
+    return sorted(offs, key=lambda o: ((10 * o[0]) ** 2 + sum(c * c for c in o[1:]), tuple(abs(c) for c in o),
+                                       tuple(c >= 0 for c in o)))
+
+
+def _check_volume(radius, volume_shape, channel_voxel_relation):
+    if radius < 1:
+        raise ValueError("radius must be >= 1")
+    if not (len(volume_shape) >= 2 and all(isinstance(dim, int) and dim > 0 for dim in volume_shape)):
+        raise ValueError("volume_shape must be a tuple of at least 2 positive integers")
+    if channel_voxel_relation not in ["indep", "intra", "inter"]:
+        raise ValueError("channel_voxel_relation must be 'indep', 'intra', or 'inter'")
+    if volume_shape[0] == 1 and channel_voxel_relation != "indep":
+        raise ValueError("channel_voxel_relation must be 'indep' when number of channels is 1")
+
+
+def _pair_table(offsets, volume_shape, dtype, device):
+    """For all offsets at once: (offset number, row voxel, column voxel) of every in-bounds pair, offset-major and
+    row-major inside an offset — the order in which the reference concatenates its per-offset index blocks."""
+    vol = reduce(mul, volume_shape)
+    coords = torch.unravel_index(torch.arange(vol, device=device), volume_shape)          # per-dimension coordinates
+    off = torch.tensor(offsets, dtype=torch.int64, device=device).reshape(len(offsets), len(volume_shape))
+    strides = torch.tensor([reduce(mul, volume_shape[d + 1:], 1) for d in range(len(volume_shape))], device=device)
+    valid = torch.ones((len(offsets), vol), dtype=torch.bool, device=device)
+    for d, size in enumerate(volume_shape):
+        tgt = coords[d].unsqueeze(0) - off[:, d:d + 1]                                   # column coordinate = row − o
+        valid &= (tgt >= 0) & (tgt < size)
+    which, row = torch.nonzero(valid, as_tuple=True)
+    col = row - (off * strides).sum(1)[which]
+    return which, row.to(dtype), col.to(dtype), vol
+
+
+def calc_pairwise_coo_indices_nd(radius: float, volume_shape: Tuple[int, ...], diag: bool = False,
+                                 upper: Optional[bool] = None, channel_voxel_relation: str = "indep",
+                                 dtype: torch.dtype = torch.int64, device=torch.device("cpu")) -> Dict[Tuple[int, ...], torch.Tensor]:
+    """Per-offset ``(2, M)`` linear index pairs ``[[row...], [row − offset...]]`` (reference :383-505), the diagonal
+    key first when ``diag``."""
+    _check_volume(radius, volume_shape, channel_voxel_relation)
+    device = torch.device(device) if device is not None else None
+    offsets = gen_offsets_nd(radius, len(volume_shape) - 1, upper, volume_shape[0], channel_voxel_relation)
+    if diag:
+        offsets = [(0,) * len(volume_shape)] + offsets
+    which, row, col, _ = _pair_table(offsets, volume_shape, dtype, device)
+    counts = torch.bincount(which, minlength=len(offsets)).tolist()
+    out, start = {}, 0
+    for o, c in zip(offsets, counts):
+        out[o] = torch.stack((row[start:start + c], col[start:start + c]))
+        start += c
+    return out
+
+
+class PairwiseEncoder(torch.nn.Module):
+    """Encode per-offset value volumes as a sparse COO / CSR neighbourhood matrix (mirrors reference :562-849)."""
+
+    def __init__(self, radius: float, volume_shape: Tuple[int, ...], diag: bool = False, upper: Optional[bool] = None,
+                 channel_voxel_relation: str = "indep", layout=torch.sparse_coo, indices_dtype: torch.dtype = torch.int64,
+                 device=torch.device("cpu")):
+        super().__init__()
+        if not ((len(volume_shape) >= 2) and all(isinstance(dim, int) and dim > 0 for dim in volume_shape)):
+            raise ValueError(
+                "`volume_shape` must be a tuple of at least 2 positive integers, representing [C, *spatial_dims]"
+            )
+        if indices_dtype not in [torch.int64, torch.int32]:
+            raise ValueError("`indices_dtype` must be torch.int64 or torch.int32 for torch.sparse_coo")
+        if layout not in (torch.sparse_coo, torch.sparse_csr):
+            raise ValueError("layout must be either torch.sparse_coo or torch.sparse_csr")
+        _check_volume(radius, volume_shape, channel_voxel_relation)
+        self.radius, self.volume_shape, self.diag, self.upper = radius, volume_shape, diag, upper
+        self.channel_voxel_relation, self.layout, self.indices_dtype = channel_voxel_relation, layout, indices_dtype
+        self.volume_numel = reduce(mul, volume_shape)
+        self.spatial_dims = len(volume_shape) - 1
+
+        offsets = gen_offsets_nd(radius, self.spatial_dims, upper, volume_shape[0], channel_voxel_relation)
+        self.offsets = ([(0,) * len(volume_shape)] if diag else []) + offsets
+        device = torch.device(device) if device is not None else torch.device("cpu")
+        which, row, col, vol = _pair_table(self.offsets, volume_shape, indices_dtype, device)
+        # position of each pair's value inside one flattened (N, C, *S) input
+        take = which * vol + row.to(torch.int64)
+        # CSR order = (row, column) ascending: ONE stable sort at construction (columns of a row are distinct)
+        key = row.to(torch.int64) * vol + col.to(torch.int64)
+        perm = torch.argsort(key, stable=True)
+        self._gather = take[perm].contiguous()           # input position of every stored entry, in CSR order
+        counts = torch.bincount(row.to(torch.int64), minlength=vol)
+        crow = torch.zeros(vol + 1, dtype=torch.int64, device=device)
+        crow[1:] = torch.cumsum(counts, 0)
+        self._rows_sorted = row[perm].contiguous()
+        self._cols_sorted = col[perm].contiguous()
+        if layout == torch.sparse_coo:
+            self.indices = torch.stack((row, col))       # the reference's attribute: offset-major, un-coalesced
+            self.csr_permutation = None
+        else:
+            self.crow_indices = crow.to(indices_dtype)
+            self.col_indices = self._cols_sorted
+            self.csr_permutation = perm
+
+    def _apply(self, fn, recurse=True):
+        # index tensors are plain attributes (not buffers), as in the reference: move them with .to() / .cuda()
+        for attr in ["indices", "csr_permutation", "crow_indices", "col_indices", "_gather", "_rows_sorted", "_cols_sorted"]:
+            tensor = getattr(self, attr, None)
+            if tensor is not None:
+                setattr(self, attr, fn(tensor))
+        return self
+
+    @property
+    def device(self):
+        return self._gather.device
+
+    def __call__(self, values: torch.Tensor) -> torch.Tensor:
+        full = self.spatial_dims + 2  # (N, C, *spatial)
+        if len(values.shape) < full or len(values.shape) > full + 1:
+            raise ValueError(
+                f"values must have {full} dimensions (N, C, *spatial_dims) "
+                f"or {full + 1} dimensions (B, N, C, *spatial_dims)"
+            )
+        got, want = values.shape[-self.spatial_dims:], self.volume_shape[-self.spatial_dims:]
+        if tuple(got) != tuple(want):
+            raise ValueError(f"Spatial dimensions do not match: expected {want}, " f"got {got}")
+        if values.shape[-full] != len(self.offsets):
+            raise ValueError(
+                f"Shape of values at index {-full} ({values.shape[-full]}) "
+                f"must match number of offsets ({len(self.offsets)})"
+            )
+        if values.dtype not in [torch.float32, torch.float64]:
+            raise ValueError("values must be either torch.float32 or torch.float64 for sparse tensors")
+
+        batched = len(values.shape) == full + 1
+        vol = self.volume_numel
+        flat = values.reshape((values.shape[0], -1) if batched else (-1,))
+        vals = flat.index_select(-1, self._gather)       # the whole trim / concatenate / permute chain in one gather
+        if self.layout == torch.sparse_csr:
+            if batched:
+                b = values.shape[0]
+                return torch.sparse_csr_tensor(self.crow_indices.repeat(b, 1), self.col_indices.repeat(b, 1), vals,
+                                               size=(b, vol, vol), dtype=vals.dtype, device=vals.device)
+            return torch.sparse_csr_tensor(self.crow_indices, self.col_indices, vals, size=(vol, vol),
+                                           dtype=vals.dtype, device=vals.device)
+        # COO, built already coalesced: (row, column) ascending is what the reference's coalesce() produces
+        idx2 = torch.stack((self._rows_sorted, self._cols_sorted))
+        if batched:
+            b, nnz = values.shape[0], idx2.shape[1]
+            bidx = torch.arange(b, dtype=idx2.dtype, device=idx2.device).repeat_interleave(nnz).unsqueeze(0)
+            idx = torch.cat((bidx, idx2.repeat(1, b)))
+            return torch.sparse_coo_tensor(idx, vals.reshape(-1), size=(b, vol, vol), is_coalesced=True)
+        return torch.sparse_coo_tensor(idx2, vals, size=(vol, vol), is_coalesced=True)
