@@ -58,7 +58,10 @@ struct RpParams {
 typedef __attribute__((address_space(3))) void* rp_lds_ptr;
 typedef const __attribute__((address_space(1))) void* rp_glb_ptr;
 
-constexpr int kRpMaxQ = 8;    // staged values per workgroup <= 8 * 256
+#ifndef TSGU_RP_MINGROUP
+#define TSGU_RP_MINGROUP 8    // smallest lane group (column lanes x entry lanes) that owns a row pair
+#endif
+constexpr int kRpMaxQ = 8 * (8 / TSGU_RP_MINGROUP);    // staged values per workgroup <= kRpMaxQ * 256
 constexpr int kRpMaxU = 12;   // union records per workgroup <= 12 * 256
 constexpr int kRpAbsent = 0x8000;
 
@@ -83,7 +86,8 @@ __global__ __launch_bounds__(kBlock) TSGU_RP_OCC void csr_rowpack_kernel(const R
     constexpr int GROUP = CL * EP;
     constexpr int GPB = kBlock / GROUP;  // lane groups (row pairs) per workgroup
     constexpr int RPB = 2 * GPB;         // rows per workgroup
-    constexpr int U = TSGU_RP_U;         // gathers in flight per lane
+    // gathers in flight per lane; the bf16 backward keeps 8 floats per gathered row: 3 fit 5 waves per SIMD better (C5: -11 %)
+    constexpr int U = (MODE == kRpBwd && VEC == 8) ? 3 : TSGU_RP_U;
     constexpr bool kDma = std::is_same<V, float>::value;  // 4-byte values go to LDS by DMA
     static_assert(SLOTS || !PERM, "permuted plans carry explicit slots");
     static_assert(EP == 1 || SLOTS, "several entry lanes per pair need explicit slots");
@@ -371,7 +375,7 @@ inline bool rp_geom(int64_t p, int& cl, int& ep) {
     const int64_t ncl = p / vec;
     if (ncl != 2 && ncl != 4 && ncl != 8 && ncl != 16) return false;
     cl = (int)ncl;
-    ep = cl >= 8 ? 1 : 8 / cl;
+    ep = cl >= TSGU_RP_MINGROUP ? 1 : TSGU_RP_MINGROUP / cl;
     return true;
 }
 
@@ -414,10 +418,12 @@ int rp_launch(RpParams P, hipStream_t stream) {
         if (small) hipLaunchKernelGGL((csr_rowpack_kernel<V, I, CLV, EPV, MODE, PERM, SL, true>), grid, block, lds, stream, P);  \
         else hipLaunchKernelGGL((csr_rowpack_kernel<V, I, CLV, EPV, MODE, PERM, SL, false>), grid, block, lds, stream, P);       \
     } while (0)
+    constexpr int MG = TSGU_RP_MINGROUP;
+#define TSGU_RP_EPOF(CLV) ((CLV) >= MG ? 1 : MG / (CLV))
     if constexpr (PERM) {
         switch (cl) {
-            case 2: TSGU_RP_GO(2, 4, true); break;
-            case 4: TSGU_RP_GO(4, 2, true); break;
+            case 2: TSGU_RP_GO(2, TSGU_RP_EPOF(2), true); break;
+            case 4: TSGU_RP_GO(4, TSGU_RP_EPOF(4), true); break;
             case 8: TSGU_RP_GO(8, 1, true); break;
             case 16: TSGU_RP_GO(16, 1, true); break;
         }
@@ -430,8 +436,8 @@ int rp_launch(RpParams P, hipStream_t stream) {
     } else {
         if (slots) {
             switch (cl) {
-                case 2: TSGU_RP_GO(2, 4, true); break;
-                case 4: TSGU_RP_GO(4, 2, true); break;
+                case 2: TSGU_RP_GO(2, TSGU_RP_EPOF(2), true); break;
+                case 4: TSGU_RP_GO(4, TSGU_RP_EPOF(4), true); break;
                 case 8: TSGU_RP_GO(8, 1, true); break;
                 case 16: TSGU_RP_GO(16, 1, true); break;
             }
@@ -443,6 +449,7 @@ int rp_launch(RpParams P, hipStream_t stream) {
             }
         }
     }
+#undef TSGU_RP_EPOF
 #undef TSGU_RP_GO
     return check_launch();
 }
