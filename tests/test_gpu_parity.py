@@ -397,6 +397,7 @@ def test_plan_policy_first_sight_runs_plan_free_then_builds_and_releases(monkeyp
     from torchsparsegradutils_amd.utils import synthetic
 
     monkeypatch.setattr(_ops, "PLAN_AFTER_USES", 1)
+    monkeypatch.setattr(_ops, "PLAN_ASYNC", False)
     monkeypatch.setattr(_ops, "PACK_MIN_NNZ", 0)
     _pattern.clear_cache()
     crow, col = synthetic.stencil27_periodic(12, 10, 8, torch.int32, device=DEV)
@@ -420,6 +421,47 @@ def test_plan_policy_first_sight_runs_plan_free_then_builds_and_releases(monkeyp
     del A, C, gA, gB, outs, core
     gc.collect()
     assert _pattern.cache_stats() == (0, 0)
+
+
+def test_plan_policy_asynchronous_build_never_stalls_a_step(monkeypatch):
+    """Default policy: from the second use on, the row-pair plans are built on a worker thread + side stream; the
+    steps in between run on the plan-free kernels, `wait_for_plans()` joins, the next step switches over, and the
+    numbers agree with the plan-free ones (bit for bit here: fp32, one entry lane per pair)."""
+    import time
+
+    from torchsparsegradutils_amd import _ops, _pattern, wait_for_plans
+    from torchsparsegradutils_amd.utils import synthetic
+
+    monkeypatch.setattr(_ops, "PLAN_AFTER_USES", 1)
+    monkeypatch.setattr(_ops, "PLAN_ASYNC", True)
+    _pattern.clear_cache()
+    crow, col = synthetic.stencil27_periodic(40, 40, 40, torch.int32, device=DEV)
+    n = 64000
+    A = torch.sparse_csr_tensor(crow, col, torch.randn(col.numel(), device=DEV), (n, n)).requires_grad_(True)
+    B = torch.randn(n, 32, device=DEV, requires_grad=True)
+    Gd = torch.randn(n, 32, device=DEV)
+
+    def step():
+        C = tsgu().sparse_mm(A, B)
+        gA, gB = torch.autograd.grad(C, (A, B), Gd)
+        return C.detach(), gA.values().detach(), gB.detach()
+
+    first = step()                                   # first sight: plan-free, nothing submitted
+    core = _pattern.from_csr(A.detach()).core
+    assert not core.packs and not core.pending
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    second = step()                                  # submits the builds, runs plan-free, returns at once
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert core.pending or core.packs
+    wait_for_plans()
+    third = step()                                   # picks the finished plans up
+    assert core.packs and core.t.core.packs and not core.pending and not core.t.core.pending
+    assert all(p is not None for p in core.packs.values())
+    for a, b_, c_ in zip(first, second, third):
+        assert torch.equal(a, b_) and torch.equal(a, c_)
+    assert dt < 0.1, f"the submitting step took {dt * 1e3:.1f} ms: it must not wait for the plan"
 
 
 @pytest.mark.parametrize("kind", ["stencil27", "stencil27_odd", "laplacian7", "grid2d"])

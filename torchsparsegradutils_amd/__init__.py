@@ -5,6 +5,7 @@ Drop-in names for ``sparse_mm`` / ``sparse_triangular_solve`` / ``sparse_generic
 kernels behind the C ABI in ``include/tsgu_hip.h``.  GPU only — there is no CPU fallback.
 """
 
+from ._pattern import wait_for_plans
 from .sparse_lstsq import SparseGenericLstsq, sparse_generic_lstsq
 from .sparse_matmul import SparseMatMul, sparse_mm
 from .sparse_solve import (
@@ -20,6 +21,7 @@ __all__ = [
     "sparse_generic_solve",
     "sparse_generic_lstsq",
     "SparseGenericLstsq",
+    "wait_for_plans",
     "SparseMatMul",
     "SparseTriangularSolve",
     "SparseGenericSolve",

@@ -25,6 +25,9 @@ PACK_MIN_NNZ = 1 << 16
 # A row-pair plan costs a few device sorts: it is built when a pattern is seen for the PLAN_AFTER_USES-th time (the
 # first use runs on the plan-free kernels), so that one-off patterns never pay for it.  0 = build at first sight.
 PLAN_AFTER_USES = int(os.environ.get("TSGU_PLAN_AFTER_USES", "1"))
+# ... and it is built on a worker thread + side stream (TSGU_PLAN_ASYNC=0: inline): the steps in between keep running
+# on the plan-free kernels, no step ever waits for a plan.  `torchsparsegradutils_amd.wait_for_plans()` joins.
+PLAN_ASYNC = os.environ.get("TSGU_PLAN_ASYNC", "1") == "1"
 
 
 def _pack_for(plan: RowGather, dense: torch.Tensor, *others: torch.Tensor, need_plain_slots: bool = False):
@@ -41,6 +44,8 @@ def _pack_for(plan: RowGather, dense: torch.Tensor, *others: torch.Tensor, need_
         return None  # SDDMM walks ownership-bit records (one entry lane per pair)
     if not plan.seen_enough(PLAN_AFTER_USES):
         return None
+    if PLAN_ASYNC and PLAN_AFTER_USES > 0:
+        return plan.rowpack_plan_async(rpb, limits, explicit_slots=entry_lanes > 1)
     return plan.rowpack_plan(rpb, limits, explicit_slots=entry_lanes > 1)
 
 

@@ -17,9 +17,32 @@ import os as _os
 import threading
 import weakref
 from collections import OrderedDict
+from concurrent.futures import ThreadPoolExecutor
 from typing import Optional, Tuple
 
 import torch
+
+
+_EXECUTOR = ThreadPoolExecutor(max_workers=1, thread_name_prefix="tsgu-plan")
+_PENDING_LOCK = threading.Lock()
+_PENDING_CORES = set()
+_SIDE_STREAMS = {}
+
+
+def _side_stream(dev: torch.device):
+    s = _SIDE_STREAMS.get(dev)
+    if s is None:
+        s = _SIDE_STREAMS[dev] = torch.cuda.Stream(device=dev)
+    return s
+
+
+def wait_for_plans() -> None:
+    """Block until every asynchronous plan build submitted so far has finished (benchmarks call this at the end of
+    their warm-up; a training loop never needs to).  The plans are picked up by the next call of the operator."""
+    with _PENDING_LOCK:
+        futs = [f for c in _PENDING_CORES for f in c.pending.values()]
+    for f in futs:
+        f.result()
 
 
 class _Core:
@@ -27,13 +50,14 @@ class _Core:
     Holds only tensors this module allocated — never the caller's index tensors — so that dropping the sparse
     tensor releases its plans (the cache entry is evicted by a finalizer on the index storage)."""
 
-    __slots__ = ("t", "has_diag", "rows", "packs", "uses", "flat", "own", "__weakref__")
+    __slots__ = ("t", "has_diag", "rows", "packs", "pending", "uses", "flat", "own", "__weakref__")
 
     def __init__(self):
         self.t: Optional[RowGather] = None
         self.has_diag: Optional[bool] = None
         self.rows = None
         self.packs = {}
+        self.pending = {}   # plan key -> Future of an asynchronous build
         self.uses = 0
         self.flat: Optional[RowGather] = None
         self.own = {}   # derived index arrays of the pattern itself (COO → crow, stable row order, ...)
@@ -93,16 +117,69 @@ class RowGather:
         key = (rows_per_block, tuple(limits), bool(explicit_slots) or self.perm is not None)
         packs = self.core.packs
         if key not in packs:
-            plan = None
-            if ENABLE_BRICKS and self.perm is not None:
-                lat = detect_lattice(self)
-                order = brick_pair_order(self.n_rows, lat, rows_per_block // 2, self.crow.device) if lat else None
-                if order is not None:
-                    plan = build_rowpack_plan(self, rows_per_block, limits, pair_order=order, lattice=lat)
-            if plan is None:
-                plan = build_rowpack_plan(self, rows_per_block, limits, explicit_slots=explicit_slots)
-            packs[key] = plan
+            fut = self.core.pending.get(key)
+            if fut is not None:           # an asynchronous build is in flight: wait for it rather than build twice
+                fut.result()
+                return self.rowpack_plan_async(rows_per_block, limits, explicit_slots)
+            packs[key] = self._build_rowpack(rows_per_block, limits, explicit_slots)
         return packs[key]
+
+    def rowpack_plan_async(self, rows_per_block: int, limits, explicit_slots: bool = False):
+        """Like `rowpack_plan`, but the plan is built on a worker thread + side stream: returns the plan once it is
+        ready (None until then, so that the caller keeps running the plan-free kernels instead of stalling a training
+        step for the plan's device sorts).  Results do not depend on when the switch happens beyond the documented
+        difference between the two kernel families."""
+        key = (rows_per_block, tuple(limits), bool(explicit_slots) or self.perm is not None)
+        core = self.core
+        if key in core.packs:
+            return core.packs[key]
+        dev = self.crow.device
+        fut = core.pending.get(key)
+        if fut is None:
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(dev))   # the index tensors are complete from here on
+            view = RowGather(self.crow, self.col, self.n_rows, self.n_cols, perm=self.perm, core=core)
+
+            def job():
+                with torch.cuda.device(dev):
+                    side = _side_stream(dev)
+                    with torch.cuda.stream(side):
+                        side.wait_event(ready)
+                        plan = view._build_rowpack(rows_per_block, limits, explicit_slots)
+                        done = torch.cuda.Event()
+                        done.record(side)
+                return plan, done
+
+            with _PENDING_LOCK:
+                core.pending[key] = _EXECUTOR.submit(job)
+                _PENDING_CORES.add(core)
+            return None
+        if not fut.done():
+            return None
+        plan, done = fut.result()   # re-raises a builder error on the caller's thread
+        main = torch.cuda.current_stream(dev)
+        main.wait_event(done)
+        if plan is not None:
+            for t in (plan.uptr, plan.ucol, plan.upos, plan.sperm, plan.order, plan.vpair, plan.eptr, plan.wcls, plan.wbase, plan.cne):
+                if t is not None:
+                    t.record_stream(main)   # allocated on the side stream, used on the caller's from now on
+        with _PENDING_LOCK:
+            core.packs[key] = plan
+            core.pending.pop(key, None)
+            if not core.pending:
+                _PENDING_CORES.discard(core)
+        return plan
+
+    def _build_rowpack(self, rows_per_block: int, limits, explicit_slots: bool):
+        plan = None
+        if ENABLE_BRICKS and self.perm is not None:
+            lat = detect_lattice(self)
+            order = brick_pair_order(self.n_rows, lat, rows_per_block // 2, self.crow.device) if lat else None
+            if order is not None:
+                plan = build_rowpack_plan(self, rows_per_block, limits, pair_order=order, lattice=lat)
+        if plan is None:
+            plan = build_rowpack_plan(self, rows_per_block, limits, explicit_slots=explicit_slots)
+        return plan
 
     @property
     def nnz(self) -> int:
