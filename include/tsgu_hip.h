@@ -66,6 +66,9 @@ int tsgu_device_info(int device, char* name, int cap, int* n_cu, int* wave_size)
  * distributions/sparse_multivariate_normal.py:96,100: ld = 1, col_stride = n) without a copy: the kernel then takes
  * one column per grid.z slice with lanes along the rows.
  *
+ * max_row_nnz: length of the longest row (0 = unknown).  Only a hint: with 16-byte dense rows and short sparse rows the
+ * kernel gives every row ONE lane, unless this says that some row is far longer than the average (ragged patterns).
+ *
  * dot_w / dot_partial (optional): when non-NULL the kernel also writes, per thread block,
  * partial[block][c] = sum_rows C[row,c] * W[row,c]  (fp32/fp64 accumulate), block-major,
  * ld = p.  W has leading dimension ldw.  `tsgu_spmm_num_blocks` gives the row count of
@@ -76,12 +79,12 @@ int tsgu_csr_spmm(int vtype, int itype,
                   const void* crow, const void* col, const void* val, const void* perm,
                   const void* B, int64_t ldb, int64_t b_col_stride, int64_t b_batch_stride,
                   void* C, int64_t ldc, int64_t c_col_stride, int64_t c_batch_stride,
-                  int64_t p, int64_t batch,
+                  int64_t p, int64_t batch, int64_t max_row_nnz,
                   const void* dot_w, int64_t ldw, void* dot_partial,
                   int device, void* stream);
 
 /* Number of thread blocks (per batch item) tsgu_csr_spmm uses for (n_rows, nnz_per_item, p, vtype). */
-int64_t tsgu_spmm_num_blocks(int vtype, int64_t n_rows, int64_t nnz_per_item, int64_t p);
+int64_t tsgu_spmm_num_blocks(int vtype, int64_t n_rows, int64_t nnz_per_item, int64_t p, int64_t max_row_nnz);
 
 /*
  * K3  out[k] = alpha * < G[row(k), :], B[col(k), :] >   for every stored entry k of A

@@ -167,11 +167,13 @@ def test_abi_library_exports_every_declared_symbol():
     assert lib.tsgu_rowpack_geometry(_backend.TSGU_F32, 12, None, None, None, None, None) != 0
     assert lib.tsgu_status_string(-2).decode().startswith("bad argument")
     # pure host-side helpers of the ABI
-    assert lib.tsgu_spmm_num_blocks(_backend.TSGU_F32, 10 ** 6, 27 * 10 ** 6, 32) == 31250
+    assert lib.tsgu_spmm_num_blocks(_backend.TSGU_F32, 10 ** 6, 27 * 10 ** 6, 32, 27) == 31250
     # 16-byte dense rows + short sparse rows: one lane per row, 256 rows per workgroup
-    assert lib.tsgu_spmm_num_blocks(_backend.TSGU_F32, 2000376, 13907376, 4) == 7814
+    assert lib.tsgu_spmm_num_blocks(_backend.TSGU_F32, 2000376, 13907376, 4, 7) == 7814
     # the same operand with long rows keeps 8 entry lanes per row (32 rows per workgroup)
-    assert lib.tsgu_spmm_num_blocks(_backend.TSGU_F32, 2000376, 40 * 2000376, 4) == 62512
+    assert lib.tsgu_spmm_num_blocks(_backend.TSGU_F32, 2000376, 40 * 2000376, 4, 0) == 62512
+    # ragged: the same short-row operand with one very long row keeps 8 entry lanes per row as well
+    assert lib.tsgu_spmm_num_blocks(_backend.TSGU_F32, 2000376, 13907376, 4, 5000) == 10419   # 32 rows x 6 runs per workgroup
     assert lib.tsgu_sptrsm_work_bytes(10, 1) >= 516
 
 

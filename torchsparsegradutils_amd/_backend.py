@@ -40,10 +40,10 @@ SIGNATURES = {
     "tsgu_device_info": (_int, [_int, ctypes.c_char_p, _int, ctypes.POINTER(_int), ctypes.POINTER(_int)]),
     "tsgu_csr_spmm": (
         _int,
-        [_int, _int, _i64, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _ptr, _i64, _i64, _i64, _i64, _i64,
+        [_int, _int, _i64, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _ptr, _i64, _i64, _i64, _i64, _i64, _i64,
          _ptr, _i64, _ptr, _int, _ptr],
     ),
-    "tsgu_spmm_num_blocks": (_i64, [_int, _i64, _i64, _i64]),
+    "tsgu_spmm_num_blocks": (_i64, [_int, _i64, _i64, _i64, _i64]),
     "tsgu_csr_sddmm": (
         _int,
         [_int, _int, _i64, _i64, _i64, _ptr, _ptr, _ptr, _i64, _i64, _ptr, _i64, _i64, _ptr, _dbl, _int, _i64, _i64,
@@ -203,7 +203,7 @@ def _bs(t: torch.Tensor) -> int:
     return t.stride(0) if (t.dim() == 3 and t.size(0) > 1) else 0
 
 
-def csr_spmm(crow, col, val, B, n_rows: int, n_cols: int, perm=None, out=None, dot_w=None):
+def csr_spmm(crow, col, val, B, n_rows: int, n_cols: int, perm=None, out=None, dot_w=None, max_row_nnz: int = 0):
     """C = A·B for (batched) CSR arrays.  B: (m, p) or (b, m, p).  Returns C or (C, dot_partial).
     A 2-D B that is a transposed view is consumed in place and C comes back in the same (transposed) layout."""
     lib = load_library()
@@ -237,14 +237,14 @@ def csr_spmm(crow, col, val, B, n_rows: int, n_cols: int, perm=None, out=None, d
     partial = None
     vt = vtype_of(val)
     if dot_w is not None:
-        nblk = lib.tsgu_spmm_num_blocks(vt, n_rows, nnz, p)
+        nblk = lib.tsgu_spmm_num_blocks(vt, n_rows, nnz, p, max_row_nnz)
         partial = torch.empty((batch * nblk, p), dtype=B.dtype, device=dev)
         dot_w = rowmajor(dot_w)
     with torch.cuda.device(dev):
         check(
             lib.tsgu_csr_spmm(
                 vt, itype_of(crow), n_rows, n_cols, nnz, _p(crow), _p(col), _p(val), _p(perm),
-                _p(B), ldb, b_cs, _bs(B), _p(out), ldc, c_cs, _bs(out), p, batch,
+                _p(B), ldb, b_cs, _bs(B), _p(out), ldc, c_cs, _bs(out), p, batch, max_row_nnz,
                 _p(dot_w), _ld(dot_w) if dot_w is not None else 0, _p(partial), dev.index, _stream(dev),
             ),
             "tsgu_csr_spmm",

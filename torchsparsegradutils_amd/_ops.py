@@ -97,7 +97,7 @@ def spmm(plan: RowGather, values: torch.Tensor, B: torch.Tensor) -> torch.Tensor
         rp = _pack_for(plan, B)
         if rp is not None:
             return _be.csr_spmm_rowpack(plan.crow, values, rp, B, plan.n_rows)
-    return _be.csr_spmm(plan.crow, plan.col, values, B, plan.n_rows, plan.n_cols, perm=plan.perm)
+    return _be.csr_spmm(plan.crow, plan.col, values, B, plan.n_rows, plan.n_cols, perm=plan.perm, max_row_nnz=plan.max_row_nnz)
 
 
 def sddmm(plan: RowGather, G: torch.Tensor, B: torch.Tensor, alpha: float = 1.0, swap_roles: bool = False) -> torch.Tensor:

@@ -73,7 +73,7 @@ class _Core:
 
         add(self.rows)
         for t in self.own.values():
-            add(t)
+            add(t)  # (non-tensor entries are ignored)
         for rp in self.packs.values():
             if rp is not None:
                 total += rp.plan_bytes()
@@ -197,6 +197,15 @@ class RowGather:
                 rows = torch.repeat_interleave(ar.repeat(self.batch), counts, output_size=self.batch * self.nnz)
                 self.core.rows = rows.view(self.batch, self.nnz)
         return self.core.rows
+
+    @property
+    def max_row_nnz(self) -> int:
+        """Length of the longest row (one small reduction + host read per pattern, cached)."""
+        m = self.core.own.get("max_row_nnz")
+        if m is None:
+            d = self.crow[..., 1:] - self.crow[..., :-1]
+            m = self.core.own["max_row_nnz"] = int(d.max()) if d.numel() else 0
+        return m
 
     @property
     def transposed(self) -> "RowGather":

@@ -48,12 +48,12 @@ int tsgu_device_info(int device, char* name, int cap, int* n_cu, int* wave_size)
     return TSGU_OK;
 }
 
-int64_t tsgu_spmm_num_blocks(int vtype, int64_t n_rows, int64_t nnz_per_item, int64_t p) {
+int64_t tsgu_spmm_num_blocks(int vtype, int64_t n_rows, int64_t nnz_per_item, int64_t p, int64_t max_row_nnz) {
     // mirrors spmm_geom(): the fused-dot path is only used with contiguous, 16-byte
     // aligned operands, so "wide" depends on p alone.
     const int wide = vtype == TSGU_F32 ? 4 : vtype == TSGU_F64 ? 2 : 8;
     RowGeom g = pick_geom(wide, p % wide == 0, p);
-    prefer_row_per_lane(g, n_rows, nnz_per_item);  // the fused-dot path never walks a permutation
+    prefer_row_per_lane(g, n_rows, nnz_per_item, max_row_nnz);  // the fused-dot path never walks a permutation
     const int64_t rpb = kBlock / (g.cl * g.ep);
     const int64_t rows = rpb * spmm_row_mult(n_rows, nnz_per_item, rpb);
     return (n_rows + rows - 1) / rows;
@@ -63,7 +63,7 @@ int tsgu_csr_spmm(int vtype, int itype, int64_t n_rows, int64_t n_cols, int64_t 
                   const void* crow, const void* col, const void* val, const void* perm,
                   const void* B, int64_t ldb, int64_t b_col_stride, int64_t b_batch_stride,
                   void* C, int64_t ldc, int64_t c_col_stride, int64_t c_batch_stride,
-                  int64_t p, int64_t batch,
+                  int64_t p, int64_t batch, int64_t max_row_nnz,
                   const void* dot_w, int64_t ldw, void* dot_partial,
                   int device, void* stream) {
     if (n_rows < 0 || n_cols < 0 || nnz_per_item < 0 || p < 0 || batch < 0) return TSGU_ERR_BAD_ARG;
@@ -87,6 +87,7 @@ int tsgu_csr_spmm(int vtype, int itype, int64_t n_rows, int64_t n_cols, int64_t 
     P.B = B;
     P.ldb = ldb;
     P.b_bs = b_batch_stride;
+    P.max_row_nnz = max_row_nnz;
     P.b_cs = b_col_stride;
     P.c_cs = c_col_stride;
     P.C = C;

@@ -32,6 +32,7 @@ struct SpmmParams {
     const void* W;
     int64_t ldw;
     void* dot_partial;
+    int64_t max_row_nnz;  // longest row of the walked pattern (0 = unknown): see prefer_row_per_lane
     int64_t nblocks;  // row blocks per batch item
     int rmul;         // runs of RPB rows per workgroup
 };
@@ -307,7 +308,7 @@ inline RowGeom spmm_geom(const SpmmParams& P, int64_t batch) {
         g.col_tiles = P.p;
         return g;
     }
-    prefer_row_per_lane(g, P.n_rows, P.nnz_per_item);
+    prefer_row_per_lane(g, P.n_rows, P.nnz_per_item, P.max_row_nnz);
     return g;
 }
 

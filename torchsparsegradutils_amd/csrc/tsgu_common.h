@@ -258,9 +258,14 @@ inline RowGeom pick_geom(int wide, bool can_wide, int64_t p) {
 // One lane per row (CL = EP = 1) for operands whose dense row is a single 16-byte access and whose sparse rows are
 // short: consecutive lanes own consecutive rows, so for banded / stencil patterns the k-th gathers of a wave fall on
 // consecutive dense rows — one contiguous kilobyte instead of 64 separate lines through L1 (C4's 7-point Laplacian
-// with 4 right-hand sides: K1 with the dot epilogue 85 -> 43 us).  Longer or ragged rows keep 8 entry lanes per row.
-inline void prefer_row_per_lane(RowGeom& g, int64_t n_rows, int64_t nnz) {
-    if (g.cl == 1 && g.vec > 1 && n_rows > 0 && nnz <= 16 * n_rows) g.ep = 1;
+// with 4 right-hand sides: K1 with the dot epilogue 85 -> 43 us).  Longer rows keep 8 entry lanes per row.
+// `max_row_nnz` (0 = unknown) guards ragged patterns: one very long row in a short-row matrix would be walked serially
+// by a single lane (K1 and the CG dot epilogue with it), so the geometry is only chosen when no row is much longer
+// than the average.
+inline void prefer_row_per_lane(RowGeom& g, int64_t n_rows, int64_t nnz, int64_t max_row_nnz = 0) {
+    if (g.cl == 1 && g.vec > 1 && n_rows > 0 && nnz <= 16 * n_rows &&
+        (max_row_nnz <= 0 || max_row_nnz <= 4 * (nnz / n_rows + 1) + 16))
+        g.ep = 1;
 }
 
 template <typename F>

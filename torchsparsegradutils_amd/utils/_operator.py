@@ -56,7 +56,7 @@ class SparseOperator:
         p = self.plan
         v = self._cast(v)
         return _be.csr_spmm(p.crow, p.col, self.values, v, p.n_rows, p.n_cols, perm=p.perm, out=out,
-                            dot_w=v if w is None else w)
+                            dot_w=v if w is None else w, max_row_nnz=p.max_row_nnz)
 
 
 def checked(out: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
