@@ -15,6 +15,7 @@ from __future__ import annotations
 
 import os as _os
 import threading
+import warnings
 import weakref
 from collections import OrderedDict
 from concurrent.futures import ThreadPoolExecutor
@@ -42,7 +43,10 @@ def wait_for_plans() -> None:
     with _PENDING_LOCK:
         futs = [f for c in _PENDING_CORES for f in c.pending.values()]
     for f in futs:
-        f.result()
+        try:
+            f.result()
+        except Exception:  # noqa: BLE001  (reported by the operator that picks the result up)
+            pass
 
 
 class _Core:
@@ -156,7 +160,17 @@ class RowGather:
             return None
         if not fut.done():
             return None
-        plan, done = fut.result()   # re-raises a builder error on the caller's thread
+        try:
+            plan, done = fut.result()
+        except Exception as exc:  # noqa: BLE001  (a failed background build must never break the caller's step)
+            warnings.warn(f"torchsparsegradutils_amd: asynchronous row-pair plan build failed ({exc!r}); "
+                          "this pattern stays on the plan-free kernels", RuntimeWarning, stacklevel=2)
+            with _PENDING_LOCK:
+                core.packs[key] = None
+                core.pending.pop(key, None)
+                if not core.pending:
+                    _PENDING_CORES.discard(core)
+            return None
         main = torch.cuda.current_stream(dev)
         main.wait_event(done)
         if plan is not None:

@@ -26,7 +26,9 @@ def capture(body, repeat: int):
     Returns None if the runtime refuses the capture; nothing has executed in that case."""
     graph = torch.cuda.CUDAGraph()
     try:
-        with torch.cuda.graph(graph):
+        # thread_local: the plan builder's worker thread (or any other thread of the application) may allocate or
+        # launch on its own stream while this thread records
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             for _ in range(repeat):
                 body()
     except Exception as exc:  # noqa: BLE001
