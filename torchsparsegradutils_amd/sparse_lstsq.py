@@ -55,63 +55,61 @@ def sparse_generic_lstsq(
     return cast(torch.Tensor, SparseGenericLstsq.apply(A, B, lstsq, transpose_lstsq))
 
 
+def _columns(t: torch.Tensor) -> torch.Tensor:
+    """(m,) -> (m, 1); matrices pass through."""
+    return t.unsqueeze(1) if t.ndim == 1 else t
+
+
 class SparseGenericLstsq(torch.autograd.Function):
-    """Autograd kernel behind :func:`sparse_generic_lstsq` (mirrors reference ``sparse_lstsq.py:156-271``)."""
+    """Autograd kernel behind :func:`sparse_generic_lstsq` (same contract as reference ``sparse_lstsq.py:156-271``:
+    solution shaped like ``B``, gradient of ``A`` on A's pattern in A's layout, ``ValueError`` for a wide ``A`` in
+    backward)."""
 
     @staticmethod
     def forward(ctx, A, B, lstsq, transpose_lstsq):
-        grad_flag = A.requires_grad or B.requires_grad
-        ctx.lstsq = lstsq
-        ctx.transpose_lstsq = transpose_lstsq
-
-        x = lstsq(A.detach(), B.detach())
-        x.requires_grad = grad_flag
-        if B.dim() == 1:
-            if x.dim() == 2:
-                x = x.squeeze()
-        elif x.dim() == 1:
-            x = x.unsqueeze(1)
-
-        ctx.save_for_backward(A.detach(), B.detach(), x.detach())
-        return x
+        ctx.solvers = (lstsq, transpose_lstsq)
+        wants_grad = A.requires_grad or B.requires_grad
+        A_, B_ = A.detach(), B.detach()
+        sol = lstsq(A_, B_)
+        # the solution has the rank of B, whatever the user's solver returned (reference :178-185)
+        if B_.ndim == 1 and sol.ndim == 2:
+            sol = sol.squeeze()
+        elif B_.ndim != 1 and sol.ndim == 1:
+            sol = sol.unsqueeze(1)
+        sol.requires_grad = wants_grad
+        ctx.save_for_backward(A_, B_, sol.detach())
+        return sol
 
     @staticmethod
     def backward(ctx, grad):  # type: ignore[override]
         A, B, x = ctx.saved_tensors
-        if B.ndim == 1:
-            B = B.unsqueeze(1)
-        if x.ndim == 1:
-            x = x.unsqueeze(1)
+        lstsq, transpose_lstsq = ctx.solvers
+        vector_rhs = grad.ndim == 1
+        B, x = _columns(B), _columns(x)
 
-        # gradB = (Aᵀ)⁺ grad   (reference :198-200)
-        gradB = ctx.transpose_lstsq(A, grad)
-        if gradB.ndim == 1:
-            gradB = gradB.unsqueeze(1)
-        if A.shape[1] > A.shape[0]:  # reference :205-206
+        grad_b = _columns(transpose_lstsq(A, grad))              # (Aᵀ)⁺ grad   (reference :198-200)
+        m_rows, n_cols = A.shape
+        if n_cols > m_rows:                                      # reference :205-206
             raise ValueError(f"A should be a tall full-rank matrix. Got A.shape={A.shape}")
 
-        # gradA[i,j] = -<gradB[i,:], x[j,:]> + <(B - A x)[i,:], (A⁺ gradB)[j,:]>   (reference :229-262) — both terms in
-        # one SDDMM over the concatenated columns, no row expansion and no nnz×p temporaries
+        # Golub–Pereyra 4.12 restricted to A's pattern (reference :229-262):
+        #   gradA[i,j] = −<grad_b[i,:], x[j,:]> + <(B − A x)[i,:], (A⁺ grad_b)[j,:]>
+        # both inner products in ONE SDDMM over the concatenated columns: no row expansion, no nnz×p temporaries
+        coo_index = None
         if A.layout == torch.sparse_coo:
             Ac = A if A.is_coalesced() else A.coalesce()
-            idx = Ac.indices()
-            plan, values = _pt.from_coo_2d(idx, A.shape, coalesced=True), Ac.values()
+            coo_index = Ac.indices()
+            plan, values = _pt.from_coo_2d(coo_index, A.shape, coalesced=True), Ac.values()
         else:
-            idx = None
             plan, values = _pt.from_csr(A), A.values()
         _be.require_device(values, B, x)
         residual = B - _ops.spmm(plan, values, x.contiguous())
-        Apgb = ctx.lstsq(A, gradB)
-        if Apgb.dim() == 1:
-            Apgb = Apgb.unsqueeze(1)
-        left = torch.cat((-gradB, residual), dim=1).contiguous()
-        right = torch.cat((x, Apgb), dim=1).contiguous()
-        gvals = _ops.sddmm(plan, left, right)
-        if idx is not None:
-            gradA = torch.sparse_coo_tensor(idx, gvals, A.shape)
+        pinv_gb = _columns(lstsq(A, grad_b))
+        row_side = torch.cat((-grad_b, residual), dim=1).contiguous()
+        col_side = torch.cat((x, pinv_gb), dim=1).contiguous()
+        grad_vals = _ops.sddmm(plan, row_side, col_side)
+        if coo_index is not None:
+            grad_a = torch.sparse_coo_tensor(coo_index, grad_vals, A.shape)
         else:
-            gradA = torch.sparse_csr_tensor(A.crow_indices(), A.col_indices(), gvals, A.shape)
-
-        if grad.ndim == 1:
-            gradB = gradB.squeeze()
-        return gradA, gradB, None, None
+            grad_a = torch.sparse_csr_tensor(A.crow_indices(), A.col_indices(), grad_vals, A.shape)
+        return grad_a, (grad_b.squeeze() if vector_rhs else grad_b), None, None
