@@ -165,6 +165,10 @@ int tsgu_csr_mm_backward(int vtype, int itype, int64_t n_rows, int64_t n_cols, i
  *                        stored entries per workgroup (with sperm).  eptr is unused.
  *   On lattice stencils (dozens of classes for millions of rows) the index streams — a third of the HBM traffic of
  *   the stream form — shrink to a few KB that stay in L2; results are bit-identical to the stream form.
+ * ROW QUADS (rows_per_group = 4): a lane group owns FOUR consecutive rows (workgroup = 4·G rows); records as in the
+ *                        form without upos, the four ownership bits in bits 28..31 of ucol (n_cols < 2^28); ecap up to twice
+ *                        max_entries.  27-point stencil: 54 union columns per quad = 13.5 gathers per row instead of 18.  Only
+ *                        for stored-order walks with one entry lane (forward SpMM, SDDMM).
  * order[nblocks]         optional (NULL = natural): workgroup b processes block order[b]; any permutation is valid.
  * ecap / ucap = capacity of the staged value slice / union records per workgroup (multiples of 256, within the limits
  * of tsgu_rowpack_geometry; ucap·(upos ? 8 : 4) + ecap·4 <= lds_budget_bytes).
@@ -180,7 +184,7 @@ typedef struct tsgu_rowpack_plan {
     int64_t nblocks;          /* workgroups */
     int32_t ecap, ucap;       /* LDS capacities (entries) */
     int32_t nclasses;         /* 0 = stream form */
-    int32_t reserved;
+    int32_t rows_per_group;   /* 0 or 2: row pairs; 4: row QUADS (stored-order walks without upos only) */
     const void* uptr;
     const void* ucol;
     const void* upos;

@@ -86,6 +86,9 @@ def main():
             plans["rp_t_nat_" + tag] = _pattern.build_rowpack_plan(pt, rpb, lim, dedup=dd)
             if po is not None:
                 plans["rp_t_brick_" + tag] = _pattern.build_rowpack_plan(pt, rpb, lim, pair_order=po, lattice=lat, dedup=dd)
+        if ep == 1:
+            for tag, dd in (("s", "off"), ("d", "force")):
+                plans["rp_fwd4_" + tag] = _pattern.build_rowpack_plan(plan, 2 * rpb, lim, dedup=dd, group=4)
         for shp in (a.brick or []):
             pox = _pattern.brick_pair_order(n, lat, rpb // 2, dev, shape=tuple(shp)) if lat is not None else None
             if pox is not None:
@@ -99,10 +102,10 @@ def main():
             if rp is None:
                 print(f"  {k}: no plan")
                 continue
-            print(f"  {k}: classes={rp.nclasses} blocks={rp.nblocks} ecap={rp.ecap} ucap={rp.ucap} bytes={rp.plan_bytes() / 1e6:.2f} MB reuse={rp.reuse:.2f}")
+            print(f"  {k}: group={rp.group} classes={rp.nclasses} blocks={rp.nblocks} ecap={rp.ecap} ucap={rp.ucap} bytes={rp.plan_bytes() / 1e6:.2f} MB reuse={rp.reuse:.2f}")
             if k.startswith("rp_fwd"):
                 add(k, "spmm", (lambda rp=rp: be.csr_spmm_rowpack(crow, val, rp, B, n)))
-                if rp.upos is None:
+                if rp.upos is None and rp.sperm is None:
                     add(k.replace("fwd", "sddmm"), "sddmm", (lambda rp=rp: be.csr_sddmm_rowpack(crow, rp, G, B, n)))
             else:
                 add(k.replace("rp_t", "rp_spmmt"), "spmm", (lambda rp=rp: be.csr_spmm_rowpack(pt.crow, val, rp, G, n)))

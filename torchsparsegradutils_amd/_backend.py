@@ -315,7 +315,7 @@ class _RowpackPlanStruct(ctypes.Structure):
     """``tsgu_rowpack_plan`` of include/tsgu_hip.h."""
 
     _fields_ = [("nblocks", _i64), ("ecap", ctypes.c_int32), ("ucap", ctypes.c_int32), ("nclasses", ctypes.c_int32),
-                ("reserved", ctypes.c_int32)] + [(k, _ptr) for k in ("uptr", "ucol", "upos", "sperm", "order", "vpair", "eptr",
+                ("rows_per_group", ctypes.c_int32)] + [(k, _ptr) for k in ("uptr", "ucol", "upos", "sperm", "order", "vpair", "eptr",
                                                                      "wcls", "wbase", "cne")]
 
 
@@ -323,7 +323,7 @@ def _plan_struct(rp):
     """ctypes image of a _pattern.RowPackPlan (cached on the plan; the plan keeps the tensors alive)."""
     st = rp._cstruct
     if st is None:
-        st = _RowpackPlanStruct(rp.nblocks, rp.ecap, rp.ucap, rp.nclasses, 0, _p(rp.uptr), _p(rp.ucol), _p(rp.upos), _p(rp.sperm),
+        st = _RowpackPlanStruct(rp.nblocks, rp.ecap, rp.ucap, rp.nclasses, rp.group, _p(rp.uptr), _p(rp.ucol), _p(rp.upos), _p(rp.sperm),
                                 _p(rp.order), _p(rp.vpair), _p(rp.eptr), _p(rp.wcls), _p(rp.wbase), _p(rp.cne))
         rp._cstruct = st
     return ctypes.addressof(st)

@@ -115,25 +115,25 @@ class RowGather:
         self.core.uses += 1
         return self.core.uses > after
 
-    def rowpack_plan(self, rows_per_block: int, limits, explicit_slots: bool = False):
-        """Plan for the row-pair gather kernels (csrc/rowpack_impl.h), None when the pattern does not qualify or
-        profit; cached per workgroup height.  See `build_rowpack_plan`."""
-        key = (rows_per_block, tuple(limits), bool(explicit_slots) or self.perm is not None)
+    def rowpack_plan(self, rows_per_block: int, limits, explicit_slots: bool = False, group: int = 2):
+        """Plan for the row-pair (group = 2) / row-quad (group = 4) gather kernels (csrc/rowpack_impl.h), None when the
+        pattern does not qualify or profit; cached per workgroup height.  See `build_rowpack_plan`."""
+        key = (rows_per_block, tuple(limits), bool(explicit_slots) or self.perm is not None, group)
         packs = self.core.packs
         if key not in packs:
             fut = self.core.pending.get(key)
             if fut is not None:           # an asynchronous build is in flight: wait for it rather than build twice
                 fut.result()
-                return self.rowpack_plan_async(rows_per_block, limits, explicit_slots)
-            packs[key] = self._build_rowpack(rows_per_block, limits, explicit_slots)
+                return self.rowpack_plan_async(rows_per_block, limits, explicit_slots, group)
+            packs[key] = self._build_rowpack(rows_per_block, limits, explicit_slots, group)
         return packs[key]
 
-    def rowpack_plan_async(self, rows_per_block: int, limits, explicit_slots: bool = False):
+    def rowpack_plan_async(self, rows_per_block: int, limits, explicit_slots: bool = False, group: int = 2):
         """Like `rowpack_plan`, but the plan is built on a worker thread + side stream: returns the plan once it is
         ready (None until then, so that the caller keeps running the plan-free kernels instead of stalling a training
         step for the plan's device sorts).  Results do not depend on when the switch happens beyond the documented
         difference between the two kernel families."""
-        key = (rows_per_block, tuple(limits), bool(explicit_slots) or self.perm is not None)
+        key = (rows_per_block, tuple(limits), bool(explicit_slots) or self.perm is not None, group)
         core = self.core
         if key in core.packs:
             return core.packs[key]
@@ -149,7 +149,7 @@ class RowGather:
                     side = _side_stream(dev)
                     with torch.cuda.stream(side):
                         side.wait_event(ready)
-                        plan = view._build_rowpack(rows_per_block, limits, explicit_slots)
+                        plan = view._build_rowpack(rows_per_block, limits, explicit_slots, group)
                         done = torch.cuda.Event()
                         done.record(side)
                 return plan, done
@@ -184,7 +184,9 @@ class RowGather:
                 _PENDING_CORES.discard(core)
         return plan
 
-    def _build_rowpack(self, rows_per_block: int, limits, explicit_slots: bool):
+    def _build_rowpack(self, rows_per_block: int, limits, explicit_slots: bool, group: int = 2):
+        if group != 2:
+            return build_rowpack_plan(self, rows_per_block, limits, group=group)
         plan = None
         if ENABLE_BRICKS and self.perm is not None:
             lat = detect_lattice(self)
@@ -247,7 +249,7 @@ class RowPackPlan:
       the index streams — a third of the kernels' HBM traffic — become L2-resident."""
 
     __slots__ = ("uptr", "ucol", "upos", "sperm", "order", "vpair", "eptr", "nblocks", "ecap", "ucap", "rpb", "reuse",
-                 "nnz", "lattice", "wcls", "wbase", "cne", "nclasses", "gpb", "_cstruct")
+                 "nnz", "lattice", "wcls", "wbase", "cne", "nclasses", "gpb", "group", "_cstruct")
 
     def __init__(self, uptr, ucol, upos, sperm, ecap, ucap, rpb, reuse, nnz, order=None, vpair=None, eptr=None,
                  nblocks=0, lattice=None, gpb=None):
@@ -255,6 +257,7 @@ class RowPackPlan:
         self.vpair, self.eptr, self.nblocks, self.lattice = vpair, eptr, nblocks, lattice
         self.ecap, self.ucap, self.rpb, self.reuse, self.nnz = ecap, ucap, rpb, reuse, nnz
         self.gpb = rpb // 2 if gpb is None else gpb
+        self.group = 2          # rows per lane group (2 = pairs, 4 = quads)
         self.wcls = self.wbase = self.cne = None
         self.nclasses = 0
         self._cstruct = None
@@ -343,12 +346,14 @@ DEDUP_MAX_FRACTION = 0.25    # dictionary form when the classes are at most this
 DEDUP_MAX_BYTES = 8 << 20    # ... and the class tables stay cache-sized
 
 
-def build_rowpack_plan(g: RowGather, rpb: int, limits, pair_order=None, lattice=None, explicit_slots=False, dedup=None):
+def build_rowpack_plan(g: RowGather, rpb: int, limits, pair_order=None, lattice=None, explicit_slots=False, dedup=None,
+                       group: int = 2):
     """Rows 2q and 2q+1 walk the sorted union of their column sets: `ucol` per union entry, `upos` = two 16-bit slots
     (one per row; bit 15 = this row has no entry there) into the value slice a workgroup of `rpb` rows stages.  For
     plans addressed through `perm` the slice is staged in the order of the permutation sorted inside the workgroup
     (`sperm`), otherwise in stored order — and then, unless `explicit_slots` (kernels with several entry lanes per
-    pair), the record only carries two ownership bits (30 / 31 of ucol) because a row's slots are consecutive.
+    pair), the record only carries ownership bits (top bits of ucol) because a row's slots are consecutive.
+    `group` = 4 builds the ROW-QUAD plan (stored order, no slots): a lane group owns four consecutive rows.
     `pair_order` (permuted plans only) assigns row pairs to lane-group slots (see brick_pair_order); None =
     consecutive.  `limits` = (max_entries, max_union, lds_budget_bytes).  `dedup` overrides DEDUP_MODE."""
     max_entries, max_union, lds_budget = limits
@@ -356,10 +361,12 @@ def build_rowpack_plan(g: RowGather, rpb: int, limits, pair_order=None, lattice=
         return None
     n, m, nnz = g.n_rows, g.n_cols, g.nnz
     dev = g.crow.device
-    gpb = rpb // 2
-    npairs = (n + 1) // 2
-    natural = pair_order is None
     slots = explicit_slots or g.perm is not None
+    if group not in (2, 4) or (group == 4 and (slots or pair_order is not None)):
+        return None
+    gpb = rpb // group
+    npairs = (n + group - 1) // group             # row groups (pairs / quads)
+    natural = pair_order is None
     if natural:
         nb = (npairs + gpb - 1) // gpb
         pair_order = torch.full((nb * gpb,), -1, dtype=torch.int64, device=dev)
@@ -379,25 +386,25 @@ def build_rowpack_plan(g: RowGather, rpb: int, limits, pair_order=None, lattice=
         c64 = g.col.to(torch.int64)
         if bool(((c64[1:] <= c64[:-1]) & (rows[1:] == rows[:-1])).any()):
             return None
-    vp = slot_of[rows // 2]                       # lane-group slot of every stored entry
+    vp = slot_of[rows // group]                   # lane-group slot of every stored entry
     blk = vp // gpb
     ne = torch.bincount(blk, minlength=nb)
     ecap = max((int(ne.max()) + 255) // 256 * 256, 256)
-    if ecap > max_entries or ecap >= _PACK_ABSENT:
+    if ecap > max_entries * (group // 2) or ecap >= _PACK_ABSENT:
         return None
     eptr = torch.zeros(nb + 1, dtype=torch.int64, device=dev)
     eptr[1:] = torch.cumsum(ne, 0)
     uniq, inv = torch.unique(vp * m + g.col.to(torch.int64), return_inverse=True)  # sorted: (slot, column) ascending
     nu = uniq.numel()
     reuse = nnz / max(nu, 1)
-    if reuse < _PACK_MIN_REUSE:
+    if reuse < _PACK_MIN_REUSE * (1.0 if group == 2 else 1.25):
         return None
     uslot = uniq // m
     uptr = torch.zeros(nslots + 1, dtype=torch.int64, device=dev)
     uptr[1:] = torch.cumsum(torch.bincount(uslot, minlength=nslots), 0)
     ub = uptr[torch.arange(0, nslots + 1, gpb, device=dev)]
     ucap = max((int((ub[1:] - ub[:-1]).max()) + 255) // 256 * 256, 256)
-    if ucap > max_union or ucap * (8 if slots else 4) + ecap * 4 > lds_budget or (not slots and m >= 2**30):
+    if ucap > max_union or ucap * (8 if slots else 4) + ecap * 4 > lds_budget or (not slots and m >= 2 ** (32 - group)):
         return None
     k = torch.arange(nnz, device=dev, dtype=torch.int64)
     sperm64 = None
@@ -411,15 +418,18 @@ def build_rowpack_plan(g: RowGather, rpb: int, limits, pair_order=None, lattice=
     ucol64 = uniq - uslot * m
     own = word64 = None
     if not slots:
-        # stored order: a row's slots are consecutive, the record only carries the ownership bits (30: row 2q, 31: 2q+1)
-        own = torch.zeros((2, nu), dtype=torch.int64, device=dev)
-        own[rows % 2, inv] = 1
-        own = (own[0] << 30) | (own[1] << 31)
+        # stored order: a row's slots are consecutive, the record only carries the ownership bits (top `group` bits)
+        bits = torch.zeros((group, nu), dtype=torch.int64, device=dev)
+        bits[rows % group, inv] = 1
+        own = torch.zeros(nu, dtype=torch.int64, device=dev)
+        for r in range(group):
+            own |= bits[r] << (32 - group + r)
     else:
         half = torch.full((2, nu), _PACK_ABSENT, dtype=torch.int64, device=dev)
         half[rows % 2, inv] = slot
         word64 = half[0] | (half[1] << 16)
-    plan = RowPackPlan(None, None, None, None, ecap, ucap, rpb, reuse, nnz, nblocks=nb, lattice=lattice)
+    plan = RowPackPlan(None, None, None, None, ecap, ucap, rpb, reuse, nnz, nblocks=nb, lattice=lattice, gpb=gpb)
+    plan.group = group
     mode = DEDUP_MODE if dedup is None else dedup
     if mode != "off" and _dedup_classes(plan, mode == "force", natural, uptr, ub, ucol64, own, word64, sperm64, pair_order,
                                         eptr, nb, gpb):
@@ -554,7 +564,8 @@ def expand_classes(plan: RowPackPlan):
         ucol = (words + wb[:, 1:2])[mu]
         upos = (plan.upos.view(-1, plan.ucap).long()[cls] & 0xFFFFFFFF)[mu]
     else:
-        ucol = (((words & 0x3FFFFFFF) + wb[:, 1:2]) | (words & 0xC0000000))[mu]
+        cmask = (1 << (32 - plan.group)) - 1
+        ucol = (((words & cmask) + wb[:, 1:2]) | (words & (0xFFFFFFFF ^ cmask)))[mu]
         upos = None
     sperm = eptr = None
     if plan.sperm is not None:

@@ -33,6 +33,7 @@ int fill(RpParams& P, int64_t n_rows, int64_t n_src, int64_t nnz, int64_t p, con
     P.nblocks = pl->nblocks;
     P.ecap = pl->ecap;
     P.ucap = pl->ucap;
+    P.rgroup = pl->rows_per_group;
     return TSGU_OK;
 }
 

@@ -52,6 +52,7 @@ struct RpParams {
     void* gradA;            // backward: [nnz] in A's order; SDDMM: [nnz] output in walked order
     float alpha;            // SDDMM scale
     int ecap, ucap;         // LDS capacities: staged values / union records per workgroup
+    int rgroup;             // rows per lane group: 2 (pairs) or 4 (quads; stored-order walks without slots only)
     int64_t nblocks;
 };
 
@@ -79,13 +80,16 @@ constexpr int kRpAbsent = 0x8000;
 
 // PERM : the values are addressed through the (workgroup-sorted) permutation `sperm`
 // SLOTS: union records carry explicit value slots (`upos`); otherwise ownership bits + running counters
-template <typename V, typename I, int CL, int EP, int MODE, bool PERM, bool SLOTS, bool SMALL>
+// R    : rows per lane group — 2 (pairs: every mode) or 4 (quads: stored-order walks without slots; the union of four
+//        consecutive stencil rows has 54 columns instead of 2 x 36 = fewer gathers through L1 per output row)
+template <typename V, typename I, int CL, int EP, int MODE, bool PERM, bool SLOTS, bool SMALL, int R = 2>
 __global__ __launch_bounds__(kBlock) TSGU_RP_OCC void csr_rowpack_kernel(const RpParams P) {
     using T = VT<V>;
     constexpr int VEC = T::kWide;
     constexpr int GROUP = CL * EP;
-    constexpr int GPB = kBlock / GROUP;  // lane groups (row pairs) per workgroup
-    constexpr int RPB = 2 * GPB;         // rows per workgroup
+    constexpr int GPB = kBlock / GROUP;  // lane groups per workgroup
+    constexpr int RPB = R * GPB;         // rows per workgroup
+    constexpr int MAXQ = kRpMaxQ * R / 2;  // staged values per workgroup <= MAXQ * 256
     // gathers in flight per lane; the bf16 backward keeps 8 floats per gathered row: 3 fit 5 waves per SIMD better (C5: -11 %)
     constexpr int U = (MODE == kRpBwd && VEC == 8) ? 3 : TSGU_RP_U;
     constexpr bool kDma = std::is_same<V, float>::value;  // 4-byte values go to LDS by DMA
@@ -93,6 +97,9 @@ __global__ __launch_bounds__(kBlock) TSGU_RP_OCC void csr_rowpack_kernel(const R
     static_assert(EP == 1 || SLOTS, "several entry lanes per pair need explicit slots");
     static_assert(MODE != kRpBwd || PERM, "the backward always walks the transposed pattern");
     static_assert(MODE != kRpSddmm || (!PERM && !SLOTS), "SDDMM walks the pattern in stored order");
+    static_assert(R == 2 || (R == 4 && !SLOTS), "quads walk ownership-bit records");
+    constexpr int kOwnShift = 32 - R;                      // ownership bits live in the top R bits of the column word
+    constexpr uint32_t kColMask = (1u << kOwnShift) - 1u;
 
     extern __shared__ uint4 rp_smem[];
     int* s_ucol = reinterpret_cast<int*>(rp_smem);
@@ -110,14 +117,14 @@ __global__ __launch_bounds__(kBlock) TSGU_RP_OCC void csr_rowpack_kernel(const R
     if (P.order) vb = P.order[vb];
     const I* __restrict__ ptr = static_cast<const I*>(P.ptr);
     const V* __restrict__ val = static_cast<const V*>(P.val);
-    const int64_t npairs = (P.n_rows + 1) / 2;
+    const int64_t ngroups = (P.n_rows + R - 1) / R;
     const bool dict = P.wcls != nullptr;
 
     // ---- where this workgroup's records live -------------------------------------------------------------
     const int* up;         // GPB+1 union offsets of the lane-group slots
     int64_t urec;          // first union record of the workgroup inside ucol / upos
     const int* sp = nullptr;  // the workgroup's slice of sperm
-    int64_t pair;
+    int64_t pair;          // index of the row group (pair / quad) this lane group owns
     int64_t colbase = 0;   // added to every (relative) union column
     int permbase = 0;      // added to every (relative) value position
     int64_t e0 = 0;        // first entry of the workgroup (plans whose values are read in stored order)
@@ -157,19 +164,21 @@ __global__ __launch_bounds__(kBlock) TSGU_RP_OCC void csr_rowpack_kernel(const R
             if (!dict) sp = P.sperm + e0;
         }
     }
-    const bool pair_ok = pair >= 0 && pair < npairs;
-    const int64_t ra = 2 * pair, rb = 2 * pair + 1;
-    const bool b_ok = rb < P.n_rows;
+    const bool pair_ok = pair >= 0 && pair < ngroups;
+    const int64_t row_first = R * pair;
+    bool row_ok[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) row_ok[r] = pair_ok && row_first + r < P.n_rows;
     const int u0 = up[0];
     const int nu = up[GPB] - u0;
     const int lo = pair_ok ? up[grp] - u0 : 0;
     const int hi = pair_ok ? up[grp + 1] - u0 : 0;
 
     // ---- phase A: union records and values of the workgroup's rows -> LDS ----
-    int qv[kRpMaxQ];
+    int qv[PERM ? MAXQ : 1];
     if constexpr (PERM) {
 #pragma unroll
-        for (int q = 0; q < kRpMaxQ; ++q) {
+        for (int q = 0; q < MAXQ; ++q) {
             const int t = q * kBlock + tid;
             qv[q] = 0;
             if (q * kBlock < ne) {
@@ -197,11 +206,11 @@ __global__ __launch_bounds__(kBlock) TSGU_RP_OCC void csr_rowpack_kernel(const R
     }
     if constexpr (MODE != kRpSddmm) {  // SDDMM reads no values
 #pragma unroll
-        for (int q = 0; q < kRpMaxQ; ++q) {
+        for (int q = 0; q < MAXQ; ++q) {
             const int t = q * kBlock + tid;
             if (q * kBlock < ne) {
                 if (t < ne) {
-                    const V* vsrc = PERM ? val + qv[q] : val + e0 + t;
+                    const V* vsrc = PERM ? val + qv[PERM ? q : 0] : val + e0 + t;
                     if constexpr (kDma) {
                         __builtin_amdgcn_global_load_lds((rp_glb_ptr)vsrc, (rp_lds_ptr)(s_val + q * kBlock + wave * kWave), 4, 0, PERM ? 0 : 2);
                     } else {
@@ -211,17 +220,24 @@ __global__ __launch_bounds__(kBlock) TSGU_RP_OCC void csr_rowpack_kernel(const R
             }
         }
     }
-    float own_a[VEC], own_b[VEC], acc_a[VEC], acc_b[VEC];
+    float own[MODE != kRpSpmm ? R : 1][VEC], acc[R][VEC];
 #pragma unroll
-    for (int v = 0; v < VEC; ++v) own_a[v] = own_b[v] = acc_a[v] = acc_b[v] = 0.f;
+    for (int r = 0; r < R; ++r) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[r][v] = 0.f;
+    }
     if constexpr (MODE != kRpSpmm) {
         const V* __restrict__ Own = static_cast<const V*>(P.Own);
-        if (pair_ok) load_vec<V, VEC>(Own + ra * P.ldown + cl * VEC, own_a);
-        if (pair_ok && b_ok) load_vec<V, VEC>(Own + rb * P.ldown + cl * VEC, own_b);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) own[r][v] = 0.f;
+            if (row_ok[r]) load_vec<V, VEC>(Own + (row_first + r) * P.ldown + cl * VEC, own[r]);
+        }
     }
     __syncthreads();
 
-    // ---- phase B: walk the union of the pair's columns; one gather serves both rows ----
+    // ---- phase B: walk the union of the group's columns; one gather serves every row that owns the column ----
     // dense row c starts at byte c·ld·sizeof(V) of a wave-uniform base: when the operand is smaller than 4 GiB and the
     // factors fit 24 bits (launcher checks) the offset is ONE full-rate v_mad_u32_u24 and the load uses the SGPR-base
     // form, instead of a quarter-rate 64-bit multiply-add + 64-bit shift-add per gather (the phase is VALU-issue-bound)
@@ -237,22 +253,22 @@ __global__ __launch_bounds__(kBlock) TSGU_RP_OCC void csr_rowpack_kernel(const R
         }
     };
 
-    auto use = [&](const float (&g)[VEC], uint32_t half, float (&acc)[VEC], const float (&own)[VEC]) {
-        if (!(half & kRpAbsent)) {  // uniform inside the CL lanes of an entry lane, divergent across the wave: exec-masked
-            const float a = s_val[half];
-#pragma unroll
-            for (int v = 0; v < VEC; ++v) acc[v] = fma(a, g[v], acc[v]);
-            if constexpr (MODE == kRpBwd) {
-                float d = own[0] * g[0];
-#pragma unroll
-                for (int v = 1; v < VEC; ++v) d = fma(own[v], g[v], d);
-                d = group_sum<float, CL>(d);
-                if (cl == 0) s_val[half] = d;
-            }
-        }
-    };
-
     if constexpr (SLOTS) {
+        auto use = [&](const float (&g)[VEC], uint32_t half, float (&a_)[VEC], const float (&own_)[VEC]) {
+            if (!(half & kRpAbsent)) {  // uniform inside the CL lanes of an entry lane, divergent across the wave: exec-masked
+                const float a = s_val[half];
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) a_[v] = fma(a, g[v], a_[v]);
+                if constexpr (MODE == kRpBwd) {
+                    float d = own_[0] * g[0];
+#pragma unroll
+                    for (int v = 1; v < VEC; ++v) d = fma(own_[v], g[v], d);
+                    d = group_sum<float, CL>(d);
+                    if (cl == 0) s_val[half] = d;
+                }
+            }
+        };
+        constexpr int OB = MODE != kRpSpmm ? 1 : 0;  // own[] has one row only for SpMM (unused)
         int i = lo + ep;
         for (; i + (U - 1) * EP < hi; i += U * EP) {
             int c[U];
@@ -267,8 +283,8 @@ __global__ __launch_bounds__(kBlock) TSGU_RP_OCC void csr_rowpack_kernel(const R
             for (int u = 0; u < U; ++u) gather(c[u], g[u]);
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                use(g[u], w[u] & 0xffffu, acc_a, own_a);
-                use(g[u], w[u] >> 16, acc_b, own_b);
+                use(g[u], w[u] & 0xffffu, acc[0], own[0]);
+                use(g[u], w[u] >> 16, acc[1], own[OB]);
             }
         }
         for (; i < hi; i += EP) {
@@ -276,37 +292,41 @@ __global__ __launch_bounds__(kBlock) TSGU_RP_OCC void csr_rowpack_kernel(const R
             const uint32_t w = s_upos[i];
             float g[VEC];
             gather(c, g);
-            use(g, w & 0xffffu, acc_a, own_a);
-            use(g, w >> 16, acc_b, own_b);
+            use(g, w & 0xffffu, acc[0], own[0]);
+            use(g, w >> 16, acc[1], own[OB]);
         }
         if constexpr (EP > 1) {
 #pragma unroll
-            for (int v = 0; v < VEC; ++v) {
-                acc_a[v] = ep_sum<float, CL, EP>(acc_a[v]);
-                acc_b[v] = ep_sum<float, CL, EP>(acc_b[v]);
+            for (int r = 0; r < R; ++r) {
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) acc[r][v] = ep_sum<float, CL, EP>(acc[r][v]);
             }
         }
     } else {
         // values in walked order: the slots of a row are consecutive, so the record only says WHICH rows own the column
-        // (bits 30 / 31 of ucol) and two running counters replace the slot words (no upos stream, half the record LDS)
+        // (top R bits of ucol) and R running counters replace the slot words (no upos stream, half the record LDS)
         int i = lo;
-        int ka = pair_ok ? (int)((int64_t)ptr[ra] - e0) : 0;
-        int kb = (pair_ok && b_ok) ? (int)((int64_t)ptr[rb] - e0) : 0;
-        auto use_seq = [&](const float (&g)[VEC], bool present, int& k, float (&acc)[VEC], const float (&own)[VEC]) {
-            if (present) {
-                if constexpr (MODE == kRpSddmm) {
-                    // gradient of the stored entry: <row operand, gathered column operand>, into the entry's slot
-                    float d = own[0] * g[0];
+        int k[R];
 #pragma unroll
-                    for (int v = 1; v < VEC; ++v) d = fma(own[v], g[v], d);
-                    d = group_sum<float, CL>(d);
-                    if (cl == 0) s_val[k] = d;
-                } else {
-                    const float a = s_val[k];
+        for (int r = 0; r < R; ++r) k[r] = row_ok[r] ? (int)((int64_t)ptr[row_first + r] - e0) : 0;
+        auto use_seq = [&](const float (&g)[VEC], uint32_t w) {
 #pragma unroll
-                    for (int v = 0; v < VEC; ++v) acc[v] = fma(a, g[v], acc[v]);
+            for (int r = 0; r < R; ++r) {
+                if ((w >> (kOwnShift + r)) & 1u) {
+                    if constexpr (MODE == kRpSddmm) {
+                        // gradient of the stored entry: <row operand, gathered column operand>, into the entry's slot
+                        float d = own[r][0] * g[0];
+#pragma unroll
+                        for (int v = 1; v < VEC; ++v) d = fma(own[r][v], g[v], d);
+                        d = group_sum<float, CL>(d);
+                        if (cl == 0) s_val[k[r]] = d;
+                    } else {
+                        const float a = s_val[k[r]];
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) acc[r][v] = fma(a, g[v], acc[r][v]);
+                    }
+                    ++k[r];
                 }
-                ++k;
             }
         };
         for (; i + U <= hi; i += U) {
@@ -315,34 +335,32 @@ __global__ __launch_bounds__(kBlock) TSGU_RP_OCC void csr_rowpack_kernel(const R
 #pragma unroll
             for (int u = 0; u < U; ++u) w[u] = (uint32_t)s_ucol[i + u];
 #pragma unroll
-            for (int u = 0; u < U; ++u) gather((int)(w[u] & 0x3fffffffu), g[u]);
+            for (int u = 0; u < U; ++u) gather((int)(w[u] & kColMask), g[u]);
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                use_seq(g[u], (w[u] >> 30) & 1u, ka, acc_a, own_a);
-                use_seq(g[u], w[u] >> 31, kb, acc_b, own_b);
-            }
+            for (int u = 0; u < U; ++u) use_seq(g[u], w[u]);
         }
         for (; i < hi; ++i) {
             const uint32_t w = (uint32_t)s_ucol[i];
             float g[VEC];
-            gather((int)(w & 0x3fffffffu), g);
-            use_seq(g, (w >> 30) & 1u, ka, acc_a, own_a);
-            use_seq(g, w >> 31, kb, acc_b, own_b);
+            gather((int)(w & kColMask), g);
+            use_seq(g, w);
         }
     }
 
     if constexpr (MODE != kRpSddmm) {
         V* __restrict__ out = static_cast<V*>(P.out);
-        if (pair_ok && ep == 0) {
-            store_vec<V, VEC, true>(out + ra * P.ldo + cl * VEC, acc_a);
-            if (b_ok) store_vec<V, VEC, true>(out + rb * P.ldo + cl * VEC, acc_b);
+        if (ep == 0) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                if (row_ok[r]) store_vec<V, VEC, true>(out + (row_first + r) * P.ldo + cl * VEC, acc[r]);
+            }
         }
     } else {
         // the block's gradients sit in stored order in LDS: one coalesced, streaming write
         __syncthreads();
         V* __restrict__ gout = static_cast<V*>(P.gradA);
 #pragma unroll
-        for (int q = 0; q < kRpMaxQ; ++q) {
+        for (int q = 0; q < MAXQ; ++q) {
             const int t = q * kBlock + tid;
             if (q * kBlock < ne) {
                 if (t < ne) {
@@ -358,7 +376,7 @@ __global__ __launch_bounds__(kBlock) TSGU_RP_OCC void csr_rowpack_kernel(const R
         __syncthreads();
         V* __restrict__ gout = static_cast<V*>(P.gradA);
 #pragma unroll
-        for (int q = 0; q < kRpMaxQ; ++q) {
+        for (int q = 0; q < MAXQ; ++q) {
             const int t = q * kBlock + tid;
             if (q * kBlock < ne) {
                 if (t < ne) gout[qv[q]] = T::down(s_val[t]);
@@ -387,10 +405,12 @@ int rp_launch(RpParams P, hipStream_t stream) {
     if (P.lds_ % vec != 0 || !aligned16(P.S)) return TSGU_ERR_BAD_ARG;
     if (MODE != kRpSddmm && (P.ldo % vec != 0 || !aligned16(P.out))) return TSGU_ERR_BAD_ARG;
     if (MODE != kRpSpmm && (P.ldown % vec != 0 || !aligned16(P.Own))) return TSGU_ERR_BAD_ARG;
-    if (P.ecap <= 0 || P.ucap <= 0 || P.ecap > kRpMaxQ * kBlock || P.ucap > kRpMaxU * kBlock || P.ecap >= kRpAbsent ||
+    const int rg = P.rgroup == 0 ? 2 : P.rgroup;
+    const bool slots = PERM || P.upos != nullptr;
+    if (rg != 2 && (rg != 4 || slots || ep != 1)) return TSGU_ERR_BAD_ARG;   // quads: ownership-bit records, one entry lane
+    if (P.ecap <= 0 || P.ucap <= 0 || P.ecap > kRpMaxQ * (rg / 2) * kBlock || P.ucap > kRpMaxU * kBlock || P.ecap >= kRpAbsent ||
         P.ucap % 4 != 0 || P.lds_ > 0xffffffffLL)
         return TSGU_ERR_BAD_ARG;
-    const bool slots = PERM || P.upos != nullptr;
     if (!slots && ep != 1) return TSGU_ERR_BAD_ARG;      // several entry lanes per pair need explicit slots
     if (MODE == kRpSddmm && slots) return TSGU_ERR_BAD_ARG;
     const int64_t gpb = kBlock / (cl * ep);
@@ -399,52 +419,52 @@ int rp_launch(RpParams P, hipStream_t stream) {
     } else if (P.vpair) {
         if (!PERM || !P.eptr) return TSGU_ERR_BAD_ARG;
     }
-    if (!(P.vpair || P.wcls)) {
-        if (P.nblocks != (P.n_rows + 2 * gpb - 1) / (2 * gpb)) return TSGU_ERR_BAD_ARG;  // consecutive ownership
-    } else if (!PERM && P.nblocks != (P.n_rows + 2 * gpb - 1) / (2 * gpb)) {
-        return TSGU_ERR_BAD_ARG;  // values in stored order are one contiguous range per workgroup
-    }
+    // without a permutation (or without vpair / classes) a workgroup owns rg·gpb consecutive rows
+    if ((!PERM || !(P.vpair || P.wcls)) && P.nblocks != (P.n_rows + rg * gpb - 1) / (rg * gpb)) return TSGU_ERR_BAD_ARG;
     if (P.nblocks > 0x7fffffffLL) return TSGU_ERR_TOO_LARGE;
     if (P.nblocks <= 0) return P.n_rows == 0 ? TSGU_OK : TSGU_ERR_BAD_ARG;
     const size_t lds = (size_t)P.ucap * (slots ? 8 : 4) + (size_t)P.ecap * 4;
-    if (!slots && P.n_src >= (1ll << 30)) return TSGU_ERR_TOO_LARGE;  // ownership bits live in bits 30 / 31 of ucol
+    if (!slots && P.n_src >= (1ll << (32 - rg))) return TSGU_ERR_TOO_LARGE;  // ownership bits live in the top bits of ucol
     if (lds > 64 * 1024) return TSGU_ERR_TOO_LARGE;
     const dim3 grid((unsigned)P.nblocks), block(kBlock);
     // 32-bit byte offsets into the gathered operand: rows < 2^24, row pitch < 2^24 bytes, whole operand < 4 GiB
     const int64_t pitch = P.lds_ * (int64_t)sizeof(V);
     const bool small = P.n_src < (1ll << 24) && pitch < (1ll << 24) && P.n_src * pitch < (1ll << 32);
-#define TSGU_RP_GO(CLV, EPV, SL)                                                                                              \
+#define TSGU_RP_GO(CLV, EPV, SL, RG)                                                                                          \
     do {                                                                                                                     \
-        if (small) hipLaunchKernelGGL((csr_rowpack_kernel<V, I, CLV, EPV, MODE, PERM, SL, true>), grid, block, lds, stream, P);  \
-        else hipLaunchKernelGGL((csr_rowpack_kernel<V, I, CLV, EPV, MODE, PERM, SL, false>), grid, block, lds, stream, P);       \
+        if (small) hipLaunchKernelGGL((csr_rowpack_kernel<V, I, CLV, EPV, MODE, PERM, SL, true, RG>), grid, block, lds, stream, P);  \
+        else hipLaunchKernelGGL((csr_rowpack_kernel<V, I, CLV, EPV, MODE, PERM, SL, false, RG>), grid, block, lds, stream, P);       \
     } while (0)
     constexpr int MG = TSGU_RP_MINGROUP;
 #define TSGU_RP_EPOF(CLV) ((CLV) >= MG ? 1 : MG / (CLV))
     if constexpr (PERM) {
         switch (cl) {
-            case 2: TSGU_RP_GO(2, TSGU_RP_EPOF(2), true); break;
-            case 4: TSGU_RP_GO(4, TSGU_RP_EPOF(4), true); break;
-            case 8: TSGU_RP_GO(8, 1, true); break;
-            case 16: TSGU_RP_GO(16, 1, true); break;
-        }
-    } else if constexpr (MODE == kRpSddmm) {
-        switch (cl) {
-            case 8: TSGU_RP_GO(8, 1, false); break;
-            case 16: TSGU_RP_GO(16, 1, false); break;
-            default: return TSGU_ERR_BAD_ARG;
+            case 2: TSGU_RP_GO(2, TSGU_RP_EPOF(2), true, 2); break;
+            case 4: TSGU_RP_GO(4, TSGU_RP_EPOF(4), true, 2); break;
+            case 8: TSGU_RP_GO(8, 1, true, 2); break;
+            case 16: TSGU_RP_GO(16, 1, true, 2); break;
         }
     } else {
         if (slots) {
+            if constexpr (MODE == kRpSddmm) return TSGU_ERR_BAD_ARG;
+            else {
+                switch (cl) {
+                    case 2: TSGU_RP_GO(2, TSGU_RP_EPOF(2), true, 2); break;
+                    case 4: TSGU_RP_GO(4, TSGU_RP_EPOF(4), true, 2); break;
+                    case 8: TSGU_RP_GO(8, 1, true, 2); break;
+                    case 16: TSGU_RP_GO(16, 1, true, 2); break;
+                }
+            }
+        } else if (rg == 4) {
             switch (cl) {
-                case 2: TSGU_RP_GO(2, TSGU_RP_EPOF(2), true); break;
-                case 4: TSGU_RP_GO(4, TSGU_RP_EPOF(4), true); break;
-                case 8: TSGU_RP_GO(8, 1, true); break;
-                case 16: TSGU_RP_GO(16, 1, true); break;
+                case 8: TSGU_RP_GO(8, 1, false, 4); break;
+                case 16: TSGU_RP_GO(16, 1, false, 4); break;
+                default: return TSGU_ERR_BAD_ARG;
             }
         } else {
             switch (cl) {
-                case 8: TSGU_RP_GO(8, 1, false); break;
-                case 16: TSGU_RP_GO(16, 1, false); break;
+                case 8: TSGU_RP_GO(8, 1, false, 2); break;
+                case 16: TSGU_RP_GO(16, 1, false, 2); break;
                 default: return TSGU_ERR_BAD_ARG;
             }
         }
