@@ -35,9 +35,12 @@ def _need_gpu_and_extension():
 def _plans_at_first_sight(monkeypatch):
     """The product builds row-pair plans when a pattern comes back (`_ops.PLAN_AFTER_USES`); the parity tests
     use every pattern once, so they ask for the plans at first sight.  test_plan_policy_* covers the default."""
-    from torchsparsegradutils_amd import _ops
+    from torchsparsegradutils_amd import _ops, _pattern
 
     monkeypatch.setattr(_ops, "PLAN_AFTER_USES", 0)
+    # the suite asserts plan forms: pin the policy switches to their defaults whatever TSGU_* the environment carries
+    monkeypatch.setattr(_ops, "ENABLE_PACK", True)
+    monkeypatch.setattr(_pattern, "DEDUP_MODE", "auto")
     yield
 
 
