@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""Randomised comparison of the public ops with DENSE fp64 autograd on the GPU (shapes, densities, dtypes, layouts,
+index dtypes, p, batch, flags drawn at random; row-pair kernels forced on for half of the cases).  Prints the worst
+normwise errors per op and exits non-zero on a violation.      python tools/fuzz_gpu.py [--cases 300] [--seed 0]"""
+import argparse
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torchsparsegradutils_amd as T  # noqa: E402
+from torchsparsegradutils_amd import _ops, _pattern  # noqa: E402
+from torchsparsegradutils_amd.utils import stack_csr  # noqa: E402
+
+DEV = "cuda:0"
+TOL = {torch.float32: 2e-5, torch.float64: 1e-11, torch.bfloat16: 2e-2}
+
+
+def nerr(a, b):
+    a, b = a.double(), b.double()
+    d = float((a - b).abs().max())
+    s = float(b.abs().max())
+    return d / s if s > 0 else d
+
+
+def sparse_from_dense(Ad, layout, idt):
+    if layout == "coo":
+        return Ad.to_sparse_coo()
+    if Ad.dim() == 2:
+        c = Ad.to_sparse_csr()
+        return torch.sparse_csr_tensor(c.crow_indices().to(idt), c.col_indices().to(idt), c.values(), c.shape)
+    parts = []
+    for a in Ad:
+        c = a.to_sparse_csr()
+        parts.append(torch.sparse_csr_tensor(c.crow_indices().to(idt), c.col_indices().to(idt), c.values(), c.shape))
+    return stack_csr(parts)
+
+
+def rand_pattern(g, n, m, kind, per_row):
+    if kind == "band":
+        rows = torch.arange(n).repeat_interleave(per_row)
+        cols = (rows * m // max(n, 1) + torch.randint(-per_row, per_row + 1, rows.shape, generator=g)).clamp(0, m - 1)
+    else:
+        nnz = min(n * per_row, n * m)
+        flat = torch.randperm(n * m, generator=g)[:nnz]
+        rows, cols = flat // m, flat % m
+    keep = torch.rand(rows.shape, generator=g) > 0.15   # ragged rows, some empty
+    mask = torch.zeros(n, m, dtype=torch.bool)
+    mask[rows[keep], cols[keep]] = True
+    return mask
+
+
+def case_mm(g, i):
+    vd = [torch.float32, torch.float32, torch.float64, torch.bfloat16][i % 4]
+    layout = ["csr", "coo"][(i // 4) % 2]
+    idt = [torch.int32, torch.int64][(i // 8) % 2]
+    batched = (i % 7 == 0)
+    n = int(torch.randint(1, 1500, (1,), generator=g))
+    m = int(torch.randint(1, 1500, (1,), generator=g))
+    p = [1, 3, 4, 8, 16, 32, 33, 64, 100, 128][int(torch.randint(0, 10, (1,), generator=g))]
+    per_row = int(torch.randint(1, 24, (1,), generator=g))
+    kind = ["band", "rand"][i % 2]
+    b = int(torch.randint(2, 5, (1,), generator=g)) if batched else 0
+    if vd == torch.bfloat16 and layout == "coo" and batched:
+        vd = torch.float32
+    if batched:
+        n, m = min(n, 300), min(m, 300)
+        mask = rand_pattern(g, n, m, kind, per_row)
+        if layout == "csr":       # batched CSR: equal nnz per item = same pattern here
+            masks = [mask] * b
+        else:
+            masks = [rand_pattern(g, n, m, kind, per_row) for _ in range(b)]
+        Ad = torch.stack([torch.where(mk, torch.randn(n, m, dtype=torch.float64, generator=g) + 0.01, torch.zeros((), dtype=torch.float64)) for mk in masks])
+        B = torch.randn(b, m, p, dtype=torch.float64, generator=g)
+    else:
+        mask = rand_pattern(g, n, m, kind, per_row)
+        Ad = torch.where(mask, torch.randn(n, m, dtype=torch.float64, generator=g) + 0.01, torch.zeros((), dtype=torch.float64))
+        B = torch.randn(m, p, dtype=torch.float64, generator=g)
+    if int((Ad != 0).sum()) == 0:
+        return None
+    Ad, B = Ad.to(vd).to(DEV), B.to(vd).to(DEV)
+    A = sparse_from_dense(Ad, layout, idt).requires_grad_(True)
+    Bs = B.clone().requires_grad_(True)
+    Adg = Ad.double().clone().requires_grad_(True)
+    Bdg = B.double().clone().requires_grad_(True)
+    out = T.sparse_mm(A, Bs)
+    ref = Adg @ Bdg
+    G = torch.randn(ref.shape, dtype=torch.float64, generator=g).to(vd).to(DEV)
+    out.backward(G)
+    ref.backward(G.double())
+    gA = A.grad.to_dense() if vd != torch.bfloat16 or layout == "coo" else None
+    if gA is None:
+        Ag = A.grad
+        gA = torch.zeros_like(Ad)
+        if Ag.dim() == 2:
+            rows = torch.repeat_interleave(torch.arange(n, device=DEV), Ag.crow_indices().long().diff())
+            gA[rows, Ag.col_indices().long()] = Ag.values()
+        else:
+            gA = torch.stack([torch.sparse_csr_tensor(Ag.crow_indices()[k], Ag.col_indices()[k], Ag.values()[k].float(), (n, m)).to_dense() for k in range(b)]).to(vd)
+    errs = (nerr(out, ref), nerr(gA, Adg.grad * (Ad != 0)), nerr(Bs.grad, Bdg.grad))
+    desc = f"mm {layout} {vd} {idt} n={n} m={m} p={p} per_row={per_row} {kind} batch={b}"
+    return desc, vd, errs
+
+
+def case_tri(g, i):
+    vd = [torch.float32, torch.float64][i % 2]
+    layout = ["csr", "coo"][(i // 2) % 2]
+    idt = [torch.int32, torch.int64][(i // 4) % 2]
+    upper, unit, transpose = bool(i & 8), bool(i & 16), bool(i & 32)
+    n = int(torch.randint(1, 700, (1,), generator=g))
+    p = [1, 2, 4, 8, 9, 32, 70][int(torch.randint(0, 7, (1,), generator=g))]
+    per_row = int(torch.randint(1, 12, (1,), generator=g))
+    mask = rand_pattern(g, n, n, "band", per_row)
+    mask = torch.triu(mask, 1) if upper else torch.tril(mask, -1)
+    M = torch.where(mask, torch.rand(n, n, dtype=torch.float64, generator=g) * 0.2 / per_row, torch.zeros((), dtype=torch.float64))
+    if not unit:
+        M = M + torch.diag(1.0 + torch.rand(n, dtype=torch.float64, generator=g))
+    if int((M != 0).sum()) == 0:
+        return None
+    B = torch.randn(n, p, dtype=torch.float64, generator=g)
+    Ad, B = M.to(vd).to(DEV), B.to(vd).to(DEV)
+    A = sparse_from_dense(Ad, layout, idt).requires_grad_(True)
+    Bs = B.clone().requires_grad_(True)
+    Adg = Ad.double().clone().requires_grad_(True)
+    Bdg = B.double().clone().requires_grad_(True)
+    X = T.sparse_triangular_solve(A, Bs, upper=upper, unitriangular=unit, transpose=transpose)
+    Aop = Adg.transpose(-1, -2) if transpose else Adg
+    ref = torch.linalg.solve_triangular(Aop, Bdg, upper=upper != transpose, unitriangular=unit)
+    Gr = torch.randn(ref.shape, dtype=torch.float64, generator=g).to(vd).to(DEV)
+    X.backward(Gr)
+    ref.backward(Gr.double())
+    gmask = (Ad != 0)
+    errs = (nerr(X, ref), nerr(A.grad.to_dense(), Adg.grad * gmask), nerr(Bs.grad, Bdg.grad))
+    return f"tri {layout} {vd} {idt} n={n} p={p} per_row={per_row} upper={upper} unit={unit} T={transpose}", vd, errs
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=300)
+    ap.add_argument("--seed", type=int, default=0)
+    a = ap.parse_args()
+    g = torch.Generator().manual_seed(a.seed)
+    worst = {}
+    bad = 0
+    for i in range(a.cases):
+        force = i % 2 == 0
+        _ops.PACK_MIN_NNZ = 0 if force else 1 << 16
+        _ops.PLAN_AFTER_USES = 0 if force else 1
+        _pattern.DEDUP_MODE = ["auto", "force", "off"][i % 3]
+        fn = case_tri if i % 5 == 4 else case_mm
+        try:
+            r = fn(g, i)
+        except Exception as exc:  # noqa: BLE001
+            print(f"case {i}: EXCEPTION {exc!r}")
+            bad += 1
+            continue
+        if r is None:
+            continue
+        desc, vd, errs = r
+        tol = TOL[vd] * (50 if desc.startswith("tri") else 1)
+        key = (desc.split()[0], str(vd))
+        worst[key] = max(worst.get(key, 0.0), max(errs))
+        if not all(e == e and e <= tol for e in errs):
+            print(f"case {i}: {desc}: errors {errs} > {tol}")
+            bad += 1
+    for k, v in sorted(worst.items()):
+        print(f"worst {k}: {v:.3g}")
+    print(f"{a.cases} cases, {bad} violations")
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
