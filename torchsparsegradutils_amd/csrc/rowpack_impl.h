@@ -56,6 +56,7 @@ struct RpParams {
     int64_t nblocks;
 };
 
+typedef float rp_f2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) void* rp_lds_ptr;
 typedef const __attribute__((address_space(1))) void* rp_glb_ptr;
 
@@ -234,12 +235,21 @@ __global__ __launch_bounds__(kBlock) TSGU_RP_OCC void csr_rowpack_kernel(const R
             }
         }
     }
-    float own[MODE != kRpSpmm ? R : 1][VEC], acc[R][VEC];
+    // The accumulators are explicit PAIRS (elements 2h, 2h+1 = the two halves of a loaded 8-byte word): left to itself
+    // the vectoriser pairs elements (1,2) and (0,3) of a row in the slotted kernels and pays three register moves per
+    // update to feed its packed FMAs (13 of the 58 VALU instructions per 4 union entries of the transposed walk).
+    float own[MODE != kRpSpmm ? R : 1][VEC];
+    rp_f2 acc2[R][VEC / 2];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) acc[r][v] = 0.f;
+        for (int h = 0; h < VEC / 2; ++h) acc2[r][h] = rp_f2{0.f, 0.f};
     }
+    auto axpy = [](float a, const float (&g)[VEC], rp_f2 (&a2)[VEC / 2]) {
+        const rp_f2 av = {a, a};
+#pragma unroll
+        for (int h = 0; h < VEC / 2; ++h) a2[h] = __builtin_elementwise_fma(av, rp_f2{g[2 * h], g[2 * h + 1]}, a2[h]);
+    };
     if constexpr (MODE != kRpSpmm) {
         const V* __restrict__ Own = static_cast<const V*>(P.Own);
 #pragma unroll
@@ -273,11 +283,10 @@ __global__ __launch_bounds__(kBlock) TSGU_RP_OCC void csr_rowpack_kernel(const R
     };
 
     if constexpr (SLOTS) {
-        auto use = [&](const float (&g)[VEC], uint32_t half, float (&a_)[VEC], const float (&own_)[VEC]) {
+        auto use = [&](const float (&g)[VEC], uint32_t half, rp_f2 (&a_)[VEC / 2], const float (&own_)[VEC]) {
             if (!(half & kRpAbsent)) {  // uniform inside the CL lanes of an entry lane, divergent across the wave: exec-masked
                 const float a = s_val[half];
-#pragma unroll
-                for (int v = 0; v < VEC; ++v) a_[v] = fma(a, g[v], a_[v]);
+                axpy(a, g, a_);
 #if !defined(TSGU_RP_NODOT)
                 if constexpr (MODE == kRpBwd) {
                     float d = own_[0] * g[0];
@@ -307,8 +316,8 @@ __global__ __launch_bounds__(kBlock) TSGU_RP_OCC void csr_rowpack_kernel(const R
             for (int u = 0; u < U; ++u) gather(c[u], g[u]);
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                use(g[u], w[u] & 0xffffu, acc[0], own[0]);
-                use(g[u], w[u] >> 16, acc[1], own[OB]);
+                use(g[u], w[u] & 0xffffu, acc2[0], own[0]);
+                use(g[u], w[u] >> 16, acc2[1], own[OB]);
             }
         }
         for (; i < hi; i += EP) {
@@ -316,14 +325,17 @@ __global__ __launch_bounds__(kBlock) TSGU_RP_OCC void csr_rowpack_kernel(const R
             const uint32_t w = s_upos[i];
             float g[VEC];
             gather(c, g);
-            use(g, w & 0xffffu, acc[0], own[0]);
-            use(g, w >> 16, acc[1], own[OB]);
+            use(g, w & 0xffffu, acc2[0], own[0]);
+            use(g, w >> 16, acc2[1], own[OB]);
         }
         if constexpr (EP > 1) {
 #pragma unroll
             for (int r = 0; r < R; ++r) {
 #pragma unroll
-                for (int v = 0; v < VEC; ++v) acc[r][v] = ep_sum<float, CL, EP>(acc[r][v]);
+                for (int h = 0; h < VEC / 2; ++h) {
+                    acc2[r][h].x = ep_sum<float, CL, EP>(acc2[r][h].x);
+                    acc2[r][h].y = ep_sum<float, CL, EP>(acc2[r][h].y);
+                }
             }
         }
     } else {
@@ -346,8 +358,7 @@ __global__ __launch_bounds__(kBlock) TSGU_RP_OCC void csr_rowpack_kernel(const R
                         if (cl == 0) s_val[k[r]] = d;
                     } else {
                         const float a = s_val[k[r]];
-#pragma unroll
-                        for (int v = 0; v < VEC; ++v) acc[r][v] = fma(a, g[v], acc[r][v]);
+                        axpy(a, g, acc2[r]);
                     }
                     ++k[r];
                 }
@@ -377,13 +388,21 @@ __global__ __launch_bounds__(kBlock) TSGU_RP_OCC void csr_rowpack_kernel(const R
     if constexpr (MODE != kRpSddmm) {
         V* __restrict__ out = static_cast<V*>(P.out);
 #if defined(TSGU_RP_NOSTORE)
-        if (ep == 0 && acc[0][0] == 12345.678f) {   // never true
+        if (ep == 0 && acc2[0][0].x == 12345.678f) {   // never true
 #else
         if (ep == 0) {
 #endif
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                if (row_ok[r]) store_vec<V, VEC, true>(out + (row_first + r) * P.ldo + cl * VEC, acc[r]);
+                if (row_ok[r]) {
+                    float res[VEC];
+#pragma unroll
+                    for (int h = 0; h < VEC / 2; ++h) {
+                        res[2 * h] = acc2[r][h].x;
+                        res[2 * h + 1] = acc2[r][h].y;
+                    }
+                    store_vec<V, VEC, true>(out + (row_first + r) * P.ldo + cl * VEC, res);
+                }
             }
         }
     } else {
