@@ -144,7 +144,9 @@ int tsgu_csr_mm_backward(int vtype, int itype, int64_t n_rows, int64_t n_cols, i
  *
  * STREAM FORM (nclasses == 0) — one record per union entry / stored entry of the whole matrix
  *   uptr [nblocks·G+1]   union-entry offsets per lane-group slot (slot s of workgroup b = b·G + s)
- *   ucol [nu]            dense-row index of each union entry (ascending inside a pair).  Without upos, bits 30 / 31
+ *   ucol [nu]            dense-row index of each union entry (ascending inside a pair when there is no upos; plans
+ *                        with upos may list a pair's entries in any order — only the order of summation inside a row
+ *                        follows it).  Without upos, bits 30 / 31
  *                        say whether row 2q / 2q+1 owns the column (n_cols < 2^30) and the value slots of a row are
  *                        consecutive in the workgroup's staged value slice.
  *   upos [nu]            optional: two 16-bit halves (low: row 2q, high: row 2q+1) = slot of that row's value in the

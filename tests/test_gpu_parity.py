@@ -455,8 +455,10 @@ def test_plan_policy_first_sight_runs_plan_free_then_builds_and_releases(monkeyp
         core = _pattern.from_csr(A.detach()).core
         built = bool(core.packs) and core.t is not None and bool(core.t.core.packs)
         assert built == (it >= 1), (it, core.packs)
-    for a, b_ in zip(outs[0], outs[2]):
-        assert torch.equal(a, b_)
+    # forward and gradA: same order of summation in both kernel families; gradB rows are summed plane-rotated by the
+    # brick plans of a 3-D lattice (see _pattern.BRICK_ROTATE): equal to rounding
+    assert torch.equal(outs[0][0], outs[2][0]) and torch.equal(outs[0][1], outs[2][1])
+    assert torch.equal(outs[0][2], outs[2][2]) if not _pattern.BRICK_ROTATE else rel(outs[2][2], outs[0][2].cpu().numpy()) < 2e-6
     entries, nbytes = _pattern.cache_stats()
     assert entries == 1 and nbytes > 0
     del A, C, gA, gB, outs, core
@@ -467,7 +469,7 @@ def test_plan_policy_first_sight_runs_plan_free_then_builds_and_releases(monkeyp
 def test_plan_policy_asynchronous_build_never_stalls_a_step(monkeypatch):
     """Default policy: from the second use on, the row-pair plans are built on a worker thread + side stream; the
     steps in between run on the plan-free kernels, `wait_for_plans()` joins, the next step switches over, and the
-    numbers agree with the plan-free ones (bit for bit here: fp32, one entry lane per pair)."""
+    numbers agree with the plan-free ones (bit for bit for the forward and gradA: fp32, one entry lane per pair)."""
     import time
 
     from torchsparsegradutils_amd import _ops, _pattern, wait_for_plans
@@ -500,8 +502,11 @@ def test_plan_policy_asynchronous_build_never_stalls_a_step(monkeypatch):
     third = step()                                   # picks the finished plans up
     assert core.packs and core.t.core.packs and not core.pending and not core.t.core.pending
     assert all(p is not None for p in core.packs.values())
-    for a, b_, c_ in zip(first, second, third):
-        assert torch.equal(a, b_) and torch.equal(a, c_)
+    for a, b_ in zip(first, second):
+        assert torch.equal(a, b_)
+    # forward and gradA keep their order of summation; gradB's rows are summed plane-rotated by the brick plans
+    assert torch.equal(first[0], third[0]) and torch.equal(first[1], third[1])
+    assert torch.equal(first[2], third[2]) if not _pattern.BRICK_ROTATE else rel(third[2], first[2].cpu().numpy()) < 2e-6
     assert dt < 0.1, f"the submitting step took {dt * 1e3:.1f} ms: it must not wait for the plan"
 
 
@@ -553,15 +558,18 @@ def test_rowpack_brick_ownership_on_lattices(kind, monkeypatch):
     gA1, gB1 = be.csr_mm_backward_rowpack(gt.crow, brick, vd, Gdev, Bd, n)
     gA0, gB0 = be.csr_mm_backward_rowpack(gt.crow, natural, vd, Gdev, Bd, n)
     assert rel(gA1, gA_o) < 1e-5 and rel(gB1, gB_o) < 1e-5
-    assert torch.equal(gA1, gA0) and torch.equal(gB1, gB0)
-    assert torch.equal(be.csr_spmm_rowpack(gt.crow, vd, brick, Gdev, n), gB0)
-    # the class-dictionary form of the same brick plan and of the natural plan: bit-identical results
+    # the dots (gradA) do not depend on the order of the walk; on 3-D lattices the bricks visit a pair's columns
+    # plane-rotated (L1 reuse between the waves of a workgroup), so gradB's rows are summed in another order there
+    rotated = len(brick.lattice) == 2 and _pattern.BRICK_ROTATE
+    assert torch.equal(gA1, gA0) and (rel(gB1, gB0.cpu().numpy()) < 2e-6 if rotated else torch.equal(gB1, gB0))
+    assert torch.equal(be.csr_spmm_rowpack(gt.crow, vd, brick, Gdev, n), gB1)
+    # the class-dictionary / stream forms of the same walks: bit-identical results
     po = _pattern.brick_pair_order(n, brick.lattice, rpb // 2, DEV)
-    for other in (_pattern.build_rowpack_plan(gt, rpb, limits, pair_order=po, lattice=brick.lattice, dedup="force"),
-                  _pattern.build_rowpack_plan(gt, rpb, limits, dedup="force"),
-                  _pattern.build_rowpack_plan(gt, rpb, limits, pair_order=po, lattice=brick.lattice, dedup="off")):
+    for other, want in ((_pattern.build_rowpack_plan(gt, rpb, limits, pair_order=po, lattice=brick.lattice, dedup="force"), gB1),
+                        (_pattern.build_rowpack_plan(gt, rpb, limits, dedup="force"), gB0),
+                        (_pattern.build_rowpack_plan(gt, rpb, limits, pair_order=po, lattice=brick.lattice, dedup="off"), gB1)):
         gA2, gB2 = be.csr_mm_backward_rowpack(gt.crow, other, vd, Gdev, Bd, n)
-        assert torch.equal(gA2, gA0) and torch.equal(gB2, gB0)
+        assert torch.equal(gA2, gA0) and torch.equal(gB2, want)
     fwd_s = be.csr_spmm_rowpack(g.crow, vd, _pattern.build_rowpack_plan(g, rpb, limits, dedup="off"), Bd, n)
     fwd_d = be.csr_spmm_rowpack(g.crow, vd, _pattern.build_rowpack_plan(g, rpb, limits, dedup="force"), Bd, n)
     assert torch.equal(fwd_s, fwd_d) and rel(fwd_d, C_o) < 1e-5

@@ -270,6 +270,7 @@ class RowPackPlan:
 _PACK_MIN_REUSE = 1.2   # stored entries per union entry (2.0 = both rows of every pair share all columns)
 _PACK_ABSENT = 0x8000
 ENABLE_BRICKS = True    # lattice patterns: permuted walks own 3-D bricks of row pairs (see brick_pair_order)
+BRICK_ROTATE = _os.environ.get("TSGU_BRICK_ROTATE", "1") == "1"   # plane-rotated record order inside bricks (L1 reuse between waves)
 
 
 def detect_lattice(g: RowGather):
@@ -400,6 +401,25 @@ def build_rowpack_plan(g: RowGather, rpb: int, limits, pair_order=None, lattice=
     if reuse < _PACK_MIN_REUSE * (1.0 if group == 2 else 1.25):
         return None
     uslot = uniq // m
+    if BRICK_ROTATE and slots and not natural and lattice is not None and len(lattice) == 2:
+        # Brick plans of a 3-D lattice: the four waves of a workgroup own the brick's four x-planes and each needs the
+        # planes x-1, x, x+1.  In ascending column order wave w reaches plane p a third of the walk after wave w+1 did —
+        # long enough for L1 to have lost it.  Rotating every pair's records by planes (wave w visits its relative
+        # plane rp in slot (rp + 1 + w) mod 3) makes the waves that share a plane fetch it at the same time; records with
+        # explicit slots may come in any order (only the order of summation inside a row changes).
+        d2 = lattice[1]
+        nxl = m // d2
+        ucolr = uniq - uslot * m
+        x_own = (2 * pair_order[uslot]) // d2
+        rp_ = (ucolr // d2 - x_own + nxl + 1) % nxl - 1          # relative plane in {-1, 0, 1} (periodic wrap)
+        wv = (uslot % gpb) // max(gpb // 4, 1)
+        phase = torch.where((rp_ >= -1) & (rp_ <= 1), (rp_ + 1 + wv) % 3, torch.full_like(rp_, 3))
+        ordr = torch.argsort((uslot * 4 + phase) * m + ucolr)
+        rank = torch.empty_like(ordr)
+        rank[ordr] = torch.arange(ordr.numel(), device=dev)
+        uniq = uniq[ordr]
+        inv = rank[inv]
+        uslot = uniq // m
     uptr = torch.zeros(nslots + 1, dtype=torch.int64, device=dev)
     uptr[1:] = torch.cumsum(torch.bincount(uslot, minlength=nslots), 0)
     ub = uptr[torch.arange(0, nslots + 1, gpb, device=dev)]
