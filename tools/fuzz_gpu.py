@@ -136,6 +136,38 @@ def case_tri(g, i):
     return f"tri {layout} {vd} {idt} n={n} p={p} per_row={per_row} upper={upper} unit={unit} T={transpose}", vd, errs
 
 
+def case_lattice(g, i):
+    """27-point periodic stencils of random (also odd / brick-indivisible) sizes: the lattice is detected, the transposed
+    walks own plane-rotated bricks, the class dictionary deduplicates them — all against dense fp64 autograd."""
+    from torchsparsegradutils_amd.utils import synthetic
+
+    vd = [torch.float32, torch.bfloat16][i % 2]
+    dims = [int(torch.randint(4, 15, (1,), generator=g)) for _ in range(3)]
+    p = [16, 32, 64, 128][int(torch.randint(0, 4, (1,), generator=g))]
+    if vd == torch.float32 and p == 16:
+        p = 32
+    n = dims[0] * dims[1] * dims[2]
+    crow, col = synthetic.stencil27_periodic(*dims, torch.int32, device=DEV)
+    if crow.diff().min() < 27:      # tiny periodic dimensions fold neighbours onto each other: still a valid CSR pattern
+        pass
+    val = (torch.randn(col.numel(), dtype=torch.float64, generator=g) + 0.01).to(vd).to(DEV)
+    A = torch.sparse_csr_tensor(crow, col, val, (n, n)).requires_grad_(True)
+    Ad = torch.sparse_csr_tensor(crow, col, val.double(), (n, n)).to_dense()
+    B = torch.randn(n, p, dtype=torch.float64, generator=g).to(vd).to(DEV)
+    Bs = B.clone().requires_grad_(True)
+    Adg = Ad.clone().requires_grad_(True)
+    Bdg = B.double().clone().requires_grad_(True)
+    out = T.sparse_mm(A, Bs)
+    ref = Adg @ Bdg
+    G = torch.randn(ref.shape, dtype=torch.float64, generator=g).to(vd).to(DEV)
+    out.backward(G)
+    ref.backward(G.double())
+    rows = torch.repeat_interleave(torch.arange(n, device=DEV), crow.long().diff())
+    gA_ref = Adg.grad[rows, col.long()]
+    errs = (nerr(out, ref), nerr(A.grad.values(), gA_ref), nerr(Bs.grad, Bdg.grad))
+    return f"lattice {vd} dims={dims} p={p}", vd, errs
+
+
 def case_solve(g, i):
     """sparse_generic_solve with each Krylov solver on a random sparse SPD band matrix vs torch.linalg.solve."""
     from torchsparsegradutils_amd import utils as U
@@ -190,7 +222,7 @@ def main():
         _ops.PACK_MIN_NNZ = 0 if force else 1 << 16
         _ops.PLAN_AFTER_USES = 0 if force else 1
         _pattern.DEDUP_MODE = ["auto", "force", "off"][i % 3]
-        fn = case_tri if i % 5 == 4 else case_solve if i % 5 == 3 else case_mm
+        fn = case_tri if i % 5 == 4 else case_solve if i % 5 == 3 else case_lattice if i % 5 == 2 else case_mm
         try:
             r = fn(g, i)
         except Exception as exc:  # noqa: BLE001
