@@ -147,6 +147,15 @@ def test_lattice_detection_and_brick_ownership():
         po = P.brick_pair_order(n, expect, 32, "cpu")
         assert po.numel() % 32 == 0 and sorted(po[po >= 0].tolist()) == list(range(n // 2))
         _check_rowpack(g.transposed, 64, lim, pair_order=po)
+        # plane rotation (BRICK_ROTATE): the same records per pair, listed plane by plane instead of ascending — every
+        # (column, slot word) of a pair is still there exactly once, and equal columns keep their slot words
+        rot = P.build_rowpack_plan(g.transposed, 64, lim, pair_order=po, lattice=expect, dedup="off")
+        asc = P.build_rowpack_plan(g.transposed, 64, lim, pair_order=po, lattice=None, dedup="off")
+        assert P.BRICK_ROTATE and torch.equal(rot.uptr, asc.uptr) and torch.equal(rot.sperm, asc.sperm)
+        key = lambda rp: (torch.repeat_interleave(torch.arange(rp.uptr.numel() - 1), (rp.uptr[1:] - rp.uptr[:-1]).long()) * (1 << 40)
+                          + (rp.ucol.long() << 8)).sort()
+        (ka, ia), (kr, ir) = key(asc), key(rot)
+        assert torch.equal(ka, kr) and torch.equal(asc.upos[ia], rot.upos[ir]) and not torch.equal(asc.ucol, rot.ucol)
         # the automatic choice for a permuted plan on a lattice is the brick plan; forward plans stay natural
         auto = g.transposed.rowpack_plan(64, lim)
         assert auto.vpair is not None and auto.lattice == expect
