@@ -188,8 +188,8 @@ def c5(dev, cpu):
             C = sparse_mm(A, B)
             torch.autograd.grad(C, (A, B), G)
 
-        ms_f = ev(fwd, 20)
-        ms_fb = ev(fwd_bwd, 10)
+        ms_f = ev(fwd, 50)
+        ms_fb = ev(fwd_bwd, 50)
         out[f"batch{b}"] = {
             "fwd_ms": round(ms_f, 4), "fwd_bwd_ms": round(ms_fb, 4),
             "fwd_GBps_algorithmic": round(b * item_bytes / ms_f / 1e6, 1), "fwd_frac_hbm": round(b * item_bytes / ms_f / 1e6 / HBM, 4),
