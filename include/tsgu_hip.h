@@ -178,7 +178,7 @@ int tsgu_csr_mm_backward(int vtype, int itype, int64_t n_rows, int64_t n_cols, i
  * dense operands with 16-byte aligned rows; 2-D operands (batched problems are passed as their block-diagonal 2-D
  * form).  n_cols (n_cols_t) = rows of the gathered dense operand; below 2^24 rows and 4 GiB the kernels use 32-bit
  * gather offsets.  With entry_lanes == 1 each row's sum runs over its own entries in ascending stored order
- * (bit-identical to the one-group-per-row kernels); with entry_lanes > 1 (narrow dense rows) the entries of a pair
+ * (bit-identical to the one-group-per-row kernels when the records are listed in ascending order); with entry_lanes > 1 (narrow dense rows) the entries of a pair
  * are dealt round-robin to the entry lanes and combined by a fixed xor tree.  A row never touches a dense row it does
  * not reference (predicated update, no multiply by zero).
  */

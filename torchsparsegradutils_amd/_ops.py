@@ -1,6 +1,7 @@
 """Kernel selection for one sparse operand: row-pair union kernels when neighbouring rows share columns (stencils,
 banded factors, meshes) and the operands qualify, plain gather kernels otherwise.  Both produce the same values
-(same per-row summation order when a pair has one entry lane); the choice is speed only.
+(same per-row summation order when a pair has one entry lane, except that brick plans of 3-D lattices sum a row of the
+transposed product plane by plane: equal to rounding); the choice is speed only.
 
 Batched CSR operands (torch layout, equal nnz per item) that qualify for the row-pair kernels are handed to them as
 ONE block-diagonal 2-D problem (`_pattern.flat_of`: two vectorised adds on the index arrays, values untouched):
