@@ -218,6 +218,66 @@ int tsgu_csr_sddmm_rowpack(int vtype, int itype, int64_t n_rows, int64_t n_cols,
                            void* out_vals, double alpha, int64_t p, int device, void* stream);
 
 /*
+ * Lattice plane-sweep kernels ("lattice"): same reference lines as tsgu_csr_spmm (sparse_matmul.py:155,229) and
+ * tsgu_csr_sddmm (sparse_matmul.py:186-205, sparse_solve.py:216-235,487-504), for patterns that are stencils on a
+ * row-major lattice:  row = ((item·nx + x)·ny + y)·nz + z,  every stored entry (row, col) has col = the lattice point at
+ * a displacement (dx, dy, dz) of row with |dx| <= 1, |dy| <= ry, |dz| <= rz (periodic wrap allowed in every direction,
+ * x wraps inside an item).  2-D lattices are passed with ny = 1, batched problems as their block-diagonal form (nb items).
+ * A workgroup of `threads` threads owns a ty × tz tile of the (y, z) plane and marches along x through `nseg` segments
+ * per item, keeping four halo planes of the gathered dense operand in LDS (filled by 16-byte LDS-DMA one plane ahead):
+ * every gather is an LDS read and the dense operand crosses L2 → CU (ty+2ry)(tz+2rz)/(ty·tz) times instead of once per
+ * stored entry.  Up to 160 KiB of LDS per workgroup (tsgu_lattice_lds_bytes tells how much a configuration needs).
+ *
+ * The plan is built once per sparsity pattern by the caller (index ops; torchsparsegradutils_amd/_lattice.py):
+ *   rcls  [rows]            uint8   class of each row: rows with the same displacement sequence share a class
+ *   lens  [ncls]            uint8   stored entries per row of the class (<= recw <= 32, recw a multiple of 4)
+ *   rstart[rows+1]          int32   first value position of each row of the VALUE-OWNING pattern (A's crow as int32);
+ *                                   not read when uniform_len > 0 (every row has uniform_len entries)
+ *   rec   kind 0 (walk in stored order: SpMM with the values of the walked rows, SDDMM):
+ *         [ring][ncls][recw] int32  entry k of a row of class c gathers the LDS row at rec[x_ring % ring][c][k] BYTES from
+ *                                   the row's own position in the halo tile, where a halo plane is (ty+2ry)·(tz+2rz) rows of
+ *                                   p·sizeof(value) bytes, z fastest, and ring slot s holds plane bytes [s·plane, (s+1)·plane):
+ *                                   rec = ((x_ring+dx) % ring)·plane + (dy·(tz+2rz) + dz)·rowbytes   (x_ring = 1 for the first
+ *                                   plane of a segment)
+ *         kind 1 (transposed walk: Aᵀ·G reads entry k' of SOURCE row i = row + displacement):
+ *         [ring][ncls][recw][2] int32  {the same for the dense rows, the same displacement in the value ring (rows of
+ *                                   `slot` = recw·4 rounded to 16 bytes) + 4·k'}
+ *   padded entries (k >= lens[c]) hold 0x7ff00: reads that far beyond the row's own position are beyond the LDS allocation and
+ *   return zero on gfx950, so padded entries contribute exactly 0 and no dense row is touched that the sparse row does not reference.
+ * Sums run in ascending entry order of the walked pattern (the order of the plan-free kernels).  fp32 and bf16 values
+ * for kind 0 (fp32 accumulation), fp32 for kind 1; p·sizeof(value)/16 in {2, 4, 8, 16}; 16-byte aligned dense rows.
+ */
+typedef struct tsgu_lattice_plan {
+    int32_t kind;             /* 0: stored-order walk (SpMM / SDDMM); 1: transposed walk (Aᵀ·G) */
+    int32_t nb, nx, ny, nz;   /* items, planes per item, lines per plane, points per line */
+    int32_t ry, rz;           /* halo radii */
+    int32_t ncls, recw;       /* row classes of the pattern (<= 255), record width */
+    int32_t nloc;             /* classes per workgroup list */
+    int32_t uniform_len;      /* > 0: every row of the value-owning pattern has this many entries */
+    int32_t ty, tz;           /* tile the records were built for */
+    int32_t nseg;             /* x segments per item */
+    int32_t threads;          /* workgroup size: 256, 512 or 1024 */
+    int32_t ring;             /* halo planes resident in LDS (4..8): 3 in use + ring-3 in flight ahead of the computation */
+    const void* rec;
+    const void* lens;
+    const void* rcls;
+    const void* rstart;
+    const void* wlist;        /* [workgroups][nloc] uint8: the classes of each workgroup's rows (0xff = unused); workgroup
+                                 ((item·nseg + seg)·tiles_y + tile_y)·tiles_z + tile_z keeps only their records in LDS */
+} tsgu_lattice_plan;
+
+/* Dynamic LDS bytes of a configuration (mode: 0 SpMM, 1 SDDMM, 2 transposed SpMM), or a negative tsgu_status when it
+ * does not fit the kernels' limits (160 KiB of LDS, DMA pieces and row passes per thread). */
+int tsgu_lattice_lds_bytes(int mode, int vtype, int64_t p, int ty, int tz, int ry, int rz, int nloc, int recw, int threads, int ring);
+/* C = A·B (plan kind 0, the pattern of A) or gradB = Aᵀ·G (plan kind 1, the transposed pattern; `val` is A's value array
+ * in A's own order, `B` is G).  n_rows = nb·nx·ny·nz. */
+int tsgu_csr_spmm_lattice(int vtype, const tsgu_lattice_plan* plan, int64_t n_rows, int64_t nnz, const void* val,
+                          const void* B, int64_t ldb, void* C, int64_t ldc, int64_t p, int device, void* stream);
+/* out_vals[k] = alpha·<R[row k,:], Cm[col k,:]> in stored order (plan kind 0). */
+int tsgu_csr_sddmm_lattice(int vtype, const tsgu_lattice_plan* plan, int64_t n_rows, int64_t nnz, const void* R, int64_t ldr,
+                           const void* Cm, int64_t ldc, void* out_vals, double alpha, int64_t p, int device, void* stream);
+
+/*
  * K4  X = op(A)^{-1} B   sparse triangular solve, sync-free (dependency-driven) CSR sweep.
  * replaces: torch.triangular_solve(B, A, upper, transpose, unitriangular).solution
  *           torchsparsegradutils/_compat.py:42-48  (from sparse_solve.py:181-183 and :202-204)

@@ -1,0 +1,282 @@
+"""Lattice plane-sweep kernels (csrc/lattice_impl.h) on the GPU, through the C ABI: parity with the oracle and with
+the plan-free kernels on stencil patterns (periodic / truncated, 7- and 27-point, triangular parts, 2-D, batched,
+ragged tiles, several launch configurations), the zero-padding guarantees, and the public autograd path."""
+
+import numpy as np
+import pytest
+import torch
+
+import _golden as G
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    from torchsparsegradutils_amd import _backend
+
+    _backend.load_library()
+    yield
+
+
+def _mods():
+    from torchsparsegradutils_amd import _backend, _lattice, _pattern
+
+    return _backend, _lattice, _pattern
+
+
+def _stencil_csr(nx, ny, nz, periodic, points=27, lower=False, nb=1):
+    from test_lattice_plan_cpu import _stencil
+
+    return _stencil(nx, ny, nz, periodic, points, lower, nb)
+
+
+def _oracle_mm(crow, col, val, B, Gd):
+    from oracle import oracle
+
+    n = crow.numel() - 1
+    return oracle.sparse_mm_fwd_bwd(crow.numpy(), col.numpy(), val.numpy(), B.numpy(), Gd.numpy(), n)
+
+
+CASES = [
+    # nb, nx, ny, nz, periodic, points, lower, configs (ty, tz, nseg, threads)
+    (1, 9, 10, 12, True, 27, False, [(4, 4, 2, 256), (5, 6, 3, 512), (10, 12, 1, 1024)]),
+    (1, 7, 9, 11, False, 27, False, [(4, 4, 1, 256), (3, 11, 2, 512)]),
+    (1, 8, 8, 16, True, 7, False, [(4, 8, 2, 512), (8, 16, 4, 1024)]),
+    (1, 6, 9, 10, False, 7, False, [(3, 5, 2, 256)]),
+    (1, 6, 8, 9, False, 27, True, [(4, 3, 1, 256), (8, 9, 2, 512)]),
+    (3, 5, 6, 8, True, 27, False, [(3, 4, 2, 256), (6, 8, 1, 512)]),
+]
+
+
+@pytest.mark.parametrize("nb,nx,ny,nz,periodic,points,lower,configs", CASES)
+@pytest.mark.parametrize("p", [32, 16, 8, 64])
+def test_lattice_kernels_match_oracle_and_plan_free_kernels_fp32(nb, nx, ny, nz, periodic, points, lower, configs, p):
+    be, lt, pt = _mods()
+    dev = torch.device("cuda:0")
+    crow, col = _stencil_csr(nx, ny, nz, periodic, points, lower, nb)
+    n = nb * nx * ny * nz
+    g = torch.Generator().manual_seed(nx * 131 + p)
+    val = torch.randn(col.numel(), generator=g)
+    B = torch.randn(n, p, generator=g)
+    Gd = torch.randn(n, p, generator=g)
+    Co, gAo, gBo = _oracle_mm(crow, col, val, B, Gd)
+    crow_d, col_d, val_d, B_d, G_d = (t.to(dev) for t in (crow, col, val, B, Gd))
+    plan = pt.RowGather(crow_d, col_d, n, n)
+    lp = lt.build_lattice_plan(plan, dims=(nb, nx, ny, nz))
+    ltp = lt.build_lattice_plan(plan.transposed, value_crow=crow_d, dims=(nb, nx, ny, nz))
+    assert lp is not None and ltp is not None
+    C0 = be.csr_spmm(crow_d, col_d, val_d, B_d, n, n)
+    gA0 = be.csr_sddmm(crow_d, col_d, G_d, B_d, n, n)
+    t = plan.transposed
+    gB0 = be.csr_spmm(t.crow, t.col, val_d, G_d, n, n, perm=t.perm)
+    for cs in configs:
+        lt._CFG_ENV = ",".join(str(v) for v in cs)
+        try:
+            lp._cfg.clear()
+            ltp._cfg.clear()
+            c1 = be.lattice_config(lp, be.LAT_SPMM, torch.float32, p)
+            c2 = be.lattice_config(lp, be.LAT_SDDMM, torch.float32, p)
+            c3 = be.lattice_config(ltp, be.LAT_SPMMT, torch.float32, p)
+        finally:
+            lt._CFG_ENV = ""
+        if c1 is None or c2 is None or c3 is None:
+            continue   # configuration beyond the kernels' limits for this p (checked by test_limits_*)
+        C = be.csr_spmm_lattice(lp, c1, val_d, B_d)
+        gA = be.csr_sddmm_lattice(lp, c2, G_d, B_d)
+        gB = be.csr_spmm_lattice(ltp, c3, val_d, G_d)
+        torch.cuda.synchronize()
+        assert G.rel_err(C.cpu().numpy(), Co) < 1e-5, cs
+        assert G.rel_err(gA.cpu().numpy(), gAo) < 1e-5, cs
+        assert G.rel_err(gB.cpu().numpy(), gBo) < 1e-5, cs
+        if p >= 32:
+            # one lane group per row and the same order of summation as the plan-free kernels: the same bits
+            # (narrower dense rows: the plan-free kernels split a row's entries over several entry lanes)
+            assert torch.equal(C, C0), cs
+            assert torch.equal(gB, gB0), cs
+            assert torch.equal(gA, gA0), cs
+
+
+def test_two_dimensional_lattice():
+    """9-point stencil on a 2-D lattice: handled as planes of ONE line (ny = 1, no y halo)."""
+    be, lt, pt = _mods()
+    dev = torch.device("cuda:0")
+    n1, n2 = 40, 24
+    rows, cols = [], []
+    for a in range(n1):
+        for b in range(n2):
+            for da in (-1, 0, 1):
+                for db in (-1, 0, 1):
+                    aa, bb = (a + da) % n1, (b + db) % n2
+                    rows.append(a * n2 + b)
+                    cols.append(aa * n2 + bb)
+    n = n1 * n2
+    mask = np.zeros((n, n), dtype=bool)
+    mask[rows, cols] = True
+    crow = torch.zeros(n + 1, dtype=torch.int32)
+    crow[1:] = torch.from_numpy(np.cumsum(mask.sum(1))).to(torch.int32)
+    col = torch.from_numpy(np.nonzero(mask)[1].astype(np.int32))
+    g = torch.Generator().manual_seed(5)
+    val, B = torch.randn(col.numel(), generator=g), torch.randn(n, 32, generator=g)
+    plan = pt.RowGather(crow.to(dev), col.to(dev), n, n)
+    lp = lt.build_lattice_plan(plan)
+    assert lp is not None and (lp.nx, lp.ny, lp.nz, lp.ry) == (n1, 1, n2, 0)
+    C0 = be.csr_spmm(plan.crow, plan.col, val.to(dev), B.to(dev), n, n)
+    for cs in ("1,8,2,256", "1,24,5,512"):
+        lt._CFG_ENV = cs
+        try:
+            lp._cfg.clear()
+            cfg = be.lattice_config(lp, be.LAT_SPMM, torch.float32, 32)
+        finally:
+            lt._CFG_ENV = ""
+        assert cfg is not None
+        assert torch.equal(be.csr_spmm_lattice(lp, cfg, val.to(dev), B.to(dev)), C0)
+
+
+def test_bf16_forward_and_sddmm():
+    be, lt, pt = _mods()
+    dev = torch.device("cuda:0")
+    nb, nx, ny, nz = 2, 8, 16, 16
+    crow, col = _stencil_csr(nx, ny, nz, True, 27, False, nb)
+    n = nb * nx * ny * nz
+    g = torch.Generator().manual_seed(11)
+    for p in (16, 32, 64):
+        val = torch.randn(col.numel(), generator=g).to(torch.bfloat16)
+        B = torch.randn(n, p, generator=g).to(torch.bfloat16)
+        Gd = torch.randn(n, p, generator=g).to(torch.bfloat16)
+        Co, gAo, _ = _oracle_mm(crow, col, val.float(), B.float(), Gd.float())
+        plan = pt.RowGather(crow.to(dev), col.to(dev), n, n)
+        lp = lt.build_lattice_plan(plan)
+        assert lp is not None and (lp.nb, lp.nx, lp.ny, lp.nz) == (nb, nx, ny, nz)
+        for cs in ("8,8,2,256", "16,16,1,512"):
+            lt._CFG_ENV = cs
+            try:
+                lp._cfg.clear()
+                c1 = be.lattice_config(lp, be.LAT_SPMM, torch.bfloat16, p)
+                c2 = be.lattice_config(lp, be.LAT_SDDMM, torch.bfloat16, p)
+            finally:
+                lt._CFG_ENV = ""
+            if c1 is None or c2 is None:
+                continue
+            C = be.csr_spmm_lattice(lp, c1, val.to(dev), B.to(dev))
+            gA = be.csr_sddmm_lattice(lp, c2, Gd.to(dev), B.to(dev))
+            # bf16 results: fp32 accumulation, one rounding at the end: within one bf16 ulp (2^-8) of the largest element
+            assert G.rel_err(C.float().cpu().numpy(), Co) < 2.0 ** -8, (p, cs)
+            assert G.rel_err(gA.float().cpu().numpy(), gAo) < 2.0 ** -8, (p, cs)
+            # ... and every element within one bf16 ulp of the fp32 oracle
+            for got, want in ((C, Co), (gA, gAo)):
+                w = torch.from_numpy(np.asarray(want))
+                ulp = torch.maximum(w.abs(), torch.tensor(1e-30)) * 2.0 ** -7
+                assert bool(((got.float().cpu() - w).abs() <= ulp + 1e-6).all()), (p, cs)
+            if p >= 64:
+                C0 = be.csr_spmm(plan.crow, plan.col, val.to(dev), B.to(dev), n, n)
+                assert torch.equal(C, C0), (p, cs)
+
+
+def test_padded_entries_touch_nothing():
+    """Rows of a truncated stencil are shorter than the record width: their padded entries must contribute exactly zero
+    even when every dense row they do NOT reference is NaN / inf (reads beyond the LDS allocation return zero on
+    gfx950, padded value slots are zeroed).  Same rule as the plan-free kernels (no multiply by zero)."""
+    be, lt, pt = _mods()
+    dev = torch.device("cuda:0")
+    nx, ny, nz = 6, 7, 9
+    crow, col = _stencil_csr(nx, ny, nz, False, 27, True)    # lower part of a truncated stencil: lengths 1..14
+    n = nx * ny * nz
+    g = torch.Generator().manual_seed(3)
+    val = torch.randn(col.numel(), generator=g)
+    B = torch.randn(n, 32, generator=g)
+    poisoned = [5, 77, 200, n - 1]
+    B[poisoned[0]] = float("nan")
+    B[poisoned[1]] = float("inf")
+    B[poisoned[2]] = -float("inf")
+    B[poisoned[3]] = float("nan")
+    val_p = val.clone()
+    val_p[::97] = float("inf")      # non-finite VALUES must stay inside their own rows too
+    plan = pt.RowGather(crow.to(dev), col.to(dev), n, n)
+    lp = lt.build_lattice_plan(plan, dims=(1, nx, ny, nz))
+    ltp = lt.build_lattice_plan(plan.transposed, value_crow=plan.crow, dims=(1, nx, ny, nz))
+    assert lp is not None and ltp is not None and lp.uniform_len == 0
+    lt._CFG_ENV = "4,5,2,256"
+    try:
+        c1 = be.lattice_config(lp, be.LAT_SPMM, torch.float32, 32)
+        c3 = be.lattice_config(ltp, be.LAT_SPMMT, torch.float32, 32)
+    finally:
+        lt._CFG_ENV = ""
+    for v in (val, val_p):
+        C = be.csr_spmm_lattice(lp, c1, v.to(dev), B.to(dev))
+        C0 = be.csr_spmm(plan.crow, plan.col, v.to(dev), B.to(dev), n, n)
+        torch.testing.assert_close(C, C0, rtol=0, atol=0, equal_nan=True)
+        t = plan.transposed
+        gB = be.csr_spmm_lattice(ltp, c3, v.to(dev), B.to(dev))
+        gB0 = be.csr_spmm(t.crow, t.col, v.to(dev), B.to(dev), n, n, perm=t.perm)
+        torch.testing.assert_close(gB, gB0, rtol=0, atol=0, equal_nan=True)
+    # rows that reference no poisoned dense row are finite
+    dense = torch.zeros(n, n)
+    rows = torch.repeat_interleave(torch.arange(n), (crow[1:] - crow[:-1]).long())
+    dense[rows, col.long()] = 1
+    clean = dense[:, poisoned].sum(1) == 0
+    C = be.csr_spmm_lattice(lp, c1, val.to(dev), B.to(dev)).cpu()
+    assert torch.isfinite(C[clean]).all() and not torch.isfinite(C[~clean]).all()
+
+
+def test_public_path_takes_the_lattice_kernels(monkeypatch):
+    """sparse_mm forward + backward on a stencil: the second sight of the pattern switches to the plane sweep; results
+    match the oracle and — same order of summation — the first (plan-free) step bit for bit."""
+    from torchsparsegradutils_amd import _ops, _pattern, sparse_mm
+    from torchsparsegradutils_amd.utils import synthetic
+
+    monkeypatch.setattr(_ops, "ENABLE_LATTICE", True)
+    monkeypatch.setattr(_ops, "PLAN_AFTER_USES", 1)
+    dev = torch.device("cuda:0")
+    nx, ny, nz, p = 16, 12, 20, 32
+    n = nx * ny * nz
+    crow, col = synthetic.stencil27_periodic(nx, ny, nz, torch.int32)
+    g = torch.Generator().manual_seed(1)
+    val = torch.randn(col.numel(), generator=g)
+    B = torch.randn(n, p, generator=g)
+    Gd = torch.randn(n, p, generator=g)
+    Co, gAo, gBo = _oracle_mm(crow, col, val, B, Gd)
+    A = torch.sparse_csr_tensor(crow.to(dev), col.to(dev), val.to(dev), (n, n)).requires_grad_(True)
+    Bd = B.to(dev).requires_grad_(True)
+    outs = []
+    for it in range(3):
+        A.grad = None
+        Bd.grad = None
+        C = sparse_mm(A, Bd)
+        C.backward(Gd.to(dev))
+        outs.append((C.detach().clone(), A.grad.values().clone(), Bd.grad.clone()))
+        core = _pattern.from_csr(A.detach()).core
+        built = core.own.get("lattice") is not None
+        assert built == (it >= 1), it
+    assert core.t.core.own.get("lattice") is not None and not core.packs, "the lattice plans replace the row-pair plans"
+    assert A.grad.crow_indices().dtype == torch.int32 and torch.equal(A.grad.col_indices().cpu(), col)
+    for C, gA, gB in outs:
+        assert G.rel_err(C.cpu().numpy(), Co) < 1e-5
+        assert G.rel_err(gA.cpu().numpy(), gAo) < 1e-5
+        assert G.rel_err(gB.cpu().numpy(), gBo) < 1e-5
+    for k in range(3):
+        assert torch.equal(outs[0][k], outs[2][k])
+
+
+def test_public_path_batched_bf16(monkeypatch):
+    """C5 shape scaled down: batched CSR, bf16, 16 RHS — forward through the lattice sweep as one block-diagonal problem."""
+    from torchsparsegradutils_amd import _ops, _pattern, sparse_mm
+    from torchsparsegradutils_amd.utils import synthetic
+
+    monkeypatch.setattr(_ops, "ENABLE_LATTICE", True)
+    monkeypatch.setattr(_ops, "PLAN_AFTER_USES", 0)
+    dev = torch.device("cuda:0")
+    b, nx, ny, nz, p = 3, 8, 16, 16, 16
+    n = nx * ny * nz
+    crow, col = synthetic.stencil27_periodic(nx, ny, nz, torch.int32)
+    g = torch.Generator().manual_seed(2)
+    val = torch.randn(b, col.numel(), generator=g).to(torch.bfloat16)
+    B = torch.randn(b, n, p, generator=g).to(torch.bfloat16)
+    A = torch.sparse_csr_tensor(crow.repeat(b, 1).to(dev), col.repeat(b, 1).to(dev), val.to(dev), (b, n, n))
+    C = sparse_mm(A, B.to(dev))
+    flat = _pattern.from_csr(A).core.flat
+    assert flat is not None and flat.core.own.get("lattice") is not None
+    for i in range(b):
+        Co, _, _ = _oracle_mm(crow, col, val[i].float(), B[i].float(), B[i].float())
+        assert G.rel_err(C[i].float().cpu().numpy(), Co) < 3e-3

@@ -1,0 +1,229 @@
+"""Lattice plans on the CPU: detection, row classes and — by emulating the kernel's LDS addressing in numpy — that every
+record of every row leads to exactly the dense row (and, for the transposed walk, the value) the CSR arrays name.
+The emulation follows csrc/lattice_impl.h: ring slot = plane index & 3, halo tile of (ty+2ry) x (tz+2rz) rows, own
+position + 16·record."""
+
+import numpy as np
+import pytest
+import torch
+
+from torchsparsegradutils_amd import _lattice as lt
+from torchsparsegradutils_amd import _pattern as pt
+from torchsparsegradutils_amd.utils import synthetic
+
+
+def _csr_from_dense_mask(mask: np.ndarray):
+    n = mask.shape[0]
+    crow = np.zeros(n + 1, dtype=np.int64)
+    crow[1:] = np.cumsum(mask.sum(1))
+    col = np.nonzero(mask)[1]
+    return torch.from_numpy(crow.astype(np.int32)), torch.from_numpy(col.astype(np.int32))
+
+
+def _stencil(nx, ny, nz, periodic, points=27, lower=False, nb=1):
+    """CSR pattern (crow, col) of a 7/27-point stencil on nb items of an nx x ny x nz lattice (block diagonal)."""
+    n1 = nx * ny * nz
+    rows, cols = [], []
+    for x in range(nx):
+        for y in range(ny):
+            for z in range(nz):
+                i = (x * ny + y) * nz + z
+                for dx in (-1, 0, 1):
+                    for dy in (-1, 0, 1):
+                        for dz in (-1, 0, 1):
+                            if points == 7 and abs(dx) + abs(dy) + abs(dz) > 1:
+                                continue
+                            xx, yy, zz = x + dx, y + dy, z + dz
+                            if periodic:
+                                xx, yy, zz = xx % nx, yy % ny, zz % nz
+                            elif not (0 <= xx < nx and 0 <= yy < ny and 0 <= zz < nz):
+                                continue
+                            j = (xx * ny + yy) * nz + zz
+                            if lower and j > i:
+                                continue
+                            rows.append(i)
+                            cols.append(j)
+    mask = np.zeros((n1, n1), dtype=bool)
+    mask[rows, cols] = True
+    if nb > 1:
+        big = np.zeros((nb * n1, nb * n1), dtype=bool)
+        for b in range(nb):
+            big[b * n1:(b + 1) * n1, b * n1:(b + 1) * n1] = mask
+        mask = big
+    return _csr_from_dense_mask(mask)
+
+
+def _emulate(plan, crow, col, perm, value_crow, ty, tz, nseg, row_bytes=128, elem=4, ring_slots=4):
+    """Walk every workgroup / plane / row / entry like the kernel does; returns the number of entries checked."""
+    slot_bytes = (plan.recw * elem + 15) // 16 * 16
+    R, K = ring_slots, ring_slots - 3
+    rec = lt.records(plan, ty, tz, row_bytes, slot_bytes, R).numpy().astype(np.int64)
+    nb, nx, ny, nz, ry, rz = plan.nb, plan.nx, plan.ny, plan.nz, plan.ry, plan.rz
+    hz, hy = tz + 2 * rz, ty + 2 * ry
+    hr = hy * hz
+    pb = hr * row_bytes
+    pvb = hr * slot_bytes
+    crow, col = crow.numpy().astype(np.int64), col.numpy().astype(np.int64)
+    rcls = plan.rcls.numpy()
+    lens = plan.lens_host.numpy()
+    seg_len = -(-nx // nseg)
+    checked = 0
+    for item in range(nb):
+        for seg in range(nseg):
+            xs = seg * seg_len
+            L = min(seg_len, nx - xs)
+            assert L >= 1
+
+            def plane_of(xrel):
+                xa = (xs - 1 + xrel) % nx
+                return (item * nx + xa) * ny * nz
+
+            for y0 in range(0, ny, ty):
+                for z0 in range(0, nz, tz):
+                    goff = np.empty(hr, dtype=np.int64)
+                    for h in range(hr):
+                        goff[h] = ((y0 - ry + h // hz) % ny) * nz + (z0 - rz + h % hz) % nz
+                    ring = {}
+                    for xr in range(K + 2):
+                        ring[xr % R] = plane_of(xr) + goff
+                    for xo in range(1, L + 1):
+                        needed = {(xo - 1) % R, xo % R, (xo + 1) % R}
+                        if xo + K <= L:
+                            assert ((xo + K + 1) % R) not in needed               # the slot being filled is not in use
+                            ring[(xo + K + 1) % R] = plane_of(xo + K + 1) + goff
+                        for ly in range(ty):
+                            for lz in range(tz):
+                                if y0 + ly >= ny or z0 + lz >= nz:
+                                    continue
+                                row = plane_of(xo) + (y0 + ly) * nz + z0 + lz
+                                hrow = (ly + ry) * hz + lz + rz
+                                c = int(rcls[row])
+                                assert lens[c] == crow[row + 1] - crow[row]
+                                for k in range(plan.recw):
+                                    w = rec[xo % R, c, k]
+                                    lo = int(w[0]) if plan.kind == 1 else int(w)
+                                    if k >= lens[c]:
+                                        assert lo == lt.PAD_LO and (plan.kind == 0 or int(w[1]) == lt.PAD_HI)
+                                        assert lo >= 256 * 1024                     # beyond any LDS allocation: reads zero
+                                        continue
+                                    addr = hrow * row_bytes + lo
+                                    s, within = divmod(addr, pb)
+                                    assert 0 <= s < R and s in needed and within % row_bytes == 0
+                                    src = ring[s][within // row_bytes]
+                                    e = crow[row] + k
+                                    assert src == col[e], (row, k, src, col[e])
+                                    if plan.kind == 1:
+                                        va = hrow * slot_bytes + int(w[1])
+                                        vs, vwithin = divmod(va, pvb)
+                                        assert vs == s
+                                        vh, kb = divmod(vwithin, slot_bytes)
+                                        assert ring[vs][vh] == src and kb % 4 == 0
+                                        assert value_crow[src] + kb // 4 == perm[e]
+                                    checked += 1
+    return checked
+
+
+def _check_workgroup_classes(plan, ty, tz, nseg):
+    wl = lt.workgroup_classes(plan, ty, tz, nseg).numpy()
+    nb, nx, ny, nz = plan.nb, plan.nx, plan.ny, plan.nz
+    seg_len = -(-nx // nseg)
+    tiles_y, tiles_z = -(-ny // ty), -(-nz // tz)
+    assert wl.shape[0] == nb * nseg * tiles_y * tiles_z
+    rcls = plan.rcls.numpy()[:plan.n_rows].reshape(nb, nx, ny, nz)
+    for b in range(nb):
+        for sg in range(nseg):
+            for iy in range(tiles_y):
+                for iz in range(tiles_z):
+                    want = set(np.unique(rcls[b, sg * seg_len:(sg + 1) * seg_len, iy * ty:(iy + 1) * ty, iz * tz:(iz + 1) * tz]).tolist())
+                    row = wl[((b * nseg + sg) * tiles_y + iy) * tiles_z + iz]
+                    got = [int(v) for v in row if v != 0xFF]
+                    assert set(got) == want and len(got) == len(want)
+
+
+CASES = [
+    # nb, nx, ny, nz, periodic, points, lower, tile, nseg
+    (1, 6, 7, 9, True, 27, False, (3, 4), 2),
+    (1, 5, 8, 8, False, 27, False, (4, 4), 1),
+    (1, 6, 6, 10, True, 7, False, (2, 5), 3),
+    (1, 4, 9, 8, False, 7, False, (4, 8), 2),
+    (1, 5, 8, 9, False, 27, True, (8, 3), 1),
+    (3, 4, 6, 8, True, 27, False, (3, 4), 2),
+]
+
+
+@pytest.mark.parametrize("nb,nx,ny,nz,periodic,points,lower,tile,nseg", CASES)
+def test_records_lead_to_the_stored_columns(nb, nx, ny, nz, periodic, points, lower, tile, nseg):
+    crow, col = _stencil(nx, ny, nz, periodic, points, lower, nb)
+    n = nb * nx * ny * nz
+    g = pt.RowGather(crow, col, n, n)
+    plan = lt.build_lattice_plan(g, dims=(nb, nx, ny, nz))
+    assert plan is not None and plan.kind == 0
+    assert (plan.nb, plan.nx, plan.ny, plan.nz) == (nb, nx, ny, nz)
+    assert plan.ncls <= 27 and plan.recw % 4 == 0
+    _check_workgroup_classes(plan, tile[0], tile[1], nseg)
+    if periodic:
+        assert plan.uniform_len == points
+    for ring_slots in (4, 5, 7):
+        got = _emulate(plan, crow, col, None, None, tile[0], tile[1], nseg, ring_slots=ring_slots)
+        assert got == col.numel()
+    # transposed walk: records must also name the value's slot inside its source row
+    t = g.transposed
+    tplan = lt.build_lattice_plan(t, value_crow=crow, dims=(nb, nx, ny, nz))
+    assert tplan is not None and tplan.kind == 1 and tplan.ncls <= 125
+    _check_workgroup_classes(tplan, tile[0], tile[1], nseg)
+    for ring_slots in (4, 6):
+        got = _emulate(tplan, t.crow, t.col, t.perm.numpy().astype(np.int64), crow.numpy().astype(np.int64), tile[0], tile[1], nseg,
+                       ring_slots=ring_slots)
+        assert got == col.numel()
+
+
+def test_detection_of_the_benchmark_lattices():
+    for shape in ((12, 10, 16), (9, 16, 12)):
+        crow, col = synthetic.stencil27_periodic(*shape)
+        n = shape[0] * shape[1] * shape[2]
+        g = pt.RowGather(crow, col, n, n)
+        plan = lt.build_lattice_plan(g)
+        assert plan is not None
+        assert (plan.nb, plan.nx, plan.ny, plan.nz) == (1,) + shape
+        assert plan.ncls == 27 and plan.recw == 28 and plan.uniform_len == 27 and (plan.ry, plan.rz) == (1, 1)
+    # block-diagonal batch of periodic items: the x period is recovered from the wrap-around offsets
+    crow, col = _stencil(6, 8, 12, True, 27, False, nb=3)
+    g = pt.RowGather(crow, col, 3 * 576, 3 * 576)
+    plan = lt.build_lattice_plan(g)
+    assert plan is not None and (plan.nb, plan.nx, plan.ny, plan.nz) == (3, 6, 8, 12)
+    # Dirichlet Laplacian (rows of different lengths), 2-D 9-point
+    crow, col, _ = synthetic.laplacian7(7, 9, 12)
+    g = pt.RowGather(crow, col, 756, 756)
+    plan = lt.build_lattice_plan(g)
+    assert plan is not None and (plan.nx, plan.ny, plan.nz) == (7, 9, 12) and plan.uniform_len == 0 and plan.recw == 8
+
+
+def test_irregular_patterns_are_rejected():
+    torch.manual_seed(0)
+    n = 4096
+    dense = torch.rand(n, 64) < 0.2
+    col = torch.nonzero(dense)[:, 1].to(torch.int32) * 64 % n
+    crow = torch.zeros(n + 1, dtype=torch.int32)
+    crow[1:] = torch.cumsum(dense.sum(1), 0)
+    g = pt.RowGather(crow, col, n, n)
+    assert lt.build_lattice_plan(g) is None
+    # a stencil with one foreign entry
+    crow, col = synthetic.stencil27_periodic(8, 8, 8)
+    col = col.clone()
+    col[5] = (col[5] + 200) % 512
+    g = pt.RowGather(crow, col, 512, 512)
+    assert lt.build_lattice_plan(g, dims=(1, 8, 8, 8)) is None
+
+
+def test_config_choice_is_within_limits():
+    crow, col = synthetic.stencil27_periodic(12, 10, 16)
+    g = pt.RowGather(crow, col, 1920, 1920)
+    plan = lt.build_lattice_plan(g)
+
+    def fake_lds(mode, vtype, p, ty, tz, ry, rz, ncls, recw, threads, ring):
+        hr = (ty + 2 * ry) * (tz + 2 * rz)
+        total = ring * hr * p * 4 + (ring - 2) * ty * tz * 112 + 8192
+        return total if total <= 160 * 1024 and hr * 8 <= 3 * threads else -3
+
+    ty, tz, nseg, threads, ring = lt.choose_config(plan, 0, 0, 32, 4, fake_lds)
+    assert ty <= plan.ny and tz <= plan.nz and 1 <= nseg <= plan.nx and threads in (512, 1024) and 4 <= ring <= 8

@@ -73,6 +73,9 @@ SIGNATURES = {
         _int, [_int, _int, _i64, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _i64, _int, _ptr]),
     "tsgu_csr_sddmm_rowpack": (
         _int, [_int, _int, _i64, _i64, _i64, _ptr, _ptr, _ptr, _i64, _ptr, _i64, _ptr, _dbl, _i64, _int, _ptr]),
+    "tsgu_lattice_lds_bytes": (_int, [_int, _int, _i64, _int, _int, _int, _int, _int, _int, _int, _int]),
+    "tsgu_csr_spmm_lattice": (_int, [_int, _ptr, _i64, _i64, _ptr, _ptr, _i64, _ptr, _i64, _i64, _int, _ptr]),
+    "tsgu_csr_sddmm_lattice": (_int, [_int, _ptr, _i64, _i64, _ptr, _i64, _ptr, _i64, _ptr, _dbl, _i64, _int, _ptr]),
     "tsgu_csr_sptrsm": (
         _int,
         [_int, _int, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _int, _int, _ptr, _i64, _i64, _ptr, _i64, _i64, _ptr, _int, _ptr],
@@ -396,6 +399,60 @@ def csr_mm_backward_rowpack(tcrow, rp, val, G, B, n_rows_t: int):
             "tsgu_csr_mm_backward_rowpack",
         )
     return grad_a, grad_b
+
+
+# ---- lattice plane-sweep kernels (csrc/lattice_impl.h; plans from _lattice.py) -------------------------------
+LAT_SPMM, LAT_SDDMM, LAT_SPMMT = 0, 1, 2
+
+
+def lattice_lds_bytes(mode: int, vtype: int, p: int, ty: int, tz: int, ry: int, rz: int, nloc: int, recw: int, threads: int,
+                      ring: int = 4) -> int:
+    """Dynamic LDS bytes of a lattice launch configuration, or a negative tsgu status when it does not fit."""
+    return int(load_library().tsgu_lattice_lds_bytes(mode, vtype, p, ty, tz, ry, rz, nloc, recw, threads, ring))
+
+
+def lattice_config(lp, mode: int, dtype: torch.dtype, p: int):
+    """Launch configuration (tile, segments, record tables) of the _lattice.LatticePlan `lp` for these operands, or None."""
+    from . import _lattice
+
+    if dtype not in (torch.float32, torch.bfloat16) or (mode == LAT_SPMMT and dtype != torch.float32):
+        return None
+    es = 4 if dtype == torch.float32 else 2
+    if (p * es) % 16 or (p * es) // 16 not in (2, 4, 8, 16):
+        return None
+    return _lattice.config_for(lp, mode, _VTYPE[dtype], p, es, lattice_lds_bytes)
+
+
+def csr_spmm_lattice(lp, cfg, val, B):
+    """C = A·B (plan kind 0) or Aᵀ·B for the transposed plan (kind 1; `val` in A's own order) by the plane sweep."""
+    lib = load_library()
+    dev = require_device(val, B)
+    B = rowmajor(B)
+    p = B.size(-1)
+    out = torch.empty((lp.n_rows, p), dtype=B.dtype, device=dev)
+    with torch.cuda.device(dev):
+        check(
+            lib.tsgu_csr_spmm_lattice(vtype_of(val), ctypes.addressof(cfg.struct), lp.n_rows, lp.nnz, _p(val.contiguous()), _p(B), _ld(B),
+                                      _p(out), _ld(out), p, dev.index, _stream(dev)),
+            "tsgu_csr_spmm_lattice",
+        )
+    return out
+
+
+def csr_sddmm_lattice(lp, cfg, R, Cm, alpha: float = 1.0):
+    """out[k] = alpha·<R[row k], Cm[col k]> in stored order by the plane sweep (plan kind 0)."""
+    lib = load_library()
+    dev = require_device(R, Cm)
+    R, Cm = rowmajor(R), rowmajor(Cm)
+    p = R.size(-1)
+    out = torch.empty((lp.nnz,), dtype=R.dtype, device=dev)
+    with torch.cuda.device(dev):
+        check(
+            lib.tsgu_csr_sddmm_lattice(vtype_of(R), ctypes.addressof(cfg.struct), lp.n_rows, lp.nnz, _p(R), _ld(R), _p(Cm), _ld(Cm),
+                                       _p(out), float(alpha), p, dev.index, _stream(dev)),
+            "tsgu_csr_sddmm_lattice",
+        )
+    return out
 
 
 def _tiled_ok(*dense) -> bool:

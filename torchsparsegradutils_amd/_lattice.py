@@ -1,0 +1,381 @@
+"""Lattice plans: the description of a stencil-like sparsity pattern that the plane-sweep kernels
+(csrc/lattice_impl.h, C ABI ``tsgu_csr_spmm_lattice`` / ``tsgu_csr_sddmm_lattice``) walk.
+
+A pattern qualifies when its rows are the points of a row-major lattice, ``row = ((item·nx + x)·ny + y)·nz + z``, and
+every stored entry couples a point with a neighbour at a displacement ``(dx, dy, dz)``, ``|dx| <= 1``, ``|dy|, |dz| <= 2``
+(periodic wrap allowed; x wraps inside an item of a batched / block-diagonal problem).  That covers what the reference's
+``PairwiseEncoder`` produces (encoders/pairwise_encoder.py) and the stencil / Laplacian matrices of its benchmarks
+(7- and 27-point, periodic or truncated at the boundary, triangular parts of them, 2-D 5- and 9-point).  Rows with the
+same displacement sequence share a *class*; the plan is the class of every row (one byte), one displacement table per
+class and — for the transposed walk — the position of every entry inside its source row.  Everything else (the LDS
+record tables of a launch configuration) is derived from these few hundred numbers on the host.
+
+Nothing here touches the values: the plan survives value updates (the training-loop case), like every other plan.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Dict, Optional, Tuple
+
+import torch
+
+MAX_CLASSES = 255
+MAX_RADIUS = 2
+MAX_LEN = 32
+PAD_LO = PAD_HI = 0x7FF00     # bytes: reads this far beyond the row's own LDS position are beyond the allocation and return 0
+_MODE_SPMM, _MODE_SDDMM, _MODE_SPMMT = 0, 1, 2
+_NUM_CU = 256
+
+
+class LatticePlan:
+    """Geometry + row classes of one pattern (kind 0: walked in stored order; kind 1: a transposed pattern whose values
+    live in the source rows of the owner's value array)."""
+
+    __slots__ = ("kind", "nb", "nx", "ny", "nz", "ry", "rz", "ncls", "recw", "uniform_len", "codes", "ksrc", "lens",
+                 "lens_host", "rcls", "rstart", "n_rows", "nnz", "_cfg")
+
+    def __init__(self):
+        self._cfg: Dict[tuple, "LatticeConfig"] = {}
+
+    def plan_bytes(self) -> int:
+        total = 0
+        for t in (self.lens, self.rcls, self.rstart):
+            if t is not None:
+                total += t.numel() * t.element_size()
+        for cfg in self._cfg.values():
+            if cfg is not None:
+                total += cfg.rec.numel() * cfg.rec.element_size() + cfg.wlist.numel()
+        return total
+
+
+class LatticeConfig:
+    """One launch configuration of a plan: tile, segments, workgroup size and the record tables built for them."""
+
+    __slots__ = ("ty", "tz", "nseg", "threads", "rec", "lds_bytes", "struct", "wlist", "nloc", "ring")
+
+
+def _frequent_offsets(g, rows64: torch.Tensor) -> Optional[list]:
+    off = (g.col.to(torch.int64) - rows64).abs()
+    uniq, cnt = torch.unique(off, return_counts=True)
+    if uniq.numel() > 8192:
+        return None
+    # a displacement of a stencil appears in (almost) every row; wrap-around images and boundary losses are rare
+    keep = uniq[(cnt * 2 > g.n_rows) & (uniq > 0)]
+    return keep.tolist()
+
+
+def detect_dims(g, rows64: torch.Tensor) -> Optional[Tuple[int, int]]:
+    """(nz, ny·nz) of the lattice this square pattern looks like a stencil on, from the clusters of |col − row|:
+    {1 … rz}, {nz − rz … nz + rz}, {ny·nz − … }.  (nz, n_rows) for a 2-D lattice.  None for anything irregular."""
+    n = g.n_rows
+    pos = _frequent_offsets(g, rows64)
+    if not pos:
+        return None
+    clusters = [[pos[0]]]
+    reach = max(pos[0], MAX_RADIUS)
+    for o in pos[1:]:
+        if o - clusters[-1][-1] <= reach:
+            clusters[-1].append(o)
+        else:
+            reach = clusters[-1][-1] + MAX_RADIUS
+            clusters.append([o])
+    # the first cluster may be missing (stencils without in-line neighbours) only if it starts beyond the radius
+    if clusters[0][0] > MAX_RADIUS:
+        clusters.insert(0, [])
+    if len(clusters) not in (2, 3) or (clusters[0] and clusters[0][-1] > MAX_RADIUS):
+        return None
+    # line stride: a divisor of n within the in-line radius of every member of the second cluster
+    lo, hi = clusters[1][0], clusters[1][-1]
+    mid = (lo + hi) // 2
+    cands = sorted((c for c in range(max(hi - MAX_RADIUS, 2), lo + MAX_RADIUS + 1) if n % c == 0), key=lambda c: abs(c - mid))
+    if not cands:
+        return None
+    nz = cands[0]
+    if len(clusters) == 2:
+        return nz, nz
+    # plane stride: a multiple of nz dividing n inside the third cluster's span (members are d2 + dy·nz + dz)
+    lo, hi = clusters[2][0], clusters[2][-1]
+    mid = (lo + hi) // 2
+    first = (max(lo - MAX_RADIUS, 2 * nz) + nz - 1) // nz * nz
+    cands = sorted((c for c in range(first, hi + MAX_RADIUS + 1, nz) if n % c == 0), key=lambda c: abs(c - mid))
+    if not cands:
+        return None
+    return nz, cands[0]
+
+
+def _mix(a: torch.Tensor, b) -> torch.Tensor:
+    """64-bit mixing with wrap-around arithmetic (only has to spread well: classes are verified exactly)."""
+    if not torch.is_tensor(b):
+        b = torch.tensor(int(b), dtype=torch.int64, device=a.device)
+    x = a * -7046029254386353131 + b * -4417276706812531889 + 1609587929392839161
+    x = x ^ (x >> 29)
+    return x * -49064778989728563
+
+
+def build_lattice_plan(g, value_crow: Optional[torch.Tensor] = None, dims: Optional[Tuple[int, int, int, int]] = None):
+    """LatticePlan of the 2-D RowGather `g`, or None when the pattern is not a lattice stencil.
+    `value_crow` (A's row pointer) must be given for a transposed pattern (`g.perm` indexes A's value array).
+    `dims` = (nb, nx, ny, nz) skips the detection (tests)."""
+    if g.batch is not None or g.n_rows != g.n_cols or g.n_rows < 8 or not (1 <= g.nnz < 2**31):
+        return None
+    kind = 0 if g.perm is None else 1
+    if kind == 1 and value_crow is None:
+        return None
+    n, nnz = g.n_rows, g.nnz
+    dev = g.crow.device
+    rows = g.row_indices().to(torch.int64)
+    cols = g.col.to(torch.int64)
+    if dims is None:
+        found = detect_dims(g, rows)
+        if found is None:
+            return None
+        nz, d2 = found
+        if n % d2 or n % nz:
+            return None
+        ny = d2 // nz
+        planes = n // d2
+        nx_given = None
+    else:
+        nb_g, nx_given, ny, nz = (int(v) for v in dims)
+        d2 = ny * nz
+        if nb_g * nx_given * d2 != n:
+            return None
+        planes = n // d2
+    X = torch.div(rows, d2, rounding_mode="floor")
+    rem = rows - X * d2
+    y = torch.div(rem, nz, rounding_mode="floor")
+    z = rem - y * nz
+    Xc = torch.div(cols, d2, rounding_mode="floor")
+    remc = cols - Xc * d2
+    yc = torch.div(remc, nz, rounding_mode="floor")
+    zc = remc - yc * nz
+    del rem, remc
+    dX = Xc - X
+    if nx_given is None:
+        m = int(dX.abs().max())
+        nx = planes if m <= 1 else m + 1
+    else:
+        nx = nx_given
+    if nx < 1 or planes % nx:
+        return None
+    nb = planes // nx
+    if nx > 1:
+        dx = torch.where(dX.abs() <= 1, dX, torch.where(dX.abs() == nx - 1, -torch.sign(dX), torch.full_like(dX, 9)))
+    else:
+        dx = dX
+    if bool((dx.abs() > 1).any()):
+        return None
+    x = X - torch.div(X, nx, rounding_mode="floor") * nx
+    item = torch.div(X, nx, rounding_mode="floor")
+    dy = torch.remainder(yc - y + ny // 2, ny) - ny // 2
+    dz = torch.remainder(zc - z + nz // 2, nz) - nz // 2
+    ry, rz = int(dy.abs().max()), int(dz.abs().max())
+    if ry > MAX_RADIUS or rz > MAX_RADIUS:
+        return None
+    expect = ((item * nx + torch.remainder(x + dx, nx)) * ny + torch.remainder(y + dy, ny)) * nz + torch.remainder(z + dz, nz)
+    if not torch.equal(expect, cols):
+        return None
+    del expect, X, Xc, y, yc, z, zc, item, x, dX
+    code = ((dx + 1) * 5 + (dy + 2)) * 5 + (dz + 2)          # < 75
+    del dx, dy, dz
+    crow64 = g.crow.to(torch.int64)
+    lens_row = crow64[1:] - crow64[:-1]
+    maxlen = int(lens_row.max())
+    if maxlen > MAX_LEN or maxlen < 1:
+        return None
+    recw = (maxlen + 3) // 4 * 4
+    pos = torch.arange(nnz, device=dev, dtype=torch.int64) - crow64[rows]
+    if kind == 1:
+        vc = value_crow.to(torch.int64)
+        ksrc = g.perm.to(torch.int64) - vc[cols]
+        if bool(((ksrc < 0) | (ksrc >= MAX_LEN)).any()):
+            return None
+        vlen = vc[1:] - vc[:-1]
+        if int(vlen.max()) > MAX_LEN:
+            return None
+        code = code * 32 + ksrc
+        del ksrc
+        uniform = int(vlen[0]) if bool((vlen == vlen[0]).all()) else 0
+        rstart = value_crow if value_crow.dtype == torch.int32 else value_crow.to(torch.int32)
+    else:
+        uniform = maxlen if bool((lens_row == maxlen).all()) else 0
+        rstart = g.crow if g.crow.dtype == torch.int32 else g.crow.to(torch.int32)
+    # ---- row classes: rows with the same (code, position) sequence ----------------------------------------
+    h = torch.zeros(n, dtype=torch.int64, device=dev)
+    h.index_add_(0, rows, _mix(code, pos + 17))
+    h += _mix(lens_row, 3)
+    uniq, inv = torch.unique(h, return_inverse=True)
+    ncls = uniq.numel()
+    if ncls > MAX_CLASSES:
+        return None
+    rep = torch.full((ncls,), n, dtype=torch.int64, device=dev).scatter_reduce_(0, inv, torch.arange(n, device=dev), "amin")
+    table = torch.full((ncls, recw), -1, dtype=torch.int64, device=dev)
+    is_rep = rep[inv] == torch.arange(n, device=dev)
+    sel = is_rep[rows]
+    table[inv[rows[sel]], pos[sel]] = code[sel]
+    cls_len = lens_row[rep]
+    # exact check (a hash collision must not produce a wrong plan)
+    if not (torch.equal(table[inv[rows], pos], code) and torch.equal(cls_len[inv], lens_row)):
+        return None
+    plan = LatticePlan()
+    plan.kind, plan.nb, plan.nx, plan.ny, plan.nz, plan.ry, plan.rz = kind, nb, nx, ny, nz, ry, rz
+    plan.ncls, plan.recw, plan.uniform_len = ncls, recw, uniform
+    plan.n_rows, plan.nnz = n, nnz
+    tab = table.cpu()
+    if kind == 1:
+        plan.ksrc = torch.where(tab >= 0, tab % 32, tab)
+        plan.codes = torch.where(tab >= 0, torch.div(tab, 32, rounding_mode="floor"), tab)
+    else:
+        plan.codes, plan.ksrc = tab, None
+    plan.lens_host = cls_len.cpu()
+    plan.lens = cls_len.to(torch.uint8)
+    rcls = torch.zeros(n + 64, dtype=torch.uint8, device=dev)
+    rcls[:n] = inv.to(torch.uint8)
+    plan.rcls = rcls
+    # never the caller's own tensor: the pattern cache is evicted when the caller's index storages die
+    plan.rstart = torch.zeros(4, dtype=torch.int32, device=dev) if uniform > 0 else rstart.contiguous().clone()
+    return plan
+
+
+def records(plan: LatticePlan, ty: int, tz: int, row_bytes: int, slot_bytes: int, ring: int = 4) -> torch.Tensor:
+    """Record tables of `plan` for a ty × tz tile (host tensor, int32): [ring][ncls][recw] byte offsets for kind 0,
+    [ring][ncls][recw][2] = (dense-row offset, value offset) for kind 1.  Entry k of a row of class c gathers the LDS row
+    `rec` bytes from the row's own position in the halo tile, in the ring slot (phase + dx) % ring — see include/tsgu_hip.h."""
+    hz = tz + 2 * plan.rz
+    hr = (ty + 2 * plan.ry) * hz
+    codes = plan.codes
+    valid = codes >= 0
+    c = torch.where(valid, codes, torch.zeros_like(codes))
+    dz = c % 5 - 2
+    dy = torch.div(c, 5, rounding_mode="floor") % 5 - 2
+    dx = torch.div(c, 25, rounding_mode="floor") - 1
+    out = []
+    for ph in range(ring):
+        slot = (ph + dx) % ring
+        lo = slot * (hr * row_bytes) + (dy * hz + dz) * row_bytes
+        lo = torch.where(valid, lo, torch.full_like(lo, PAD_LO))
+        if plan.kind == 0:
+            out.append(lo.to(torch.int32))
+        else:
+            k = torch.where(valid, plan.ksrc, torch.zeros_like(plan.ksrc))
+            hi = slot * (hr * slot_bytes) + (dy * hz + dz) * slot_bytes + k * 4
+            hi = torch.where(valid, hi, torch.full_like(hi, PAD_HI))
+            out.append(torch.stack((lo, hi), -1).to(torch.int32))
+    return torch.stack(out, 0).contiguous()
+
+
+def workgroup_classes(plan: LatticePlan, ty: int, tz: int, nseg: int) -> torch.Tensor:
+    """[workgroups][nloc] uint8: the classes that occur among the rows of each workgroup (0xff = unused), workgroup order
+    ((item·nseg + seg)·tiles_y + tile_y)·tiles_z + tile_z as in the kernel.  A workgroup keeps only these records in LDS."""
+    nb, nx, ny, nz = plan.nb, plan.nx, plan.ny, plan.nz
+    n = plan.n_rows
+    dev = plan.rcls.device
+    seg_len = -(-nx // nseg)
+    tiles_y, tiles_z = -(-ny // ty), -(-nz // tz)
+    r = torch.arange(n, device=dev, dtype=torch.int64)
+    z = r % nz
+    y = torch.div(r, nz, rounding_mode="floor") % ny
+    xx = torch.div(r, ny * nz, rounding_mode="floor")
+    x = xx % nx
+    item = torch.div(xx, nx, rounding_mode="floor")
+    blk = ((item * nseg + torch.div(x, seg_len, rounding_mode="floor")) * tiles_y + torch.div(y, ty, rounding_mode="floor")) * tiles_z \
+        + torch.div(z, tz, rounding_mode="floor")
+    nblocks = nb * nseg * tiles_y * tiles_z
+    pairs = torch.unique(blk * 256 + plan.rcls[:n].to(torch.int64))          # sorted: by workgroup, then class
+    pb = torch.div(pairs, 256, rounding_mode="floor")
+    counts = torch.bincount(pb, minlength=nblocks)
+    nloc = int(counts.max())
+    start = torch.zeros(nblocks + 1, dtype=torch.int64, device=dev)
+    start[1:] = torch.cumsum(counts, 0)
+    within = torch.arange(pairs.numel(), device=dev) - start[pb]
+    wl = torch.full((nblocks, nloc), 0xFF, dtype=torch.uint8, device=dev)
+    wl[pb, within] = (pairs % 256).to(torch.uint8)
+    return wl.contiguous()
+
+
+# ---- launch configuration ------------------------------------------------------------------------------------
+
+_NLOC_GUESS = (27, 48)    # classes a workgroup typically meets (stored-order / transposed walk): sizes the LDS estimate
+_CFG_ENV = os.environ.get("TSGU_LATTICE_CFG", "")   # "ty,tz,nseg,threads[,ring]" overrides the choice (experiments)
+
+
+def _candidates(limit: int):
+    for ty in (1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 20, 24, 32):
+        for tz in (4, 5, 6, 8, 10, 12, 16, 20, 24, 32, 50, 64):
+            if ty * tz <= limit:
+                yield ty, tz
+
+
+def choose_config(plan: LatticePlan, mode: int, vtype: int, p: int, elem_bytes: int, lds_bytes_fn) -> Optional[Tuple[int, int, int, int, int]]:
+    """(ty, tz, nseg, threads, ring) for `plan`: the tile with the best modelled throughput that fits the kernels' limits."""
+    if _CFG_ENV:
+        v = [int(t) for t in _CFG_ENV.split(",")]
+        return v[0], v[1], min(v[2], plan.nx), v[3], (v[4] if len(v) > 4 else 4)
+    cl = p * elem_bytes // 16
+    best, best_cost = None, None
+    for threads in (512, 1024):
+        rpp = threads // cl
+        for ty, tz in _candidates(2 * rpp):
+            if ty > plan.ny or tz > plan.nz or (plan.ny == 1 and ty != 1):
+                continue
+            ring = 4
+            lds = lds_bytes_fn(mode, vtype, p, ty, tz, plan.ry, plan.rz, min(plan.ncls, _NLOC_GUESS[plan.kind]), plan.recw, threads, ring)
+            if lds <= 0:
+                continue
+            per_cu = min(160 * 1024 // lds, 2048 // threads)
+            if per_cu < 1:
+                continue
+            nr = ty * tz
+            passes = -(-nr // rpp)
+            tiles = -(-plan.ny // ty) * -(-plan.nz // tz)
+            lane_util = (plan.ny * plan.nz) / (tiles * passes * rpp)
+            halo = (ty + 2 * plan.ry) * (tz + 2 * plan.rz) / nr
+            slots = _NUM_CU * per_cu
+            # x segments: enough workgroups to fill the chip, as few as possible beyond that (each costs two halo planes)
+            base = plan.nb * tiles
+            nseg = max(1, min(plan.nx, -(-slots // base)))
+            while nseg > 1 and -(-plan.nx // nseg) * (nseg - 1) >= plan.nx:
+                nseg -= 1
+            nwg = base * nseg
+            rounds = -(-nwg // slots)
+            fill = nwg / (rounds * slots)
+            seg_len = -(-plan.nx // nseg)
+            waves_per_cu = per_cu * threads // 64
+            hide = 1.0 if waves_per_cu >= 16 else 1.25
+            cost = (1.0 / lane_util) * (1.0 + 0.35 * (halo - 1.0)) * (1.0 + 2.0 / seg_len) / fill * hide
+            if best_cost is None or cost < best_cost:
+                best, best_cost = (ty, tz, nseg, threads, ring), cost
+    return best
+
+
+class _LatticePlanStruct(ctypes.Structure):
+    """``tsgu_lattice_plan`` of include/tsgu_hip.h."""
+
+    _fields_ = [(k, ctypes.c_int32) for k in ("kind", "nb", "nx", "ny", "nz", "ry", "rz", "ncls", "recw", "nloc", "uniform_len",
+                                               "ty", "tz", "nseg", "threads", "ring")] + [(k, ctypes.c_void_p) for k in ("rec", "lens", "rcls", "rstart", "wlist")]
+
+
+def config_for(plan: LatticePlan, mode: int, vtype: int, p: int, elem_bytes: int, lds_bytes_fn) -> Optional[LatticeConfig]:
+    """Cached launch configuration (tile choice + record tables on the device + ctypes image) of a plan."""
+    key = (mode, vtype, p)
+    cfg = plan._cfg.get(key)
+    if cfg is None and key not in plan._cfg:
+        choice = choose_config(plan, mode, vtype, p, elem_bytes, lds_bytes_fn)
+        if choice is not None:
+            ty, tz, nseg, threads, ring = choice
+            wlist = workgroup_classes(plan, ty, tz, nseg)
+            nloc = wlist.size(1)
+            lds = lds_bytes_fn(mode, vtype, p, ty, tz, plan.ry, plan.rz, nloc, plan.recw, threads, ring)
+            if lds > 0:
+                slot = (plan.recw * (4 if mode == _MODE_SDDMM else elem_bytes) + 15) // 16 * 16
+                cfg = LatticeConfig()
+                cfg.ty, cfg.tz, cfg.nseg, cfg.threads, cfg.lds_bytes = ty, tz, nseg, threads, lds
+                cfg.wlist, cfg.nloc, cfg.ring = wlist, nloc, ring
+                cfg.rec = records(plan, ty, tz, p * elem_bytes, slot, ring).to(plan.rcls.device)
+                cfg.struct = _LatticePlanStruct(plan.kind, plan.nb, plan.nx, plan.ny, plan.nz, plan.ry, plan.rz, plan.ncls, plan.recw,
+                                                nloc, plan.uniform_len, ty, tz, nseg, threads, ring, cfg.rec.data_ptr(), plan.lens.data_ptr(),
+                                                plan.rcls.data_ptr(), plan.rstart.data_ptr(), wlist.data_ptr())
+        plan._cfg[key] = cfg
+    return cfg

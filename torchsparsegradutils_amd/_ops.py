@@ -14,6 +14,7 @@ import os
 import torch
 
 from . import _backend as _be
+from . import _lattice as _lt
 from . import _pattern as _pt
 from ._pattern import RowGather
 
@@ -29,6 +30,42 @@ PLAN_AFTER_USES = int(os.environ.get("TSGU_PLAN_AFTER_USES", "1"))
 # ... and it is built on a worker thread + side stream (TSGU_PLAN_ASYNC=0: inline): the steps in between keep running
 # on the plan-free kernels, no step ever waits for a plan.  `torchsparsegradutils_amd.wait_for_plans()` joins.
 PLAN_ASYNC = os.environ.get("TSGU_PLAN_ASYNC", "1") == "1"
+
+
+# Lattice plane-sweep kernels (csrc/lattice_impl.h): patterns that are stencils on a row-major lattice (what the
+# reference's PairwiseEncoder and its stencil benchmarks produce) are walked tile by tile with the halo of the dense
+# operand in LDS.  First choice when the pattern qualifies; anything else takes the row-pair / plan-free kernels.
+ENABLE_LATTICE = os.environ.get("TSGU_ENABLE_LATTICE", "1") == "1"
+
+
+def _lattice_plan(plan: RowGather, value_crow=None):
+    """LatticePlan of the 2-D `plan` (None: not a lattice stencil / not seen often enough yet); cached with the pattern.
+    The detection + class build is a handful of index ops (no sorts of the entries): done inline at the
+    PLAN_AFTER_USES-th sight of the pattern."""
+    if not ENABLE_LATTICE or plan.batch is not None or plan.nnz < PACK_MIN_NNZ or plan.n_rows != plan.n_cols:
+        return None
+    if (plan.perm is not None) != (value_crow is not None):
+        return None
+    own = plan.core.own
+    if "lattice" not in own:
+        seen = own["lattice_uses"] = own.get("lattice_uses", 0) + 1
+        if seen <= PLAN_AFTER_USES:
+            return None
+        own["lattice"] = _lt.build_lattice_plan(plan, value_crow=value_crow)
+    return own["lattice"]
+
+
+def _lattice_cfg(plan: RowGather, mode: int, dense: torch.Tensor, *others: torch.Tensor, value_crow=None):
+    """(LatticePlan, LatticeConfig) for these operands or None."""
+    if not ENABLE_LATTICE or dense.dim() != 2 or not _be._tiled_ok(*(_be.rowmajor(t) for t in (dense,) + others)):
+        return None
+    if dense.dtype not in (torch.float32, torch.bfloat16):
+        return None
+    lp = _lattice_plan(plan, value_crow)
+    if lp is None:
+        return None
+    cfg = _be.lattice_config(lp, mode, dense.dtype, dense.size(-1))
+    return None if cfg is None else (lp, cfg)
 
 
 def _pack_for(plan: RowGather, dense: torch.Tensor, *others: torch.Tensor, need_plain_slots: bool = False):
@@ -66,9 +103,36 @@ def _flat(plan: RowGather, *dense: torch.Tensor):
     return _pt.flat_of(plan), flat
 
 
+def _lattice_backward(plan: RowGather, values: torch.Tensor, G: torch.Tensor, B: torch.Tensor):
+    """Both gradients of C = A·B by two plane sweeps: the SDDMM in A's stored order (gradA leaves fully coalesced) and
+    Aᵀ·G on the transposed pattern with the values read from A's own array.  None when the pattern is not a lattice."""
+    if plan.perm is not None:
+        return None
+    fplan, Gf, Bf = plan, G, B
+    if plan.batch is not None:
+        fl = _flat(plan, G, B)
+        if fl is None:
+            return None
+        fplan, (Gf, Bf) = fl
+    fwd = _lattice_cfg(fplan, _be.LAT_SDDMM, Bf, Gf)
+    if fwd is None:
+        return None
+    bwd = _lattice_cfg(fplan.transposed, _be.LAT_SPMMT, Gf, value_crow=fplan.crow)
+    if bwd is None:
+        return None
+    vals = values.reshape(-1)
+    ga = _be.csr_sddmm_lattice(fwd[0], fwd[1], Gf, Bf)
+    gb = _be.csr_spmm_lattice(bwd[0], bwd[1], vals, Gf)
+    return ga.view(values.shape), gb.view(B.shape)
+
+
 def mm_backward(plan: RowGather, values: torch.Tensor, G: torch.Tensor, B: torch.Tensor):
     """(gradA values in A's order, gradB) of C = A·B in one pass over the transposed pattern."""
     same = values.dtype == G.dtype == B.dtype
+    if same and ENABLE_LATTICE and values.dtype == torch.float32:
+        got = _lattice_backward(plan, values, G, B)
+        if got is not None:
+            return got
     if same and plan.batch is not None and ENABLE_PACK:
         fl = _flat(plan, G, B)
         if fl is not None:
@@ -84,9 +148,24 @@ def mm_backward(plan: RowGather, values: torch.Tensor, G: torch.Tensor, B: torch
     return _be.csr_mm_backward(t, values, G, B, plan.n_rows, plan.n_cols)
 
 
-def spmm(plan: RowGather, values: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
-    """A·B for the operand described by (plan, values); perm-aware (transposed / un-coalesced plans)."""
+def spmm(plan: RowGather, values: torch.Tensor, B: torch.Tensor, owner: RowGather = None) -> torch.Tensor:
+    """A·B for the operand described by (plan, values); perm-aware (transposed / un-coalesced plans).  `owner`: when
+    `plan` is `owner.transposed`, the pattern whose stored order the values are in (lets Aᵀ·G take the lattice sweep)."""
     if values.dtype == B.dtype and not _be.is_transposed_view(B):  # transposed views: zero-copy column-strided K1
+        stored = plan.perm is None
+        if ENABLE_LATTICE and (stored or (owner is not None and owner.perm is None and values.dtype == torch.float32)):
+            src = plan if stored else owner
+            fsrc, Bf = src, B
+            if src.batch is not None:
+                fl = _flat(src, B)
+                fsrc, Bf = (fl[0], fl[1][0]) if fl is not None else (None, None)
+            got = None
+            if fsrc is not None:
+                got = (_lattice_cfg(fsrc, _be.LAT_SPMM, Bf) if stored
+                       else _lattice_cfg(fsrc.transposed, _be.LAT_SPMMT, Bf, value_crow=fsrc.crow))
+            if got is not None:
+                out = _be.csr_spmm_lattice(got[0], got[1], values.reshape(-1), Bf)
+                return out.view(B.shape[:-2] + (plan.n_rows, B.size(-1)))
         if plan.batch is not None and ENABLE_PACK:
             fl = _flat(plan, B)
             if fl is not None:
@@ -106,6 +185,9 @@ def sddmm(plan: RowGather, G: torch.Tensor, B: torch.Tensor, alpha: float = 1.0,
     gathered = G if swap_roles else B
     rowop = B if swap_roles else G
     if plan.perm is None and G.dtype == B.dtype:
+        got = _lattice_cfg(plan, _be.LAT_SDDMM, gathered, rowop)
+        if got is not None:
+            return _be.csr_sddmm_lattice(got[0], got[1], rowop, gathered, alpha=alpha)
         rp = _pack_for(plan, gathered, rowop, need_plain_slots=True)
         if rp is not None and rp.upos is None:
             return _be.csr_sddmm_rowpack(plan.crow, rp, rowop, gathered, plan.n_rows, alpha=alpha)

@@ -1,0 +1,658 @@
+// Lattice plane-sweep kernels ("lattice"): stencil-like patterns on a row-major 3-D (or batched 3-D, or 2-D) lattice.
+//
+// Why: the gather kernels (spmm_impl.h, rowpack_impl.h) pull every referenced dense row through the vector L1 — 18-27
+// requests of 128 B per sparse row — and are bounded by the number of L1 misses a CU can keep in flight.
+// On a lattice the rows a tile of points references are the tile plus a halo, so here a workgroup owns a TY x TZ tile of
+// the (y, z) plane and MARCHES along x: it keeps a rolling window of four halo planes of the gathered dense operand in
+// LDS (three in use + ring-3 being filled), filled by 16-byte LDS-DMA (`global_load_lds_dwordx4`) issued ring-3 planes ahead,
+// so every gather is a `ds_read_b128` and the dense operand crosses L2 -> CU ~1.5x instead of 18-27x.  The DMA of plane
+// x+2 and of the values of plane x+1 is in flight during the whole computation of plane x: latency is hidden by the
+// ring, not by occupancy (one or two workgroups per CU, up to the full 160 KiB of LDS).
+//
+// Pattern description (built once per sparsity pattern by _lattice.build_lattice_plan, layout in include/tsgu_hip.h):
+//   row = ((item*nx + x)*ny + y)*nz + z;  every stored entry (row, col) has col = the lattice point at a displacement
+//   (dx, dy, dz), |dx| <= 1, |dy| <= ry, |dz| <= rz, periodic wrap allowed (wrapped halo rows are simply loaded from the
+//   wrapped address).  Rows with the same displacement sequence form a CLASS (27 for a periodic or a Dirichlet 27-point
+//   stencil); `rcls[row]` names the class and a per-class record table turns entry k into an LDS offset relative to the
+//   row's own position in the halo tile.  There is one copy of the table per ring phase (x & 3), so that an address is
+//   ONE shift-add.  Tables are padded to `recw` (multiple of 4) entries with records that point beyond the LDS
+//   allocation: such reads return zero on gfx950 (tools/probe_lds.hip, tests/test_gpu_lattice.py), and the padded value
+//   slots are zeroed, so no predicate is needed in the inner loop and a row never touches a dense row it does not reference.
+//
+// Modes (one template):
+//   kLatSpmm   C = A·B                  ring = B halo planes, values of the tile's own rows staged per plane (stored order)
+//   kLatSddmm  out[k] = alpha·<R[row], Cm[col(k)]>   ring = Cm halo planes, R rows in registers, result in stored order
+//   kLatSpmmT  gradB = Aᵀ·G on the transposed pattern: ring = G halo planes + a second ring with the VALUES of the halo
+//              rows (entry k of source row i sits at slot k of i's value row), records carry both offsets
+// Summation runs in ascending entry order of the walked pattern: the same order as the plan-free kernels.
+//
+// Synchronisation: the DMA is issued by inline asm (invisible to hipcc's s_waitcnt bookkeeping, which would otherwise
+// drain it at the first LDS read); every plane step ends with `s_waitcnt vmcnt(0) lgkmcnt(0)` + `s_barrier`.  Ordinary
+// global loads inside the loop (class bytes, row starts, the SDDMM's own rows) are issued at the END of a step for the next
+// one and pinned at the top of the next step before any DMA is issued, so that hipcc's wait for them never drains the DMA.
+#pragma once
+
+#include <atomic>
+
+#include "tsgu_common.h"
+
+namespace tsgu {
+
+enum LatMode { kLatSpmm = 0, kLatSddmm = 1, kLatSpmmT = 2 };
+
+constexpr int kLatND = 3;    // ring DMA pieces per thread and plane   (halo rows x chunks <= kLatND * NT)
+constexpr int kLatNVD = 2;   // value DMA pieces per thread and plane
+constexpr int kLatNP = 1;    // row passes per plane                   (tile rows <= kLatNP * NT / CL)
+constexpr int kLatMaxLds = 160 * 1024;
+#ifndef TSGU_LAT_PROBE
+#define TSGU_LAT_PROBE 0    // 1 / 2: timing probes of tools/build_variant_one.sh (never in the product build)
+#endif
+constexpr int kLatPadRec = 0x7ff00;  // record of a padded table entry: this many bytes beyond the row's own LDS position
+
+struct LatParams {
+    int nb, nx, ny, nz;      // items, planes per item, lines per plane, points per line
+    int ty, tz, ry, rz;      // tile (lines x points) and halo radii
+    int ring;                // halo planes resident in LDS: 3 in use + (ring - 3) being filled ahead (4..8)
+    int tiles_y, tiles_z;    // tiles per plane
+    int nseg, seg_len;       // x segments per item, planes per segment (the last one may be shorter)
+    int ncls, recw;          // row classes of the whole pattern, record width (multiple of 4, <= 32)
+    int nloc;                // classes per workgroup list (the records of a workgroup's own classes are what it keeps in LDS)
+    const unsigned char* wlist;  // [nblocks][nloc] class ids of each workgroup's rows, 0xff = unused
+    int uniform_len;         // > 0: every row of the value-owning pattern has this many entries (`rstart` is not read)
+    int slot;                // bytes of one staged value row (recw values rounded up to 16 bytes)
+    const void* rec;         // [ring][ncls][recw] int32 byte offsets (SpMM / SDDMM) or pairs of them (SpMMT) — see tsgu_hip.h
+    const unsigned char* lens;  // [ncls] entries per row of the class
+    const unsigned char* rcls;  // [rows] class of each row of the walked pattern
+    const int* rstart;       // [rows+1] first value position of each row of the VALUE-OWNING pattern (A's crow)
+    const void* val;
+    int64_t nnz;
+    const void* S;           // gathered dense operand
+    int64_t lds_;
+    const void* Own;         // SDDMM: row operand
+    int64_t ldown;
+    void* out;               // C / gradB
+    int64_t ldo;
+    void* gvals;             // SDDMM output [nnz]
+    float alpha;
+    int64_t nblocks;
+    // LDS layout (bytes from the start of the dynamic region; filled by lat_layout)
+    int o_vals, o_zero, o_tab, o_len, o_map, lds_bytes;
+};
+
+typedef __attribute__((address_space(3))) void* lat_lds_ptr;
+
+__device__ __forceinline__ unsigned lat_lds_addr(const void* p) { return (unsigned)(size_t)(lat_lds_ptr)p; }
+
+// 16-byte LDS-DMA: lane l's 16 bytes land at `lds_wave_base + 16*l` (wave-uniform base in M0); the source is a
+// wave-uniform 64-bit base (SGPR pair) + a per-lane 32-bit byte offset.
+template <bool NT_POLICY>
+__device__ __forceinline__ void lat_dma16(const void* sbase64, uint32_t voff, unsigned lds_wave_base) {
+    unsigned keep;
+    if constexpr (NT_POLICY)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(sbase64), "s"(lds_wave_base) : "memory");
+    else
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(sbase64), "s"(lds_wave_base) : "memory");
+}
+
+__device__ __forceinline__ void lat_step_sync() {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+template <typename X>
+__device__ __forceinline__ void lat_pin(X& x) { asm volatile("" : "+v"(x)); }
+
+__device__ __forceinline__ int lat_mod(int v, int n) {
+    v %= n;
+    return v < 0 ? v + n : v;
+}
+
+constexpr uint32_t kLatNone = 0xffffffffu;
+
+// NCH > 0: the record width is 4·NCH, known at compile time (the entry loop is unrolled and scheduled as one block)
+template <typename V, int CL, int MODE, int NT, int NCH>
+__global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   // 4 waves per SIMD: at most 128 VGPRs
+    using T = VT<V>;
+    constexpr int VEC = T::kWide;
+    constexpr int RB = CL * 16;          // bytes of a dense row
+    constexpr int RPP = NT / CL;         // rows per pass
+    constexpr int kVB = (int)sizeof(V);
+    constexpr int kRecB = MODE == kLatSpmmT ? 8 : 4;   // bytes of a record
+    constexpr int kUnroll = NCH > 0 ? NCH : 2;
+    static_assert(NT % kWave == 0 && NT % CL == 0 && RB % 16 == 0, "geometry");
+    static_assert(std::is_same<V, float>::value || MODE != kLatSpmmT, "the transposed walk stages 4-byte values");
+
+    extern __shared__ uint4 lat_smem[];
+    char* const sm = reinterpret_cast<char*>(lat_smem);
+    const unsigned sbase = lat_lds_addr(lat_smem);
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
+    const int c = tid % CL;
+    const int g = tid / CL;
+
+    const int HZ = P.tz + 2 * P.rz, HY = P.ty + 2 * P.ry, HR = HY * HZ, NR = P.ty * P.tz;
+    const int PB = HR * RB;
+    const int VL = P.slot / 16;
+    const int plane_rows = P.ny * P.nz;
+    const int R = P.ring, K = P.ring - 3, VB = P.ring - 2;   // ring slots, planes in flight ahead, value buffers (SpMM)
+    const bool uniform = P.uniform_len > 0;
+    auto wrap = [](int v, int m) { return v >= m ? v - m : v; };
+
+    // ---- the tile and x segment of this workgroup -------------------------------------------------------
+    const int64_t vblock = xcd_chunked_block(blockIdx.x, P.nblocks);
+    int64_t vb = vblock;
+    const int tzi = (int)(vb % P.tiles_z);
+    vb /= P.tiles_z;
+    const int tyi = (int)(vb % P.tiles_y);
+    vb /= P.tiles_y;
+    const int seg = (int)(vb % P.nseg);
+    const int item = (int)(vb / P.nseg);
+    const int xs = seg * P.seg_len;
+    const int L = P.seg_len < P.nx - xs ? P.seg_len : P.nx - xs;   // output planes of this segment
+    const int y0 = tyi * P.ty, z0 = tzi * P.tz;
+    const int item_row0 = item * P.nx * plane_rows;
+    // ring plane xrel (xrel = 1 is the first output plane) is lattice plane (xs - 1 + xrel) mod nx of the item
+    auto row_of_x = [&](int x) -> int { return item_row0 + x * plane_rows; };   // first row of lattice plane x
+
+    // ---- records of this workgroup's classes -> LDS (ordinary loads: before anything asynchronous exists) ----------
+    // local class li = wlist[block][li]; cmap[global class] = li | len << 8.  A pattern has up to 255 classes (125 for the
+    // transposed walk of a periodic 27-point stencil), a workgroup's tile column meets a handful of them.
+    {
+        const unsigned char* wl = P.wlist + vblock * P.nloc;
+        unsigned short* cmap = reinterpret_cast<unsigned short*>(sm + P.o_map);
+        for (int li = tid; li < P.nloc; li += NT) {
+            const int gc = wl[li];
+            if (gc != 0xff) cmap[gc] = (unsigned short)(li | (P.lens[gc] << 8));
+        }
+        const int cw = P.recw * kRecB / 4;            // words per class row
+        const int tab_words = P.ring * P.nloc * cw;
+        const int* src = static_cast<const int*>(P.rec);
+        int* dst = reinterpret_cast<int*>(sm + P.o_tab);
+        for (int i = tid; i < tab_words; i += NT) {
+            const int ph = i / (P.nloc * cw), r = i - ph * (P.nloc * cw);
+            const int li = r / cw, w = r - li * cw;
+            const int gc = wl[li];
+            dst[i] = gc != 0xff ? src[(ph * P.ncls + gc) * cw + w] : 0;
+        }
+        if (MODE == kLatSpmmT && tid < 4) reinterpret_cast<int*>(sm + P.o_zero)[tid] = 0;
+    }
+
+    // ---- per-thread descriptors: 32-bit byte offsets inside a plane, constant for the whole march -------------------
+    const uint32_t ldsb = (uint32_t)P.lds_ * kVB;
+    // ring pieces: piece e = d*NT + tid is chunk (e % CL) = c of halo row e / CL
+    uint32_t roff[kLatND];
+    const int ring_pieces = HR * CL;
+#pragma unroll
+    for (int d = 0; d < kLatND; ++d) {
+        const int e = d * NT + tid;
+        const int hr = e / CL;
+        const int hy = hr / HZ, hz = hr - hy * HZ;
+        roff[d] = e < ring_pieces ? (uint32_t)(lat_mod(y0 - P.ry + hy, P.ny) * P.nz + lat_mod(z0 - P.rz + hz, P.nz)) * ldsb + (uint32_t)c * 16u : kLatNone;
+    }
+    // value pieces: SpMM: piece e is chunk e % VL of tile row e / VL;  SpMMT: of halo row e / VL.
+    // vrow = row of the piece inside its plane (-1: none); vuo = its byte offset from the plane's first value when every row
+    // has uniform_len entries (then no row start is ever loaded)
+    int vrow[kLatNVD];
+    uint32_t vch16[kLatNVD], vuo[kLatNVD];
+    const int val_pieces = MODE == kLatSpmm ? NR * VL : (MODE == kLatSpmmT ? HR * VL : 0);
+    if constexpr (MODE != kLatSddmm) {
+#pragma unroll
+        for (int d = 0; d < kLatNVD; ++d) {
+            const int e = d * NT + tid;
+            const int r = e / VL;
+            vch16[d] = (uint32_t)(e - r * VL) * 16u;
+            vrow[d] = -1;
+            if (e < val_pieces) {
+                if constexpr (MODE == kLatSpmm) {
+                    const int ly = r / P.tz, lz = r - ly * P.tz;
+                    if (y0 + ly < P.ny && z0 + lz < P.nz) vrow[d] = (y0 + ly) * P.nz + z0 + lz;
+                } else {
+                    const int hy = r / HZ, hz = r - hy * HZ;
+                    vrow[d] = lat_mod(y0 - P.ry + hy, P.ny) * P.nz + lat_mod(z0 - P.rz + hz, P.nz);
+                }
+            }
+            vuo[d] = (uint32_t)(vrow[d] < 0 ? 0 : vrow[d]) * (uint32_t)(P.uniform_len * kVB) + vch16[d];
+        }
+    }
+    // compute rows: pass q handles tile row q*RPP + g
+    int crow[kLatNP];                    // row inside its plane (-1: none)
+    uint32_t coo[kLatNP];                // byte offset of the row's 16-byte piece inside a plane of the output
+    int cen[kLatNP], csl[kLatNP];        // LDS: own position in a halo plane (+ chunk), own value / stage row
+    const uint32_t ldob = (uint32_t)P.ldo * kVB;
+#pragma unroll
+    for (int q = 0; q < kLatNP; ++q) {
+        const int r = q * RPP + g;
+        const int ly = r / P.tz, lz = r - ly * P.tz;
+        const bool ok = r < NR && y0 + ly < P.ny && z0 + lz < P.nz;
+        crow[q] = ok ? (y0 + ly) * P.nz + z0 + lz : -1;
+        coo[q] = (uint32_t)(ok ? crow[q] : 0) * ldob + (uint32_t)c * 16u;
+        const int hrow = (ly + P.ry) * HZ + lz + P.rz;
+        cen[q] = hrow * RB + c * 16;
+        csl[q] = MODE == kLatSpmmT ? hrow * P.slot : r * P.slot;
+    }
+
+    const char* const Sb = static_cast<const char*>(P.S);
+    const char* const valb = static_cast<const char*>(P.val);
+    const uint32_t val_bytes = (uint32_t)(P.nnz * kVB);
+
+    // ring plane with first row `prow` into ring slot `slot`
+    auto dma_ring = [&](int prow, int slot) {
+        const char* const pbase = Sb + (int64_t)prow * ldsb;      // wave-uniform
+        const unsigned base = sbase + (unsigned)(slot * PB) + (unsigned)(wave * kWave * 16);
+#pragma unroll
+        for (int d = 0; d < kLatND; ++d) {
+            if (d * NT < ring_pieces) {
+                if (roff[d] != kLatNone) lat_dma16<false>(pbase, roff[d], base + (unsigned)(d * NT * 16));
+            }
+        }
+    };
+    // values of the plane with first row `prow` into value buffer `buf` (SpMM: of R - 2; SpMMT: ring slot); `st` = row
+    // starts (elements) of the pieces when the rows are not all of one length
+    auto dma_vals = [&](int prow, int buf, const int (&st)[kLatNVD]) {
+        if constexpr (MODE != kLatSddmm) {
+            const unsigned region = MODE == kLatSpmm ? (unsigned)(P.o_vals + buf * NR * P.slot) : (unsigned)(P.o_vals + buf * HR * P.slot);
+            const unsigned base = sbase + region + (unsigned)(wave * kWave * 16);
+            const uint32_t plane0 = uniform ? (uint32_t)prow * (uint32_t)(P.uniform_len * kVB) : 0u;   // bytes before the plane's values
+            const char* const pbase = valb + plane0;
+#pragma unroll
+            for (int d = 0; d < kLatNVD; ++d) {
+                if (d * NT < val_pieces) {
+                    if (vrow[d] >= 0) {
+                        const uint32_t off = uniform ? vuo[d] : (uint32_t)st[d] * kVB + vch16[d];
+                        if (__builtin_expect(plane0 + off + 16u <= val_bytes, 1)) {
+                            lat_dma16<true>(pbase, off, base + (unsigned)(d * NT * 16));
+                        } else {
+                            // the last 16 bytes of the value array: element-wise, never reading beyond the array
+                            V* dst = reinterpret_cast<V*>(sm + region + (d * NT + tid) * 16);
+#pragma nounroll
+                            for (int e = 0; e < VEC; ++e) {
+                                V z;
+                                __builtin_memset(&z, 0, sizeof(V));
+                                dst[e] = plane0 + off + (e + 1) * kVB <= val_bytes ? *reinterpret_cast<const V*>(pbase + off + e * kVB) : z;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    };
+    auto load_vst = [&](int prow, int (&st)[kLatNVD]) {   // only for rows of different lengths
+        if constexpr (MODE != kLatSddmm) {
+            if (!uniform) {
+                const int* const rs = P.rstart + prow;
+#pragma unroll
+                for (int d = 0; d < kLatNVD; ++d) {
+                    st[d] = 0;
+                    if (d * NT < val_pieces) {
+                        if (vrow[d] >= 0) st[d] = rs[(uint32_t)vrow[d]];
+                    }
+                }
+            }
+        }
+    };
+    // what a compute row needs from memory besides the rings: class byte; for the SDDMM its value start and its own dense row
+    struct RowRegs {
+        int cls[kLatNP];
+        int rst[MODE == kLatSddmm ? kLatNP : 1];
+        float own[MODE == kLatSddmm ? kLatNP : 1][VEC];
+    };
+    auto load_rows = [&](int prow, RowRegs& rr) {
+        const unsigned char* const cbase = P.rcls + prow;                                              // wave-uniform bases,
+        const char* const obase = static_cast<const char*>(P.Own) + (int64_t)prow * P.ldown * kVB;     // 32-bit lane offsets
+#pragma unroll
+        for (int q = 0; q < kLatNP; ++q) {
+            rr.cls[q] = 0;
+            if (q * RPP < NR) {
+                if (crow[q] >= 0) {
+                    rr.cls[q] = cbase[(uint32_t)crow[q]];
+                    if constexpr (MODE == kLatSddmm) {
+                        rr.rst[q] = uniform ? (prow + crow[q]) * P.uniform_len : P.rstart[prow + crow[q]];
+                        load_vec<V, VEC>(reinterpret_cast<const V*>(obase + (uint32_t)crow[q] * ((uint32_t)P.ldown * kVB) + (uint32_t)c * 16u), rr.own[q]);
+                    }
+                }
+            }
+        }
+    };
+    auto pin_rows = [&](RowRegs& rr) {
+#pragma unroll
+        for (int q = 0; q < kLatNP; ++q) {
+            lat_pin(rr.cls[q]);
+            if constexpr (MODE == kLatSddmm) {
+                lat_pin(rr.rst[q]);
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) lat_pin(rr.own[q][v]);
+            }
+        }
+    };
+    auto pin_vst = [&](int (&st)[kLatNVD]) {
+        if constexpr (MODE != kLatSddmm) {
+            if (!uniform) {
+#pragma unroll
+                for (int d = 0; d < kLatNVD; ++d) lat_pin(st[d]);
+            }
+        }
+    };
+
+    // ---- prologue: ring planes 0 .. K+1, values of planes 1 .. K (SpMM) / 0 .. K+1 (SpMMT) --------------------------
+    int vst[kLatNVD];      // row starts for the NEXT value DMA, loaded one step ahead (rows of different lengths only)
+#pragma unroll
+    for (int d = 0; d < kLatNVD; ++d) vst[d] = 0;
+    RowRegs nxt;           // rows of the NEXT output plane, loaded one step ahead
+    int x_run = lat_mod(xs - 1, P.nx);      // lattice plane of ring index 0
+    for (int xr = 0; xr <= K + 1; ++xr) {
+        const int prow = row_of_x(x_run);
+        dma_ring(prow, xr);
+        if ((MODE == kLatSpmmT) || (MODE == kLatSpmm && xr >= 1 && xr <= K)) {
+            load_vst(prow, vst);
+            pin_vst(vst);
+            dma_vals(prow, MODE == kLatSpmm ? wrap(xr, VB) : xr, vst);
+            if (!uniform) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // vst is reused by the next plane
+        }
+        x_run = wrap(x_run + 1, P.nx);
+    }
+    // x_run = lattice plane of ring index K + 2: the next plane the march fetches
+    int x_out = xs;                           // ring index 1
+    int x_nxt = wrap(xs + 1, P.nx);           // ring index 2
+    if constexpr (MODE == kLatSpmm) load_vst(row_of_x(lat_mod(xs + K, P.nx)), vst);          // plane K + 1: its values go out in step 1
+    if constexpr (MODE == kLatSpmmT) load_vst(row_of_x(x_run), vst);                         // plane K + 2
+    load_rows(row_of_x(x_out), nxt);
+    lat_step_sync();
+
+    const unsigned short* const cmap_s = reinterpret_cast<const unsigned short*>(sm + P.o_map);
+    const int vbuf = NR * P.slot;
+
+    // results of the previous plane leave at the START of the next step, so that the wait for the DMA at the end of a step
+    // never waits for a store acknowledgement (and, for the SDDMM, the stage rows are read after the barrier)
+    float acc[MODE == kLatSddmm ? 1 : kLatNP][VEC];
+    int plen[MODE == kLatSddmm ? kLatNP : 1], prst[MODE == kLatSddmm ? kLatNP : 1];
+    auto flush = [&](int prow) {
+        if constexpr (MODE != kLatSddmm) {
+            char* const obase = static_cast<char*>(P.out) + (int64_t)prow * ldob;
+#pragma unroll
+            for (int q = 0; q < kLatNP; ++q) {
+                if (q * RPP < NR) {
+                    if (crow[q] >= 0) store_vec<V, VEC, true>(reinterpret_cast<V*>(obase + coo[q]), acc[q]);
+                }
+            }
+        } else {
+            // the row's gradients in stored order: 16-byte pieces where four fit, single elements at the end
+#pragma unroll
+            for (int q = 0; q < kLatNP; ++q) {
+                if (q * RPP < NR) {
+                    if (crow[q] >= 0) {
+                        const float* const st = reinterpret_cast<const float*>(sm + P.o_vals + csl[q]);
+                        V* const go = static_cast<V*>(P.gvals) + prst[q];
+                        const int len = plen[q];
+#pragma nounroll
+                        for (int k0 = c * 4; k0 < len; k0 += CL * 4) {
+                            const float4 w = *reinterpret_cast<const float4*>(st + k0);
+                            const float wv[4] = {w.x, w.y, w.z, w.w};
+                            if (k0 + 4 <= len) {
+                                if constexpr (kVB == 4) {
+                                    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+                                    const f4u o = {w.x, w.y, w.z, w.w};
+                                    __builtin_nontemporal_store(o, reinterpret_cast<f4u*>(go + k0));
+                                } else {
+#pragma unroll
+                                    for (int j = 0; j < 4; ++j) go[k0 + j] = T::down(wv[j]);
+                                }
+                            } else {
+#pragma unroll
+                                for (int j = 0; j < 4; ++j)
+                                    if (k0 + j < len) go[k0 + j] = T::down(wv[j]);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    };
+
+    // ---- the march ------------------------------------------------------------------------------------------
+    int ph = 1 % R;          // ring slot of the output plane = phase of the record tables
+    int vbi = 1 % VB;        // value buffer of the output plane (SpMM)
+    int prow_prev = 0;
+    for (int xo = 1; xo <= L; ++xo) {
+        // 1. what was loaded during the previous step is complete (the step ended with vmcnt(0)): take it over
+        pin_rows(nxt);
+        pin_vst(vst);
+        RowRegs cur = nxt;
+        int cl_li[kLatNP];   // local class | length << 8 of the rows of this plane (one LDS read, waited for in the compute part)
+#pragma unroll
+        for (int q = 0; q < kLatNP; ++q) cl_li[q] = (q * RPP < NR) ? cmap_s[cur.cls[q]] : 0;
+#if TSGU_LAT_PROBE != 2
+        if (xo > 1) flush(prow_prev);
+#endif
+        // 2. asynchronous fetches for later planes
+#if TSGU_LAT_PROBE == 1   // probe build (wrong results): no DMA inside the march
+        if (false) {
+#else
+        if (xo + K <= L) {   // output plane xo + K exists: its last halo plane (ring index xo + K + 1) and its values are fetched now
+#endif
+            const int tgt = wrap(ph + R - 2, R);                     // slot of ring index xo + K + 1 (free since the last barrier)
+            const int prow_dma = row_of_x(x_run);
+            dma_ring(prow_dma, tgt);
+            if constexpr (MODE == kLatSpmm) dma_vals(row_of_x(x_run == 0 ? P.nx - 1 : x_run - 1), wrap(vbi + VB - 1, VB), vst);   // ring index xo + K
+            if constexpr (MODE == kLatSpmmT) dma_vals(prow_dma, tgt, vst);
+        }
+        // 3. small ordinary loads for the next step: they complete behind the computation below
+        if (xo < L) {
+            load_rows(row_of_x(x_nxt), nxt);
+            if constexpr (MODE == kLatSpmm) load_vst(row_of_x(x_run), vst);                       // ring index xo + K + 1
+            if constexpr (MODE == kLatSpmmT) load_vst(row_of_x(wrap(x_run + 1, P.nx)), vst);      // ring index xo + K + 2
+        }
+        // 4. the output plane
+        prow_prev = row_of_x(x_out);
+        const char* const tabs = sm + P.o_tab + ph * P.nloc * P.recw * kRecB;
+#pragma unroll
+        for (int q = 0; q < kLatNP; ++q) {
+#if TSGU_LAT_PROBE == 2   // probe build (wrong results): DMA and barriers only
+            if (false) {
+#else
+            if (q * RPP < NR) {
+#endif
+                if (crow[q] >= 0) {
+                    const int len = cl_li[q] >> 8;
+                    const char* const tb = tabs + (cl_li[q] & 0xff) * (P.recw * kRecB);
+                    const char* const cb = sm + cen[q];
+                    const int recw = NCH > 0 ? 4 * NCH : P.recw;
+                    if constexpr (MODE == kLatSpmm) {
+                        char* const vs = sm + P.o_vals + vbi * vbuf + csl[q];
+                        if (len < recw) {   // padded slots hold whatever follows the row in the value array: zero them
+#pragma nounroll
+                            for (int t = len + c; t < recw; t += CL) __builtin_memset(vs + t * kVB, 0, kVB);
+                        }
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) acc[q][v] = 0.f;
+                        auto chunk_vals = [&](int k0, float (&a)[4]) {
+                            if constexpr (kVB == 4) {
+                                const uint4 w = *reinterpret_cast<const uint4*>(vs + k0 * 4);
+                                a[0] = __uint_as_float(w.x), a[1] = __uint_as_float(w.y), a[2] = __uint_as_float(w.z), a[3] = __uint_as_float(w.w);
+                            } else {
+                                const uint2 w = *reinterpret_cast<const uint2*>(vs + k0 * 2);
+                                a[0] = __uint_as_float(w.x << 16), a[1] = __uint_as_float(w.x & 0xffff0000u);
+                                a[2] = __uint_as_float(w.y << 16), a[3] = __uint_as_float(w.y & 0xffff0000u);
+                            }
+                        };
+                        if constexpr (NCH > 0) {
+                            // Software pipeline over chunks of four entries: the dense rows of chunk i+1 are requested before
+                            // chunk i is consumed, so that a wave issues LDS reads at the rate it retires them instead of
+                            // queueing a whole row's reads behind every other wave's (LDS and VALU then run side by side).
+                            // The empty asm statements are compiler fences: they pin the order of the LDS requests.
+                            // Three stages: values + records of chunk i+2, dense rows of chunk i+1, FMAs of chunk i.
+                            float a[3][4];
+                            int4 ro[3];
+                            float b[2][4][VEC];
+                            auto stage_a = [&](int i) {
+                                chunk_vals(4 * i, a[i % 3]);
+                                ro[i % 3] = *reinterpret_cast<const int4*>(tb + 16 * i);
+                            };
+                            auto stage_b = [&](int i) {
+                                const int rv[4] = {ro[i % 3].x, ro[i % 3].y, ro[i % 3].z, ro[i % 3].w};
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) load_vec<V, VEC>(reinterpret_cast<const V*>(cb + rv[j]), b[i & 1][j]);
+                            };
+                            stage_a(0);
+                            if (NCH > 1) stage_a(1);
+                            asm volatile("" ::: "memory");
+                            stage_b(0);
+#pragma unroll
+                            for (int i = 0; i < NCH; ++i) {
+                                if (i + 2 < NCH) stage_a(i + 2);
+                                asm volatile("" ::: "memory");
+                                if (i + 1 < NCH) stage_b(i + 1);
+                                asm volatile("" ::: "memory");
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                                    for (int v = 0; v < VEC; ++v) acc[q][v] = fmaf(a[i % 3][j], b[i & 1][j][v], acc[q][v]);
+                                }
+                            }
+                        } else {
+#pragma unroll 2
+                            for (int k0 = 0; k0 < recw; k0 += 4) {
+                                float a[4];
+                                chunk_vals(k0, a);
+                                const int4 ro = *reinterpret_cast<const int4*>(tb + k0 * 4);
+                                const int rv[4] = {ro.x, ro.y, ro.z, ro.w};
+                                float b[4][VEC];
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) load_vec<V, VEC>(reinterpret_cast<const V*>(cb + rv[j]), b[j]);
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                                    for (int v = 0; v < VEC; ++v) acc[q][v] = fmaf(a[j], b[j][v], acc[q][v]);
+                                }
+                            }
+                        }
+                    } else if constexpr (MODE == kLatSddmm) {
+                        float* const st = reinterpret_cast<float*>(sm + P.o_vals + csl[q]);   // fp32 staging row (slot = recw*4 bytes in this mode)
+                        plen[q] = len;
+                        prst[q] = cur.rst[q];
+#pragma unroll kUnroll
+                        for (int k0 = 0; k0 < recw; k0 += 4) {
+                            const int4 ro = *reinterpret_cast<const int4*>(tb + k0 * 4);
+                            const int rv[4] = {ro.x, ro.y, ro.z, ro.w};
+                            float b[4][VEC];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) load_vec<V, VEC>(reinterpret_cast<const V*>(cb + rv[j]), b[j]);
+                            float dsum[4];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                float d = cur.own[q][0] * b[j][0];
+#pragma unroll
+                                for (int v = 1; v < VEC; ++v) d = fmaf(cur.own[q][v], b[j][v], d);
+                                dsum[j] = group_sum<float, CL>(d);
+                            }
+                            if constexpr (CL >= 4) {
+                                if (c < 4) {
+                                    const float mine = c == 0 ? dsum[0] : (c == 1 ? dsum[1] : (c == 2 ? dsum[2] : dsum[3]));
+                                    st[k0 + c] = P.alpha * mine;
+                                }
+                            } else {   // two lanes per row: each stages two of the four sums
+                                st[k0 + c] = P.alpha * (c == 0 ? dsum[0] : dsum[1]);
+                                st[k0 + 2 + c] = P.alpha * (c == 0 ? dsum[2] : dsum[3]);
+                            }
+                        }
+                    } else {
+                        // transposed walk: value of entry k of halo row i sits at slot k of i's staged value row
+                        // (padded entries point both reads beyond the LDS allocation: 0 · 0)
+                        const char* const vcb = sm + P.o_vals + csl[q];
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) acc[q][v] = 0.f;
+#pragma unroll kUnroll
+                        for (int k0 = 0; k0 < recw; k0 += 4) {
+                            const int4 r01 = *reinterpret_cast<const int4*>(tb + k0 * 8);
+                            const int4 r23 = *reinterpret_cast<const int4*>(tb + k0 * 8 + 16);
+                            const int go[4] = {r01.x, r01.z, r23.x, r23.z}, vo[4] = {r01.y, r01.w, r23.y, r23.w};
+                            float b[4][VEC], a[4];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                load_vec<V, VEC>(reinterpret_cast<const V*>(cb + go[j]), b[j]);
+                                a[j] = *reinterpret_cast<const float*>(vcb + vo[j]);
+                            }
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                                for (int v = 0; v < VEC; ++v) acc[q][v] = fmaf(a[j], b[j][v], acc[q][v]);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        ph = wrap(ph + 1, R);
+        vbi = wrap(vbi + 1, VB);
+        x_out = x_nxt;
+        x_nxt = wrap(x_nxt + 1, P.nx);
+        x_run = wrap(x_run + 1, P.nx);
+        lat_step_sync();
+    }
+#if TSGU_LAT_PROBE != 2
+    flush(prow_prev);
+#endif
+}
+
+// ---- host side --------------------------------------------------------------------------------------------------
+
+inline int lat_round16(int v) { return (v + 15) / 16 * 16; }
+
+// Fills the LDS layout of P for (mode, CL, sizeof(V)); returns the dynamic LDS bytes or a negative status.
+inline int lat_layout(LatParams& P, int mode, int cl, int vbytes, int nt) {
+    if (P.ring < 4 || P.ring > 8) return TSGU_ERR_BAD_ARG;
+    const int64_t R = P.ring;
+    if (P.ty <= 0 || P.tz <= 0 || P.ry < 0 || P.rz < 0 || P.ncls <= 0 || P.ncls > 255 || P.nloc <= 0 || P.nloc > P.ncls || P.recw <= 0 ||
+        P.recw % 4 || P.recw > 32)
+        return TSGU_ERR_BAD_ARG;
+    const int HR = (P.ty + 2 * P.ry) * (P.tz + 2 * P.rz), NR = P.ty * P.tz, RB = cl * 16;
+    P.slot = lat_round16(P.recw * (mode == kLatSddmm ? 4 : vbytes));
+    const int VL = P.slot / 16;
+    if ((int64_t)HR * cl > (int64_t)kLatND * nt || NR > kLatNP * (nt / cl)) return TSGU_ERR_TOO_LARGE;
+    if (mode == kLatSpmm && (int64_t)NR * VL > (int64_t)kLatNVD * nt) return TSGU_ERR_TOO_LARGE;
+    if (mode == kLatSpmmT && (int64_t)HR * VL > (int64_t)kLatNVD * nt) return TSGU_ERR_TOO_LARGE;
+    int64_t o = R * HR * RB;
+    P.o_vals = (int)o;
+    if (mode == kLatSpmm) o += (R - 2) * NR * P.slot;
+    else if (mode == kLatSddmm) o += (int64_t)NR * P.slot;
+    else o += R * HR * P.slot;
+    P.o_zero = (int)o;
+    o += 16;
+    P.o_tab = (int)o;
+    o += lat_round16(P.ring * P.nloc * P.recw * (mode == kLatSpmmT ? 8 : 4));
+    P.o_len = (int)o;
+    P.o_map = (int)o;
+    o += 512;     // uint16 per class of the pattern: local class | length << 8
+    if (o > kLatMaxLds) return TSGU_ERR_TOO_LARGE;
+    P.lds_bytes = (int)o;
+    return (int)o;
+}
+
+template <typename V, int CL, int MODE, int NT, int NCH>
+int lat_launch_nch(const LatParams& P, hipStream_t stream) {
+    // more than 64 KiB of dynamic LDS has to be allowed once per kernel and device
+    static std::atomic<uint64_t> allowed{0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return TSGU_ERR_RUNTIME;
+    if (!(allowed.load(std::memory_order_acquire) >> dev & 1ull)) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lattice_kernel<V, CL, MODE, NT, NCH>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, kLatMaxLds) != hipSuccess)
+            return TSGU_ERR_RUNTIME;
+        allowed.fetch_or(1ull << dev, std::memory_order_release);
+    }
+    hipLaunchKernelGGL((lattice_kernel<V, CL, MODE, NT, NCH>), dim3((unsigned)P.nblocks), dim3(NT), (size_t)P.lds_bytes, stream, P);
+    return check_launch();
+}
+
+// record widths with an unrolled entry loop: 28 (27-point stencils) and 8 (7-point); anything else loops at run time
+template <typename V, int CL, int MODE, int NT>
+int lat_launch_one(const LatParams& P, hipStream_t stream) {
+    if (P.recw == 28) return lat_launch_nch<V, CL, MODE, NT, 7>(P, stream);
+    if (P.recw == 8) return lat_launch_nch<V, CL, MODE, NT, 2>(P, stream);
+    return lat_launch_nch<V, CL, MODE, NT, 0>(P, stream);
+}
+
+}  // namespace tsgu
