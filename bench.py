@@ -272,41 +272,78 @@ def main():
     A.grad = None
     B.grad = None
 
+    # ---- the step's two halves inside the autograd step (HIP events around the forward and around the backward) ----
+    def step_halves():
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        e[0].record()
+        C = sparse_mm(A, B)
+        e[1].record()
+        torch.autograd.grad(C, (A, B), G)
+        e[2].record()
+        return e
+
+    evs = [step_halves() for _ in range(max(args.steps, 10))]
+    torch.cuda.synchronize(dev)
+    in_step = {"forward": sum(e[0].elapsed_time(e[1]) for e in evs) / len(evs), "backward": sum(e[1].elapsed_time(e[2]) for e in evs) / len(evs)}
+
     # ---- per-kernel durations (HIP events on the launch stream), same resident operands ----
     plan = _pattern.from_csr(A.detach())
     pt = plan.transposed
     Bd, vd = B.detach(), val
     reps = max(args.steps, 20)
-    rp_t = _ops._pack_for(pt, G, Bd)
-    rp_f = _ops._pack_for(plan, Bd)
-    rp_s = _ops._pack_for(plan, Bd, G, need_plain_slots=True)
-
-    def form(rp):
-        return "class dictionary, %d classes" % rp.nclasses if rp.nclasses else "per-workgroup streams"
-
-    bwd_name = (f"csr_rowpack_kernel (K2+K3 fused bwd, row pairs, {form(rp_t)})" if rp_t is not None
-                else "csr_mm_backward_kernel (K2+K3 fused bwd)")
-    fwd_name = f"csr_rowpack_kernel (K1 fwd, row pairs, {form(rp_f)})" if rp_f is not None else "csr_spmm_kernel (K1 fwd)"
-    kern = {
-        fwd_name: time_events(lambda: _ops.spmm(plan, vd, Bd), reps, dev),
-        bwd_name: time_events(lambda: _ops.mm_backward(plan, vd, G, Bd), reps, dev),
-    }
     ab = alg_bytes(n, nnz, p)
-    kbytes = {fwd_name: ab["spmm"], bwd_name: ab["bwd"]}
-    # kernels the step does not run (one-sided gradients, plan-free first sight), for reference
     kern_alt = {}
+    lat_f = _ops._lattice_cfg(plan, be.LAT_SPMM, Bd)
+    lat_s = _ops._lattice_cfg(plan, be.LAT_SDDMM, Bd, G)
+    lat_t = _ops._lattice_cfg(pt, be.LAT_SPMMT, G, value_crow=plan.crow)
+    lattice = lat_f is not None and lat_s is not None and lat_t is not None
+    rp_t = rp_f = rp_s = None
 
     def alt(name, nbytes, fn):
         kern_alt[name] = time_events(fn, reps, dev)
         kbytes[name] = nbytes
 
-    if rp_s is not None:
-        alt("csr_rowpack_kernel (K3 alone, row-pair SDDMM: A-only gradients)", ab["sddmm"], lambda: _ops.sddmm(plan, G, Bd))
-    if rp_t is not None:
-        alt("csr_rowpack_kernel (K2 alone, row pairs: B-only gradients)", ab["spmm_t"], lambda: _ops.spmm(pt, vd, G))
+    if lattice:
+        def cfgs(c):
+            return f"tile {c.ty}x{c.tz}, {c.nseg} x-segments, {c.threads} threads, ring {c.ring}, {c.lds_bytes} B LDS"
+
+        fwd_name = f"lattice_kernel SpMM (K1 fwd, plane sweep: {cfgs(lat_f[1])})"
+        sdd_name = f"lattice_kernel SDDMM (K3 gradA, plane sweep: {cfgs(lat_s[1])})"
+        bwd_name = f"lattice_kernel SpMM-T (K2 gradB, plane sweep: {cfgs(lat_t[1])})"
+        kern = {
+            fwd_name: time_events(lambda: _ops.spmm(plan, vd, Bd), reps, dev),
+            sdd_name: time_events(lambda: _ops.sddmm(plan, G, Bd), reps, dev),
+            bwd_name: time_events(lambda: _ops.spmm(pt, vd, G, owner=plan), reps, dev),
+        }
+        kbytes = {fwd_name: ab["spmm"], sdd_name: ab["sddmm"], bwd_name: ab["spmm_t"]}
+        traffic_key = {fwd_name: "lattice_spmm", sdd_name: "lattice_sddmm", bwd_name: "lattice_spmm_t"}
         alt("csr_mm_backward_kernel (K2+K3 fused bwd, plan-free first sight)", ab["bwd"], lambda: be.csr_mm_backward(pt, vd, G, Bd, n, n))
-    if rp_f is not None:
         alt("csr_spmm_kernel (K1 fwd, plan-free first sight)", ab["spmm"], lambda: be.csr_spmm(plan.crow, plan.col, vd, Bd, n, n))
+    else:
+        rp_t = _ops._pack_for(pt, G, Bd)
+        rp_f = _ops._pack_for(plan, Bd)
+        rp_s = _ops._pack_for(plan, Bd, G, need_plain_slots=True)
+
+        def form(rp):
+            return "class dictionary, %d classes" % rp.nclasses if rp.nclasses else "per-workgroup streams"
+
+        bwd_name = (f"csr_rowpack_kernel (K2+K3 fused bwd, row pairs, {form(rp_t)})" if rp_t is not None
+                    else "csr_mm_backward_kernel (K2+K3 fused bwd)")
+        fwd_name = f"csr_rowpack_kernel (K1 fwd, row pairs, {form(rp_f)})" if rp_f is not None else "csr_spmm_kernel (K1 fwd)"
+        kern = {
+            fwd_name: time_events(lambda: _ops.spmm(plan, vd, Bd), reps, dev),
+            bwd_name: time_events(lambda: _ops.mm_backward(plan, vd, G, Bd), reps, dev),
+        }
+        kbytes = {fwd_name: ab["spmm"], bwd_name: ab["bwd"]}
+        traffic_key = {fwd_name: "forward", bwd_name: "fused_backward"}
+        # kernels the step does not run (one-sided gradients, plan-free first sight), for reference
+        if rp_s is not None:
+            alt("csr_rowpack_kernel (K3 alone, row-pair SDDMM: A-only gradients)", ab["sddmm"], lambda: _ops.sddmm(plan, G, Bd))
+        if rp_t is not None:
+            alt("csr_rowpack_kernel (K2 alone, row pairs: B-only gradients)", ab["spmm_t"], lambda: _ops.spmm(pt, vd, G))
+            alt("csr_mm_backward_kernel (K2+K3 fused bwd, plan-free first sight)", ab["bwd"], lambda: be.csr_mm_backward(pt, vd, G, Bd, n, n))
+        if rp_f is not None:
+            alt("csr_spmm_kernel (K1 fwd, plan-free first sight)", ab["spmm"], lambda: be.csr_spmm(plan.crow, plan.col, vd, Bd, n, n))
     alt("csr_sddmm_kernel (K3 alone, plan-free)", ab["sddmm"], lambda: be.csr_sddmm(plan.crow, plan.col, G, Bd, n, n))
     alt("csr_spmm_kernel perm (K2 alone, plan-free)", ab["spmm_t"], lambda: be.csr_spmm(pt.crow, pt.col, vd, G, n, n, perm=pt.perm))
     dominant = max(kern, key=kern.get)
@@ -315,9 +352,8 @@ def main():
     if os.path.exists(tpath) and [nx, ny, nz, p] == [100, 100, 100, 32]:
         try:
             tj = json.load(open(tpath))
-            key = "fused_backward" if dominant == bwd_name else "forward"
-            if tj.get("plan_form") == (form(rp_t) if dominant == bwd_name else form(rp_f)).split(",")[0]:
-                traffic = tj.get(key)
+            traffic = tj.get(traffic_key[dominant])
+            if traffic is not None:
                 traffic_source = f"{tj.get('source')}@{tj.get('commit')} (rocprofv3 PMC passes; not measured in this run)"
         except Exception:  # noqa: BLE001
             traffic = None
@@ -343,7 +379,7 @@ def main():
     plan_stats = {"cache_entries": _pattern.cache_stats()[0], "plan_bytes_resident": _pattern.cache_stats()[1]}
     c5 = None
     if not args.no_c5:
-        del A, B, G, val, crow, col, plan, pt, rp_t, rp_f, rp_s, Bd, vd
+        del A, B, G, val, crow, col, plan, pt, rp_t, rp_f, rp_s, Bd, vd, lat_f, lat_s, lat_t
         _pattern.clear_cache()
         torch.cuda.empty_cache()
         try:
@@ -381,9 +417,11 @@ def main():
                               "(reference harness form, includes torch's AccumulateGrad copies of the sparse gradient) is ms_per_step_backward_call",
                 "first_steps_ms": [round(x, 2) for x in first_ms],
                 "plan_policy": f"first sight of a pattern: plan-free gather kernels + transposed pattern; from use {_ops.PLAN_AFTER_USES + 1} on "
-                               + ("the row-pair plans are built on a worker thread + side stream while the steps keep running plan-free "
-                                  "(first_steps_ms[1:] are such steps); the warm-up joins the build" if _ops.PLAN_ASYNC else
-                                  "the row-pair plans are built inline (first_steps_ms[1] includes the build)"),
+                               + ("the lattice plans (row classes of the stencil) are built inline — first_steps_ms[1] includes that — and "
+                                  "the step runs on the plane-sweep kernels" if lattice else
+                                  ("the row-pair plans are built on a worker thread + side stream while the steps keep running plan-free "
+                                   "(first_steps_ms[1:] are such steps); the warm-up joins the build" if _ops.PLAN_ASYNC else
+                                   "the row-pair plans are built inline (first_steps_ms[1] includes the build)")),
                 "plan_join_ms_after_3_steps": round(plan_join_ms, 1),
                 "plans": plan_stats,
             },
@@ -402,6 +440,7 @@ def main():
                 "algorithmic_bytes_per_launch": kbytes[dominant],
             },
             "kernels_ms": {k: round(v, 5) for k, v in {**kern, **kern_alt}.items()},
+            "kernels_ms_in_step": {k: round(v, 5) for k, v in in_step.items()},
             "kernels_GBps": {k: round(kbytes[k] / (v * 1e-3) / 1e9, 1) for k, v in {**kern, **kern_alt}.items()},
             "device_copy_GBps": round(copy_gbs, 1),
             "cpu_baseline": cpu,

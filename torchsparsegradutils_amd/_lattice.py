@@ -297,7 +297,8 @@ def workgroup_classes(plan: LatticePlan, ty: int, tz: int, nseg: int) -> torch.T
 
 # ---- launch configuration ------------------------------------------------------------------------------------
 
-_NLOC_GUESS = (27, 48)    # classes a workgroup typically meets (stored-order / transposed walk): sizes the LDS estimate
+_NLOC_GUESS = (8, 27)     # classes a workgroup meets at least (stored-order / transposed walk): optimistic LDS estimate for
+                          # ranking; config_for checks the real lists and falls back to the next candidate
 _CFG_ENV = os.environ.get("TSGU_LATTICE_CFG", "")   # "ty,tz,nseg,threads[,ring]" overrides the choice (experiments)
 
 
@@ -310,14 +311,21 @@ def _candidates(limit: int):
 
 def choose_config(plan: LatticePlan, mode: int, vtype: int, p: int, elem_bytes: int, lds_bytes_fn) -> Optional[Tuple[int, int, int, int, int]]:
     """(ty, tz, nseg, threads, ring) for `plan`: the tile with the best modelled throughput that fits the kernels' limits."""
+    ranked = rank_configs(plan, mode, vtype, p, elem_bytes, lds_bytes_fn)
+    return ranked[0] if ranked else None
+
+
+def rank_configs(plan: LatticePlan, mode: int, vtype: int, p: int, elem_bytes: int, lds_bytes_fn, keep: int = 6):
+    """Candidate launch configurations, best modelled throughput first."""
     if _CFG_ENV:
         v = [int(t) for t in _CFG_ENV.split(",")]
-        return v[0], v[1], min(v[2], plan.nx), v[3], (v[4] if len(v) > 4 else 4)
+        return [(v[0], v[1], min(v[2], plan.nx), v[3], (v[4] if len(v) > 4 else 4))]
     cl = p * elem_bytes // 16
-    best, best_cost = None, None
+    found = {}
+    alpha = 0.35 if plan.kind == 0 else 0.8       # what a halo row costs relative to an own row (the transposed walk also stages its values)
     for threads in (512, 1024):
         rpp = threads // cl
-        for ty, tz in _candidates(2 * rpp):
+        for ty, tz in _candidates(rpp):           # one row per lane group and plane step
             if ty > plan.ny or tz > plan.nz or (plan.ny == 1 and ty != 1):
                 continue
             ring = 4
@@ -328,26 +336,27 @@ def choose_config(plan: LatticePlan, mode: int, vtype: int, p: int, elem_bytes: 
             if per_cu < 1:
                 continue
             nr = ty * tz
-            passes = -(-nr // rpp)
             tiles = -(-plan.ny // ty) * -(-plan.nz // tz)
-            lane_util = (plan.ny * plan.nz) / (tiles * passes * rpp)
+            lane_util = (plan.ny * plan.nz) / (tiles * rpp)
             halo = (ty + 2 * plan.ry) * (tz + 2 * plan.rz) / nr
             slots = _NUM_CU * per_cu
-            # x segments: enough workgroups to fill the chip, as few as possible beyond that (each costs two halo planes)
+            # measured (C2, fp32): two independent workgroups per CU overlap each other's barrier / DMA waits (1.0); one
+            # workgroup of 16 waves is ~15 % slower; 8 waves per CU cannot hide the LDS latency (~1.5x)
+            waves = per_cu * threads // 64
+            hide = 1.5 if waves < 16 else (1.0 if per_cu >= 2 else 1.15)
             base = plan.nb * tiles
-            nseg = max(1, min(plan.nx, -(-slots // base)))
-            while nseg > 1 and -(-plan.nx // nseg) * (nseg - 1) >= plan.nx:
-                nseg -= 1
-            nwg = base * nseg
-            rounds = -(-nwg // slots)
-            fill = nwg / (rounds * slots)
-            seg_len = -(-plan.nx // nseg)
-            waves_per_cu = per_cu * threads // 64
-            hide = 1.0 if waves_per_cu >= 16 else 1.25
-            cost = (1.0 / lane_util) * (1.0 + 0.35 * (halo - 1.0)) * (1.0 + 2.0 / seg_len) / fill * hide
-            if best_cost is None or cost < best_cost:
-                best, best_cost = (ty, tz, nseg, threads, ring), cost
-    return best
+            # x segments: fill the chip's workgroup slots evenly; every segment re-reads two halo planes
+            for nseg in range(1, min(plan.nx, 64) + 1):
+                seg_len = -(-plan.nx // nseg)
+                if seg_len * (nseg - 1) >= plan.nx:
+                    continue
+                nwg = base * nseg
+                fill = nwg / (-(-nwg // slots) * slots)
+                cost = (1.0 / lane_util) * (1.0 + alpha * (halo - 1.0)) * (1.0 + 2.0 / seg_len) / fill * hide
+                key = (ty, tz, threads)
+                if key not in found or cost < found[key][0]:
+                    found[key] = (cost, (ty, tz, nseg, threads, ring))
+    return [c for _, c in sorted(found.values())[:keep]]
 
 
 class _LatticePlanStruct(ctypes.Structure):
@@ -362,20 +371,20 @@ def config_for(plan: LatticePlan, mode: int, vtype: int, p: int, elem_bytes: int
     key = (mode, vtype, p)
     cfg = plan._cfg.get(key)
     if cfg is None and key not in plan._cfg:
-        choice = choose_config(plan, mode, vtype, p, elem_bytes, lds_bytes_fn)
-        if choice is not None:
-            ty, tz, nseg, threads, ring = choice
+        for ty, tz, nseg, threads, ring in rank_configs(plan, mode, vtype, p, elem_bytes, lds_bytes_fn):
             wlist = workgroup_classes(plan, ty, tz, nseg)
             nloc = wlist.size(1)
             lds = lds_bytes_fn(mode, vtype, p, ty, tz, plan.ry, plan.rz, nloc, plan.recw, threads, ring)
-            if lds > 0:
-                slot = (plan.recw * (4 if mode == _MODE_SDDMM else elem_bytes) + 15) // 16 * 16
-                cfg = LatticeConfig()
-                cfg.ty, cfg.tz, cfg.nseg, cfg.threads, cfg.lds_bytes = ty, tz, nseg, threads, lds
-                cfg.wlist, cfg.nloc, cfg.ring = wlist, nloc, ring
-                cfg.rec = records(plan, ty, tz, p * elem_bytes, slot, ring).to(plan.rcls.device)
-                cfg.struct = _LatticePlanStruct(plan.kind, plan.nb, plan.nx, plan.ny, plan.nz, plan.ry, plan.rz, plan.ncls, plan.recw,
-                                                nloc, plan.uniform_len, ty, tz, nseg, threads, ring, cfg.rec.data_ptr(), plan.lens.data_ptr(),
-                                                plan.rcls.data_ptr(), plan.rstart.data_ptr(), wlist.data_ptr())
+            if lds <= 0:
+                continue      # the workgroups of this tiling meet more classes than the ranking assumed
+            slot = (plan.recw * (4 if mode == _MODE_SDDMM else elem_bytes) + 15) // 16 * 16
+            cfg = LatticeConfig()
+            cfg.ty, cfg.tz, cfg.nseg, cfg.threads, cfg.lds_bytes = ty, tz, nseg, threads, lds
+            cfg.wlist, cfg.nloc, cfg.ring = wlist, nloc, ring
+            cfg.rec = records(plan, ty, tz, p * elem_bytes, slot, ring).to(plan.rcls.device)
+            cfg.struct = _LatticePlanStruct(plan.kind, plan.nb, plan.nx, plan.ny, plan.nz, plan.ry, plan.rz, plan.ncls, plan.recw,
+                                            nloc, plan.uniform_len, ty, tz, nseg, threads, ring, cfg.rec.data_ptr(), plan.lens.data_ptr(),
+                                            plan.rcls.data_ptr(), plan.rstart.data_ptr(), wlist.data_ptr())
+            break
         plan._cfg[key] = cfg
     return cfg

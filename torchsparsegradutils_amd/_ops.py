@@ -38,7 +38,7 @@ PLAN_ASYNC = os.environ.get("TSGU_PLAN_ASYNC", "1") == "1"
 ENABLE_LATTICE = os.environ.get("TSGU_ENABLE_LATTICE", "1") == "1"
 
 
-def _lattice_plan(plan: RowGather, value_crow=None):
+def _lattice_plan(plan: RowGather, value_crow=None, count: bool = True):
     """LatticePlan of the 2-D `plan` (None: not a lattice stencil / not seen often enough yet); cached with the pattern.
     The detection + class build is a handful of index ops (no sorts of the entries): done inline at the
     PLAN_AFTER_USES-th sight of the pattern."""
@@ -48,20 +48,21 @@ def _lattice_plan(plan: RowGather, value_crow=None):
         return None
     own = plan.core.own
     if "lattice" not in own:
-        seen = own["lattice_uses"] = own.get("lattice_uses", 0) + 1
+        # one count per step: the product (forward / transposed walk) counts, the SDDMM of the same step does not
+        seen = own["lattice_uses"] = own.get("lattice_uses", 0) + (1 if count else 0)
         if seen <= PLAN_AFTER_USES:
             return None
         own["lattice"] = _lt.build_lattice_plan(plan, value_crow=value_crow)
     return own["lattice"]
 
 
-def _lattice_cfg(plan: RowGather, mode: int, dense: torch.Tensor, *others: torch.Tensor, value_crow=None):
+def _lattice_cfg(plan: RowGather, mode: int, dense: torch.Tensor, *others: torch.Tensor, value_crow=None, count: bool = True):
     """(LatticePlan, LatticeConfig) for these operands or None."""
     if not ENABLE_LATTICE or dense.dim() != 2 or not _be._tiled_ok(*(_be.rowmajor(t) for t in (dense,) + others)):
         return None
     if dense.dtype not in (torch.float32, torch.bfloat16):
         return None
-    lp = _lattice_plan(plan, value_crow)
+    lp = _lattice_plan(plan, value_crow, count)
     if lp is None:
         return None
     cfg = _be.lattice_config(lp, mode, dense.dtype, dense.size(-1))
@@ -114,10 +115,10 @@ def _lattice_backward(plan: RowGather, values: torch.Tensor, G: torch.Tensor, B:
         if fl is None:
             return None
         fplan, (Gf, Bf) = fl
-    fwd = _lattice_cfg(fplan, _be.LAT_SDDMM, Bf, Gf)
+    bwd = _lattice_cfg(fplan.transposed, _be.LAT_SPMMT, Gf, value_crow=fplan.crow)
+    fwd = _lattice_cfg(fplan, _be.LAT_SDDMM, Bf, Gf, count=False)
     if fwd is None:
         return None
-    bwd = _lattice_cfg(fplan.transposed, _be.LAT_SPMMT, Gf, value_crow=fplan.crow)
     if bwd is None:
         return None
     vals = values.reshape(-1)
@@ -185,7 +186,7 @@ def sddmm(plan: RowGather, G: torch.Tensor, B: torch.Tensor, alpha: float = 1.0,
     gathered = G if swap_roles else B
     rowop = B if swap_roles else G
     if plan.perm is None and G.dtype == B.dtype:
-        got = _lattice_cfg(plan, _be.LAT_SDDMM, gathered, rowop)
+        got = _lattice_cfg(plan, _be.LAT_SDDMM, gathered, rowop, count=plan.core.own.get("lattice_uses", 0) <= PLAN_AFTER_USES and plan.core.t is None)
         if got is not None:
             return _be.csr_sddmm_lattice(got[0], got[1], rowop, gathered, alpha=alpha)
         rp = _pack_for(plan, gathered, rowop, need_plain_slots=True)

@@ -533,19 +533,13 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
                         float* const st = reinterpret_cast<float*>(sm + P.o_vals + csl[q]);   // fp32 staging row (slot = recw*4 bytes in this mode)
                         plen[q] = len;
                         prst[q] = cur.rst[q];
-#pragma unroll kUnroll
-                        for (int k0 = 0; k0 < recw; k0 += 4) {
-                            const int4 ro = *reinterpret_cast<const int4*>(tb + k0 * 4);
-                            const int rv[4] = {ro.x, ro.y, ro.z, ro.w};
-                            float b[4][VEC];
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) load_vec<V, VEC>(reinterpret_cast<const V*>(cb + rv[j]), b[j]);
+                        auto consume = [&](int k0, const float (&bb)[4][VEC]) {
                             float dsum[4];
 #pragma unroll
                             for (int j = 0; j < 4; ++j) {
-                                float d = cur.own[q][0] * b[j][0];
+                                float d = cur.own[q][0] * bb[j][0];
 #pragma unroll
-                                for (int v = 1; v < VEC; ++v) d = fmaf(cur.own[q][v], b[j][v], d);
+                                for (int v = 1; v < VEC; ++v) d = fmaf(cur.own[q][v], bb[j][v], d);
                                 dsum[j] = group_sum<float, CL>(d);
                             }
                             if constexpr (CL >= 4) {
@@ -557,6 +551,37 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
                                 st[k0 + c] = P.alpha * (c == 0 ? dsum[0] : dsum[1]);
                                 st[k0 + 2 + c] = P.alpha * (c == 0 ? dsum[2] : dsum[3]);
                             }
+                        };
+                        if constexpr (NCH > 0) {   // three stages, as in the SpMM above
+                            int4 ro[3];
+                            float b[2][4][VEC];
+                            auto stage_b = [&](int i) {
+                                const int rv[4] = {ro[i % 3].x, ro[i % 3].y, ro[i % 3].z, ro[i % 3].w};
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) load_vec<V, VEC>(reinterpret_cast<const V*>(cb + rv[j]), b[i & 1][j]);
+                            };
+                            ro[0] = *reinterpret_cast<const int4*>(tb);
+                            if (NCH > 1) ro[1] = *reinterpret_cast<const int4*>(tb + 16);
+                            asm volatile("" ::: "memory");
+                            stage_b(0);
+#pragma unroll
+                            for (int i = 0; i < NCH; ++i) {
+                                if (i + 2 < NCH) ro[(i + 2) % 3] = *reinterpret_cast<const int4*>(tb + 16 * (i + 2));
+                                asm volatile("" ::: "memory");
+                                if (i + 1 < NCH) stage_b(i + 1);
+                                asm volatile("" ::: "memory");
+                                consume(4 * i, b[i & 1]);
+                            }
+                        } else {
+#pragma unroll 2
+                            for (int k0 = 0; k0 < recw; k0 += 4) {
+                                const int4 ro = *reinterpret_cast<const int4*>(tb + k0 * 4);
+                                const int rv[4] = {ro.x, ro.y, ro.z, ro.w};
+                                float b[4][VEC];
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) load_vec<V, VEC>(reinterpret_cast<const V*>(cb + rv[j]), b[j]);
+                                consume(k0, b);
+                            }
                         }
                     } else {
                         // transposed walk: value of entry k of halo row i sits at slot k of i's staged value row
@@ -564,21 +589,55 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
                         const char* const vcb = sm + P.o_vals + csl[q];
 #pragma unroll
                         for (int v = 0; v < VEC; ++v) acc[q][v] = 0.f;
-#pragma unroll kUnroll
-                        for (int k0 = 0; k0 < recw; k0 += 4) {
-                            const int4 r01 = *reinterpret_cast<const int4*>(tb + k0 * 8);
-                            const int4 r23 = *reinterpret_cast<const int4*>(tb + k0 * 8 + 16);
-                            const int go[4] = {r01.x, r01.z, r23.x, r23.z}, vo[4] = {r01.y, r01.w, r23.y, r23.w};
-                            float b[4][VEC], a[4];
+                        if constexpr (NCH > 0) {   // three stages: records of chunk i+2, dense rows + values of chunk i+1, FMAs of chunk i
+                            int4 r01[3], r23[3];
+                            float b[2][4][VEC], a[2][4];
+                            auto stage_a = [&](int i) {
+                                r01[i % 3] = *reinterpret_cast<const int4*>(tb + 32 * i);
+                                r23[i % 3] = *reinterpret_cast<const int4*>(tb + 32 * i + 16);
+                            };
+                            auto stage_b = [&](int i) {
+                                const int go[4] = {r01[i % 3].x, r01[i % 3].z, r23[i % 3].x, r23[i % 3].z};
+                                const int vo[4] = {r01[i % 3].y, r01[i % 3].w, r23[i % 3].y, r23[i % 3].w};
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                load_vec<V, VEC>(reinterpret_cast<const V*>(cb + go[j]), b[j]);
-                                a[j] = *reinterpret_cast<const float*>(vcb + vo[j]);
+                                for (int j = 0; j < 4; ++j) {
+                                    load_vec<V, VEC>(reinterpret_cast<const V*>(cb + go[j]), b[i & 1][j]);
+                                    a[i & 1][j] = *reinterpret_cast<const float*>(vcb + vo[j]);
+                                }
+                            };
+                            stage_a(0);
+                            if (NCH > 1) stage_a(1);
+                            asm volatile("" ::: "memory");
+                            stage_b(0);
+#pragma unroll
+                            for (int i = 0; i < NCH; ++i) {
+                                if (i + 2 < NCH) stage_a(i + 2);
+                                asm volatile("" ::: "memory");
+                                if (i + 1 < NCH) stage_b(i + 1);
+                                asm volatile("" ::: "memory");
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                                    for (int v = 0; v < VEC; ++v) acc[q][v] = fmaf(a[i & 1][j], b[i & 1][j][v], acc[q][v]);
+                                }
                             }
+                        } else {
+#pragma unroll 2
+                            for (int k0 = 0; k0 < recw; k0 += 4) {
+                                const int4 r01 = *reinterpret_cast<const int4*>(tb + k0 * 8);
+                                const int4 r23 = *reinterpret_cast<const int4*>(tb + k0 * 8 + 16);
+                                const int go[4] = {r01.x, r01.z, r23.x, r23.z}, vo[4] = {r01.y, r01.w, r23.y, r23.w};
+                                float b[4][VEC], a[4];
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) {
+                                for (int j = 0; j < 4; ++j) {
+                                    load_vec<V, VEC>(reinterpret_cast<const V*>(cb + go[j]), b[j]);
+                                    a[j] = *reinterpret_cast<const float*>(vcb + vo[j]);
+                                }
 #pragma unroll
-                                for (int v = 0; v < VEC; ++v) acc[q][v] = fmaf(a[j], b[j][v], acc[q][v]);
+                                for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                                    for (int v = 0; v < VEC; ++v) acc[q][v] = fmaf(a[j], b[j][v], acc[q][v]);
+                                }
                             }
                         }
                     }
