@@ -241,7 +241,9 @@ int tsgu_csr_sddmm_rowpack(int vtype, int itype, int64_t n_rows, int64_t n_cols,
  *                                   plane of a segment)
  *         kind 1 (transposed walk: Aᵀ·G reads entry k' of SOURCE row i = row + displacement):
  *         [ring][ncls][recw][2] int32  {the same for the dense rows, the same displacement in the value ring (rows of
- *                                   `slot` = recw·4 rounded to 16 bytes) + 4·k'}
+ *                                   `slot` = recw·4 rounded to 16 bytes) + 4·k'};  when a dense row is a multiple of 128 bytes
+ *                                   the value ring takes the pitch of the dense ring and the table is [ring][ncls][recw] int32:
+ *                                   dense-row offset (a multiple of 128) + 4·k' in the low 7 bits
  *   padded entries (k >= lens[c]) hold 0x7ff00: reads that far beyond the row's own position are beyond the LDS allocation and
  *   return zero on gfx950, so padded entries contribute exactly 0 and no dense row is touched that the sparse row does not reference.
  * Sums run in ascending entry order of the walked pattern (the order of the plan-free kernels).  fp32 and bf16 values
@@ -258,6 +260,8 @@ typedef struct tsgu_lattice_plan {
     int32_t nseg;             /* x segments per item */
     int32_t threads;          /* workgroup size: 256, 512 or 1024 */
     int32_t ring;             /* halo planes resident in LDS (4..8): 3 in use + ring-3 in flight ahead of the computation */
+    int32_t chunks_per_lane;  /* 16-byte chunks of a dense row per lane: 1, or 2 (dense rows of >= 128 bytes, recw == 28): half the
+                                 lanes per row, twice the rows per wave */
     const void* rec;
     const void* lens;
     const void* rcls;
@@ -268,7 +272,8 @@ typedef struct tsgu_lattice_plan {
 
 /* Dynamic LDS bytes of a configuration (mode: 0 SpMM, 1 SDDMM, 2 transposed SpMM), or a negative tsgu_status when it
  * does not fit the kernels' limits (160 KiB of LDS, DMA pieces and row passes per thread). */
-int tsgu_lattice_lds_bytes(int mode, int vtype, int64_t p, int ty, int tz, int ry, int rz, int nloc, int recw, int threads, int ring);
+int tsgu_lattice_lds_bytes(int mode, int vtype, int64_t p, int ty, int tz, int ry, int rz, int nloc, int recw, int threads, int ring,
+                           int chunks_per_lane);
 /* C = A·B (plan kind 0, the pattern of A) or gradB = Aᵀ·G (plan kind 1, the transposed pattern; `val` is A's value array
  * in A's own order, `B` is G).  n_rows = nb·nx·ny·nz. */
 int tsgu_csr_spmm_lattice(int vtype, const tsgu_lattice_plan* plan, int64_t n_rows, int64_t nnz, const void* val,

@@ -265,6 +265,7 @@ def test_public_path_batched_bf16(monkeypatch):
     from torchsparsegradutils_amd.utils import synthetic
 
     monkeypatch.setattr(_ops, "ENABLE_LATTICE", True)
+    monkeypatch.setattr(_ops, "LATTICE_DTYPES", (torch.float32, torch.bfloat16))
     monkeypatch.setattr(_ops, "PLAN_AFTER_USES", 0)
     dev = torch.device("cuda:0")
     b, nx, ny, nz, p = 3, 8, 16, 16, 16

@@ -56,6 +56,9 @@ def _stencil(nx, ny, nz, periodic, points=27, lower=False, nb=1):
 def _emulate(plan, crow, col, perm, value_crow, ty, tz, nseg, row_bytes=128, elem=4, ring_slots=4):
     """Walk every workgroup / plane / row / entry like the kernel does; returns the number of entries checked."""
     slot_bytes = (plan.recw * elem + 15) // 16 * 16
+    packed = lt.PACKED_T and plan.kind == 1 and row_bytes % 128 == 0
+    if packed:
+        slot_bytes = row_bytes
     R, K = ring_slots, ring_slots - 3
     rec = lt.records(plan, ty, tz, row_bytes, slot_bytes, R).numpy().astype(np.int64)
     nb, nx, ny, nz, ry, rz = plan.nb, plan.nx, plan.ny, plan.nz, plan.ry, plan.rz
@@ -101,6 +104,8 @@ def _emulate(plan, crow, col, perm, value_crow, ty, tz, nseg, row_bytes=128, ele
                                 assert lens[c] == crow[row + 1] - crow[row]
                                 for k in range(plan.recw):
                                     w = rec[xo % R, c, k]
+                                    if packed:
+                                        w = (int(w) & ~127, int(w))
                                     lo = int(w[0]) if plan.kind == 1 else int(w)
                                     if k >= lens[c]:
                                         assert lo == lt.PAD_LO and (plan.kind == 0 or int(w[1]) == lt.PAD_HI)
@@ -171,9 +176,9 @@ def test_records_lead_to_the_stored_columns(nb, nx, ny, nz, periodic, points, lo
     tplan = lt.build_lattice_plan(t, value_crow=crow, dims=(nb, nx, ny, nz))
     assert tplan is not None and tplan.kind == 1 and tplan.ncls <= 125
     _check_workgroup_classes(tplan, tile[0], tile[1], nseg)
-    for ring_slots in (4, 6):
+    for ring_slots, row_bytes in ((4, 128), (6, 128), (4, 64)):      # 128-byte rows: packed records; 64: two words
         got = _emulate(tplan, t.crow, t.col, t.perm.numpy().astype(np.int64), crow.numpy().astype(np.int64), tile[0], tile[1], nseg,
-                       ring_slots=ring_slots)
+                       row_bytes=row_bytes, ring_slots=ring_slots)
         assert got == col.numel()
 
 
@@ -220,10 +225,10 @@ def test_config_choice_is_within_limits():
     g = pt.RowGather(crow, col, 1920, 1920)
     plan = lt.build_lattice_plan(g)
 
-    def fake_lds(mode, vtype, p, ty, tz, ry, rz, ncls, recw, threads, ring):
+    def fake_lds(mode, vtype, p, ty, tz, ry, rz, ncls, recw, threads, ring, cpl=1):
         hr = (ty + 2 * ry) * (tz + 2 * rz)
         total = ring * hr * p * 4 + (ring - 2) * ty * tz * 112 + 8192
         return total if total <= 160 * 1024 and hr * 8 <= 3 * threads else -3
 
-    ty, tz, nseg, threads, ring = lt.choose_config(plan, 0, 0, 32, 4, fake_lds)
+    ty, tz, nseg, threads, ring, cpl = lt.choose_config(plan, 0, 0, 32, 4, fake_lds)
     assert ty <= plan.ny and tz <= plan.nz and 1 <= nseg <= plan.nx and threads in (512, 1024) and 4 <= ring <= 8

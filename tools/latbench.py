@@ -114,7 +114,7 @@ def main():
                 d = (out.float() - ref[m].float()).abs().max().item()
                 err = f" maxdiff={d:.3g} equal={torch.equal(out, ref[m])}"
             ms = ev(fn, a.reps)
-            print(f"{m:6s} cfg=({cfg.ty},{cfg.tz},{cfg.nseg},{cfg.threads},{cfg.ring}) nloc={cfg.nloc} lds={cfg.lds_bytes}: {ms * 1e3:8.1f} us  {by[m] / ms / 1e6:7.0f} GB/s{err}", flush=True)
+            print(f"{m:6s} cfg=({cfg.ty},{cfg.tz},{cfg.nseg},{cfg.threads},{cfg.ring},{cfg.cpl}) nloc={cfg.nloc} lds={cfg.lds_bytes}: {ms * 1e3:8.1f} us  {by[m] / ms / 1e6:7.0f} GB/s{err}", flush=True)
 
 
 if __name__ == "__main__":

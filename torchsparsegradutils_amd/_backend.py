@@ -73,7 +73,7 @@ SIGNATURES = {
         _int, [_int, _int, _i64, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _i64, _int, _ptr]),
     "tsgu_csr_sddmm_rowpack": (
         _int, [_int, _int, _i64, _i64, _i64, _ptr, _ptr, _ptr, _i64, _ptr, _i64, _ptr, _dbl, _i64, _int, _ptr]),
-    "tsgu_lattice_lds_bytes": (_int, [_int, _int, _i64, _int, _int, _int, _int, _int, _int, _int, _int]),
+    "tsgu_lattice_lds_bytes": (_int, [_int, _int, _i64, _int, _int, _int, _int, _int, _int, _int, _int, _int]),
     "tsgu_csr_spmm_lattice": (_int, [_int, _ptr, _i64, _i64, _ptr, _ptr, _i64, _ptr, _i64, _i64, _int, _ptr]),
     "tsgu_csr_sddmm_lattice": (_int, [_int, _ptr, _i64, _i64, _ptr, _i64, _ptr, _i64, _ptr, _dbl, _i64, _int, _ptr]),
     "tsgu_csr_sptrsm": (
@@ -406,9 +406,9 @@ LAT_SPMM, LAT_SDDMM, LAT_SPMMT = 0, 1, 2
 
 
 def lattice_lds_bytes(mode: int, vtype: int, p: int, ty: int, tz: int, ry: int, rz: int, nloc: int, recw: int, threads: int,
-                      ring: int = 4) -> int:
+                      ring: int = 4, cpl: int = 1) -> int:
     """Dynamic LDS bytes of a lattice launch configuration, or a negative tsgu status when it does not fit."""
-    return int(load_library().tsgu_lattice_lds_bytes(mode, vtype, p, ty, tz, ry, rz, nloc, recw, threads, ring))
+    return int(load_library().tsgu_lattice_lds_bytes(mode, vtype, p, ty, tz, ry, rz, nloc, recw, threads, ring, cpl))
 
 
 def lattice_config(lp, mode: int, dtype: torch.dtype, p: int):
@@ -423,35 +423,58 @@ def lattice_config(lp, mode: int, dtype: torch.dtype, p: int):
     return _lattice.config_for(lp, mode, _VTYPE[dtype], p, es, lattice_lds_bytes)
 
 
+class _on_device:
+    """`with torch.cuda.device(dev)` only when `dev` is not already current (the context manager costs ~8 us per launch)."""
+
+    __slots__ = ("ctx",)
+
+    def __init__(self, dev: torch.device):
+        self.ctx = None if torch.cuda.current_device() == dev.index else torch.cuda.device(dev)
+
+    def __enter__(self):
+        if self.ctx is not None:
+            self.ctx.__enter__()
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+
+
 def csr_spmm_lattice(lp, cfg, val, B):
     """C = A·B (plan kind 0) or Aᵀ·B for the transposed plan (kind 1; `val` in A's own order) by the plane sweep."""
-    lib = load_library()
-    dev = require_device(val, B)
+    lib = _lib or load_library()
+    dev = B.device
+    if not B.is_cuda or val.device != dev:
+        require_device(val, B)
+        raise RuntimeError(f"all operands must be on the same device, got {val.device} and {dev}")
     B = rowmajor(B)
     p = B.size(-1)
     out = torch.empty((lp.n_rows, p), dtype=B.dtype, device=dev)
-    with torch.cuda.device(dev):
-        check(
-            lib.tsgu_csr_spmm_lattice(vtype_of(val), ctypes.addressof(cfg.struct), lp.n_rows, lp.nnz, _p(val.contiguous()), _p(B), _ld(B),
-                                      _p(out), _ld(out), p, dev.index, _stream(dev)),
-            "tsgu_csr_spmm_lattice",
-        )
+    if not val.is_contiguous():
+        val = val.contiguous()
+    with _on_device(dev):
+        rc = lib.tsgu_csr_spmm_lattice(_VTYPE[val.dtype], cfg.struct_addr, lp.n_rows, lp.nnz, val.data_ptr(), B.data_ptr(), _ld(B),
+                                       out.data_ptr(), p, p, dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    if rc:
+        check(rc, "tsgu_csr_spmm_lattice")
     return out
 
 
 def csr_sddmm_lattice(lp, cfg, R, Cm, alpha: float = 1.0):
     """out[k] = alpha·<R[row k], Cm[col k]> in stored order by the plane sweep (plan kind 0)."""
-    lib = load_library()
-    dev = require_device(R, Cm)
+    lib = _lib or load_library()
+    dev = R.device
+    if not R.is_cuda or Cm.device != dev:
+        require_device(R, Cm)
+        raise RuntimeError(f"all operands must be on the same device, got {Cm.device} and {dev}")
     R, Cm = rowmajor(R), rowmajor(Cm)
     p = R.size(-1)
     out = torch.empty((lp.nnz,), dtype=R.dtype, device=dev)
-    with torch.cuda.device(dev):
-        check(
-            lib.tsgu_csr_sddmm_lattice(vtype_of(R), ctypes.addressof(cfg.struct), lp.n_rows, lp.nnz, _p(R), _ld(R), _p(Cm), _ld(Cm),
-                                       _p(out), float(alpha), p, dev.index, _stream(dev)),
-            "tsgu_csr_sddmm_lattice",
-        )
+    with _on_device(dev):
+        rc = lib.tsgu_csr_sddmm_lattice(_VTYPE[R.dtype], cfg.struct_addr, lp.n_rows, lp.nnz, R.data_ptr(), _ld(R), Cm.data_ptr(), _ld(Cm),
+                                        out.data_ptr(), float(alpha), p, dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    if rc:
+        check(rc, "tsgu_csr_sddmm_lattice")
     return out
 
 

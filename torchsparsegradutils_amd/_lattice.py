@@ -26,6 +26,7 @@ MAX_RADIUS = 2
 MAX_LEN = 32
 PAD_LO = PAD_HI = 0x7FF00     # bytes: reads this far beyond the row's own LDS position are beyond the allocation and return 0
 _MODE_SPMM, _MODE_SDDMM, _MODE_SPMMT = 0, 1, 2
+PACKED_T = False    # one-word records for the transposed walk (must match kPacked in csrc/lattice_impl.h; measured slower)
 _NUM_CU = 256
 
 
@@ -53,7 +54,7 @@ class LatticePlan:
 class LatticeConfig:
     """One launch configuration of a plan: tile, segments, workgroup size and the record tables built for them."""
 
-    __slots__ = ("ty", "tz", "nseg", "threads", "rec", "lds_bytes", "struct", "wlist", "nloc", "ring")
+    __slots__ = ("ty", "tz", "nseg", "threads", "rec", "lds_bytes", "struct", "struct_addr", "wlist", "nloc", "ring", "cpl")
 
 
 def _frequent_offsets(g, rows64: torch.Tensor) -> Optional[list]:
@@ -260,9 +261,14 @@ def records(plan: LatticePlan, ty: int, tz: int, row_bytes: int, slot_bytes: int
             out.append(lo.to(torch.int32))
         else:
             k = torch.where(valid, plan.ksrc, torch.zeros_like(plan.ksrc))
-            hi = slot * (hr * slot_bytes) + (dy * hz + dz) * slot_bytes + k * 4
-            hi = torch.where(valid, hi, torch.full_like(hi, PAD_HI))
-            out.append(torch.stack((lo, hi), -1).to(torch.int32))
+            if PACKED_T and row_bytes % 128 == 0:
+                # the value ring has the pitch of the dense ring: one word, value index in the low 7 bits
+                assert slot_bytes == row_bytes
+                out.append(torch.where(valid, lo + k * 4, torch.full_like(lo, PAD_LO)).to(torch.int32))
+            else:
+                hi = slot * (hr * slot_bytes) + (dy * hz + dz) * slot_bytes + k * 4
+                hi = torch.where(valid, hi, torch.full_like(hi, PAD_HI))
+                out.append(torch.stack((lo, hi), -1).to(torch.int32))
     return torch.stack(out, 0).contiguous()
 
 
@@ -299,7 +305,7 @@ def workgroup_classes(plan: LatticePlan, ty: int, tz: int, nseg: int) -> torch.T
 
 _NLOC_GUESS = (8, 27)     # classes a workgroup meets at least (stored-order / transposed walk): optimistic LDS estimate for
                           # ranking; config_for checks the real lists and falls back to the next candidate
-_CFG_ENV = os.environ.get("TSGU_LATTICE_CFG", "")   # "ty,tz,nseg,threads[,ring]" overrides the choice (experiments)
+_CFG_ENV = os.environ.get("TSGU_LATTICE_CFG", "")   # "ty,tz,nseg,threads[,ring[,chunks per lane]]" overrides the choice (experiments)
 
 
 def _candidates(limit: int):
@@ -319,7 +325,7 @@ def rank_configs(plan: LatticePlan, mode: int, vtype: int, p: int, elem_bytes: i
     """Candidate launch configurations, best modelled throughput first."""
     if _CFG_ENV:
         v = [int(t) for t in _CFG_ENV.split(",")]
-        return [(v[0], v[1], min(v[2], plan.nx), v[3], (v[4] if len(v) > 4 else 4))]
+        return [(v[0], v[1], min(v[2], plan.nx), v[3], (v[4] if len(v) > 4 else 4), (v[5] if len(v) > 5 else 1))]
     cl = p * elem_bytes // 16
     found = {}
     alpha = 0.35 if plan.kind == 0 else 0.8       # what a halo row costs relative to an own row (the transposed walk also stages its values)
@@ -355,7 +361,7 @@ def rank_configs(plan: LatticePlan, mode: int, vtype: int, p: int, elem_bytes: i
                 cost = (1.0 / lane_util) * (1.0 + alpha * (halo - 1.0)) * (1.0 + 2.0 / seg_len) / fill * hide
                 key = (ty, tz, threads)
                 if key not in found or cost < found[key][0]:
-                    found[key] = (cost, (ty, tz, nseg, threads, ring))
+                    found[key] = (cost, (ty, tz, nseg, threads, ring, 1))
     return [c for _, c in sorted(found.values())[:keep]]
 
 
@@ -363,7 +369,7 @@ class _LatticePlanStruct(ctypes.Structure):
     """``tsgu_lattice_plan`` of include/tsgu_hip.h."""
 
     _fields_ = [(k, ctypes.c_int32) for k in ("kind", "nb", "nx", "ny", "nz", "ry", "rz", "ncls", "recw", "nloc", "uniform_len",
-                                               "ty", "tz", "nseg", "threads", "ring")] + [(k, ctypes.c_void_p) for k in ("rec", "lens", "rcls", "rstart", "wlist")]
+                                               "ty", "tz", "nseg", "threads", "ring", "chunks_per_lane")] + [(k, ctypes.c_void_p) for k in ("rec", "lens", "rcls", "rstart", "wlist")]
 
 
 def config_for(plan: LatticePlan, mode: int, vtype: int, p: int, elem_bytes: int, lds_bytes_fn) -> Optional[LatticeConfig]:
@@ -371,20 +377,23 @@ def config_for(plan: LatticePlan, mode: int, vtype: int, p: int, elem_bytes: int
     key = (mode, vtype, p)
     cfg = plan._cfg.get(key)
     if cfg is None and key not in plan._cfg:
-        for ty, tz, nseg, threads, ring in rank_configs(plan, mode, vtype, p, elem_bytes, lds_bytes_fn):
+        for ty, tz, nseg, threads, ring, cpl in rank_configs(plan, mode, vtype, p, elem_bytes, lds_bytes_fn):
             wlist = workgroup_classes(plan, ty, tz, nseg)
             nloc = wlist.size(1)
-            lds = lds_bytes_fn(mode, vtype, p, ty, tz, plan.ry, plan.rz, nloc, plan.recw, threads, ring)
+            lds = lds_bytes_fn(mode, vtype, p, ty, tz, plan.ry, plan.rz, nloc, plan.recw, threads, ring, cpl)
             if lds <= 0:
                 continue      # the workgroups of this tiling meet more classes than the ranking assumed
             slot = (plan.recw * (4 if mode == _MODE_SDDMM else elem_bytes) + 15) // 16 * 16
+            if PACKED_T and mode == _MODE_SPMMT and (p * elem_bytes) % 128 == 0:
+                slot = p * elem_bytes      # packed records: the value ring has the pitch of the dense ring
             cfg = LatticeConfig()
             cfg.ty, cfg.tz, cfg.nseg, cfg.threads, cfg.lds_bytes = ty, tz, nseg, threads, lds
-            cfg.wlist, cfg.nloc, cfg.ring = wlist, nloc, ring
+            cfg.wlist, cfg.nloc, cfg.ring, cfg.cpl = wlist, nloc, ring, cpl
             cfg.rec = records(plan, ty, tz, p * elem_bytes, slot, ring).to(plan.rcls.device)
             cfg.struct = _LatticePlanStruct(plan.kind, plan.nb, plan.nx, plan.ny, plan.nz, plan.ry, plan.rz, plan.ncls, plan.recw,
-                                            nloc, plan.uniform_len, ty, tz, nseg, threads, ring, cfg.rec.data_ptr(), plan.lens.data_ptr(),
+                                            nloc, plan.uniform_len, ty, tz, nseg, threads, ring, cpl, cfg.rec.data_ptr(), plan.lens.data_ptr(),
                                             plan.rcls.data_ptr(), plan.rstart.data_ptr(), wlist.data_ptr())
+            cfg.struct_addr = ctypes.addressof(cfg.struct)
             break
         plan._cfg[key] = cfg
     return cfg

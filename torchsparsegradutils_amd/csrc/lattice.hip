@@ -38,6 +38,8 @@ int fill(LatParams& P, const tsgu_lattice_plan* pl, int mode, int vtype, int64_t
     P.nb = pl->nb, P.nx = pl->nx, P.ny = pl->ny, P.nz = pl->nz;
     P.ty = pl->ty, P.tz = pl->tz, P.ry = pl->ry, P.rz = pl->rz;
     P.ring = pl->ring;
+    P.cpl = pl->chunks_per_lane == 0 ? 1 : pl->chunks_per_lane;
+    if (P.cpl == 2 && (cl < 8 || pl->recw != 28)) return TSGU_ERR_BAD_ARG;
     P.tiles_y = (pl->ny + pl->ty - 1) / pl->ty;
     P.tiles_z = (pl->nz + pl->tz - 1) / pl->tz;
     P.nseg = pl->nseg;
@@ -69,12 +71,14 @@ int dispatch(int vtype, int mode, int cl, int threads, const LatParams& P, void*
 
 extern "C" {
 
-int tsgu_lattice_lds_bytes(int mode, int vtype, int64_t p, int ty, int tz, int ry, int rz, int nloc, int recw, int threads, int ring) {
+int tsgu_lattice_lds_bytes(int mode, int vtype, int64_t p, int ty, int tz, int ry, int rz, int nloc, int recw, int threads, int ring,
+                           int chunks_per_lane) {
     const int cl = lanes_of(vtype, p);
     if (cl == 0 || mode < 0 || mode > 2 || (mode == kLatSpmmT && vtype != TSGU_F32)) return TSGU_ERR_BAD_DTYPE;
     if (threads != 256 && threads != 512 && threads != 1024) return TSGU_ERR_BAD_ARG;
     LatParams P{};
     P.ty = ty, P.tz = tz, P.ry = ry, P.rz = rz, P.ncls = nloc, P.nloc = nloc, P.recw = recw, P.ring = ring;
+    P.cpl = chunks_per_lane == 0 ? 1 : chunks_per_lane;
     return lat_layout(P, mode, cl, vbytes_of(vtype), threads);
 }
 

@@ -52,6 +52,7 @@ constexpr int kLatPadRec = 0x7ff00;  // record of a padded table entry: this man
 struct LatParams {
     int nb, nx, ny, nz;      // items, planes per item, lines per plane, points per line
     int ty, tz, ry, rz;      // tile (lines x points) and halo radii
+    int cpl;                 // 16-byte chunks of a dense row per lane (1 or 2)
     int ring;                // halo planes resident in LDS: 3 in use + (ring - 3) being filled ahead (4..8)
     int tiles_y, tiles_z;    // tiles per plane
     int nseg, seg_len;       // x segments per item, planes per segment (the last one may be shorter)
@@ -113,16 +114,24 @@ __device__ __forceinline__ int lat_mod(int v, int n) {
 constexpr uint32_t kLatNone = 0xffffffffu;
 
 // NCH > 0: the record width is 4·NCH, known at compile time (the entry loop is unrolled and scheduled as one block)
-template <typename V, int CL, int MODE, int NT, int NCH>
+// CPL = 16-byte chunks of a dense row per lane: CL / CPL lanes own a row.  CPL = 2 halves the per-entry bookkeeping (records,
+// values, addresses are per lane GROUP) and the cross-lane reduction of the SDDMM; a wave then covers twice the rows.
+template <typename V, int CL, int CPL, int MODE, int NT, int NCH>
 __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   // 4 waves per SIMD: at most 128 VGPRs
     using T = VT<V>;
     constexpr int VEC = T::kWide;
     constexpr int RB = CL * 16;          // bytes of a dense row
-    constexpr int RPP = NT / CL;         // rows per pass
+    constexpr int LPR = CL / CPL;        // lanes per row
+    constexpr int RPP = NT / LPR;        // rows per pass
     constexpr int kVB = (int)sizeof(V);
-    constexpr int kRecB = MODE == kLatSpmmT ? 8 : 4;   // bytes of a record
+    // transposed walk with dense rows of a multiple of 128 bytes: the value ring has the pitch of the dense ring and ONE word
+    // carries both offsets (dense-row offset = multiple of 128, + 4·k' in its low 7 bits); otherwise two words per entry
+    // (measured: slower — with a 128-byte value pitch the broadcast value reads of the eight rows of a wave fall on ONE bank,
+    // C2 transposed product 107 -> 136 us; the 112-byte pitch of the two-word form spreads them.  Kept switched off.)
+    constexpr bool kPacked = false && MODE == kLatSpmmT && RB % 128 == 0;
+    constexpr int kRecB = (MODE == kLatSpmmT && !kPacked) ? 8 : 4;   // bytes of a record
     constexpr int kUnroll = NCH > 0 ? NCH : 2;
-    static_assert(NT % kWave == 0 && NT % CL == 0 && RB % 16 == 0, "geometry");
+    static_assert(NT % kWave == 0 && NT % CL == 0 && RB % 16 == 0 && (CPL == 1 || CPL == 2) && CL % CPL == 0, "geometry");
     static_assert(std::is_same<V, float>::value || MODE != kLatSpmmT, "the transposed walk stages 4-byte values");
 
     extern __shared__ uint4 lat_smem[];
@@ -131,8 +140,9 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
-    const int c = tid % CL;
-    const int g = tid / CL;
+    const int cd = tid % CL;             // chunk of a dense row this lane moves in the ring DMA
+    const int c = tid % LPR;             // lane inside the group that owns a row
+    const int g = tid / LPR;
 
     const int HZ = P.tz + 2 * P.rz, HY = P.ty + 2 * P.ry, HR = HY * HZ, NR = P.ty * P.tz;
     const int PB = HR * RB;
@@ -191,7 +201,7 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
         const int e = d * NT + tid;
         const int hr = e / CL;
         const int hy = hr / HZ, hz = hr - hy * HZ;
-        roff[d] = e < ring_pieces ? (uint32_t)(lat_mod(y0 - P.ry + hy, P.ny) * P.nz + lat_mod(z0 - P.rz + hz, P.nz)) * ldsb + (uint32_t)c * 16u : kLatNone;
+        roff[d] = e < ring_pieces ? (uint32_t)(lat_mod(y0 - P.ry + hy, P.ny) * P.nz + lat_mod(z0 - P.rz + hz, P.nz)) * ldsb + (uint32_t)cd * 16u : kLatNone;
     }
     // value pieces: SpMM: piece e is chunk e % VL of tile row e / VL;  SpMMT: of halo row e / VL.
     // vrow = row of the piece inside its plane (-1: none); vuo = its byte offset from the plane's first value when every row
@@ -219,9 +229,12 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
         }
     }
     // compute rows: pass q handles tile row q*RPP + g
+    // With two chunks per lane, lane c of a row owns chunks c and c + LPR and reads them in an order that depends on the
+    // row (bit 1 of its index): the four rows a 16-lane LDS access covers then fall on four different bank quarters.
     int crow[kLatNP];                    // row inside its plane (-1: none)
-    uint32_t coo[kLatNP];                // byte offset of the row's 16-byte piece inside a plane of the output
-    int cen[kLatNP], csl[kLatNP];        // LDS: own position in a halo plane (+ chunk), own value / stage row
+    uint32_t coo[kLatNP][CPL];           // byte offsets of the row's 16-byte pieces inside a plane of the output
+    uint32_t cown[kLatNP][CPL];          // ... of the row operand (SDDMM)
+    int cen[kLatNP][CPL], csl[kLatNP];   // LDS: own position in a halo plane (+ chunk), own value / stage row
     const uint32_t ldob = (uint32_t)P.ldo * kVB;
 #pragma unroll
     for (int q = 0; q < kLatNP; ++q) {
@@ -229,9 +242,15 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
         const int ly = r / P.tz, lz = r - ly * P.tz;
         const bool ok = r < NR && y0 + ly < P.ny && z0 + lz < P.nz;
         crow[q] = ok ? (y0 + ly) * P.nz + z0 + lz : -1;
-        coo[q] = (uint32_t)(ok ? crow[q] : 0) * ldob + (uint32_t)c * 16u;
         const int hrow = (ly + P.ry) * HZ + lz + P.rz;
-        cen[q] = hrow * RB + c * 16;
+        const int swap = CPL == 2 ? ((r >> 1) & 1) : 0;
+#pragma unroll
+        for (int cp = 0; cp < CPL; ++cp) {
+            const int chunk = c + LPR * (cp ^ swap);
+            coo[q][cp] = (uint32_t)(ok ? crow[q] : 0) * ldob + (uint32_t)chunk * 16u;
+            cown[q][cp] = (uint32_t)(ok ? crow[q] : 0) * ((uint32_t)P.ldown * kVB) + (uint32_t)chunk * 16u;
+            cen[q][cp] = hrow * RB + chunk * 16;
+        }
         csl[q] = MODE == kLatSpmmT ? hrow * P.slot : r * P.slot;
     }
 
@@ -298,7 +317,7 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
     struct RowRegs {
         int cls[kLatNP];
         int rst[MODE == kLatSddmm ? kLatNP : 1];
-        float own[MODE == kLatSddmm ? kLatNP : 1][VEC];
+        float own[MODE == kLatSddmm ? kLatNP : 1][CPL][VEC];
     };
     auto load_rows = [&](int prow, RowRegs& rr) {
         const unsigned char* const cbase = P.rcls + prow;                                              // wave-uniform bases,
@@ -311,7 +330,8 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
                     rr.cls[q] = cbase[(uint32_t)crow[q]];
                     if constexpr (MODE == kLatSddmm) {
                         rr.rst[q] = uniform ? (prow + crow[q]) * P.uniform_len : P.rstart[prow + crow[q]];
-                        load_vec<V, VEC>(reinterpret_cast<const V*>(obase + (uint32_t)crow[q] * ((uint32_t)P.ldown * kVB) + (uint32_t)c * 16u), rr.own[q]);
+#pragma unroll
+                        for (int cp = 0; cp < CPL; ++cp) load_vec<V, VEC>(reinterpret_cast<const V*>(obase + cown[q][cp]), rr.own[q][cp]);
                     }
                 }
             }
@@ -324,7 +344,10 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
             if constexpr (MODE == kLatSddmm) {
                 lat_pin(rr.rst[q]);
 #pragma unroll
-                for (int v = 0; v < VEC; ++v) lat_pin(rr.own[q][v]);
+                for (int cp = 0; cp < CPL; ++cp) {
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) lat_pin(rr.own[q][cp][v]);
+                }
             }
         }
     };
@@ -367,7 +390,7 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
 
     // results of the previous plane leave at the START of the next step, so that the wait for the DMA at the end of a step
     // never waits for a store acknowledgement (and, for the SDDMM, the stage rows are read after the barrier)
-    float acc[MODE == kLatSddmm ? 1 : kLatNP][VEC];
+    float acc[MODE == kLatSddmm ? 1 : kLatNP][CPL][VEC];
     int plen[MODE == kLatSddmm ? kLatNP : 1], prst[MODE == kLatSddmm ? kLatNP : 1];
     auto flush = [&](int prow) {
         if constexpr (MODE != kLatSddmm) {
@@ -375,7 +398,10 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
 #pragma unroll
             for (int q = 0; q < kLatNP; ++q) {
                 if (q * RPP < NR) {
-                    if (crow[q] >= 0) store_vec<V, VEC, true>(reinterpret_cast<V*>(obase + coo[q]), acc[q]);
+                    if (crow[q] >= 0) {
+#pragma unroll
+                        for (int cp = 0; cp < CPL; ++cp) store_vec<V, VEC, true>(reinterpret_cast<V*>(obase + coo[q][cp]), acc[q][cp]);
+                    }
                 }
             }
         } else {
@@ -388,7 +414,7 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
                         V* const go = static_cast<V*>(P.gvals) + prst[q];
                         const int len = plen[q];
 #pragma nounroll
-                        for (int k0 = c * 4; k0 < len; k0 += CL * 4) {
+                        for (int k0 = c * 4; k0 < len; k0 += LPR * 4) {
                             const float4 w = *reinterpret_cast<const float4*>(st + k0);
                             const float wv[4] = {w.x, w.y, w.z, w.w};
                             if (k0 + 4 <= len) {
@@ -458,16 +484,32 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
                 if (crow[q] >= 0) {
                     const int len = cl_li[q] >> 8;
                     const char* const tb = tabs + (cl_li[q] & 0xff) * (P.recw * kRecB);
-                    const char* const cb = sm + cen[q];
+                    const char* const cb = sm + cen[q][0];
+                    const char* const cb1 = sm + cen[q][CPL - 1];   // second chunk (= cb with one chunk per lane)
+                    // the dense row at byte offset `rec` from the own position: this lane's chunk(s)
+                    auto load_b = [&](int rec, float (&bb)[CPL][VEC]) {
+                        load_vec<V, VEC>(reinterpret_cast<const V*>(cb + rec), bb[0]);
+                        if constexpr (CPL == 2) load_vec<V, VEC>(reinterpret_cast<const V*>(cb1 + rec), bb[1]);
+                    };
+                    auto axpy = [&](float a, const float (&bb)[CPL][VEC]) {
+#pragma unroll
+                        for (int cp = 0; cp < CPL; ++cp) {
+#pragma unroll
+                            for (int v = 0; v < VEC; ++v) acc[MODE == kLatSddmm ? 0 : q][cp][v] = fmaf(a, bb[cp][v], acc[MODE == kLatSddmm ? 0 : q][cp][v]);
+                        }
+                    };
                     const int recw = NCH > 0 ? 4 * NCH : P.recw;
                     if constexpr (MODE == kLatSpmm) {
                         char* const vs = sm + P.o_vals + vbi * vbuf + csl[q];
                         if (len < recw) {   // padded slots hold whatever follows the row in the value array: zero them
 #pragma nounroll
-                            for (int t = len + c; t < recw; t += CL) __builtin_memset(vs + t * kVB, 0, kVB);
+                            for (int t = len + c; t < recw; t += LPR) __builtin_memset(vs + t * kVB, 0, kVB);
                         }
 #pragma unroll
-                        for (int v = 0; v < VEC; ++v) acc[q][v] = 0.f;
+                        for (int cp = 0; cp < CPL; ++cp) {
+#pragma unroll
+                            for (int v = 0; v < VEC; ++v) acc[q][cp][v] = 0.f;
+                        }
                         auto chunk_vals = [&](int k0, float (&a)[4]) {
                             if constexpr (kVB == 4) {
                                 const uint4 w = *reinterpret_cast<const uint4*>(vs + k0 * 4);
@@ -486,7 +528,7 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
                             // Three stages: values + records of chunk i+2, dense rows of chunk i+1, FMAs of chunk i.
                             float a[3][4];
                             int4 ro[3];
-                            float b[2][4][VEC];
+                            float b[2][4][CPL][VEC];
                             auto stage_a = [&](int i) {
                                 chunk_vals(4 * i, a[i % 3]);
                                 ro[i % 3] = *reinterpret_cast<const int4*>(tb + 16 * i);
@@ -494,7 +536,7 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
                             auto stage_b = [&](int i) {
                                 const int rv[4] = {ro[i % 3].x, ro[i % 3].y, ro[i % 3].z, ro[i % 3].w};
 #pragma unroll
-                                for (int j = 0; j < 4; ++j) load_vec<V, VEC>(reinterpret_cast<const V*>(cb + rv[j]), b[i & 1][j]);
+                                for (int j = 0; j < 4; ++j) load_b(rv[j], b[i & 1][j]);
                             };
                             stage_a(0);
                             if (NCH > 1) stage_a(1);
@@ -507,10 +549,7 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
                                 if (i + 1 < NCH) stage_b(i + 1);
                                 asm volatile("" ::: "memory");
 #pragma unroll
-                                for (int j = 0; j < 4; ++j) {
-#pragma unroll
-                                    for (int v = 0; v < VEC; ++v) acc[q][v] = fmaf(a[i % 3][j], b[i & 1][j][v], acc[q][v]);
-                                }
+                                for (int j = 0; j < 4; ++j) axpy(a[i % 3][j], b[i & 1][j]);
                             }
                         } else {
 #pragma unroll 2
@@ -519,30 +558,31 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
                                 chunk_vals(k0, a);
                                 const int4 ro = *reinterpret_cast<const int4*>(tb + k0 * 4);
                                 const int rv[4] = {ro.x, ro.y, ro.z, ro.w};
-                                float b[4][VEC];
+                                float b[4][CPL][VEC];
 #pragma unroll
-                                for (int j = 0; j < 4; ++j) load_vec<V, VEC>(reinterpret_cast<const V*>(cb + rv[j]), b[j]);
+                                for (int j = 0; j < 4; ++j) load_b(rv[j], b[j]);
 #pragma unroll
-                                for (int j = 0; j < 4; ++j) {
-#pragma unroll
-                                    for (int v = 0; v < VEC; ++v) acc[q][v] = fmaf(a[j], b[j][v], acc[q][v]);
-                                }
+                                for (int j = 0; j < 4; ++j) axpy(a[j], b[j]);
                             }
                         }
                     } else if constexpr (MODE == kLatSddmm) {
                         float* const st = reinterpret_cast<float*>(sm + P.o_vals + csl[q]);   // fp32 staging row (slot = recw*4 bytes in this mode)
                         plen[q] = len;
                         prst[q] = cur.rst[q];
-                        auto consume = [&](int k0, const float (&bb)[4][VEC]) {
+                        auto consume = [&](int k0, const float (&bb)[4][CPL][VEC]) {
                             float dsum[4];
 #pragma unroll
                             for (int j = 0; j < 4; ++j) {
-                                float d = cur.own[q][0] * bb[j][0];
+                                float d = cur.own[q][0][0] * bb[j][0][0];
 #pragma unroll
-                                for (int v = 1; v < VEC; ++v) d = fmaf(cur.own[q][v], bb[j][v], d);
-                                dsum[j] = group_sum<float, CL>(d);
+                                for (int v = 1; v < VEC; ++v) d = fmaf(cur.own[q][0][v], bb[j][0][v], d);
+                                if constexpr (CPL == 2) {
+#pragma unroll
+                                    for (int v = 0; v < VEC; ++v) d = fmaf(cur.own[q][1][v], bb[j][1][v], d);
+                                }
+                                dsum[j] = group_sum<float, LPR>(d);
                             }
-                            if constexpr (CL >= 4) {
+                            if constexpr (LPR >= 4) {
                                 if (c < 4) {
                                     const float mine = c == 0 ? dsum[0] : (c == 1 ? dsum[1] : (c == 2 ? dsum[2] : dsum[3]));
                                     st[k0 + c] = P.alpha * mine;
@@ -554,11 +594,11 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
                         };
                         if constexpr (NCH > 0) {   // three stages, as in the SpMM above
                             int4 ro[3];
-                            float b[2][4][VEC];
+                            float b[2][4][CPL][VEC];
                             auto stage_b = [&](int i) {
                                 const int rv[4] = {ro[i % 3].x, ro[i % 3].y, ro[i % 3].z, ro[i % 3].w};
 #pragma unroll
-                                for (int j = 0; j < 4; ++j) load_vec<V, VEC>(reinterpret_cast<const V*>(cb + rv[j]), b[i & 1][j]);
+                                for (int j = 0; j < 4; ++j) load_b(rv[j], b[i & 1][j]);
                             };
                             ro[0] = *reinterpret_cast<const int4*>(tb);
                             if (NCH > 1) ro[1] = *reinterpret_cast<const int4*>(tb + 16);
@@ -577,9 +617,9 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
                             for (int k0 = 0; k0 < recw; k0 += 4) {
                                 const int4 ro = *reinterpret_cast<const int4*>(tb + k0 * 4);
                                 const int rv[4] = {ro.x, ro.y, ro.z, ro.w};
-                                float b[4][VEC];
+                                float b[4][CPL][VEC];
 #pragma unroll
-                                for (int j = 0; j < 4; ++j) load_vec<V, VEC>(reinterpret_cast<const V*>(cb + rv[j]), b[j]);
+                                for (int j = 0; j < 4; ++j) load_b(rv[j], b[j]);
                                 consume(k0, b);
                             }
                         }
@@ -588,20 +628,34 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
                         // (padded entries point both reads beyond the LDS allocation: 0 · 0)
                         const char* const vcb = sm + P.o_vals + csl[q];
 #pragma unroll
-                        for (int v = 0; v < VEC; ++v) acc[q][v] = 0.f;
+                        for (int cp = 0; cp < CPL; ++cp) {
+#pragma unroll
+                            for (int v = 0; v < VEC; ++v) acc[q][cp][v] = 0.f;
+                        }
                         if constexpr (NCH > 0) {   // three stages: records of chunk i+2, dense rows + values of chunk i+1, FMAs of chunk i
                             int4 r01[3], r23[3];
-                            float b[2][4][VEC], a[2][4];
+                            float b[2][4][CPL][VEC], a[2][4];
                             auto stage_a = [&](int i) {
-                                r01[i % 3] = *reinterpret_cast<const int4*>(tb + 32 * i);
-                                r23[i % 3] = *reinterpret_cast<const int4*>(tb + 32 * i + 16);
+                                if constexpr (kPacked) {
+                                    r01[i % 3] = *reinterpret_cast<const int4*>(tb + 16 * i);
+                                } else {
+                                    r01[i % 3] = *reinterpret_cast<const int4*>(tb + 32 * i);
+                                    r23[i % 3] = *reinterpret_cast<const int4*>(tb + 32 * i + 16);
+                                }
                             };
                             auto stage_b = [&](int i) {
-                                const int go[4] = {r01[i % 3].x, r01[i % 3].z, r23[i % 3].x, r23[i % 3].z};
-                                const int vo[4] = {r01[i % 3].y, r01[i % 3].w, r23[i % 3].y, r23[i % 3].w};
+                                int go[4], vo[4];
+                                if constexpr (kPacked) {
+                                    const int w[4] = {r01[i % 3].x, r01[i % 3].y, r01[i % 3].z, r01[i % 3].w};
+#pragma unroll
+                                    for (int j = 0; j < 4; ++j) go[j] = w[j] & ~127, vo[j] = w[j];
+                                } else {
+                                    go[0] = r01[i % 3].x, go[1] = r01[i % 3].z, go[2] = r23[i % 3].x, go[3] = r23[i % 3].z;
+                                    vo[0] = r01[i % 3].y, vo[1] = r01[i % 3].w, vo[2] = r23[i % 3].y, vo[3] = r23[i % 3].w;
+                                }
 #pragma unroll
                                 for (int j = 0; j < 4; ++j) {
-                                    load_vec<V, VEC>(reinterpret_cast<const V*>(cb + go[j]), b[i & 1][j]);
+                                    load_b(go[j], b[i & 1][j]);
                                     a[i & 1][j] = *reinterpret_cast<const float*>(vcb + vo[j]);
                                 }
                             };
@@ -616,28 +670,31 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
                                 if (i + 1 < NCH) stage_b(i + 1);
                                 asm volatile("" ::: "memory");
 #pragma unroll
-                                for (int j = 0; j < 4; ++j) {
-#pragma unroll
-                                    for (int v = 0; v < VEC; ++v) acc[q][v] = fmaf(a[i & 1][j], b[i & 1][j][v], acc[q][v]);
-                                }
+                                for (int j = 0; j < 4; ++j) axpy(a[i & 1][j], b[i & 1][j]);
                             }
                         } else {
 #pragma unroll 2
                             for (int k0 = 0; k0 < recw; k0 += 4) {
-                                const int4 r01 = *reinterpret_cast<const int4*>(tb + k0 * 8);
-                                const int4 r23 = *reinterpret_cast<const int4*>(tb + k0 * 8 + 16);
-                                const int go[4] = {r01.x, r01.z, r23.x, r23.z}, vo[4] = {r01.y, r01.w, r23.y, r23.w};
-                                float b[4][VEC], a[4];
+                                int go[4], vo[4];
+                                if constexpr (kPacked) {
+                                    const int4 r = *reinterpret_cast<const int4*>(tb + k0 * 4);
+                                    const int w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+                                    for (int j = 0; j < 4; ++j) go[j] = w[j] & ~127, vo[j] = w[j];
+                                } else {
+                                    const int4 r01 = *reinterpret_cast<const int4*>(tb + k0 * 8);
+                                    const int4 r23 = *reinterpret_cast<const int4*>(tb + k0 * 8 + 16);
+                                    go[0] = r01.x, go[1] = r01.z, go[2] = r23.x, go[3] = r23.z;
+                                    vo[0] = r01.y, vo[1] = r01.w, vo[2] = r23.y, vo[3] = r23.w;
+                                }
+                                float b[4][CPL][VEC], a[4];
 #pragma unroll
                                 for (int j = 0; j < 4; ++j) {
-                                    load_vec<V, VEC>(reinterpret_cast<const V*>(cb + go[j]), b[j]);
+                                    load_b(go[j], b[j]);
                                     a[j] = *reinterpret_cast<const float*>(vcb + vo[j]);
                                 }
 #pragma unroll
-                                for (int j = 0; j < 4; ++j) {
-#pragma unroll
-                                    for (int v = 0; v < VEC; ++v) acc[q][v] = fmaf(a[j], b[j][v], acc[q][v]);
-                                }
+                                for (int j = 0; j < 4; ++j) axpy(a[j], b[j]);
                             }
                         }
                     }
@@ -668,9 +725,13 @@ inline int lat_layout(LatParams& P, int mode, int cl, int vbytes, int nt) {
         P.recw % 4 || P.recw > 32)
         return TSGU_ERR_BAD_ARG;
     const int HR = (P.ty + 2 * P.ry) * (P.tz + 2 * P.rz), NR = P.ty * P.tz, RB = cl * 16;
-    P.slot = lat_round16(P.recw * (mode == kLatSddmm ? 4 : vbytes));
+    const bool packed = false && mode == kLatSpmmT && RB % 128 == 0;   // see kPacked in lattice_kernel
+    P.slot = packed ? RB : lat_round16(P.recw * (mode == kLatSddmm ? 4 : vbytes));
+    if (packed && P.recw * vbytes > RB) return TSGU_ERR_TOO_LARGE;
     const int VL = P.slot / 16;
-    if ((int64_t)HR * cl > (int64_t)kLatND * nt || NR > kLatNP * (nt / cl)) return TSGU_ERR_TOO_LARGE;
+    if (P.cpl != 1 && P.cpl != 2) return TSGU_ERR_BAD_ARG;
+    if (cl % P.cpl || (P.cpl == 2 && cl < 4)) return TSGU_ERR_BAD_ARG;
+    if ((int64_t)HR * cl > (int64_t)kLatND * nt || NR > kLatNP * (nt / (cl / P.cpl))) return TSGU_ERR_TOO_LARGE;
     if (mode == kLatSpmm && (int64_t)NR * VL > (int64_t)kLatNVD * nt) return TSGU_ERR_TOO_LARGE;
     if (mode == kLatSpmmT && (int64_t)HR * VL > (int64_t)kLatNVD * nt) return TSGU_ERR_TOO_LARGE;
     int64_t o = R * HR * RB;
@@ -681,7 +742,7 @@ inline int lat_layout(LatParams& P, int mode, int cl, int vbytes, int nt) {
     P.o_zero = (int)o;
     o += 16;
     P.o_tab = (int)o;
-    o += lat_round16(P.ring * P.nloc * P.recw * (mode == kLatSpmmT ? 8 : 4));
+    o += lat_round16(P.ring * P.nloc * P.recw * (mode == kLatSpmmT && !packed ? 8 : 4));
     P.o_len = (int)o;
     P.o_map = (int)o;
     o += 512;     // uint16 per class of the pattern: local class | length << 8
@@ -690,28 +751,36 @@ inline int lat_layout(LatParams& P, int mode, int cl, int vbytes, int nt) {
     return (int)o;
 }
 
-template <typename V, int CL, int MODE, int NT, int NCH>
+template <typename V, int CL, int CPL, int MODE, int NT, int NCH>
 int lat_launch_nch(const LatParams& P, hipStream_t stream) {
     // more than 64 KiB of dynamic LDS has to be allowed once per kernel and device
     static std::atomic<uint64_t> allowed{0};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return TSGU_ERR_RUNTIME;
     if (!(allowed.load(std::memory_order_acquire) >> dev & 1ull)) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lattice_kernel<V, CL, MODE, NT, NCH>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lattice_kernel<V, CL, CPL, MODE, NT, NCH>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, kLatMaxLds) != hipSuccess)
             return TSGU_ERR_RUNTIME;
         allowed.fetch_or(1ull << dev, std::memory_order_release);
     }
-    hipLaunchKernelGGL((lattice_kernel<V, CL, MODE, NT, NCH>), dim3((unsigned)P.nblocks), dim3(NT), (size_t)P.lds_bytes, stream, P);
+    hipLaunchKernelGGL((lattice_kernel<V, CL, CPL, MODE, NT, NCH>), dim3((unsigned)P.nblocks), dim3(NT), (size_t)P.lds_bytes, stream, P);
     return check_launch();
 }
 
 // record widths with an unrolled entry loop: 28 (27-point stencils) and 8 (7-point); anything else loops at run time
 template <typename V, int CL, int MODE, int NT>
 int lat_launch_one(const LatParams& P, hipStream_t stream) {
-    if (P.recw == 28) return lat_launch_nch<V, CL, MODE, NT, 7>(P, stream);
-    if (P.recw == 8) return lat_launch_nch<V, CL, MODE, NT, 2>(P, stream);
-    return lat_launch_nch<V, CL, MODE, NT, 0>(P, stream);
+    if (P.cpl == 2) {
+        // two chunks per lane: compiled for the 27-point record width and the stored-order walks only (measured at C2: no
+        // faster than one chunk per lane — half the waves per CU cancel the saved instructions; kept for wider rows)
+        if constexpr (CL >= 8 && MODE != kLatSpmmT) {
+            if (P.recw == 28) return lat_launch_nch<V, CL, 2, MODE, NT, 7>(P, stream);
+        }
+        return TSGU_ERR_BAD_ARG;
+    }
+    if (P.recw == 28) return lat_launch_nch<V, CL, 1, MODE, NT, 7>(P, stream);
+    if (P.recw == 8) return lat_launch_nch<V, CL, 1, MODE, NT, 2>(P, stream);
+    return lat_launch_nch<V, CL, 1, MODE, NT, 0>(P, stream);
 }
 
 }  // namespace tsgu
