@@ -283,6 +283,33 @@ int tsgu_csr_sddmm_lattice(int vtype, const tsgu_lattice_plan* plan, int64_t n_r
                            const void* Cm, int64_t ldc, void* out_vals, double alpha, int64_t p, int device, void* stream);
 
 /*
+ * Row analysis for lattice plans (plan building, once per sparsity pattern; no reference counterpart — the reference
+ * re-derives structure per call, sparse_matmul.py:186-192,229).  One thread per row; nothing is sorted.
+ *   tsgu_lattice_rows       displacement code ((dx+1)·5 + dy+2)·5 + dz+2 of every entry of every row (nd == 0), or — nd > 0 —
+ *                           of every entry of every row of the TRANSPOSED pattern without building it: the entries (i, j) of
+ *                           transposed row j are found by searching the rows i = j − d for every displacement d of `disp[nd]`
+ *                           (the codes that occur in the pattern), ordered by i, element = code(j→i)·32 + position of j in row i.
+ *                           Pass 1 (ctable == NULL): the 64-bit hash of the row's sequence goes into an open-addressing table
+ *                             (thash[tsgu_lattice_slots()] pre-set to 0x8000000000000000, trep[...] pre-set to INT_MAX: smallest
+ *                             row of the slot); slot[row] (uint16) names the row's slot.  Rows with equal hashes are class candidates.
+ *                           Pass 2 (ctable [ncls][32] int32, -1 beyond the class length; remap[slots] uint8; lens[ncls] uint8):
+ *                             rcls[row] = remap[slot[row]] and every row is compared with its class exactly.
+ *   tsgu_lattice_row_codes  sequences of `nrows` given rows (the class representatives) -> out [nrows][32] int32.
+ *   tsgu_lattice_block_classes  mask[block][4] (uint64, zeroed by the caller): the set of classes among the rows of each
+ *                           workgroup of a launch configuration (the lists a tsgu_lattice_plan carries in `wlist`).
+ * status (device int32[4], zeroed by the caller): [0] rows that are not lattice rows (or differ from their class, or more than
+ * tsgu_lattice_slots() distinct rows), [1] max |dy|, [2] max |dz|, [3] longest row.  Rows longer than 32 entries are not-lattice.
+ */
+int tsgu_lattice_slots(void);
+int tsgu_lattice_rows(int itype, int64_t n_rows, const void* crow, const void* col, int nb, int nx, int ny, int nz, const void* disp, int nd,
+                      void* slot, void* thash, void* trep, const void* remap, const void* ctable, const void* lens, void* rcls, void* status,
+                      int device, void* stream);
+int tsgu_lattice_row_codes(int itype, int64_t n_rows, const void* crow, const void* col, int nb, int nx, int ny, int nz, const void* disp,
+                           int nd, const void* rows, int nrows, void* out, int device, void* stream);
+int tsgu_lattice_block_classes(int64_t n_rows, const void* rcls, int nb, int nx, int ny, int nz, int ty, int tz, int nseg, void* mask,
+                               int device, void* stream);
+
+/*
  * K4  X = op(A)^{-1} B   sparse triangular solve, sync-free (dependency-driven) CSR sweep.
  * replaces: torch.triangular_solve(B, A, upper, transpose, unitriangular).solution
  *           torchsparsegradutils/_compat.py:42-48  (from sparse_solve.py:181-183 and :202-204)

@@ -221,13 +221,12 @@ def test_padded_entries_touch_nothing():
 
 
 def test_public_path_takes_the_lattice_kernels(monkeypatch):
-    """sparse_mm forward + backward on a stencil: the second sight of the pattern switches to the plane sweep; results
-    match the oracle and — same order of summation — the first (plan-free) step bit for bit."""
+    """sparse_mm forward + backward on a stencil: the plane sweep from the first sight of the pattern (its plans are a few
+    milliseconds of row-analysis kernels), no transposed pattern, results = oracle and = the plan-free kernels bit for bit."""
     from torchsparsegradutils_amd import _ops, _pattern, sparse_mm
     from torchsparsegradutils_amd.utils import synthetic
 
     monkeypatch.setattr(_ops, "ENABLE_LATTICE", True)
-    monkeypatch.setattr(_ops, "PLAN_AFTER_USES", 1)
     dev = torch.device("cuda:0")
     nx, ny, nz, p = 16, 12, 20, 32
     n = nx * ny * nz
@@ -240,23 +239,76 @@ def test_public_path_takes_the_lattice_kernels(monkeypatch):
     A = torch.sparse_csr_tensor(crow.to(dev), col.to(dev), val.to(dev), (n, n)).requires_grad_(True)
     Bd = B.to(dev).requires_grad_(True)
     outs = []
-    for it in range(3):
+    for it in range(2):
         A.grad = None
         Bd.grad = None
         C = sparse_mm(A, Bd)
         C.backward(Gd.to(dev))
         outs.append((C.detach().clone(), A.grad.values().clone(), Bd.grad.clone()))
         core = _pattern.from_csr(A.detach()).core
-        built = core.own.get("lattice") is not None
-        assert built == (it >= 1), it
-    assert core.t.core.own.get("lattice") is not None and not core.packs, "the lattice plans replace the row-pair plans"
+        assert core.own.get("lattice") is not None and core.own.get("lattice_t") is not None, it
+    assert core.t is None and not core.packs, "neither a transposed pattern nor row-pair plans are built for a lattice stencil"
     assert A.grad.crow_indices().dtype == torch.int32 and torch.equal(A.grad.col_indices().cpu(), col)
     for C, gA, gB in outs:
         assert G.rel_err(C.cpu().numpy(), Co) < 1e-5
         assert G.rel_err(gA.cpu().numpy(), gAo) < 1e-5
         assert G.rel_err(gB.cpu().numpy(), gBo) < 1e-5
-    for k in range(3):
-        assert torch.equal(outs[0][k], outs[2][k])
+    # one-sided gradients take the same kernels
+    A2 = A.detach().clone().requires_grad_(False)
+    C = sparse_mm(A2, Bd)
+    (gB_only,) = torch.autograd.grad(C, (Bd,), Gd.to(dev))
+    assert torch.equal(gB_only, outs[0][2])
+    # and the plan-free kernels (lattice switched off) give the same bits
+    monkeypatch.setattr(_ops, "ENABLE_LATTICE", False)
+    monkeypatch.setattr(_ops, "ENABLE_PACK", False)
+    A.grad = None
+    Bd.grad = None
+    C = sparse_mm(A, Bd)
+    C.backward(Gd.to(dev))
+    assert torch.equal(C.detach(), outs[0][0]) and torch.equal(A.grad.values(), outs[0][1]) and torch.equal(Bd.grad, outs[0][2])
+
+
+def test_row_kernels_build_the_same_plans_as_the_tensor_op_builder():
+    """csrc/lattice_plan.hip against _lattice.build_lattice_plan: same classes (same numbering), tables, lengths — for the
+    stored-order walk and for the transposed walk (found without a transposed pattern)."""
+    be, lt, pt = _mods()
+    dev = torch.device("cuda:0")
+    cases = [(1, 9, 10, 12, True, 27, False), (1, 7, 9, 11, False, 27, False), (1, 8, 8, 16, True, 7, False),
+             (1, 6, 8, 9, False, 27, True), (3, 5, 6, 8, True, 27, False)]
+    for nb, nx, ny, nz, periodic, points, lower in cases:
+        crow, col = _stencil_csr(nx, ny, nz, periodic, points, lower, nb)
+        n = nb * nx * ny * nz
+        for idt in (torch.int32, torch.int64):
+            plan = pt.RowGather(crow.to(dev).to(idt), col.to(dev).to(idt), n, n)
+            dims = (nb, nx, ny, nz)
+            ref = lt.build_lattice_plan(plan, dims=dims)
+            got = lt.build_lattice_plan_hip(plan, be, dims=dims)
+            reft = lt.build_lattice_plan(plan.transposed, value_crow=plan.crow, dims=dims)
+            gott = lt.build_lattice_plan_hip(plan, be, forward=got)
+            for a, b in ((ref, got), (reft, gott)):
+                assert a is not None and b is not None
+                for f in ("kind", "nb", "nx", "ny", "nz", "ry", "rz", "ncls", "recw", "uniform_len"):
+                    assert getattr(a, f) == getattr(b, f), (f, getattr(a, f), getattr(b, f))
+                assert torch.equal(a.codes, b.codes) and torch.equal(a.lens_host, b.lens_host)
+                assert torch.equal(a.rcls, b.rcls) and torch.equal(a.lens, b.lens)
+                if a.kind == 1:
+                    assert torch.equal(a.ksrc, b.ksrc)
+                for ty, tz, nseg in ((4, 4, 2), (3, 5, 1), (8, 8, 3)):
+                    if nseg <= a.nx:
+                        assert torch.equal(lt.workgroup_classes(a, ty, tz, nseg), lt.workgroup_classes_hip(b, ty, tz, nseg, be))
+    # the sampled detection proposes the right lattice for the benchmark shapes and for block-diagonal batches
+    from torchsparsegradutils_amd.utils import synthetic
+
+    crow, col = synthetic.stencil27_periodic(24, 20, 32, torch.int32, device=dev)
+    got = lt.build_lattice_plan_hip(pt.RowGather(crow, col, 24 * 20 * 32, 24 * 20 * 32), be)
+    assert got is not None and (got.nb, got.nx, got.ny, got.nz) == (1, 24, 20, 32) and got.ncls == 27
+    crow, col = _stencil_csr(6, 8, 12, True, 27, False, nb=3)
+    got = lt.build_lattice_plan_hip(pt.RowGather(crow.to(dev), col.to(dev), 3 * 576, 3 * 576), be)
+    assert got is not None and (got.nb, got.nx, got.ny, got.nz) == (3, 6, 8, 12)
+    # irregular patterns and a stencil with one foreign entry are rejected
+    bad = col.clone()
+    bad[5] = (bad[5] + 200) % 576
+    assert lt.build_lattice_plan_hip(pt.RowGather(crow.to(dev), bad.to(dev), 3 * 576, 3 * 576), be, dims=(3, 6, 8, 12)) is None
 
 
 def test_public_path_batched_bf16(monkeypatch):
@@ -266,7 +318,6 @@ def test_public_path_batched_bf16(monkeypatch):
 
     monkeypatch.setattr(_ops, "ENABLE_LATTICE", True)
     monkeypatch.setattr(_ops, "LATTICE_DTYPES", (torch.float32, torch.bfloat16))
-    monkeypatch.setattr(_ops, "PLAN_AFTER_USES", 0)
     dev = torch.device("cuda:0")
     b, nx, ny, nz, p = 3, 8, 16, 16, 16
     n = nx * ny * nz

@@ -76,6 +76,11 @@ SIGNATURES = {
     "tsgu_lattice_lds_bytes": (_int, [_int, _int, _i64, _int, _int, _int, _int, _int, _int, _int, _int, _int]),
     "tsgu_csr_spmm_lattice": (_int, [_int, _ptr, _i64, _i64, _ptr, _ptr, _i64, _ptr, _i64, _i64, _int, _ptr]),
     "tsgu_csr_sddmm_lattice": (_int, [_int, _ptr, _i64, _i64, _ptr, _i64, _ptr, _i64, _ptr, _dbl, _i64, _int, _ptr]),
+    "tsgu_lattice_slots": (_int, []),
+    "tsgu_lattice_rows": (_int, [_int, _i64, _ptr, _ptr, _int, _int, _int, _int, _ptr, _int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr,
+                                 _int, _ptr]),
+    "tsgu_lattice_row_codes": (_int, [_int, _i64, _ptr, _ptr, _int, _int, _int, _int, _ptr, _int, _ptr, _int, _ptr, _int, _ptr]),
+    "tsgu_lattice_block_classes": (_int, [_i64, _ptr, _int, _int, _int, _int, _int, _int, _int, _ptr, _int, _ptr]),
     "tsgu_csr_sptrsm": (
         _int,
         [_int, _int, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _int, _int, _ptr, _i64, _i64, _ptr, _i64, _i64, _ptr, _int, _ptr],
@@ -420,7 +425,41 @@ def lattice_config(lp, mode: int, dtype: torch.dtype, p: int):
     es = 4 if dtype == torch.float32 else 2
     if (p * es) % 16 or (p * es) // 16 not in (2, 4, 8, 16):
         return None
-    return _lattice.config_for(lp, mode, _VTYPE[dtype], p, es, lattice_lds_bytes)
+    import sys
+
+    return _lattice.config_for(lp, mode, _VTYPE[dtype], p, es, lattice_lds_bytes, be=sys.modules[__name__])
+
+
+def lattice_rows(crow, col, dims, status, slot, thash=None, trep=None, remap=None, ctable=None, lens=None, rcls=None, disp=None):
+    """Row analysis kernels of csrc/lattice_plan.hip: pass 1 (hash -> slot table) when `ctable` is None, pass 2 (class
+    assignment + exact check) otherwise; the rows of the transposed pattern when `disp` is given."""
+    lib = _lib or load_library()
+    dev = require_device(crow, col, status)
+    nb, nx, ny, nz = dims
+    with _on_device(dev):
+        rc = lib.tsgu_lattice_rows(itype_of(crow), crow.numel() - 1, _p(crow), _p(col), nb, nx, ny, nz, _p(disp),
+                                   0 if disp is None else disp.numel(), _p(slot), _p(thash), _p(trep), _p(remap), _p(ctable), _p(lens),
+                                   _p(rcls), _p(status), dev.index, _stream(dev))
+    check(rc, "tsgu_lattice_rows")
+
+
+def lattice_block_classes(rcls, n_rows, dims, ty, tz, nseg, mask):
+    lib = _lib or load_library()
+    dev = require_device(rcls, mask)
+    nb, nx, ny, nz = dims
+    with _on_device(dev):
+        rc = lib.tsgu_lattice_block_classes(n_rows, _p(rcls), nb, nx, ny, nz, ty, tz, nseg, _p(mask), dev.index, _stream(dev))
+    check(rc, "tsgu_lattice_block_classes")
+
+
+def lattice_row_codes(crow, col, dims, rows, out, disp=None):
+    lib = _lib or load_library()
+    dev = require_device(crow, col, rows, out)
+    nb, nx, ny, nz = dims
+    with _on_device(dev):
+        rc = lib.tsgu_lattice_row_codes(itype_of(crow), crow.numel() - 1, _p(crow), _p(col), nb, nx, ny, nz, _p(disp),
+                                        0 if disp is None else disp.numel(), _p(rows), rows.numel(), _p(out), dev.index, _stream(dev))
+    check(rc, "tsgu_lattice_row_codes")
 
 
 class _on_device:

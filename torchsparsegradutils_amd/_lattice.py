@@ -57,21 +57,22 @@ class LatticeConfig:
     __slots__ = ("ty", "tz", "nseg", "threads", "rec", "lds_bytes", "struct", "struct_addr", "wlist", "nloc", "ring", "cpl")
 
 
-def _frequent_offsets(g, rows64: torch.Tensor) -> Optional[list]:
-    off = (g.col.to(torch.int64) - rows64).abs()
+def _frequent_offsets(cols64: torch.Tensor, rows64: torch.Tensor, nrows: int) -> Optional[list]:
+    off = (cols64 - rows64).abs()
     uniq, cnt = torch.unique(off, return_counts=True)
     if uniq.numel() > 8192:
         return None
     # a displacement of a stencil appears in (almost) every row; wrap-around images and boundary losses are rare
-    keep = uniq[(cnt * 2 > g.n_rows) & (uniq > 0)]
+    keep = uniq[(cnt * 2 > nrows) & (uniq > 0)]
     return keep.tolist()
 
 
-def detect_dims(g, rows64: torch.Tensor) -> Optional[Tuple[int, int]]:
+def detect_dims(g, rows64: torch.Tensor, cols64: Optional[torch.Tensor] = None, nrows: Optional[int] = None) -> Optional[Tuple[int, int]]:
     """(nz, ny·nz) of the lattice this square pattern looks like a stencil on, from the clusters of |col − row|:
-    {1 … rz}, {nz − rz … nz + rz}, {ny·nz − … }.  (nz, n_rows) for a 2-D lattice.  None for anything irregular."""
+    {1 … rz}, {nz − rz … nz + rz}, {ny·nz − … }.  (nz, n_rows) for a 2-D lattice.  None for anything irregular.
+    `rows64` / `cols64` may be the entries of the first `nrows` rows only (a sample)."""
     n = g.n_rows
-    pos = _frequent_offsets(g, rows64)
+    pos = _frequent_offsets(g.col.to(torch.int64) if cols64 is None else cols64, rows64, n if nrows is None else nrows)
     if not pos:
         return None
     clusters = [[pos[0]]]
@@ -240,6 +241,181 @@ def build_lattice_plan(g, value_crow: Optional[torch.Tensor] = None, dims: Optio
     return plan
 
 
+SAMPLE_ROWS = 2048
+
+
+def _clusters_to_dims(pos, n: int) -> Optional[Tuple[int, int]]:
+    """(nz, ny·nz) from the sorted frequent |col − row| offsets `pos` (see detect_dims)."""
+    if not pos:
+        return None
+    clusters = [[pos[0]]]
+    reach = max(pos[0], MAX_RADIUS)
+    for o in pos[1:]:
+        if o - clusters[-1][-1] <= reach:
+            clusters[-1].append(o)
+        else:
+            reach = clusters[-1][-1] + MAX_RADIUS
+            clusters.append([o])
+    if clusters[0][0] > MAX_RADIUS:
+        clusters.insert(0, [])
+    if len(clusters) not in (2, 3) or (clusters[0] and clusters[0][-1] > MAX_RADIUS):
+        return None
+    lo, hi = clusters[1][0], clusters[1][-1]
+    mid = (lo + hi) // 2
+    cands = sorted((c for c in range(max(hi - MAX_RADIUS, 2), lo + MAX_RADIUS + 1) if n % c == 0), key=lambda c: abs(c - mid))
+    if not cands:
+        return None
+    nz = cands[0]
+    if len(clusters) == 2:
+        return nz, nz
+    lo, hi = clusters[2][0], clusters[2][-1]
+    mid = (lo + hi) // 2
+    first = (max(lo - MAX_RADIUS, 2 * nz) + nz - 1) // nz * nz
+    cands = sorted((c for c in range(first, hi + MAX_RADIUS + 1, nz) if n % c == 0), key=lambda c: abs(c - mid))
+    if not cands:
+        return None
+    return nz, cands[0]
+
+
+def _sample_dims(g) -> Optional[Tuple[int, int, int, int]]:
+    """(nb, nx, ny, nz) guessed on the HOST from two small samples of rows (no device op that would have to be loaded first):
+    SAMPLE_ROWS rows from the middle of the matrix give the strides (interior rows: no wrap-around offsets), the first
+    SAMPLE_ROWS rows (the x = 0 plane of the first item) give the x period.  Only a proposal: the row kernels check every entry."""
+    import numpy as np
+
+    n = g.n_rows
+    m = min(n, SAMPLE_ROWS)
+    r0 = max(0, n // 2 - m // 2)
+
+    def sample(first):
+        ptr = g.crow[first:first + m + 1].cpu().numpy().astype(np.int64)
+        cols = g.col[int(ptr[0]):int(ptr[-1])].cpu().numpy().astype(np.int64)
+        rows = np.repeat(np.arange(first, first + m, dtype=np.int64), np.diff(ptr))
+        return rows, cols
+
+    rows, cols = sample(r0)
+    if cols.size == 0:
+        return None
+    uniq, cnt = np.unique(np.abs(cols - rows), return_counts=True)
+    found = _clusters_to_dims(uniq[(cnt * 2 > m) & (uniq > 0)].tolist(), n)
+    if found is None:
+        return None
+    nz, d2 = found
+    if n % d2 or n % nz:
+        return None
+    planes = n // d2
+    rows, cols = (rows, cols) if r0 == 0 else sample(0)
+    mx = int(np.abs(cols // d2 - rows // d2).max()) if cols.size else 0
+    nx = planes if mx <= 1 else mx + 1
+    if nx < 1 or planes % nx:
+        return None
+    return planes // nx, nx, d2 // nz, nz
+
+
+def build_lattice_plan_hip(g, be, forward: Optional[LatticePlan] = None, dims=None) -> Optional[LatticePlan]:
+    """The same plan as `build_lattice_plan`, with the per-entry work done by the row kernels of csrc/lattice_plan.hip
+    (two passes over the pattern, nothing sorted: the distinct row hashes meet in a small device hash table) instead of
+    ~40 tensor ops over the entries.
+    `forward` None: plan of the stored-order walk of `g`.  `forward` = that plan: plan of the TRANSPOSED walk of the same
+    `g` — found by searching the neighbour rows, the transposed pattern is never built."""
+    import numpy as np
+
+    if g.batch is not None or g.perm is not None or g.n_rows != g.n_cols or g.n_rows < 8 or not (1 <= g.nnz < 2**31):
+        return None
+    n = g.n_rows
+    dev = g.crow.device
+    kind = 0 if forward is None else 1
+    if kind == 1:
+        dims = (forward.nb, forward.nx, forward.ny, forward.nz)
+        codes = forward.codes
+        disp = torch.unique(codes[codes >= 0]).to(torch.uint8).to(dev)
+    else:
+        disp = None
+        if dims is None:
+            dims = _sample_dims(g)
+        if dims is None:
+            return None
+    crow, col = g.crow.contiguous(), g.col.contiguous()
+    slots = be.load_library().tsgu_lattice_slots()
+    # one small work buffer: status[4] int32 | trep[slots] int32 | thash[slots] int64, pre-set by one copy from the host
+    init = np.empty(4 + slots + 2 * slots, dtype=np.int32)
+    init[:4] = 0
+    init[4:4 + slots] = np.iinfo(np.int32).max
+    init[4 + slots:].view(np.int64)[:] = np.iinfo(np.int64).min
+    work = torch.from_numpy(init).to(dev)
+    status, trep, thash = work[:4], work[4:4 + slots], work[4 + slots:].view(torch.int64)
+    slot = torch.empty(n, dtype=torch.int16, device=dev)
+    be.lattice_rows(crow, col, dims, status, slot, thash=thash, trep=trep, disp=disp)
+    host = work.cpu().numpy()
+    bad, ry, rz, maxlen = (int(v) for v in host[:4])
+    if bad or maxlen > MAX_LEN or maxlen < 1:
+        return None
+    hh = host[4 + slots:].view(np.int64)
+    used = np.nonzero(hh != np.iinfo(np.int64).min)[0]
+    ncls = used.size
+    if ncls > MAX_CLASSES or ncls == 0:
+        return None
+    order = used[np.argsort(hh[used], kind="stable")]          # classes numbered by ascending hash, like torch.unique
+    remap = np.zeros(slots, dtype=np.uint8)
+    remap[order] = np.arange(ncls, dtype=np.uint8)
+    rep = torch.from_numpy(host[4:4 + slots][order].astype(np.int64)).to(dev)
+    table = torch.empty((ncls, 32), dtype=torch.int32, device=dev)
+    be.lattice_row_codes(crow, col, dims, rep, table, disp=disp)
+    lens = (table >= 0).sum(1).to(torch.uint8)
+    rcls = torch.zeros(n + 64, dtype=torch.uint8, device=dev)
+    status.zero_()
+    be.lattice_rows(crow, col, dims, status, slot, remap=torch.from_numpy(remap).to(dev), ctable=table, lens=lens, rcls=rcls, disp=disp)
+    tab = torch.cat((table.reshape(-1), status)).cpu()      # exact check: hash collisions must not pass
+    if int(tab[-4]) != 0:
+        return None
+    tab = tab[:-4].view(ncls, 32).to(torch.int64)
+    cl = (tab >= 0).sum(1)
+    if kind == 0:
+        uniform = int(cl[0]) if bool((cl == cl[0]).all()) else 0
+        if uniform:
+            rstart = torch.zeros(4, dtype=torch.int32, device=dev)
+        else:
+            rstart = (crow if crow.dtype == torch.int32 else crow.to(torch.int32)).clone()
+        if dims[2] == 1:
+            ry = 0
+    else:
+        uniform, rstart, ry, rz = forward.uniform_len, forward.rstart, forward.ry, forward.rz
+    nb, nx, ny, nz = dims
+    recw = (int(cl.max()) + 3) // 4 * 4
+    tab = tab[:, :recw].contiguous()
+    plan = LatticePlan()
+    plan.kind, plan.nb, plan.nx, plan.ny, plan.nz, plan.ry, plan.rz = kind, nb, nx, ny, nz, ry, rz
+    plan.ncls, plan.recw, plan.uniform_len = ncls, recw, uniform
+    plan.n_rows, plan.nnz = n, g.nnz
+    if kind == 1:
+        plan.ksrc = torch.where(tab >= 0, tab % 32, tab)
+        plan.codes = torch.where(tab >= 0, torch.div(tab, 32, rounding_mode="floor"), tab)
+    else:
+        plan.codes, plan.ksrc = tab, None
+    plan.lens_host = cl
+    plan.lens = lens
+    plan.rcls = rcls
+    plan.rstart = rstart
+    return plan
+
+
+def workgroup_classes_hip(plan: LatticePlan, ty: int, tz: int, nseg: int, be) -> torch.Tensor:
+    """`workgroup_classes` by one kernel (a 256-bit class set per workgroup) + a few host operations on the sets."""
+    import numpy as np
+
+    nb, nx, ny, nz = plan.nb, plan.nx, plan.ny, plan.nz
+    nblocks = nb * nseg * -(-ny // ty) * -(-nz // tz)
+    dev = plan.rcls.device
+    mask = torch.zeros((nblocks, 4), dtype=torch.int64, device=dev)
+    be.lattice_block_classes(plan.rcls, plan.n_rows, (nb, nx, ny, nz), ty, tz, nseg, mask)
+    bits = np.unpackbits(mask.cpu().numpy().view(np.uint8).reshape(nblocks, 32), axis=1, bitorder="little")   # [nblocks][256]
+    nloc = int(bits.sum(1).max())
+    # stable argsort puts the set bits first (as ascending class ids)
+    idx = np.argsort(1 - bits, axis=1, kind="stable")[:, :nloc].astype(np.uint8)
+    wl = np.where(np.take_along_axis(bits, idx.astype(np.int64), axis=1) == 1, idx, np.uint8(0xFF))
+    return torch.from_numpy(np.ascontiguousarray(wl)).to(dev)
+
+
 def records(plan: LatticePlan, ty: int, tz: int, row_bytes: int, slot_bytes: int, ring: int = 4) -> torch.Tensor:
     """Record tables of `plan` for a ty × tz tile (host tensor, int32): [ring][ncls][recw] byte offsets for kind 0,
     [ring][ncls][recw][2] = (dense-row offset, value offset) for kind 1.  Entry k of a row of class c gathers the LDS row
@@ -372,13 +548,13 @@ class _LatticePlanStruct(ctypes.Structure):
                                                "ty", "tz", "nseg", "threads", "ring", "chunks_per_lane")] + [(k, ctypes.c_void_p) for k in ("rec", "lens", "rcls", "rstart", "wlist")]
 
 
-def config_for(plan: LatticePlan, mode: int, vtype: int, p: int, elem_bytes: int, lds_bytes_fn) -> Optional[LatticeConfig]:
+def config_for(plan: LatticePlan, mode: int, vtype: int, p: int, elem_bytes: int, lds_bytes_fn, be=None) -> Optional[LatticeConfig]:
     """Cached launch configuration (tile choice + record tables on the device + ctypes image) of a plan."""
     key = (mode, vtype, p)
     cfg = plan._cfg.get(key)
     if cfg is None and key not in plan._cfg:
         for ty, tz, nseg, threads, ring, cpl in rank_configs(plan, mode, vtype, p, elem_bytes, lds_bytes_fn):
-            wlist = workgroup_classes(plan, ty, tz, nseg)
+            wlist = workgroup_classes_hip(plan, ty, tz, nseg, be) if be is not None else workgroup_classes(plan, ty, tz, nseg)
             nloc = wlist.size(1)
             lds = lds_bytes_fn(mode, vtype, p, ty, tz, plan.ry, plan.rz, nloc, plan.recw, threads, ring, cpl)
             if lds <= 0:

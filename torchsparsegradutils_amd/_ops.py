@@ -41,31 +41,32 @@ ENABLE_LATTICE = os.environ.get("TSGU_ENABLE_LATTICE", "1") == "1"
 LATTICE_DTYPES = (torch.float32,)
 
 
-def _lattice_plan(plan: RowGather, value_crow=None, count: bool = True):
-    """LatticePlan of the 2-D `plan` (None: not a lattice stencil / not seen often enough yet); cached with the pattern.
-    The detection + class build is a handful of index ops (no sorts of the entries): done inline at the
-    PLAN_AFTER_USES-th sight of the pattern."""
-    if not ENABLE_LATTICE or plan.batch is not None or plan.nnz < PACK_MIN_NNZ or plan.n_rows != plan.n_cols:
-        return None
-    if (plan.perm is not None) != (value_crow is not None):
+def _lattice_plan(plan: RowGather, transposed: bool = False):
+    """LatticePlan of the stored-order walk of the 2-D `plan` (or, `transposed`, of the walk of its transposed pattern; the
+    values stay in `plan`'s stored order), None when the pattern is not a lattice stencil.  Cached with the pattern.
+    Built at FIRST sight: the row kernels of csrc/lattice_plan.hip make it a few milliseconds (two passes over the
+    pattern + a sort of one word per row), and the transposed walk needs no transposed pattern."""
+    if not ENABLE_LATTICE or plan.batch is not None or plan.perm is not None or plan.nnz < PACK_MIN_NNZ or plan.n_rows != plan.n_cols:
         return None
     own = plan.core.own
     if "lattice" not in own:
-        # one count per step: the product (forward / transposed walk) counts, the SDDMM of the same step does not
-        seen = own["lattice_uses"] = own.get("lattice_uses", 0) + (1 if count else 0)
-        if seen <= PLAN_AFTER_USES:
-            return None
-        own["lattice"] = _lt.build_lattice_plan(plan, value_crow=value_crow)
-    return own["lattice"]
+        own["lattice"] = _lt.build_lattice_plan_hip(plan, _be)
+    fwd = own["lattice"]
+    if not transposed or fwd is None:
+        return fwd
+    if "lattice_t" not in own:
+        own["lattice_t"] = _lt.build_lattice_plan_hip(plan, _be, forward=fwd)
+    return own["lattice_t"]
 
 
-def _lattice_cfg(plan: RowGather, mode: int, dense: torch.Tensor, *others: torch.Tensor, value_crow=None, count: bool = True):
-    """(LatticePlan, LatticeConfig) for these operands or None."""
+def _lattice_cfg(plan: RowGather, mode: int, dense: torch.Tensor, *others: torch.Tensor):
+    """(LatticePlan, LatticeConfig) for these operands or None; `plan` is always the pattern the values are stored in (the
+    transposed product walks its transposed pattern through the plan's own arrays)."""
     if not ENABLE_LATTICE or dense.dim() != 2 or not _be._tiled_ok(*(_be.rowmajor(t) for t in (dense,) + others)):
         return None
     if dense.dtype not in LATTICE_DTYPES:
         return None
-    lp = _lattice_plan(plan, value_crow, count)
+    lp = _lattice_plan(plan, transposed=mode == _be.LAT_SPMMT)
     if lp is None:
         return None
     cfg = _be.lattice_config(lp, mode, dense.dtype, dense.size(-1))
@@ -118,10 +119,10 @@ def _lattice_backward(plan: RowGather, values: torch.Tensor, G: torch.Tensor, B:
         if fl is None:
             return None
         fplan, (Gf, Bf) = fl
-    bwd = _lattice_cfg(fplan.transposed, _be.LAT_SPMMT, Gf, value_crow=fplan.crow)
-    fwd = _lattice_cfg(fplan, _be.LAT_SDDMM, Bf, Gf, count=False)
+    fwd = _lattice_cfg(fplan, _be.LAT_SDDMM, Bf, Gf)
     if fwd is None:
         return None
+    bwd = _lattice_cfg(fplan, _be.LAT_SPMMT, Gf)
     if bwd is None:
         return None
     vals = values.reshape(-1)
@@ -165,8 +166,7 @@ def spmm(plan: RowGather, values: torch.Tensor, B: torch.Tensor, owner: RowGathe
                 fsrc, Bf = (fl[0], fl[1][0]) if fl is not None else (None, None)
             got = None
             if fsrc is not None:
-                got = (_lattice_cfg(fsrc, _be.LAT_SPMM, Bf) if stored
-                       else _lattice_cfg(fsrc.transposed, _be.LAT_SPMMT, Bf, value_crow=fsrc.crow))
+                got = _lattice_cfg(fsrc, _be.LAT_SPMM if stored else _be.LAT_SPMMT, Bf)
             if got is not None:
                 out = _be.csr_spmm_lattice(got[0], got[1], values.reshape(-1), Bf)
                 return out.view(B.shape[:-2] + (plan.n_rows, B.size(-1)))
@@ -184,12 +184,27 @@ def spmm(plan: RowGather, values: torch.Tensor, B: torch.Tensor, owner: RowGathe
     return _be.csr_spmm(plan.crow, plan.col, values, B, plan.n_rows, plan.n_cols, perm=plan.perm, max_row_nnz=plan.max_row_nnz)
 
 
+def spmm_t(owner: RowGather, values: torch.Tensor, G: torch.Tensor) -> torch.Tensor:
+    """Aᵀ·G for the operand (owner, values): the lattice sweep walks the transposed pattern through the owner's own arrays;
+    everything else goes through the cached transposed pattern (built on first use)."""
+    if ENABLE_LATTICE and owner.perm is None and values.dtype == G.dtype == torch.float32 and not _be.is_transposed_view(G):
+        fsrc, Gf = owner, G
+        if owner.batch is not None:
+            fl = _flat(owner, G)
+            fsrc, Gf = (fl[0], fl[1][0]) if fl is not None else (None, None)
+        got = _lattice_cfg(fsrc, _be.LAT_SPMMT, Gf) if fsrc is not None else None
+        if got is not None:
+            out = _be.csr_spmm_lattice(got[0], got[1], values.reshape(-1), Gf)
+            return out.view(G.shape[:-2] + (owner.n_cols, G.size(-1)))
+    return spmm(owner.transposed, values, G, owner=owner)
+
+
 def sddmm(plan: RowGather, G: torch.Tensor, B: torch.Tensor, alpha: float = 1.0, swap_roles: bool = False) -> torch.Tensor:
     """alpha·<G[row k], B[col k]> (or roles swapped) at the plan's stored entries, in plan order."""
     gathered = G if swap_roles else B
     rowop = B if swap_roles else G
     if plan.perm is None and G.dtype == B.dtype:
-        got = _lattice_cfg(plan, _be.LAT_SDDMM, gathered, rowop, count=plan.core.own.get("lattice_uses", 0) <= PLAN_AFTER_USES and plan.core.t is None)
+        got = _lattice_cfg(plan, _be.LAT_SDDMM, gathered, rowop)
         if got is not None:
             return _be.csr_sddmm_lattice(got[0], got[1], rowop, gathered, alpha=alpha)
         rp = _pack_for(plan, gathered, rowop, need_plain_slots=True)

@@ -150,7 +150,7 @@ class SparseMatMul(torch.autograd.Function):
 
         if need_b:
             # gradB = Aᵀ·G as a gather over the cached transposed pattern (reference :229)
-            gradB = _ops.spmm(plan.transposed, values, G, owner=plan)
+            gradB = _ops.spmm_t(plan, values, G)
             if ctx.batch_size is not None:
                 gradB = gradB.view(ctx.B_shape)
 

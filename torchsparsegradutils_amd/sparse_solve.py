@@ -231,7 +231,7 @@ class _MaskedOuter(torch.autograd.Function):
         if ctx.needs_input_grad[0]:  # dG[i,:] = Σ_k∈row i w[k]·X[col k,:]
             dG = _ops.spmm(plan, w, X.detach())
         if ctx.needs_input_grad[1]:  # dX[j,:] = Σ_k: col k = j  w[k]·G[row k,:]
-            dX = _ops.spmm(plan.transposed, w, G.detach(), owner=plan)
+            dX = _ops.spmm_t(plan, w, G.detach())
         return dG, dX, None, None
 
 
