@@ -68,7 +68,7 @@ def _worker(rank, world, port, batch, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("batch", [4, 5])
+@pytest.mark.parametrize("batch", [4, 5, 8])
 def test_sharded_batched_apply_gloo_world2(batch):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

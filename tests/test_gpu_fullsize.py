@@ -239,3 +239,64 @@ def test_triangular_solve_empty_right_hand_side():
     A = torch.eye(5, device=DEV).to_sparse_csr()
     x = sparse_triangular_solve(A, torch.zeros(5, 0, device=DEV), upper=False)
     assert x.shape == (5, 0)
+
+
+# --------------------------------------------------------------------------- C5 -------------
+@pytest.mark.parametrize("batch", [8, 64])
+def test_c5_full_size_batched_bf16_properties(batch):
+    """BASELINE configs[4] at full size: `batch` periodic 27-pt stencils on 64x64x32 (N=131072), bf16, 16 RHS, as ONE batched
+    CSR operand (batch = 8 is one GPU's share of the 8-GPU job, 64 the whole job on one GPU: a block-diagonal problem of
+    8.4 M rows).  Size-independent checks in the spirit of the C2 test: linearity in B (scaling by 2 is exact in bf16), the
+    adjoint identity <A·B, G> = <B, Aᵀ·G> = Σ val·gradA (fp32 accumulation, bf16 results: 2e-3 of the sum of magnitudes),
+    and sampled rows / entries per item against the oracle evaluated on the same bf16-rounded inputs (1 bf16 ulp)."""
+    from oracle import oracle
+    from torchsparsegradutils_amd import sparse_mm, wait_for_plans
+    from torchsparsegradutils_amd.utils import synthetic
+
+    nx, ny, nz, p = 64, 64, 32, 16
+    n = nx * ny * nz
+    crow1, col1 = synthetic.stencil27_periodic(nx, ny, nz, torch.int32, device=DEV)
+    nnz = col1.numel()
+    g = torch.Generator(device=DEV).manual_seed(77)
+    val = torch.randn((batch, nnz), device=DEV, generator=g).to(torch.bfloat16)
+    B = torch.randn((batch, n, p), device=DEV, generator=g).to(torch.bfloat16).requires_grad_(True)
+    Gd = torch.randn((batch, n, p), device=DEV, generator=g).to(torch.bfloat16)
+    A = torch.sparse_csr_tensor(crow1.unsqueeze(0).repeat(batch, 1), col1.unsqueeze(0).repeat(batch, 1), val, (batch, n, n)).requires_grad_(True)
+    for it in range(3):   # first sight on the plan-free kernels, then the row-pair kernels once their plan is in
+        A.grad = None
+        B.grad = None
+        C = sparse_mm(A, B)
+        C.backward(Gd)
+        wait_for_plans()
+        C1 = sparse_mm(A.detach(), B.detach())          # (the same kernel family as C2: plans may have come in since C)
+        C2 = sparse_mm(A.detach(), 2.0 * B.detach())
+        assert float((C2.float() - 2 * C1.float()).abs().max()) == 0.0
+        lhs = float((C.detach().double() * Gd.double()).sum())
+        mid = float((B.detach().double() * B.grad.double()).sum())
+        rhs = float((val.double() * A.grad.values().double()).sum())
+        scale = float((C.detach().double().abs() * Gd.double().abs()).sum())
+        assert abs(lhs - mid) / scale < 2e-3 and abs(lhs - rhs) / scale < 2e-3, (it, lhs, mid, rhs, scale)
+        assert A.grad.values().dtype == torch.bfloat16 and A.grad.crow_indices().dtype == torch.int32
+        cr, cc = crow1.cpu().numpy(), col1.cpu().numpy()
+        items = sorted(set([0, batch - 1, batch // 2] + torch.randint(0, batch, (3,)).tolist()))
+        for b in items:
+            Bh, Gh, vh = B[b].detach().float().cpu().numpy(), Gd[b].float().cpu().numpy(), val[b].float().cpu().numpy()
+            rows = torch.cat((torch.randint(0, n, (12,)), torch.tensor([0, nz - 1, n - 1, n // 2]))).tolist()
+            for r in rows:
+                s, e = cr[r], cr[r + 1]
+                crow_r = np.array([0, e - s])
+                c_ref = oracle.csr_spmm(crow_r, cc[s:e], vh[s:e], Bh)[0]
+                got = C[b, r].detach().float().cpu().numpy()
+                assert np.all(np.abs(got - c_ref) <= np.maximum(np.abs(c_ref), 1e-3) * 2.0 ** -7 + 1e-6), (it, b, r)
+                g_ref = oracle.csr_sddmm(crow_r, cc[s:e], Gh[r: r + 1], Bh)
+                gotg = A.grad.values()[b, s:e].float().cpu().numpy()
+                assert np.all(np.abs(gotg - g_ref) <= np.maximum(np.abs(g_ref), 1e-3) * 2.0 ** -7 + 1e-6), (it, b, r)
+            for j in rows[-6:]:
+                acc = np.zeros(p, dtype=np.float64)
+                s, e = cr[j], cr[j + 1]
+                for i in cc[s:e]:
+                    si, ei = cr[i], cr[i + 1]
+                    k = si + int(np.nonzero(cc[si:ei] == j)[0][0])
+                    acc += float(vh[k]) * Gh[i].astype(np.float64)
+                gotb = B.grad[b, j].float().cpu().numpy()
+                assert np.all(np.abs(gotb - acc) <= np.maximum(np.abs(acc), 1e-3) * 2.0 ** -7 + 1e-6), (it, b, j)

@@ -462,6 +462,22 @@ def lattice_row_codes(crow, col, dims, rows, out, disp=None):
     check(rc, "tsgu_lattice_row_codes")
 
 
+# Per-kernel timing hook (bench.py): a list to which the lattice launchers append (name, start event, end event) recorded on the
+# launch stream around the C call.  None = off (the product never pays for it).
+KERNEL_EVENTS = None
+
+
+def _timed(name: str, dev: torch.device):
+    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+    ev[0].record(torch.cuda.current_stream(dev))
+    return name, ev
+
+
+def _timed_end(tok, dev: torch.device) -> None:
+    tok[1][1].record(torch.cuda.current_stream(dev))
+    KERNEL_EVENTS.append((tok[0], tok[1][0], tok[1][1]))
+
+
 class _on_device:
     """`with torch.cuda.device(dev)` only when `dev` is not already current (the context manager costs ~8 us per launch)."""
 
@@ -491,9 +507,12 @@ def csr_spmm_lattice(lp, cfg, val, B):
     out = torch.empty((lp.n_rows, p), dtype=B.dtype, device=dev)
     if not val.is_contiguous():
         val = val.contiguous()
+    tok = _timed("lattice_spmm_t" if lp.kind else "lattice_spmm", dev) if KERNEL_EVENTS is not None else None
     with _on_device(dev):
         rc = lib.tsgu_csr_spmm_lattice(_VTYPE[val.dtype], cfg.struct_addr, lp.n_rows, lp.nnz, val.data_ptr(), B.data_ptr(), _ld(B),
                                        out.data_ptr(), p, p, dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    if tok is not None:
+        _timed_end(tok, dev)
     if rc:
         check(rc, "tsgu_csr_spmm_lattice")
     return out
@@ -509,9 +528,12 @@ def csr_sddmm_lattice(lp, cfg, R, Cm, alpha: float = 1.0):
     R, Cm = rowmajor(R), rowmajor(Cm)
     p = R.size(-1)
     out = torch.empty((lp.nnz,), dtype=R.dtype, device=dev)
+    tok = _timed("lattice_sddmm", dev) if KERNEL_EVENTS is not None else None
     with _on_device(dev):
         rc = lib.tsgu_csr_sddmm_lattice(_VTYPE[R.dtype], cfg.struct_addr, lp.n_rows, lp.nnz, R.data_ptr(), _ld(R), Cm.data_ptr(), _ld(Cm),
                                         out.data_ptr(), float(alpha), p, dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    if tok is not None:
+        _timed_end(tok, dev)
     if rc:
         check(rc, "tsgu_csr_sddmm_lattice")
     return out

@@ -293,18 +293,23 @@ def _sample_dims(g) -> Optional[Tuple[int, int, int, int]]:
         rows = np.repeat(np.arange(first, first + m, dtype=np.int64), np.diff(ptr))
         return rows, cols
 
-    rows, cols = sample(r0)
-    if cols.size == 0:
-        return None
-    uniq, cnt = np.unique(np.abs(cols - rows), return_counts=True)
-    found = _clusters_to_dims(uniq[(cnt * 2 > m) & (uniq > 0)].tolist(), n)
+    found = None
+    # the strides from interior rows: the middle of the matrix, or (block-diagonal batches put an item boundary there) two
+    # other places
+    for first in dict.fromkeys((r0, max(0, n // 3 - m // 2), max(0, min(n - m, (2 * n) // 3 + 17 * m)))):
+        rows, cols = sample(first)
+        if cols.size == 0:
+            continue
+        uniq, cnt = np.unique(np.abs(cols - rows), return_counts=True)
+        found = _clusters_to_dims(uniq[(cnt * 2 > m) & (uniq > 0)].tolist(), n)
+        if found is not None and n % found[1] == 0 and n % found[0] == 0:
+            break
+        found = None
     if found is None:
         return None
     nz, d2 = found
-    if n % d2 or n % nz:
-        return None
     planes = n // d2
-    rows, cols = (rows, cols) if r0 == 0 else sample(0)
+    rows, cols = sample(0)
     mx = int(np.abs(cols // d2 - rows // d2).max()) if cols.size else 0
     nx = planes if mx <= 1 else mx + 1
     if nx < 1 or planes % nx:
@@ -505,7 +510,7 @@ def rank_configs(plan: LatticePlan, mode: int, vtype: int, p: int, elem_bytes: i
     cl = p * elem_bytes // 16
     found = {}
     alpha = 0.35 if plan.kind == 0 else 0.8       # what a halo row costs relative to an own row (the transposed walk also stages its values)
-    for threads in (512, 1024):
+    for threads in (256, 512, 1024):
         rpp = threads // cl
         for ty, tz in _candidates(rpp):           # one row per lane group and plane step
             if ty > plan.ny or tz > plan.nz or (plan.ny == 1 and ty != 1):
@@ -559,7 +564,9 @@ def config_for(plan: LatticePlan, mode: int, vtype: int, p: int, elem_bytes: int
             lds = lds_bytes_fn(mode, vtype, p, ty, tz, plan.ry, plan.rz, nloc, plan.recw, threads, ring, cpl)
             if lds <= 0:
                 continue      # the workgroups of this tiling meet more classes than the ranking assumed
-            slot = (plan.recw * (4 if mode == _MODE_SDDMM else elem_bytes) + 15) // 16 * 16
+            slot = (plan.recw * (4 if mode == _MODE_SDDMM else elem_bytes) + (6 if mode == _MODE_SPMM and elem_bytes == 2 else 0) + 15) // 16 * 16
+            if slot % 64 == 0:
+                slot += 16                 # as lat_layout (csrc/lattice_impl.h): value rows must not share four banks
             if PACKED_T and mode == _MODE_SPMMT and (p * elem_bytes) % 128 == 0:
                 slot = p * elem_bytes      # packed records: the value ring has the pitch of the dense ring
             cfg = LatticeConfig()

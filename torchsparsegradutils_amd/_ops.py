@@ -36,9 +36,9 @@ PLAN_ASYNC = os.environ.get("TSGU_PLAN_ASYNC", "1") == "1"
 # reference's PairwiseEncoder and its stencil benchmarks produce) are walked tile by tile with the halo of the dense
 # operand in LDS.  First choice when the pattern qualifies; anything else takes the row-pair / plan-free kernels.
 ENABLE_LATTICE = os.environ.get("TSGU_ENABLE_LATTICE", "1") == "1"
-# bf16 rows of odd length start at 2-byte aligned addresses, which the 16-byte value DMA of the sweep handles badly (C5:
-# 1.35 ms against 0.64 ms on the row-pair kernels): bf16 stays on the row-pair kernels until the staging is realigned
-LATTICE_DTYPES = (torch.float32,)
+# fp32: all three sweeps.  bf16: the stored-order walks (SpMM, SDDMM); the transposed product of a bf16 operand stays on the
+# row-pair kernels (the sweep stages 4-byte values there).
+LATTICE_DTYPES = (torch.float32, torch.bfloat16)
 
 
 def _lattice_plan(plan: RowGather, transposed: bool = False):
@@ -64,7 +64,7 @@ def _lattice_cfg(plan: RowGather, mode: int, dense: torch.Tensor, *others: torch
     transposed product walks its transposed pattern through the plan's own arrays)."""
     if not ENABLE_LATTICE or dense.dim() != 2 or not _be._tiled_ok(*(_be.rowmajor(t) for t in (dense,) + others)):
         return None
-    if dense.dtype not in LATTICE_DTYPES:
+    if dense.dtype not in LATTICE_DTYPES or (mode == _be.LAT_SPMMT and dense.dtype != torch.float32):
         return None
     lp = _lattice_plan(plan, transposed=mode == _be.LAT_SPMMT)
     if lp is None:

@@ -41,7 +41,7 @@ namespace tsgu {
 enum LatMode { kLatSpmm = 0, kLatSddmm = 1, kLatSpmmT = 2 };
 
 constexpr int kLatND = 3;    // ring DMA pieces per thread and plane   (halo rows x chunks <= kLatND * NT)
-constexpr int kLatNVD = 2;   // value DMA pieces per thread and plane
+constexpr int kLatNVD = 3;   // value DMA pieces per thread and plane
 constexpr int kLatNP = 1;    // row passes per plane                   (tile rows <= kLatNP * NT / CL)
 constexpr int kLatMaxLds = 160 * 1024;
 #ifndef TSGU_LAT_PROBE
@@ -131,6 +131,7 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
     constexpr bool kPacked = false && MODE == kLatSpmmT && RB % 128 == 0;
     constexpr int kRecB = (MODE == kLatSpmmT && !kPacked) ? 8 : 4;   // bytes of a record
     constexpr int kUnroll = NCH > 0 ? NCH : 2;
+    constexpr bool kValShift = MODE == kLatSpmm && kVB == 2;   // staged value rows may start one element late (see dma_vals)
     static_assert(NT % kWave == 0 && NT % CL == 0 && RB % 16 == 0 && (CPL == 1 || CPL == 2) && CL % CPL == 0, "geometry");
     static_assert(std::is_same<V, float>::value || MODE != kLatSpmmT, "the transposed walk stages 4-byte values");
 
@@ -281,7 +282,10 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
             for (int d = 0; d < kLatNVD; ++d) {
                 if (d * NT < val_pieces) {
                     if (vrow[d] >= 0) {
-                        const uint32_t off = uniform ? vuo[d] : (uint32_t)st[d] * kVB + vch16[d];
+                        uint32_t off = uniform ? vuo[d] : (uint32_t)st[d] * kVB + vch16[d];
+                        // 2-byte values: rows of odd length start on 2-byte boundaries, which the 16-byte DMA handles badly;
+                        // the copy starts on the 4-byte boundary below and the reader shifts by one element (kValShift)
+                        if constexpr (kVB == 2) off -= (plane0 + off) & 2u;
                         if (__builtin_expect(plane0 + off + 16u <= val_bytes, 1)) {
                             lat_dma16<true>(pbase, off, base + (unsigned)(d * NT * 16));
                         } else {
@@ -316,7 +320,7 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
     // what a compute row needs from memory besides the rings: class byte; for the SDDMM its value start and its own dense row
     struct RowRegs {
         int cls[kLatNP];
-        int rst[MODE == kLatSddmm ? kLatNP : 1];
+        int rst[(MODE == kLatSddmm || kValShift) ? kLatNP : 1];
         float own[MODE == kLatSddmm ? kLatNP : 1][CPL][VEC];
     };
     auto load_rows = [&](int prow, RowRegs& rr) {
@@ -328,8 +332,8 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
             if (q * RPP < NR) {
                 if (crow[q] >= 0) {
                     rr.cls[q] = cbase[(uint32_t)crow[q]];
+                    if constexpr (MODE == kLatSddmm || kValShift) rr.rst[q] = uniform ? (prow + crow[q]) * P.uniform_len : P.rstart[prow + crow[q]];
                     if constexpr (MODE == kLatSddmm) {
-                        rr.rst[q] = uniform ? (prow + crow[q]) * P.uniform_len : P.rstart[prow + crow[q]];
 #pragma unroll
                         for (int cp = 0; cp < CPL; ++cp) load_vec<V, VEC>(reinterpret_cast<const V*>(obase + cown[q][cp]), rr.own[q][cp]);
                     }
@@ -341,6 +345,7 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
 #pragma unroll
         for (int q = 0; q < kLatNP; ++q) {
             lat_pin(rr.cls[q]);
+            if constexpr (kValShift) lat_pin(rr.rst[q]);
             if constexpr (MODE == kLatSddmm) {
                 lat_pin(rr.rst[q]);
 #pragma unroll
@@ -487,23 +492,41 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
                     const char* const cb = sm + cen[q][0];
                     const char* const cb1 = sm + cen[q][CPL - 1];   // second chunk (= cb with one chunk per lane)
                     // the dense row at byte offset `rec` from the own position: this lane's chunk(s)
-                    auto load_b = [&](int rec, float (&bb)[CPL][VEC]) {
-                        load_vec<V, VEC>(reinterpret_cast<const V*>(cb + rec), bb[0]);
-                        if constexpr (CPL == 2) load_vec<V, VEC>(reinterpret_cast<const V*>(cb1 + rec), bb[1]);
+                    // (kept as the 16 raw bytes until it is used: a staged bf16 row widened to eight floats would double the registers
+                    // of the pipeline's buffers)
+                    auto load_b = [&](int rec, uint4 (&bb)[CPL]) {
+                        bb[0] = *reinterpret_cast<const uint4*>(cb + rec);
+                        if constexpr (CPL == 2) bb[1] = *reinterpret_cast<const uint4*>(cb1 + rec);
                     };
-                    auto axpy = [&](float a, const float (&bb)[CPL][VEC]) {
+                    auto widen = [](const uint4& raw, float (&f)[VEC]) {
+                        const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+                        if constexpr (kVB == 4) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) f[i] = __uint_as_float(w[i]);
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                f[2 * i] = __uint_as_float(w[i] << 16);
+                                f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+                            }
+                        }
+                    };
+                    auto axpy = [&](float a, const uint4 (&bb)[CPL]) {
 #pragma unroll
                         for (int cp = 0; cp < CPL; ++cp) {
+                            float f[VEC];
+                            widen(bb[cp], f);
 #pragma unroll
-                            for (int v = 0; v < VEC; ++v) acc[MODE == kLatSddmm ? 0 : q][cp][v] = fmaf(a, bb[cp][v], acc[MODE == kLatSddmm ? 0 : q][cp][v]);
+                            for (int v = 0; v < VEC; ++v) acc[MODE == kLatSddmm ? 0 : q][cp][v] = fmaf(a, f[v], acc[MODE == kLatSddmm ? 0 : q][cp][v]);
                         }
                     };
                     const int recw = NCH > 0 ? 4 * NCH : P.recw;
                     if constexpr (MODE == kLatSpmm) {
                         char* const vs = sm + P.o_vals + vbi * vbuf + csl[q];
+                        const int vsh = kValShift ? (cur.rst[q] & 1) : 0;     // elements the staged row starts late
                         if (len < recw) {   // padded slots hold whatever follows the row in the value array: zero them
 #pragma nounroll
-                            for (int t = len + c; t < recw; t += LPR) __builtin_memset(vs + t * kVB, 0, kVB);
+                            for (int t = len + c; t < recw; t += LPR) __builtin_memset(vs + (t + vsh) * kVB, 0, kVB);
                         }
 #pragma unroll
                         for (int cp = 0; cp < CPL; ++cp) {
@@ -516,8 +539,10 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
                                 a[0] = __uint_as_float(w.x), a[1] = __uint_as_float(w.y), a[2] = __uint_as_float(w.z), a[3] = __uint_as_float(w.w);
                             } else {
                                 const uint2 w = *reinterpret_cast<const uint2*>(vs + k0 * 2);
-                                a[0] = __uint_as_float(w.x << 16), a[1] = __uint_as_float(w.x & 0xffff0000u);
-                                a[2] = __uint_as_float(w.y << 16), a[3] = __uint_as_float(w.y & 0xffff0000u);
+                                const uint32_t w2 = *reinterpret_cast<const uint32_t*>(vs + k0 * 2 + 8);
+                                const uint32_t x0 = __builtin_amdgcn_alignbit(w.y, w.x, 16 * vsh), x1 = __builtin_amdgcn_alignbit(w2, w.y, 16 * vsh);
+                                a[0] = __uint_as_float(x0 << 16), a[1] = __uint_as_float(x0 & 0xffff0000u);
+                                a[2] = __uint_as_float(x1 << 16), a[3] = __uint_as_float(x1 & 0xffff0000u);
                             }
                         };
                         if constexpr (NCH > 0) {
@@ -528,7 +553,7 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
                             // Three stages: values + records of chunk i+2, dense rows of chunk i+1, FMAs of chunk i.
                             float a[3][4];
                             int4 ro[3];
-                            float b[2][4][CPL][VEC];
+                            uint4 b[2][4][CPL];
                             auto stage_a = [&](int i) {
                                 chunk_vals(4 * i, a[i % 3]);
                                 ro[i % 3] = *reinterpret_cast<const int4*>(tb + 16 * i);
@@ -558,7 +583,7 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
                                 chunk_vals(k0, a);
                                 const int4 ro = *reinterpret_cast<const int4*>(tb + k0 * 4);
                                 const int rv[4] = {ro.x, ro.y, ro.z, ro.w};
-                                float b[4][CPL][VEC];
+                                uint4 b[4][CPL];
 #pragma unroll
                                 for (int j = 0; j < 4; ++j) load_b(rv[j], b[j]);
 #pragma unroll
@@ -569,16 +594,19 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
                         float* const st = reinterpret_cast<float*>(sm + P.o_vals + csl[q]);   // fp32 staging row (slot = recw*4 bytes in this mode)
                         plen[q] = len;
                         prst[q] = cur.rst[q];
-                        auto consume = [&](int k0, const float (&bb)[4][CPL][VEC]) {
+                        auto consume = [&](int k0, const uint4 (&bb)[4][CPL]) {
                             float dsum[4];
 #pragma unroll
                             for (int j = 0; j < 4; ++j) {
-                                float d = cur.own[q][0][0] * bb[j][0][0];
+                                float f[VEC];
+                                widen(bb[j][0], f);
+                                float d = cur.own[q][0][0] * f[0];
 #pragma unroll
-                                for (int v = 1; v < VEC; ++v) d = fmaf(cur.own[q][0][v], bb[j][0][v], d);
+                                for (int v = 1; v < VEC; ++v) d = fmaf(cur.own[q][0][v], f[v], d);
                                 if constexpr (CPL == 2) {
+                                    widen(bb[j][1], f);
 #pragma unroll
-                                    for (int v = 0; v < VEC; ++v) d = fmaf(cur.own[q][1][v], bb[j][1][v], d);
+                                    for (int v = 0; v < VEC; ++v) d = fmaf(cur.own[q][1][v], f[v], d);
                                 }
                                 dsum[j] = group_sum<float, LPR>(d);
                             }
@@ -594,7 +622,7 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
                         };
                         if constexpr (NCH > 0) {   // three stages, as in the SpMM above
                             int4 ro[3];
-                            float b[2][4][CPL][VEC];
+                            uint4 b[2][4][CPL];
                             auto stage_b = [&](int i) {
                                 const int rv[4] = {ro[i % 3].x, ro[i % 3].y, ro[i % 3].z, ro[i % 3].w};
 #pragma unroll
@@ -617,7 +645,7 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
                             for (int k0 = 0; k0 < recw; k0 += 4) {
                                 const int4 ro = *reinterpret_cast<const int4*>(tb + k0 * 4);
                                 const int rv[4] = {ro.x, ro.y, ro.z, ro.w};
-                                float b[4][CPL][VEC];
+                                uint4 b[4][CPL];
 #pragma unroll
                                 for (int j = 0; j < 4; ++j) load_b(rv[j], b[j]);
                                 consume(k0, b);
@@ -634,7 +662,8 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
                         }
                         if constexpr (NCH > 0) {   // three stages: records of chunk i+2, dense rows + values of chunk i+1, FMAs of chunk i
                             int4 r01[3], r23[3];
-                            float b[2][4][CPL][VEC], a[2][4];
+                            uint4 b[2][4][CPL];
+                            float a[2][4];
                             auto stage_a = [&](int i) {
                                 if constexpr (kPacked) {
                                     r01[i % 3] = *reinterpret_cast<const int4*>(tb + 16 * i);
@@ -687,7 +716,8 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
                                     go[0] = r01.x, go[1] = r01.z, go[2] = r23.x, go[3] = r23.z;
                                     vo[0] = r01.y, vo[1] = r01.w, vo[2] = r23.y, vo[3] = r23.w;
                                 }
-                                float b[4][CPL][VEC], a[4];
+                                uint4 b[4][CPL];
+                                float a[4];
 #pragma unroll
                                 for (int j = 0; j < 4; ++j) {
                                     load_b(go[j], b[j]);
@@ -726,7 +756,11 @@ inline int lat_layout(LatParams& P, int mode, int cl, int vbytes, int nt) {
         return TSGU_ERR_BAD_ARG;
     const int HR = (P.ty + 2 * P.ry) * (P.tz + 2 * P.rz), NR = P.ty * P.tz, RB = cl * 16;
     const bool packed = false && mode == kLatSpmmT && RB % 128 == 0;   // see kPacked in lattice_kernel
-    P.slot = packed ? RB : lat_round16(P.recw * (mode == kLatSddmm ? 4 : vbytes));
+    // (2-byte values of the SpMM: one element of slack for rows staged from the 4-byte boundary below their start, and the
+    // reader's look-ahead word)
+    P.slot = packed ? RB : lat_round16(P.recw * (mode == kLatSddmm ? 4 : vbytes) + (mode == kLatSpmm && vbytes == 2 ? 6 : 0));
+    // a pitch of a multiple of 64 bytes would put the value rows of a wave on four banks (bf16, 28 entries: 64 -> 80 bytes)
+    if (!packed && P.slot % 64 == 0) P.slot += 16;
     if (packed && P.recw * vbytes > RB) return TSGU_ERR_TOO_LARGE;
     const int VL = P.slot / 16;
     if (P.cpl != 1 && P.cpl != 2) return TSGU_ERR_BAD_ARG;
@@ -778,7 +812,9 @@ int lat_launch_one(const LatParams& P, hipStream_t stream) {
         }
         return TSGU_ERR_BAD_ARG;
     }
-    if (P.recw == 28) return lat_launch_nch<V, CL, 1, MODE, NT, 7>(P, stream);
+    // (the unrolled, three-stage SpMM of 2-byte values needs more than the 128 registers of four waves per SIMD: it takes
+    // the run-time loop)
+    if (P.recw == 28 && !(MODE == kLatSpmm && sizeof(V) == 2)) return lat_launch_nch<V, CL, 1, MODE, NT, 7>(P, stream);
     if (P.recw == 8) return lat_launch_nch<V, CL, 1, MODE, NT, 2>(P, stream);
     return lat_launch_nch<V, CL, 1, MODE, NT, 0>(P, stream);
 }

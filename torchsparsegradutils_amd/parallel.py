@@ -63,11 +63,15 @@ def _apply_overlapped(op, A_local, B_local, batch: int, chunks: int, group) -> t
     """Rank-local compute in `chunks` runs of batch items; the all-gather of run c (asynchronous, on the backend's
     own stream) overlaps the computation of run c+1.  Per-GPU compute of a C5-sized item is tens of microseconds
     while its share of the gather over xGMI is hundreds, so the collective is the long pole: chunking hides the
-    compute behind it instead of serialising the two.  Equal shards only."""
+    compute behind it instead of serialising the two.  Equal shards only.
+
+    Every run is gathered with ONE `all_gather_into_tensor` into its own contiguous (world, run, n, p) slab — the collective
+    writes its final bytes directly (a gather into a list of strided views makes c10d stage through a flattened temporary
+    and copy out per rank, inside the collective).  The slabs are chunk-major; one strided device copy per run, issued after
+    that run's collective and overlapping the later ones, lays the result out rank-major as the contract promises."""
     world = dist.get_world_size(group)
     b_local = A_local.size(0)
     bounds = [(b_local * c // chunks, b_local * (c + 1) // chunks) for c in range(chunks)]
-    out = None
     works = []
     for lo, hi in bounds:
         if hi == lo:
@@ -75,13 +79,14 @@ def _apply_overlapped(op, A_local, B_local, batch: int, chunks: int, group) -> t
         a = torch.sparse_csr_tensor(A_local.crow_indices()[lo:hi], A_local.col_indices()[lo:hi], A_local.values()[lo:hi],
                                     (hi - lo,) + tuple(A_local.shape[1:]))
         part = op(a, B_local[lo:hi]).detach().contiguous()
-        if out is None:
-            out = torch.empty((world, b_local) + tuple(part.shape[1:]), dtype=part.dtype, device=part.device)
-        # rank r's run lands in out[r, lo:hi] (contiguous slices: no staging copy on our side)
-        works.append((dist.all_gather([out[r, lo:hi] for r in range(world)], part, group=group, async_op=True), part))
-    for w, _keep in works:
+        slab = torch.empty((world * part.size(0),) + tuple(part.shape[1:]), dtype=part.dtype, device=part.device)   # rank-major rows
+        works.append((dist.all_gather_into_tensor(slab, part, group=group, async_op=True), part, slab, lo, hi))
+    tail = tuple(works[0][1].shape[1:])
+    out = torch.empty((world, b_local) + tail, dtype=works[0][1].dtype, device=works[0][1].device)
+    for w, _keep, slab, lo, hi in works:
         w.wait()
-    return out.reshape((batch,) + tuple(out.shape[2:]))
+        out[:, lo:hi].copy_(slab.view((world, hi - lo) + tail))
+    return out.reshape((batch,) + tail)
 
 
 def sharded_batched_apply(
