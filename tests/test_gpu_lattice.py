@@ -161,6 +161,17 @@ def test_bf16_forward_and_sddmm():
                 continue
             C = be.csr_spmm_lattice(lp, c1, val.to(dev), B.to(dev))
             gA = be.csr_sddmm_lattice(lp, c2, Gd.to(dev), B.to(dev))
+            ltp = lt.build_lattice_plan_hip(plan, be, forward=lp)
+            lt._CFG_ENV = cs
+            try:
+                ltp._cfg.clear()
+                c3 = be.lattice_config(ltp, be.LAT_SPMMT, torch.bfloat16, p)
+            finally:
+                lt._CFG_ENV = ""
+            if c3 is not None:
+                _, _, gBo = _oracle_mm(crow, col, val.float(), B.float(), Gd.float())
+                gB = be.csr_spmm_lattice(ltp, c3, val.to(dev), Gd.to(dev))
+                assert G.rel_err(gB.float().cpu().numpy(), gBo) < 2.0 ** -8, (p, cs)
             # bf16 results: fp32 accumulation, one rounding at the end: within one bf16 ulp (2^-8) of the largest element
             assert G.rel_err(C.float().cpu().numpy(), Co) < 2.0 ** -8, (p, cs)
             assert G.rel_err(gA.float().cpu().numpy(), gAo) < 2.0 ** -8, (p, cs)

@@ -67,16 +67,15 @@ def main():
     modes = a.modes.split(",")
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    lp = lt.build_lattice_plan(plan)
+    lp = lt.build_lattice_plan_hip(plan, be)
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     print(f"forward plan: {None if lp is None else (lp.nb, lp.nx, lp.ny, lp.nz, lp.ry, lp.rz, lp.ncls, lp.recw, lp.uniform_len)} in {(t1 - t0) * 1e3:.0f} ms")
     ltp = None
-    if "spmmt" in modes and dt == torch.float32:
-        t = plan.transposed
+    if "spmmt" in modes:
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        ltp = lt.build_lattice_plan(t, value_crow=crow)
+        ltp = lt.build_lattice_plan_hip(plan, be, forward=lp)
         torch.cuda.synchronize()
         print(f"transposed plan: {None if ltp is None else (ltp.nb, ltp.nx, ltp.ny, ltp.nz, ltp.ncls, ltp.recw, ltp.uniform_len)} in {(time.perf_counter() - t0) * 1e3:.0f} ms")
     ref = {}

@@ -420,7 +420,7 @@ def lattice_config(lp, mode: int, dtype: torch.dtype, p: int):
     """Launch configuration (tile, segments, record tables) of the _lattice.LatticePlan `lp` for these operands, or None."""
     from . import _lattice
 
-    if dtype not in (torch.float32, torch.bfloat16) or (mode == LAT_SPMMT and dtype != torch.float32):
+    if dtype not in (torch.float32, torch.bfloat16):
         return None
     es = 4 if dtype == torch.float32 else 2
     if (p * es) % 16 or (p * es) // 16 not in (2, 4, 8, 16):

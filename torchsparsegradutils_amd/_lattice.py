@@ -421,7 +421,7 @@ def workgroup_classes_hip(plan: LatticePlan, ty: int, tz: int, nseg: int, be) ->
     return torch.from_numpy(np.ascontiguousarray(wl)).to(dev)
 
 
-def records(plan: LatticePlan, ty: int, tz: int, row_bytes: int, slot_bytes: int, ring: int = 4) -> torch.Tensor:
+def records(plan: LatticePlan, ty: int, tz: int, row_bytes: int, slot_bytes: int, ring: int = 4, elem_bytes: int = 4) -> torch.Tensor:
     """Record tables of `plan` for a ty × tz tile (host tensor, int32): [ring][ncls][recw] byte offsets for kind 0,
     [ring][ncls][recw][2] = (dense-row offset, value offset) for kind 1.  Entry k of a row of class c gathers the LDS row
     `rec` bytes from the row's own position in the halo tile, in the ring slot (phase + dx) % ring — see include/tsgu_hip.h."""
@@ -447,7 +447,7 @@ def records(plan: LatticePlan, ty: int, tz: int, row_bytes: int, slot_bytes: int
                 assert slot_bytes == row_bytes
                 out.append(torch.where(valid, lo + k * 4, torch.full_like(lo, PAD_LO)).to(torch.int32))
             else:
-                hi = slot * (hr * slot_bytes) + (dy * hz + dz) * slot_bytes + k * 4
+                hi = slot * (hr * slot_bytes) + (dy * hz + dz) * slot_bytes + k * elem_bytes
                 hi = torch.where(valid, hi, torch.full_like(hi, PAD_HI))
                 out.append(torch.stack((lo, hi), -1).to(torch.int32))
     return torch.stack(out, 0).contiguous()
@@ -564,7 +564,7 @@ def config_for(plan: LatticePlan, mode: int, vtype: int, p: int, elem_bytes: int
             lds = lds_bytes_fn(mode, vtype, p, ty, tz, plan.ry, plan.rz, nloc, plan.recw, threads, ring, cpl)
             if lds <= 0:
                 continue      # the workgroups of this tiling meet more classes than the ranking assumed
-            slot = (plan.recw * (4 if mode == _MODE_SDDMM else elem_bytes) + (6 if mode == _MODE_SPMM and elem_bytes == 2 else 0) + 15) // 16 * 16
+            slot = (plan.recw * (4 if mode == _MODE_SDDMM else elem_bytes) + 15) // 16 * 16
             if slot % 64 == 0:
                 slot += 16                 # as lat_layout (csrc/lattice_impl.h): value rows must not share four banks
             if PACKED_T and mode == _MODE_SPMMT and (p * elem_bytes) % 128 == 0:
@@ -572,7 +572,7 @@ def config_for(plan: LatticePlan, mode: int, vtype: int, p: int, elem_bytes: int
             cfg = LatticeConfig()
             cfg.ty, cfg.tz, cfg.nseg, cfg.threads, cfg.lds_bytes = ty, tz, nseg, threads, lds
             cfg.wlist, cfg.nloc, cfg.ring, cfg.cpl = wlist, nloc, ring, cpl
-            cfg.rec = records(plan, ty, tz, p * elem_bytes, slot, ring).to(plan.rcls.device)
+            cfg.rec = records(plan, ty, tz, p * elem_bytes, slot, ring, elem_bytes).to(plan.rcls.device)
             cfg.struct = _LatticePlanStruct(plan.kind, plan.nb, plan.nx, plan.ny, plan.nz, plan.ry, plan.rz, plan.ncls, plan.recw,
                                             nloc, plan.uniform_len, ty, tz, nseg, threads, ring, cpl, cfg.rec.data_ptr(), plan.lens.data_ptr(),
                                             plan.rcls.data_ptr(), plan.rstart.data_ptr(), wlist.data_ptr())

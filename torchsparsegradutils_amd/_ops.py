@@ -36,8 +36,7 @@ PLAN_ASYNC = os.environ.get("TSGU_PLAN_ASYNC", "1") == "1"
 # reference's PairwiseEncoder and its stencil benchmarks produce) are walked tile by tile with the halo of the dense
 # operand in LDS.  First choice when the pattern qualifies; anything else takes the row-pair / plan-free kernels.
 ENABLE_LATTICE = os.environ.get("TSGU_ENABLE_LATTICE", "1") == "1"
-# fp32: all three sweeps.  bf16: the stored-order walks (SpMM, SDDMM); the transposed product of a bf16 operand stays on the
-# row-pair kernels (the sweep stages 4-byte values there).
+# value types the sweeps are compiled for (fp32 accumulation for bf16)
 LATTICE_DTYPES = (torch.float32, torch.bfloat16)
 
 
@@ -64,7 +63,7 @@ def _lattice_cfg(plan: RowGather, mode: int, dense: torch.Tensor, *others: torch
     transposed product walks its transposed pattern through the plan's own arrays)."""
     if not ENABLE_LATTICE or dense.dim() != 2 or not _be._tiled_ok(*(_be.rowmajor(t) for t in (dense,) + others)):
         return None
-    if dense.dtype not in LATTICE_DTYPES or (mode == _be.LAT_SPMMT and dense.dtype != torch.float32):
+    if dense.dtype not in LATTICE_DTYPES:
         return None
     lp = _lattice_plan(plan, transposed=mode == _be.LAT_SPMMT)
     if lp is None:
@@ -134,7 +133,7 @@ def _lattice_backward(plan: RowGather, values: torch.Tensor, G: torch.Tensor, B:
 def mm_backward(plan: RowGather, values: torch.Tensor, G: torch.Tensor, B: torch.Tensor):
     """(gradA values in A's order, gradB) of C = A·B in one pass over the transposed pattern."""
     same = values.dtype == G.dtype == B.dtype
-    if same and ENABLE_LATTICE and values.dtype == torch.float32:
+    if same and ENABLE_LATTICE and values.dtype in LATTICE_DTYPES:
         got = _lattice_backward(plan, values, G, B)
         if got is not None:
             return got
@@ -158,7 +157,7 @@ def spmm(plan: RowGather, values: torch.Tensor, B: torch.Tensor, owner: RowGathe
     `plan` is `owner.transposed`, the pattern whose stored order the values are in (lets Aᵀ·G take the lattice sweep)."""
     if values.dtype == B.dtype and not _be.is_transposed_view(B):  # transposed views: zero-copy column-strided K1
         stored = plan.perm is None
-        if ENABLE_LATTICE and (stored or (owner is not None and owner.perm is None and values.dtype == torch.float32)):
+        if ENABLE_LATTICE and (stored or (owner is not None and owner.perm is None)):
             src = plan if stored else owner
             fsrc, Bf = src, B
             if src.batch is not None:
@@ -187,7 +186,7 @@ def spmm(plan: RowGather, values: torch.Tensor, B: torch.Tensor, owner: RowGathe
 def spmm_t(owner: RowGather, values: torch.Tensor, G: torch.Tensor) -> torch.Tensor:
     """Aᵀ·G for the operand (owner, values): the lattice sweep walks the transposed pattern through the owner's own arrays;
     everything else goes through the cached transposed pattern (built on first use)."""
-    if ENABLE_LATTICE and owner.perm is None and values.dtype == G.dtype == torch.float32 and not _be.is_transposed_view(G):
+    if ENABLE_LATTICE and owner.perm is None and values.dtype == G.dtype and not _be.is_transposed_view(G):
         fsrc, Gf = owner, G
         if owner.batch is not None:
             fl = _flat(owner, G)

@@ -24,7 +24,6 @@ int fill(LatParams& P, const tsgu_lattice_plan* pl, int mode, int vtype, int64_t
     if (!pl || n_rows < 0 || nnz < 0) return TSGU_ERR_BAD_ARG;
     cl = lanes_of(vtype, p);
     if (cl == 0) return TSGU_ERR_BAD_DTYPE;
-    if (mode == kLatSpmmT && vtype != TSGU_F32) return TSGU_ERR_BAD_DTYPE;
     if ((pl->kind != 0) != (mode == kLatSpmmT)) return TSGU_ERR_BAD_ARG;
     if (pl->nb <= 0 || pl->nx <= 0 || pl->ny <= 0 || pl->nz <= 0 || pl->nseg <= 0 || pl->nseg > pl->nx) return TSGU_ERR_BAD_ARG;
     if ((int64_t)pl->nb * pl->nx * pl->ny * pl->nz != n_rows) return TSGU_ERR_BAD_ARG;
@@ -74,7 +73,7 @@ extern "C" {
 int tsgu_lattice_lds_bytes(int mode, int vtype, int64_t p, int ty, int tz, int ry, int rz, int nloc, int recw, int threads, int ring,
                            int chunks_per_lane) {
     const int cl = lanes_of(vtype, p);
-    if (cl == 0 || mode < 0 || mode > 2 || (mode == kLatSpmmT && vtype != TSGU_F32)) return TSGU_ERR_BAD_DTYPE;
+    if (cl == 0 || mode < 0 || mode > 2) return TSGU_ERR_BAD_DTYPE;
     if (threads != 256 && threads != 512 && threads != 1024) return TSGU_ERR_BAD_ARG;
     LatParams P{};
     P.ty = ty, P.tz = tz, P.ry = ry, P.rz = rz, P.ncls = nloc, P.nloc = nloc, P.recw = recw, P.ring = ring;

@@ -1,4 +1,4 @@
-// bf16 instantiations of the lattice plane-sweep kernels (stored-order walks: SpMM and SDDMM; fp32 accumulation).
+// bf16 instantiations of the lattice plane-sweep kernels (fp32 accumulation).
 #include "lattice_impl.h"
 
 namespace tsgu {
@@ -19,6 +19,7 @@ static int lat_mode_bf16(int mode, int cl, const LatParams& P, hipStream_t s) {
     switch (mode) {
         case kLatSpmm: return lat_go_bf16<kLatSpmm, NT>(cl, P, s);
         case kLatSddmm: return lat_go_bf16<kLatSddmm, NT>(cl, P, s);
+        case kLatSpmmT: return lat_go_bf16<kLatSpmmT, NT>(cl, P, s);
     }
     return TSGU_ERR_BAD_DTYPE;
 }

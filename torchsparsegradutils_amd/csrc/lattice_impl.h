@@ -41,7 +41,8 @@ namespace tsgu {
 enum LatMode { kLatSpmm = 0, kLatSddmm = 1, kLatSpmmT = 2 };
 
 constexpr int kLatND = 3;    // ring DMA pieces per thread and plane   (halo rows x chunks <= kLatND * NT)
-constexpr int kLatNVD = 3;   // value DMA pieces per thread and plane
+// value DMA pieces per thread and plane: as few as the supported geometries need (each costs registers for the whole march)
+constexpr int lat_nvd(int mode, int vbytes) { return vbytes == 4 ? 2 : (mode == 2 ? 4 : 3); }
 constexpr int kLatNP = 1;    // row passes per plane                   (tile rows <= kLatNP * NT / CL)
 constexpr int kLatMaxLds = 160 * 1024;
 #ifndef TSGU_LAT_PROBE
@@ -129,11 +130,10 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
     // (measured: slower — with a 128-byte value pitch the broadcast value reads of the eight rows of a wave fall on ONE bank,
     // C2 transposed product 107 -> 136 us; the 112-byte pitch of the two-word form spreads them.  Kept switched off.)
     constexpr bool kPacked = false && MODE == kLatSpmmT && RB % 128 == 0;
+    constexpr int kNVD = lat_nvd(MODE, kVB);
     constexpr int kRecB = (MODE == kLatSpmmT && !kPacked) ? 8 : 4;   // bytes of a record
     constexpr int kUnroll = NCH > 0 ? NCH : 2;
-    constexpr bool kValShift = MODE == kLatSpmm && kVB == 2;   // staged value rows may start one element late (see dma_vals)
     static_assert(NT % kWave == 0 && NT % CL == 0 && RB % 16 == 0 && (CPL == 1 || CPL == 2) && CL % CPL == 0, "geometry");
-    static_assert(std::is_same<V, float>::value || MODE != kLatSpmmT, "the transposed walk stages 4-byte values");
 
     extern __shared__ uint4 lat_smem[];
     char* const sm = reinterpret_cast<char*>(lat_smem);
@@ -207,12 +207,12 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
     // value pieces: SpMM: piece e is chunk e % VL of tile row e / VL;  SpMMT: of halo row e / VL.
     // vrow = row of the piece inside its plane (-1: none); vuo = its byte offset from the plane's first value when every row
     // has uniform_len entries (then no row start is ever loaded)
-    int vrow[kLatNVD];
-    uint32_t vch16[kLatNVD], vuo[kLatNVD];
+    int vrow[kNVD];
+    uint32_t vch16[kNVD], vuo[kNVD];
     const int val_pieces = MODE == kLatSpmm ? NR * VL : (MODE == kLatSpmmT ? HR * VL : 0);
     if constexpr (MODE != kLatSddmm) {
 #pragma unroll
-        for (int d = 0; d < kLatNVD; ++d) {
+        for (int d = 0; d < kNVD; ++d) {
             const int e = d * NT + tid;
             const int r = e / VL;
             vch16[d] = (uint32_t)(e - r * VL) * 16u;
@@ -272,20 +272,19 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
     };
     // values of the plane with first row `prow` into value buffer `buf` (SpMM: of R - 2; SpMMT: ring slot); `st` = row
     // starts (elements) of the pieces when the rows are not all of one length
-    auto dma_vals = [&](int prow, int buf, const int (&st)[kLatNVD]) {
+    auto dma_vals = [&](int prow, int buf, const int (&st)[kNVD]) {
         if constexpr (MODE != kLatSddmm) {
             const unsigned region = MODE == kLatSpmm ? (unsigned)(P.o_vals + buf * NR * P.slot) : (unsigned)(P.o_vals + buf * HR * P.slot);
             const unsigned base = sbase + region + (unsigned)(wave * kWave * 16);
             const uint32_t plane0 = uniform ? (uint32_t)prow * (uint32_t)(P.uniform_len * kVB) : 0u;   // bytes before the plane's values
             const char* const pbase = valb + plane0;
 #pragma unroll
-            for (int d = 0; d < kLatNVD; ++d) {
+            for (int d = 0; d < kNVD; ++d) {
                 if (d * NT < val_pieces) {
                     if (vrow[d] >= 0) {
-                        uint32_t off = uniform ? vuo[d] : (uint32_t)st[d] * kVB + vch16[d];
-                        // 2-byte values: rows of odd length start on 2-byte boundaries, which the 16-byte DMA handles badly;
-                        // the copy starts on the 4-byte boundary below and the reader shifts by one element (kValShift)
-                        if constexpr (kVB == 2) off -= (plane0 + off) & 2u;
+                        // (2-byte values: rows of odd length start on 2-byte boundaries; the 16-byte LDS-DMA takes such sources at
+                        // full speed — measured faster than staging from the 4-byte boundary below and shifting in the reader)
+                        const uint32_t off = uniform ? vuo[d] : (uint32_t)st[d] * kVB + vch16[d];
                         if (__builtin_expect(plane0 + off + 16u <= val_bytes, 1)) {
                             lat_dma16<true>(pbase, off, base + (unsigned)(d * NT * 16));
                         } else {
@@ -303,12 +302,12 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
             }
         }
     };
-    auto load_vst = [&](int prow, int (&st)[kLatNVD]) {   // only for rows of different lengths
+    auto load_vst = [&](int prow, int (&st)[kNVD]) {   // only for rows of different lengths
         if constexpr (MODE != kLatSddmm) {
             if (!uniform) {
                 const int* const rs = P.rstart + prow;
 #pragma unroll
-                for (int d = 0; d < kLatNVD; ++d) {
+                for (int d = 0; d < kNVD; ++d) {
                     st[d] = 0;
                     if (d * NT < val_pieces) {
                         if (vrow[d] >= 0) st[d] = rs[(uint32_t)vrow[d]];
@@ -320,8 +319,8 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
     // what a compute row needs from memory besides the rings: class byte; for the SDDMM its value start and its own dense row
     struct RowRegs {
         int cls[kLatNP];
-        int rst[(MODE == kLatSddmm || kValShift) ? kLatNP : 1];
-        float own[MODE == kLatSddmm ? kLatNP : 1][CPL][VEC];
+        int rst[MODE == kLatSddmm ? kLatNP : 1];
+        uint4 own[MODE == kLatSddmm ? kLatNP : 1][CPL];    // the row operand's 16-byte pieces, as loaded
     };
     auto load_rows = [&](int prow, RowRegs& rr) {
         const unsigned char* const cbase = P.rcls + prow;                                              // wave-uniform bases,
@@ -332,10 +331,10 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
             if (q * RPP < NR) {
                 if (crow[q] >= 0) {
                     rr.cls[q] = cbase[(uint32_t)crow[q]];
-                    if constexpr (MODE == kLatSddmm || kValShift) rr.rst[q] = uniform ? (prow + crow[q]) * P.uniform_len : P.rstart[prow + crow[q]];
+                    if constexpr (MODE == kLatSddmm) rr.rst[q] = uniform ? (prow + crow[q]) * P.uniform_len : P.rstart[prow + crow[q]];
                     if constexpr (MODE == kLatSddmm) {
 #pragma unroll
-                        for (int cp = 0; cp < CPL; ++cp) load_vec<V, VEC>(reinterpret_cast<const V*>(obase + cown[q][cp]), rr.own[q][cp]);
+                        for (int cp = 0; cp < CPL; ++cp) rr.own[q][cp] = *reinterpret_cast<const uint4*>(obase + cown[q][cp]);
                     }
                 }
             }
@@ -345,30 +344,31 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
 #pragma unroll
         for (int q = 0; q < kLatNP; ++q) {
             lat_pin(rr.cls[q]);
-            if constexpr (kValShift) lat_pin(rr.rst[q]);
             if constexpr (MODE == kLatSddmm) {
                 lat_pin(rr.rst[q]);
 #pragma unroll
                 for (int cp = 0; cp < CPL; ++cp) {
-#pragma unroll
-                    for (int v = 0; v < VEC; ++v) lat_pin(rr.own[q][cp][v]);
+                    lat_pin(rr.own[q][cp].x);
+                    lat_pin(rr.own[q][cp].y);
+                    lat_pin(rr.own[q][cp].z);
+                    lat_pin(rr.own[q][cp].w);
                 }
             }
         }
     };
-    auto pin_vst = [&](int (&st)[kLatNVD]) {
+    auto pin_vst = [&](int (&st)[kNVD]) {
         if constexpr (MODE != kLatSddmm) {
             if (!uniform) {
 #pragma unroll
-                for (int d = 0; d < kLatNVD; ++d) lat_pin(st[d]);
+                for (int d = 0; d < kNVD; ++d) lat_pin(st[d]);
             }
         }
     };
 
     // ---- prologue: ring planes 0 .. K+1, values of planes 1 .. K (SpMM) / 0 .. K+1 (SpMMT) --------------------------
-    int vst[kLatNVD];      // row starts for the NEXT value DMA, loaded one step ahead (rows of different lengths only)
+    int vst[kNVD];      // row starts for the NEXT value DMA, loaded one step ahead (rows of different lengths only)
 #pragma unroll
-    for (int d = 0; d < kLatNVD; ++d) vst[d] = 0;
+    for (int d = 0; d < kNVD; ++d) vst[d] = 0;
     RowRegs nxt;           // rows of the NEXT output plane, loaded one step ahead
     int x_run = lat_mod(xs - 1, P.nx);      // lattice plane of ring index 0
     for (int xr = 0; xr <= K + 1; ++xr) {
@@ -428,8 +428,23 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
                                     const f4u o = {w.x, w.y, w.z, w.w};
                                     __builtin_nontemporal_store(o, reinterpret_cast<f4u*>(go + k0));
                                 } else {
-#pragma unroll
-                                    for (int j = 0; j < 4; ++j) go[k0 + j] = T::down(wv[j]);
+                                    // four bf16 gradients: packed conversions, 4-byte aligned pair stores (a row of odd length
+                                    // starts on a 2-byte boundary: then the pairs straddle the piece and its ends go out alone;
+                                    // 8-byte stores on 2-byte boundaries were measured 40 % slower than this)
+                                    uint32_t p01, p23, p12;
+                                    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(p01) : "v"(wv[0]), "v"(wv[1]));
+                                    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(p23) : "v"(wv[2]), "v"(wv[3]));
+                                    unsigned short* const g16 = reinterpret_cast<unsigned short*>(go + k0);
+                                    if (((prst[q] + k0) & 1) == 0) {
+                                        uint32_t* const g32 = reinterpret_cast<uint32_t*>(g16);
+                                        __builtin_nontemporal_store(p01, g32);
+                                        __builtin_nontemporal_store(p23, g32 + 1);
+                                    } else {
+                                        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(p12) : "v"(wv[1]), "v"(wv[2]));
+                                        g16[0] = (unsigned short)p01;
+                                        __builtin_nontemporal_store(p12, reinterpret_cast<uint32_t*>(g16 + 1));
+                                        g16[3] = (unsigned short)(p23 >> 16);
+                                    }
                                 }
                             } else {
 #pragma unroll
@@ -523,10 +538,9 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
                     const int recw = NCH > 0 ? 4 * NCH : P.recw;
                     if constexpr (MODE == kLatSpmm) {
                         char* const vs = sm + P.o_vals + vbi * vbuf + csl[q];
-                        const int vsh = kValShift ? (cur.rst[q] & 1) : 0;     // elements the staged row starts late
                         if (len < recw) {   // padded slots hold whatever follows the row in the value array: zero them
 #pragma nounroll
-                            for (int t = len + c; t < recw; t += LPR) __builtin_memset(vs + (t + vsh) * kVB, 0, kVB);
+                            for (int t = len + c; t < recw; t += LPR) __builtin_memset(vs + t * kVB, 0, kVB);
                         }
 #pragma unroll
                         for (int cp = 0; cp < CPL; ++cp) {
@@ -539,10 +553,8 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
                                 a[0] = __uint_as_float(w.x), a[1] = __uint_as_float(w.y), a[2] = __uint_as_float(w.z), a[3] = __uint_as_float(w.w);
                             } else {
                                 const uint2 w = *reinterpret_cast<const uint2*>(vs + k0 * 2);
-                                const uint32_t w2 = *reinterpret_cast<const uint32_t*>(vs + k0 * 2 + 8);
-                                const uint32_t x0 = __builtin_amdgcn_alignbit(w.y, w.x, 16 * vsh), x1 = __builtin_amdgcn_alignbit(w2, w.y, 16 * vsh);
-                                a[0] = __uint_as_float(x0 << 16), a[1] = __uint_as_float(x0 & 0xffff0000u);
-                                a[2] = __uint_as_float(x1 << 16), a[3] = __uint_as_float(x1 & 0xffff0000u);
+                                a[0] = __uint_as_float(w.x << 16), a[1] = __uint_as_float(w.x & 0xffff0000u);
+                                a[2] = __uint_as_float(w.y << 16), a[3] = __uint_as_float(w.y & 0xffff0000u);
                             }
                         };
                         if constexpr (NCH > 0) {
@@ -598,15 +610,32 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
                             float dsum[4];
 #pragma unroll
                             for (int j = 0; j < 4; ++j) {
-                                float f[VEC];
-                                widen(bb[j][0], f);
-                                float d = cur.own[q][0][0] * f[0];
+                                float d;
+                                if constexpr (kVB == 2) {
+                                    // packed bf16 pairs straight into the dot instruction (fp32 accumulation, no widening)
+                                    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+                                    d = 0.f;
 #pragma unroll
-                                for (int v = 1; v < VEC; ++v) d = fmaf(cur.own[q][0][v], f[v], d);
-                                if constexpr (CPL == 2) {
-                                    widen(bb[j][1], f);
+                                    for (int cp = 0; cp < CPL; ++cp) {
+                                        const uint32_t ow[4] = {cur.own[q][cp].x, cur.own[q][cp].y, cur.own[q][cp].z, cur.own[q][cp].w};
+                                        const uint32_t bw[4] = {bb[j][cp].x, bb[j][cp].y, bb[j][cp].z, bb[j][cp].w};
 #pragma unroll
-                                    for (int v = 0; v < VEC; ++v) d = fmaf(cur.own[q][1][v], f[v], d);
+                                        for (int i = 0; i < 4; ++i)
+                                            d = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, ow[i]), __builtin_bit_cast(bf2, bw[i]), d, false);
+                                    }
+                                } else {
+                                    float f[VEC], o[VEC];
+                                    widen(bb[j][0], f);
+                                    widen(cur.own[q][0], o);
+                                    d = o[0] * f[0];
+#pragma unroll
+                                    for (int v = 1; v < VEC; ++v) d = fmaf(o[v], f[v], d);
+                                    if constexpr (CPL == 2) {
+                                        widen(bb[j][1], f);
+                                        widen(cur.own[q][1], o);
+#pragma unroll
+                                        for (int v = 0; v < VEC; ++v) d = fmaf(o[v], f[v], d);
+                                    }
                                 }
                                 dsum[j] = group_sum<float, LPR>(d);
                             }
@@ -655,6 +684,10 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
                         // transposed walk: value of entry k of halo row i sits at slot k of i's staged value row
                         // (padded entries point both reads beyond the LDS allocation: 0 · 0)
                         const char* const vcb = sm + P.o_vals + csl[q];
+                        auto load_val = [](const char* at) -> float {
+                            if constexpr (kVB == 4) return *reinterpret_cast<const float*>(at);
+                            else return __uint_as_float((uint32_t)*reinterpret_cast<const unsigned short*>(at) << 16);
+                        };
 #pragma unroll
                         for (int cp = 0; cp < CPL; ++cp) {
 #pragma unroll
@@ -685,7 +718,7 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
 #pragma unroll
                                 for (int j = 0; j < 4; ++j) {
                                     load_b(go[j], b[i & 1][j]);
-                                    a[i & 1][j] = *reinterpret_cast<const float*>(vcb + vo[j]);
+                                    a[i & 1][j] = load_val(vcb + vo[j]);
                                 }
                             };
                             stage_a(0);
@@ -721,7 +754,7 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
 #pragma unroll
                                 for (int j = 0; j < 4; ++j) {
                                     load_b(go[j], b[j]);
-                                    a[j] = *reinterpret_cast<const float*>(vcb + vo[j]);
+                                    a[j] = load_val(vcb + vo[j]);
                                 }
 #pragma unroll
                                 for (int j = 0; j < 4; ++j) axpy(a[j], b[j]);
@@ -756,9 +789,7 @@ inline int lat_layout(LatParams& P, int mode, int cl, int vbytes, int nt) {
         return TSGU_ERR_BAD_ARG;
     const int HR = (P.ty + 2 * P.ry) * (P.tz + 2 * P.rz), NR = P.ty * P.tz, RB = cl * 16;
     const bool packed = false && mode == kLatSpmmT && RB % 128 == 0;   // see kPacked in lattice_kernel
-    // (2-byte values of the SpMM: one element of slack for rows staged from the 4-byte boundary below their start, and the
-    // reader's look-ahead word)
-    P.slot = packed ? RB : lat_round16(P.recw * (mode == kLatSddmm ? 4 : vbytes) + (mode == kLatSpmm && vbytes == 2 ? 6 : 0));
+    P.slot = packed ? RB : lat_round16(P.recw * (mode == kLatSddmm ? 4 : vbytes));
     // a pitch of a multiple of 64 bytes would put the value rows of a wave on four banks (bf16, 28 entries: 64 -> 80 bytes)
     if (!packed && P.slot % 64 == 0) P.slot += 16;
     if (packed && P.recw * vbytes > RB) return TSGU_ERR_TOO_LARGE;
@@ -766,8 +797,8 @@ inline int lat_layout(LatParams& P, int mode, int cl, int vbytes, int nt) {
     if (P.cpl != 1 && P.cpl != 2) return TSGU_ERR_BAD_ARG;
     if (cl % P.cpl || (P.cpl == 2 && cl < 4)) return TSGU_ERR_BAD_ARG;
     if ((int64_t)HR * cl > (int64_t)kLatND * nt || NR > kLatNP * (nt / (cl / P.cpl))) return TSGU_ERR_TOO_LARGE;
-    if (mode == kLatSpmm && (int64_t)NR * VL > (int64_t)kLatNVD * nt) return TSGU_ERR_TOO_LARGE;
-    if (mode == kLatSpmmT && (int64_t)HR * VL > (int64_t)kLatNVD * nt) return TSGU_ERR_TOO_LARGE;
+    if (mode == kLatSpmm && (int64_t)NR * VL > (int64_t)lat_nvd(mode, vbytes) * nt) return TSGU_ERR_TOO_LARGE;
+    if (mode == kLatSpmmT && (int64_t)HR * VL > (int64_t)lat_nvd(mode, vbytes) * nt) return TSGU_ERR_TOO_LARGE;
     int64_t o = R * HR * RB;
     P.o_vals = (int)o;
     if (mode == kLatSpmm) o += (R - 2) * NR * P.slot;
@@ -812,9 +843,9 @@ int lat_launch_one(const LatParams& P, hipStream_t stream) {
         }
         return TSGU_ERR_BAD_ARG;
     }
-    // (the unrolled, three-stage SpMM of 2-byte values needs more than the 128 registers of four waves per SIMD: it takes
+    // (the unrolled, three-stage products of 2-byte values need more than the 128 registers of four waves per SIMD: they take
     // the run-time loop)
-    if (P.recw == 28 && !(MODE == kLatSpmm && sizeof(V) == 2)) return lat_launch_nch<V, CL, 1, MODE, NT, 7>(P, stream);
+    if (P.recw == 28 && !(MODE != kLatSddmm && sizeof(V) == 2)) return lat_launch_nch<V, CL, 1, MODE, NT, 7>(P, stream);
     if (P.recw == 8) return lat_launch_nch<V, CL, 1, MODE, NT, 2>(P, stream);
     return lat_launch_nch<V, CL, 1, MODE, NT, 0>(P, stream);
 }
