@@ -395,6 +395,8 @@ def main():
     dst = torch.empty_like(src)
     copy_ms = time_events(lambda: dst.copy_(src), 20, dev)
     copy_gbs = 2 * src.numel() * 4 / (copy_ms * 1e-3) / 1e9
+    copy16_ms = time_events(lambda: be.device_copy(src, dst), 20, dev)      # the library's own 16-bytes-per-lane streaming kernel
+    copy16_gbs = 2 * src.numel() * 4 / (copy16_ms * 1e-3) / 1e9
     del src, dst
 
     # ---- RCCL all-gather of the forward result (outside the timed region) ----
@@ -477,6 +479,7 @@ def main():
             "kernels_ms_alone": None if kern_alone is None else {k: round(v, 5) for k, v in kern_alone.items()},
             "kernels_GBps": {k: round(kbytes[k] / (v * 1e-3) / 1e9, 1) for k, v in {**kern, **kern_alt}.items()},
             "device_copy_GBps": round(copy_gbs, 1),
+            "device_copy16_GBps": round(copy16_gbs, 1),
             "cpu_baseline": cpu,
             "c5": c5,
         }

@@ -396,3 +396,17 @@ def test_full_size_c2_on_the_lattice_kernels(monkeypatch):
     C = sparse_mm(A, B)
     C.backward(Gd)
     assert torch.equal(C.detach(), first[0]) and torch.equal(A.grad.values(), first[1]) and torch.equal(B.grad, first[2])
+
+
+def test_bounded_fuzz_run_of_the_public_ops():
+    """tools/fuzz_gpu.py (random shapes, densities, dtypes, layouts, index dtypes, flags against dense fp64 autograd) with a
+    fixed seed and a bounded number of cases, run as a child process so that its module-level switches do not leak."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_gpu.py"), "--cases", "60", "--seed", "3"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "60 cases, 0 violations" in r.stdout

@@ -221,44 +221,6 @@ def _close(mine, ref, dt):
 
 
 @pytest.mark.parametrize("form", ["stream", "dictionary"])
-@pytest.mark.parametrize("dt,p", [(torch.float32, 32), (torch.float32, 64), (torch.bfloat16, 64), (torch.bfloat16, 128)])
-def test_rowpack_quad_plans_are_bit_identical_to_pairs(dt, p, form, monkeypatch):
-    """Row QUADS (rows_per_group = 4: a lane group walks the union of four consecutive rows; stored-order walks with
-    ownership bits only): SpMM and SDDMM through quad plans equal the pair plans and the plan-free kernels bit for bit
-    (one lane group per row in all three: same order of summation), on a ragged pattern and on a lattice stencil."""
-    from torchsparsegradutils_amd import _backend as be, _pattern
-    from torchsparsegradutils_amd.utils import synthetic
-
-    monkeypatch.setattr(_pattern, "DEDUP_MODE", "force" if form == "dictionary" else "off")
-    rng = np.random.default_rng(99 + p)
-    n, m = 1031, 977
-    rows = rng.integers(0, n, 30000)
-    cols = np.clip(rows * m // n + rng.integers(-7, 8, 30000), 0, m - 1)
-    rows[rows % 11 == 0] += 1
-    Ac = torch.sparse_coo_tensor(np.stack([np.minimum(rows, n - 1), cols]), rng.standard_normal(30000), (n, m)).coalesce().to_sparse_csr()
-    cases = [(Ac.crow_indices().to(torch.int32).to(DEV), Ac.col_indices().to(torch.int32).to(DEV), n, m)]
-    crow, col = synthetic.stencil27_periodic(12, 10, 8, torch.int32, device=DEV)
-    cases.append((crow, col, 960, 960))
-    rpb, limits, ep = be.rowpack_geometry(dt, p)
-    assert ep == 1
-    for crow, col, nr, nc in cases:
-        g = _pattern.RowGather(crow, col, nr, nc)
-        vd = torch.randn(col.numel(), device=DEV).to(dt)
-        Bd = torch.randn(nc, p, device=DEV).to(dt)
-        Gd = torch.randn(nr, p, device=DEV).to(dt)
-        pair = g.rowpack_plan(rpb, limits)
-        quad = g.rowpack_plan(2 * rpb, limits, group=4)
-        assert pair is not None and quad is not None and quad.group == 4 and quad.upos is None and quad.sperm is None
-        assert (quad.nclasses > 0) == (form == "dictionary")
-        want = be.csr_spmm(g.crow, g.col, vd, Bd, nr, nc)
-        assert torch.equal(be.csr_spmm_rowpack(g.crow, vd, quad, Bd, nr), want)
-        assert torch.equal(be.csr_spmm_rowpack(g.crow, vd, pair, Bd, nr), want)
-        assert torch.equal(be.csr_sddmm_rowpack(g.crow, quad, Gd, Bd, nr), be.csr_sddmm_rowpack(g.crow, pair, Gd, Bd, nr))
-        ref = be.csr_sddmm(g.crow, g.col, Gd, Bd, nr, nc)
-        assert _close(be.csr_sddmm_rowpack(g.crow, quad, Gd, Bd, nr, alpha=1.0), ref.float().cpu().numpy(), dt)
-
-
-@pytest.mark.parametrize("form", ["stream", "dictionary"])
 @pytest.mark.parametrize("dt,p", [(torch.float32, 8), (torch.float32, 16), (torch.float32, 32), (torch.float32, 64),
                                   (torch.bfloat16, 16), (torch.bfloat16, 32), (torch.bfloat16, 64), (torch.bfloat16, 128)])
 @pytest.mark.parametrize("itype", [torch.int32, torch.int64])

@@ -86,9 +86,6 @@ def main():
             plans["rp_t_nat_" + tag] = _pattern.build_rowpack_plan(pt, rpb, lim, dedup=dd)
             if po is not None:
                 plans["rp_t_brick_" + tag] = _pattern.build_rowpack_plan(pt, rpb, lim, pair_order=po, lattice=lat, dedup=dd)
-        if ep == 1:
-            for tag, dd in (("s", "off"), ("d", "force")):
-                plans["rp_fwd4_" + tag] = _pattern.build_rowpack_plan(plan, 2 * rpb, lim, dedup=dd, group=4)
         for shp in (a.brick or []):
             pox = _pattern.brick_pair_order(n, lat, rpb // 2, dev, shape=tuple(shp)) if lat is not None else None
             if pox is not None:

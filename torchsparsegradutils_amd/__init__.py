@@ -5,6 +5,7 @@ Drop-in names for ``sparse_mm`` / ``sparse_triangular_solve`` / ``sparse_generic
 kernels behind the C ABI in ``include/tsgu_hip.h``.  GPU only — there is no CPU fallback.
 """
 
+from ._backend import poll_errors
 from ._pattern import wait_for_plans
 from .sparse_lstsq import SparseGenericLstsq, sparse_generic_lstsq
 from .sparse_matmul import SparseMatMul, sparse_mm
@@ -22,6 +23,7 @@ __all__ = [
     "sparse_generic_lstsq",
     "SparseGenericLstsq",
     "wait_for_plans",
+    "poll_errors",
     "SparseMatMul",
     "SparseTriangularSolve",
     "SparseGenericSolve",

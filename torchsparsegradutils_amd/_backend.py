@@ -38,6 +38,7 @@ SIGNATURES = {
     "tsgu_abi_version": (_int, []),
     "tsgu_status_string": (ctypes.c_char_p, [_int]),
     "tsgu_device_info": (_int, [_int, ctypes.c_char_p, _int, ctypes.POINTER(_int), ctypes.POINTER(_int)]),
+    "tsgu_device_copy": (_int, [_ptr, _ptr, _i64, _int, _ptr]),
     "tsgu_csr_spmm": (
         _int,
         [_int, _int, _i64, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _ptr, _i64, _i64, _i64, _i64, _i64, _i64,
@@ -596,7 +597,10 @@ def csr_sptrsm(ptr, idx, val, B, n: int, lower: bool, unit: bool, perm=None):
 
 _PENDING = []            # (event, pinned int32 slot, what)
 _PENDING_LOCK = threading.Lock()
-_SYNC_CHECK = os.environ.get("TSGU_SPTRSM_CHECK", "lazy") == "sync"
+# Default: the error word of a solve is read back before X is handed out (one host sync per solve; a C3-sized solve takes
+# milliseconds).  TSGU_SPTRSM_CHECK=lazy defers the check (X is then UNVERIFIED until `poll_errors()` — exported by the
+# package — has looked at it: the next solve, wait_for_plans() and interpreter exit call it).
+_SYNC_CHECK = os.environ.get("TSGU_SPTRSM_CHECK", "sync") != "lazy"
 
 
 def _defer_error_check(word: torch.Tensor, dev: torch.device, what: str = "tsgu_csr_sptrsm (dependency wait)") -> None:
@@ -611,6 +615,21 @@ def _defer_error_check(word: torch.Tensor, dev: torch.device, what: str = "tsgu_
     ev.record(torch.cuda.current_stream(dev))
     with _PENDING_LOCK:
         _PENDING.append((ev, host, what))
+
+
+def _poll_at_exit() -> None:
+    try:
+        poll_errors(block=True)
+    except Exception as exc:  # noqa: BLE001
+        import sys
+
+        print(f"torchsparsegradutils_amd: {exc}", file=sys.stderr)
+
+
+if not _SYNC_CHECK:
+    import atexit
+
+    atexit.register(_poll_at_exit)
 
 
 def poll_errors(block: bool = False) -> None:
@@ -655,6 +674,17 @@ def coldot(X, Y):
             "tsgu_coldot",
         )
     return out
+
+
+def device_copy(src: torch.Tensor, dst: torch.Tensor) -> None:
+    """dst <- src by the library's own 16-bytes-per-lane streaming kernel (the measured HBM ceiling of bench.py)."""
+    lib = load_library()
+    dev = require_device(src, dst)
+    nbytes = src.numel() * src.element_size()
+    if dst.numel() * dst.element_size() != nbytes or not (src.is_contiguous() and dst.is_contiguous()):
+        raise RuntimeError("device_copy: contiguous tensors of equal byte size expected")
+    with torch.cuda.device(dev):
+        check(lib.tsgu_device_copy(_p(src), _p(dst), nbytes, dev.index, _stream(dev)), "tsgu_device_copy")
 
 
 def device_info(index: int = 0):

@@ -86,7 +86,8 @@ def _pack_for(plan: RowGather, dense: torch.Tensor, *others: torch.Tensor, need_
         return None  # SDDMM walks ownership-bit records (one entry lane per pair)
     if not plan.seen_enough(PLAN_AFTER_USES):
         return None
-    if PLAN_ASYNC and PLAN_AFTER_USES > 0:
+    # (deterministic mode: the step at which the kernels switch must not depend on a worker thread's timing)
+    if PLAN_ASYNC and PLAN_AFTER_USES > 0 and not torch.are_deterministic_algorithms_enabled():
         return plan.rowpack_plan_async(rpb, limits, explicit_slots=entry_lanes > 1)
     return plan.rowpack_plan(rpb, limits, explicit_slots=entry_lanes > 1)
 

@@ -47,6 +47,9 @@ def wait_for_plans() -> None:
             f.result()
         except Exception:  # noqa: BLE001  (reported by the operator that picks the result up)
             pass
+    from . import _backend
+
+    _backend.poll_errors(block=True)     # deferred device-side error words (lazy triangular-solve checks), if any
 
 
 class _Core:
@@ -140,6 +143,11 @@ class RowGather:
         dev = self.crow.device
         fut = core.pending.get(key)
         if fut is None:
+            if torch.cuda.is_current_stream_capturing():
+                return None      # no cross-stream event inside a graph capture: the plan is asked for again after it
+            # everything the builder reads lazily from the shared core is produced HERE, on the caller's stream, before the
+            # event: the worker's side stream then only reads it (no unsynchronised write of core.rows from two streams)
+            self.row_indices()
             ready = torch.cuda.Event()
             ready.record(torch.cuda.current_stream(dev))   # the index tensors are complete from here on
             view = RowGather(self.crow, self.col, self.n_rows, self.n_cols, perm=self.perm, core=core)
@@ -171,6 +179,8 @@ class RowGather:
                 if not core.pending:
                     _PENDING_CORES.discard(core)
             return None
+        if torch.cuda.is_current_stream_capturing():
+            return None          # picked up by the first call outside the capture
         main = torch.cuda.current_stream(dev)
         main.wait_event(done)
         if plan is not None:
@@ -363,8 +373,8 @@ def build_rowpack_plan(g: RowGather, rpb: int, limits, pair_order=None, lattice=
     n, m, nnz = g.n_rows, g.n_cols, g.nnz
     dev = g.crow.device
     slots = explicit_slots or g.perm is not None
-    if group not in (2, 4) or (group == 4 and (slots or pair_order is not None)):
-        return None
+    if group != 2:
+        return None      # (row quads, group = 4, are no longer compiled: csrc/rowpack_impl.h)
     gpb = rpb // group
     npairs = (n + group - 1) // group             # row groups (pairs / quads)
     natural = pair_order is None

@@ -48,6 +48,28 @@ int tsgu_device_info(int device, char* name, int cap, int* n_cu, int* wave_size)
     return TSGU_OK;
 }
 
+// Streaming copy, 16 bytes per lane, grid-stride: the measured HBM ceiling a kernel of this library can be compared with
+// (bench.py reports it next to torch's copy_; MI355X_MICROARCH.md quotes 6.29 TB/s for a float4 copy kernel).
+__global__ __launch_bounds__(256) void tsgu_copy16_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, int64_t n16) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) {
+        const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(src + i));
+        __builtin_nontemporal_store(v, reinterpret_cast<u32x4_t*>(dst + i));
+    }
+}
+
+int tsgu_device_copy(const void* src, void* dst, int64_t bytes, int device, void* stream) {
+    if (!src || !dst || bytes < 0 || bytes % 16 || !aligned16(src) || !aligned16(dst)) return TSGU_ERR_BAD_ARG;
+    if (bytes == 0) return TSGU_OK;
+    if (const int rc = set_device(device)) return rc;
+    const int64_t n16 = bytes / 16;
+    const int64_t want = (n16 + 255) / 256;
+    const unsigned blocks = (unsigned)(want < 256 * 32 ? want : 256 * 32);   // 32 workgroups per CU, grid-stride beyond that
+    hipLaunchKernelGGL(tsgu_copy16_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const uint4*>(src),
+                       static_cast<uint4*>(dst), n16);
+    return check_launch();
+}
+
 int64_t tsgu_spmm_num_blocks(int vtype, int64_t n_rows, int64_t nnz_per_item, int64_t p, int64_t max_row_nnz) {
     // mirrors spmm_geom(): the fused-dot path is only used with contiguous, 16-byte
     // aligned operands, so "wide" depends on p alone.

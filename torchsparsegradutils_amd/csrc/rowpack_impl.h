@@ -78,13 +78,24 @@ constexpr int kRpAbsent = 0x8000;
 #ifndef TSGU_RP_U
 #define TSGU_RP_U 4
 #endif
-// Phase probes (tools/build_variant_one.sh + tools/ab_kbench.sh; every one of them gives WRONG RESULTS and exists only
+// Phase probes — compiled only with -DTSGU_RP_PROBES (never in the product build: without that guard every probe macro is
+// dropped right here).
+// (tools/build_variant_one.sh + tools/ab_kbench.sh; every one of them gives WRONG RESULTS and exists only
 // to time what is left when a part of the kernel is taken away — DESIGN.md §3 lists what they showed):
 //   TSGU_RP_NOGATHER  no dense-row loads            TSGU_RP_NOSTORE  no result rows written
 //   TSGU_RP_NOWALK    staging + epilogue only       TSGU_RP_NODOT    backward without its SDDMM half
 //   TSGU_RP_NOGRADA   backward without the gradA write
 //   TSGU_RP_FAKEVAL   value slice read from an L2-resident 16 KB
 //   TSGU_RP_FAKEPERM  consecutive value positions (coalesced value reads and gradA writes)
+#ifndef TSGU_RP_PROBES
+#undef TSGU_RP_NOGATHER
+#undef TSGU_RP_NOSTORE
+#undef TSGU_RP_NOWALK
+#undef TSGU_RP_NODOT
+#undef TSGU_RP_NOGRADA
+#undef TSGU_RP_FAKEVAL
+#undef TSGU_RP_FAKEPERM
+#endif
 
 // PERM : the values are addressed through the (workgroup-sorted) permutation `sperm`
 // SLOTS: union records carry explicit value slots (`upos`); otherwise ownership bits + running counters
@@ -510,11 +521,8 @@ int rp_launch(RpParams P, hipStream_t stream) {
                 }
             }
         } else if (rg == 4) {
-            switch (cl) {
-                case 8: TSGU_RP_GO(8, 1, false, 4); break;
-                case 16: TSGU_RP_GO(16, 1, false, 4); break;
-                default: return TSGU_ERR_BAD_ARG;
-            }
+            // row quads were parity-green but never faster than pairs where it mattered: not compiled any more
+            return TSGU_ERR_BAD_ARG;
         } else {
             switch (cl) {
                 case 8: TSGU_RP_GO(8, 1, false, 2); break;
