@@ -13,7 +13,7 @@ import subprocess
 import sys
 from collections import defaultdict
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(root, "profiles")
@@ -26,7 +26,7 @@ for name, pat in (("bench_kernel_stats.csv", "stats/**/*kernel_stats.csv"), ("be
         if name.endswith("trace.csv"):  # keep the tsgu kernels only (the trace of torch's setup kernels is noise)
             rows = list(csv.reader(open(hits[0])))
             keep = [rows[0]] + [r for r in rows[1:] if any("tsgu::" in c for c in r)]
-            csv.writer(open(out, "w", newline="")).writerows(keep[:400])
+            csv.writer(open(out, "w", newline="")).writerows(keep[:60] + keep[-340:])
         else:
             shutil.copy(hits[0], out)
         print("wrote", out)
@@ -45,6 +45,9 @@ for kind in ("fetch", "write"):
 
 def role(kname):
     """forward / fused_backward / ... from the template arguments <V, I, CL, EP, MODE, PERM, SLOTS, SMALL>."""
+    if "lattice_kernel" in kname:   # <V, CL, CPL, MODE, NT, NCH>
+        args = kname.split("<", 1)[1].split(">")[0].replace(" ", "").split(",")
+        return {"0": "lattice_spmm", "1": "lattice_sddmm", "2": "lattice_spmm_t"}.get(args[3])
     if "csr_rowpack_kernel" in kname:
         args = kname.split("<", 1)[1].split(">")[0].replace(" ", "").split(",")
         mode, perm = args[4], args[5]
@@ -73,7 +76,8 @@ if traffic:
         bench = json.load(open(os.path.join(src, "bench.json")))
     except Exception:  # noqa: BLE001
         pass
-    form = "class dictionary" if "class dictionary" in json.dumps(bench.get("kernels_ms", {})) else "per-workgroup streams"
+    form = ("lattice plane sweep" if "lattice_kernel" in json.dumps(bench.get("kernels_ms", {})) else
+            "class dictionary" if "class dictionary" in json.dumps(bench.get("kernels_ms", {})) else "per-workgroup streams")
     out = {
         "_comment": "HBM bytes per launch at C2 (N=1e6, 27 nnz/row, 32 RHS, fp32/int32) from two rocprofv3 PMC passes around bench.py "
                     "(FETCH_SIZE and WRITE_SIZE in separate runs): (2*FETCH_SIZE + WRITE_SIZE)*1024 — FETCH_SIZE doubled as "
@@ -84,7 +88,8 @@ if traffic:
         "plan_form": form,
         **traffic,
         "_raw": raw,
-        "_algorithmic": {"forward": 476000004, "fused_backward": 712000004, "sddmm_alone": 476000004, "transposed_spmm_alone": 476000004},
+        "_algorithmic": {"lattice_spmm": 476000004, "lattice_sddmm": 476000004, "lattice_spmm_t": 476000004, "forward": 476000004,
+                         "fused_backward": 712000004, "sddmm_alone": 476000004, "transposed_spmm_alone": 476000004},
     }
     json.dump(out, open(os.path.join(dst, "hbm_traffic.json"), "w"), indent=1)
     print(json.dumps({k: v for k, v in out.items() if not k.startswith("_")}, indent=1))

@@ -5,7 +5,7 @@
 #   3. the un-profiled bench line and the secondary configurations               -> gpurun_out/prof_<tag>/*.json(l)
 # Copy the summaries into profiles/ with tools/collect_profiles.py afterwards.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
