@@ -332,11 +332,15 @@ def main():
 
     if lattice:
         def cfgs(c):
-            return f"tile {c.ty}x{c.tz}, {c.nseg} x-segments, {c.threads} threads, ring {c.ring}, {c.lds_bytes} B LDS"
+            fam = "plane march" if getattr(c, "march", False) else "plane sweep"
+            return f"{fam}: tile {c.ty}x{c.tz}, {c.nseg} x-segments, {c.threads} threads, ring {c.ring}, {c.lds_bytes} B LDS"
 
-        fwd_name = f"lattice_kernel SpMM (K1 fwd, plane sweep: {cfgs(lat_f[1])})"
-        sdd_name = f"lattice_kernel SDDMM (K3 gradA, plane sweep: {cfgs(lat_s[1])})"
-        bwd_name = f"lattice_kernel SpMM-T (K2 gradB, plane sweep: {cfgs(lat_t[1])})"
+        def kname(c):
+            return "march_kernel" if getattr(c, "march", False) else "lattice_kernel"
+
+        fwd_name = f"{kname(lat_f[1])} SpMM (K1 fwd, {cfgs(lat_f[1])})"
+        sdd_name = f"{kname(lat_s[1])} SDDMM (K3 gradA, {cfgs(lat_s[1])})"
+        bwd_name = f"{kname(lat_t[1])} SpMM-T (K2 gradB, {cfgs(lat_t[1])})"
         kern = {
             fwd_name: time_events(lambda: _ops.spmm(plan, vd, Bd), reps, dev),
             sdd_name: time_events(lambda: _ops.sddmm(plan, G, Bd), reps, dev),

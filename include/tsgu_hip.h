@@ -285,6 +285,44 @@ int tsgu_csr_sddmm_lattice(int vtype, const tsgu_lattice_plan* plan, int64_t n_r
                            const void* Cm, int64_t ldc, void* out_vals, double alpha, int64_t p, int device, void* stream);
 
 /*
+ * Plane-march kernels (csrc/march_impl.h): the plane sweep for FULL periodic box stencils — every row stores all 3·ntap
+ * displacements (dx, dy, dz), |dx|, |dy|, |dz| <= 1 (periodic 27-point stencils: ntap = 9), in some order.  Same call sites as
+ * the lattice kernels above.  The sums are taken source plane by source plane: the dense rows of a halo plane are read from LDS
+ * once per in-plane displacement and serve the three output planes x-1, x, x+1 (accumulators in registers), so a row costs
+ * ntap LDS row reads instead of 3·ntap, there are no record tables, and two halo planes are resident instead of four.
+ *   ident        the class whose rows store their entries in ascending (dx, dy, dz) — the CANONICAL order (interior rows)
+ *   tap_dy/dz    the in-plane displacements in that order
+ *   kidx         [ncls][32] uint8: stored position of canonical slot (dx+1)·ntap + tap in a row of the class (a permutation)
+ *   rcls         [rows (+ padding)] uint8 class of each row (the lattice plan's)
+ * Values are staged in canonical order (16-byte LDS-DMA for waves of `ident` rows, 4-byte LDS-DMA gathers through kidx for the
+ * others); gradA is written in A's stored order.  Sums run in canonical order: bit-identical to the plan-free kernels for
+ * `ident` rows, equal to rounding for rows that wrap around a lattice face.  The transposed product needs no transposed
+ * pattern and no second plan: entry (i -> j) is read from canonical slot (dx+1)·ntap + tap(dy, dz) of source row i's staged values.
+ * fp32 only; p in {32, 64}.
+ */
+typedef struct tsgu_march_plan {
+    int32_t nb, nx, ny, nz;   /* items, planes per item, lines per plane, points per line (each of nx, ny, nz >= 3) */
+    int32_t ry, rz;           /* halo radii: 1, 1 */
+    int32_t ntap;             /* in-plane displacements: 9 */
+    int32_t tap_dy[9], tap_dz[9];
+    int32_t ncls, ident;      /* row classes (<= 64), the canonical one */
+    int32_t ty, tz;           /* tile */
+    int32_t nseg;             /* x segments per item */
+    int32_t threads;          /* workgroup size: 256 or 512 */
+    const void* kidx;
+    const void* rcls;
+} tsgu_march_plan;
+
+/* Dynamic LDS bytes of a configuration (mode: 0 SpMM, 1 SDDMM, 2 transposed SpMM) or a negative tsgu_status. */
+int tsgu_march_lds_bytes(int mode, int vtype, int64_t p, int ty, int tz, int ry, int rz, int ncls, int threads);
+/* C = A·B (transposed == 0) or gradB = Aᵀ·G (transposed != 0; `val` is A's value array in A's own order, `B` is G). */
+int tsgu_csr_spmm_march(int vtype, const tsgu_march_plan* plan, int transposed, int64_t n_rows, int64_t nnz, const void* val,
+                        const void* B, int64_t ldb, void* C, int64_t ldc, int64_t p, int device, void* stream);
+/* out_vals[k] = alpha·<R[row k,:], Cm[col k,:]> in A's stored order. */
+int tsgu_csr_sddmm_march(int vtype, const tsgu_march_plan* plan, int64_t n_rows, int64_t nnz, const void* R, int64_t ldr,
+                         const void* Cm, int64_t ldc, void* out_vals, double alpha, int64_t p, int device, void* stream);
+
+/*
  * Row analysis for lattice plans (plan building, once per sparsity pattern; no reference counterpart — the reference
  * re-derives structure per call, sparse_matmul.py:186-192,229).  One thread per row; nothing is sorted.
  *   tsgu_lattice_rows       displacement code ((dx+1)·5 + dy+2)·5 + dz+2 of every entry of every row (nd == 0), or — nd > 0 —

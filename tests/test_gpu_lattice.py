@@ -20,6 +20,15 @@ def _need_gpu():
     yield
 
 
+@pytest.fixture(autouse=True)
+def _general_sweep_only(monkeypatch):
+    """This file pins the general plane-sweep kernels; the plane-march kernels that full periodic stencils take on the product
+    path are covered by tests/test_gpu_march.py."""
+    from torchsparsegradutils_amd import _lattice
+
+    monkeypatch.setattr(_lattice, "ENABLE_MARCH", False)
+
+
 def _mods():
     from torchsparsegradutils_amd import _backend, _lattice, _pattern
 
@@ -342,60 +351,6 @@ def test_public_path_batched_bf16(monkeypatch):
     for i in range(b):
         Co, _, _ = _oracle_mm(crow, col, val[i].float(), B[i].float(), B[i].float())
         assert G.rel_err(C[i].float().cpu().numpy(), Co) < 3e-3
-
-
-def test_full_size_c2_on_the_lattice_kernels(monkeypatch):
-    """BASELINE config C2 at full size (N=1e6, 27/row, 32 RHS) on the product path (plane-sweep kernels): size-independent
-    checks — linearity of the product in B, the adjoint identity <A·B, G> = <B, Aᵀ·G> = Σ val·gradA — plus sampled rows,
-    sampled entries of gradA and sampled rows of gradB against the oracle on the same inputs, and run-to-run bit identity."""
-    from oracle import oracle
-    from torchsparsegradutils_amd import _ops, _pattern, sparse_mm
-    from torchsparsegradutils_amd.utils import synthetic
-
-    monkeypatch.setattr(_ops, "ENABLE_LATTICE", True)
-    dev = "cuda:0"
-    n, p = 10 ** 6, 32
-    crow, col = synthetic.stencil27_periodic(100, 100, 100, torch.int32, device=dev)
-    val = torch.randn(col.numel(), device=dev)
-    A = torch.sparse_csr_tensor(crow, col, val, (n, n)).requires_grad_(True)
-    B = torch.randn(n, p, device=dev, requires_grad=True)
-    Gd = torch.randn(n, p, device=dev)
-    C = sparse_mm(A, B)
-    C.backward(Gd)
-    core = _pattern.from_csr(A.detach()).core
-    assert core.own.get("lattice") is not None and core.own.get("lattice_t") is not None and core.t is None
-    C2 = sparse_mm(A.detach(), 2.0 * B.detach())
-    assert float((C2 - 2 * C.detach()).abs().max()) == 0.0  # scaling by 2 is exact in fp32
-    lhs = float((C.detach().double() * Gd.double()).sum())
-    mid = float((B.detach().double() * B.grad.double()).sum())
-    rhs = float((val.double() * A.grad.values().double()).sum())
-    scale = float((C.detach().double().abs() * Gd.double().abs()).sum())
-    assert abs(lhs - mid) / scale < 1e-6 and abs(lhs - rhs) / scale < 1e-6
-    rows = torch.cat((torch.randint(0, n, (56,), device=dev), torch.tensor([0, 99, 9999, 10000, n - 10000, n - 100, n - 1, 505050], device=dev)))
-    cr, cc = crow.cpu().numpy(), col.cpu().numpy()
-    Bh, Gh, vh = B.detach().cpu().numpy(), Gd.cpu().numpy(), val.cpu().numpy()
-    for r in rows.tolist():
-        s, e = cr[r], cr[r + 1]
-        crow1 = np.array([0, e - s])
-        c_ref = oracle.csr_spmm(crow1, cc[s:e], vh[s:e], Bh)
-        assert G.rel_err(C[r].detach().cpu().numpy(), c_ref[0]) < 1e-5
-        g_ref = oracle.csr_sddmm(crow1, cc[s:e], Gh[r: r + 1], Bh)
-        assert G.rel_err(A.grad.values()[s:e].cpu().numpy(), g_ref) < 1e-5
-    for j in rows[-24:].tolist():
-        acc = np.zeros(p, dtype=np.float64)
-        s, e = cr[j], cr[j + 1]
-        for i in cc[s:e]:  # structurally symmetric pattern: row i holds column j
-            si, ei = cr[i], cr[i + 1]
-            k = si + int(np.nonzero(cc[si:ei] == j)[0][0])
-            acc += float(vh[k]) * Gh[i].astype(np.float64)
-        assert G.rel_err(B.grad[j].cpu().numpy(), acc) < 1e-5
-    # bit-identical run to run
-    first = (C.detach().clone(), A.grad.values().clone(), B.grad.clone())
-    A.grad = None
-    B.grad = None
-    C = sparse_mm(A, B)
-    C.backward(Gd)
-    assert torch.equal(C.detach(), first[0]) and torch.equal(A.grad.values(), first[1]) and torch.equal(B.grad, first[2])
 
 
 def test_bounded_fuzz_run_of_the_public_ops():

@@ -1,0 +1,290 @@
+"""Plane-march kernels (csrc/march_impl.h) on the GPU, through the C ABI: full periodic 27-point stencils — parity with the
+oracle, bit-identity with the plan-free kernels on the rows of the canonical class (and for every dot of gradA), rounding-level
+agreement on the rows that wrap around a lattice face, several launch configurations (ragged tiles, segments of one and two
+planes, batched items), what is NOT covered (falls back to the general plane sweep), and the public autograd path at small and
+full size."""
+
+import numpy as np
+import pytest
+import torch
+
+import _golden as G
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    from torchsparsegradutils_amd import _backend
+
+    _backend.load_library()
+    yield
+
+
+def _mods():
+    from torchsparsegradutils_amd import _backend, _lattice, _pattern
+
+    return _backend, _lattice, _pattern
+
+
+def _stencil_csr(nx, ny, nz, periodic, points=27, lower=False, nb=1):
+    from test_lattice_plan_cpu import _stencil
+
+    return _stencil(nx, ny, nz, periodic, points, lower, nb)
+
+
+def _oracle_mm(crow, col, val, B, Gd):
+    from oracle import oracle
+
+    n = crow.numel() - 1
+    return oracle.sparse_mm_fwd_bwd(crow.numpy(), col.numpy(), val.numpy(), B.numpy(), Gd.numpy(), n)
+
+
+CASES = [
+    # nb, nx, ny, nz, configs (ty, tz, nseg, threads)
+    (1, 9, 10, 12, [(4, 8, 2, 256), (8, 8, 3, 512), (4, 8, 9, 256), (8, 8, 5, 512)]),      # ragged tiles; segments of 1 and 2 planes
+    (1, 3, 3, 3, [(4, 8, 1, 256), (8, 8, 3, 512)]),                                          # the smallest lattice: every row wraps
+    (1, 16, 8, 8, [(4, 8, 1, 256), (8, 8, 4, 512), (2, 8, 2, 256)]),                         # exact tiles
+    (3, 5, 6, 8, [(4, 8, 2, 256), (8, 8, 1, 512)]),                                          # batched items: x wraps inside an item
+]
+
+
+@pytest.mark.parametrize("nb,nx,ny,nz,configs", CASES)
+@pytest.mark.parametrize("p", [32, 64])
+def test_march_kernels_match_oracle_and_plan_free_kernels(nb, nx, ny, nz, configs, p):
+    be, lt, pt = _mods()
+    dev = torch.device("cuda:0")
+    crow, col = _stencil_csr(nx, ny, nz, True, 27, False, nb)
+    n = nb * nx * ny * nz
+    g = torch.Generator().manual_seed(nx * 131 + p)
+    val = torch.randn(col.numel(), generator=g)
+    B = torch.randn(n, p, generator=g)
+    Gd = torch.randn(n, p, generator=g)
+    Co, gAo, gBo = _oracle_mm(crow, col, val, B, Gd)
+    crow_d, col_d, val_d, B_d, G_d = (t.to(dev) for t in (crow, col, val, B, Gd))
+    plan = pt.RowGather(crow_d, col_d, n, n)
+    lp = lt.build_lattice_plan_hip(plan, be, dims=(nb, nx, ny, nz))
+    assert lp is not None
+    mt = lt.march_tables(lp)
+    assert mt is not None and lp.ncls == 27
+    inner = (lp.rcls[:n] == mt.ident)
+    C0 = be.csr_spmm(crow_d, col_d, val_d, B_d, n, n)
+    gA0 = be.csr_sddmm(crow_d, col_d, G_d, B_d, n, n)
+    t = plan.transposed
+    gB0 = be.csr_spmm(t.crow, t.col, val_d, G_d, n, n, perm=t.perm)
+    for cs in configs:
+        groups = cs[3] // (p // 4)
+        if groups < cs[0] * cs[1] or 2 * groups < (cs[0] + 2) * (cs[1] + 2):
+            continue                                   # tile rows > row groups of the workgroup (halo rows > twice) for this p
+        lt._MARCH_CFG_ENV = ",".join(str(v) for v in cs)
+        try:
+            mt._cfg.clear()
+            c1 = be.march_config(lp, be.LAT_SPMM, torch.float32, p)
+            c2 = be.march_config(lp, be.LAT_SDDMM, torch.float32, p)
+            c3 = be.march_config(lp, be.LAT_SPMMT, torch.float32, p)
+        finally:
+            lt._MARCH_CFG_ENV = ""
+        assert c1 is not None and c2 is not None and c3 is not None, cs
+        assert (c1.ty, c1.tz, c1.threads) == (cs[0], cs[1], cs[3])
+        C = be.csr_spmm_lattice(lp, c1, val_d, B_d)
+        gA = be.csr_sddmm_lattice(lp, c2, G_d, B_d)
+        gB = be.csr_spmm_lattice(lp, c3, val_d, G_d)
+        assert G.rel_err(C.cpu().numpy(), Co) < 1e-5, cs
+        assert G.rel_err(gA.cpu().numpy(), gAo) < 1e-5, cs
+        assert G.rel_err(gB.cpu().numpy(), gBo) < 1e-5, cs
+        # the dots do not depend on the order of the walk; the sums run in canonical order = stored order of the canonical class
+        assert torch.equal(gA, gA0), cs
+        assert torch.equal(C[inner], C0[inner]) and torch.equal(gB[inner], gB0[inner]), cs
+    mt._cfg.clear()
+
+
+def test_alpha_and_leading_dimensions():
+    """alpha scales gradA; dense operands that are column slices of wider arrays (leading dimension > p)."""
+    be, lt, pt = _mods()
+    dev = torch.device("cuda:0")
+    nx, ny, nz, p = 6, 9, 10, 32
+    crow, col = _stencil_csr(nx, ny, nz, True)
+    n = nx * ny * nz
+    g = torch.Generator().manual_seed(5)
+    val = torch.randn(col.numel(), generator=g).to(dev)
+    wide = torch.randn(n, 2 * p + 8, generator=g).to(dev)
+    B_d, G_d = wide[:, :p], wide[:, p + 8:]
+    plan = pt.RowGather(crow.to(dev), col.to(dev), n, n)
+    lp = lt.build_lattice_plan_hip(plan, be)
+    cfgs = [be.march_config(lp, m, torch.float32, p) for m in (be.LAT_SPMM, be.LAT_SDDMM, be.LAT_SPMMT)]
+    assert all(c is not None for c in cfgs)
+    C = be.csr_spmm_lattice(lp, cfgs[0], val, B_d)
+    gA = be.csr_sddmm_lattice(lp, cfgs[1], G_d, B_d, alpha=-0.5)
+    gB = be.csr_spmm_lattice(lp, cfgs[2], val, G_d)
+    Bc, Gc = B_d.contiguous(), G_d.contiguous()
+    assert torch.equal(C, be.csr_spmm_lattice(lp, cfgs[0], val, Bc))
+    assert torch.equal(gB, be.csr_spmm_lattice(lp, cfgs[2], val, Gc))
+    assert torch.equal(gA, -0.5 * be.csr_sddmm_lattice(lp, cfgs[1], Gc, Bc))
+    assert torch.equal(be.csr_sddmm_lattice(lp, cfgs[1], Gc, Bc), be.csr_sddmm(plan.crow, plan.col, Gc, Bc, n, n))
+
+
+@pytest.mark.parametrize("what", ["truncated", "seven", "lower", "bf16", "p16", "two_d"])
+def test_not_covered_falls_back_to_the_general_sweep(what):
+    """Truncated / 7-point / triangular stencils, bf16 and 16 columns are not plane-march cases: march_config says None and the
+    public path takes the general plane sweep (tests/test_gpu_lattice.py)."""
+    be, lt, pt = _mods()
+    dev = torch.device("cuda:0")
+    if what == "two_d":
+        crow, col = _stencil_csr(12, 1, 16, True)
+        n = 12 * 16
+    else:
+        nx, ny, nz = 6, 8, 10
+        crow, col = _stencil_csr(nx, ny, nz, what != "truncated", 7 if what == "seven" else 27, what == "lower")
+        n = nx * ny * nz
+    plan = pt.RowGather(crow.to(dev), col.to(dev), n, n)
+    lp = lt.build_lattice_plan_hip(plan, be)
+    assert lp is not None
+    dtype = torch.bfloat16 if what == "bf16" else torch.float32
+    p = 16 if what == "p16" else 32
+    assert be.march_config(lp, be.LAT_SPMM, dtype, p) is None
+    if what in ("bf16", "p16"):
+        assert lt.march_tables(lp) is not None            # the pattern qualifies, the operands do not
+    else:
+        assert lt.march_tables(lp) is None
+    assert be.lattice_config(lp, be.LAT_SPMM, dtype, p) is not None
+
+
+def test_public_path_takes_the_march_kernels(monkeypatch):
+    """sparse_mm forward + backward on a periodic 27-point stencil: the plane-march kernels from the first sight of the pattern,
+    neither a transposed plan nor a transposed pattern; results = oracle, gradA = the plan-free kernels bit for bit, C and gradB
+    bit for bit on the rows of the canonical class."""
+    from torchsparsegradutils_amd import _ops, _pattern, sparse_mm
+    from torchsparsegradutils_amd.utils import synthetic
+
+    monkeypatch.setattr(_ops, "ENABLE_LATTICE", True)
+    dev = torch.device("cuda:0")
+    nx, ny, nz, p = 16, 12, 20, 32
+    n = nx * ny * nz
+    crow, col = synthetic.stencil27_periodic(nx, ny, nz, torch.int32)
+    g = torch.Generator().manual_seed(1)
+    val = torch.randn(col.numel(), generator=g)
+    B = torch.randn(n, p, generator=g)
+    Gd = torch.randn(n, p, generator=g)
+    Co, gAo, gBo = _oracle_mm(crow, col, val, B, Gd)
+    A = torch.sparse_csr_tensor(crow.to(dev), col.to(dev), val.to(dev), (n, n)).requires_grad_(True)
+    Bd = B.to(dev).requires_grad_(True)
+    outs = []
+    for it in range(2):
+        A.grad = None
+        Bd.grad = None
+        C = sparse_mm(A, Bd)
+        C.backward(Gd.to(dev))
+        outs.append((C.detach().clone(), A.grad.values().clone(), Bd.grad.clone()))
+        core = _pattern.from_csr(A.detach()).core
+        lp = core.own.get("lattice")
+        assert lp is not None and lp._march and core.own.get("lattice_t") is None, it
+    assert core.t is None and not core.packs, "neither a transposed pattern nor row-pair plans are built for a periodic stencil"
+    assert A.grad.crow_indices().dtype == torch.int32 and torch.equal(A.grad.col_indices().cpu(), col)
+    for C, gA, gB in outs:
+        assert G.rel_err(C.cpu().numpy(), Co) < 1e-5
+        assert G.rel_err(gA.cpu().numpy(), gAo) < 1e-5
+        assert G.rel_err(gB.cpu().numpy(), gBo) < 1e-5
+    assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1]))
+    # one-sided gradients take the same kernels
+    A2 = A.detach().clone().requires_grad_(False)
+    C = sparse_mm(A2, Bd)
+    (gB_only,) = torch.autograd.grad(C, (Bd,), Gd.to(dev))
+    assert torch.equal(gB_only, outs[0][2])
+    # the plan-free kernels (lattice switched off)
+    inner = lp.rcls[:n] == lp._march.ident
+    monkeypatch.setattr(_ops, "ENABLE_LATTICE", False)
+    monkeypatch.setattr(_ops, "ENABLE_PACK", False)
+    A.grad = None
+    Bd.grad = None
+    C = sparse_mm(A, Bd)
+    C.backward(Gd.to(dev))
+    assert torch.equal(A.grad.values(), outs[0][1])
+    assert torch.equal(C.detach()[inner], outs[0][0][inner]) and torch.equal(Bd.grad[inner], outs[0][2][inner])
+    assert float((C.detach() - outs[0][0]).abs().max()) < 1e-4 and float((Bd.grad - outs[0][2]).abs().max()) < 1e-4
+
+
+def test_public_path_batched_fp32(monkeypatch):
+    """A batched CSR operand of periodic stencils is one block-diagonal lattice of several items."""
+    from torchsparsegradutils_amd import _ops, _pattern, sparse_mm
+    from torchsparsegradutils_amd.utils import synthetic
+
+    monkeypatch.setattr(_ops, "ENABLE_LATTICE", True)
+    dev = torch.device("cuda:0")
+    b, nx, ny, nz, p = 3, 8, 8, 16, 32
+    n = nx * ny * nz
+    crow, col = synthetic.stencil27_periodic(nx, ny, nz, torch.int32)
+    g = torch.Generator().manual_seed(2)
+    val = torch.randn(b, col.numel(), generator=g)
+    B = torch.randn(b, n, p, generator=g)
+    Gd = torch.randn(b, n, p, generator=g)
+    A = torch.sparse_csr_tensor(crow.repeat(b, 1).to(dev), col.repeat(b, 1).to(dev), val.to(dev), (b, n, n)).requires_grad_(True)
+    Bd = B.to(dev).requires_grad_(True)
+    C = sparse_mm(A, Bd)
+    C.backward(Gd.to(dev))
+    flat = _pattern.flat_of(_pattern.from_csr(A.detach()))
+    lp = flat.core.own.get("lattice")
+    assert lp is not None and lp.nb == b and lp._march
+    for i in range(b):
+        Co, gAo, gBo = _oracle_mm(crow, col, val[i], B[i], Gd[i])
+        assert G.rel_err(C[i].detach().cpu().numpy(), Co) < 1e-5
+        assert G.rel_err(A.grad.values()[i].cpu().numpy(), gAo) < 1e-5
+        assert G.rel_err(Bd.grad[i].cpu().numpy(), gBo) < 1e-5
+
+
+def test_full_size_c2_on_the_product_path(monkeypatch):
+    """BASELINE config C2 at full size (N=1e6, 27/row, 32 RHS) on the product path (plane-march kernels): size-independent
+    checks — linearity of the product in B, the adjoint identity <A·B, G> = <B, Aᵀ·G> = Σ val·gradA — plus sampled rows,
+    sampled entries of gradA and sampled rows of gradB against the oracle on the same inputs, and run-to-run bit identity."""
+    from oracle import oracle
+    from torchsparsegradutils_amd import _ops, _pattern, sparse_mm
+    from torchsparsegradutils_amd.utils import synthetic
+
+    monkeypatch.setattr(_ops, "ENABLE_LATTICE", True)
+    dev = "cuda:0"
+    n, p = 10 ** 6, 32
+    crow, col = synthetic.stencil27_periodic(100, 100, 100, torch.int32, device=dev)
+    val = torch.randn(col.numel(), device=dev)
+    A = torch.sparse_csr_tensor(crow, col, val, (n, n)).requires_grad_(True)
+    B = torch.randn(n, p, device=dev, requires_grad=True)
+    Gd = torch.randn(n, p, device=dev)
+    C = sparse_mm(A, B)
+    C.backward(Gd)
+    core = _pattern.from_csr(A.detach()).core
+    lp = core.own.get("lattice")
+    assert lp is not None and lp._march and core.own.get("lattice_t") is None and core.t is None   # no transposed plan / pattern
+    assert all(c is not None for c in lp._march._cfg.values()) and len(lp._march._cfg) == 3
+    C2 = sparse_mm(A.detach(), 2.0 * B.detach())
+    assert float((C2 - 2 * C.detach()).abs().max()) == 0.0  # scaling by 2 is exact in fp32
+    lhs = float((C.detach().double() * Gd.double()).sum())
+    mid = float((B.detach().double() * B.grad.double()).sum())
+    rhs = float((val.double() * A.grad.values().double()).sum())
+    scale = float((C.detach().double().abs() * Gd.double().abs()).sum())
+    assert abs(lhs - mid) / scale < 1e-6 and abs(lhs - rhs) / scale < 1e-6
+    rows = torch.cat((torch.randint(0, n, (56,), device=dev), torch.tensor([0, 99, 9999, 10000, n - 10000, n - 100, n - 1, 505050], device=dev)))
+    cr, cc = crow.cpu().numpy(), col.cpu().numpy()
+    Bh, Gh, vh = B.detach().cpu().numpy(), Gd.cpu().numpy(), val.cpu().numpy()
+    for r in rows.tolist():
+        s, e = cr[r], cr[r + 1]
+        crow1 = np.array([0, e - s])
+        c_ref = oracle.csr_spmm(crow1, cc[s:e], vh[s:e], Bh)
+        assert G.rel_err(C[r].detach().cpu().numpy(), c_ref[0]) < 1e-5
+        g_ref = oracle.csr_sddmm(crow1, cc[s:e], Gh[r: r + 1], Bh)
+        assert G.rel_err(A.grad.values()[s:e].cpu().numpy(), g_ref) < 1e-5
+    for j in rows[-24:].tolist():
+        acc = np.zeros(p, dtype=np.float64)
+        s, e = cr[j], cr[j + 1]
+        for i in cc[s:e]:  # structurally symmetric pattern: row i holds column j
+            si, ei = cr[i], cr[i + 1]
+            k = si + int(np.nonzero(cc[si:ei] == j)[0][0])
+            acc += float(vh[k]) * Gh[i].astype(np.float64)
+        assert G.rel_err(B.grad[j].cpu().numpy(), acc) < 1e-5
+    # bit-identical run to run
+    first = (C.detach().clone(), A.grad.values().clone(), B.grad.clone())
+    A.grad = None
+    B.grad = None
+    C = sparse_mm(A, B)
+    C.backward(Gd)
+    assert torch.equal(C.detach(), first[0]) and torch.equal(A.grad.values(), first[1]) and torch.equal(B.grad, first[2])
+
+

@@ -77,6 +77,9 @@ SIGNATURES = {
     "tsgu_lattice_lds_bytes": (_int, [_int, _int, _i64, _int, _int, _int, _int, _int, _int, _int, _int, _int]),
     "tsgu_csr_spmm_lattice": (_int, [_int, _ptr, _i64, _i64, _ptr, _ptr, _i64, _ptr, _i64, _i64, _int, _ptr]),
     "tsgu_csr_sddmm_lattice": (_int, [_int, _ptr, _i64, _i64, _ptr, _i64, _ptr, _i64, _ptr, _dbl, _i64, _int, _ptr]),
+    "tsgu_march_lds_bytes": (_int, [_int, _int, _i64, _int, _int, _int, _int, _int, _int]),
+    "tsgu_csr_spmm_march": (_int, [_int, _ptr, _int, _i64, _i64, _ptr, _ptr, _i64, _ptr, _i64, _i64, _int, _ptr]),
+    "tsgu_csr_sddmm_march": (_int, [_int, _ptr, _i64, _i64, _ptr, _i64, _ptr, _i64, _ptr, _dbl, _i64, _int, _ptr]),
     "tsgu_lattice_slots": (_int, []),
     "tsgu_lattice_rows": (_int, [_int, _i64, _ptr, _ptr, _int, _int, _int, _int, _ptr, _int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr,
                                  _int, _ptr]),
@@ -463,6 +466,21 @@ def lattice_row_codes(crow, col, dims, rows, out, disp=None):
     check(rc, "tsgu_lattice_row_codes")
 
 
+def march_lds_bytes(mode: int, vtype: int, p: int, ty: int, tz: int, ry: int, rz: int, ncls: int, threads: int) -> int:
+    """Dynamic LDS bytes of a plane-march launch configuration (csrc/march_impl.h), or a negative tsgu status."""
+    return int(load_library().tsgu_march_lds_bytes(mode, vtype, p, ty, tz, ry, rz, ncls, threads))
+
+
+def march_config(lp, mode: int, dtype: torch.dtype, p: int):
+    """Launch configuration of the plane-march kernels for the stored-order _lattice.LatticePlan `lp`, or None when the pattern
+    is not a full periodic box stencil / the operands are not covered (fp32, 32 or 64 columns)."""
+    from . import _lattice
+
+    if dtype != torch.float32 or lp is None or lp.kind != 0:
+        return None
+    return _lattice.march_config_for(lp, mode, _VTYPE[dtype], p, march_lds_bytes)
+
+
 # Per-kernel timing hook (bench.py): a list to which the lattice launchers append (name, start event, end event) recorded on the
 # launch stream around the C call.  None = off (the product never pays for it).
 KERNEL_EVENTS = None
@@ -508,14 +526,20 @@ def csr_spmm_lattice(lp, cfg, val, B):
     out = torch.empty((lp.n_rows, p), dtype=B.dtype, device=dev)
     if not val.is_contiguous():
         val = val.contiguous()
-    tok = _timed("lattice_spmm_t" if lp.kind else "lattice_spmm", dev) if KERNEL_EVENTS is not None else None
+    march = getattr(cfg, "march", False)
+    transposed = cfg.mode == LAT_SPMMT if march else bool(lp.kind)
+    tok = _timed("lattice_spmm_t" if transposed else "lattice_spmm", dev) if KERNEL_EVENTS is not None else None
     with _on_device(dev):
-        rc = lib.tsgu_csr_spmm_lattice(_VTYPE[val.dtype], cfg.struct_addr, lp.n_rows, lp.nnz, val.data_ptr(), B.data_ptr(), _ld(B),
-                                       out.data_ptr(), p, p, dev.index, torch.cuda.current_stream(dev).cuda_stream)
+        if march:
+            rc = lib.tsgu_csr_spmm_march(_VTYPE[val.dtype], cfg.struct_addr, int(transposed), lp.n_rows, lp.nnz, val.data_ptr(), B.data_ptr(),
+                                         _ld(B), out.data_ptr(), p, p, dev.index, torch.cuda.current_stream(dev).cuda_stream)
+        else:
+            rc = lib.tsgu_csr_spmm_lattice(_VTYPE[val.dtype], cfg.struct_addr, lp.n_rows, lp.nnz, val.data_ptr(), B.data_ptr(), _ld(B),
+                                           out.data_ptr(), p, p, dev.index, torch.cuda.current_stream(dev).cuda_stream)
     if tok is not None:
         _timed_end(tok, dev)
     if rc:
-        check(rc, "tsgu_csr_spmm_lattice")
+        check(rc, "tsgu_csr_spmm_march" if march else "tsgu_csr_spmm_lattice")
     return out
 
 
@@ -530,9 +554,10 @@ def csr_sddmm_lattice(lp, cfg, R, Cm, alpha: float = 1.0):
     p = R.size(-1)
     out = torch.empty((lp.nnz,), dtype=R.dtype, device=dev)
     tok = _timed("lattice_sddmm", dev) if KERNEL_EVENTS is not None else None
+    fn = lib.tsgu_csr_sddmm_march if getattr(cfg, "march", False) else lib.tsgu_csr_sddmm_lattice
     with _on_device(dev):
-        rc = lib.tsgu_csr_sddmm_lattice(_VTYPE[R.dtype], cfg.struct_addr, lp.n_rows, lp.nnz, R.data_ptr(), _ld(R), Cm.data_ptr(), _ld(Cm),
-                                        out.data_ptr(), float(alpha), p, dev.index, torch.cuda.current_stream(dev).cuda_stream)
+        rc = fn(_VTYPE[R.dtype], cfg.struct_addr, lp.n_rows, lp.nnz, R.data_ptr(), _ld(R), Cm.data_ptr(), _ld(Cm),
+                out.data_ptr(), float(alpha), p, dev.index, torch.cuda.current_stream(dev).cuda_stream)
     if tok is not None:
         _timed_end(tok, dev)
     if rc:

@@ -35,10 +35,11 @@ class LatticePlan:
     live in the source rows of the owner's value array)."""
 
     __slots__ = ("kind", "nb", "nx", "ny", "nz", "ry", "rz", "ncls", "recw", "uniform_len", "codes", "ksrc", "lens",
-                 "lens_host", "rcls", "rstart", "n_rows", "nnz", "_cfg")
+                 "lens_host", "rcls", "rstart", "n_rows", "nnz", "_cfg", "_march")
 
     def __init__(self):
         self._cfg: Dict[tuple, "LatticeConfig"] = {}
+        self._march = False          # False: not derived yet; None: not a full periodic box stencil; else MarchTables
 
     def plan_bytes(self) -> int:
         total = 0
@@ -579,4 +580,130 @@ def config_for(plan: LatticePlan, mode: int, vtype: int, p: int, elem_bytes: int
             cfg.struct_addr = ctypes.addressof(cfg.struct)
             break
         plan._cfg[key] = cfg
+    return cfg
+
+
+# ---- plane-march kernels (csrc/march_impl.h): full periodic box stencils --------------------------------------------
+ENABLE_MARCH = os.environ.get("TSGU_ENABLE_MARCH", "1") == "1"
+_MARCH_CFG_ENV = os.environ.get("TSGU_MARCH_CFG", "")   # "ty,tz,nseg,threads" overrides the choice (experiments)
+MARCH_TAPS = 9
+MARCH_MAX_CLASSES = 64
+_MARCH_WAVES_PER_CU = {0: 20, 1: 16, 2: 16}     # resident waves per CU by the kernels' register use (84 / 97 / 99 VGPRs)
+# workgroup sizes in order of preference (measured at C2: the small tile hides the DMA latency with more independent
+# workgroups; the transposed product stages two rings and prefers the smaller halo of the 8 x 8 tile)
+_MARCH_THREADS = {0: (256, 512), 1: (256, 512), 2: (512, 256)}
+_MARCH_HALO_COST = {0: 0.1, 1: 0.1, 2: 0.8}     # what a halo row costs relative to an own row
+
+
+class MarchTables:
+    """What the plane-march kernels need besides the lattice plan's `rcls`: the canonical class and the per-class map
+    canonical slot -> stored position (include/tsgu_hip.h, tsgu_march_plan)."""
+
+    __slots__ = ("ident", "taps", "kidx_host", "kidx", "_cfg")
+
+
+class MarchConfig:
+    """One launch configuration of the plane-march kernels (quacks like LatticeConfig where bench.py / tests look)."""
+
+    __slots__ = ("mode", "ty", "tz", "nseg", "threads", "lds_bytes", "struct", "struct_addr", "ring", "cpl", "nloc", "tables")
+    march = True
+
+
+class _MarchPlanStruct(ctypes.Structure):
+    """``tsgu_march_plan`` of include/tsgu_hip.h."""
+
+    _fields_ = ([(k, ctypes.c_int32) for k in ("nb", "nx", "ny", "nz", "ry", "rz", "ntap")] + [("tap_dy", ctypes.c_int32 * 9), ("tap_dz", ctypes.c_int32 * 9)]
+                + [(k, ctypes.c_int32) for k in ("ncls", "ident", "ty", "tz", "nseg", "threads")] + [(k, ctypes.c_void_p) for k in ("kidx", "rcls")])
+
+
+def march_tables(plan: LatticePlan) -> Optional[MarchTables]:
+    """MarchTables of a stored-order lattice plan whose rows all hold the full 3 x 3 x 3 box (a periodic 27-point stencil on a
+    lattice of at least 3 points per dimension), else None.  Host work on the [classes][28] code table only."""
+    if plan._march is not False:
+        return plan._march
+    plan._march = None
+    ns = 3 * MARCH_TAPS
+    if (plan.kind != 0 or plan.uniform_len != ns or plan.ry != 1 or plan.rz != 1 or min(plan.nx, plan.ny, plan.nz) < 3
+            or plan.ncls > MARCH_MAX_CLASSES):
+        return None
+    canon = [((dx + 1) * 5 + dy + 2) * 5 + dz + 2 for dx in (-1, 0, 1) for dy in (-1, 0, 1) for dz in (-1, 0, 1)]   # ascending
+    codes = plan.codes[:, :ns].tolist()
+    ident = None
+    kidx = [[0xFF] * 32 for _ in range(plan.ncls)]
+    for c, row in enumerate(codes):
+        if sorted(row) != canon:
+            return None
+        if row == canon:
+            ident = c
+        pos = {code: k for k, code in enumerate(row)}
+        for slot, code in enumerate(canon):
+            kidx[c][slot] = pos[code]
+    if ident is None:
+        return None
+    mt = MarchTables()
+    mt.ident = ident
+    mt.taps = [(dy, dz) for dy in (-1, 0, 1) for dz in (-1, 0, 1)]
+    mt.kidx_host = torch.tensor(kidx, dtype=torch.uint8)
+    mt.kidx = mt.kidx_host.to(plan.rcls.device)
+    mt._cfg = {}
+    plan._march = mt
+    return mt
+
+
+def march_config_for(plan: LatticePlan, mode: int, vtype: int, p: int, lds_bytes_fn) -> Optional[MarchConfig]:
+    """Cached launch configuration of the plane-march kernels for a stored-order plan, or None (pattern / operands not covered)."""
+    if not ENABLE_MARCH or vtype != 0 or p not in (32, 64):
+        return None
+    mt = march_tables(plan)
+    if mt is None:
+        return None
+    key = (mode, p)
+    if key in mt._cfg:
+        return mt._cfg[key]
+    cl = p // 4
+    best = None
+    if _MARCH_CFG_ENV:
+        v = [int(t) for t in _MARCH_CFG_ENV.split(",")]
+        cands = [(v[0], v[1], min(v[2], plan.nx), v[3])]
+    else:
+        # a wave = 64 / cl consecutive rows of one z-line (conflict-free LDS row reads): tz = 8 rows (p = 32) or a multiple
+        cands = []
+        for threads in _MARCH_THREADS[mode]:
+            rpp = threads // cl
+            tz = 8
+            if rpp // tz >= 1 and rpp // tz <= plan.ny and tz <= plan.nz:
+                cands.append((rpp // tz, tz, 0, threads))
+    for ty, tz, nseg, threads in cands:
+        lds = lds_bytes_fn(mode, vtype, p, ty, tz, plan.ry, plan.rz, plan.ncls, threads)
+        if lds <= 0:
+            continue
+        per_cu = max(1, min(160 * 1024 // lds, _MARCH_WAVES_PER_CU[mode] * 64 // threads))
+        slots = _NUM_CU * per_cu
+        tiles = -(-plan.ny // ty) * -(-plan.nz // tz)
+        base = plan.nb * tiles
+        util = (plan.ny * plan.nz) / (tiles * ty * tz)
+        halo = (ty + 2 * plan.ry) * (tz + 2 * plan.rz) / (ty * tz)
+        util /= 1.0 + _MARCH_HALO_COST[mode] * (halo - 1.0)
+        choices = [nseg] if nseg else range(1, min(plan.nx, 64) + 1)
+        for ns_ in choices:
+            seg_len = -(-plan.nx // ns_)
+            if seg_len * (ns_ - 1) >= plan.nx:
+                continue
+            nwg = base * ns_
+            # a workgroup marches seg_len + 2 source planes (+ ~3 steps of prologue); workgroups run in rounds of `slots`
+            cost = -(-nwg // slots) * (seg_len + 5) / util
+            if best is None or cost < best[0]:
+                best = (cost, ty, tz, ns_, threads, lds)
+    cfg = None
+    if best is not None:
+        _, ty, tz, nseg, threads, lds = best
+        cfg = MarchConfig()
+        cfg.mode, cfg.ty, cfg.tz, cfg.nseg, cfg.threads, cfg.lds_bytes = mode, ty, tz, nseg, threads, lds
+        cfg.ring, cfg.cpl, cfg.nloc, cfg.tables = 2, 1, plan.ncls, mt
+        dy = (ctypes.c_int32 * 9)(*[t[0] for t in mt.taps])
+        dz = (ctypes.c_int32 * 9)(*[t[1] for t in mt.taps])
+        cfg.struct = _MarchPlanStruct(plan.nb, plan.nx, plan.ny, plan.nz, plan.ry, plan.rz, MARCH_TAPS, dy, dz, plan.ncls, mt.ident,
+                                      ty, tz, nseg, threads, mt.kidx.data_ptr(), plan.rcls.data_ptr())
+        cfg.struct_addr = ctypes.addressof(cfg.struct)
+    mt._cfg[key] = cfg
     return cfg

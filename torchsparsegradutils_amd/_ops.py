@@ -65,7 +65,14 @@ def _lattice_cfg(plan: RowGather, mode: int, dense: torch.Tensor, *others: torch
         return None
     if dense.dtype not in LATTICE_DTYPES:
         return None
-    lp = _lattice_plan(plan, transposed=mode == _be.LAT_SPMMT)
+    fwd = _lattice_plan(plan)
+    if fwd is None:
+        return None
+    # full periodic box stencils: the plane-march kernels (all three products from the stored-order plan alone)
+    cfg = _be.march_config(fwd, mode, dense.dtype, dense.size(-1))
+    if cfg is not None:
+        return fwd, cfg
+    lp = _lattice_plan(plan, transposed=True) if mode == _be.LAT_SPMMT else fwd
     if lp is None:
         return None
     cfg = _be.lattice_config(lp, mode, dense.dtype, dense.size(-1))

@@ -572,6 +572,9 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
                             };
                             auto stage_b = [&](int i) {
                                 const int rv[4] = {ro[i % 3].x, ro[i % 3].y, ro[i % 3].z, ro[i % 3].w};
+#if TSGU_LAT_PROBE == 3   // probe build (wrong results): a third of the dense-row reads
+                                if (i >= 2) return;
+#endif
 #pragma unroll
                                 for (int j = 0; j < 4; ++j) load_b(rv[j], b[i & 1][j]);
                             };
@@ -654,6 +657,9 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
                             uint4 b[2][4][CPL];
                             auto stage_b = [&](int i) {
                                 const int rv[4] = {ro[i % 3].x, ro[i % 3].y, ro[i % 3].z, ro[i % 3].w};
+#if TSGU_LAT_PROBE == 3   // probe build (wrong results): a third of the dense-row reads
+                                if (i >= 2) return;
+#endif
 #pragma unroll
                                 for (int j = 0; j < 4; ++j) load_b(rv[j], b[i & 1][j]);
                             };
@@ -717,6 +723,9 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
                                 }
 #pragma unroll
                                 for (int j = 0; j < 4; ++j) {
+#if TSGU_LAT_PROBE == 3
+                                    if (i < 2)
+#endif
                                     load_b(go[j], b[i & 1][j]);
                                     a[i & 1][j] = load_val(vcb + vo[j]);
                                 }

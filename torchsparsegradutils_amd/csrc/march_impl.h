@@ -1,0 +1,562 @@
+// Plane-march kernels: the lattice plane sweep (lattice_impl.h) for FULL periodic box stencils, organised by SOURCE plane.
+//
+// lattice_impl.h walks an output plane's rows entry by entry: 27 `ds_read_b128` of dense rows per row, and the LDS pipe is
+// what its kernels wait for (a build that skips two thirds of those reads is 17-24 us faster per kernel at C2).  When every
+// row holds the whole (2·1+1) x NTAP box — a periodic stencil: all rows have 3·NTAP entries, and every row's entries are a
+// permutation of the same displacement set — the sum can be taken source plane by source plane instead:
+//
+//     at step s the dense rows of halo plane s are read ONCE per in-plane displacement ("tap", NTAP = 9) and used for the
+//     three output planes s+1 (its dx = -1 part), s (dx = 0) and s-1 (dx = +1), whose accumulators live in registers and
+//     rotate; an output plane is complete after three steps.
+//
+// So a row costs NTAP dense-row reads instead of 3·NTAP, the tap offsets are the same for all rows (nine wave-uniform
+// constants: no record tables, no per-entry address arithmetic beyond one add per tap), and only TWO halo planes are
+// resident (the one in use and the one being filled) — the ring that limited the residency of lattice_impl.h is halved.
+//
+// Canonical order.  The class of the interior rows ("ident") stores its entries in ascending (dx, dy, dz): slot
+// p·NTAP + i = part p (dx = p - 1), tap i.  Rows of the other classes (wrap-around at a lattice face: 6 % of C2) hold the same
+// displacements in another order; `kidx[class][slot]` is the stored position of canonical slot `slot`.  Values are staged in LDS in
+// CANONICAL order: waves whose rows are all `ident` copy them with the 16-byte LDS-DMA, the others gather them with the 4-byte
+// LDS-DMA (`global_load_lds_dword`, one lane per value, source offset through `kidx`) — both asynchronous, same LDS layout.
+// The SDDMM scatters through the same table when it writes a row's gradients to its stage row, so gradA leaves in A's stored
+// order as before.  Summation order = canonical order: bit-identical to the plan-free kernels for `ident` rows, equal to
+// rounding for the wrapped ones.
+//
+// Modes:  kLatSpmm   C = A·B      values of the tile's own rows, four plane buffers (targets s-1, s, s+1 + the one being filled)
+//         kLatSddmm  gradA        own rows of the three targets in registers; a lane keeps the dots of the slots = its lane (mod CL)
+//         kLatSpmmT  gradB = Aᵀ·G  a second two-plane ring holds the canonical VALUE rows of the halo rows: entry (i -> j) sits in
+//                                 source row i at slot (dx+1)·NTAP + tap(dy, dz), and the source of target j through tap i' is the
+//                                 row at -tap: slot (dx+1)·NTAP + NTAP-1-i' of the row at own + tap i' (the tap list is symmetric).
+//                                 No transposed pattern, no transposed plan.
+#pragma once
+
+#include "lattice_impl.h"
+
+namespace tsgu {
+
+constexpr int kMarchMaxCls = 64;     // classes of a pattern (27 for a periodic 27-point stencil)
+constexpr int kMarchND = 3;          // ring DMA pieces per thread and plane
+
+struct MarchParams {
+    int nb, nx, ny, nz;
+    int ty, tz, ry, rz;
+    int tiles_y, tiles_z;
+    int nseg, seg_len;
+    int ncls, ident;
+    int tap_row[9];              // halo-row displacement dy·HZ + dz of tap i, ascending
+    const unsigned char* kidx;   // [ncls][32] stored position of canonical slot s
+    const unsigned char* rcls;   // [rows] class of each row
+    const void* val;
+    int64_t nnz;
+    const void* S;               // gathered dense operand
+    int64_t lds_;
+    const void* Own;             // SDDMM: row operand
+    int64_t ldown;
+    void* out;                   // C / gradB
+    int64_t ldo;
+    void* gvals;                 // SDDMM output [nnz]
+    float alpha;
+    int64_t nblocks;
+    int o_vals, o_tab, o_rows, lds_bytes;   // LDS layout (bytes), filled by march_layout
+};
+
+// 4-byte LDS-DMA: lane l's dword lands at `lds_wave_base + 4*l`
+__device__ __forceinline__ void lat_dma4(const void* sbase64, uint32_t voff, unsigned lds_wave_base) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2 nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase64), "s"(lds_wave_base) : "memory");
+}
+
+template <typename V, int CL, int MODE, int NT, int NTAP>
+__global__ __launch_bounds__(NT, 4) void march_kernel(const MarchParams P) {
+    static_assert(sizeof(V) == 4, "fp32 values and operands");
+    constexpr int RB = CL * 16;                 // bytes of a dense row
+    constexpr int NG = NT / CL;                 // row groups of the workgroup
+    constexpr int RPW = kWave / CL;             // rows per wave
+    constexpr int NS = 3 * NTAP;                // entries per row
+    constexpr int SLOTS = (NS + 3) / 4 * 4;     // slots of a staged value row
+    constexpr int VP = SLOTS * 4;               // its pitch in bytes (112: the rows of a wave fall on different banks)
+    constexpr int VL = SLOTS / 4;               // its 16-byte pieces
+    constexpr int NGI = (RPW * SLOTS + kWave - 1) / kWave;   // 4-byte DMA instructions that gather the value rows of a wave
+    constexpr int NPASS = MODE == kLatSpmmT ? 2 : 1;        // staged rows: tile rows (one per group) or halo rows (up to two)
+    constexpr int RJ = (NS + CL - 1) / CL;      // SDDMM: dots a lane keeps per target
+    static_assert(NT % kWave == 0 && kWave % CL == 0 && RPW * VL <= kWave && VP % 64 != 0, "geometry");
+
+    extern __shared__ uint4 lat_smem[];
+    char* const sm = reinterpret_cast<char*>(lat_smem);
+    const unsigned sbase = lat_lds_addr(lat_smem);
+
+    const int tid = threadIdx.x;
+    const int lane = tid % kWave;
+    const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
+    const int c = tid % CL;
+    const int g = tid / CL;
+
+    const int HZ = P.tz + 2 * P.rz, HY = P.ty + 2 * P.ry, HR = HY * HZ, NR = P.ty * P.tz;
+    const int PB = HR * RB;
+    const int plane_rows = P.ny * P.nz;
+    auto wrap = [](int v, int m) { return v >= m ? v - m : v; };
+
+    // ---- the tile and x segment of this workgroup (as lattice_kernel) ---------------------------------------------
+    const int64_t vblock = xcd_chunked_block(blockIdx.x, P.nblocks);
+    int64_t vb = vblock;
+    const int tzi = (int)(vb % P.tiles_z);
+    vb /= P.tiles_z;
+    const int tyi = (int)(vb % P.tiles_y);
+    vb /= P.tiles_y;
+    const int seg = (int)(vb % P.nseg);
+    const int item = (int)(vb / P.nseg);
+    const int xs = seg * P.seg_len;
+    const int L = P.seg_len < P.nx - xs ? P.seg_len : P.nx - xs;   // output planes: ring indices 1 .. L; halo planes 0 and L+1
+    const int y0 = tyi * P.ty, z0 = tzi * P.tz;
+    const int item_row0 = item * P.nx * plane_rows;
+    auto row_of_x = [&](int x) -> int { return item_row0 + x * plane_rows; };
+
+    // ---- tables -> LDS: kidx, and the row-in-plane index of every staged row (-1: outside the lattice) ----------------
+    const int staged_rows = MODE == kLatSpmmT ? HR : NR;
+    {
+        const int* src = reinterpret_cast<const int*>(P.kidx);
+        int* dst = reinterpret_cast<int*>(sm + P.o_tab);
+        for (int i = tid; i < P.ncls * 8; i += NT) dst[i] = src[i];
+        int* rows = reinterpret_cast<int*>(sm + P.o_rows);
+        for (int r = tid; r < staged_rows; r += NT) {
+            int v;
+            if constexpr (MODE == kLatSpmmT) {
+                const int hy = r / HZ, hz = r - hy * HZ;
+                v = lat_mod(y0 - P.ry + hy, P.ny) * P.nz + lat_mod(z0 - P.rz + hz, P.nz);
+            } else {
+                const int ly = r / P.tz, lz = r - ly * P.tz;
+                v = (y0 + ly < P.ny && z0 + lz < P.nz) ? (y0 + ly) * P.nz + z0 + lz : -1;
+            }
+            rows[r] = v;
+        }
+    }
+    __syncthreads();
+    const unsigned char* const kidx_s = reinterpret_cast<const unsigned char*>(sm + P.o_tab);
+    const int* const rows_s = reinterpret_cast<const int*>(sm + P.o_rows);
+
+    // ---- per-thread descriptors ---------------------------------------------------------------------------------
+    const uint32_t ldsb = (uint32_t)P.lds_ * 4u;
+    uint32_t roff[kMarchND];
+    const int ring_pieces = HR * CL;
+#pragma unroll
+    for (int d = 0; d < kMarchND; ++d) {
+        const int e = d * NT + tid;
+        const int hr = e / CL;
+        const int hy = hr / HZ, hz = hr - hy * HZ;
+        roff[d] = e < ring_pieces ? (uint32_t)(lat_mod(y0 - P.ry + hy, P.ny) * P.nz + lat_mod(z0 - P.rz + hz, P.nz)) * ldsb + (uint32_t)c * 16u : kLatNone;
+    }
+    // the compute row of this lane group
+    const int ly = g / P.tz, lz = g - ly * P.tz;
+    const bool ok = g < NR && y0 + ly < P.ny && z0 + lz < P.nz;
+    const int crow = ok ? (y0 + ly) * P.nz + z0 + lz : -1;          // row inside its plane
+    const int hrow = (ly + P.ry) * HZ + lz + P.rz;                  // its position in a halo plane
+    const uint32_t coo = (uint32_t)(ok ? crow : 0) * ((uint32_t)P.ldo * 4u) + (uint32_t)c * 16u;
+    const uint32_t cown = (uint32_t)(ok ? crow : 0) * ((uint32_t)P.ldown * 4u) + (uint32_t)c * 16u;
+    const int cen = hrow * RB + c * 16;
+
+    // staged value rows: pass q, wave w stages rows q·NG + w·RPW .. + RPW - 1 (tile rows, or halo rows for the transposed product)
+    //   srow[q]  the row whose class this lane loads (its group's row)
+    //   foff[q]  fast path: byte offset of this lane's 16-byte piece inside the plane's values (kLatNone: nothing)
+    int srow[NPASS];
+    uint32_t foff[NPASS];
+    if constexpr (MODE != kLatSddmm) {
+#pragma unroll
+        for (int q = 0; q < NPASS; ++q) {
+            const int r = q * NG + g;
+            srow[q] = r < staged_rows ? rows_s[r] : -1;
+            const int fr = q * NG + wave * RPW + lane / VL;
+            const int frow = (lane < RPW * VL && fr < staged_rows) ? rows_s[fr] : -1;
+            foff[q] = frow >= 0 ? (uint32_t)frow * (uint32_t)(NS * 4) + (uint32_t)(lane % VL) * 16u : kLatNone;
+        }
+    }
+
+    const char* const Sb = static_cast<const char*>(P.S);
+    const char* const valb = static_cast<const char*>(P.val);
+    const uint32_t val_bytes = (uint32_t)(P.nnz * 4);
+
+    auto dma_ring = [&](int prow, int slot) {
+        const char* const pbase = Sb + (int64_t)prow * ldsb;
+        const unsigned base = sbase + (unsigned)(slot * PB) + (unsigned)(wave * kWave * 16);
+#pragma unroll
+        for (int d = 0; d < kMarchND; ++d) {
+            if (d * NT < ring_pieces) {
+                if (roff[d] != kLatNone) lat_dma16<false>(pbase, roff[d], base + (unsigned)(d * NT * 16));
+            }
+        }
+    };
+    // canonical value rows of the plane with first row `prow` into the buffer at byte `region`; cls[q] = class of srow[q]
+    auto stage_vals = [&](int prow, unsigned region, const int (&cls)[NPASS]) {
+        if constexpr (MODE != kLatSddmm) {
+            const uint32_t plane0 = (uint32_t)prow * (uint32_t)(NS * 4);
+            const char* const pbase = valb + plane0;
+#pragma unroll
+            for (int q = 0; q < NPASS; ++q) {
+                const int first = q * NG + wave * RPW;                       // wave-uniform
+                if (first < staged_rows) {
+                    const unsigned wbase = sbase + region + (unsigned)(first * VP);
+                    const bool plain = __builtin_amdgcn_ballot_w64(srow[q] >= 0 && cls[q] != P.ident) == 0;
+                    if (plain) {
+                        if (foff[q] != kLatNone) {
+                            if (__builtin_expect(plane0 + foff[q] + 16u <= val_bytes, 1)) {
+                                lat_dma16<true>(pbase, foff[q], wbase);
+                            } else {   // the last 16 bytes of the value array: element-wise, never reading beyond the array
+                                float* dst = reinterpret_cast<float*>(sm + region + first * VP + lane * 16);
+#pragma nounroll
+                                for (int e = 0; e < 4; ++e)
+                                    dst[e] = plane0 + foff[q] + (e + 1) * 4 <= val_bytes ? *reinterpret_cast<const float*>(pbase + foff[q] + e * 4) : 0.f;
+                            }
+                        }
+                    } else {
+#pragma unroll
+                        for (int n = 0; n < NGI; ++n) {
+                            const int e = n * kWave + lane;
+                            const int rw = e / SLOTS, slot = e - rw * SLOTS;
+                            // class of row rw of this wave: held by the lanes of its group
+                            const int rc = __builtin_amdgcn_ds_bpermute((rw < RPW ? rw * CL : 0) * 4, cls[q]);
+                            const int rr = (rw < RPW && first + rw < staged_rows) ? rows_s[first + rw] : -1;
+                            if (rr >= 0 && slot < NS) {
+                                const int k = kidx_s[rc * 32 + slot];
+                                lat_dma4(pbase, (uint32_t)rr * (uint32_t)(NS * 4) + (uint32_t)k * 4u, wbase + (unsigned)(n * kWave * 4));
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    };
+    auto load_cls = [&](int prow, int (&cls)[NPASS]) {
+        if constexpr (MODE != kLatSddmm) {
+            const unsigned char* const cbase = P.rcls + prow;
+#pragma unroll
+            for (int q = 0; q < NPASS; ++q) {
+                cls[q] = P.ident;
+                if (srow[q] >= 0) cls[q] = cbase[(uint32_t)srow[q]];
+            }
+        }
+    };
+    auto pin_cls = [&](int (&cls)[NPASS]) {
+#pragma unroll
+        for (int q = 0; q < NPASS; ++q) lat_pin(cls[q]);
+    };
+
+    int tapb[NTAP];   // byte offset of tap i from the row's own position in a halo plane (wave-uniform)
+#pragma unroll
+    for (int i = 0; i < NTAP; ++i) tapb[i] = P.tap_row[i] * RB;
+
+    auto as4 = [](const uint4& raw, float (&f)[4]) {
+        f[0] = __uint_as_float(raw.x), f[1] = __uint_as_float(raw.y), f[2] = __uint_as_float(raw.z), f[3] = __uint_as_float(raw.w);
+    };
+
+    // lattice planes: ring index s of this segment is plane (xs - 1 + s) mod nx of the item
+    int x_ring = lat_mod(xs - 1, P.nx);
+
+    if constexpr (MODE == kLatSpmm || MODE == kLatSpmmT) {
+        constexpr int VB = MODE == kLatSpmm ? 4 : 2;                        // value buffers
+        const int vbuf = (MODE == kLatSpmm ? NR : HR) * VP;
+        // SpMM stages the values of target plane s+2 at step s; SpMMT those of halo plane s+1 (with the dense plane)
+        int x_val = MODE == kLatSpmm ? xs : x_ring;                         // lattice plane of the next value plane (ring 1 / ring 0)
+        int cls[NPASS], cld[NPASS];
+        load_cls(row_of_x(x_val), cls);
+        pin_cls(cls);
+        dma_ring(row_of_x(x_ring), 0);
+        stage_vals(row_of_x(x_val), (unsigned)(P.o_vals + (MODE == kLatSpmm ? 1 : 0) * vbuf), cls);
+        x_ring = wrap(x_ring + 1, P.nx);
+        x_val = wrap(x_val + 1, P.nx);
+        const int first_next = MODE == kLatSpmm ? 2 : 1;                    // ring index of the next value plane
+        const int last_val = MODE == kLatSpmm ? L : L + 1;
+        if (first_next <= last_val) load_cls(row_of_x(x_val), cld);
+        else {
+#pragma unroll
+            for (int q = 0; q < NPASS; ++q) cld[q] = P.ident;
+        }
+        lat_step_sync();
+
+        float accP[4], accC[4], accN[4], done[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) accP[v] = accC[v] = accN[v] = done[v] = 0.f;
+        int x_out = xs;          // lattice plane of the next result to leave (ring index 1)
+        const uint32_t ldob = (uint32_t)P.ldo * 4u;
+        auto flush = [&]() {
+            if (crow >= 0) {
+                char* const obase = static_cast<char*>(P.out) + (int64_t)row_of_x(x_out) * ldob;
+                typedef float f4v __attribute__((ext_vector_type(4)));
+                const f4v o = {done[0], done[1], done[2], done[3]};
+                __builtin_nontemporal_store(o, reinterpret_cast<f4v*>(obase + coo));
+            }
+            x_out = wrap(x_out + 1, P.nx);
+        };
+        for (int s = 0; s <= L + 1; ++s) {
+            // 1. the class bytes loaded during the previous step; the results that were completed by it
+            pin_cls(cld);
+#pragma unroll
+            for (int q = 0; q < NPASS; ++q) cls[q] = cld[q];
+            if (s >= 3) flush();
+            // 2. asynchronous fetches: the next halo plane, the next value plane
+            if (s + 1 <= L + 1) dma_ring(row_of_x(x_ring), (s + 1) & 1);
+            const int vnext = MODE == kLatSpmm ? s + 2 : s + 1;
+            if (vnext <= last_val) stage_vals(row_of_x(x_val), (unsigned)(P.o_vals + (vnext & (VB - 1)) * vbuf), cls);
+            x_ring = wrap(x_ring + 1, P.nx);
+            x_val = wrap(x_val + 1, P.nx);
+            // 3. class bytes for the next step
+            if (vnext + 1 <= last_val) load_cls(row_of_x(x_val), cld);
+            // 4. source plane s: targets s+1 (N, part 0), s (C, part 1), s-1 (P, part 2).  A target outside 1..L accumulates
+            // whatever its value buffer holds: it is never stored
+#pragma unroll
+            for (int v = 0; v < 4; ++v) accN[v] = 0.f;
+            if (crow >= 0) {
+                const char* const bb = sm + (s & 1) * PB + cen;
+                if constexpr (MODE == kLatSpmm) {
+                    // values: part p of a row = slots p·NTAP .. p·NTAP + NTAP - 1 of its canonical row
+                    const char* const vrow = sm + P.o_vals + g * VP;
+                    const char* const vp[3] = {vrow + ((s + 1) & 3) * vbuf, vrow + (s & 3) * vbuf, vrow + ((s - 1) & 3) * vbuf};
+                    constexpr int kF0 = 0, kF1 = NTAP / 4, kF2 = 2 * NTAP / 4;
+                    constexpr int kN0 = (NTAP - 1) / 4 - kF0 + 1, kN1 = (2 * NTAP - 1) / 4 - kF1 + 1, kN2 = (3 * NTAP - 1) / 4 - kF2 + 1;
+                    constexpr int kNA = kN0 > kN1 ? (kN0 > kN2 ? kN0 : kN2) : (kN1 > kN2 ? kN1 : kN2);
+                    float a[3][kNA * 4];
+                    constexpr int first[3] = {kF0, kF1, kF2}, count[3] = {kN0, kN1, kN2};
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) {
+#pragma unroll
+                        for (int m = 0; m < count[p]; ++m) {
+                            const uint4 w = *reinterpret_cast<const uint4*>(vp[p] + (first[p] + m) * 16);
+                            a[p][4 * m] = __uint_as_float(w.x), a[p][4 * m + 1] = __uint_as_float(w.y);
+                            a[p][4 * m + 2] = __uint_as_float(w.z), a[p][4 * m + 3] = __uint_as_float(w.w);
+                        }
+                    }
+                    uint4 b[NTAP];
+                    constexpr int kAhead = 3;
+#pragma unroll
+                    for (int i = 0; i < kAhead && i < NTAP; ++i) b[i] = *reinterpret_cast<const uint4*>(bb + tapb[i]);
+#pragma unroll
+                    for (int i = 0; i < NTAP; ++i) {
+                        if (i + kAhead < NTAP) b[i + kAhead] = *reinterpret_cast<const uint4*>(bb + tapb[i + kAhead]);
+                        asm volatile("" ::: "memory");
+                        float f[4];
+                        as4(b[i], f);
+                        const float a0 = a[0][i - 4 * first[0]], a1 = a[1][NTAP + i - 4 * first[1]], a2 = a[2][2 * NTAP + i - 4 * first[2]];
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) {
+                            accN[v] = fmaf(a0, f[v], accN[v]);
+                            accC[v] = fmaf(a1, f[v], accC[v]);
+                            accP[v] = fmaf(a2, f[v], accP[v]);
+                        }
+                    }
+                } else {
+                    // transposed walk: the source through tap i is the halo row at own + tap i; its entry towards a target
+                    // at dx sits at canonical slot (dx+1)·NTAP + (NTAP-1-i) of ITS value row
+                    const char* const vb0 = sm + P.o_vals + (s & 1) * vbuf + hrow * VP;
+                    int tapv[NTAP];
+#pragma unroll
+                    for (int i = 0; i < NTAP; ++i) tapv[i] = P.tap_row[i] * VP;
+                    uint4 b[NTAP];
+                    float a[NTAP][3];
+                    constexpr int kAhead = 2;
+                    auto fetch = [&](int i) {
+                        b[i] = *reinterpret_cast<const uint4*>(bb + tapb[i]);
+                        const char* const vr = vb0 + tapv[i];
+#pragma unroll
+                        for (int p = 0; p < 3; ++p) a[i][p] = *reinterpret_cast<const float*>(vr + ((2 - p) * NTAP + NTAP - 1 - i) * 4);
+                    };
+#pragma unroll
+                    for (int i = 0; i < kAhead && i < NTAP; ++i) fetch(i);
+#pragma unroll
+                    for (int i = 0; i < NTAP; ++i) {
+                        if (i + kAhead < NTAP) fetch(i + kAhead);
+                        asm volatile("" ::: "memory");
+                        float f[4];
+                        as4(b[i], f);
+                        // part index here counts the TARGET: N = s+1 (dx = +1), C = s (dx = 0), P = s-1 (dx = -1)
+                        const float aN = a[i][0], aC = a[i][1], aP = a[i][2];
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) {
+                            accN[v] = fmaf(aN, f[v], accN[v]);
+                            accC[v] = fmaf(aC, f[v], accC[v]);
+                            accP[v] = fmaf(aP, f[v], accP[v]);
+                        }
+                    }
+                }
+            }
+            // 5. target s-1 is complete; rotate
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                done[v] = accP[v];
+                accP[v] = accC[v];
+                accC[v] = accN[v];
+            }
+            lat_step_sync();
+        }
+        flush();   // target L (target L-1 left at the top of step L+1; with L = 1 nothing left earlier)
+    } else {
+        // ---- SDDMM -----------------------------------------------------------------------------------------------
+        struct Own {
+            uint4 row;
+            int cls;
+        };
+        auto load_own = [&](int prow, Own& o) {
+            o.cls = P.ident;
+            o.row = make_uint4(0, 0, 0, 0);
+            if (crow >= 0) {
+                o.cls = P.rcls[prow + crow];
+                o.row = *reinterpret_cast<const uint4*>(static_cast<const char*>(P.Own) + (int64_t)prow * P.ldown * 4 + cown);
+            }
+        };
+        auto pin_own = [&](Own& o) {
+            lat_pin(o.cls);
+            lat_pin(o.row.x);
+            lat_pin(o.row.y);
+            lat_pin(o.row.z);
+            lat_pin(o.row.w);
+        };
+        Own oP, oC, oN, old;
+        oP.row = oC.row = make_uint4(0, 0, 0, 0);
+        oP.cls = oC.cls = P.ident;
+        int x_own = xs;                                       // lattice plane of ring index 1
+        load_own(row_of_x(x_own), oN);
+        pin_own(oN);
+        x_own = wrap(x_own + 1, P.nx);
+        old = oN;
+        dma_ring(row_of_x(x_ring), 0);
+        x_ring = wrap(x_ring + 1, P.nx);
+        lat_step_sync();
+
+        float rP[RJ], rC[RJ], rN[RJ];
+#pragma unroll
+        for (int j = 0; j < RJ; ++j) rP[j] = rC[j] = rN[j] = 0.f;
+        float* const st = reinterpret_cast<float*>(sm + P.o_vals + g * VP);   // this row's stage row (wave-private)
+        int x_out = xs;
+        bool staged = false;
+        auto flush = [&]() {
+            // the row's gradients in stored order: 16-byte pieces, single elements at the end
+            if (crow >= 0) {
+                float* const go = static_cast<float*>(P.gvals) + (int64_t)(row_of_x(x_out) + crow) * NS;
+#pragma nounroll
+                for (int k0 = c * 4; k0 < NS; k0 += CL * 4) {
+                    const float4 w = *reinterpret_cast<const float4*>(st + k0);
+                    if (k0 + 4 <= NS) {
+                        typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+                        const f4u o = {w.x, w.y, w.z, w.w};
+                        __builtin_nontemporal_store(o, reinterpret_cast<f4u*>(go + k0));
+                    } else {
+                        const float wv[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (k0 + j < NS) go[k0 + j] = wv[j];
+                    }
+                }
+            }
+            x_out = wrap(x_out + 1, P.nx);
+        };
+        for (int s = 0; s <= L + 1; ++s) {
+            // 1. take over the rows loaded during the previous step: they are target s+1 now
+            if (s >= 1) {
+                pin_own(old);
+                oP = oC, oC = oN, oN = old;
+            }
+            if (staged) flush();
+            staged = false;
+            // 2. the next halo plane; 3. own rows of target s+2
+            if (s + 1 <= L + 1) dma_ring(row_of_x(x_ring), (s + 1) & 1);
+            x_ring = wrap(x_ring + 1, P.nx);
+            if (s + 2 <= L) load_own(row_of_x(x_own), old);
+            x_own = wrap(x_own + 1, P.nx);
+            // 4. source plane s
+            if (crow >= 0) {
+                const char* const bb = sm + (s & 1) * PB + cen;
+                float on[4], oc[4], op[4];
+                as4(oN.row, on);
+                as4(oC.row, oc);
+                as4(oP.row, op);
+                uint4 b[NTAP];
+                constexpr int kAhead = 3;
+#pragma unroll
+                for (int i = 0; i < kAhead && i < NTAP; ++i) b[i] = *reinterpret_cast<const uint4*>(bb + tapb[i]);
+#pragma unroll
+                for (int i = 0; i < NTAP; ++i) {
+                    if (i + kAhead < NTAP) b[i + kAhead] = *reinterpret_cast<const uint4*>(bb + tapb[i + kAhead]);
+                    asm volatile("" ::: "memory");
+                    float f[4];
+                    as4(b[i], f);
+                    auto dot = [&](const float (&o)[4]) {
+                        float d = o[0] * f[0];
+#pragma unroll
+                        for (int v = 1; v < 4; ++v) d = fmaf(o[v], f[v], d);
+                        return group_sum<float, CL>(d);
+                    };
+                    const float dN = dot(on), dC = dot(oc), dP = dot(op);
+                    // slot p·NTAP + i belongs to lane slot % CL, register slot / CL
+                    const int sN = i, sC = NTAP + i, sP = 2 * NTAP + i;
+#pragma unroll
+                    for (int j = 0; j < RJ; ++j) {
+                        if (sN / CL == j) rN[j] = c == sN % CL ? dN : rN[j];
+                        if (sC / CL == j) rC[j] = c == sC % CL ? dC : rC[j];
+                        if (sP / CL == j) rP[j] = c == sP % CL ? dP : rP[j];
+                    }
+                }
+                // 5. target s-1 is complete: its dots go to the stage row at their STORED positions
+                if (s >= 2) {
+                    const bool plain = oP.cls == P.ident;
+#pragma unroll
+                    for (int j = 0; j < RJ; ++j) {
+                        const int slot = j * CL + c;
+                        if (slot < NS) {
+                            const int k = plain ? slot : (int)kidx_s[oP.cls * 32 + slot];
+                            st[k] = P.alpha * rP[j];
+                        }
+                    }
+                    staged = true;
+                }
+            } else if (s >= 2) {
+                staged = true;     // keeps x_out in step for lanes without a row (flush() only advances it)
+            }
+#pragma unroll
+            for (int j = 0; j < RJ; ++j) {
+                rP[j] = rC[j];
+                rC[j] = rN[j];
+            }
+            lat_step_sync();
+        }
+        if (staged) flush();
+    }
+}
+
+// ---- host side ------------------------------------------------------------------------------------------------------
+
+// Fills the LDS layout of P for (mode, CL); returns the dynamic LDS bytes or a negative status.
+inline int march_layout(MarchParams& P, int mode, int cl, int nt, int ntap) {
+    if (P.ty <= 0 || P.tz <= 0 || P.ry < 0 || P.rz < 0 || P.ncls <= 0 || P.ncls > kMarchMaxCls || ntap != 9) return TSGU_ERR_BAD_ARG;
+    const int HR = (P.ty + 2 * P.ry) * (P.tz + 2 * P.rz), NR = P.ty * P.tz, RB = cl * 16;
+    const int VP = (3 * ntap + 3) / 4 * 4 * 4;
+    const int NG = nt / cl;
+    if ((int64_t)HR * cl > (int64_t)kMarchND * nt || NR > NG) return TSGU_ERR_TOO_LARGE;
+    if (mode == kLatSpmmT && HR > 2 * NG) return TSGU_ERR_TOO_LARGE;
+    int64_t o = 2 * (int64_t)HR * RB;
+    P.o_vals = (int)o;
+    if (mode == kLatSpmm) o += 4 * (int64_t)NR * VP;
+    else if (mode == kLatSddmm) o += (int64_t)NR * VP;
+    else o += 2 * (int64_t)HR * VP;
+    P.o_tab = (int)o;
+    o += P.ncls * 32;
+    P.o_rows = (int)o;
+    o += lat_round16((mode == kLatSpmmT ? HR : NR) * 4);
+    if (o > kLatMaxLds) return TSGU_ERR_TOO_LARGE;
+    P.lds_bytes = (int)o;
+    return (int)o;
+}
+
+template <typename V, int CL, int MODE, int NT>
+int march_launch(const MarchParams& P, hipStream_t stream) {
+    static std::atomic<uint64_t> allowed{0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return TSGU_ERR_RUNTIME;
+    if (!(allowed.load(std::memory_order_acquire) >> dev & 1ull)) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&march_kernel<V, CL, MODE, NT, 9>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                kLatMaxLds) != hipSuccess)
+            return TSGU_ERR_RUNTIME;
+        allowed.fetch_or(1ull << dev, std::memory_order_release);
+    }
+    hipLaunchKernelGGL((march_kernel<V, CL, MODE, NT, 9>), dim3((unsigned)P.nblocks), dim3(NT), (size_t)P.lds_bytes, stream, P);
+    return check_launch();
+}
+
+}  // namespace tsgu
