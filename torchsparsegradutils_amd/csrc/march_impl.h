@@ -30,6 +30,8 @@
 //                                 No transposed pattern, no transposed plan.
 #pragma once
 
+#include <type_traits>
+
 #include "lattice_impl.h"
 
 namespace tsgu {
@@ -65,6 +67,43 @@ __device__ __forceinline__ void lat_dma4(const void* sbase64, uint32_t voff, uns
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2 nt\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(sbase64), "s"(lds_wave_base) : "memory");
+}
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void lat_static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        lat_static_for<I + 1, N>(f);
+    }
+}
+
+// N <= 8 partial sums per lane -> lane c < N of an 8-lane group gets the group total of d[c] (the other lanes: anything).
+// 21 instructions for eight sums (eight butterflies cost 40), and the same summation tree as group_sum<float, 8>:
+// ((0+1)+(2+3)) + ((4+5)+(6+7)), bit for bit.
+// (scalars, not an array: a select between two array elements becomes an indexed access and the array then lives in a
+// ladder of v_cndmask)
+template <int CTRL>
+__device__ __forceinline__ float lat_pair_sum(bool odd, float a0, float a1) {   // "even" lanes keep a0, "odd" lanes a1
+    const float u = odd ? a1 : a0, w = odd ? a0 : a1;
+    return u + dpp_move<CTRL>(w);
+}
+template <int N>
+__device__ __forceinline__ float group_sum_t8(float d0, float d1, float d2, float d3, float d4, float d5, float d6, float d7, int c) {
+    static_assert(N >= 1 && N <= 8, "one value per lane of the group");
+    const bool b0 = (c & 1) != 0, b1 = (c & 2) != 0, b2 = (c & 4) != 0;
+    // lanes c^1
+    const float t0 = N > 1 ? lat_pair_sum<0xB1>(b0, d0, d1) : d0 + dpp_move<0xB1>(d0);
+    const float t1 = N > 3 ? lat_pair_sum<0xB1>(b0, d2, d3) : (N > 2 ? d2 + dpp_move<0xB1>(d2) : 0.f);
+    const float t2 = N > 5 ? lat_pair_sum<0xB1>(b0, d4, d5) : (N > 4 ? d4 + dpp_move<0xB1>(d4) : 0.f);
+    const float t3 = N > 7 ? lat_pair_sum<0xB1>(b0, d6, d7) : (N > 6 ? d6 + dpp_move<0xB1>(d6) : 0.f);
+    // lanes c^2
+    const float r0 = N > 2 ? lat_pair_sum<0x4E>(b1, t0, t1) : t0 + dpp_move<0x4E>(t0);
+    const float r1 = N > 6 ? lat_pair_sum<0x4E>(b1, t2, t3) : (N > 4 ? t2 + dpp_move<0x4E>(t2) : 0.f);
+    // lanes c^4: lanes 0-3 of a group add lane + 4 (row_shl:4), lanes 4-7 add lane - 4 (row_shr:4)
+    const float lo = r0 + dpp_move<0x104>(r0);
+    if constexpr (N <= 4) return lo;
+    const float hi = r1 + dpp_move<0x114>(r1);
+    return b2 ? hi : lo;
 }
 
 template <typename V, int CL, int MODE, int NT, int NTAP>
@@ -468,6 +507,7 @@ __global__ __launch_bounds__(NT, 4) void march_kernel(const MarchParams P) {
                 as4(oC.row, oc);
                 as4(oP.row, op);
                 uint4 b[NTAP];
+                float pd[3][NTAP];
                 constexpr int kAhead = 3;
 #pragma unroll
                 for (int i = 0; i < kAhead && i < NTAP; ++i) b[i] = *reinterpret_cast<const uint4*>(bb + tapb[i]);
@@ -477,20 +517,51 @@ __global__ __launch_bounds__(NT, 4) void march_kernel(const MarchParams P) {
                     asm volatile("" ::: "memory");
                     float f[4];
                     as4(b[i], f);
+                    // (as instructions: the vectoriser would pair the dots of neighbouring taps into v_pk_fma_f32 and pay two
+                    // register moves per pair to line their operands up)
                     auto dot = [&](const float (&o)[4]) {
-                        float d = o[0] * f[0];
+                        float d;
+                        asm("v_mul_f32 %0, %1, %2" : "=v"(d) : "v"(o[0]), "v"(f[0]));
 #pragma unroll
-                        for (int v = 1; v < 4; ++v) d = fmaf(o[v], f[v], d);
-                        return group_sum<float, CL>(d);
+                        for (int v = 1; v < 4; ++v) asm("v_fmac_f32 %0, %1, %2" : "+v"(d) : "v"(o[v]), "v"(f[v]));
+                        return d;
                     };
-                    const float dN = dot(on), dC = dot(oc), dP = dot(op);
-                    // slot p·NTAP + i belongs to lane slot % CL, register slot / CL
-                    const int sN = i, sC = NTAP + i, sP = 2 * NTAP + i;
+                    pd[0][i] = dot(on), pd[1][i] = dot(oc), pd[2][i] = dot(op);
+                }
+                // the 3·NTAP partial dots of this step, by canonical slot p·NTAP + i; slot j·CL + c belongs to lane c, register j
+                if constexpr (CL == 8) {
+                    // eight slots at a time: the transposed reduction leaves the total of slot 8j + c in lane c
+                    lat_static_for<0, RJ>([&](auto J) {
+                        constexpr int j = decltype(J)::value;
+                        auto sl = [&](auto E) -> float {      // partial dot of canonical slot 8j + e
+                            constexpr int slot = 8 * j + decltype(E)::value;
+                            if constexpr (slot < NS) return pd[slot / NTAP][slot % NTAP];
+                            else return 0.f;
+                        };
+                        using std::integral_constant;
+                        const float tot = group_sum_t8<(NS - 8 * j < 8 ? NS - 8 * j : 8)>(
+                            sl(integral_constant<int, 0>{}), sl(integral_constant<int, 1>{}), sl(integral_constant<int, 2>{}), sl(integral_constant<int, 3>{}),
+                            sl(integral_constant<int, 4>{}), sl(integral_constant<int, 5>{}), sl(integral_constant<int, 6>{}), sl(integral_constant<int, 7>{}), c);
 #pragma unroll
-                    for (int j = 0; j < RJ; ++j) {
-                        if (sN / CL == j) rN[j] = c == sN % CL ? dN : rN[j];
-                        if (sC / CL == j) rC[j] = c == sC % CL ? dC : rC[j];
-                        if (sP / CL == j) rP[j] = c == sP % CL ? dP : rP[j];
+                        for (int p = 0; p < 3; ++p) {
+                            const int lo = (p * NTAP > 8 * j ? p * NTAP : 8 * j) - 8 * j, hi = ((p + 1) * NTAP < 8 * j + 8 ? (p + 1) * NTAP : 8 * j + 8) - 8 * j;
+                            if (lo < hi) {
+                                float& r = p == 0 ? rN[j] : (p == 1 ? rC[j] : rP[j]);
+                                const bool whole = lo == 0 && (hi == 8 || 8 * j + hi == NS);   // (lanes beyond the last slot are never read)
+                                r = whole || (c >= lo && c < hi) ? tot : r;
+                            }
+                        }
+                    });
+                } else {
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) {
+#pragma unroll
+                        for (int i = 0; i < NTAP; ++i) {
+                            const float tot = group_sum<float, CL>(pd[p][i]);
+                            const int slot = p * NTAP + i;
+                            float& r = p == 0 ? rN[slot / CL] : (p == 1 ? rC[slot / CL] : rP[slot / CL]);
+                            r = c == slot % CL ? tot : r;
+                        }
                     }
                 }
                 // 5. target s-1 is complete: its dots go to the stage row at their STORED positions
