@@ -588,10 +588,10 @@ ENABLE_MARCH = os.environ.get("TSGU_ENABLE_MARCH", "1") == "1"
 _MARCH_CFG_ENV = os.environ.get("TSGU_MARCH_CFG", "")   # "ty,tz,nseg,threads" overrides the choice (experiments)
 MARCH_TAPS = 9
 MARCH_MAX_CLASSES = 64
-_MARCH_WAVES_PER_CU = {0: 20, 1: 16, 2: 16}     # resident waves per CU by the kernels' register use (84 / 97 / 99 VGPRs)
-# workgroup sizes in order of preference (measured at C2: the small tile hides the DMA latency with more independent
-# workgroups; the transposed product stages two rings and prefers the smaller halo of the 8 x 8 tile)
-_MARCH_THREADS = {0: (256, 512), 1: (256, 512), 2: (512, 256)}
+_MARCH_WAVES_PER_CU = {0: 20, 1: 16, 2: 16}     # resident waves per CU the segment count is planned for
+# workgroup sizes in order of preference: the first that fits the lattice is taken (measured at C2, same box, us:
+# forward 4x8/256: 80.8-85.5, 8x8/512: 88.1;  SDDMM 8x8/512: 87.4, 4x8/256: 94.6-101.7;  transposed 8x8/512: 102.4, 4x8/256: 99.5-103.0)
+_MARCH_THREADS = {0: (256, 512), 1: (512, 256), 2: (512, 256)}
 _MARCH_HALO_COST = {0: 0.1, 1: 0.1, 2: 0.8}     # what a halo row costs relative to an own row
 
 
@@ -694,6 +694,8 @@ def march_config_for(plan: LatticePlan, mode: int, vtype: int, p: int, lds_bytes
             cost = -(-nwg // slots) * (seg_len + 5) / util
             if best is None or cost < best[0]:
                 best = (cost, ty, tz, ns_, threads, lds)
+        if best is not None:
+            break
     cfg = None
     if best is not None:
         _, ty, tz, nseg, threads, lds = best

@@ -502,10 +502,20 @@ __global__ __launch_bounds__(NT, 4) void march_kernel(const MarchParams P) {
             // 4. source plane s
             if (crow >= 0) {
                 const char* const bb = sm + (s & 1) * PB + cen;
-                float on[4], oc[4], op[4];
-                as4(oN.row, on);
-                as4(oC.row, oc);
-                as4(oP.row, op);
+                // The dots of targets s+1 and s share every dense row: they run as the two halves of packed instructions (own
+                // columns paired {N, C}, the dense column broadcast by op_sel — each half is the same mul + fma chain as the
+                // scalar form, bit for bit); target s-1 runs scalar.
+                typedef float f2v __attribute__((ext_vector_type(2)));
+                f2v nc[4];
+                float op[4];
+                {
+                    float on[4], oc[4];
+                    as4(oN.row, on);
+                    as4(oC.row, oc);
+                    as4(oP.row, op);
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) nc[v] = f2v{on[v], oc[v]};
+                }
                 uint4 b[NTAP];
                 float pd[3][NTAP];
                 constexpr int kAhead = 3;
@@ -517,16 +527,19 @@ __global__ __launch_bounds__(NT, 4) void march_kernel(const MarchParams P) {
                     asm volatile("" ::: "memory");
                     float f[4];
                     as4(b[i], f);
-                    // (as instructions: the vectoriser would pair the dots of neighbouring taps into v_pk_fma_f32 and pay two
-                    // register moves per pair to line their operands up)
-                    auto dot = [&](const float (&o)[4]) {
-                        float d;
-                        asm("v_mul_f32 %0, %1, %2" : "=v"(d) : "v"(o[0]), "v"(f[0]));
+                    const f2v f01 = {f[0], f[1]}, f23 = {f[2], f[3]};
+                    f2v d2;
+                    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(d2) : "v"(nc[0]), "v"(f01));
+                    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(d2) : "v"(nc[1]), "v"(f01));
+                    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(d2) : "v"(nc[2]), "v"(f23));
+                    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(d2) : "v"(nc[3]), "v"(f23));
+                    // (as instructions: the vectoriser would pair the dots of neighbouring taps instead and pay two register
+                    // moves per pair to line their operands up)
+                    float d;
+                    asm("v_mul_f32 %0, %1, %2" : "=v"(d) : "v"(op[0]), "v"(f[0]));
 #pragma unroll
-                        for (int v = 1; v < 4; ++v) asm("v_fmac_f32 %0, %1, %2" : "+v"(d) : "v"(o[v]), "v"(f[v]));
-                        return d;
-                    };
-                    pd[0][i] = dot(on), pd[1][i] = dot(oc), pd[2][i] = dot(op);
+                    for (int v = 1; v < 4; ++v) asm("v_fmac_f32 %0, %1, %2" : "+v"(d) : "v"(op[v]), "v"(f[v]));
+                    pd[0][i] = d2.x, pd[1][i] = d2.y, pd[2][i] = d;
                 }
                 // the 3·NTAP partial dots of this step, by canonical slot p·NTAP + i; slot j·CL + c belongs to lane c, register j
                 if constexpr (CL == 8) {
