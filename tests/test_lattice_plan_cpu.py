@@ -232,3 +232,97 @@ def test_config_choice_is_within_limits():
 
     ty, tz, nseg, threads, ring, cpl = lt.choose_config(plan, 0, 0, 32, 4, fake_lds)
     assert ty <= plan.ny and tz <= plan.nz and 1 <= nseg <= plan.nx and threads in (512, 1024) and 4 <= ring <= 8
+
+
+# ---- plane-march kernels (csrc/march_impl.h): the tables the host derives from a stored-order plan ------------------------
+def _emulate_march(plan, mt, crow, col, ty, tz, nseg):
+    """Walk every workgroup / source plane / row / tap like the march kernels: the value the kernel takes for (target row,
+    part, tap) must be the entry whose column is the row at that displacement — for the stored-order product through
+    kidx of the TARGET row, for the transposed product through kidx of the SOURCE row.  Returns the entries checked (twice)."""
+    nb, nx, ny, nz = plan.nb, plan.nx, plan.ny, plan.nz
+    cr, cc = crow.numpy().astype(np.int64), col.numpy().astype(np.int64)
+    rcls = plan.rcls.numpy()
+    kidx = mt.kidx_host.numpy()
+    seg_len = -(-nx // nseg)
+    seen_f = np.zeros(cc.size, dtype=np.int32)
+    seen_t = np.zeros(cc.size, dtype=np.int32)
+
+    def row(item, x, y, z):
+        return ((item * nx + x % nx) * ny + y % ny) * nz + z % nz
+
+    for item in range(nb):
+        for seg in range(nseg):
+            xs = seg * seg_len
+            L = min(seg_len, nx - xs)
+            assert L >= 1
+            for y0 in range(0, ny, ty):
+                for z0 in range(0, nz, tz):
+                    for s in range(L + 2):                       # source plane: ring index s = lattice plane xs - 1 + s
+                        xsrc = xs - 1 + s
+                        for ly in range(min(ty, ny - y0)):
+                            for lz in range(min(tz, nz - z0)):
+                                y, z = y0 + ly, z0 + lz
+                                for p in range(3):               # part p: target plane t = s + 1 - p, dx = p - 1 (source = target + dx)
+                                    t = s + 1 - p
+                                    if not 1 <= t <= L:
+                                        continue
+                                    xt = xs - 1 + t
+                                    j = row(item, xt, y, z)
+                                    for i, (dy, dz) in enumerate(mt.taps):
+                                        # stored-order product: entry of target j towards (p - 1, dy, dz)
+                                        k = cr[j] + kidx[rcls[j]][p * 9 + i]
+                                        assert cc[k] == row(item, xsrc, y + dy, z + dz)
+                                        seen_f[k] += 1
+                                        # transposed product: the source through tap i is the row at own + tap; its entry towards
+                                        # the target (dx = t - s = 1 - p) sits at canonical slot (dx + 1)·9 + 8 - i of ITS row
+                                        src = row(item, xsrc, y + dy, z + dz)
+                                        k = cr[src] + kidx[rcls[src]][(2 - p) * 9 + 8 - i]
+                                        assert cc[k] == j
+                                        seen_t[k] += 1
+    assert (seen_f == 1).all() and (seen_t == 1).all()
+    return int(seen_f.sum() + seen_t.sum())
+
+
+@pytest.mark.parametrize("nb,nx,ny,nz,tile,nseg", [(1, 5, 6, 9, (4, 8), 2), (1, 3, 3, 3, (8, 8), 3), (2, 4, 5, 8, (2, 8), 1), (1, 7, 8, 8, (8, 8), 7)])
+def test_march_tables_lead_to_the_stored_entries(nb, nx, ny, nz, tile, nseg):
+    crow, col = _stencil(nx, ny, nz, True, 27, False, nb)
+    n = nb * nx * ny * nz
+    g = pt.RowGather(crow, col, n, n)
+    plan = lt.build_lattice_plan(g, dims=(nb, nx, ny, nz))
+    assert plan is not None and plan.uniform_len == 27
+    mt = lt.march_tables(plan)
+    assert mt is not None and lt.march_tables(plan) is mt
+    assert mt.taps == [(dy, dz) for dy in (-1, 0, 1) for dz in (-1, 0, 1)]
+    k = mt.kidx_host.numpy()
+    assert k.shape == (plan.ncls, 32) and (np.sort(k[:, :27], axis=1) == np.arange(27)).all() and (k[:, 27:] == 0xFF).all()
+    assert (k[mt.ident, :27] == np.arange(27)).all()
+    assert _emulate_march(plan, mt, crow, col, tile[0], tile[1], nseg) == 2 * col.numel()
+
+
+@pytest.mark.parametrize("what", ["truncated", "seven", "lower", "two_planes"])
+def test_march_tables_only_for_full_periodic_boxes(what):
+    if what == "two_planes":
+        crow, col = _stencil(2, 6, 8, True)          # dx = -1 and +1 meet the same plane: rows hold 18 entries
+        n = 96
+    else:
+        crow, col = _stencil(5, 6, 8, what != "truncated", 7 if what == "seven" else 27, what == "lower")
+        n = 240
+    plan = lt.build_lattice_plan(pt.RowGather(crow, col, n, n))
+    if plan is not None:
+        assert lt.march_tables(plan) is None
+
+
+def test_march_config_choice_is_within_limits():
+    from torchsparsegradutils_amd import _backend as be
+
+    be.load_library()      # the LDS layout is computed by the library (host code: no GPU needed)
+    crow, col = _stencil(6, 9, 16, True)
+    plan = lt.build_lattice_plan(pt.RowGather(crow, col, 864, 864))
+    for mode in (0, 1, 2):
+        for p in (32, 64):
+            cfg = lt.march_config_for(plan, mode, 0, p, be.march_lds_bytes)
+            assert cfg is not None and cfg.march and cfg.lds_bytes <= 160 * 1024
+            assert cfg.ty * cfg.tz <= cfg.threads // (p // 4) and 1 <= cfg.nseg <= plan.nx
+            assert cfg.struct.ntap == 9 and cfg.struct.ident == cfg.tables.ident
+        assert lt.march_config_for(plan, mode, 0, 16, be.march_lds_bytes) is None      # 16 columns: general sweep
+        assert lt.march_config_for(plan, mode, 1, 32, be.march_lds_bytes) is None      # bf16: general sweep
