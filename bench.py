@@ -455,12 +455,15 @@ def main():
                 "first_steps_ms": [round(x, 2) for x in first_ms],
                 "warmup_steps_run": warm_steps,
                 "plan_policy": f"first sight of a pattern: plan-free gather kernels + transposed pattern; from use {_ops.PLAN_AFTER_USES + 1} on "
-                               + ("(lattice stencil: the lattice plans — row classes, found by two row-analysis kernels — are built at FIRST sight, "
-                                  "first_steps_ms[0] includes that; every step runs on the plane-sweep kernels and no transposed "
-                                  "pattern is ever built)" if lattice else
+                               + ("(lattice stencil: the lattice plan — row classes, found by two row-analysis kernels — is built at FIRST sight, "
+                                  "first_steps_ms[0] includes that; every step runs on the plane-march / plane-sweep kernels and neither a "
+                                  "transposed pattern nor, for a periodic stencil, a transposed plan is ever built)" if lattice else
                                   ("the row-pair plans are built on a worker thread + side stream while the steps keep running plan-free "
                                    "(first_steps_ms[1:] are such steps); the warm-up joins the build" if _ops.PLAN_ASYNC else
                                    "the row-pair plans are built inline (first_steps_ms[1] includes the build)")),
+                "first_step_note": "torch.autograd imports torch.fx.experimental.symbolic_shapes (sympy) inside the first backward that is given "
+                                   "explicit output gradients (150-450 ms); the package starts that import on a helper thread when it is "
+                                   "imported (TSGU_PREFETCH_IMPORTS=0 restores torch's lazy behaviour), so first_steps_ms[0] does not contain it",
                 "plan_join_ms_after_3_steps": round(plan_join_ms, 1),
                 "plans": plan_stats,
             },

@@ -45,6 +45,9 @@ for kind in ("fetch", "write"):
 
 def role(kname):
     """forward / fused_backward / ... from the template arguments <V, I, CL, EP, MODE, PERM, SLOTS, SMALL>."""
+    if "march_kernel" in kname:     # <V, CL, MODE, NT, NTAP>: the bench's traffic keys are shared with the plane sweep
+        args = kname.split("<", 1)[1].split(">")[0].replace(" ", "").split(",")
+        return {"0": "lattice_spmm", "1": "lattice_sddmm", "2": "lattice_spmm_t"}.get(args[2])
     if "lattice_kernel" in kname:   # <V, CL, CPL, MODE, NT, NCH>
         args = kname.split("<", 1)[1].split(">")[0].replace(" ", "").split(",")
         return {"0": "lattice_spmm", "1": "lattice_sddmm", "2": "lattice_spmm_t"}.get(args[3])
@@ -76,7 +79,8 @@ if traffic:
         bench = json.load(open(os.path.join(src, "bench.json")))
     except Exception:  # noqa: BLE001
         pass
-    form = ("lattice plane sweep" if "lattice_kernel" in json.dumps(bench.get("kernels_ms", {})) else
+    form = ("plane march" if "march_kernel" in json.dumps(bench.get("kernels_ms", {})) else
+            "lattice plane sweep" if "lattice_kernel" in json.dumps(bench.get("kernels_ms", {})) else
             "class dictionary" if "class dictionary" in json.dumps(bench.get("kernels_ms", {})) else "per-workgroup streams")
     out = {
         "_comment": "HBM bytes per launch at C2 (N=1e6, 27 nnz/row, 32 RHS, fp32/int32) from two rocprofv3 PMC passes around bench.py "

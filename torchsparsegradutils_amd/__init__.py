@@ -30,3 +30,26 @@ __all__ = [
 ]
 
 __version__ = "0.1.0"
+
+
+def _prefetch_lazy_torch_modules() -> None:
+    """torch.autograd's Python front end imports torch.fx.experimental.symbolic_shapes (and with it sympy: 150-450 ms)
+    the first time a backward pass is given explicit output gradients — inside the first training step of every process.
+    Start that import on a helper thread now, while the caller is still building its operands (TSGU_PREFETCH_IMPORTS=0: off)."""
+    import os
+
+    if os.environ.get("TSGU_PREFETCH_IMPORTS", "1") != "1":
+        return
+    import importlib
+    import threading
+
+    def work():
+        try:
+            importlib.import_module("torch.fx.experimental.symbolic_shapes")
+        except Exception:  # noqa: BLE001  (purely an optimisation)
+            pass
+
+    threading.Thread(target=work, name="tsgu-import-prefetch", daemon=True).start()
+
+
+_prefetch_lazy_torch_modules()

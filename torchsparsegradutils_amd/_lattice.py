@@ -242,7 +242,7 @@ def build_lattice_plan(g, value_crow: Optional[torch.Tensor] = None, dims: Optio
     return plan
 
 
-SAMPLE_ROWS = 2048
+SAMPLE_ROWS = 256
 
 
 def _clusters_to_dims(pos, n: int) -> Optional[Tuple[int, int]]:
@@ -279,30 +279,35 @@ def _clusters_to_dims(pos, n: int) -> Optional[Tuple[int, int]]:
 
 
 def _sample_dims(g) -> Optional[Tuple[int, int, int, int]]:
-    """(nb, nx, ny, nz) guessed on the HOST from two small samples of rows (no device op that would have to be loaded first):
-    SAMPLE_ROWS rows from the middle of the matrix give the strides (interior rows: no wrap-around offsets), the first
-    SAMPLE_ROWS rows (the x = 0 plane of the first item) give the x period.  Only a proposal: the row kernels check every entry."""
-    import numpy as np
+    """(nb, nx, ny, nz) guessed on the HOST from small samples of rows: SAMPLE_ROWS rows from the middle of the matrix give
+    the strides (interior rows: no wrap-around offsets), the first SAMPLE_ROWS rows (the x = 0 plane of the first item) give
+    the x period.  Only a proposal: the row kernels check every entry.  Plain Python on two short lists — on a fresh
+    process every distinct library routine (a torch reduction, numpy's unique) first has to be paged in, which costs
+    more than this whole function."""
+    from collections import Counter
 
     n = g.n_rows
     m = min(n, SAMPLE_ROWS)
     r0 = max(0, n // 2 - m // 2)
 
     def sample(first):
-        ptr = g.crow[first:first + m + 1].cpu().numpy().astype(np.int64)
-        cols = g.col[int(ptr[0]):int(ptr[-1])].cpu().numpy().astype(np.int64)
-        rows = np.repeat(np.arange(first, first + m, dtype=np.int64), np.diff(ptr))
-        return rows, cols
+        ptr = g.crow[first:first + m + 1].tolist()
+        cols = g.col[ptr[0]:ptr[-1]].tolist()
+        return ptr, cols
 
     found = None
     # the strides from interior rows: the middle of the matrix, or (block-diagonal batches put an item boundary there) two
     # other places
     for first in dict.fromkeys((r0, max(0, n // 3 - m // 2), max(0, min(n - m, (2 * n) // 3 + 17 * m)))):
-        rows, cols = sample(first)
-        if cols.size == 0:
+        ptr, cols = sample(first)
+        if not cols:
             continue
-        uniq, cnt = np.unique(np.abs(cols - rows), return_counts=True)
-        found = _clusters_to_dims(uniq[(cnt * 2 > m) & (uniq > 0)].tolist(), n)
+        cnt = Counter()
+        base = ptr[0]
+        for i in range(m):
+            r = first + i
+            cnt.update(abs(c - r) for c in cols[ptr[i] - base:ptr[i + 1] - base])
+        found = _clusters_to_dims(sorted(o for o, k in cnt.items() if k * 2 > m and o > 0), n)
         if found is not None and n % found[1] == 0 and n % found[0] == 0:
             break
         found = None
@@ -310,8 +315,12 @@ def _sample_dims(g) -> Optional[Tuple[int, int, int, int]]:
         return None
     nz, d2 = found
     planes = n // d2
-    rows, cols = sample(0)
-    mx = int(np.abs(cols // d2 - rows // d2).max()) if cols.size else 0
+    ptr, cols = sample(0)
+    base, mx = ptr[0], 0
+    for i in range(m):
+        px = i // d2
+        for c in cols[ptr[i] - base:ptr[i + 1] - base]:
+            mx = max(mx, abs(c // d2 - px))
     nx = planes if mx <= 1 else mx + 1
     if nx < 1 or planes % nx:
         return None
@@ -367,14 +376,14 @@ def build_lattice_plan_hip(g, be, forward: Optional[LatticePlan] = None, dims=No
     rep = torch.from_numpy(host[4:4 + slots][order].astype(np.int64)).to(dev)
     table = torch.empty((ncls, 32), dtype=torch.int32, device=dev)
     be.lattice_row_codes(crow, col, dims, rep, table, disp=disp)
-    lens = (table >= 0).sum(1).to(torch.uint8)
+    tab_host = table.cpu()                                   # [classes][32] words: the rest of the class bookkeeping is host work
+    lens = torch.from_numpy((tab_host.numpy() >= 0).sum(1).astype(np.uint8)).to(dev)
     rcls = torch.zeros(n + 64, dtype=torch.uint8, device=dev)
     status.zero_()
     be.lattice_rows(crow, col, dims, status, slot, remap=torch.from_numpy(remap).to(dev), ctable=table, lens=lens, rcls=rcls, disp=disp)
-    tab = torch.cat((table.reshape(-1), status)).cpu()      # exact check: hash collisions must not pass
-    if int(tab[-4]) != 0:
+    if int(status[:1].cpu()[0]) != 0:                        # exact check: hash collisions must not pass
         return None
-    tab = tab[:-4].view(ncls, 32).to(torch.int64)
+    tab = tab_host.to(torch.int64)
     cl = (tab >= 0).sum(1)
     if kind == 0:
         uniform = int(cl[0]) if bool((cl == cl[0]).all()) else 0
