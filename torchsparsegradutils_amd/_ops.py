@@ -65,6 +65,9 @@ def _lattice_cfg(plan: RowGather, mode: int, dense: torch.Tensor, *others: torch
         return None
     if dense.dtype not in LATTICE_DTYPES:
         return None
+    row_bytes = dense.size(-1) * dense.element_size()
+    if row_bytes % 16 or row_bytes // 16 not in (2, 4, 8, 16):
+        return None            # dense rows the sweeps are not compiled for: do not even analyse the pattern
     fwd = _lattice_plan(plan)
     if fwd is None:
         return None
