@@ -109,6 +109,9 @@ __global__ __launch_bounds__(kBlock) void sptrsm_syncfree_kernel(const TrsmParam
         V acc = 0;
         V diag = 0;
         bool dead = false;
+        // the right-hand side is requested BEFORE the row waits for its dependencies: its latency is off the critical path
+        V rhs = 0;
+        if (ep == 0 && col_ok) rhs = B[row * P.ldb + c * P.bcs];
         for (int64_t base = s; base < e; base += EP) {
             // entries are visited farthest-dependency first: ascending columns for a lower sweep, descending for an
             // upper one.  The nearest rows are the ones solved last (the critical path), so everything else of the row
@@ -163,7 +166,6 @@ __global__ __launch_bounds__(kBlock) void sptrsm_syncfree_kernel(const TrsmParam
             diag += shfl_xor_acc(diag, m);
         }
         if (ep == 0 && col_ok) {
-            const V rhs = B[row * P.ldb + c * P.bcs];
             V x = rhs - acc;
             if (!P.unit) x = x / diag;
             Bits xb = S::bits(x);
