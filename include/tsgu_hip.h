@@ -249,7 +249,7 @@ int tsgu_csr_sddmm_rowpack(int vtype, int itype, int64_t n_rows, int64_t n_cols,
  *   padded entries (k >= lens[c]) hold 0x7ff00: reads that far beyond the row's own position are beyond the LDS allocation and
  *   return zero on gfx950, so padded entries contribute exactly 0 and no dense row is touched that the sparse row does not reference.
  * Sums run in ascending entry order of the walked pattern (the order of the plan-free kernels).  fp32 and bf16 values
- * for kind 0 (fp32 accumulation), fp32 for kind 1; p·sizeof(value)/16 in {2, 4, 8, 16}; 16-byte aligned dense rows.
+ * for kind 0 (fp32 accumulation), fp32 for kind 1; p·sizeof(value)/16 in {2, 4, 8, 16} (SpMM, fp32: also 1); 16-byte aligned dense rows.
  */
 typedef struct tsgu_lattice_plan {
     int32_t kind;             /* 0: stored-order walk (SpMM / SDDMM); 1: transposed walk (Aᵀ·G) */
@@ -280,6 +280,14 @@ int tsgu_lattice_lds_bytes(int mode, int vtype, int64_t p, int ty, int tz, int r
  * in A's own order, `B` is G).  n_rows = nb·nx·ny·nz. */
 int tsgu_csr_spmm_lattice(int vtype, const tsgu_lattice_plan* plan, int64_t n_rows, int64_t nnz, const void* val,
                           const void* B, int64_t ldb, void* C, int64_t ldc, int64_t p, int device, void* stream);
+/* C = A·B (plan kind 0, fp32) with the Krylov loops' dot epilogue: dot_partial[w][c] = Σ over the rows of workgroup w of
+ * C[row, c]·B[row, c] (the own row of B is the centre of the halo plane in LDS; deterministic).  dot_rows must be the number of
+ * workgroups of the configuration, nb·nseg·⌈ny/ty⌉·⌈nz/tz⌉; one chunk per lane.  This entry also takes 16-byte dense rows
+ * (p = 4: one lane per row) — replaces tsgu_csr_spmm(..., dot_w = B, ...) inside utils/linear_cg.py:322 + :64-65 on lattice
+ * stencils, without reading a column index. */
+int tsgu_csr_spmm_lattice_dot(int vtype, const tsgu_lattice_plan* plan, int64_t n_rows, int64_t nnz, const void* val,
+                              const void* B, int64_t ldb, void* C, int64_t ldc, int64_t p, void* dot_partial, int64_t dot_rows,
+                              int device, void* stream);
 /* out_vals[k] = alpha·<R[row k,:], Cm[col k,:]> in stored order (plan kind 0). */
 int tsgu_csr_sddmm_lattice(int vtype, const tsgu_lattice_plan* plan, int64_t n_rows, int64_t nnz, const void* R, int64_t ldr,
                            const void* Cm, int64_t ldc, void* out_vals, double alpha, int64_t p, int device, void* stream);

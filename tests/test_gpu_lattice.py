@@ -365,3 +365,80 @@ def test_bounded_fuzz_run_of_the_public_ops():
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "60 cases, 0 violations" in r.stdout
+
+
+@pytest.mark.parametrize("periodic,points,dims", [(False, 7, (9, 10, 12)), (True, 7, (6, 8, 16)), (True, 27, (5, 9, 11)), (False, 27, (7, 6, 9))])
+@pytest.mark.parametrize("p", [4, 32])
+def test_spmm_with_the_dot_epilogue_of_the_krylov_loops(periodic, points, dims, p):
+    """C = A·v plus the per-workgroup partial sums of <C[row], v[row]> per column (what linear_cg's fused step consumes), on
+    16-byte dense rows (4 right-hand sides: one lane per row) and on 128-byte rows: C bit-identical to the plan-free kernel,
+    the column sums of the partials equal to its own dot epilogue's to rounding, run-to-run bit-identical."""
+    be, lt, pt = _mods()
+    dev = torch.device("cuda:0")
+    nx, ny, nz = dims
+    crow, col = _stencil_csr(nx, ny, nz, periodic, points)
+    n = nx * ny * nz
+    g = torch.Generator().manual_seed(7 + p)
+    val = torch.randn(col.numel(), generator=g).to(dev)
+    v = torch.randn(n, p, generator=g).to(dev)
+    plan = pt.RowGather(crow.to(dev), col.to(dev), n, n)
+    lp = lt.build_lattice_plan_hip(plan, be)
+    assert lp is not None
+    C0, part0 = be.csr_spmm(plan.crow, plan.col, val, v, n, n, dot_w=v)
+    for cs in ((4, 8, 2, 256), (6, 12, 3, 512)) if p == 4 else ((4, 4, 2, 256), (5, 6, 3, 512)):
+        lt._CFG_ENV = ",".join(str(x) for x in cs)
+        try:
+            lp._cfg.clear()
+            cfg = be.lattice_config(lp, be.LAT_SPMM, torch.float32, p)
+        finally:
+            lt._CFG_ENV = ""
+        assert cfg is not None, cs
+        C, part = be.csr_spmm_lattice(lp, cfg, val, v, dot=True)
+        assert part.shape == (cfg.nseg * -(-ny // cfg.ty) * -(-nz // cfg.tz), p)
+        assert torch.equal(C, be.csr_spmm_lattice(lp, cfg, val, v))          # the epilogue does not touch the product
+        if p >= 32:
+            assert torch.equal(C, C0), cs
+        else:
+            assert G.rel_err(C.cpu().numpy(), C0.cpu().numpy()) < 1e-6, cs
+        want = (C0.double() * v.double()).sum(0)
+        scale = (C0.double().abs() * v.double().abs()).sum(0)          # fp32 partial sums: errors relative to the sum of magnitudes
+        got = part.double().sum(0)
+        assert float(((got - want).abs() / scale).max()) < 1e-6, cs
+        assert float(((part0.double().sum(0) - want).abs() / scale).max()) < 1e-6
+        C2, part2 = be.csr_spmm_lattice(lp, cfg, val, v, dot=True)
+        assert torch.equal(part, part2) and torch.equal(C, C2)
+    lp._cfg.clear()
+    # not offered where it does not exist: bf16, the transposed walk
+    assert be.lattice_config(lp, be.LAT_SDDMM, torch.float32, 4) is None
+    assert be.lattice_config(lp, be.LAT_SPMM, torch.bfloat16, 8) is None
+
+
+def test_linear_cg_takes_the_plane_sweep_with_the_fused_dot():
+    """linear_cg on a 7-point Laplacian with 4 right-hand sides: K1 is the plane sweep (no column index is read), iterates equal
+    to the plan-free path to rounding."""
+    from torchsparsegradutils_amd import _ops
+    from torchsparsegradutils_amd.utils import LinearCGSettings, linear_cg, synthetic
+
+    dev = torch.device("cuda:0")
+    cc, ci, cv = synthetic.laplacian7(20, 24, 32)
+    n = 20 * 24 * 32
+    A = torch.sparse_csr_tensor(cc.to(dev), ci.to(dev), cv.to(dev), (n, n))
+    B = torch.randn(n, 4, generator=torch.Generator().manual_seed(3)).to(dev)
+    st = LinearCGSettings(max_cg_iterations=25, cg_tolerance=1e-30)
+    import warnings
+
+    outs = []
+    for lattice in (True, False):
+        _ops.ENABLE_LATTICE = lattice
+        try:
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                outs.append(linear_cg(A, B, max_tridiag_iter=25, settings=st))
+        finally:
+            _ops.ENABLE_LATTICE = True
+    from torchsparsegradutils_amd import _pattern
+
+    core = _pattern.from_csr(A).core
+    lp = core.own.get("lattice")
+    assert lp is not None and any(k[2] == 4 and c is not None for k, c in lp._cfg.items()), "the plane sweep was not taken"
+    assert G.rel_err(outs[0].cpu().numpy(), outs[1].cpu().numpy()) < 1e-4

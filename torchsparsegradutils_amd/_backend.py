@@ -76,6 +76,7 @@ SIGNATURES = {
         _int, [_int, _int, _i64, _i64, _i64, _ptr, _ptr, _ptr, _i64, _ptr, _i64, _ptr, _dbl, _i64, _int, _ptr]),
     "tsgu_lattice_lds_bytes": (_int, [_int, _int, _i64, _int, _int, _int, _int, _int, _int, _int, _int, _int]),
     "tsgu_csr_spmm_lattice": (_int, [_int, _ptr, _i64, _i64, _ptr, _ptr, _i64, _ptr, _i64, _i64, _int, _ptr]),
+    "tsgu_csr_spmm_lattice_dot": (_int, [_int, _ptr, _i64, _i64, _ptr, _ptr, _i64, _ptr, _i64, _i64, _ptr, _i64, _int, _ptr]),
     "tsgu_csr_sddmm_lattice": (_int, [_int, _ptr, _i64, _i64, _ptr, _i64, _ptr, _i64, _ptr, _dbl, _i64, _int, _ptr]),
     "tsgu_march_lds_bytes": (_int, [_int, _int, _i64, _int, _int, _int, _int, _int, _int]),
     "tsgu_csr_spmm_march": (_int, [_int, _ptr, _int, _i64, _i64, _ptr, _ptr, _i64, _ptr, _i64, _i64, _int, _ptr]),
@@ -427,8 +428,9 @@ def lattice_config(lp, mode: int, dtype: torch.dtype, p: int):
     if dtype not in (torch.float32, torch.bfloat16):
         return None
     es = 4 if dtype == torch.float32 else 2
-    if (p * es) % 16 or (p * es) // 16 not in (2, 4, 8, 16):
-        return None
+    lanes = (p * es) // 16
+    if (p * es) % 16 or lanes not in (1, 2, 4, 8, 16) or (lanes == 1 and not (mode == LAT_SPMM and dtype == torch.float32 and lp.kind == 0)):
+        return None      # (one lane per row — 4 fp32 columns — is compiled for the stored-order product only)
     import sys
 
     return _lattice.config_for(lp, mode, _VTYPE[dtype], p, es, lattice_lds_bytes, be=sys.modules[__name__])
@@ -514,8 +516,10 @@ class _on_device:
             self.ctx.__exit__(*exc)
 
 
-def csr_spmm_lattice(lp, cfg, val, B):
-    """C = A·B (plan kind 0) or Aᵀ·B for the transposed plan (kind 1; `val` in A's own order) by the plane sweep."""
+def csr_spmm_lattice(lp, cfg, val, B, dot: bool = False):
+    """C = A·B (plan kind 0) or Aᵀ·B for the transposed plan (kind 1; `val` in A's own order) by the plane sweep / plane march.
+    `dot` (plane sweep, fp32, stored order): also the per-workgroup partial sums of <C[row], B[row]> per column — returns
+    (C, partial [workgroups][p]), the Krylov loops' fused dot epilogue."""
     lib = _lib or load_library()
     dev = B.device
     if not B.is_cuda or val.device != dev:
@@ -528,6 +532,18 @@ def csr_spmm_lattice(lp, cfg, val, B):
         val = val.contiguous()
     march = getattr(cfg, "march", False)
     transposed = cfg.mode == LAT_SPMMT if march else bool(lp.kind)
+    if dot:
+        if march or transposed or B.dtype != torch.float32:
+            raise RuntimeError("csr_spmm_lattice: the dot epilogue exists for the fp32 stored-order plane sweep only")
+        nwg = lp.nb * cfg.nseg * -(-lp.ny // cfg.ty) * -(-lp.nz // cfg.tz)
+        partial = torch.empty((nwg, p), dtype=torch.float32, device=dev)
+        with _on_device(dev):
+            rc = lib.tsgu_csr_spmm_lattice_dot(_VTYPE[val.dtype], cfg.struct_addr, lp.n_rows, lp.nnz, val.data_ptr(), B.data_ptr(), _ld(B),
+                                               out.data_ptr(), p, p, partial.data_ptr(), nwg, dev.index,
+                                               torch.cuda.current_stream(dev).cuda_stream)
+        if rc:
+            check(rc, "tsgu_csr_spmm_lattice_dot")
+        return out, partial
     tok = _timed("lattice_spmm_t" if transposed else "lattice_spmm", dev) if KERNEL_EVENTS is not None else None
     with _on_device(dev):
         if march:

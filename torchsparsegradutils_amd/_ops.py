@@ -66,7 +66,8 @@ def _lattice_cfg(plan: RowGather, mode: int, dense: torch.Tensor, *others: torch
     if dense.dtype not in LATTICE_DTYPES:
         return None
     row_bytes = dense.size(-1) * dense.element_size()
-    if row_bytes % 16 or row_bytes // 16 not in (2, 4, 8, 16):
+    lanes = row_bytes // 16
+    if row_bytes % 16 or lanes not in (1, 2, 4, 8, 16) or (lanes == 1 and not (mode == _be.LAT_SPMM and dense.dtype == torch.float32)):
         return None            # dense rows the sweeps are not compiled for: do not even analyse the pattern
     fwd = _lattice_plan(plan)
     if fwd is None:

@@ -12,17 +12,18 @@ namespace {
 
 int vbytes_of(int vtype) { return vtype == TSGU_F32 ? 4 : (vtype == TSGU_BF16 ? 2 : 0); }
 
-// column lanes of 16 bytes per dense row
-int lanes_of(int vtype, int64_t p) {
+// column lanes of 16 bytes per dense row (one lane: fp32 SpMM only)
+int lanes_of(int vtype, int64_t p, int mode) {
     const int vb = vbytes_of(vtype);
     if (vb == 0 || p <= 0 || (p * vb) % 16) return 0;
     const int64_t cl = p * vb / 16;
+    if (cl == 1) return vtype == TSGU_F32 && mode == kLatSpmm ? 1 : 0;
     return (cl == 2 || cl == 4 || cl == 8 || cl == 16) ? (int)cl : 0;
 }
 
 int fill(LatParams& P, const tsgu_lattice_plan* pl, int mode, int vtype, int64_t p, int64_t n_rows, int64_t nnz, int& cl) {
     if (!pl || n_rows < 0 || nnz < 0) return TSGU_ERR_BAD_ARG;
-    cl = lanes_of(vtype, p);
+    cl = lanes_of(vtype, p, mode);
     if (cl == 0) return TSGU_ERR_BAD_DTYPE;
     if ((pl->kind != 0) != (mode == kLatSpmmT)) return TSGU_ERR_BAD_ARG;
     if (pl->nb <= 0 || pl->nx <= 0 || pl->ny <= 0 || pl->nz <= 0 || pl->nseg <= 0 || pl->nseg > pl->nx) return TSGU_ERR_BAD_ARG;
@@ -72,7 +73,7 @@ extern "C" {
 
 int tsgu_lattice_lds_bytes(int mode, int vtype, int64_t p, int ty, int tz, int ry, int rz, int nloc, int recw, int threads, int ring,
                            int chunks_per_lane) {
-    const int cl = lanes_of(vtype, p);
+    const int cl = lanes_of(vtype, p, mode);
     if (cl == 0 || mode < 0 || mode > 2) return TSGU_ERR_BAD_DTYPE;
     if (threads != 256 && threads != 512 && threads != 1024) return TSGU_ERR_BAD_ARG;
     LatParams P{};
@@ -81,12 +82,13 @@ int tsgu_lattice_lds_bytes(int mode, int vtype, int64_t p, int ty, int tz, int r
     return lat_layout(P, mode, cl, vbytes_of(vtype), threads);
 }
 
-int tsgu_csr_spmm_lattice(int vtype, const tsgu_lattice_plan* plan, int64_t n_rows, int64_t nnz, const void* val, const void* B,
-                          int64_t ldb, void* C, int64_t ldc, int64_t p, int device, void* stream) {
+static int spmm_lattice(int vtype, const tsgu_lattice_plan* plan, int64_t n_rows, int64_t nnz, const void* val, const void* B, int64_t ldb,
+                        void* C, int64_t ldc, int64_t p, void* dot_partial, int64_t dot_rows, int device, void* stream) {
     LatParams P{};
     int cl = 0;
     const int mode = plan && plan->kind != 0 ? kLatSpmmT : kLatSpmm;
     if (const int rc = fill(P, plan, mode, vtype, p, n_rows, nnz, cl)) return rc;
+    if (dot_partial && (mode != kLatSpmm || vtype != TSGU_F32 || P.cpl != 1 || dot_rows != P.nblocks)) return TSGU_ERR_BAD_ARG;
     if (n_rows == 0) return TSGU_OK;
     if (!B || !C || (nnz > 0 && !val) || ldb < p || ldc < p) return TSGU_ERR_BAD_ARG;
     const int vec = 16 / vbytes_of(vtype);
@@ -99,7 +101,20 @@ int tsgu_csr_spmm_lattice(int vtype, const tsgu_lattice_plan* plan, int64_t n_ro
     P.lds_ = ldb;
     P.out = C;
     P.ldo = ldc;
+    P.dot_partial = static_cast<float*>(dot_partial);
     return dispatch(vtype, mode, cl, plan->threads, P, stream);
+}
+
+int tsgu_csr_spmm_lattice(int vtype, const tsgu_lattice_plan* plan, int64_t n_rows, int64_t nnz, const void* val, const void* B,
+                          int64_t ldb, void* C, int64_t ldc, int64_t p, int device, void* stream) {
+    return spmm_lattice(vtype, plan, n_rows, nnz, val, B, ldb, C, ldc, p, nullptr, 0, device, stream);
+}
+
+int tsgu_csr_spmm_lattice_dot(int vtype, const tsgu_lattice_plan* plan, int64_t n_rows, int64_t nnz, const void* val, const void* B,
+                              int64_t ldb, void* C, int64_t ldc, int64_t p, void* dot_partial, int64_t dot_rows, int device,
+                              void* stream) {
+    if (!dot_partial) return TSGU_ERR_BAD_ARG;
+    return spmm_lattice(vtype, plan, n_rows, nnz, val, B, ldb, C, ldc, p, dot_partial, dot_rows, device, stream);
 }
 
 int tsgu_csr_sddmm_lattice(int vtype, const tsgu_lattice_plan* plan, int64_t n_rows, int64_t nnz, const void* R, int64_t ldr,

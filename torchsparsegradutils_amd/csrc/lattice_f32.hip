@@ -6,6 +6,9 @@ namespace tsgu {
 template <int MODE, int NT>
 static int lat_go_f32(int cl, const LatParams& P, hipStream_t s) {
     switch (cl) {
+        case 1:   // 16-byte dense rows (4 fp32 columns: the Krylov loops' right-hand sides): the stored-order product only
+            if constexpr (MODE == kLatSpmm) return lat_launch_one<float, 1, MODE, NT>(P, s);
+            else return TSGU_ERR_BAD_ARG;
         case 2: return lat_launch_one<float, 2, MODE, NT>(P, s);
         case 4: return lat_launch_one<float, 4, MODE, NT>(P, s);
         case 8: return lat_launch_one<float, 8, MODE, NT>(P, s);

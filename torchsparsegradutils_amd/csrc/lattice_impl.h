@@ -76,6 +76,7 @@ struct LatParams {
     int64_t ldo;
     void* gvals;             // SDDMM output [nnz]
     float alpha;
+    float* dot_partial;      // SpMM, fp32: [workgroups][p] partial sums of <out[row,:], S[row,:]> per column (Krylov loops), or null
     int64_t nblocks;
     // LDS layout (bytes from the start of the dynamic region; filled by lat_layout)
     int o_vals, o_zero, o_tab, o_len, o_map, lds_bytes;
@@ -397,6 +398,16 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
     // never waits for a store acknowledgement (and, for the SDDMM, the stage rows are read after the barrier)
     float acc[MODE == kLatSddmm ? 1 : kLatNP][CPL][VEC];
     int plen[MODE == kLatSddmm ? kLatNP : 1], prst[MODE == kLatSddmm ? kLatNP : 1];
+    // fused dot epilogue (SpMM, fp32): Σ over this lane's rows of out[row, c]·S[row, c] — the own row of S is the centre of the
+    // halo plane in LDS
+    constexpr bool kCanDot = MODE == kLatSpmm && kVB == 4 && CPL == 1;
+    float dotp[kCanDot ? CPL : 1][VEC];
+#pragma unroll
+    for (int cp = 0; cp < (kCanDot ? CPL : 1); ++cp) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) dotp[cp][v] = 0.f;
+    }
+    const bool want_dot = kCanDot && P.dot_partial != nullptr;
     auto flush = [&](int prow) {
         if constexpr (MODE != kLatSddmm) {
             char* const obase = static_cast<char*>(P.out) + (int64_t)prow * ldob;
@@ -605,6 +616,18 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
                                 for (int j = 0; j < 4; ++j) axpy(a[j], b[j]);
                             }
                         }
+                        if constexpr (kCanDot) {
+                            if (want_dot) {
+#pragma unroll
+                                for (int cp = 0; cp < CPL; ++cp) {
+                                    const uint4 wr = *reinterpret_cast<const uint4*>(sm + ph * PB + cen[q][cp]);
+                                    float f[VEC];
+                                    widen(wr, f);
+#pragma unroll
+                                    for (int v = 0; v < VEC; ++v) dotp[cp][v] = fmaf(acc[q][cp][v], f[v], dotp[cp][v]);
+                                }
+                            }
+                        }
                     } else if constexpr (MODE == kLatSddmm) {
                         float* const st = reinterpret_cast<float*>(sm + P.o_vals + csl[q]);   // fp32 staging row (slot = recw*4 bytes in this mode)
                         plen[q] = len;
@@ -783,6 +806,25 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
 #if TSGU_LAT_PROBE != 2
     flush(prow_prev);
 #endif
+    if constexpr (kCanDot) {
+        if (want_dot) {
+            // the workgroup's partial row: column cc = chunk·VEC + v summed over the lanes that own that chunk, in lane order
+            // (the last step ended with a barrier: the ring is free)
+            float* const red = reinterpret_cast<float*>(sm);
+#pragma unroll
+            for (int cp = 0; cp < CPL; ++cp) {
+                const int chunk = c + LPR * cp;
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) red[(g * CL + chunk) * VEC + v] = dotp[cp][v];
+            }
+            __syncthreads();
+            if (tid < CL * VEC) {
+                float s = 0.f;
+                for (int r = 0; r < NT / LPR; ++r) s += red[r * CL * VEC + tid];
+                P.dot_partial[vblock * (CL * VEC) + tid] = s;
+            }
+        }
+    }
 }
 
 // ---- host side --------------------------------------------------------------------------------------------------
