@@ -178,6 +178,36 @@ def test_pairwise_encoder_output_and_gradients_through_sparse_mm(tag, lay, iname
         enc(vals.detach()[..., :-1])
 
 
+@pytest.mark.parametrize("lay", ["csr", "coo"])
+@pytest.mark.parametrize("batch", [0, 3])
+def test_encoder_calls_share_their_index_storages_and_the_pattern_plans(lay, batch):
+    """Repeated calls of one encoder hand sparse_mm the SAME index storages (memoised per batch size), so the pattern cache —
+    keyed on index storage identity — sees one pattern: its plans (transposed pattern, lattice / row-pair plans) are built once,
+    not at every call of a training loop."""
+    from torchsparsegradutils_amd import _pattern, sparse_mm
+    from torchsparsegradutils_amd.encoders import PairwiseEncoder
+
+    _pattern.clear_cache()
+    enc = PairwiseEncoder(1.0, (1, 12, 10, 16), diag=True, layout=torch.sparse_csr if lay == "csr" else torch.sparse_coo,
+                          indices_dtype=torch.int32 if lay == "csr" else torch.int64, device=DEV)
+    shape = ((batch,) if batch else ()) + (len(enc.offsets), 1, 12, 10, 16)
+    n = 12 * 10 * 16
+    ptrs, entries = set(), set()
+    for it in range(3):
+        w = torch.randn(shape, device=DEV, requires_grad=True)
+        A = enc(w)
+        idx = A.col_indices() if lay == "csr" else A.indices()
+        ptrs.add(idx.data_ptr())
+        B = torch.randn(((batch,) if batch else ()) + (n, 32), device=DEV, requires_grad=True)
+        sparse_mm(A, B).square().sum().backward()
+        assert w.grad is not None and bool(torch.isfinite(w.grad).all())
+        entries.add(_pattern.cache_stats()[0])
+    assert len(ptrs) == 1, "every call built fresh index tensors"
+    assert entries == {max(entries)} and max(entries) <= 2, entries      # (a batched operand also caches its block-diagonal view)
+    enc2 = enc.to(torch.device("cpu"))
+    assert enc2._index_memo == {}
+
+
 # --------------------------------------------------------------------------- f-1: the multivariate normal's call pattern
 def _mvn_inputs(z, vn):
     from torchsparsegradutils_amd.encoders import PairwiseEncoder

@@ -141,6 +141,10 @@ class PairwiseEncoder(torch.nn.Module):
         crow[1:] = torch.cumsum(counts, 0)
         self._rows_sorted = row[perm].contiguous()
         self._cols_sorted = col[perm].contiguous()
+        # index tensors handed to the sparse constructors, built once per (layout, batch size): every call then passes the SAME
+        # index storages, which is what the pattern cache of the kernels keys on (plans survive from call to call; a fresh
+        # stack / repeat per call made every call a first sight)
+        self._index_memo = {}
         if layout == torch.sparse_coo:
             self.indices = torch.stack((row, col))       # the reference's attribute: offset-major, un-coalesced
             self.csr_permutation = None
@@ -155,7 +159,27 @@ class PairwiseEncoder(torch.nn.Module):
             tensor = getattr(self, attr, None)
             if tensor is not None:
                 setattr(self, attr, fn(tensor))
+        self._index_memo = {}
         return self
+
+    def _indices_for(self, batch: int):
+        """Index tensors of the output for `batch` stacked volumes (0: unbatched), memoised (a handful of batch sizes)."""
+        hit = self._index_memo.get(batch)
+        if hit is None:
+            if self.layout == torch.sparse_csr:
+                hit = (self.crow_indices, self.col_indices) if batch == 0 else (self.crow_indices.repeat(batch, 1), self.col_indices.repeat(batch, 1))
+            else:
+                idx2 = torch.stack((self._rows_sorted, self._cols_sorted))
+                if batch == 0:
+                    hit = (idx2,)
+                else:
+                    nnz = idx2.shape[1]
+                    bidx = torch.arange(batch, dtype=idx2.dtype, device=idx2.device).repeat_interleave(nnz).unsqueeze(0)
+                    hit = (torch.cat((bidx, idx2.repeat(1, batch))),)
+            if len(self._index_memo) >= 8:
+                self._index_memo.pop(next(iter(self._index_memo)))
+            self._index_memo[batch] = hit
+        return hit
 
     @property
     def device(self):
@@ -183,18 +207,13 @@ class PairwiseEncoder(torch.nn.Module):
         vol = self.volume_numel
         flat = values.reshape((values.shape[0], -1) if batched else (-1,))
         vals = flat.index_select(-1, self._gather)       # the whole trim / concatenate / permute chain in one gather
+        b = values.shape[0] if batched else 0
         if self.layout == torch.sparse_csr:
-            if batched:
-                b = values.shape[0]
-                return torch.sparse_csr_tensor(self.crow_indices.repeat(b, 1), self.col_indices.repeat(b, 1), vals,
-                                               size=(b, vol, vol), dtype=vals.dtype, device=vals.device)
-            return torch.sparse_csr_tensor(self.crow_indices, self.col_indices, vals, size=(vol, vol),
-                                           dtype=vals.dtype, device=vals.device)
+            crow, col = self._indices_for(b)
+            return torch.sparse_csr_tensor(crow, col, vals, size=(b, vol, vol) if batched else (vol, vol), dtype=vals.dtype,
+                                           device=vals.device)
         # COO, built already coalesced: (row, column) ascending is what the reference's coalesce() produces
-        idx2 = torch.stack((self._rows_sorted, self._cols_sorted))
+        (idx,) = self._indices_for(b)
         if batched:
-            b, nnz = values.shape[0], idx2.shape[1]
-            bidx = torch.arange(b, dtype=idx2.dtype, device=idx2.device).repeat_interleave(nnz).unsqueeze(0)
-            idx = torch.cat((bidx, idx2.repeat(1, b)))
             return torch.sparse_coo_tensor(idx, vals.reshape(-1), size=(b, vol, vol), is_coalesced=True)
-        return torch.sparse_coo_tensor(idx2, vals, size=(vol, vol), is_coalesced=True)
+        return torch.sparse_coo_tensor(idx, vals, size=(vol, vol), is_coalesced=True)
