@@ -107,6 +107,84 @@ def test_lattice_kernels_match_oracle_and_plan_free_kernels_fp32(nb, nx, ny, nz,
             assert torch.equal(gA, gA0), cs
 
 
+@pytest.mark.parametrize("nb,nx,ny,nz,periodic,points,lower,configs", CASES)
+@pytest.mark.parametrize("p", [32, 16, 4])
+def test_lattice_kernels_fp64(nb, nx, ny, nz, periodic, points, lower, configs, p):
+    """fp64 is first-class in the reference (tests/test_config.py:3-9): the sweeps in double precision against the oracle at
+    fp64 tolerance, all three products, and the public path."""
+    be, lt, pt = _mods()
+    dev = torch.device("cuda:0")
+    crow, col = _stencil_csr(nx, ny, nz, periodic, points, lower, nb)
+    n = nb * nx * ny * nz
+    g = torch.Generator().manual_seed(nx * 17 + p)
+    val = torch.randn(col.numel(), generator=g, dtype=torch.float64)
+    B = torch.randn(n, p, generator=g, dtype=torch.float64)
+    Gd = torch.randn(n, p, generator=g, dtype=torch.float64)
+    Co, gAo, gBo = _oracle_mm(crow, col, val, B, Gd)
+    crow_d, col_d, val_d, B_d, G_d = (t.to(dev) for t in (crow, col, val, B, Gd))
+    plan = pt.RowGather(crow_d, col_d, n, n)
+    lp = lt.build_lattice_plan_hip(plan, be, dims=(nb, nx, ny, nz))
+    ltp = lt.build_lattice_plan_hip(plan, be, forward=lp)
+    assert lp is not None and ltp is not None
+    ran = 0
+    for cs in configs:
+        lt._CFG_ENV = ",".join(str(v) for v in cs)
+        try:
+            lp._cfg.clear()
+            ltp._cfg.clear()
+            c1 = be.lattice_config(lp, be.LAT_SPMM, torch.float64, p)
+            c2 = be.lattice_config(lp, be.LAT_SDDMM, torch.float64, p)
+            c3 = be.lattice_config(ltp, be.LAT_SPMMT, torch.float64, p)
+        finally:
+            lt._CFG_ENV = ""
+        if c1 is None or c2 is None or c3 is None:
+            continue   # configuration beyond the kernels' limits for this p
+        ran += 1
+        C = be.csr_spmm_lattice(lp, c1, val_d, B_d)
+        gA = be.csr_sddmm_lattice(lp, c2, G_d, B_d, alpha=-1.0)
+        gB = be.csr_spmm_lattice(ltp, c3, val_d, G_d)
+        assert C.dtype == gA.dtype == gB.dtype == torch.float64
+        assert G.rel_err(C.cpu().numpy(), Co) < 1e-12, cs
+        assert G.rel_err(-gA.cpu().numpy(), gAo) < 1e-12, cs
+        assert G.rel_err(gB.cpu().numpy(), gBo) < 1e-12, cs
+    lp._cfg.clear()
+    ltp._cfg.clear()
+    assert ran >= 1 or p == 32
+
+
+def test_public_path_fp64_takes_the_sweeps(monkeypatch):
+    from torchsparsegradutils_amd import _ops, _pattern, sparse_mm
+    from torchsparsegradutils_amd.utils import synthetic
+
+    monkeypatch.setattr(_ops, "ENABLE_LATTICE", True)
+    dev = torch.device("cuda:0")
+    nx, ny, nz, p = 16, 12, 20, 32
+    n = nx * ny * nz
+    crow, col = synthetic.stencil27_periodic(nx, ny, nz, torch.int32)
+    g = torch.Generator().manual_seed(9)
+    val = torch.randn(col.numel(), generator=g, dtype=torch.float64)
+    B = torch.randn(n, p, generator=g, dtype=torch.float64)
+    Gd = torch.randn(n, p, generator=g, dtype=torch.float64)
+    Co, gAo, gBo = _oracle_mm(crow, col, val, B, Gd)
+    A = torch.sparse_csr_tensor(crow.to(dev), col.to(dev), val.to(dev), (n, n)).requires_grad_(True)
+    Bd = B.to(dev).requires_grad_(True)
+    C = sparse_mm(A, Bd)
+    C.backward(Gd.to(dev))
+    core = _pattern.from_csr(A.detach()).core
+    lp = core.own.get("lattice")
+    assert lp is not None and any(k[1] == be_vtype(torch.float64) and c is not None for k, c in lp._cfg.items()), "fp64 did not reach the sweeps"
+    assert core.t is None
+    assert G.rel_err(C.detach().cpu().numpy(), Co) < 1e-12
+    assert G.rel_err(A.grad.values().cpu().numpy(), gAo) < 1e-12
+    assert G.rel_err(Bd.grad.cpu().numpy(), gBo) < 1e-12
+
+
+def be_vtype(dtype):
+    from torchsparsegradutils_amd import _backend
+
+    return _backend._VTYPE[dtype]
+
+
 def test_two_dimensional_lattice():
     """9-point stencil on a 2-D lattice: handled as planes of ONE line (ny = 1, no y halo)."""
     be, lt, pt = _mods()

@@ -2,7 +2,7 @@
 """Developer micro-benchmark of the lattice plane-sweep kernels: correctness against the plan-free kernels + HIP-event
 timings for a list of launch configurations.  Not part of the product or the test-suite.
 
-    python tools/latbench.py [--grid 100 100 100] [--rhs 32] [--dtype f32|bf16] [--batch B] [--reps 30]
+    python tools/latbench.py [--grid 100 100 100] [--rhs 32] [--dtype f32|bf16|f64] [--batch B] [--reps 30]
                              [--cfg ty,tz,nseg,threads[,ring] ...] [--modes fwd,sddmm,spmmt]
 """
 import argparse
@@ -45,7 +45,7 @@ def main():
     ap.add_argument("--nocheck", action="store_true")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
-    dt = {"f32": torch.float32, "bf16": torch.bfloat16}[a.dtype]
+    dt = {"f32": torch.float32, "bf16": torch.bfloat16, "f64": torch.float64}[a.dtype]
     nx, ny, nz = a.grid
     n1, p, b = nx * ny * nz, a.rhs, a.batch
     gen = synthetic.stencil27_periodic if a.stencil == 27 else synthetic.stencil7_periodic

@@ -425,9 +425,9 @@ def lattice_config(lp, mode: int, dtype: torch.dtype, p: int):
     """Launch configuration (tile, segments, record tables) of the _lattice.LatticePlan `lp` for these operands, or None."""
     from . import _lattice
 
-    if dtype not in (torch.float32, torch.bfloat16):
+    if dtype not in (torch.float32, torch.bfloat16, torch.float64):
         return None
-    es = 4 if dtype == torch.float32 else 2
+    es = {torch.float32: 4, torch.bfloat16: 2, torch.float64: 8}[dtype]
     lanes = (p * es) // 16
     if (p * es) % 16 or lanes not in (1, 2, 4, 8, 16) or (lanes == 1 and not (mode == LAT_SPMM and dtype == torch.float32 and lp.kind == 0)):
         return None      # (one lane per row — 4 fp32 columns — is compiled for the stored-order product only)

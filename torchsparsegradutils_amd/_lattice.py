@@ -525,6 +525,8 @@ def rank_configs(plan: LatticePlan, mode: int, vtype: int, p: int, elem_bytes: i
         for ty, tz in _candidates(rpp):           # one row per lane group and plane step
             if ty > plan.ny or tz > plan.nz or (plan.ny == 1 and ty != 1):
                 continue
+            if elem_bytes == 8 and tz % 4 and plan.nz >= 8:
+                continue      # fp64: a wave's rows inside one z-line (measured at C2: 4x8 226 / 335 / 281 us, 5x6 263 / 368 / 292 us)
             ring = 4
             lds = lds_bytes_fn(mode, vtype, p, ty, tz, plan.ry, plan.rz, min(plan.ncls, _NLOC_GUESS[plan.kind]), plan.recw, threads, ring)
             if lds <= 0:
@@ -574,7 +576,7 @@ def config_for(plan: LatticePlan, mode: int, vtype: int, p: int, elem_bytes: int
             lds = lds_bytes_fn(mode, vtype, p, ty, tz, plan.ry, plan.rz, nloc, plan.recw, threads, ring, cpl)
             if lds <= 0:
                 continue      # the workgroups of this tiling meet more classes than the ranking assumed
-            slot = (plan.recw * (4 if mode == _MODE_SDDMM else elem_bytes) + 15) // 16 * 16
+            slot = (plan.recw * (max(4, elem_bytes if elem_bytes == 8 else 4) if mode == _MODE_SDDMM else elem_bytes) + 15) // 16 * 16
             if slot % 64 == 0:
                 slot += 16                 # as lat_layout (csrc/lattice_impl.h): value rows must not share four banks
             if PACKED_T and mode == _MODE_SPMMT and (p * elem_bytes) % 128 == 0:

@@ -37,7 +37,7 @@ PLAN_ASYNC = os.environ.get("TSGU_PLAN_ASYNC", "1") == "1"
 # operand in LDS.  First choice when the pattern qualifies; anything else takes the row-pair / plan-free kernels.
 ENABLE_LATTICE = os.environ.get("TSGU_ENABLE_LATTICE", "1") == "1"
 # value types the sweeps are compiled for (fp32 accumulation for bf16)
-LATTICE_DTYPES = (torch.float32, torch.bfloat16)
+LATTICE_DTYPES = (torch.float32, torch.bfloat16, torch.float64)
 
 
 def _lattice_plan(plan: RowGather, transposed: bool = False):

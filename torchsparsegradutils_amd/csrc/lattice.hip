@@ -4,13 +4,14 @@
 namespace tsgu {
 int lat_dispatch_f32(int mode, int cl, int threads, const LatParams& P, hipStream_t s);
 int lat_dispatch_bf16(int mode, int cl, int threads, const LatParams& P, hipStream_t s);
+int lat_dispatch_f64(int mode, int cl, int threads, const LatParams& P, hipStream_t s);
 }  // namespace tsgu
 
 using namespace tsgu;
 
 namespace {
 
-int vbytes_of(int vtype) { return vtype == TSGU_F32 ? 4 : (vtype == TSGU_BF16 ? 2 : 0); }
+int vbytes_of(int vtype) { return vtype == TSGU_F32 ? 4 : (vtype == TSGU_BF16 ? 2 : (vtype == TSGU_F64 ? 8 : 0)); }
 
 // column lanes of 16 bytes per dense row (one lane: fp32 SpMM only)
 int lanes_of(int vtype, int64_t p, int mode) {
@@ -64,6 +65,7 @@ int dispatch(int vtype, int mode, int cl, int threads, const LatParams& P, void*
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (vtype == TSGU_F32) return lat_dispatch_f32(mode, cl, threads, P, s);
     if (vtype == TSGU_BF16) return lat_dispatch_bf16(mode, cl, threads, P, s);
+    if (vtype == TSGU_F64) return lat_dispatch_f64(mode, cl, threads, P, s);
     return TSGU_ERR_BAD_DTYPE;
 }
 

@@ -42,7 +42,7 @@ enum LatMode { kLatSpmm = 0, kLatSddmm = 1, kLatSpmmT = 2 };
 
 constexpr int kLatND = 3;    // ring DMA pieces per thread and plane   (halo rows x chunks <= kLatND * NT)
 // value DMA pieces per thread and plane: as few as the supported geometries need (each costs registers for the whole march)
-constexpr int lat_nvd(int mode, int vbytes) { return vbytes == 4 ? 2 : (mode == 2 ? 4 : 3); }
+constexpr int lat_nvd(int mode, int vbytes) { return vbytes == 4 ? 2 : (vbytes == 8 || mode == 2 ? 4 : 3); }
 constexpr int kLatNP = 1;    // row passes per plane                   (tile rows <= kLatNP * NT / CL)
 constexpr int kLatMaxLds = 160 * 1024;
 #ifndef TSGU_LAT_PROBE
@@ -121,6 +121,7 @@ constexpr uint32_t kLatNone = 0xffffffffu;
 template <typename V, int CL, int CPL, int MODE, int NT, int NCH>
 __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   // 4 waves per SIMD: at most 128 VGPRs
     using T = VT<V>;
+    using A = typename T::Acc;           // accumulation type: fp32 (fp32 / bf16 operands) or fp64
     constexpr int VEC = T::kWide;
     constexpr int RB = CL * 16;          // bytes of a dense row
     constexpr int LPR = CL / CPL;        // lanes per row
@@ -396,7 +397,7 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
 
     // results of the previous plane leave at the START of the next step, so that the wait for the DMA at the end of a step
     // never waits for a store acknowledgement (and, for the SDDMM, the stage rows are read after the barrier)
-    float acc[MODE == kLatSddmm ? 1 : kLatNP][CPL][VEC];
+    A acc[MODE == kLatSddmm ? 1 : kLatNP][CPL][VEC];
     int plen[MODE == kLatSddmm ? kLatNP : 1], prst[MODE == kLatSddmm ? kLatNP : 1];
     // fused dot epilogue (SpMM, fp32): Σ over this lane's rows of out[row, c]·S[row, c] — the own row of S is the centre of the
     // halo plane in LDS
@@ -426,9 +427,24 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
             for (int q = 0; q < kLatNP; ++q) {
                 if (q * RPP < NR) {
                     if (crow[q] >= 0) {
-                        const float* const st = reinterpret_cast<const float*>(sm + P.o_vals + csl[q]);
                         V* const go = static_cast<V*>(P.gvals) + prst[q];
                         const int len = plen[q];
+                        if constexpr (kVB == 8) {
+                            // fp64: 16-byte pieces of two (a row starts on an 8-byte boundary), a single element at the end
+                            const double* const st = reinterpret_cast<const double*>(sm + P.o_vals + csl[q]);
+#pragma nounroll
+                            for (int k0 = c * 2; k0 < len; k0 += LPR * 2) {
+                                if (k0 + 2 <= len) {
+                                    typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
+                                    const d2u o = {st[k0], st[k0 + 1]};
+                                    __builtin_nontemporal_store(o, reinterpret_cast<d2u*>(reinterpret_cast<double*>(go) + k0));
+                                } else {
+                                    reinterpret_cast<double*>(go)[k0] = st[k0];
+                                }
+                            }
+                            continue;
+                        }
+                        const float* const st = reinterpret_cast<const float*>(sm + P.o_vals + csl[q]);
 #pragma nounroll
                         for (int k0 = c * 4; k0 < len; k0 += LPR * 4) {
                             const float4 w = *reinterpret_cast<const float4*>(st + k0);
@@ -460,7 +476,7 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
                             } else {
 #pragma unroll
                                 for (int j = 0; j < 4; ++j)
-                                    if (k0 + j < len) go[k0 + j] = T::down(wv[j]);
+                                    if (k0 + j < len) go[k0 + j] = T::down((A)wv[j]);
                             }
                         }
                     }
@@ -524,9 +540,12 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
                         bb[0] = *reinterpret_cast<const uint4*>(cb + rec);
                         if constexpr (CPL == 2) bb[1] = *reinterpret_cast<const uint4*>(cb1 + rec);
                     };
-                    auto widen = [](const uint4& raw, float (&f)[VEC]) {
+                    auto widen = [](const uint4& raw, A (&f)[VEC]) {
                         const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
-                        if constexpr (kVB == 4) {
+                        if constexpr (kVB == 8) {
+                            f[0] = __hiloint2double((int)w[1], (int)w[0]);
+                            f[1] = __hiloint2double((int)w[3], (int)w[2]);
+                        } else if constexpr (kVB == 4) {
 #pragma unroll
                             for (int i = 0; i < 4; ++i) f[i] = __uint_as_float(w[i]);
                         } else {
@@ -537,13 +556,13 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
                             }
                         }
                     };
-                    auto axpy = [&](float a, const uint4 (&bb)[CPL]) {
+                    auto axpy = [&](A a, const uint4 (&bb)[CPL]) {
 #pragma unroll
                         for (int cp = 0; cp < CPL; ++cp) {
-                            float f[VEC];
+                            A f[VEC];
                             widen(bb[cp], f);
 #pragma unroll
-                            for (int v = 0; v < VEC; ++v) acc[MODE == kLatSddmm ? 0 : q][cp][v] = fmaf(a, f[v], acc[MODE == kLatSddmm ? 0 : q][cp][v]);
+                            for (int v = 0; v < VEC; ++v) acc[MODE == kLatSddmm ? 0 : q][cp][v] = fma(a, f[v], acc[MODE == kLatSddmm ? 0 : q][cp][v]);
                         }
                     };
                     const int recw = NCH > 0 ? 4 * NCH : P.recw;
@@ -556,10 +575,14 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
 #pragma unroll
                         for (int cp = 0; cp < CPL; ++cp) {
 #pragma unroll
-                            for (int v = 0; v < VEC; ++v) acc[q][cp][v] = 0.f;
+                            for (int v = 0; v < VEC; ++v) acc[q][cp][v] = (A)0;
                         }
-                        auto chunk_vals = [&](int k0, float (&a)[4]) {
-                            if constexpr (kVB == 4) {
+                        auto chunk_vals = [&](int k0, A (&a)[4]) {
+                            if constexpr (kVB == 8) {
+                                const uint4 w0 = *reinterpret_cast<const uint4*>(vs + k0 * 8), w1 = *reinterpret_cast<const uint4*>(vs + k0 * 8 + 16);
+                                a[0] = __hiloint2double((int)w0.y, (int)w0.x), a[1] = __hiloint2double((int)w0.w, (int)w0.z);
+                                a[2] = __hiloint2double((int)w1.y, (int)w1.x), a[3] = __hiloint2double((int)w1.w, (int)w1.z);
+                            } else if constexpr (kVB == 4) {
                                 const uint4 w = *reinterpret_cast<const uint4*>(vs + k0 * 4);
                                 a[0] = __uint_as_float(w.x), a[1] = __uint_as_float(w.y), a[2] = __uint_as_float(w.z), a[3] = __uint_as_float(w.w);
                             } else {
@@ -574,7 +597,7 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
                             // queueing a whole row's reads behind every other wave's (LDS and VALU then run side by side).
                             // The empty asm statements are compiler fences: they pin the order of the LDS requests.
                             // Three stages: values + records of chunk i+2, dense rows of chunk i+1, FMAs of chunk i.
-                            float a[3][4];
+                            A a[3][4];
                             int4 ro[3];
                             uint4 b[2][4][CPL];
                             auto stage_a = [&](int i) {
@@ -605,7 +628,7 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
                         } else {
 #pragma unroll 2
                             for (int k0 = 0; k0 < recw; k0 += 4) {
-                                float a[4];
+                                A a[4];
                                 chunk_vals(k0, a);
                                 const int4 ro = *reinterpret_cast<const int4*>(tb + k0 * 4);
                                 const int rv[4] = {ro.x, ro.y, ro.z, ro.w};
@@ -629,14 +652,14 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
                             }
                         }
                     } else if constexpr (MODE == kLatSddmm) {
-                        float* const st = reinterpret_cast<float*>(sm + P.o_vals + csl[q]);   // fp32 staging row (slot = recw*4 bytes in this mode)
+                        A* const st = reinterpret_cast<A*>(sm + P.o_vals + csl[q]);   // staging row in the accumulation type (slot = recw*sizeof(A) bytes in this mode)
                         plen[q] = len;
                         prst[q] = cur.rst[q];
                         auto consume = [&](int k0, const uint4 (&bb)[4][CPL]) {
-                            float dsum[4];
+                            A dsum[4];
 #pragma unroll
                             for (int j = 0; j < 4; ++j) {
-                                float d;
+                                A d;
                                 if constexpr (kVB == 2) {
                                     // packed bf16 pairs straight into the dot instruction (fp32 accumulation, no widening)
                                     typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
@@ -650,29 +673,29 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
                                             d = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, ow[i]), __builtin_bit_cast(bf2, bw[i]), d, false);
                                     }
                                 } else {
-                                    float f[VEC], o[VEC];
+                                    A f[VEC], o[VEC];
                                     widen(bb[j][0], f);
                                     widen(cur.own[q][0], o);
                                     d = o[0] * f[0];
 #pragma unroll
-                                    for (int v = 1; v < VEC; ++v) d = fmaf(o[v], f[v], d);
+                                    for (int v = 1; v < VEC; ++v) d = fma(o[v], f[v], d);
                                     if constexpr (CPL == 2) {
                                         widen(bb[j][1], f);
                                         widen(cur.own[q][1], o);
 #pragma unroll
-                                        for (int v = 0; v < VEC; ++v) d = fmaf(o[v], f[v], d);
+                                        for (int v = 0; v < VEC; ++v) d = fma(o[v], f[v], d);
                                     }
                                 }
-                                dsum[j] = group_sum<float, LPR>(d);
+                                dsum[j] = group_sum<A, LPR>(d);
                             }
                             if constexpr (LPR >= 4) {
                                 if (c < 4) {
-                                    const float mine = c == 0 ? dsum[0] : (c == 1 ? dsum[1] : (c == 2 ? dsum[2] : dsum[3]));
-                                    st[k0 + c] = P.alpha * mine;
+                                    const A mine = c == 0 ? dsum[0] : (c == 1 ? dsum[1] : (c == 2 ? dsum[2] : dsum[3]));
+                                    st[k0 + c] = (A)P.alpha * mine;
                                 }
                             } else {   // two lanes per row: each stages two of the four sums
-                                st[k0 + c] = P.alpha * (c == 0 ? dsum[0] : dsum[1]);
-                                st[k0 + 2 + c] = P.alpha * (c == 0 ? dsum[2] : dsum[3]);
+                                st[k0 + c] = (A)P.alpha * (c == 0 ? dsum[0] : dsum[1]);
+                                st[k0 + 2 + c] = (A)P.alpha * (c == 0 ? dsum[2] : dsum[3]);
                             }
                         };
                         if constexpr (NCH > 0) {   // three stages, as in the SpMM above
@@ -713,19 +736,20 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
                         // transposed walk: value of entry k of halo row i sits at slot k of i's staged value row
                         // (padded entries point both reads beyond the LDS allocation: 0 · 0)
                         const char* const vcb = sm + P.o_vals + csl[q];
-                        auto load_val = [](const char* at) -> float {
-                            if constexpr (kVB == 4) return *reinterpret_cast<const float*>(at);
+                        auto load_val = [](const char* at) -> A {
+                            if constexpr (kVB == 8) return *reinterpret_cast<const double*>(at);
+                            else if constexpr (kVB == 4) return *reinterpret_cast<const float*>(at);
                             else return __uint_as_float((uint32_t)*reinterpret_cast<const unsigned short*>(at) << 16);
                         };
 #pragma unroll
                         for (int cp = 0; cp < CPL; ++cp) {
 #pragma unroll
-                            for (int v = 0; v < VEC; ++v) acc[q][cp][v] = 0.f;
+                            for (int v = 0; v < VEC; ++v) acc[q][cp][v] = (A)0;
                         }
                         if constexpr (NCH > 0) {   // three stages: records of chunk i+2, dense rows + values of chunk i+1, FMAs of chunk i
                             int4 r01[3], r23[3];
                             uint4 b[2][4][CPL];
-                            float a[2][4];
+                            A a[2][4];
                             auto stage_a = [&](int i) {
                                 if constexpr (kPacked) {
                                     r01[i % 3] = *reinterpret_cast<const int4*>(tb + 16 * i);
@@ -782,7 +806,7 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
                                     vo[0] = r01.y, vo[1] = r01.w, vo[2] = r23.y, vo[3] = r23.w;
                                 }
                                 uint4 b[4][CPL];
-                                float a[4];
+                                A a[4];
 #pragma unroll
                                 for (int j = 0; j < 4; ++j) {
                                     load_b(go[j], b[j]);
@@ -840,7 +864,7 @@ inline int lat_layout(LatParams& P, int mode, int cl, int vbytes, int nt) {
         return TSGU_ERR_BAD_ARG;
     const int HR = (P.ty + 2 * P.ry) * (P.tz + 2 * P.rz), NR = P.ty * P.tz, RB = cl * 16;
     const bool packed = false && mode == kLatSpmmT && RB % 128 == 0;   // see kPacked in lattice_kernel
-    P.slot = packed ? RB : lat_round16(P.recw * (mode == kLatSddmm ? 4 : vbytes));
+    P.slot = packed ? RB : lat_round16(P.recw * (mode == kLatSddmm ? (vbytes == 8 ? 8 : 4) : vbytes));   // SDDMM: a row of the accumulation type
     // a pitch of a multiple of 64 bytes would put the value rows of a wave on four banks (bf16, 28 entries: 64 -> 80 bytes)
     if (!packed && P.slot % 64 == 0) P.slot += 16;
     if (packed && P.recw * vbytes > RB) return TSGU_ERR_TOO_LARGE;
@@ -896,6 +920,7 @@ int lat_launch_one(const LatParams& P, hipStream_t stream) {
     }
     // (the unrolled, three-stage products of 2-byte values need more than the 128 registers of four waves per SIMD: they take
     // the run-time loop)
+    if (sizeof(V) == 8) return lat_launch_nch<V, CL, 1, MODE, NT, 0>(P, stream);   // fp64: the run-time loop (the unrolled pipeline needs twice the registers)
     if (P.recw == 28 && !(MODE != kLatSddmm && sizeof(V) == 2)) return lat_launch_nch<V, CL, 1, MODE, NT, 7>(P, stream);
     if (P.recw == 8) return lat_launch_nch<V, CL, 1, MODE, NT, 2>(P, stream);
     return lat_launch_nch<V, CL, 1, MODE, NT, 0>(P, stream);
