@@ -288,7 +288,7 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
                         // full speed — measured faster than staging from the 4-byte boundary below and shifting in the reader)
                         const uint32_t off = uniform ? vuo[d] : (uint32_t)st[d] * kVB + vch16[d];
                         if (__builtin_expect(plane0 + off + 16u <= val_bytes, 1)) {
-                            lat_dma16<true>(pbase, off, base + (unsigned)(d * NT * 16));
+                            lat_dma16<MODE == kLatSpmm>(pbase, off, base + (unsigned)(d * NT * 16));   // (transposed walk: the neighbouring tiles read these halo value rows again — no streaming policy)
                         } else {
                             // the last 16 bytes of the value array: element-wise, never reading beyond the array
                             V* dst = reinterpret_cast<V*>(sm + region + (d * NT + tid) * 16);

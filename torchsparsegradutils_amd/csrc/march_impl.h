@@ -62,11 +62,17 @@ struct MarchParams {
     int o_vals, o_tab, o_rows, lds_bytes;   // LDS layout (bytes), filled by march_layout
 };
 
-// 4-byte LDS-DMA: lane l's dword lands at `lds_wave_base + 4*l`
+// 4-byte LDS-DMA: lane l's dword lands at `lds_wave_base + 4*l`.  NT_POLICY: streaming (the values of a tile's own rows are read
+// once); off for the transposed product, whose halo value rows the neighbouring tiles read again (they should stay in L2)
+template <bool NT_POLICY>
 __device__ __forceinline__ void lat_dma4(const void* sbase64, uint32_t voff, unsigned lds_wave_base) {
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2 nt\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(sbase64), "s"(lds_wave_base) : "memory");
+    if constexpr (NT_POLICY)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2 nt\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(sbase64), "s"(lds_wave_base) : "memory");
+    else
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(sbase64), "s"(lds_wave_base) : "memory");
 }
 
 template <int I, int N, typename F>
@@ -238,7 +244,7 @@ __global__ __launch_bounds__(NT, 4) void march_kernel(const MarchParams P) {
                     if (plain) {
                         if (foff[q] != kLatNone) {
                             if (__builtin_expect(plane0 + foff[q] + 16u <= val_bytes, 1)) {
-                                lat_dma16<true>(pbase, foff[q], wbase);
+                                lat_dma16<MODE == kLatSpmm>(pbase, foff[q], wbase);
                             } else {   // the last 16 bytes of the value array: element-wise, never reading beyond the array
                                 float* dst = reinterpret_cast<float*>(sm + region + first * VP + lane * 16);
 #pragma nounroll
@@ -256,7 +262,7 @@ __global__ __launch_bounds__(NT, 4) void march_kernel(const MarchParams P) {
                             const int rr = (rw < RPW && first + rw < staged_rows) ? rows_s[first + rw] : -1;
                             if (rr >= 0 && slot < NS) {
                                 const int k = kidx_s[rc * 32 + slot];
-                                lat_dma4(pbase, (uint32_t)rr * (uint32_t)(NS * 4) + (uint32_t)k * 4u, wbase + (unsigned)(n * kWave * 4));
+                                lat_dma4<MODE == kLatSpmm>(pbase, (uint32_t)rr * (uint32_t)(NS * 4) + (uint32_t)k * 4u, wbase + (unsigned)(n * kWave * 4));
                             }
                         }
                     }
