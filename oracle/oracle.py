@@ -174,13 +174,17 @@ def triangular_solve_fwd_bwd(crow, col, val, B, G, upper, unit, transpose):
 
 
 def linear_cg(crow, col, val, rhs, tolerance, max_iter=1000, eps=1e-10, stop_updating_after=1e-10,
-              record_iters=()):
-    """Multi-RHS CG without preconditioner (reference utils/linear_cg.py:213-430, n_tridiag=0).
+              record_iters=(), n_tridiag=0, max_tridiag_iter=20, precond_diag=None):
+    """Multi-RHS CG (reference utils/linear_cg.py:213-430), optionally with a diagonal (Jacobi) preconditioner
+    `precond_diag` (z = r * precond_diag) and with the Lanczos tridiagonal matrices of the first `n_tridiag` columns
+    (reference :303-310, :385-427).
 
-    Returns (x, iterations, snapshots) where snapshots[k] is the un-normalised iterate after k
-    iterations for k in record_iters."""
+    Returns (x, iterations, snapshots) where snapshots[k] is the un-normalised iterate after k iterations for k in
+    record_iters — and, for n_tridiag > 0, (x, iterations, snapshots, T) with T of shape (n_tridiag, r, r)."""
     dt = rhs.dtype
     e = dt.type(eps)
+    n = rhs.shape[0]
+    n_tridiag_iter = min(max_tridiag_iter, n)  # :251
     rhs_norm = np.sqrt((rhs * rhs).sum(0, keepdims=True, dtype=dt))  # :257
     rhs_is_zero = rhs_norm < e
     rhs_norm = np.where(rhs_is_zero, dt.type(1), rhs_norm)
@@ -190,33 +194,62 @@ def linear_cg(crow, col, val, rhs, tolerance, max_iter=1000, eps=1e-10, stop_upd
     rnorm = np.sqrt((r * r).sum(0, keepdims=True, dtype=dt))
     has_conv = rnorm < dt.type(stop_updating_after)
     snaps = {}
-    if has_conv.all():
-        return x * rhs_norm, 0, snaps
-    pvec = r.copy()
-    rr = (r * r).sum(0, keepdims=True, dtype=dt)  # :294
+    t_mat = np.zeros((n_tridiag_iter, n_tridiag_iter, n_tridiag), dtype=dt) if n_tridiag else None
+
+    def done(k_done, last):
+        if n_tridiag:
+            return x * rhs_norm, k_done, snaps, np.ascontiguousarray(t_mat[: last + 1, : last + 1].transpose(2, 0, 1))  # :426-427
+        return x * rhs_norm, k_done, snaps
+
+    if has_conv.all() and not n_tridiag:  # :286
+        return done(0, 0)
+    prec = (lambda v: v.copy()) if precond_diag is None else (lambda v: v * precond_diag.reshape(-1, 1).astype(dt))
+    z = prec(r)
+    pvec = z.copy()
+    rz = (z * r).sum(0, keepdims=True, dtype=dt)  # :294
     k_done = 0
+    update_tridiag, last_tridiag_iter = True, 0
+    prev_alpha_recip = prev_beta = None
     for k in range(max_iter):
         Ap = csr_spmm(crow, col, val, pvec)  # :322
         pAp = (pvec * Ap).sum(0, keepdims=True, dtype=dt)  # :64-65
         zero = pAp < e
-        alpha = np.where(zero, dt.type(0), rr / np.where(zero, dt.type(1), pAp))  # :68-71
+        alpha = np.where(zero, dt.type(0), rz / np.where(zero, dt.type(1), pAp))  # :68-71
         alpha = np.where(has_conv, dt.type(0), alpha)  # :74
         r = r - alpha * Ap  # :78
+        z = prec(r)
         x = x + alpha * pvec  # :32
-        rr_old = rr
-        rr = (r * r).sum(0, keepdims=True, dtype=dt)  # :36-37
-        zero = rr_old < e
-        beta = np.where(zero, dt.type(0), rr / np.where(zero, dt.type(1), rr_old))  # :40-43
-        pvec = pvec * beta + r  # :47
+        rz_old = rz
+        rz = (z * r).sum(0, keepdims=True, dtype=dt)  # :36-37
+        zero = rz_old < e
+        beta = np.where(zero, dt.type(0), rz / np.where(zero, dt.type(1), rz_old))  # :40-43
+        pvec = pvec * beta + z  # :47
         rnorm = np.sqrt((r * r).sum(0, keepdims=True, dtype=dt))  # :372
         rnorm = np.where(rhs_is_zero, dt.type(0), rnorm)
         has_conv = rnorm < dt.type(stop_updating_after)  # :374
         k_done = k + 1
         if k_done in record_iters:
             snaps[k_done] = (x * rhs_norm).copy()
-        if k >= min(10, max_iter - 1) and rnorm.mean() < tolerance:  # :376-382
+        if (k >= min(10, max_iter - 1) and rnorm.mean() < tolerance
+                and not (n_tridiag and k < min(n_tridiag_iter, max_iter - 1))):  # :376-382
             break
-    return x * rhs_norm, k_done, snaps
+        if n_tridiag and k < n_tridiag_iter and update_tridiag:  # :385-406
+            a_t = alpha[0, :n_tridiag]
+            b_t = beta[0, :n_tridiag]
+            a_zero = a_t == 0
+            a_recip = dt.type(1) / np.where(a_zero, dt.type(1), a_t)
+            if k == 0:
+                t_mat[k, k] = a_recip
+            else:
+                t_mat[k, k] = a_recip + prev_beta * prev_alpha_recip
+                t_mat[k, k - 1] = np.sqrt(prev_beta) * prev_alpha_recip
+                t_mat[k - 1, k] = t_mat[k, k - 1]
+                if t_mat[k - 1, k].max() < 1e-6:
+                    update_tridiag = False
+            last_tridiag_iter = k
+            prev_alpha_recip = a_recip
+            prev_beta = b_t.copy()
+    return done(k_done, last_tridiag_iter)
 
 
 def bicgstab(crow, col, val, b, matvec_max=None, abstol=1e-8, reltol=1e-6):

@@ -706,6 +706,53 @@ def test_cg_iterates_match_reference(dt):
     assert rel(x, z[vn + "_final"]) < 10 * tol
 
 
+def test_cg_lanczos_tridiagonal_matrices_match_reference():
+    """linear_cg(n_tridiag > 0) on the GPU (reference utils/linear_cg.py:303-310, :385-427; its tests/test_linear_cg.py:42,79):
+    solution and Lanczos tridiagonal matrices against golden vectors of the real reference — plain, all columns with the early
+    stop, a five-iteration cap, Jacobi-preconditioned, batched right-hand sides, fp32; and the eigenvalue property the
+    reference's own test checks."""
+    from torchsparsegradutils_amd.utils import linear_cg
+
+    z = G.load("cg_tridiag.npz")
+    n = z["rhs"].shape[0]
+
+    def mat(dt):
+        return torch.sparse_csr_tensor(G.t(z["crow"], DEV), G.t(z["col"], DEV), G.t(z["val"], DEV).to(dt), (n, n))
+
+    cases = (("plain", dict(n_tridiag=4, max_tridiag_iter=10, max_iter=n, tolerance=0, eps=1e-15), torch.float64),
+             ("all_cols", dict(n_tridiag=6, max_tridiag_iter=25, max_iter=40, tolerance=1e-3), torch.float64),
+             ("short", dict(n_tridiag=2, max_tridiag_iter=5, max_iter=5, tolerance=0), torch.float64),
+             ("f32", dict(n_tridiag=5, max_tridiag_iter=10, max_iter=n, tolerance=0, eps=1e-15), torch.float32))
+    import warnings
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for tag, kw, dt in cases:
+            x, T = linear_cg(mat(dt), G.t(z["rhs"], DEV).to(dt), **kw)
+            tol = 1e-9 if dt == torch.float64 else 2e-4
+            assert tuple(T.shape) == z[tag + "_T"].shape and T.dtype == dt, tag
+            assert rel(T, z[tag + "_T"]) < tol, (tag, rel(T, z[tag + "_T"]))
+            assert rel(x, z[tag + "_x"]) < tol, (tag, rel(x, z[tag + "_x"]))
+        dinv = G.t(z["dinv"], DEV)
+        x, T = linear_cg(mat(torch.float64), G.t(z["rhs"], DEV), n_tridiag=3, max_tridiag_iter=8, max_iter=n, tolerance=0, eps=1e-15,
+                         preconditioner=lambda v: v * dinv)
+        assert rel(T, z["jacobi_T"]) < 1e-9 and rel(x, z["jacobi_x"]) < 1e-9
+        x, T = linear_cg(mat(torch.float64), G.t(z["batched_rhs"], DEV), n_tridiag=2, max_tridiag_iter=7, max_iter=n, tolerance=0, eps=1e-15)
+        assert tuple(T.shape) == z["batched_T"].shape == (2, 2, 7, 7)
+        assert rel(T, z["batched_T"]) < 1e-9 and rel(x, z["batched_x"]) < 1e-9
+        # a callable operator and a vector right-hand side
+        A = mat(torch.float64)
+        x1, T1 = linear_cg(lambda v: A @ v, G.t(z["rhs"], DEV)[:, 0], n_tridiag=1, max_tridiag_iter=10, max_iter=n, tolerance=0, eps=1e-15)
+        assert x1.shape == (n,) and T1.shape == (1, 10, 10) and rel(T1[0], z["plain_T"][0]) < 1e-9
+    # what the reference's own test checks: the extreme eigenvalues of T approximate those of A
+    ev = torch.linalg.eigvalsh(T1[0].cpu())
+    dense = torch.sparse_csr_tensor(G.t(z["crow"]), G.t(z["col"]), G.t(z["val"]), (n, n)).to_dense()
+    ea = torch.linalg.eigvalsh(dense)
+    assert abs(float(ev[-1] - ea[-1])) / float(ea[-1]) < 5e-2 and float(ev[0]) >= float(ea[0]) - 1e-9
+    with pytest.raises(RuntimeError, match="Getting a tridiagonalization larger"):
+        linear_cg(A, G.t(z["rhs"], DEV), n_tridiag=1, max_tridiag_iter=10, max_iter=5)
+
+
 def test_cg_stops_on_tolerance_and_vector_rhs():
     from torchsparsegradutils_amd.utils import LinearCGSettings, linear_cg
     from oracle import oracle

@@ -127,6 +127,24 @@ def test_cg_iterates_and_count(vn, dt):
     assert G.rel_err(x, z[vn + "_final"]) < tol
 
 
+def test_cg_lanczos_tridiagonal_matrices():
+    """linear_cg(n_tridiag > 0): the oracle's solution and tridiagonal matrices against the real reference's
+    (tests/golden/make_golden_r3.py): plain, all columns with an early stop, a five-iteration cap, Jacobi-preconditioned, fp32."""
+    z = G.load("cg_tridiag.npz")
+    A = (z["crow"], z["col"], z["val"])
+    cases = (("plain", dict(n_tridiag=4, max_tridiag_iter=10, max_iter=336, tolerance=0, eps=1e-15), np.float64, None),
+             ("all_cols", dict(n_tridiag=6, max_tridiag_iter=25, max_iter=40, tolerance=1e-3), np.float64, None),
+             ("short", dict(n_tridiag=2, max_tridiag_iter=5, max_iter=5, tolerance=0), np.float64, None),
+             ("jacobi", dict(n_tridiag=3, max_tridiag_iter=8, max_iter=336, tolerance=0, eps=1e-15), np.float64, z["dinv"]),
+             ("f32", dict(n_tridiag=5, max_tridiag_iter=10, max_iter=336, tolerance=0, eps=1e-15), np.float32, None))
+    for tag, kw, dt, dinv in cases:
+        x, _, _, T = oracle.linear_cg(A[0], A[1], A[2].astype(dt), z["rhs"].astype(dt), precond_diag=dinv, **kw)
+        tol = 1e-9 if dt == np.float64 else 2e-4
+        assert T.shape == z[tag + "_T"].shape, tag
+        assert G.rel_err(T, z[tag + "_T"]) < tol, (tag, G.rel_err(T, z[tag + "_T"]))
+        assert G.rel_err(x, z[tag + "_x"]) < tol, (tag, G.rel_err(x, z[tag + "_x"]))
+
+
 def test_bicgstab_fp32_default_settings():
     z = G.load("generic_small.npz")
     T = z["nonsym_T"].astype(np.float32)

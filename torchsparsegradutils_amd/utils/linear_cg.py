@@ -67,9 +67,10 @@ def linear_cg(
     r"""Solve SPD systems :math:`A x = b` for one or many right-hand sides with conjugate gradients.
 
     ``matmul_closure`` is a tensor (dense, or sparse COO/CSR → HIP SpMM) or a callable ``v -> A v``;
-    ``rhs`` is ``(n,)`` or ``(n, k)`` on the GPU.  Arguments and defaults mirror the reference; the
-    Lanczos tridiagonalisation output (``n_tridiag > 0``, reference :303-310, :385-406) is not
-    provided by this build and raises ``NotImplementedError``.
+    ``rhs`` is ``(n,)`` or ``(n, k)`` (or batched ``(*batch, n, k)``) on the GPU.  Arguments and defaults mirror the
+    reference.  ``n_tridiag > 0`` also returns the Lanczos tridiagonal matrices of the first ``n_tridiag`` columns,
+    ``(n_tridiag, *batch, r, r)`` (reference :303-310, :385-406): those solves run the recurrences as tensor ops around the HIP
+    SpMM and dot kernels (the coefficients of every iteration are needed on the way), not the fused step kernels.
     """
     _be.require_device(rhs)
     if rhs.ndimension() > 2:
@@ -92,13 +93,14 @@ def linear_cg(
         tolerance = settings.cg_tolerance
     if max_tridiag_iter > max_iter:
         raise RuntimeError("Getting a tridiagonalization larger than the number of CG iterations run is not possible!")
-    if n_tridiag:
-        raise NotImplementedError("Lanczos tridiagonalisation (n_tridiag > 0) is outside the gfx950 hot path")
-
     op = as_operator(matmul_closure)
 
     num_rows, p = rhs.shape
     n_iter = min(max_iter, num_rows) if settings.terminate_cg_by_size else max_iter
+    n_tridiag = int(n_tridiag)
+    if n_tridiag < 0 or n_tridiag > p:
+        raise RuntimeError(f"n_tridiag must be between 0 and the number of right-hand sides ({p}), got {n_tridiag}")
+    n_tridiag_iter = min(max_tridiag_iter, num_rows)
     dtype, dev = rhs.dtype, rhs.device
     if dtype not in (torch.float32, torch.float64):
         raise RuntimeError(f"linear_cg: unsupported dtype {dtype}")
@@ -125,18 +127,22 @@ def linear_cg(
 
     residual_norm = _colnorm(residual)
     has_converged = torch.lt(residual_norm, stop_updating_after)
-    if bool(has_converged.all()):
+    if bool(has_converged.all()) and not n_tridiag:          # (reference :286)
         n_iter = 0
 
     tolerance_reached = False
     k_done = 0
+    t_mat = None
+    if n_tridiag:
+        t_mat = torch.zeros(n_tridiag_iter, n_tridiag_iter, n_tridiag, dtype=dtype, device=dev)
     if n_iter > 0:
-        if preconditioner is not None:
-            result, residual_norm, k_done, tolerance_reached = _pcg_loop(
+        if preconditioner is not None or n_tridiag:
+            result, residual_norm, k_done, tolerance_reached, last_tridiag_iter = _pcg_loop(
                 op, preconditioner, rhs_is_zero, result, residual, has_converged, n_iter, max_iter, tolerance, eps,
-                stop_updating_after,
+                stop_updating_after, n_tridiag, n_tridiag_iter, t_mat,
             )
         else:
+            last_tridiag_iter = 0
             result, residual_norm, k_done, tolerance_reached = _fused_loop(
                 op, rhs_is_zero, result, residual, has_converged, n_iter, max_iter, tolerance, eps,
                 stop_updating_after,
@@ -164,6 +170,10 @@ def linear_cg(
 
     if is_vector:
         result = result.squeeze(-1)
+    if n_tridiag:
+        last = last_tridiag_iter if n_iter > 0 else 0
+        t_mat = t_mat[: last + 1, : last + 1]
+        return result, t_mat.permute(-1, 0, 1).contiguous()       # (reference :426-427)
     return result
 
 
@@ -187,8 +197,6 @@ def _batched_rhs(matmul_closure, rhs, n_tridiag, tolerance, eps, stop_updating_a
     and convergence are per (batch, column), the stop rule is their mean): the batch is folded into the columns,
     ``(n, batch·k)``, and solved by the 2-D path.  A 2-D sparse operator applies to every column alike; any other
     closure sees its own ``(*batch, n, k)`` layout through a reshaping wrapper."""
-    if n_tridiag:
-        raise NotImplementedError("Lanczos tridiagonalisation (n_tridiag > 0) is outside the gfx950 hot path")
     batch_shape = tuple(rhs.shape[:-2])
     n, k = rhs.shape[-2:]
     nb = 1
@@ -210,8 +218,17 @@ def _batched_rhs(matmul_closure, rhs, n_tridiag, tolerance, eps, stop_updating_a
         op = wrap(as_operator(matmul_closure))
     x0 = None if initial_guess is None else fold(initial_guess.expand(rhs.shape))
     pre = None if preconditioner is None else wrap(preconditioner)
-    out = linear_cg(op, fold(rhs).contiguous(), 0, tolerance, eps, stop_updating_after, max_iter, max_tridiag_iter, x0, pre, settings)
-    return unfold(out)
+    if not n_tridiag:
+        out = linear_cg(op, fold(rhs).contiguous(), 0, tolerance, eps, stop_updating_after, max_iter, max_tridiag_iter, x0, pre, settings)
+        return unfold(out)
+    # Lanczos coefficients of the first n_tridiag columns of EVERY batch item: tridiagonalise all folded columns, then pick
+    if n_tridiag > k:
+        raise RuntimeError(f"n_tridiag must be between 0 and the number of right-hand sides ({k}), got {n_tridiag}")
+    out, t_all = linear_cg(op, fold(rhs).contiguous(), nb * k, tolerance, eps, stop_updating_after, max_iter, max_tridiag_iter, x0,
+                           pre, settings)
+    r = t_all.shape[-1]
+    t_sel = t_all.reshape(nb, k, r, r)[:, :n_tridiag]                       # (batch, n_tridiag, r, r)
+    return unfold(out), t_sel.permute(1, 0, 2, 3).reshape((n_tridiag,) + batch_shape + (r, r)).contiguous()
 
 
 def _fused_loop(op, rhs_is_zero, x, r, has_converged, n_iter, max_iter, tolerance, eps, stop_after):
@@ -284,10 +301,14 @@ def _fused_loop(op, rhs_is_zero, x, r, has_converged, n_iter, max_iter, toleranc
     return x, rnorm, k_done, done
 
 
-def _pcg_loop(op, preconditioner, rhs_is_zero, x, r, has_converged, n_iter, max_iter, tolerance, eps, stop_after):
-    """Preconditioned iterations (reference :323-355).  The user's preconditioner is an opaque
-    callable, so the recurrences run as device tensor ops around it; SpMM and dots stay on the HIP kernels."""
+def _pcg_loop(op, preconditioner, rhs_is_zero, x, r, has_converged, n_iter, max_iter, tolerance, eps, stop_after,
+              n_tridiag=0, n_tridiag_iter=0, t_mat=None):
+    """Iterations with the recurrences as device tensor ops (reference :319-406): preconditioned solves — the user's
+    preconditioner is an opaque callable — and solves that also return Lanczos tridiagonal matrices, which need alpha and beta
+    of every iteration.  SpMM and dots stay on the HIP kernels."""
     dtype = r.dtype
+    if preconditioner is None:
+        preconditioner = _default_preconditioner
     z = preconditioner(r)
     pvec = z.clone() if z is r else z
     rz = _be.coldot(z.contiguous(), r).unsqueeze(0)
@@ -295,6 +316,8 @@ def _pcg_loop(op, preconditioner, rhs_is_zero, x, r, has_converged, n_iter, max_
     done = False
     k_done = 0
     eps_t = torch.tensor(eps, dtype=dtype, device=r.device)
+    update_tridiag, last_tridiag_iter = True, 0
+    prev_alpha_reciprocal = prev_beta = None
     for k in range(n_iter):
         Ap = checked(op(pvec), dtype).contiguous()
         pap = _be.coldot(pvec.contiguous(), Ap).unsqueeze(0)
@@ -312,7 +335,25 @@ def _pcg_loop(op, preconditioner, rhs_is_zero, x, r, has_converged, n_iter, max_
         rnorm = _colnorm(r.contiguous()).masked_fill_(rhs_is_zero, 0)
         has_converged = rnorm < stop_after
         k_done = k + 1
-        if k >= min(10, max_iter - 1) and bool(rnorm.mean() < tolerance):
+        if (k >= min(10, max_iter - 1) and bool(rnorm.mean() < tolerance)
+                and not (n_tridiag and k < min(n_tridiag_iter, max_iter - 1))):
             done = True
             break
-    return x, rnorm, k_done, done
+        # Lanczos tridiagonal matrices from the CG coefficients (reference :385-406)
+        if n_tridiag and k < n_tridiag_iter and update_tridiag:
+            alpha_tridiag = alpha.squeeze(0)[:n_tridiag]
+            beta_tridiag = beta.squeeze(0)[:n_tridiag]
+            alpha_is_zero = alpha_tridiag == 0
+            alpha_reciprocal = torch.where(alpha_is_zero, torch.ones_like(alpha_tridiag), alpha_tridiag).reciprocal()
+            if k == 0:
+                t_mat[k, k].copy_(alpha_reciprocal)
+            else:
+                t_mat[k, k] = alpha_reciprocal + prev_beta * prev_alpha_reciprocal
+                t_mat[k, k - 1] = prev_beta.sqrt() * prev_alpha_reciprocal
+                t_mat[k - 1, k].copy_(t_mat[k, k - 1])
+                if float(t_mat[k - 1, k].max()) < 1e-6:
+                    update_tridiag = False
+            last_tridiag_iter = k
+            prev_alpha_reciprocal = alpha_reciprocal
+            prev_beta = beta_tridiag.clone()
+    return x, rnorm, k_done, done, last_tridiag_iter
