@@ -370,6 +370,7 @@ int tsgu_lattice_block_classes(int64_t n_rows, const void* rcls, int nb, int nx,
  * Entries on the wrong side of the diagonal are ignored; with unit != 0 stored diagonal entries
  * are ignored too (same as the reference's backend).  X must NOT alias B.  B(i, c) = B[i·ldb + c·b_col_stride]
  * (b_col_stride = 1: row-major; transposed views are read in place), X is row-major.
+ * fp32, fp64 and bf16 (bf16 elements, fp32 arithmetic, x rounded once when it is published).
  * `work` : device scratch, tsgu_sptrsm_work_bytes() bytes, contents irrelevant on entry.
  */
 int tsgu_csr_sptrsm(int vtype, int itype,

@@ -706,6 +706,33 @@ def test_cg_iterates_match_reference(dt):
     assert rel(x, z[vn + "_final"]) < 10 * tol
 
 
+@pytest.mark.parametrize("transpose", [False, True])
+def test_triangular_solve_bf16(transpose):
+    """bf16 triangular solve (bf16 elements, fp32 arithmetic, x rounded once when it is published) and its gradients against the
+    fp64 oracle on the same bf16-rounded inputs: within bf16 rounding."""
+    from oracle import oracle
+    from torchsparsegradutils_amd import sparse_triangular_solve
+    from torchsparsegradutils_amd.utils import synthetic
+
+    n, k = 2048, 8
+    crow, col, val = synthetic.banded_lower(n, per_row=6, band=64)
+    g = torch.Generator().manual_seed(4)
+    vb = val.to(torch.bfloat16)
+    B = torch.randn(n, k, generator=g).to(torch.bfloat16)
+    Gd = torch.randn(n, k, generator=g).to(torch.bfloat16)
+    L = torch.sparse_csr_tensor(crow.to(DEV), col.to(DEV), vb.to(DEV), (n, n)).requires_grad_(True)
+    Bd = B.to(DEV).requires_grad_(True)
+    x = sparse_triangular_solve(L, Bd, upper=False, transpose=transpose)
+    assert x.dtype == torch.bfloat16
+    x.backward(Gd.to(DEV))
+    xo, gAo, gBo = oracle.triangular_solve_fwd_bwd(crow.numpy(), col.numpy(), vb.double().numpy(), B.double().numpy(), Gd.double().numpy(),
+                                                   False, False, transpose)
+    assert rel(x.detach().float(), xo) < 1.5e-2
+    assert rel(Bd.grad.float(), gBo) < 3e-2
+    assert rel(L.grad.values().float(), gAo) < 3e-2
+    assert L.grad.values().dtype == torch.bfloat16 and torch.equal(L.grad.col_indices().cpu(), col)
+
+
 def test_cg_lanczos_tridiagonal_matrices_match_reference():
     """linear_cg(n_tridiag > 0) on the GPU (reference utils/linear_cg.py:303-310, :385-427; its tests/test_linear_cg.py:42,79):
     solution and Lanczos tridiagonal matrices against golden vectors of the real reference — plain, all columns with the early

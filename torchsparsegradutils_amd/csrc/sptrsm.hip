@@ -59,6 +59,15 @@ struct Sentinel<double> {
     __device__ static __forceinline__ double val(Bits b) { return __longlong_as_double((long long)b); }
 };
 
+template <>
+struct Sentinel<bf16_t> {   // bf16 elements, fp32 arithmetic: x is rounded once, when it is published
+    using Bits = unsigned short;
+    static constexpr Bits kTag = 0x7fc5u;
+    static constexpr Bits kCanon = 0x7fc0u;
+    __device__ static __forceinline__ Bits bits(float v) { return VT<bf16_t>::down(v).bits; }
+    __device__ static __forceinline__ float val(Bits b) { return __uint_as_float((unsigned int)b << 16); }
+};
+
 template <typename V>
 __global__ __launch_bounds__(kBlock) void sptrsm_fill_kernel(void* X, int64_t ldx, int64_t n, int64_t p, TrsmWork* work) {
     using S = Sentinel<V>;
@@ -80,6 +89,7 @@ __global__ __launch_bounds__(kBlock) void sptrsm_syncfree_kernel(const TrsmParam
 
     using S = Sentinel<V>;
     using Bits = typename S::Bits;
+    using A = typename VT<V>::Acc;
     constexpr int EP = kWave / CL;
 
     const int lane = threadIdx.x & (kWave - 1);
@@ -106,12 +116,12 @@ __global__ __launch_bounds__(kBlock) void sptrsm_syncfree_kernel(const TrsmParam
         const int64_t s = (int64_t)ptr[row];
         const int64_t e = (int64_t)ptr[row + 1];
 
-        V acc = 0;
-        V diag = 0;
+        A acc = 0;
+        A diag = 0;
         bool dead = false;
         // the right-hand side is requested BEFORE the row waits for its dependencies: its latency is off the critical path
-        V rhs = 0;
-        if (ep == 0 && col_ok) rhs = B[row * P.ldb + c * P.bcs];
+        A rhs = 0;
+        if (ep == 0 && col_ok) rhs = VT<V>::up(B[row * P.ldb + c * P.bcs]);
         for (int64_t base = s; base < e; base += EP) {
             // entries are visited farthest-dependency first: ascending columns for a lower sweep, descending for an
             // upper one.  The nearest rows are the ones solved last (the critical path), so everything else of the row
@@ -119,10 +129,10 @@ __global__ __launch_bounds__(kBlock) void sptrsm_syncfree_kernel(const TrsmParam
             const int64_t k = P.lower ? base + ep : (e - 1) - (base - s) - ep;
             bool need = false;
             int64_t j = 0;
-            V a = 0;
+            A a = 0;
             if (k >= s && k < e) {
                 j = (int64_t)idx[k];
-                a = val[perm ? (int64_t)perm[k] : k];
+                a = VT<V>::up(val[perm ? (int64_t)perm[k] : k]);
                 if (j == row) {
                     diag += a;
                 } else {
@@ -166,7 +176,7 @@ __global__ __launch_bounds__(kBlock) void sptrsm_syncfree_kernel(const TrsmParam
             diag += shfl_xor_acc(diag, m);
         }
         if (ep == 0 && col_ok) {
-            V x = rhs - acc;
+            A x = rhs - acc;
             if (!P.unit) x = x / diag;
             Bits xb = S::bits(x);
             if (x != x) xb = S::kCanon;
@@ -267,6 +277,9 @@ int tsgu_csr_sptrsm(int vtype, int itype, int64_t n, int64_t nnz,
     } else if (vtype == TSGU_F64) {
         if (itype == TSGU_I32) return sptrsm_launch<double, int32_t>(P, n_cu, s);
         if (itype == TSGU_I64) return sptrsm_launch<double, int64_t>(P, n_cu, s);
+    } else if (vtype == TSGU_BF16) {
+        if (itype == TSGU_I32) return sptrsm_launch<bf16_t, int32_t>(P, n_cu, s);
+        if (itype == TSGU_I64) return sptrsm_launch<bf16_t, int64_t>(P, n_cu, s);
     }
     return TSGU_ERR_BAD_DTYPE;
 }
