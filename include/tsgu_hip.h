@@ -307,7 +307,7 @@ int tsgu_csr_sddmm_lattice(int vtype, const tsgu_lattice_plan* plan, int64_t n_r
  * others); gradA is written in A's stored order.  Sums run in canonical order: bit-identical to the plan-free kernels for
  * `ident` rows, equal to rounding for rows that wrap around a lattice face.  The transposed product needs no transposed
  * pattern and no second plan: entry (i -> j) is read from canonical slot (dx+1)·ntap + tap(dy, dz) of source row i's staged values.
- * fp32 only; p in {32, 64}.
+ * fp32 only; p in {16, 32, 64}.
  */
 typedef struct tsgu_march_plan {
     int32_t nb, nx, ny, nz;   /* items, planes per item, lines per plane, points per line (each of nx, ny, nz >= 3) */

@@ -51,7 +51,7 @@ CASES = [
 
 
 @pytest.mark.parametrize("nb,nx,ny,nz,configs", CASES)
-@pytest.mark.parametrize("p", [32, 64])
+@pytest.mark.parametrize("p", [32, 64, 16])
 def test_march_kernels_match_oracle_and_plan_free_kernels(nb, nx, ny, nz, configs, p):
     be, lt, pt = _mods()
     dev = torch.device("cuda:0")
@@ -93,9 +93,11 @@ def test_march_kernels_match_oracle_and_plan_free_kernels(nb, nx, ny, nz, config
         assert G.rel_err(C.cpu().numpy(), Co) < 1e-5, cs
         assert G.rel_err(gA.cpu().numpy(), gAo) < 1e-5, cs
         assert G.rel_err(gB.cpu().numpy(), gBo) < 1e-5, cs
-        # the dots do not depend on the order of the walk; the sums run in canonical order = stored order of the canonical class
-        assert torch.equal(gA, gA0), cs
-        assert torch.equal(C[inner], C0[inner]) and torch.equal(gB[inner], gB0[inner]), cs
+        if p >= 32:
+            # the dots do not depend on the order of the walk; the sums run in canonical order = stored order of the canonical
+            # class (narrower dense rows: the plan-free kernels split a row's entries over several entry lanes)
+            assert torch.equal(gA, gA0), cs
+            assert torch.equal(C[inner], C0[inner]) and torch.equal(gB[inner], gB0[inner]), cs
     mt._cfg.clear()
 
 
@@ -124,9 +126,9 @@ def test_alpha_and_leading_dimensions():
     assert torch.equal(be.csr_sddmm_lattice(lp, cfgs[1], Gc, Bc), be.csr_sddmm(plan.crow, plan.col, Gc, Bc, n, n))
 
 
-@pytest.mark.parametrize("what", ["truncated", "seven", "lower", "bf16", "p16", "two_d"])
+@pytest.mark.parametrize("what", ["truncated", "seven", "lower", "bf16", "p8", "two_d"])
 def test_not_covered_falls_back_to_the_general_sweep(what):
-    """Truncated / 7-point / triangular stencils, bf16 and 16 columns are not plane-march cases: march_config says None and the
+    """Truncated / 7-point / triangular stencils, bf16 and 8 columns are not plane-march cases: march_config says None and the
     public path takes the general plane sweep (tests/test_gpu_lattice.py)."""
     be, lt, pt = _mods()
     dev = torch.device("cuda:0")
@@ -141,9 +143,9 @@ def test_not_covered_falls_back_to_the_general_sweep(what):
     lp = lt.build_lattice_plan_hip(plan, be)
     assert lp is not None
     dtype = torch.bfloat16 if what == "bf16" else torch.float32
-    p = 16 if what == "p16" else 32
+    p = 8 if what == "p8" else 32
     assert be.march_config(lp, be.LAT_SPMM, dtype, p) is None
-    if what in ("bf16", "p16"):
+    if what in ("bf16", "p8"):
         assert lt.march_tables(lp) is not None            # the pattern qualifies, the operands do not
     else:
         assert lt.march_tables(lp) is None

@@ -86,3 +86,9 @@ def floor():
 
 
 t("trivial Function + autograd.grad (torch's floor)", floor)
+
+torch.autograd.set_multithreading_enabled(False)
+t("step, autograd multithreading OFF", step)
+t("trivial Function + grad, multithreading OFF", floor)
+torch.autograd.set_multithreading_enabled(True)
+t("step, multithreading ON again", step)

@@ -663,8 +663,10 @@ def march_tables(plan: LatticePlan) -> Optional[MarchTables]:
 
 def march_config_for(plan: LatticePlan, mode: int, vtype: int, p: int, lds_bytes_fn) -> Optional[MarchConfig]:
     """Cached launch configuration of the plane-march kernels for a stored-order plan, or None (pattern / operands not covered)."""
-    if not ENABLE_MARCH or vtype != 0 or p not in (32, 64):
+    if not ENABLE_MARCH or vtype != 0 or p not in (16, 32, 64):
         return None
+    if p == 16 and mode == 0 and not _MARCH_CFG_ENV:
+        return None      # 16 columns, forward: the general sweep is faster (measured at C2's lattice: 46 against 58 us; SDDMM 89 / 77, transposed 86 / 71)
     mt = march_tables(plan)
     if mt is None:
         return None

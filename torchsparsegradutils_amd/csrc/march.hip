@@ -8,7 +8,7 @@ namespace {
 int march_lanes(int vtype, int64_t p) {
     if (vtype != TSGU_F32 || p <= 0 || (p * 4) % 16) return 0;
     const int64_t cl = p * 4 / 16;
-    return (cl == 8 || cl == 16) ? (int)cl : 0;   // p = 32 or 64 (a wave stages the value rows of its own 64 / cl rows)
+    return (cl == 4 || cl == 8 || cl == 16) ? (int)cl : 0;   // p = 16, 32 or 64
 }
 
 int fill(MarchParams& P, const tsgu_march_plan* pl, int mode, int vtype, int64_t p, int64_t n_rows, int64_t nnz, int& cl) {
@@ -50,6 +50,7 @@ int fill(MarchParams& P, const tsgu_march_plan* pl, int mode, int vtype, int64_t
 template <int MODE, int NT>
 int go(int cl, const MarchParams& P, hipStream_t s) {
     switch (cl) {
+        case 4: return march_launch<float, 4, MODE, NT>(P, s);
         case 8: return march_launch<float, 8, MODE, NT>(P, s);
         case 16: return march_launch<float, 16, MODE, NT>(P, s);
     }

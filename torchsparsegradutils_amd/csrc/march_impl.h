@@ -125,7 +125,8 @@ __global__ __launch_bounds__(NT, 4) void march_kernel(const MarchParams P) {
     constexpr int NGI = (RPW * SLOTS + kWave - 1) / kWave;   // 4-byte DMA instructions that gather the value rows of a wave
     constexpr int NPASS = MODE == kLatSpmmT ? 2 : 1;        // staged rows: tile rows (one per group) or halo rows (up to two)
     constexpr int RJ = (NS + CL - 1) / CL;      // SDDMM: dots a lane keeps per target
-    static_assert(NT % kWave == 0 && kWave % CL == 0 && RPW * VL <= kWave && VP % 64 != 0, "geometry");
+    constexpr int NF = (RPW * VL + kWave - 1) / kWave;       // 16-byte DMA instructions that copy the value rows of a wave (plain path)
+    static_assert(NT % kWave == 0 && kWave % CL == 0 && VP % 64 != 0, "geometry");
 
     extern __shared__ uint4 lat_smem[];
     char* const sm = reinterpret_cast<char*>(lat_smem);
@@ -202,17 +203,21 @@ __global__ __launch_bounds__(NT, 4) void march_kernel(const MarchParams P) {
 
     // staged value rows: pass q, wave w stages rows q·NG + w·RPW .. + RPW - 1 (tile rows, or halo rows for the transposed product)
     //   srow[q]  the row whose class this lane loads (its group's row)
-    //   foff[q]  fast path: byte offset of this lane's 16-byte piece inside the plane's values (kLatNone: nothing)
+    //   foff[q][f]  plain path: byte offset of this lane's f-th 16-byte piece inside the plane's values (kLatNone: nothing)
     int srow[NPASS];
-    uint32_t foff[NPASS];
+    uint32_t foff[NPASS][NF];
     if constexpr (MODE != kLatSddmm) {
 #pragma unroll
         for (int q = 0; q < NPASS; ++q) {
             const int r = q * NG + g;
             srow[q] = r < staged_rows ? rows_s[r] : -1;
-            const int fr = q * NG + wave * RPW + lane / VL;
-            const int frow = (lane < RPW * VL && fr < staged_rows) ? rows_s[fr] : -1;
-            foff[q] = frow >= 0 ? (uint32_t)frow * (uint32_t)(NS * 4) + (uint32_t)(lane % VL) * 16u : kLatNone;
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                const int piece = f * kWave + lane;
+                const int fr = q * NG + wave * RPW + piece / VL;
+                const int frow = (piece < RPW * VL && fr < staged_rows) ? rows_s[fr] : -1;
+                foff[q][f] = frow >= 0 ? (uint32_t)frow * (uint32_t)(NS * 4) + (uint32_t)(piece % VL) * 16u : kLatNone;
+            }
         }
     }
 
@@ -242,14 +247,18 @@ __global__ __launch_bounds__(NT, 4) void march_kernel(const MarchParams P) {
                     const unsigned wbase = sbase + region + (unsigned)(first * VP);
                     const bool plain = __builtin_amdgcn_ballot_w64(srow[q] >= 0 && cls[q] != P.ident) == 0;
                     if (plain) {
-                        if (foff[q] != kLatNone) {
-                            if (__builtin_expect(plane0 + foff[q] + 16u <= val_bytes, 1)) {
-                                lat_dma16<MODE == kLatSpmm>(pbase, foff[q], wbase);
-                            } else {   // the last 16 bytes of the value array: element-wise, never reading beyond the array
-                                float* dst = reinterpret_cast<float*>(sm + region + first * VP + lane * 16);
+#pragma unroll
+                        for (int f = 0; f < NF; ++f) {
+                            const uint32_t fo = foff[q][f];
+                            if (fo != kLatNone) {
+                                if (__builtin_expect(plane0 + fo + 16u <= val_bytes, 1)) {
+                                    lat_dma16<MODE == kLatSpmm>(pbase, fo, wbase + (unsigned)(f * kWave * 16));
+                                } else {   // the last 16 bytes of the value array: element-wise, never reading beyond the array
+                                    float* dst = reinterpret_cast<float*>(sm + region + first * VP + (f * kWave + lane) * 16);
 #pragma nounroll
-                                for (int e = 0; e < 4; ++e)
-                                    dst[e] = plane0 + foff[q] + (e + 1) * 4 <= val_bytes ? *reinterpret_cast<const float*>(pbase + foff[q] + e * 4) : 0.f;
+                                    for (int e = 0; e < 4; ++e)
+                                        dst[e] = plane0 + fo + (e + 1) * 4 <= val_bytes ? *reinterpret_cast<const float*>(pbase + fo + e * 4) : 0.f;
+                                }
                             }
                         }
                     } else {
