@@ -97,6 +97,19 @@ __global__ __launch_bounds__(kBlock) void sptrsm_fill_kernel(void* X, int64_t ld
     }
 }
 
+// Sum over the EP consecutive lanes of a group (every lane gets the total): DPP for groups up to a row of 16, wave shuffles beyond
+template <typename A, int EP>
+__device__ __forceinline__ A entry_sum(A x) {
+    if constexpr (EP <= 16) {
+        return group_sum<A, EP>(x);
+    } else {
+        x = group_sum<A, 16>(x);
+#pragma unroll
+        for (int m = 16; m < EP; m <<= 1) x += shfl_xor_acc(x, m);
+        return x;
+    }
+}
+
 template <typename V, typename I, int CL>
 __global__ __launch_bounds__(kBlock) void sptrsm_syncfree_kernel(const TrsmParams P) {
 
@@ -106,8 +119,10 @@ __global__ __launch_bounds__(kBlock) void sptrsm_syncfree_kernel(const TrsmParam
     constexpr int EP = kWave / CL;
 
     const int lane = threadIdx.x & (kWave - 1);
-    const int cl = lane % CL;
-    const int ep = lane / CL;
+    // the EP entry lanes of a column are NEIGHBOURS (lane = column·EP + entry): their sums are DPP row operations (a few cycles
+    // each) instead of ds_bpermute round trips — this reduction sits on the critical path of every dependency hop
+    const int cl = lane / EP;
+    const int ep = lane % EP;
     const int tile = blockIdx.y;
     const int64_t c = (int64_t)tile * CL + cl;
     const bool col_ok = c < P.p;
@@ -132,6 +147,7 @@ __global__ __launch_bounds__(kBlock) void sptrsm_syncfree_kernel(const TrsmParam
 
         A acc = 0;
         A diag = 0;
+        A inv = 1;            // 1 / diagonal: ready BEFORE the row's last dependency arrives (the diagonal is the last entry visited)
         bool dead = false;
         // the right-hand side is requested BEFORE the row waits for its dependencies: its latency is off the critical path
         A rhs = 0;
@@ -152,6 +168,10 @@ __global__ __launch_bounds__(kBlock) void sptrsm_syncfree_kernel(const TrsmParam
                 } else {
                     need = col_ok && (P.lower ? j < row : j > row);
                 }
+            }
+            if (base + EP >= e && !P.unit) {       // last round: the diagonal is among these entries
+                const A d = entry_sum<A, EP>(diag);
+                inv = (A)1 / d;
             }
             Bits xb = S::kTag;
             // poll: back-to-back agent-scope loads (the hop latency of the solve's critical path is the
@@ -184,14 +204,10 @@ __global__ __launch_bounds__(kBlock) void sptrsm_syncfree_kernel(const TrsmParam
             if (lane == 0) __hip_atomic_store(&work->error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             break;
         }
-#pragma unroll
-        for (int m = CL; m < kWave; m <<= 1) {
-            acc += shfl_xor_acc(acc, m);
-            diag += shfl_xor_acc(diag, m);
-        }
+        acc = entry_sum<A, EP>(acc);
         if (ep == 0 && col_ok) {
             A x = rhs - acc;
-            if (!P.unit) x = x / diag;
+            x = x * inv;       // (unit: inv = 1)
             Bits xb = S::bits(x);
             if (x != x) xb = S::kCanon;
             __hip_atomic_store(X + row * P.ldx + c, xb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
