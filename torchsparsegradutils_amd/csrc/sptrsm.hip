@@ -178,7 +178,7 @@ __global__ __launch_bounds__(kBlock) void sptrsm_syncfree_kernel(const TrsmParam
             // time between the producer's store and the first poll that sees it); the wall clock and the
             // error word are only consulted every 256 spins.
 #ifndef TSGU_TRSM_SLEEP
-#define TSGU_TRSM_SLEEP 4
+#define TSGU_TRSM_SLEEP 1
 #endif
             long long t0 = 0;
             for (unsigned spin = 0;; ++spin) {
