@@ -462,7 +462,7 @@ def main():
                                    "(first_steps_ms[1:] are such steps); the warm-up joins the build" if _ops.PLAN_ASYNC else
                                    "the row-pair plans are built inline (first_steps_ms[1] includes the build)")),
                 "first_step_note": "torch.autograd imports torch.fx.experimental.symbolic_shapes (sympy) inside the first backward that is given "
-                                   "explicit output gradients (150-450 ms); the package starts that import on a helper thread when it is "
+                                   "explicit output gradients (150-450 ms); the package performs that import when it is itself "
                                    "imported (TSGU_PREFETCH_IMPORTS=0 restores torch's lazy behaviour), so first_steps_ms[0] does not contain it",
                 "plan_join_ms_after_3_steps": round(plan_join_ms, 1),
                 "plans": plan_stats,

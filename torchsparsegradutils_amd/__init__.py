@@ -35,21 +35,19 @@ __version__ = "0.1.0"
 def _prefetch_lazy_torch_modules() -> None:
     """torch.autograd's Python front end imports torch.fx.experimental.symbolic_shapes (and with it sympy: 150-450 ms)
     the first time a backward pass is given explicit output gradients — inside the first training step of every process.
-    Start that import on a helper thread now, while the caller is still building its operands (TSGU_PREFETCH_IMPORTS=0: off)."""
+    Import it now, together with this package, where a start-up cost belongs (TSGU_PREFETCH_IMPORTS=0: off).  On the importing
+    thread on purpose: a helper thread would save the time but can meet the main thread's own imports in a lock cycle, which
+    Python resolves by handing one of them a half-initialised module."""
     import os
 
     if os.environ.get("TSGU_PREFETCH_IMPORTS", "1") != "1":
         return
-    import importlib
-    import threading
+    try:
+        import importlib
 
-    def work():
-        try:
-            importlib.import_module("torch.fx.experimental.symbolic_shapes")
-        except Exception:  # noqa: BLE001  (purely an optimisation)
-            pass
-
-    threading.Thread(target=work, name="tsgu-import-prefetch", daemon=True).start()
+        importlib.import_module("torch.fx.experimental.symbolic_shapes")
+    except Exception:  # noqa: BLE001  (purely an optimisation)
+        pass
 
 
 _prefetch_lazy_torch_modules()
