@@ -286,6 +286,40 @@ def main():
     ms_backward_call = timed_loop(step_backward_call)
     A.grad = None
     B.grad = None
+    # host side of a step: the same loop on a 1/64 problem (the GPU needs ~10 us per step there), and the full-size step with
+    # torch's autograd engine kept on the calling thread (a public torch switch; the default hands every backward to a worker
+    # thread, whose wake-up is at the mercy of the host — see DESIGN.md, Host side)
+    host_ms = ms_single_thread = None
+    if rank == 0 or world == 1:
+        try:
+            sc, sl = synthetic.stencil27_periodic(25, 25, 25, torch.int32, device=dev)
+            sA = torch.sparse_csr_tensor(sc, sl, torch.randn(sl.numel(), device=dev), (25 ** 3, 25 ** 3)).requires_grad_(True)
+            sB = torch.randn(25 ** 3, p, device=dev, requires_grad=True)
+            sG = torch.randn(25 ** 3, p, device=dev)
+
+            def small_step():
+                torch.autograd.grad(sparse_mm(sA, sB), (sA, sB), sG)
+
+            for _ in range(20):
+                small_step()
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(200):
+                small_step()
+            host_ms = (time.perf_counter() - t0) / 200 * 1e3
+            torch.cuda.synchronize(dev)
+            del sA, sB, sG, sc, sl
+        except Exception:  # noqa: BLE001
+            host_ms = None
+    try:
+        torch.autograd.set_multithreading_enabled(False)
+        for _ in range(5):
+            step()
+        ms_single_thread = timed_loop(step)
+    except Exception:  # noqa: BLE001
+        ms_single_thread = None
+    finally:
+        torch.autograd.set_multithreading_enabled(True)
 
     # ---- the step's two halves inside the autograd step (HIP events around the forward and around the backward) ----
     def step_halves():
@@ -441,6 +475,8 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 5),
             "ms_per_step_backward_call": round(ms_backward_call, 5),
+            "ms_per_step_single_thread_autograd": None if ms_single_thread is None else round(ms_single_thread, 5),
+            "host_ms_per_step": None if host_ms is None else round(host_ms, 5),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
