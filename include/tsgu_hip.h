@@ -409,6 +409,11 @@ int tsgu_cg_update1(int vtype, int64_t n, int64_t p,
                     void* r, const void* Ap, void* x, const void* pvec,
                     const void* scal, const int* flags, void* rr_partial,
                     int device, void* stream);
+/* steps 1 + 2 in ONE launch for n_partial <= 1024 partial rows (what K1 on the plane sweep leaves) and p <= 256: every
+ * workgroup sums the partial rows itself, in row order — all workgroups hold the same alpha, bit for bit the alpha of
+ * tsgu_cg_alpha.  Same operands as the two calls it replaces; returns TSGU_ERR_TOO_LARGE beyond the limits. */
+int tsgu_cg_update1_alpha(int vtype, int64_t n, int64_t p, void* r, const void* Ap, void* x, const void* pvec, const void* pap_partial,
+                          int64_t n_partial, void* scal, const int* flags, double eps, void* rr_partial, int device, void* stream);
 /* rows of rr_partial written by tsgu_cg_update1; r/Ap/x/pvec must be contiguous [n][p], 16-byte aligned */
 int64_t tsgu_cg_num_blocks(int vtype, int64_t n, int64_t p);
 int tsgu_cg_beta(int vtype, const void* rr_partial, int64_t n_partial, void* scal, int* flags,

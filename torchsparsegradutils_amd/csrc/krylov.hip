@@ -124,6 +124,75 @@ __global__ __launch_bounds__(kBlock) void cg_update1_kernel(int64_t n, int64_t p
     }
 }
 
+// Steps 1 + 2 in one launch when K1 left few partial rows (the plane sweep: one per workgroup): EVERY workgroup of the update sums
+// the partial rows itself — the same rows in the same order, so all of them hold the same alpha bit for bit — instead of waiting
+// for a single-workgroup kernel and a launch boundary (4.9 + 2.2 us of a 98 us iteration at C4).  n_partial x p values are read
+// from L2 per workgroup: 8 KB at C4.
+template <typename V, int VEC>
+__global__ __launch_bounds__(kBlock) void cg_update1_alpha_kernel(int64_t n, int64_t p, V* __restrict__ r, const V* __restrict__ Ap,
+                                                                  V* __restrict__ x, const V* __restrict__ pv,
+                                                                  const V* __restrict__ pap_partial, int64_t n_partial, V* __restrict__ scal,
+                                                                  const int* __restrict__ flags, V eps, int lpr, int rpp,
+                                                                  V* __restrict__ rr_partial) {
+    __shared__ V red[kBlock * VEC];
+    __shared__ V alpha_s[kBlock];        // p <= kBlock columns (checked by the launcher)
+    if (flags[0] != 0) return;
+    const int t = threadIdx.x;
+    for (int64_t c0 = 0; c0 < p; c0 += 64) {
+        const int w = (int)(p - c0 < 64 ? p - c0 : 64);
+        const V pap = block_colsum<V>(pap_partial, n_partial, p, c0, w, red);
+        if (t < w) {
+            const int64_t c = c0 + t;
+            V a = pap < eps ? (V)0 : scal[c] / pap;          // safe division (linear_cg.py:67-71)
+            if (flags[2 + c] != 0) a = 0;                     // converged columns are frozen (:74)
+            alpha_s[c] = a;
+            if (blockIdx.x == 0) scal[p + c] = a;             // (kept in the state for diagnostics; nobody reads it in this launch)
+        }
+        __syncthreads();
+    }
+    const int cl = t % lpr, rs = t / lpr;
+    const int64_t c = (int64_t)cl * VEC;
+    const bool act = rs < rpp && c < p;
+    V alpha[VEC], acc[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+        acc[v] = 0;
+        alpha[v] = act ? alpha_s[c + v] : (V)0;
+    }
+    const int64_t r0 = (int64_t)blockIdx.x * rpp * kPasses;
+#pragma unroll
+    for (int ps = 0; ps < kPasses; ++ps) {
+        const int64_t row = r0 + (int64_t)ps * rpp + rs;
+        if (act && row < n) {
+            const int64_t o = row * p + c;
+            V rv[VEC], av[VEC], xv[VEC], pvv[VEC];
+            load_vec<V, VEC>(r + o, rv);
+            load_vec<V, VEC>(Ap + o, av);
+            load_vec<V, VEC>(x + o, xv);
+            load_vec<V, VEC>(pv + o, pvv);
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                rv[v] = fma(-alpha[v], av[v], rv[v]);   // r -= alpha·Ap   (linear_cg.py:78)
+                xv[v] = fma(alpha[v], pvv[v], xv[v]);   // x += alpha·p    (linear_cg.py:32)
+                acc[v] = fma(rv[v], rv[v], acc[v]);     // rᵀr             (linear_cg.py:36-37)
+            }
+            store_vec<V, VEC>(r + o, rv);
+            store_vec<V, VEC>(x + o, xv);
+        }
+    }
+    __syncthreads();
+    if (rs < rpp) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) red[(rs * lpr + cl) * VEC + v] = acc[v];
+    }
+    __syncthreads();
+    for (int64_t cc = t; cc < p; cc += kBlock) {
+        V s = 0;
+        for (int k = 0; k < rpp; ++k) s += red[k * lpr * VEC + cc];
+        rr_partial[(int64_t)blockIdx.x * p + cc] = s;
+    }
+}
+
 template <typename V>
 __global__ __launch_bounds__(kBlock) void cg_beta_kernel(const V* __restrict__ rr_partial, int64_t n_partial, int64_t p,
                                                          V* __restrict__ scal, int* __restrict__ flags, V eps, V stop_after,
@@ -294,6 +363,34 @@ int tsgu_cg_update1(int vtype, int64_t n, int64_t p, void* r, const void* Ap, vo
                                p, (V*)r, (const V*)Ap, (V*)x, (const V*)pvec, (const V*)scal, flags, g.lpr,     \
                                g.rpp, (V*)rr_partial);                                                          \
         return check_launch();                                                                                  \
+    }
+    TSGU_VSWITCH(vtype, TSGU_BODY, TSGU_BODY);
+#undef TSGU_BODY
+    return TSGU_OK;
+}
+
+int tsgu_cg_update1_alpha(int vtype, int64_t n, int64_t p, void* r, const void* Ap, void* x, const void* pvec, const void* pap_partial,
+                          int64_t n_partial, void* scal, const int* flags, double eps, void* rr_partial, int device, void* stream) {
+    if (n <= 0 || p <= 0 || p > kBlock || !r || !Ap || !x || !pvec || !pap_partial || n_partial <= 0 || !scal || !flags || !rr_partial)
+        return TSGU_ERR_BAD_ARG;
+    if (n_partial > 1024) return TSGU_ERR_TOO_LARGE;      // (every workgroup reads all partial rows: use tsgu_cg_alpha + tsgu_cg_update1)
+    if (const int rc = set_device(device)) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+#define TSGU_BODY                                                                                                     \
+    {                                                                                                                 \
+        VecGeom g;                                                                                                    \
+        constexpr int wide = VT<V>::kWide;                                                                            \
+        if (!(aligned16(r) && aligned16(Ap) && aligned16(x) && aligned16(pvec))) return TSGU_ERR_BAD_ARG;            \
+        if (!geom_for<V>(n, p, true, g)) return TSGU_ERR_TOO_LARGE;                                                   \
+        if (g.vec == 1)                                                                                               \
+            hipLaunchKernelGGL((cg_update1_alpha_kernel<V, 1>), dim3((unsigned)g.blocks), dim3(kBlock), 0, s, n, p,   \
+                               (V*)r, (const V*)Ap, (V*)x, (const V*)pvec, (const V*)pap_partial, n_partial,         \
+                               (V*)scal, flags, (V)eps, g.lpr, g.rpp, (V*)rr_partial);                               \
+        else                                                                                                          \
+            hipLaunchKernelGGL((cg_update1_alpha_kernel<V, wide>), dim3((unsigned)g.blocks), dim3(kBlock), 0, s, n,   \
+                               p, (V*)r, (const V*)Ap, (V*)x, (const V*)pvec, (const V*)pap_partial, n_partial,      \
+                               (V*)scal, flags, (V)eps, g.lpr, g.rpp, (V*)rr_partial);                               \
+        return check_launch();                                                                                        \
     }
     TSGU_VSWITCH(vtype, TSGU_BODY, TSGU_BODY);
 #undef TSGU_BODY

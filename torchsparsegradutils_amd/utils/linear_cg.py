@@ -263,11 +263,18 @@ def _fused_loop(op, rhs_is_zero, x, r, has_converged, n_iter, max_iter, toleranc
             pap = _be.coldot(pvec, Ap).unsqueeze(0)
             n_partial = 1
         s = stream()
-        _be.check(lib.tsgu_cg_alpha(vt, pap.data_ptr(), n_partial, fold.data_ptr(), scal.data_ptr(), flags.data_ptr(), eps, p,
-                                    dev.index, s), "tsgu_cg_alpha")
-        _be.check(lib.tsgu_cg_update1(vt, n, p, r.data_ptr(), Ap.data_ptr(), x.data_ptr(), pvec.data_ptr(),
-                                      scal.data_ptr(), flags.data_ptr(), rr_partial.data_ptr(), dev.index, s),
-                  "tsgu_cg_update1")
+        if n_partial <= 1024 and p <= 256 and pap.is_contiguous():
+            # few partial rows (K1 on the plane sweep, or an operator with its own dot): alpha is summed by every workgroup of the
+            # update itself — one launch and one single-workgroup kernel less per iteration
+            _be.check(lib.tsgu_cg_update1_alpha(vt, n, p, r.data_ptr(), Ap.data_ptr(), x.data_ptr(), pvec.data_ptr(), pap.data_ptr(),
+                                                n_partial, scal.data_ptr(), flags.data_ptr(), eps, rr_partial.data_ptr(), dev.index, s),
+                      "tsgu_cg_update1_alpha")
+        else:
+            _be.check(lib.tsgu_cg_alpha(vt, pap.data_ptr(), n_partial, fold.data_ptr(), scal.data_ptr(), flags.data_ptr(), eps, p,
+                                        dev.index, s), "tsgu_cg_alpha")
+            _be.check(lib.tsgu_cg_update1(vt, n, p, r.data_ptr(), Ap.data_ptr(), x.data_ptr(), pvec.data_ptr(),
+                                          scal.data_ptr(), flags.data_ptr(), rr_partial.data_ptr(), dev.index, s),
+                      "tsgu_cg_update1")
         # iteration index -1: the counter is flags[1] on the device, every iteration is the same launch
         _be.check(lib.tsgu_cg_beta(vt, rr_partial.data_ptr(), nb_upd, scal.data_ptr(), flags.data_ptr(), eps,
                                    stop_after, float(tolerance), -1, min_iter_index, p, dev.index, s),
