@@ -74,7 +74,9 @@ __device__ __forceinline__ int lat_slot_of(int64_t h, int64_t row, unsigned long
         if (cur == (unsigned long long)h || (cur == (unsigned long long)kLatEmpty &&
                                              (atomicCAS(thash + s, (unsigned long long)kLatEmpty, (unsigned long long)h) == (unsigned long long)kLatEmpty ||
                                               thash[s] == (unsigned long long)h))) {
-            atomicMin(trep + s, (int)row);
+            // (an atomic only when it can change the word: one address serves ~80 M atomics per second, and the interior class
+            // alone would send a million rows to one slot — a stale read only costs a redundant atomic)
+            if ((int)row < *(volatile int*)(trep + s)) atomicMin(trep + s, (int)row);
             return (int)s;
         }
         s = (s + 1) & (kLatSlots - 1);
@@ -126,10 +128,13 @@ __global__ __launch_bounds__(256) void lat_rows_kernel(int64_t n_rows, const I* 
         bad |= s < 0;
         slot[row] = (unsigned short)(s < 0 ? 0 : s);
     }
+    // status maxima: atomics only while they still raise the word (every row hitting three addresses was most of a pass: 12 ms at
+    // 1e6 rows)
+    volatile int* const st = status;
     if (bad) atomicAdd(status + 0, 1);
-    if (my > 0) atomicMax(status + 1, my);
-    if (mz > 0) atomicMax(status + 2, mz);
-    atomicMax(status + 3, len);
+    if (my > st[1]) atomicMax(status + 1, my);
+    if (mz > st[2]) atomicMax(status + 2, mz);
+    if (len > st[3]) atomicMax(status + 3, len);
 }
 
 // code sequences of a few rows (class representatives): out[r][k] = code, -1 beyond the row
@@ -231,7 +236,7 @@ __global__ __launch_bounds__(256) void lat_trows_kernel(int64_t n_rows, const I*
         slot[j] = (unsigned short)(s < 0 ? 0 : s);
     }
     if (bad) atomicAdd(status + 0, 1);
-    atomicMax(status + 3, cnt);
+    if (cnt > *(volatile int*)(status + 3)) atomicMax(status + 3, cnt);
 }
 
 // The classes of the rows of every workgroup of a launch configuration: mask[block] = 256-bit set of class ids
