@@ -281,7 +281,7 @@ int tsgu_lattice_lds_bytes(int mode, int vtype, int64_t p, int ty, int tz, int r
  * in A's own order, `B` is G).  n_rows = nb·nx·ny·nz. */
 int tsgu_csr_spmm_lattice(int vtype, const tsgu_lattice_plan* plan, int64_t n_rows, int64_t nnz, const void* val,
                           const void* B, int64_t ldb, void* C, int64_t ldc, int64_t p, int device, void* stream);
-/* C = A·B (plan kind 0, fp32) with the Krylov loops' dot epilogue: dot_partial[w][c] = Σ over the rows of workgroup w of
+/* C = A·B (plan kind 0, fp32 or fp64; partial sums in the value type) with the Krylov loops' dot epilogue: dot_partial[w][c] = Σ over the rows of workgroup w of
  * C[row, c]·B[row, c] (the own row of B is the centre of the halo plane in LDS; deterministic).  dot_rows must be the number of
  * workgroups of the configuration, nb·nseg·⌈ny/ty⌉·⌈nz/tz⌉; one chunk per lane.  This entry also takes 16-byte dense rows
  * (p = 4: one lane per row) — replaces tsgu_csr_spmm(..., dot_w = B, ...) inside utils/linear_cg.py:322 + :64-65 on lattice

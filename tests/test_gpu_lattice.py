@@ -448,6 +448,15 @@ def test_bounded_fuzz_run_of_the_public_ops():
 @pytest.mark.parametrize("periodic,points,dims", [(False, 7, (9, 10, 12)), (True, 7, (6, 8, 16)), (True, 27, (5, 9, 11)), (False, 27, (7, 6, 9))])
 @pytest.mark.parametrize("p", [4, 32])
 def test_spmm_with_the_dot_epilogue_of_the_krylov_loops(periodic, points, dims, p):
+    _dot_epilogue_case(periodic, points, dims, p, torch.float32)
+
+
+@pytest.mark.parametrize("p", [4, 16])
+def test_spmm_with_the_dot_epilogue_fp64(p):
+    _dot_epilogue_case(False, 7, (9, 10, 12), p, torch.float64)
+
+
+def _dot_epilogue_case(periodic, points, dims, p, dt):
     """C = A·v plus the per-workgroup partial sums of <C[row], v[row]> per column (what linear_cg's fused step consumes), on
     16-byte dense rows (4 right-hand sides: one lane per row) and on 128-byte rows: C bit-identical to the plan-free kernel,
     the column sums of the partials equal to its own dot epilogue's to rounding, run-to-run bit-identical."""
@@ -457,36 +466,40 @@ def test_spmm_with_the_dot_epilogue_of_the_krylov_loops(periodic, points, dims, 
     crow, col = _stencil_csr(nx, ny, nz, periodic, points)
     n = nx * ny * nz
     g = torch.Generator().manual_seed(7 + p)
-    val = torch.randn(col.numel(), generator=g).to(dev)
-    v = torch.randn(n, p, generator=g).to(dev)
+    val = torch.randn(col.numel(), generator=g, dtype=dt).to(dev)
+    v = torch.randn(n, p, generator=g, dtype=dt).to(dev)
     plan = pt.RowGather(crow.to(dev), col.to(dev), n, n)
     lp = lt.build_lattice_plan_hip(plan, be)
     assert lp is not None
     C0, part0 = be.csr_spmm(plan.crow, plan.col, val, v, n, n, dot_w=v)
-    for cs in ((4, 8, 2, 256), (6, 12, 3, 512)) if p == 4 else ((4, 4, 2, 256), (5, 6, 3, 512)):
+    for cs in ((4, 8, 2, 256), (6, 12, 3, 512)) if p * v.element_size() <= 32 else ((4, 4, 2, 256), (5, 6, 3, 512)):
         lt._CFG_ENV = ",".join(str(x) for x in cs)
         try:
             lp._cfg.clear()
-            cfg = be.lattice_config(lp, be.LAT_SPMM, torch.float32, p)
+            cfg = be.lattice_config(lp, be.LAT_SPMM, dt, p)
         finally:
             lt._CFG_ENV = ""
         assert cfg is not None, cs
         C, part = be.csr_spmm_lattice(lp, cfg, val, v, dot=True)
+        assert part.dtype == dt
         assert part.shape == (cfg.nseg * -(-ny // cfg.ty) * -(-nz // cfg.tz), p)
         assert torch.equal(C, be.csr_spmm_lattice(lp, cfg, val, v))          # the epilogue does not touch the product
+        tol = 1e-6 if dt == torch.float32 else 1e-13
         if p >= 32:
             assert torch.equal(C, C0), cs
         else:
-            assert G.rel_err(C.cpu().numpy(), C0.cpu().numpy()) < 1e-6, cs
+            assert G.rel_err(C.cpu().numpy(), C0.cpu().numpy()) < tol, cs
         want = (C0.double() * v.double()).sum(0)
-        scale = (C0.double().abs() * v.double().abs()).sum(0)          # fp32 partial sums: errors relative to the sum of magnitudes
+        scale = (C0.double().abs() * v.double().abs()).sum(0)          # partial sums: errors relative to the sum of magnitudes
         got = part.double().sum(0)
-        assert float(((got - want).abs() / scale).max()) < 1e-6, cs
-        assert float(((part0.double().sum(0) - want).abs() / scale).max()) < 1e-6
+        assert float(((got - want).abs() / scale).max()) < tol, cs
+        assert float(((part0.double().sum(0) - want).abs() / scale).max()) < tol
         C2, part2 = be.csr_spmm_lattice(lp, cfg, val, v, dot=True)
         assert torch.equal(part, part2) and torch.equal(C, C2)
     lp._cfg.clear()
     # not offered where it does not exist: bf16, the transposed walk
+    if dt != torch.float32:
+        return
     assert be.lattice_config(lp, be.LAT_SDDMM, torch.float32, 4) is None
     assert be.lattice_config(lp, be.LAT_SPMM, torch.bfloat16, 8) is None
 

@@ -539,10 +539,10 @@ def csr_spmm_lattice(lp, cfg, val, B, dot: bool = False):
     march = getattr(cfg, "march", False)
     transposed = cfg.mode == LAT_SPMMT if march else bool(lp.kind)
     if dot:
-        if march or transposed or B.dtype != torch.float32:
-            raise RuntimeError("csr_spmm_lattice: the dot epilogue exists for the fp32 stored-order plane sweep only")
+        if march or transposed or B.dtype not in (torch.float32, torch.float64):
+            raise RuntimeError("csr_spmm_lattice: the dot epilogue exists for the fp32 / fp64 stored-order plane sweep only")
         nwg = lp.nb * cfg.nseg * -(-lp.ny // cfg.ty) * -(-lp.nz // cfg.tz)
-        partial = torch.empty((nwg, p), dtype=torch.float32, device=dev)
+        partial = torch.empty((nwg, p), dtype=B.dtype, device=dev)
         with _on_device(dev):
             rc = lib.tsgu_csr_spmm_lattice_dot(_VTYPE[val.dtype], cfg.struct_addr, lp.n_rows, lp.nnz, val.data_ptr(), B.data_ptr(), _ld(B),
                                                out.data_ptr(), p, p, partial.data_ptr(), nwg, dev.index,

@@ -90,7 +90,7 @@ static int spmm_lattice(int vtype, const tsgu_lattice_plan* plan, int64_t n_rows
     int cl = 0;
     const int mode = plan && plan->kind != 0 ? kLatSpmmT : kLatSpmm;
     if (const int rc = fill(P, plan, mode, vtype, p, n_rows, nnz, cl)) return rc;
-    if (dot_partial && (mode != kLatSpmm || vtype != TSGU_F32 || P.cpl != 1 || dot_rows != P.nblocks)) return TSGU_ERR_BAD_ARG;
+    if (dot_partial && (mode != kLatSpmm || (vtype != TSGU_F32 && vtype != TSGU_F64) || P.cpl != 1 || dot_rows != P.nblocks)) return TSGU_ERR_BAD_ARG;
     if (n_rows == 0) return TSGU_OK;
     if (!B || !C || (nnz > 0 && !val) || ldb < p || ldc < p) return TSGU_ERR_BAD_ARG;
     const int vec = 16 / vbytes_of(vtype);
@@ -103,7 +103,7 @@ static int spmm_lattice(int vtype, const tsgu_lattice_plan* plan, int64_t n_rows
     P.lds_ = ldb;
     P.out = C;
     P.ldo = ldc;
-    P.dot_partial = static_cast<float*>(dot_partial);
+    P.dot_partial = dot_partial;
     return dispatch(vtype, mode, cl, plan->threads, P, stream);
 }
 

@@ -76,7 +76,7 @@ struct LatParams {
     int64_t ldo;
     void* gvals;             // SDDMM output [nnz]
     float alpha;
-    float* dot_partial;      // SpMM, fp32: [workgroups][p] partial sums of <out[row,:], S[row,:]> per column (Krylov loops), or null
+    void* dot_partial;       // SpMM, fp32 / fp64: [workgroups][p] partial sums of <out[row,:], S[row,:]> per column (Krylov loops), or null
     int64_t nblocks;
     // LDS layout (bytes from the start of the dynamic region; filled by lat_layout)
     int o_vals, o_zero, o_tab, o_len, o_map, lds_bytes;
@@ -401,12 +401,12 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
     int plen[MODE == kLatSddmm ? kLatNP : 1], prst[MODE == kLatSddmm ? kLatNP : 1];
     // fused dot epilogue (SpMM, fp32): Σ over this lane's rows of out[row, c]·S[row, c] — the own row of S is the centre of the
     // halo plane in LDS
-    constexpr bool kCanDot = MODE == kLatSpmm && kVB == 4 && CPL == 1;
-    float dotp[kCanDot ? CPL : 1][VEC];
+    constexpr bool kCanDot = MODE == kLatSpmm && (kVB == 4 || kVB == 8) && CPL == 1;
+    A dotp[kCanDot ? CPL : 1][VEC];
 #pragma unroll
     for (int cp = 0; cp < (kCanDot ? CPL : 1); ++cp) {
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) dotp[cp][v] = 0.f;
+        for (int v = 0; v < VEC; ++v) dotp[cp][v] = (A)0;
     }
     const bool want_dot = kCanDot && P.dot_partial != nullptr;
     auto flush = [&](int prow) {
@@ -644,10 +644,10 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
 #pragma unroll
                                 for (int cp = 0; cp < CPL; ++cp) {
                                     const uint4 wr = *reinterpret_cast<const uint4*>(sm + ph * PB + cen[q][cp]);
-                                    float f[VEC];
+                                    A f[VEC];
                                     widen(wr, f);
 #pragma unroll
-                                    for (int v = 0; v < VEC; ++v) dotp[cp][v] = fmaf(acc[q][cp][v], f[v], dotp[cp][v]);
+                                    for (int v = 0; v < VEC; ++v) dotp[cp][v] = fma(acc[q][cp][v], f[v], dotp[cp][v]);
                                 }
                             }
                         }
@@ -834,7 +834,7 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
         if (want_dot) {
             // the workgroup's partial row: column cc = chunk·VEC + v summed over the lanes that own that chunk, in lane order
             // (the last step ended with a barrier: the ring is free)
-            float* const red = reinterpret_cast<float*>(sm);
+            A* const red = reinterpret_cast<A*>(sm);
 #pragma unroll
             for (int cp = 0; cp < CPL; ++cp) {
                 const int chunk = c + LPR * cp;
@@ -843,9 +843,9 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
             }
             __syncthreads();
             if (tid < CL * VEC) {
-                float s = 0.f;
+                A s = (A)0;
                 for (int r = 0; r < NT / LPR; ++r) s += red[r * CL * VEC + tid];
-                P.dot_partial[vblock * (CL * VEC) + tid] = s;
+                static_cast<A*>(P.dot_partial)[vblock * (CL * VEC) + tid] = s;
             }
         }
     }

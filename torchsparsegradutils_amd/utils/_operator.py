@@ -55,7 +55,7 @@ class SparseOperator:
         ``out`` (optional, must not alias ``v``) receives A·v in place."""
         p = self.plan
         v = self._cast(v)
-        if w is None and out is None and v.dtype == torch.float32 and self.values.dtype == torch.float32 and v.dim() == 2:
+        if w is None and out is None and v.dtype in (torch.float32, torch.float64) and self.values.dtype == v.dtype and v.dim() == 2:
             # stencil on a lattice: the plane sweep needs no column indices, and the own row of v is already in LDS for the dot
             got = _ops._lattice_cfg(p, _be.LAT_SPMM, v) if p.perm is None and p.batch is None else None
             if got is not None and not getattr(got[1], "march", False) and got[1].cpl == 1:
