@@ -290,3 +290,70 @@ def test_full_size_c2_on_the_product_path(monkeypatch):
     assert torch.equal(C.detach(), first[0]) and torch.equal(A.grad.values(), first[1]) and torch.equal(B.grad, first[2])
 
 
+
+
+def test_randomised_stencils_through_the_public_path(monkeypatch):
+    """Random lattices (3..14 points per dimension, periodic or truncated, 7 / 27 points, 1-3 items), value types and widths
+    through sparse_mm forward + backward against dense fp64 autograd: whichever kernel family the selection takes (plane march,
+    general sweep, row pairs, plan-free), the results must agree with the dense computation."""
+    import random
+
+    from torchsparsegradutils_amd import _ops, _pattern, sparse_mm
+
+    monkeypatch.setattr(_ops, "PACK_MIN_NNZ", 1)          # (the structured kernels are only tried from 65536 entries on)
+    rng = random.Random(20260303)
+    dev = torch.device("cuda:0")
+    took = {"march": 0, "sweep": 0, "other": 0}
+    for case in range(40):
+        nb = rng.choice([1, 1, 2, 3])
+        nx, ny, nz = (rng.randint(3, 14) for _ in range(3))
+        if rng.random() < 0.5:
+            nz = 8 * rng.randint(1, 2)
+        periodic = rng.random() < 0.6
+        points = rng.choice([27, 27, 7])
+        dt = rng.choice([torch.float32, torch.float32, torch.float64, torch.bfloat16])
+        p = rng.choice([4, 8, 16, 32, 64] if dt != torch.bfloat16 else [8, 16, 32])
+        crow, col = _stencil_csr(nx, ny, nz, periodic, points, False, 1)
+        n = nx * ny * nz
+        g = torch.Generator().manual_seed(case)
+        val = torch.randn(nb, col.numel(), generator=g, dtype=torch.float64)
+        B = torch.randn(nb, n, p, generator=g, dtype=torch.float64)
+        Gd = torch.randn(nb, n, p, generator=g, dtype=torch.float64)
+        if dt == torch.bfloat16:
+            val, B, Gd = (t.to(dt).double() for t in (val, B, Gd))
+        # dense fp64 reference
+        row = torch.repeat_interleave(torch.arange(n), crow[1:] - crow[:-1])
+        Ad = torch.zeros(nb, n, n, dtype=torch.float64)
+        Ad[:, row, col.long()] = val
+        Ad.requires_grad_(True)
+        Bref = B.clone().requires_grad_(True)
+        (Ad @ Bref).backward(Gd)
+        Cref, gAref, gBref = (Ad.detach() @ B), Ad.grad[:, row, col.long()], Bref.grad
+        # the package
+        if nb == 1:
+            A = torch.sparse_csr_tensor(crow.to(dev), col.to(dev), val[0].to(dt).to(dev), (n, n)).requires_grad_(True)
+            Bd = B[0].to(dt).to(dev).requires_grad_(True)
+            Gdev = Gd[0].to(dt).to(dev)
+        else:
+            A = torch.sparse_csr_tensor(crow.repeat(nb, 1).to(dev), col.repeat(nb, 1).to(dev), val.to(dt).to(dev), (nb, n, n)).requires_grad_(True)
+            Bd = B.to(dt).to(dev).requires_grad_(True)
+            Gdev = Gd.to(dt).to(dev)
+        C = sparse_mm(A, Bd)
+        C.backward(Gdev)
+        tol = {torch.float32: 2e-5, torch.float64: 1e-12, torch.bfloat16: 2e-2}[dt]
+        what = (nb, nx, ny, nz, periodic, points, dt, p)
+        assert G.rel_err(C.detach().double().cpu().reshape(Cref.shape).numpy(), Cref.numpy()) < tol, what
+        assert G.rel_err(A.grad.values().double().cpu().reshape(gAref.shape).numpy(), gAref.numpy()) < tol, what
+        assert G.rel_err(Bd.grad.double().cpu().reshape(gBref.shape).numpy(), gBref.numpy()) < tol, what
+        plan = _pattern.from_csr(A.detach())
+        flat = _pattern.flat_of(plan) if nb > 1 else plan
+        lp = flat.core.own.get("lattice")
+        if lp is not None and lp._march and any(c is not None for c in lp._march._cfg.values()):
+            took["march"] += 1
+        elif lp is not None and any(c is not None for c in lp._cfg.values()):
+            took["sweep"] += 1
+        else:
+            took["other"] += 1
+        _pattern.clear_cache()
+    assert took["march"] >= 3 and took["sweep"] >= 8, took
+
