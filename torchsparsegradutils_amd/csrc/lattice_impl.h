@@ -262,7 +262,10 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
     const uint32_t val_bytes = (uint32_t)(P.nnz * kVB);
 
     // ring plane with first row `prow` into ring slot `slot`
+    // (`prow` is wave-uniform; the readfirstlane says so to the compiler, which must keep the DMA's base in scalar registers)
     auto dma_ring = [&](int prow, int slot) {
+        prow = __builtin_amdgcn_readfirstlane(prow);
+        slot = __builtin_amdgcn_readfirstlane(slot);
         const char* const pbase = Sb + (int64_t)prow * ldsb;      // wave-uniform
         const unsigned base = sbase + (unsigned)(slot * PB) + (unsigned)(wave * kWave * 16);
 #pragma unroll
@@ -276,6 +279,8 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
     // starts (elements) of the pieces when the rows are not all of one length
     auto dma_vals = [&](int prow, int buf, const int (&st)[kNVD]) {
         if constexpr (MODE != kLatSddmm) {
+            prow = __builtin_amdgcn_readfirstlane(prow);
+            buf = __builtin_amdgcn_readfirstlane(buf);
             const unsigned region = MODE == kLatSpmm ? (unsigned)(P.o_vals + buf * NR * P.slot) : (unsigned)(P.o_vals + buf * HR * P.slot);
             const unsigned base = sbase + region + (unsigned)(wave * kWave * 16);
             const uint32_t plane0 = uniform ? (uint32_t)prow * (uint32_t)(P.uniform_len * kVB) : 0u;   // bytes before the plane's values
@@ -422,6 +427,53 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
                 }
             }
         } else {
+            if constexpr (kVB == 2 && kLatNP == 1 && CPL == 1) {
+                // bf16, rows of one length, a wave covering whole z-lines of the tile: the gradients of a line are ONE contiguous
+                // run of the output (consecutive rows), written as 16-byte aligned pieces of eight across the row boundaries
+                // (+ 2-byte stores for the unaligned ends).  Row by row a 54-byte row takes 14 four-byte stores, and at C5 the
+                // store path was what the kernel waited for (117 M vector-L1 accesses per launch).
+                constexpr int RPW = kWave / LPR;
+                if (uniform && RPW % P.tz == 0) {
+                    const int ulen = P.uniform_len, lane = tid % kWave;
+                    const int sl4 = P.slot / 4;                       // floats per stage row
+                    for (int li = 0; li < RPW / P.tz; ++li) {
+                        const int rl = wave * RPW + li * P.tz;          // first tile row of the line
+                        const int lyy = rl / P.tz;
+                        if (rl >= NR || y0 + lyy >= P.ny) break;
+                        const int nrows = P.nz - z0 < P.tz ? P.nz - z0 : P.tz;
+                        const int64_t elem0 = ((int64_t)prow + (int64_t)(y0 + lyy) * P.nz + z0) * ulen;
+                        const int nel = nrows * ulen;
+                        const float* const st0 = reinterpret_cast<const float*>(sm + P.o_vals) + (int64_t)rl * sl4;
+                        unsigned short* const go = reinterpret_cast<unsigned short*>(P.gvals) + elem0;
+                        auto at = [&](int e) -> float {               // element e of the line (row e / ulen, entry e % ulen)
+                            const int rr = e / ulen;
+                            return st0[rr * sl4 + (e - rr * ulen)];
+                        };
+                        const int head = (int)((8 - (elem0 & 7)) & 7) < nel ? (int)((8 - (elem0 & 7)) & 7) : nel;
+                        const int chunks = (nel - head) / 8;
+                        const int tail0 = head + chunks * 8;
+                        if (lane < head) go[lane] = T::down(at(lane)).bits;
+                        if (lane < nel - tail0) go[tail0 + lane] = T::down(at(tail0 + lane)).bits;
+                        for (int ch = lane; ch < chunks; ch += kWave) {
+                            const int e = head + ch * 8;
+                            int rr = e / ulen, kk = e - rr * ulen;
+                            float f[8];
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {
+                                f[j] = st0[rr * sl4 + kk];
+                                if (++kk == ulen) kk = 0, ++rr;
+                            }
+                            uint32_t w[4];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w[j]) : "v"(f[2 * j]), "v"(f[2 * j + 1]));
+                            typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+                            const u4v o = {w[0], w[1], w[2], w[3]};
+                            __builtin_nontemporal_store(o, reinterpret_cast<u4v*>(go + e));
+                        }
+                    }
+                    return;
+                }
+            }
             // the row's gradients in stored order: 16-byte pieces where four fit, single elements at the end
 #pragma unroll
             for (int q = 0; q < kLatNP; ++q) {
