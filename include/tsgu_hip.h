@@ -442,9 +442,16 @@ int tsgu_bicg_scalar(int vtype, int phase, const void* partial, int64_t n_partia
 int tsgu_bicg_vector(int vtype, int which, int64_t n, int64_t p, void* a0, void* a1, const void* a2, const void* a3,
                      const void* a4, const void* scal, const int* flags, void* partial, int64_t set_stride,
                      int device, void* stream);
+/* The x / r update of a right-preconditioned iteration (settings.precon, reference utils/bicgstab.py:191-194, 216-219,
+ * 227-233): r = s - omega·t; x = (x + omega·z) + alpha·q with q = M p, z = M s applied by the caller between the steps
+ * (v = A q, t = A z); columns finishing after the half step take x += alpha·q; |r|^2 partials.  Replaces
+ * tsgu_bicg_vector(which = 3) in the step sequence above; everything else is unchanged. */
+int tsgu_bicg_update_x_precond(int vtype, int64_t n, int64_t p, void* x, void* r, const void* s, const void* t,
+                               const void* q, const void* z, const void* scal, const int* flags, void* partial,
+                               int device, void* stream);
 
 /*
- * K7: fused MINRES recurrences (no preconditioner, one shift), all right-hand sides at once — replaces the per-iteration
+ * K7: fused MINRES recurrences (one shift, no preconditioner; the general form follows), all right-hand sides at once — replaces the per-iteration
  * ATen op chain of reference utils/minres.py:259-296 (Lanczos step, Givens QR, solution update) and its
  * every-10-iterations stopping test (:299-305).  One iteration = tsgu_csr_spmm(+ <z, A z> partials) ->
  * tsgu_minres_scalar(0: alpha) -> tsgu_minres_vector(0: z_c = (A z - alpha z) - beta z_prev2 over z_prev2, |z_c|^2
@@ -461,6 +468,22 @@ int tsgu_minres_scalar(int vtype, int phase, const void* partial, int64_t n_part
 int tsgu_minres_vector(int vtype, int which, int64_t n, int64_t p, void* a0, const void* a1, void* a2, const void* a3,
                        void* a4, const void* scal, const int* flags, void* partial, int64_t set_stride, int with_norms,
                        int device, void* stream);
+/* The same steps for (value·A + shift_s·I) x_s = b with several shifts at once and, optionally, a preconditioner
+ * (reference utils/minres.py:140-311: `shifts`, `value`, `preconditioner`).  The Lanczos vectors and alpha / beta are
+ * shared by the shifts; rotations, w vectors and solutions are per shift: scal is [n_shift][12][p] (rows 0, 1, 11 of
+ * block 0 serve every shift; the caller initialises rows 2, 4, 6 of every block), w_prev2 / w_prev / sol are n_shift
+ * planes [n][p], `shift_stride` elements apart (>= n·p, a multiple of 16 bytes), the stopping test reads 2·n_shift partial sets
+ * (|update_s|^2 at set 2s, |sol_s|^2 at 2s+1) and averages over shifts and columns.  `shifts`: n_shift device values of
+ * the value type.  scalar(0) stores alpha = value·<q, A q>, vector(0) forms z_c = (value·(A q) − alpha z) − beta z_prev2
+ * from the unscaled product.  Preconditioned: the caller computes q_c = M z_c after vector(0), passes <z_c, q_c>
+ * partials to scalar(1) (instead of |z_c|^2), and vector(1) gets a1 = q_prev and qc = q_c (normalised in place next
+ * to z_c); without a preconditioner a1 = z_prev and qc = NULL. */
+int tsgu_minres_scalar_ms(int vtype, int phase, const void* partial, int64_t n_partial, int64_t set_stride, void* fold,
+                          void* scal, int* flags, double eps, double tol, const void* shifts, int n_shift, double value,
+                          int64_t p, int device, void* stream);
+int tsgu_minres_vector_ms(int vtype, int which, int64_t n, int64_t p, void* a0, const void* a1, void* a2, const void* a3,
+                          void* a4, void* qc, const void* scal, const int* flags, void* partial, int64_t set_stride,
+                          int with_norms, int n_shift, int64_t shift_stride, double value, int device, void* stream);
 
 /* Column-wise dot products  out[c] = Σ_i X[i,c]·Y[i,c]  (two-stage, deterministic).
  * replaces: torch.dot / mul+sum in utils/bicgstab.py:168,199,222-224 and linear_cg.py:294 */

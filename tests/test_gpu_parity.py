@@ -931,10 +931,25 @@ def test_krylov_hipgraph_replay_is_bitwise_identical_to_eager_launches(monkeypat
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.float64])
 def test_minres_fused_matches_reference_op_chain(dt, monkeypatch):
-    """K7: the fused single-shift MINRES against the line-by-line op chain of the reference (same module, reached with
-    `value=1.0`): multi-RHS incl. a zero column, a vector RHS, a shift, an iteration cap that is not a multiple of 10,
-    an indefinite matrix; then hipGraph replay of 10-iteration chunks is bit-identical to eager launches."""
-    from torchsparsegradutils_amd.utils import MINRESSettings, _graph, minres
+    """K7: the fused MINRES against the line-by-line op chain of the reference (same module, `ENABLE_FUSED = False`):
+    multi-RHS incl. a zero column, a vector RHS, a shift, an iteration cap that is not a multiple of 10,
+    an indefinite matrix; then hipGraph replay of 10-iteration chunks is bit-identical to eager launches.
+    (A self-comparison: the pins to the real reference are test_gpu_fullsize.py and test_gpu_precond_solvers.py.)"""
+    import sys
+
+    from torchsparsegradutils_amd.utils import MINRESSettings, _graph
+    from torchsparsegradutils_amd.utils import minres as fused_minres
+
+    mr_mod = sys.modules[fused_minres.__module__]
+
+    def minres(*a, value=None, **kw):
+        if value is None:
+            return fused_minres(*a, **kw)
+        monkeypatch.setattr(mr_mod, "ENABLE_FUSED", False)   # `value=1.0` marks the op-chain calls below
+        try:
+            return fused_minres(*a, value=value, **kw)
+        finally:
+            monkeypatch.setattr(mr_mod, "ENABLE_FUSED", True)
 
     z = G.load("cg_lap16.npz")
     n = 4096

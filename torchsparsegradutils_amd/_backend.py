@@ -64,6 +64,15 @@ SIGNATURES = {
         _int,
         [_int, _int, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _int, _int, _ptr],
     ),
+    "tsgu_minres_scalar_ms": (
+        _int,
+        [_int, _int, _ptr, _i64, _i64, _ptr, _ptr, _ptr, _dbl, _dbl, _ptr, _int, _dbl, _i64, _int, _ptr],
+    ),
+    "tsgu_minres_vector_ms": (
+        _int,
+        [_int, _int, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _int, _int, _i64, _dbl, _int, _ptr],
+    ),
+    "tsgu_bicg_update_x_precond": (_int, [_int, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _int, _ptr]),
     "tsgu_rowpack_geometry": (
         _int,
         [_int, _i64, ctypes.POINTER(_int), ctypes.POINTER(_int), ctypes.POINTER(_int), ctypes.POINTER(_int),

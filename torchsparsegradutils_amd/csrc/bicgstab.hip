@@ -1,4 +1,4 @@
-// K6: fused BiCGSTAB recurrences on gfx950 (no preconditioner), every right-hand side at once.
+// K6: fused BiCGSTAB recurrences on gfx950 (optionally right-preconditioned), every right-hand side at once.
 //
 // The reference (utils/bicgstab.py:113-247, a pykrylov port) solves the columns one after the other
 // in a Python loop, with ~12 small ATen ops and two host reads of the residual norm per iteration and
@@ -245,14 +245,15 @@ __global__ __launch_bounds__(kBlock) void bicg_dots3_kernel(int64_t n, int64_t p
     }
 }
 
-// half-finished columns: x += alpha*p.  active columns: r = s - omega*t; x = (x + omega*s) + alpha*p; partial |r|^2
-// (bicgstab.py:207-210, 227-235)
-template <typename V, int VEC>
+// half-finished columns: x += alpha*q.  active columns: r = s - omega*t; x = (x + omega*z) + alpha*q; partial |r|^2
+// (bicgstab.py:207-210, 227-235).  Without a preconditioner q is p and z is s (PRE = false: `pv` serves as q, `s` as z);
+// with one, q = M p and z = M s arrive in `pv` and `zv` (bicgstab.py:191-194, 216-219).
+template <typename V, int VEC, bool PRE = false>
 __global__ __launch_bounds__(kBlock) void bicg_update_x_kernel(int64_t n, int64_t p, V* __restrict__ x, V* __restrict__ r,
                                                                const V* __restrict__ s, const V* __restrict__ tv,
                                                                const V* __restrict__ pv, const V* __restrict__ scal,
                                                                const int* __restrict__ flags, int lpr, int rpp,
-                                                               V* __restrict__ partial) {
+                                                               V* __restrict__ partial, const V* __restrict__ zv) {
     __shared__ V red[kBlock * VEC];
     if (flags[0] != 0) return;
     const int t = threadIdx.x;
@@ -276,17 +277,18 @@ __global__ __launch_bounds__(kBlock) void bicg_update_x_kernel(int64_t n, int64_
         const int64_t row = rb + (int64_t)ps * rpp + rs;
         if (on && row < n) {
             const int64_t o = row * p + c;
-            V xx[VEC], rr[VEC], ss[VEC], tt[VEC], pp[VEC];
+            V xx[VEC], rr[VEC], ss[VEC], tt[VEC], pp[VEC], zz[VEC];
             load_vec<V, VEC>(x + o, xx);
             load_vec<V, VEC>(r + o, rr);
             load_vec<V, VEC>(s + o, ss);
             load_vec<V, VEC>(tv + o, tt);
             load_vec<V, VEC>(pv + o, pp);
+            if constexpr (PRE) load_vec<V, VEC>(zv + o, zz);
 #pragma unroll
             for (int k = 0; k < VEC; ++k) {
                 const V ap = alpha[k] * pp[k];
                 const V xh = xx[k] + ap;
-                const V xa = (xx[k] + omega[k] * ss[k]) + ap;
+                const V xa = (xx[k] + omega[k] * (PRE ? zz[k] : ss[k])) + ap;
                 const V rn = ss[k] - omega[k] * tt[k];
                 xx[k] = hf[k] ? xh : (act[k] ? xa : xx[k]);
                 rr[k] = act[k] ? rn : rr[k];
@@ -376,12 +378,41 @@ int tsgu_bicg_vector(int vtype, int which, int64_t n, int64_t p, void* a0, void*
                     set_stride);                                                                                   \
         else                                                                                                       \
             TSGU_GO(bicg_update_x_kernel, n, p, (V*)a0, (V*)a1, (const V*)a2, (const V*)a3, (const V*)a4, (const V*)scal, \
-                    flags, g.lpr, g.rpp, (V*)partial);                                                             \
+                    flags, g.lpr, g.rpp, (V*)partial, (const V*)nullptr);                                          \
         return check_launch();                                                                                     \
     }
     TSGU_VSWITCH(vtype, TSGU_BODY, TSGU_BODY);
 #undef TSGU_BODY
 #undef TSGU_GO
+    return TSGU_OK;
+}
+
+// The x / r update of a preconditioned iteration: r = s - omega*t; x = (x + omega*z) + alpha*q with q = M p, z = M s
+// (columns finishing after the half step: x += alpha*q); partial |r|^2.  Arrays contiguous [n][p], 16-byte aligned.
+int tsgu_bicg_update_x_precond(int vtype, int64_t n, int64_t p, void* x, void* r, const void* s_, const void* t,
+                               const void* q, const void* z, const void* scal, const int* flags, void* partial,
+                               int device, void* stream) {
+    if (n <= 0 || p <= 0 || !x || !r || !s_ || !t || !q || !z || !scal || !flags || !partial) return TSGU_ERR_BAD_ARG;
+    if (!(aligned16(x) && aligned16(r) && aligned16(s_) && aligned16(t) && aligned16(q) && aligned16(z))) return TSGU_ERR_BAD_ARG;
+    if (const int rc = set_device(device)) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+#define TSGU_BODY                                                                                                  \
+    {                                                                                                              \
+        constexpr int wide = VT<V>::kWide;                                                                         \
+        VecGeom g;                                                                                                 \
+        if (!geom_for<V>(n, p, true, g)) return TSGU_ERR_TOO_LARGE;                                                \
+        if (g.vec == 1)                                                                                            \
+            hipLaunchKernelGGL((bicg_update_x_kernel<V, 1, true>), dim3((unsigned)g.blocks), dim3(kBlock), 0, s, n, p, (V*)x, \
+                               (V*)r, (const V*)s_, (const V*)t, (const V*)q, (const V*)scal, flags, g.lpr, g.rpp,   \
+                               (V*)partial, (const V*)z);                                                          \
+        else                                                                                                       \
+            hipLaunchKernelGGL((bicg_update_x_kernel<V, wide, true>), dim3((unsigned)g.blocks), dim3(kBlock), 0, s, n, p, \
+                               (V*)x, (V*)r, (const V*)s_, (const V*)t, (const V*)q, (const V*)scal, flags, g.lpr,   \
+                               g.rpp, (V*)partial, (const V*)z);                                                   \
+        return check_launch();                                                                                     \
+    }
+    TSGU_VSWITCH(vtype, TSGU_BODY, TSGU_BODY);
+#undef TSGU_BODY
     return TSGU_OK;
 }
 

@@ -22,6 +22,7 @@ from .. import _backend as _be
 from . import _graph
 from ._operator import SparseOperator, as_operator, checked
 
+ENABLE_FUSED = True  # False: the reference's op chain around the K1 matvec, column by column (tests compare the two)
 _POLL = 4  # iterations enqueued between two reads of the device "all columns finished" word
 _GRAPH_AFTER = 16  # iterations run eagerly before a chunk is recorded as a hipGraph
 
@@ -55,7 +56,9 @@ def bicgstab(
     ``matmul_closure``: tensor (dense or sparse COO/CSR) or callable; ``rhs``: ``(n,)`` or ``(n, k)``
     on the GPU.  Returns the solution with the shape of ``rhs``."""
     _be.require_device(rhs)
-    if settings.precon is None and rhs.dtype in (torch.float32, torch.float64) and rhs.dim() in (1, 2) \
+    if settings.precon is not None and not (torch.is_tensor(settings.precon) or callable(settings.precon)):
+        raise RuntimeError("settings.precon must be a tensor, or a callable object!")
+    if ENABLE_FUSED and rhs.dtype in (torch.float32, torch.float64) and rhs.dim() in (1, 2) \
             and rhs.shape[-1 if rhs.dim() == 2 else 0] > 0 and (rhs.dim() == 1 or rhs.shape[1] <= 1024):
         return _bicgstab_fused(matmul_closure, rhs, initial_guess, settings)
     if rhs.dim() > 1:
@@ -73,10 +76,8 @@ def bicgstab(
         precon = None
     elif torch.is_tensor(settings.precon):
         precon = settings.precon.matmul
-    elif callable(settings.precon):
-        precon = settings.precon
     else:
-        raise RuntimeError("settings.precon must be a tensor, or a callable object!")
+        precon = settings.precon
 
     rhs = rhs.contiguous()
     x = torch.zeros(n, dtype=rhs.dtype, device=rhs.device) if initial_guess is None else initial_guess.clone()
@@ -140,7 +141,9 @@ def bicgstab(
 
 def _bicgstab_fused(matmul_closure, rhs, initial_guess, settings: BICGSTABSettings) -> torch.Tensor:
     """All columns in lock-step on the K6 kernels (csrc/bicgstab.hip); same per-column arithmetic and stopping
-    rules as the reference's column loop (utils/bicgstab.py:126-247)."""
+    rules as the reference's column loop (utils/bicgstab.py:126-247).  A preconditioner (settings.precon, :191-194,
+    :216-219) is applied between the kernels: a tensor to all columns at once, a callable column by column on
+    contiguous vectors, as the reference calls it."""
     lib = _be.load_library()
     is_vector = rhs.dim() == 1
     B = (rhs.unsqueeze(-1) if is_vector else rhs).contiguous()
@@ -151,6 +154,14 @@ def _bicgstab_fused(matmul_closure, rhs, initial_guess, settings: BICGSTABSettin
     fused_dot = isinstance(op, SparseOperator) and op.dtype == dtype
     matvec_max = 2 * n if settings.matvec_max is None else int(settings.matvec_max)
     matvec_max = min(matvec_max, 2**31 - 1)
+    if settings.precon is None:
+        precon = None
+    elif torch.is_tensor(settings.precon):
+        m_op = as_operator(settings.precon)
+        precon = lambda V: checked(m_op(V), dtype).contiguous()  # noqa: E731
+    else:
+        m_fn = settings.precon
+        precon = lambda V: checked(torch.stack([m_fn(V[:, j].contiguous()) for j in range(p)], dim=1), dtype)  # noqa: E731
 
     if initial_guess is None:
         x = torch.zeros_like(B)
@@ -192,24 +203,32 @@ def _bicgstab_fused(matmul_closure, rhs, initial_guess, settings: BICGSTABSettin
         def iteration():
             scalar(1, None, 0)                      # beta, rho (bicgstab.py:183-184)
             vector(0, pv, r, v)                     # p update (:187-189)
+            q = pv if precon is None else precon(pv)  # (:191-194)
             if fused_dot:
-                _, pr0v = op.matmul_with_dot(pv, r0, out=v)  # v = A p with <r0, v> partials (:196-199)
+                _, pr0v = op.matmul_with_dot(q, r0, out=v)  # v = A q with <r0, v> partials (:196-199)
                 scalar(2, pr0v, pr0v.shape[0])
             else:
-                v.copy_(checked(op(pv), dtype))
+                v.copy_(checked(op(q), dtype))
                 scalar(2, _be.coldot(r0, v).unsqueeze(0).contiguous(), 1)
             vector(1, s, r, v, partial=part[0])     # s = r - alpha v, |s|^2 (:200-203)
             scalar(3, part[0], nb)                  # early exit / matvec budget (:207-214)
-            t = checked(op(s), dtype).contiguous()                  # t = A s (:221)
+            z = s if precon is None else precon(s)  # (:216-219)
+            t = checked(op(z), dtype).contiguous()                  # t = A z (:221)
             vector(2, t, s, r0, partial=part, set_stride=nb * p)
             scalar(4, part, nb, nb * p)             # omega, rho_next (:223-224)
-            vector(3, x, r, s, t, pv, partial=part[0])  # r, x updates, |r|^2 (:227-235)
+            if precon is None:
+                vector(3, x, r, s, t, pv, partial=part[0])  # r, x updates, |r|^2 (:227-235)
+            else:
+                _be.check(lib.tsgu_bicg_update_x_precond(vt, n, p, x.data_ptr(), r.data_ptr(), s.data_ptr(), t.data_ptr(),
+                                                         q.data_ptr(), z.data_ptr(), scal.data_ptr(), flags.data_ptr(),
+                                                         part[0].data_ptr(), dev.index, stream()), "tsgu_bicg_update_x_precond")
             scalar(5, part[0], nb)                  # stop tests (:239-241)
 
         done = bool(flags[0].item())
         k = 0
         graph = None
-        try_graph = fused_dot and _graph.enabled()  # user callables are opaque (may synchronise): never captured
+        # user callables (operator or preconditioner) are opaque (may synchronise): never captured
+        try_graph = fused_dot and _graph.enabled() and (precon is None or torch.is_tensor(settings.precon))
         while not done:
             if try_graph and graph is None and k >= _GRAPH_AFTER and (matvec_max - nmv0) // 2 - k >= _graph.MIN_ITERS:
                 # still running after _GRAPH_AFTER iterations: record one chunk as a hipGraph and replay it

@@ -1,12 +1,13 @@
 """``minres`` — drop-in for reference ``torchsparsegradutils/utils/minres.py`` (the default solver of
 ``sparse_generic_solve``, reference sparse_solve.py:406-410).
 
-Without a preconditioner and with a single shift (the ``sparse_generic_solve`` default path) the
-Lanczos + Givens recurrences run on the fused K7 kernels (``csrc/minres.hip``): five launches per
-iteration around the K1 SpMM, all per-column scalars on the device, one host read every 10
-iterations — where the reference synchronises for its stopping test — and hipGraph replay of
-10-iteration chunks for long solves.  A preconditioner, several shifts or a ``value`` factor use
-the same mathematics as device tensor ops around the K1 matvec.  Signature, settings, the rhs
+The Lanczos + Givens recurrences run on the fused K7 kernels (``csrc/minres.hip``): five launches
+per iteration around the K1 SpMM, all per-column (and per-shift) scalars on the device, one host
+read every 10 iterations — where the reference synchronises for its stopping test — and hipGraph
+replay of 10-iteration chunks for long solves.  Several shifts share the Lanczos vectors and update
+their solutions in one launch; ``value`` scales the product inside the Lanczos kernel; a
+preconditioner is called between two of the kernels.  Batched right-hand sides (more than two
+dimensions) use the same mathematics as device tensor ops around the K1 matvec.  Signature, settings, the rhs
 normalisation, the ``max_iter = min(max_iter, n+1)`` cap, the every-10-iterations relative-update
 stopping test and the shifted-system output layout follow reference ``utils/minres.py:140-311``.
 """
@@ -21,6 +22,9 @@ import torch
 from .. import _backend as _be
 from . import _graph
 from ._operator import SparseOperator, as_operator, checked
+
+
+ENABLE_FUSED = True  # False: the reference's op chain around the K1 matvec (tests compare the two)
 
 
 class MINRESSettings(NamedTuple):
@@ -66,14 +70,18 @@ def minres(
         out = mm(v)
         return out.mul(value) if value is not None else out
 
-    if (preconditioner is None and value is None and shifts.numel() == 1 and rhs.dim() == 2
+    n_sh = shifts.numel()
+    if (ENABLE_FUSED and rhs.dim() == 2 and shifts.dim() <= 1 and 0 < n_sh <= 64 and shifts.device == rhs.device
             and rhs.dtype in (torch.float32, torch.float64) and 0 < rhs.size(-1) <= 1024 and rhs.size(-2) > 0):
-        sol = _minres_fused(mm, rhs.contiguous(), float(shifts), eps, max_iter, settings).unsqueeze(0)
+        sol = _minres_fused(mm, rhs.contiguous(), shifts.reshape(-1).to(rhs.dtype).contiguous(), value, preconditioner, eps,
+                            max_iter, settings)
         sol = sol.masked_fill(rhs_is_zero, 0)
         if squeeze:
             sol = sol.squeeze(-1)
             rhs_norm = rhs_norm.squeeze(-1)
-        return sol.squeeze(0).mul(rhs_norm)
+        if n_sh == 1:
+            sol = sol.squeeze(0)
+        return sol.mul(rhs_norm)
 
     probe = apply(rhs)
     shifts = shifts.reshape(shifts.shape + (1,) * (probe.dim() - shifts.dim() + 1))
@@ -154,53 +162,74 @@ def minres(
     return sol.mul(rhs_norm)
 
 
-def _minres_fused(op, rhs: torch.Tensor, shift: float, eps: float, max_iter: int, settings: MINRESSettings) -> torch.Tensor:
-    """Un-preconditioned single-shift MINRES on the K7 kernels; `rhs` is the normalised (n, p) right-hand side
-    (reference utils/minres.py:241-311; without a preconditioner q == z)."""
+def _minres_fused(op, rhs: torch.Tensor, shifts: torch.Tensor, value, precond, eps: float, max_iter: int,
+                  settings: MINRESSettings) -> torch.Tensor:
+    """MINRES on the K7 kernels; `rhs` is the normalised (n, p) right-hand side, `shifts` the (S,) shifts; returns the
+    (S, n, p) solutions (reference utils/minres.py:241-311; without a preconditioner q == z)."""
     lib = _be.load_library()
     n, p = rhs.shape
+    S = shifts.numel()
     dev, dtype = rhs.device, rhs.dtype
     vt = _be.vtype_of(rhs)
     fused_dot = isinstance(op, SparseOperator) and op.dtype == dtype
+    val = 1.0 if value is None else float(value)
     nb = lib.tsgu_cg_num_blocks(vt, n, p)
     if nb < 0:
         raise RuntimeError("minres: more than 1024 simultaneous right-hand sides are not supported")
 
     z = [torch.zeros_like(rhs), rhs.clone()]                     # [z two steps back, z one step back]
-    beta0 = (z[1] * z[1]).sum(dim=-2).sqrt()                    # (minres.py:246-248)
-    z[1] = z[1] / beta0
-    w = [torch.zeros_like(rhs), torch.zeros_like(rhs)]
-    sol = torch.zeros_like(rhs)
-    scal = torch.zeros(12 * p, dtype=dtype, device=dev)
-    scal[p : 2 * p] = beta0
-    scal[11 * p :] = beta0
-    scal[6 * p : 7 * p] = beta0                                  # scale_prev (minres.py:255)
-    scal[2 * p : 3 * p] = 1
-    scal[4 * p : 5 * p] = 1
+    if precond is None:
+        q = None
+        beta0 = (z[1] * z[1]).sum(dim=-2).sqrt()                # (minres.py:246-248)
+        z[1] = z[1] / beta0
+    else:
+        q = [None, checked(precond(z[1]), dtype).contiguous()]  # [scratch, q one step back]  (minres.py:245)
+        beta0 = (z[1] * q[1]).sum(dim=-2).sqrt()
+        z[1] = z[1] / beta0
+        q[1] = q[1] / beta0
+    plane = -(-n * p // 4) * 4                                   # per-shift planes start on 16-byte boundaries
+    w = [torch.zeros((S, plane), dtype=dtype, device=dev), torch.zeros((S, plane), dtype=dtype, device=dev)]
+    sol = torch.zeros((S, plane), dtype=dtype, device=dev)
+    scal = torch.zeros((S, 12, p), dtype=dtype, device=dev)
+    scal[0, 1] = beta0
+    scal[0, 11] = beta0
+    scal[:, 6] = beta0                                           # scale_prev (minres.py:255)
+    scal[:, 2] = 1
+    scal[:, 4] = 1
     flags = torch.zeros(2, dtype=torch.int32, device=dev)
-    part = torch.empty((2, nb, p), dtype=dtype, device=dev)
+    part = torch.empty((2 * S, nb, p), dtype=dtype, device=dev)
     fold = torch.empty((lib.tsgu_cg_fold_rows(), p), dtype=dtype, device=dev)
     stream = lambda: torch.cuda.current_stream(dev).cuda_stream  # noqa: E731
 
     def scalar(phase, partial, rows, set_stride=0):
-        _be.check(lib.tsgu_minres_scalar(vt, phase, partial.data_ptr(), rows, set_stride, fold.data_ptr(), scal.data_ptr(),
-                                         flags.data_ptr(), float(eps), float(settings.minres_tolerance), shift, p,
-                                         dev.index, stream()), "tsgu_minres_scalar")
+        _be.check(lib.tsgu_minres_scalar_ms(vt, phase, partial.data_ptr(), rows, set_stride, fold.data_ptr(), scal.data_ptr(),
+                                            flags.data_ptr(), float(eps), float(settings.minres_tolerance), shifts.data_ptr(),
+                                            S, val, p, dev.index, stream()), "tsgu_minres_scalar_ms")
+
+    def vector(which, a0, a1, a2, a3=None, a4=None, qc=None, with_norms=False):
+        _be.check(lib.tsgu_minres_vector_ms(vt, which, n, p, a0.data_ptr(), a1.data_ptr(), a2.data_ptr(),
+                                            None if a3 is None else a3.data_ptr(), None if a4 is None else a4.data_ptr(),
+                                            None if qc is None else qc.data_ptr(), scal.data_ptr(), flags.data_ptr(),
+                                            part.data_ptr(), nb * p, int(with_norms), S, plane, val, dev.index, stream()),
+                  "tsgu_minres_vector_ms")
 
     def iteration(check: bool):
+        qp = z[1] if q is None else q[1]
         if fused_dot:
-            prod, pzz = op.matmul_with_dot(z[1])                # A z with <z, A z> partials (minres.py:261-262)
+            prod, pqq = op.matmul_with_dot(qp)                  # A q with <q, A q> partials (minres.py:261-262)
         else:
-            prod = checked(op(z[1]), dtype).contiguous()
-            pzz = _be.coldot(prod, z[1]).unsqueeze(0).contiguous()
-        scalar(0, pzz, pzz.shape[0])
-        _be.check(lib.tsgu_minres_vector(vt, 0, n, p, z[0].data_ptr(), z[1].data_ptr(), prod.data_ptr(), None, None,
-                                         scal.data_ptr(), flags.data_ptr(), part.data_ptr(), 0, 0, dev.index, stream()),
-                  "tsgu_minres_vector")
-        scalar(1, part[0], nb)
-        _be.check(lib.tsgu_minres_vector(vt, 1, n, p, z[0].data_ptr(), z[1].data_ptr(), w[0].data_ptr(), w[1].data_ptr(),
-                                         sol.data_ptr(), scal.data_ptr(), flags.data_ptr(), part.data_ptr(), nb * p,
-                                         int(check), dev.index, stream()), "tsgu_minres_vector")
+            prod = checked(op(qp), dtype).contiguous()
+            pqq = _be.coldot(prod, qp).unsqueeze(0).contiguous()
+        scalar(0, pqq, pqq.shape[0])
+        vector(0, z[0], z[1], prod)                             # z_c over z two steps back, |z_c|^2 partials (:263-268)
+        if q is None:
+            scalar(1, part[0], nb)
+            vector(1, z[0], z[1], w[0], w[1], sol, with_norms=check)
+        else:
+            q[0] = checked(precond(z[0]), dtype).contiguous()   # q_c = M z_c, beta_c = sqrt <z_c, q_c> (:267-268)
+            scalar(1, _be.coldot(z[0], q[0]).unsqueeze(0).contiguous(), 1)
+            vector(1, z[0], q[1], w[0], w[1], sol, qc=q[0], with_norms=check)
+            q.reverse()
         if check:
             scalar(2, part, nb, nb * p)                          # every 10th iteration (minres.py:299-305)
         z.reverse()                                              # the buffer that held z two steps back now holds z_c
@@ -213,7 +242,7 @@ def _minres_fused(op, rhs: torch.Tensor, shift: float, eps: float, max_iter: int
     total = max_iter + 2                                         # (minres.py:259)
     i = 0
     graph = None
-    try_graph = fused_dot and _graph.enabled()
+    try_graph = fused_dot and precond is None and _graph.enabled()  # user callables are opaque: never captured
     with torch.cuda.device(dev):
         while i < total:
             if i % 10 == 0 and total - i >= 10:
@@ -236,8 +265,8 @@ def _minres_fused(op, rhs: torch.Tensor, shift: float, eps: float, max_iter: int
                 if i % 10 == 0 and bool(flags[0].item()):
                     break
     _INFO.last = {"solver": "minres", "iterations": i, "tolerance_reached": bool(flags[0].item()),
-                  "tolerance": float(settings.minres_tolerance)}
-    return sol
+                  "tolerance": float(settings.minres_tolerance), "shifts": S}
+    return sol[:, : n * p].reshape(S, n, p)
 
 
 class _Info(threading.local):
