@@ -419,6 +419,12 @@ int64_t tsgu_cg_num_blocks(int vtype, int64_t n, int64_t p);
 int tsgu_cg_beta(int vtype, const void* rr_partial, int64_t n_partial, void* scal, int* flags,
                  double eps, double stop_updating_after, double tolerance, int iter_index,
                  int min_iter_index, int64_t p, int device, void* stream);
+/* Preconditioned CG (reference utils/linear_cg.py:80-84, :319-382 with `preconditioner`): scal + 0*p holds <r, z>, z = M r
+ * applied by the caller after step 2; step 3 takes the <r, z> partials next to the |r|^2 partials (beta and the next alpha
+ * from <r, z>, residual norm / has_converged / stop test from |r|^2), step 4 is tsgu_cg_update2 with z in the place of r. */
+int tsgu_cg_beta_precond(int vtype, const void* rr_partial, int64_t n_partial, const void* rz_partial, int64_t n_rz, void* scal,
+                         int* flags, double eps, double stop_updating_after, double tolerance, int iter_index,
+                         int min_iter_index, int64_t p, int device, void* stream);
 int tsgu_cg_update2(int vtype, int64_t n, int64_t p, const void* r, void* pvec,
                     const void* scal, const int* flags, int device, void* stream);
 

@@ -166,3 +166,45 @@ def test_minres_shift_planes_of_any_size():
     for i in range(2):
         one = minres(A, B, shifts=sh[i : i + 1], settings=st)
         assert rel(both[i], one.cpu().numpy()) < 2e-5
+
+
+@pytest.mark.parametrize("vn", ["f32", "f64"])
+@pytest.mark.parametrize("fused_pcg", [True, False], ids=["fused", "opchain"])
+def test_linear_cg_preconditioned_iterates_match_reference(vn, fused_pcg, monkeypatch):
+    """Preconditioned linear_cg (reference utils/linear_cg.py:80-84, :291-294) on the fused step kernels (the preconditioner is
+    called between the residual update and the beta step) and as tensor ops: iterates after 5 and 15 iterations, a run that
+    stops on its tolerance, an initial guess, a vector right-hand side, a zero column — tests/golden/pcg.npz from the real
+    reference.  Tolerances: 1e-10 normwise in fp64, 1e-4 in fp32."""
+    import sys
+    import warnings
+
+    from torchsparsegradutils_amd.utils import linear_cg
+    from torchsparsegradutils_amd.utils.linear_cg import last_solve_info
+
+    monkeypatch.setattr(sys.modules[linear_cg.__module__], "ENABLE_FUSED_PRECOND", fused_pcg)
+    z = G.load("pcg.npz")
+    dt = torch.float32 if vn == "f32" else torch.float64
+    tol = 1e-4 if vn == "f32" else 1e-10
+    n = z["rhs"].shape[0]
+    A = torch.sparse_csr_tensor(G.t(z["crow"], DEV), G.t(z["col"], DEV), G.t(z["val"], DEV).to(dt), (n, n))
+    b = G.t(z["rhs"], DEV).to(dt)
+    di = G.t(z["dinv"], DEV).to(dt)
+    pre = lambda v: v * di  # noqa: E731
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for it in (5, 15):
+            x = linear_cg(A, b.clone(), max_iter=it, max_tridiag_iter=it, tolerance=0, preconditioner=pre)
+            assert rel(x, z[f"{vn}_it{it}"]) < tol, (it, rel(x, z[f"{vn}_it{it}"]))
+            assert last_solve_info()["iterations"] == it
+            assert float(x[:, 3].abs().max()) == 0.0
+        x = linear_cg(A, b.clone(), tolerance=1e-4, preconditioner=pre)
+        assert rel(x, z[f"{vn}_tol"]) < 50 * tol and last_solve_info()["tolerance_reached"]
+        x = linear_cg(A, b.clone(), max_iter=7, max_tridiag_iter=7, tolerance=0, initial_guess=G.t(z["x0"], DEV).to(dt), preconditioner=pre)
+        assert rel(x, z[f"{vn}_guess_it7"]) < tol
+        xv = linear_cg(A, b[:, 0].clone(), max_iter=9, max_tridiag_iter=9, tolerance=0,
+                       preconditioner=lambda v: v * di.squeeze(-1) if v.dim() == 1 else v * di)
+        assert xv.shape == (n,) and rel(xv, z[f"{vn}_vec_it9"]) < tol
+        # an identity preconditioner that returns its argument: same iterates as no preconditioner
+        x_id = linear_cg(A, b.clone(), max_iter=15, max_tridiag_iter=15, tolerance=0, preconditioner=lambda v: v)
+        x_no = linear_cg(A, b.clone(), max_iter=15, max_tridiag_iter=15, tolerance=0)
+        assert rel(x_id, x_no.cpu().numpy()) < tol

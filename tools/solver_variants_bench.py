@@ -10,12 +10,15 @@ import time
 import torch
 
 sys.path.insert(0, ".")
-from torchsparsegradutils_amd.utils import BICGSTABSettings, MINRESSettings, bicgstab, minres, synthetic  # noqa: E402
+from torchsparsegradutils_amd.utils import BICGSTABSettings, MINRESSettings, bicgstab, linear_cg, minres, synthetic  # noqa: E402
 
 DEV = "cuda:0"
 
 
 def timed(fn, reps=3):
+    import warnings
+
+    warnings.simplefilter("ignore")
     fn()
     torch.cuda.synchronize()
     best = 1e9
@@ -43,7 +46,9 @@ def main():
     iters = 100
     out = {}
     mods = {"minres": sys.modules[minres.__module__], "bicgstab": sys.modules[bicgstab.__module__]}
+    cg_mod = sys.modules[linear_cg.__module__]
     cases = {
+        "linear_cg_jacobi": lambda: linear_cg(A, B, max_iter=iters, max_tridiag_iter=iters, tolerance=0, preconditioner=lambda v: v * dcol),
         "minres_3_shifts": lambda: minres(A, B, shifts=sh, max_iter=iters - 2, settings=MINRESSettings(minres_tolerance=0.0)),
         "minres_value": lambda: minres(A, B, value=0.5, max_iter=iters - 2, settings=MINRESSettings(minres_tolerance=0.0)),
         "minres_jacobi": lambda: minres(A, B, preconditioner=lambda v: v * dcol, max_iter=iters - 2, settings=MINRESSettings(minres_tolerance=0.0)),
@@ -58,9 +63,11 @@ def main():
         for label, flag in (("fused_ms_per_iter", True), ("op_chain_ms_per_iter", False)):
             for mod in mods.values():
                 mod.ENABLE_FUSED = flag
+            cg_mod.ENABLE_FUSED_PRECOND = flag
             row[label] = round(timed(fn) / iters * 1e3, 4)
         for mod in mods.values():
             mod.ENABLE_FUSED = True
+        cg_mod.ENABLE_FUSED_PRECOND = True
         row["speedup"] = round(row["op_chain_ms_per_iter"] / row["fused_ms_per_iter"], 2)
         out[name] = row
         print(json.dumps({name: row}), flush=True)

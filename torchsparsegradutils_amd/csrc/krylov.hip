@@ -196,7 +196,8 @@ __global__ __launch_bounds__(kBlock) void cg_update1_alpha_kernel(int64_t n, int
 template <typename V>
 __global__ __launch_bounds__(kBlock) void cg_beta_kernel(const V* __restrict__ rr_partial, int64_t n_partial, int64_t p,
                                                          V* __restrict__ scal, int* __restrict__ flags, V eps, V stop_after,
-                                                         V tolerance, int iter_index, int min_iter_index) {
+                                                         V tolerance, int iter_index, int min_iter_index,
+                                                         const V* __restrict__ rz_partial, int64_t n_rz) {
     // single block: needs the mean of the residual norms over ALL columns for the stop test.
     __shared__ V red[kBlock];
     __shared__ V normsum[kBlock];
@@ -206,12 +207,14 @@ __global__ __launch_bounds__(kBlock) void cg_beta_kernel(const V* __restrict__ r
     for (int64_t c0 = 0; c0 < p; c0 += 64) {
         const int w = (int)(p - c0 < 64 ? p - c0 : 64);
         const V rr_new = block_colsum<V>(rr_partial, n_partial, p, c0, w, red);
+        // preconditioned: the recurrences run on <r, z> (z = M r, linear_cg.py:80-84), the stop test still on |r|
+        const V ip_new = rz_partial ? block_colsum<V>(rz_partial, n_rz, p, c0, w, red) : rr_new;
         if (t < w) {
             const int64_t c = c0 + t;
             const V rr_old = scal[c];
-            // beta = rr_new / rr_old with the reference's safe division (linear_cg.py:35-43)
-            const V beta = rr_old < eps ? (V)0 : rr_new / rr_old;
-            scal[c] = rr_new;
+            // beta = <r,z>_new / <r,z>_old with the reference's safe division (linear_cg.py:35-43)
+            const V beta = rr_old < eps ? (V)0 : ip_new / rr_old;
+            scal[c] = ip_new;
             scal[2 * p + c] = beta;
             V nrm = sqrt(rr_new);                       // ‖r‖₂ (linear_cg.py:372)
             if (flags[2 + p + c] != 0) nrm = 0;         // rhs_is_zero mask (:373)
@@ -400,14 +403,21 @@ int tsgu_cg_update1_alpha(int vtype, int64_t n, int64_t p, void* r, const void* 
 int tsgu_cg_beta(int vtype, const void* rr_partial, int64_t n_partial, void* scal, int* flags, double eps,
                  double stop_updating_after, double tolerance, int iter_index, int min_iter_index, int64_t p,
                  int device, void* stream) {
-    if (!rr_partial || !scal || !flags || p <= 0 || n_partial < 0) return TSGU_ERR_BAD_ARG;
+    return tsgu_cg_beta_precond(vtype, rr_partial, n_partial, nullptr, 0, scal, flags, eps, stop_updating_after, tolerance,
+                                iter_index, min_iter_index, p, device, stream);
+}
+
+int tsgu_cg_beta_precond(int vtype, const void* rr_partial, int64_t n_partial, const void* rz_partial, int64_t n_rz, void* scal,
+                         int* flags, double eps, double stop_updating_after, double tolerance, int iter_index,
+                         int min_iter_index, int64_t p, int device, void* stream) {
+    if (!rr_partial || !scal || !flags || p <= 0 || n_partial < 0 || n_rz < 0) return TSGU_ERR_BAD_ARG;
     if (const int rc = set_device(device)) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
 #define TSGU_BODY                                                                                             \
     {                                                                                                         \
         hipLaunchKernelGGL((cg_beta_kernel<V>), dim3(1), dim3(kBlock), 0, s, (const V*)rr_partial, n_partial, \
                            p, (V*)scal, flags, (V)eps, (V)stop_updating_after, (V)tolerance, iter_index,      \
-                           min_iter_index);                                                                   \
+                           min_iter_index, (const V*)rz_partial, n_rz);                                       \
         return check_launch();                                                                                \
     }
     TSGU_VSWITCH(vtype, TSGU_BODY, TSGU_BODY);

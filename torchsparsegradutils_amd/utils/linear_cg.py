@@ -29,6 +29,7 @@ from .. import _backend as _be
 from . import _graph
 from ._operator import SparseOperator, as_operator, checked
 
+ENABLE_FUSED_PRECOND = True  # False: preconditioned solves run the recurrences as tensor ops (tests compare the two)
 _POLL = 8  # iterations enqueued between two reads of the device stop flag
 
 
@@ -136,7 +137,7 @@ def linear_cg(
     if n_tridiag:
         t_mat = torch.zeros(n_tridiag_iter, n_tridiag_iter, n_tridiag, dtype=dtype, device=dev)
     if n_iter > 0:
-        if preconditioner is not None or n_tridiag:
+        if n_tridiag or (preconditioner is not None and not ENABLE_FUSED_PRECOND):
             result, residual_norm, k_done, tolerance_reached, last_tridiag_iter = _pcg_loop(
                 op, preconditioner, rhs_is_zero, result, residual, has_converged, n_iter, max_iter, tolerance, eps,
                 stop_updating_after, n_tridiag, n_tridiag_iter, t_mat,
@@ -145,7 +146,7 @@ def linear_cg(
             last_tridiag_iter = 0
             result, residual_norm, k_done, tolerance_reached = _fused_loop(
                 op, rhs_is_zero, result, residual, has_converged, n_iter, max_iter, tolerance, eps,
-                stop_updating_after,
+                stop_updating_after, preconditioner,
             )
 
     result = result.mul(rhs_norm)
@@ -231,8 +232,9 @@ def _batched_rhs(matmul_closure, rhs, n_tridiag, tolerance, eps, stop_updating_a
     return unfold(out), t_sel.permute(1, 0, 2, 3).reshape((n_tridiag,) + batch_shape + (r, r)).contiguous()
 
 
-def _fused_loop(op, rhs_is_zero, x, r, has_converged, n_iter, max_iter, tolerance, eps, stop_after):
-    """Un-preconditioned CG iterations on the fused gfx950 kernels (reference :319-382, :50-95)."""
+def _fused_loop(op, rhs_is_zero, x, r, has_converged, n_iter, max_iter, tolerance, eps, stop_after, preconditioner=None):
+    """CG iterations on the fused gfx950 kernels (reference :319-382, :50-95).  A preconditioner is called between the
+    residual update and the beta step (z = M r); the recurrences then run on <r, z>, the stop test on |r|."""
     lib = _be.load_library()
     n, p = r.shape
     dev, dtype = r.device, r.dtype
@@ -243,13 +245,18 @@ def _fused_loop(op, rhs_is_zero, x, r, has_converged, n_iter, max_iter, toleranc
 
     # device state: scal = [rr | alpha | beta | rnorm], flags = [done, iters, has_converged[p], rhs_is_zero[p]]
     scal = torch.zeros(4 * p, dtype=dtype, device=dev)
-    scal[:p] = _be.coldot(r, r)  # residual_inner_prod (reference :294)
+    if preconditioner is None:
+        scal[:p] = _be.coldot(r, r)  # residual_inner_prod (reference :294)
+        pvec = r.clone()  # curr_conjugate_vec (reference :293)
+    else:
+        z = checked(preconditioner(r), dtype).contiguous()  # (reference :291-294)
+        scal[:p] = _be.coldot(z, r)
+        pvec = z.clone() if z.data_ptr() == r.data_ptr() else z
     flags = torch.zeros(2 + 2 * p, dtype=torch.int32, device=dev)
     flags[2 : 2 + p] = has_converged.reshape(-1).to(torch.int32)
     flags[2 + p :] = rhs_is_zero.reshape(-1).to(torch.int32)
     rr_partial = torch.empty((nb_upd, p), dtype=dtype, device=dev)
     fold = torch.empty((lib.tsgu_cg_fold_rows(), p), dtype=dtype, device=dev)
-    pvec = r.clone()  # curr_conjugate_vec (reference :293)
     fused_dot = isinstance(op, SparseOperator) and op.dtype == dtype
     stream = lambda: torch.cuda.current_stream(dev).cuda_stream  # noqa: E731
     min_iter_index = min(10, max_iter - 1)
@@ -276,16 +283,24 @@ def _fused_loop(op, rhs_is_zero, x, r, has_converged, n_iter, max_iter, toleranc
                                           scal.data_ptr(), flags.data_ptr(), rr_partial.data_ptr(), dev.index, s),
                       "tsgu_cg_update1")
         # iteration index -1: the counter is flags[1] on the device, every iteration is the same launch
-        _be.check(lib.tsgu_cg_beta(vt, rr_partial.data_ptr(), nb_upd, scal.data_ptr(), flags.data_ptr(), eps,
-                                   stop_after, float(tolerance), -1, min_iter_index, p, dev.index, s),
-                  "tsgu_cg_beta")
-        _be.check(lib.tsgu_cg_update2(vt, n, p, r.data_ptr(), pvec.data_ptr(), scal.data_ptr(),
+        if preconditioner is None:
+            _be.check(lib.tsgu_cg_beta(vt, rr_partial.data_ptr(), nb_upd, scal.data_ptr(), flags.data_ptr(), eps,
+                                       stop_after, float(tolerance), -1, min_iter_index, p, dev.index, s),
+                      "tsgu_cg_beta")
+            z = r
+        else:
+            z = checked(preconditioner(r), dtype).contiguous()  # z = M r (reference :80)
+            rz = _be.coldot(z, r)
+            _be.check(lib.tsgu_cg_beta_precond(vt, rr_partial.data_ptr(), nb_upd, rz.data_ptr(), 1, scal.data_ptr(), flags.data_ptr(),
+                                               eps, stop_after, float(tolerance), -1, min_iter_index, p, dev.index, s),
+                      "tsgu_cg_beta_precond")
+        _be.check(lib.tsgu_cg_update2(vt, n, p, z.data_ptr(), pvec.data_ptr(), scal.data_ptr(),
                                       flags.data_ptr(), dev.index, s), "tsgu_cg_update2")
 
     done = False
     k = 0
     graph = None
-    try_graph = fused_dot and _graph.enabled()  # user callables are opaque (may synchronise): never captured
+    try_graph = fused_dot and preconditioner is None and _graph.enabled()  # user callables are opaque (may synchronise): never captured
     with torch.cuda.device(dev):
         while k < n_iter and not done:
             if try_graph and graph is None and k > min_iter_index and n_iter - k >= _graph.MIN_ITERS:
