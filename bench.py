@@ -138,11 +138,23 @@ def c5_leg(dev, world, rank, steps, warmup, barrier):
         return parallel.sharded_batched_apply(sparse_mm, A, B, gather=True, overlap_chunks=min(4, hi - lo))
 
     def timed(fn):
-        for _ in range(max(warmup, 2)):
-            fn()
-        wait_for_plans()
-        for _ in range(2):
-            fn()
+        # a rank that fails in its warm-up must not leave the others waiting in the barrier below: agree first
+        err = None
+        try:
+            for _ in range(max(warmup, 2)):
+                fn()
+            wait_for_plans()
+            for _ in range(2):
+                fn()
+        except Exception as exc:  # noqa: BLE001
+            err = exc
+        if world > 1:
+            ok = torch.tensor([0 if err is not None else 1], device=dev, dtype=torch.int32)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0 and err is None:
+                err = RuntimeError("another rank failed in the warm-up of this leg")
+        if err is not None:
+            raise err
         barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -286,7 +298,9 @@ def main():
     ms_backward_call = timed_loop(step_backward_call)
     A.grad = None
     B.grad = None
-    # host side of a step: the same loop on a 1/64 problem (the GPU needs ~10 us per step there), and the full-size step with
+    # host side of a step: the same loop on a 1/64 problem (the GPU needs ~10 us per step there; a different number of columns, so
+    # that its launches are other kernel instantiations than the C2 step's and a rocprofv3 --stats average of those stays the
+    # C2 average), and the full-size step with
     # torch's autograd engine kept on the calling thread (a public torch switch; the default hands every backward to a worker
     # thread, whose wake-up is at the mercy of the host — see DESIGN.md, Host side)
     host_ms = ms_single_thread = None
@@ -294,8 +308,9 @@ def main():
         try:
             sc, sl = synthetic.stencil27_periodic(25, 25, 25, torch.int32, device=dev)
             sA = torch.sparse_csr_tensor(sc, sl, torch.randn(sl.numel(), device=dev), (25 ** 3, 25 ** 3)).requires_grad_(True)
-            sB = torch.randn(25 ** 3, p, device=dev, requires_grad=True)
-            sG = torch.randn(25 ** 3, p, device=dev)
+            hp = 16 if p != 16 else 32
+            sB = torch.randn(25 ** 3, hp, device=dev, requires_grad=True)
+            sG = torch.randn(25 ** 3, hp, device=dev)
 
             def small_step():
                 torch.autograd.grad(sparse_mm(sA, sB), (sA, sB), sG)

@@ -39,8 +39,15 @@ acc = defaultdict(lambda: defaultdict(list))
 for kind in ("fetch", "write"):
     for f in glob.glob(os.path.join(src, kind, "**", "*counter_collection.csv"), recursive=True):
         shutil.copy(f, os.path.join(dst, f"{tag}_pmc_{kind}_counter_collection.csv"))
-        for r in csv.DictReader(open(f)):
-            acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        rows = list(csv.DictReader(open(f)))
+        # bench.py also steps a 1/64-size problem (host_ms_per_step) through the same kernel instantiations: per kernel name keep
+        # the launches of the LARGEST grid only — the C2 launches
+        biggest = defaultdict(int)
+        for r in rows:
+            biggest[r["Kernel_Name"]] = max(biggest[r["Kernel_Name"]], int(r["Grid_Size"]))
+        for r in rows:
+            if int(r["Grid_Size"]) == biggest[r["Kernel_Name"]]:
+                acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 
 
 def role(kname):
