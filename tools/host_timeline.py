@@ -1,4 +1,5 @@
-"""Where the host time of one autograd step goes: timestamps at forward end / backward begin / backward end / grad() return."""
+"""Where the host time of one autograd step goes: timestamps at forward end / backward begin / backward end / grad() return,
+with torch's engine thread (the default) and on the calling thread only."""
 import sys, time
 import torch
 sys.path.insert(0, ".")
@@ -39,18 +40,32 @@ m.wait_for_plans()
 for _ in range(5):
     C = m.sparse_mm(A, B); torch.autograd.grad(C, (A, B), G)
 torch.cuda.synchronize()
-acc = {k: 0.0 for k in ("pre_fwd", "fwd", "fwd_end->bwd_begin", "bwd", "bwd_end->return")}
 N = 500
-for _ in range(N):
-    t0 = time.perf_counter()
-    C = m.sparse_mm(A, B)
-    torch.autograd.grad(C, (A, B), G)
-    t1 = time.perf_counter()
-    acc["pre_fwd"] += T["f0"] - t0
-    acc["fwd"] += T["f1"] - T["f0"]
-    acc["fwd_end->bwd_begin"] += T["b0"] - T["f1"]
-    acc["bwd"] += T["b1"] - T["b0"]
-    acc["bwd_end->return"] += t1 - T["b1"]
-torch.cuda.synchronize()
-for k, v in acc.items():
-    print(f"{k:22s} {v / N * 1e6:7.1f} us")
+
+
+def measure(label):
+    acc = {k: 0.0 for k in ("pre_fwd", "fwd", "fwd_end->bwd_begin", "bwd", "bwd_end->return", "total")}
+    torch.cuda.synchronize()
+    for _ in range(N):
+        t0 = time.perf_counter()
+        C = m.sparse_mm(A, B)
+        torch.autograd.grad(C, (A, B), G)
+        t1 = time.perf_counter()
+        acc["pre_fwd"] += T["f0"] - t0
+        acc["fwd"] += T["f1"] - T["f0"]
+        acc["fwd_end->bwd_begin"] += T["b0"] - T["f1"]
+        acc["bwd"] += T["b1"] - T["b0"]
+        acc["bwd_end->return"] += t1 - T["b1"]
+        acc["total"] += t1 - t0
+    torch.cuda.synchronize()
+    print(label + ": " + "  ".join(f"{k} {v / N * 1e6:.1f}" for k, v in acc.items()), flush=True)
+
+
+for rep in range(4):
+    measure("engine threads (default)")
+torch.autograd.set_multithreading_enabled(False)
+for rep in range(3):
+    measure("calling thread only     ")
+torch.autograd.set_multithreading_enabled(True)
+for rep in range(2):
+    measure("engine threads again    ")
