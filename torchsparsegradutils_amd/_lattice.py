@@ -555,6 +555,17 @@ def rank_configs(plan: LatticePlan, mode: int, vtype: int, p: int, elem_bytes: i
                 key = (ty, tz, threads)
                 if key not in found or cost < found[key][0]:
                     found[key] = (cost, (ty, tz, nseg, threads, ring, 1))
+    if mode == _MODE_SPMMT and elem_bytes == 2:
+        # bf16 transposed walk: its ring (dense rows + value rows of the halo) and per-phase record tables leave room for ONE
+        # workgroup per CU, and four waves cannot cover the LDS latency of their own reads.  The same tile run by 512 threads —
+        # every second row group idle in the products, all of them moving the ring — is faster (measured at C5, 64 items:
+        # 8x16 tile 561 -> 510 us; 8 items 145 -> 130 us)
+        for (ty, tz, threads), (cost, c) in list(found.items()):
+            if threads != 256:
+                continue
+            lds = lds_bytes_fn(mode, vtype, p, ty, tz, plan.ry, plan.rz, min(plan.ncls, _NLOC_GUESS[plan.kind]), plan.recw, 512, c[4])
+            if lds > 0 and 160 * 1024 // lds < 2:
+                found[(ty, tz, 512)] = (cost * 0.92, (ty, tz, c[2], 512, c[4], c[5]))
     return [c for _, c in sorted(found.values())[:keep]]
 
 
