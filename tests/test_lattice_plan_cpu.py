@@ -234,17 +234,17 @@ def test_config_choice_is_within_limits():
     assert ty <= plan.ny and tz <= plan.nz and 1 <= nseg <= plan.nx and threads in (512, 1024) and 4 <= ring <= 8
 
 
-def test_bf16_transposed_walk_runs_its_lds_bound_tile_with_512_threads():
+def test_bf16_transposed_walk_runs_its_lds_bound_tile_with_more_threads():
     """The bf16 transposed walk fits one workgroup per CU (ring of dense + value rows, per-phase record tables): the ranking
-    offers the tile of the 256-thread form to 512 threads first (measured faster at C5), other operands keep their ranking."""
+    offers the tile of the 256-thread form to 1024 and 512 threads first (measured faster at C5), other operands keep their ranking."""
     from types import SimpleNamespace as NS
 
     from torchsparsegradutils_amd import _backend as be
 
     plan = NS(kind=1, nb=64, nx=64, ny=64, nz=32, ry=1, rz=1, ncls=125, recw=28)
     ranked = lt.rank_configs(plan, 2, 2, 16, 2, be.lattice_lds_bytes)
-    assert ranked[0][:2] == (8, 16) and ranked[0][3] == 512
-    assert (8, 16, ranked[0][2], 256, 4, 1) in ranked
+    assert ranked[0][:2] == (8, 16) and ranked[0][3] == 1024 and (8, 16, ranked[0][2], 512, 4, 1) in ranked
+    assert (8, 16, ranked[0][2], 256, 4, 1) in lt.rank_configs(plan, 2, 2, 16, 2, be.lattice_lds_bytes, keep=12)
     fwd = NS(kind=0, nb=64, nx=64, ny=64, nz=32, ry=1, rz=1, ncls=27, recw=28)
     assert all(ty * tz == threads // 2 for ty, tz, _, threads, _, _ in lt.rank_configs(fwd, 0, 2, 16, 2, be.lattice_lds_bytes)[:2])
 

@@ -557,15 +557,16 @@ def rank_configs(plan: LatticePlan, mode: int, vtype: int, p: int, elem_bytes: i
                     found[key] = (cost, (ty, tz, nseg, threads, ring, 1))
     if mode == _MODE_SPMMT and elem_bytes == 2:
         # bf16 transposed walk: its ring (dense rows + value rows of the halo) and per-phase record tables leave room for ONE
-        # workgroup per CU, and four waves cannot cover the LDS latency of their own reads.  The same tile run by 512 threads —
-        # every second row group idle in the products, all of them moving the ring — is faster (measured at C5, 64 items:
-        # 8x16 tile 561 -> 510 us; 8 items 145 -> 130 us)
+        # workgroup per CU, and four waves cannot cover the LDS latency of their own reads.  The same tile run by more threads —
+        # only every second / fourth row group busy in the products, all of them moving the ring — is faster (measured at C5,
+        # 64 items, 8x16 tile: 256 threads 561 us, 512 threads 508 us, 1024 threads 474 us)
         for (ty, tz, threads), (cost, c) in list(found.items()):
             if threads != 256:
                 continue
-            lds = lds_bytes_fn(mode, vtype, p, ty, tz, plan.ry, plan.rz, min(plan.ncls, _NLOC_GUESS[plan.kind]), plan.recw, 512, c[4])
-            if lds > 0 and 160 * 1024 // lds < 2:
-                found[(ty, tz, 512)] = (cost * 0.92, (ty, tz, c[2], 512, c[4], c[5]))
+            for more, gain in ((512, 0.92), (1024, 0.85)):
+                lds = lds_bytes_fn(mode, vtype, p, ty, tz, plan.ry, plan.rz, min(plan.ncls, _NLOC_GUESS[plan.kind]), plan.recw, more, c[4])
+                if lds > 0 and 160 * 1024 // lds < 2:
+                    found[(ty, tz, more)] = (cost * gain, (ty, tz, c[2], more, c[4], c[5]))
     return [c for _, c in sorted(found.values())[:keep]]
 
 
