@@ -533,3 +533,46 @@ def test_linear_cg_takes_the_plane_sweep_with_the_fused_dot():
     lp = core.own.get("lattice")
     assert lp is not None and any(k[2] == 4 and c is not None for k, c in lp._cfg.items()), "the plane sweep was not taken"
     assert G.rel_err(outs[0].cpu().numpy(), outs[1].cpu().numpy()) < 1e-4
+
+
+@pytest.mark.parametrize("dt,p", [(torch.bfloat16, 16), (torch.float32, 32), (torch.float64, 8)])
+def test_measured_configuration_choice_keeps_the_bits(dt, p, monkeypatch):
+    """A pattern that comes back gets its launch configuration measured (`_lattice.tune_config`): the best-ranked candidates
+    of every workgroup size are timed once; every configuration sums a row in the same order, so the steps before and after
+    the choice agree bit for bit; the choice happens once per (product, operand type, width)."""
+    from torchsparsegradutils_amd import _lattice as lt
+    from torchsparsegradutils_amd import _ops, _pattern, sparse_mm
+    from torchsparsegradutils_amd.utils import synthetic
+
+    monkeypatch.setattr(lt, "TUNE", True)
+    monkeypatch.setattr(lt, "TUNE_AFTER_USES", 2)
+    monkeypatch.setattr(_ops, "PACK_MIN_NNZ", 1)
+    dev = torch.device("cuda:0")
+    nx, ny, nz = 12, 32, 32
+    crow, col = synthetic.stencil27_periodic(nx, ny, nz, torch.int32, device=dev)
+    n = nx * ny * nz
+    g = torch.Generator(device=dev).manual_seed(3)
+    A = torch.sparse_csr_tensor(crow, col, torch.randn(col.numel(), device=dev, generator=g).to(dt), (n, n)).requires_grad_(True)
+    B = torch.randn(n, p, device=dev, generator=g).to(dt).requires_grad_(True)
+    Gd = torch.randn(n, p, device=dev, generator=g).to(dt)
+    before = len(lt.TUNE_LOG)
+
+    def step():
+        C = sparse_mm(A, B)
+        gA, gB = torch.autograd.grad(C, (A, B), Gd)
+        return C.detach(), gA.values().detach(), gB.detach()
+
+    first = step()
+    assert len(lt.TUNE_LOG) == before                         # first sight: the ranked choice
+    later = [step() for _ in range(3)]
+    log = lt.TUNE_LOG[before:]
+    assert len(log) == 3 and sorted(e[1] for e in log) == [0, 1, 2]     # forward, SDDMM, transposed product: once each
+    for kind, mode, vtype, width, tried, chosen in log:
+        assert width == p and len(tried) >= 2 and chosen in [c for c, _ in tried]
+        assert min(ms for _, ms in tried) == dict(tried)[chosen]
+    for out in later:
+        for a, b in zip(first, out):
+            assert torch.equal(a, b)
+    plan = _pattern.from_csr(A.detach())
+    got = _ops._lattice_cfg(plan, 0, B.detach())
+    assert got is not None and got[1].tuned

@@ -447,6 +447,16 @@ def lattice_config(lp, mode: int, dtype: torch.dtype, p: int):
     return _lattice.config_for(lp, mode, _VTYPE[dtype], p, es, lattice_lds_bytes, be=sys.modules[__name__])
 
 
+def lattice_tune(lp, mode: int, dtype: torch.dtype, p: int, time_ms):
+    """Measured choice among the best-ranked launch configurations of `lp` for these operands (`_lattice.tune_config`)."""
+    import sys
+
+    from . import _lattice
+
+    es = {torch.float32: 4, torch.bfloat16: 2, torch.float64: 8}[dtype]
+    return _lattice.tune_config(lp, mode, _VTYPE[dtype], p, es, lattice_lds_bytes, sys.modules[__name__], time_ms)
+
+
 def lattice_rows(crow, col, dims, status, slot, thash=None, trep=None, remap=None, ctable=None, lens=None, rcls=None, disp=None):
     """Row analysis kernels of csrc/lattice_plan.hip: pass 1 (hash -> slot table) when `ctable` is None, pass 2 (class
     assignment + exact check) otherwise; the rows of the transposed pattern when `disp` is given."""

@@ -55,7 +55,7 @@ class LatticePlan:
 class LatticeConfig:
     """One launch configuration of a plan: tile, segments, workgroup size and the record tables built for them."""
 
-    __slots__ = ("ty", "tz", "nseg", "threads", "rec", "lds_bytes", "struct", "struct_addr", "wlist", "nloc", "ring", "cpl")
+    __slots__ = ("ty", "tz", "nseg", "threads", "rec", "lds_bytes", "struct", "struct_addr", "wlist", "nloc", "ring", "cpl", "uses", "tuned")
 
 
 def _frequent_offsets(cols64: torch.Tensor, rows64: torch.Tensor, nrows: int) -> Optional[list]:
@@ -577,33 +577,94 @@ class _LatticePlanStruct(ctypes.Structure):
                                                "ty", "tz", "nseg", "threads", "ring", "chunks_per_lane")] + [(k, ctypes.c_void_p) for k in ("rec", "lens", "rcls", "rstart", "wlist")]
 
 
+def build_config(plan: LatticePlan, cand, mode: int, vtype: int, p: int, elem_bytes: int, lds_bytes_fn, be=None) -> Optional[LatticeConfig]:
+    """The launch configuration `cand` = (ty, tz, nseg, threads, ring, chunks per lane) with its record tables on the device, or
+    None when the workgroups of this tiling meet more classes than fit."""
+    ty, tz, nseg, threads, ring, cpl = cand
+    wlist = workgroup_classes_hip(plan, ty, tz, nseg, be) if be is not None else workgroup_classes(plan, ty, tz, nseg)
+    nloc = wlist.size(1)
+    lds = lds_bytes_fn(mode, vtype, p, ty, tz, plan.ry, plan.rz, nloc, plan.recw, threads, ring, cpl)
+    if lds <= 0:
+        return None
+    slot = (plan.recw * (max(4, elem_bytes if elem_bytes == 8 else 4) if mode == _MODE_SDDMM else elem_bytes) + 15) // 16 * 16
+    if slot % 64 == 0:
+        slot += 16                 # as lat_layout (csrc/lattice_impl.h): value rows must not share four banks
+    if PACKED_T and mode == _MODE_SPMMT and (p * elem_bytes) % 128 == 0:
+        slot = p * elem_bytes      # packed records: the value ring has the pitch of the dense ring
+    cfg = LatticeConfig()
+    cfg.ty, cfg.tz, cfg.nseg, cfg.threads, cfg.lds_bytes = ty, tz, nseg, threads, lds
+    cfg.wlist, cfg.nloc, cfg.ring, cfg.cpl = wlist, nloc, ring, cpl
+    cfg.uses, cfg.tuned = 0, False
+    cfg.rec = records(plan, ty, tz, p * elem_bytes, slot, ring, elem_bytes).to(plan.rcls.device)
+    cfg.struct = _LatticePlanStruct(plan.kind, plan.nb, plan.nx, plan.ny, plan.nz, plan.ry, plan.rz, plan.ncls, plan.recw,
+                                    nloc, plan.uniform_len, ty, tz, nseg, threads, ring, cpl, cfg.rec.data_ptr(), plan.lens.data_ptr(),
+                                    plan.rcls.data_ptr(), plan.rstart.data_ptr(), wlist.data_ptr())
+    cfg.struct_addr = ctypes.addressof(cfg.struct)
+    return cfg
+
+
 def config_for(plan: LatticePlan, mode: int, vtype: int, p: int, elem_bytes: int, lds_bytes_fn, be=None) -> Optional[LatticeConfig]:
-    """Cached launch configuration (tile choice + record tables on the device + ctypes image) of a plan."""
+    """Cached launch configuration (tile choice + record tables on the device + ctypes image) of a plan: the best-ranked
+    candidate that fits (a pattern that keeps coming back gets the measured choice, `tune_config`)."""
     key = (mode, vtype, p)
     cfg = plan._cfg.get(key)
     if cfg is None and key not in plan._cfg:
-        for ty, tz, nseg, threads, ring, cpl in rank_configs(plan, mode, vtype, p, elem_bytes, lds_bytes_fn):
-            wlist = workgroup_classes_hip(plan, ty, tz, nseg, be) if be is not None else workgroup_classes(plan, ty, tz, nseg)
-            nloc = wlist.size(1)
-            lds = lds_bytes_fn(mode, vtype, p, ty, tz, plan.ry, plan.rz, nloc, plan.recw, threads, ring, cpl)
-            if lds <= 0:
-                continue      # the workgroups of this tiling meet more classes than the ranking assumed
-            slot = (plan.recw * (max(4, elem_bytes if elem_bytes == 8 else 4) if mode == _MODE_SDDMM else elem_bytes) + 15) // 16 * 16
-            if slot % 64 == 0:
-                slot += 16                 # as lat_layout (csrc/lattice_impl.h): value rows must not share four banks
-            if PACKED_T and mode == _MODE_SPMMT and (p * elem_bytes) % 128 == 0:
-                slot = p * elem_bytes      # packed records: the value ring has the pitch of the dense ring
-            cfg = LatticeConfig()
-            cfg.ty, cfg.tz, cfg.nseg, cfg.threads, cfg.lds_bytes = ty, tz, nseg, threads, lds
-            cfg.wlist, cfg.nloc, cfg.ring, cfg.cpl = wlist, nloc, ring, cpl
-            cfg.rec = records(plan, ty, tz, p * elem_bytes, slot, ring, elem_bytes).to(plan.rcls.device)
-            cfg.struct = _LatticePlanStruct(plan.kind, plan.nb, plan.nx, plan.ny, plan.nz, plan.ry, plan.rz, plan.ncls, plan.recw,
-                                            nloc, plan.uniform_len, ty, tz, nseg, threads, ring, cpl, cfg.rec.data_ptr(), plan.lens.data_ptr(),
-                                            plan.rcls.data_ptr(), plan.rstart.data_ptr(), wlist.data_ptr())
-            cfg.struct_addr = ctypes.addressof(cfg.struct)
-            break
+        for cand in rank_configs(plan, mode, vtype, p, elem_bytes, lds_bytes_fn):
+            cfg = build_config(plan, cand, mode, vtype, p, elem_bytes, lds_bytes_fn, be)
+            if cfg is not None:
+                break
         plan._cfg[key] = cfg
     return cfg
+
+
+# The ranking is a model fitted at C2 (fp32, 32 columns); other operands (C5: bf16, 16 columns) have their best tile elsewhere
+# (measured: forward 8x16 / 256 threads 300 us against the model's 16x16 / 512 at 338 us; SDDMM 16x32 / 1024 threads 285 us
+# against 330 us).  A pattern that keeps coming back is therefore MEASURED once: a few launches of the best-ranked candidates
+# of every workgroup size on the caller's operands.  Every configuration sums a row in the same order, so the choice does not
+# change a result bit.
+TUNE = os.environ.get("TSGU_LATTICE_TUNE", "1") == "1"
+TUNE_AFTER_USES = int(os.environ.get("TSGU_LATTICE_TUNE_AFTER", "3"))
+TUNE_PER_SIZE = 3
+TUNE_LOG = []        # (plan kind, mode, vtype, p, [(candidate, ms)], chosen) of every measured choice (diagnostics, tests)
+
+
+def tune_candidates(plan: LatticePlan, mode: int, vtype: int, p: int, elem_bytes: int, lds_bytes_fn):
+    """The TUNE_PER_SIZE best-ranked candidates of every workgroup size, best-ranked first."""
+    if _CFG_ENV:
+        return []
+    ranked = rank_configs(plan, mode, vtype, p, elem_bytes, lds_bytes_fn, keep=1 << 30)
+    taken, per = [], {}
+    for c in ranked:
+        if per.get(c[3], 0) < TUNE_PER_SIZE:
+            per[c[3]] = per.get(c[3], 0) + 1
+            taken.append(c)
+    return taken
+
+
+def tune_config(plan: LatticePlan, mode: int, vtype: int, p: int, elem_bytes: int, lds_bytes_fn, be, time_ms) -> Optional[LatticeConfig]:
+    """Replace the cached configuration of (mode, vtype, p) by the fastest of `tune_candidates`; `time_ms(cfg)` launches the
+    kernel on the caller's operands and returns milliseconds per launch.  Returns the chosen configuration."""
+    key = (mode, vtype, p)
+    cur = plan._cfg.get(key)
+    if cur is None:
+        return None
+    cur.tuned = True
+    tried = []
+    best, best_ms = cur, None
+    for cand in tune_candidates(plan, mode, vtype, p, elem_bytes, lds_bytes_fn):
+        same = cand == (cur.ty, cur.tz, cur.nseg, cur.threads, cur.ring, cur.cpl)
+        cfg = cur if same else build_config(plan, cand, mode, vtype, p, elem_bytes, lds_bytes_fn, be)
+        if cfg is None:
+            continue
+        ms = time_ms(cfg)
+        tried.append((cand, ms))
+        if best_ms is None or ms < best_ms:
+            best, best_ms = cfg, ms
+    best.tuned = True
+    best.uses = cur.uses
+    plan._cfg[key] = best
+    TUNE_LOG.append((plan.kind, mode, vtype, p, tried, (best.ty, best.tz, best.nseg, best.threads, best.ring, best.cpl)))
+    return best
 
 
 # ---- plane-march kernels (csrc/march_impl.h): full periodic box stencils --------------------------------------------
