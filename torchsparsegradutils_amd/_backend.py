@@ -208,6 +208,8 @@ def is_transposed_view(t: torch.Tensor) -> bool:
 
 def rowmajor(t: torch.Tensor) -> torch.Tensor:
     """Return `t` (2-D or 3-D) with unit stride in the last dim and a sane leading dimension."""
+    if t.is_contiguous():
+        return t
     if t.stride(-1) != 1 and t.size(-1) != 1:
         return t.contiguous()
     if t.dim() >= 2 and t.size(-2) > 1 and t.stride(-2) < t.size(-1):

@@ -61,7 +61,23 @@ def _lattice_plan(plan: RowGather, transposed: bool = False):
 def _lattice_cfg(plan: RowGather, mode: int, dense: torch.Tensor, *others: torch.Tensor):
     """(LatticePlan, LatticeConfig) for these operands or None; `plan` is always the pattern the values are stored in (the
     transposed product walks its transposed pattern through the plan's own arrays)."""
-    if not ENABLE_LATTICE or dense.dim() != 2 or not _be._tiled_ok(*(_be.rowmajor(t) for t in (dense,) + others)):
+    if not ENABLE_LATTICE:
+        return None
+    # steady state: contiguous 16-byte aligned operands of a pattern whose configuration is final — one dictionary lookup
+    # (the checks below cost the host more than the launch itself, and a step asks three times)
+    plain = dense.dim() == 2 and dense.is_contiguous() and dense.data_ptr() % 16 == 0
+    for t in others:
+        plain = plain and t.dim() == 2 and t.is_contiguous() and t.data_ptr() % 16 == 0
+    memo = key = None
+    if plain and plan.batch is None and plan.perm is None:
+        memo = plan.core.own.get("lattice_memo")
+        if memo is None:
+            memo = plan.core.own["lattice_memo"] = {}
+        key = (mode, dense.dtype, dense.size(-1), ENABLE_LATTICE, _lt.ENABLE_MARCH)
+        hit = memo.get(key)
+        if hit is not None:
+            return hit
+    if dense.dim() != 2 or not _be._tiled_ok(*(_be.rowmajor(t) for t in (dense,) + others)):
         return None
     if dense.dtype not in LATTICE_DTYPES:
         return None
@@ -75,6 +91,8 @@ def _lattice_cfg(plan: RowGather, mode: int, dense: torch.Tensor, *others: torch
     # full periodic box stencils: the plane-march kernels (all three products from the stored-order plan alone)
     cfg = _be.march_config(fwd, mode, dense.dtype, dense.size(-1))
     if cfg is not None:
+        if memo is not None:
+            memo[key] = (fwd, cfg)
         return fwd, cfg
     lp = _lattice_plan(plan, transposed=True) if mode == _be.LAT_SPMMT else fwd
     if lp is None:
@@ -86,6 +104,8 @@ def _lattice_cfg(plan: RowGather, mode: int, dense: torch.Tensor, *others: torch
         cfg.uses += 1
         if cfg.uses >= _lt.TUNE_AFTER_USES and not torch.cuda.is_current_stream_capturing():
             cfg = _measured_cfg(lp, mode, dense, cfg)
+    if memo is not None and (cfg.tuned or not _lt.TUNE):
+        memo[key] = (lp, cfg)
     return lp, cfg
 
 
