@@ -576,3 +576,34 @@ def test_measured_configuration_choice_keeps_the_bits(dt, p, monkeypatch):
     plan = _pattern.from_csr(A.detach())
     got = _ops._lattice_cfg(plan, 0, B.detach())
     assert got is not None and got[1].tuned
+
+
+def test_bf16_products_are_within_one_ulp_of_the_exact_result():
+    """The bf16 sweeps take two entries per v_dot2_f32_bf16 (fp32 accumulation of exact bf16 products): forward and transposed
+    product against the fp64 product of the same bf16 inputs — every element within one bf16 ulp of its exact value (half an
+    ulp is the final rounding), and no worse than the plan-free kernels' one-entry-at-a-time fp32 FMAs."""
+    from torchsparsegradutils_amd import _backend as be
+    from torchsparsegradutils_amd import _ops, _pattern
+    from torchsparsegradutils_amd.utils import synthetic
+
+    dev = torch.device("cuda:0")
+    nx, ny, nz, p = 10, 32, 32, 16
+    crow, col = synthetic.stencil27_periodic(nx, ny, nz, torch.int32, device=dev)
+    n = nx * ny * nz
+    g = torch.Generator(device=dev).manual_seed(21)
+    val = torch.randn(col.numel(), device=dev, generator=g).to(torch.bfloat16)
+    B = torch.randn(n, p, device=dev, generator=g).to(torch.bfloat16)
+    plan = _pattern.RowGather(crow, col, n, n)
+    A64 = torch.sparse_csr_tensor(crow, col, val.double(), (n, n))
+    exact = {"fwd": A64 @ B.double(), "t": A64.t().to_sparse_csr() @ B.double()}
+    got = {"fwd": _ops.spmm(plan, val, B), "t": _ops.spmm_t(plan, val, B)}
+    free = {"fwd": be.csr_spmm(crow, col, val, B, n, n)}
+    assert _ops._lattice_cfg(plan, be.LAT_SPMM, B) is not None and _ops._lattice_cfg(plan, be.LAT_SPMMT, B) is not None
+
+    def ulps(x, ref):
+        ulp = torch.exp2(torch.floor(torch.log2(ref.abs().clamp_min(1e-30))) - 7)     # bf16: 8 significant bits
+        return float(((x.double() - ref).abs() / ulp).max())
+
+    for k in ("fwd", "t"):
+        assert ulps(got[k], exact[k]) <= 1.0, (k, ulps(got[k], exact[k]))
+    assert ulps(got["fwd"], exact["fwd"]) <= ulps(free["fwd"], exact["fwd"]) + 0.05

@@ -45,6 +45,9 @@ constexpr int kLatND = 3;    // ring DMA pieces per thread and plane   (halo row
 constexpr int lat_nvd(int mode, int vbytes) { return vbytes == 4 ? 2 : (vbytes == 8 || mode == 2 ? 4 : 3); }
 constexpr int kLatNP = 1;    // row passes per plane                   (tile rows <= kLatNP * NT / CL)
 constexpr int kLatMaxLds = 160 * 1024;
+#ifndef TSGU_LAT_DOT2
+#define TSGU_LAT_DOT2 1     // 0: bf16 products by widening + fp32 FMAs (one entry at a time), the round-3 form before the pairs
+#endif
 #ifndef TSGU_LAT_PROBE
 #define TSGU_LAT_PROBE 0    // 1 / 2: timing probes of tools/build_variant_one.sh (never in the product build)
 #endif
@@ -132,6 +135,7 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
     // (measured: slower — with a 128-byte value pitch the broadcast value reads of the eight rows of a wave fall on ONE bank,
     // C2 transposed product 107 -> 136 us; the 112-byte pitch of the two-word form spreads them.  Kept switched off.)
     constexpr bool kPacked = false && MODE == kLatSpmmT && RB % 128 == 0;
+    constexpr bool kDot2 = TSGU_LAT_DOT2 && kVB == 2 && MODE != kLatSddmm;   // bf16 products: two entries per v_dot2_f32_bf16
     constexpr int kNVD = lat_nvd(MODE, kVB);
     constexpr int kRecB = (MODE == kLatSpmmT && !kPacked) ? 8 : 4;   // bytes of a record
     constexpr int kUnroll = NCH > 0 ? NCH : 2;
@@ -617,6 +621,39 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
                             for (int v = 0; v < VEC; ++v) acc[MODE == kLatSddmm ? 0 : q][cp][v] = fma(a, f[v], acc[MODE == kLatSddmm ? 0 : q][cp][v]);
                         }
                     };
+                    // bf16 products: two entries per instruction.  acc[col] += a0·b0[col] + a1·b1[col] is one v_dot2_f32_bf16 on
+                    // the packed pair (a0, a1) and the pair (b0[col], b1[col]) that one v_perm_b32 gathers from the two raw rows —
+                    // 2 instructions per column and entry pair, against 2 widenings + 1 packed FMA per column pair and entry
+                    // (the widening was a third of the kernel's VALU work).  Entries pair up by their position in the row
+                    // (2k, 2k+1): the same pairs in every launch configuration.
+                    auto axpy2 = [&](uint32_t ap, const uint4 (&b0)[CPL], const uint4 (&b1)[CPL]) {
+                        if constexpr (kDot2) {
+                            typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+                            const bf2 av = __builtin_bit_cast(bf2, ap);
+#pragma unroll
+                            for (int cp = 0; cp < CPL; ++cp) {
+                                const uint32_t x[4] = {b0[cp].x, b0[cp].y, b0[cp].z, b0[cp].w};
+                                const uint32_t y[4] = {b1[cp].x, b1[cp].y, b1[cp].z, b1[cp].w};
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) {
+                                    const uint32_t lo = __builtin_amdgcn_perm(y[i], x[i], 0x05040100u);   // (b0[2i],   b1[2i])
+                                    const uint32_t hi = __builtin_amdgcn_perm(y[i], x[i], 0x07060302u);   // (b0[2i+1], b1[2i+1])
+                                    acc[q][cp][2 * i] = __builtin_amdgcn_fdot2_f32_bf16(av, __builtin_bit_cast(bf2, lo), acc[q][cp][2 * i], false);
+                                    acc[q][cp][2 * i + 1] = __builtin_amdgcn_fdot2_f32_bf16(av, __builtin_bit_cast(bf2, hi), acc[q][cp][2 * i + 1], false);
+                                }
+                            }
+                        }
+                    };
+                    // four entries: a[] holds four values, or — kDot2 — the two raw bf16 pairs as bit patterns in a[0], a[1]
+                    auto axpy4 = [&](const A (&a)[4], const uint4 (&b)[4][CPL]) {
+                        if constexpr (kDot2) {
+                            axpy2(__float_as_uint(a[0]), b[0], b[1]);
+                            axpy2(__float_as_uint(a[1]), b[2], b[3]);
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) axpy(a[j], b[j]);
+                        }
+                    };
                     const int recw = NCH > 0 ? 4 * NCH : P.recw;
                     if constexpr (MODE == kLatSpmm) {
                         char* const vs = sm + P.o_vals + vbi * vbuf + csl[q];
@@ -639,8 +676,12 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
                                 a[0] = __uint_as_float(w.x), a[1] = __uint_as_float(w.y), a[2] = __uint_as_float(w.z), a[3] = __uint_as_float(w.w);
                             } else {
                                 const uint2 w = *reinterpret_cast<const uint2*>(vs + k0 * 2);
-                                a[0] = __uint_as_float(w.x << 16), a[1] = __uint_as_float(w.x & 0xffff0000u);
-                                a[2] = __uint_as_float(w.y << 16), a[3] = __uint_as_float(w.y & 0xffff0000u);
+                                if constexpr (kDot2) {   // the packed pairs (entries k0, k0+1) and (k0+2, k0+3), untouched
+                                    a[0] = __uint_as_float(w.x), a[1] = __uint_as_float(w.y), a[2] = a[3] = 0.f;
+                                } else {
+                                    a[0] = __uint_as_float(w.x << 16), a[1] = __uint_as_float(w.x & 0xffff0000u);
+                                    a[2] = __uint_as_float(w.y << 16), a[3] = __uint_as_float(w.y & 0xffff0000u);
+                                }
                             }
                         };
                         if constexpr (NCH > 0) {
@@ -674,8 +715,7 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
                                 asm volatile("" ::: "memory");
                                 if (i + 1 < NCH) stage_b(i + 1);
                                 asm volatile("" ::: "memory");
-#pragma unroll
-                                for (int j = 0; j < 4; ++j) axpy(a[i % 3][j], b[i & 1][j]);
+                                axpy4(a[i % 3], b[i & 1]);
                             }
                         } else {
 #pragma unroll 2
@@ -687,8 +727,7 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
                                 uint4 b[4][CPL];
 #pragma unroll
                                 for (int j = 0; j < 4; ++j) load_b(rv[j], b[j]);
-#pragma unroll
-                                for (int j = 0; j < 4; ++j) axpy(a[j], b[j]);
+                                axpy4(a, b);
                             }
                         }
                         if constexpr (kCanDot) {
@@ -791,7 +830,19 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
                         auto load_val = [](const char* at) -> A {
                             if constexpr (kVB == 8) return *reinterpret_cast<const double*>(at);
                             else if constexpr (kVB == 4) return *reinterpret_cast<const float*>(at);
+                            else if constexpr (kDot2) return __uint_as_float((uint32_t)*reinterpret_cast<const unsigned short*>(at));   // raw bits
                             else return __uint_as_float((uint32_t)*reinterpret_cast<const unsigned short*>(at) << 16);
+                        };
+                        // kDot2: the raw bf16 values of four entries -> two packed pairs in p2[0], p2[1] (axpy4's form)
+                        auto pair_up = [](const A (&a)[4], A (&p2)[4]) {
+                            if constexpr (kDot2) {
+                                p2[0] = __uint_as_float(__float_as_uint(a[0]) | (__float_as_uint(a[1]) << 16));
+                                p2[1] = __uint_as_float(__float_as_uint(a[2]) | (__float_as_uint(a[3]) << 16));
+                                p2[2] = p2[3] = 0.f;
+                            } else {
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) p2[j] = a[j];
+                            }
                         };
 #pragma unroll
                         for (int cp = 0; cp < CPL; ++cp) {
@@ -839,8 +890,9 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
                                 asm volatile("" ::: "memory");
                                 if (i + 1 < NCH) stage_b(i + 1);
                                 asm volatile("" ::: "memory");
-#pragma unroll
-                                for (int j = 0; j < 4; ++j) axpy(a[i & 1][j], b[i & 1][j]);
+                                A p2[4];
+                                pair_up(a[i & 1], p2);
+                                axpy4(p2, b[i & 1]);
                             }
                         } else {
 #pragma unroll 2
@@ -864,8 +916,9 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
                                     load_b(go[j], b[j]);
                                     a[j] = load_val(vcb + vo[j]);
                                 }
-#pragma unroll
-                                for (int j = 0; j < 4; ++j) axpy(a[j], b[j]);
+                                A p2[4];
+                                pair_up(a, p2);
+                                axpy4(p2, b);
                             }
                         }
                     }
