@@ -174,6 +174,9 @@ def c5_leg(dev, world, rank, steps, warmup, barrier):
         "workload": f"C5: batched CSR SpMM, {batch} items of periodic 27-pt {nx}x{ny}x{nz} (N={n}, nnz={nnz}), {p} RHS, bf16 values / "
                     f"int32 indices, {world} rank(s) x {hi - lo} items, sharded by parallel.sharded_batched_apply",
         "algorithmic_bytes_fwd_whole_job": ab["spmm"],
+        "bytes_note": "algorithmic bytes are those of a CSR kernel (crow, col, values, B in, C out: SURVEY 8d); the plane sweeps this "
+                      "lattice pattern runs on read no column index (906 MB of the 1929 MB), so their HBM traffic is ~1.05 GB per "
+                      "forward launch (profiles/r03_pmc_c5/, 2*FETCH_SIZE + WRITE_SIZE) - GBps_whole_job above ~4 TB/s is algorithmic, not wire, rate",
         "fwd_compute_only": {"ms": round(ms_fwd, 4), "GBps_whole_job": round(ab["spmm"] / (ms_fwd * 1e-3) / 1e9, 1),
                              "frac_of_hbm_peak_per_gpu": round(ab["spmm"] / world / (ms_fwd * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
         "fwd_bwd_compute_only": {"ms": round(ms_fb, 4), "GBps_whole_job": round(ab["fwd_bwd"] / (ms_fb * 1e-3) / 1e9, 1),
