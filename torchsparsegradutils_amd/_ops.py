@@ -124,11 +124,11 @@ def _measured_cfg(lp, mode: int, dense: torch.Tensor, cfg):
         run(c)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        run(c)
-        run(c)
+        for _ in range(4):
+            run(c)
         e1.record()
         e1.synchronize()
-        return e0.elapsed_time(e1) / 2
+        return e0.elapsed_time(e1) / 4
 
     events, _be.KERNEL_EVENTS = _be.KERNEL_EVENTS, None      # (bench.py's per-kernel hook does not see the trial launches)
     try:
