@@ -248,9 +248,10 @@ int tsgu_csr_sddmm_rowpack(int vtype, int itype, int64_t n_rows, int64_t n_cols,
  *                                   dense-row offset (a multiple of 128) + 4·k' in the low 7 bits
  *   padded entries (k >= lens[c]) hold 0x7ff00: reads that far beyond the row's own position are beyond the LDS allocation and
  *   return zero on gfx950, so padded entries contribute exactly 0 and no dense row is touched that the sparse row does not reference.
- * Sums run in ascending entry order of the walked pattern (the order of the plan-free kernels).  fp32 and bf16 values
- * for kind 0 (fp32 accumulation), fp32 for kind 1, fp64 for both; p·sizeof(value)/16 in {2, 4, 8, 16} (SpMM, fp32: also 1); 16-byte
- * aligned dense rows.
+ * Sums run in ascending entry order of the walked pattern (the order of the plan-free kernels).  fp32, fp64 and bf16 values
+ * for both kinds (bf16: fp32 accumulation; the SpMM / Aᵀ·G walks add entries in pairs (2k, 2k+1) with v_dot2_f32_bf16 — exact
+ * products, one fp32 addition per pair — within one bf16 ulp of the exact result like the one-entry-at-a-time kernels, not
+ * bit-identical to them); p·sizeof(value)/16 in {2, 4, 8, 16} (SpMM, fp32: also 1); 16-byte aligned dense rows.
  */
 typedef struct tsgu_lattice_plan {
     int32_t kind;             /* 0: stored-order walk (SpMM / SDDMM); 1: transposed walk (Aᵀ·G) */
