@@ -208,14 +208,20 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
-    dev = torch.device("cuda", local_rank)
+    # test hook (tools/bench_world2_one_gpu.sh): exercise the N > 1 code path on a ONE-GPU box — every rank on cuda:0, gloo
+    # instead of RCCL (which refuses two ranks on one device).  Never set by the driver; the numbers of such a run mean nothing.
+    test_backend = os.environ.get("TSGU_BENCH_TEST_BACKEND", "")
+    dev = torch.device("cuda", 0 if test_backend else local_rank)
     torch.cuda.set_device(dev)
 
     import torch.distributed as dist
 
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+        if test_backend:
+            dist.init_process_group(test_backend)
+        else:
+            dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
 
     from torchsparsegradutils_amd import _backend as be
     from torchsparsegradutils_amd import _ops, _pattern, sparse_mm, wait_for_plans
@@ -459,7 +465,7 @@ def main():
     allgather = None
     if world > 1:
         C = step().detach()
-        out = torch.empty((world,) + tuple(C.shape), device=dev, dtype=C.dtype)
+        out = torch.empty((world * C.size(0), C.size(1)), device=dev, dtype=C.dtype)   # rank-major rows
         barrier()
         ag_ms = time_events(lambda: dist.all_gather_into_tensor(out, C), 10, dev)
         allgather = {"ms": round(ag_ms, 4), "bytes_per_rank": C.numel() * 4,

@@ -78,7 +78,10 @@ for k, d in acc.items():
         continue
     fetch = sum(d["FETCH_SIZE"]) / len(d["FETCH_SIZE"])
     write = sum(d["WRITE_SIZE"]) / len(d["WRITE_SIZE"])
-    traffic[r] = int((2 * fetch + write) * 1024)
+    t = int((2 * fetch + write) * 1024)
+    if t <= traffic.get(r, -1):
+        continue      # several instantiations share a role (bench.py's host-time leg steps a small problem with another column count): the C2 launches move the most bytes
+    traffic[r] = t
     raw[r] = {"FETCH_SIZE_KB": round(fetch, 1), "WRITE_SIZE_KB": round(write, 1), "kernel": k[:120]}
 if traffic:
     bench = {}
