@@ -1,0 +1,35 @@
+"""bench.py's N > 1 code path on a one-GPU box: two ranks share cuda:0 and talk over gloo (RCCL refuses two ranks on one
+device; `TSGU_BENCH_TEST_BACKEND` is a test hook).  Checks that both ranks get through the barriers, the max-over-ranks timing,
+the sharded C5 leg (plain and chunk-overlapped gathers) and the all-gather leg, and that rank 0 prints ONE well-formed line —
+the numbers of such a run mean nothing.  Needs an MI355X: `pytest -m gpu`."""
+
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_runs_with_two_ranks():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    env = dict(os.environ, TSGU_BENCH_TEST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29519", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 3 and j["scaling"] == "weak" and j["value"] > 0 and j["cpu_baseline"] is None
+    assert j["allgather"]["bytes_per_rank"] == 10 ** 6 * 32 * 4
+    c5 = j["c5"]
+    assert "error" not in c5, c5
+    for key in ("fwd_compute_only", "fwd_bwd_compute_only", "fwd_end_to_end_with_allgather", "fwd_end_to_end_overlapped_chunks"):
+        assert c5[key]["ms"] > 0, key
+    assert "2 rank(s) x 32 items" in c5["workload"]
