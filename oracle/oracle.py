@@ -7,8 +7,9 @@ loops of ``csr_oracle.c``, the algorithm of the reference's hot path:
 * ``sparse_mm`` forward/backward            reference sparse_matmul.py:141-234
 * ``sparse_triangular_solve`` fwd/bwd       reference sparse_solve.py:161-252, _compat.py:42-48
 * ``sparse_generic_solve`` backward rule    reference sparse_solve.py:455-519
-* ``linear_cg`` (no preconditioner/Lanczos) reference utils/linear_cg.py:213-430
-* ``bicgstab``                              reference utils/bicgstab.py:112-247
+* ``linear_cg`` (+ Jacobi, Lanczos output)   reference utils/linear_cg.py:213-430
+* ``bicgstab`` (+ diagonal preconditioner)   reference utils/bicgstab.py:112-247
+* ``minres`` (shifts, value, preconditioner) reference utils/minres.py:140-311
 
 The arithmetic itself lives in PyTorch ATen (third-party; the reference pins ``torch>=2.5``,
 pyproject.toml:23), so each kernel-level function restates the mathematical definition of the
@@ -252,15 +253,23 @@ def linear_cg(crow, col, val, rhs, tolerance, max_iter=1000, eps=1e-10, stop_upd
     return done(k_done, last_tridiag_iter)
 
 
-def bicgstab(crow, col, val, b, matvec_max=None, abstol=1e-8, reltol=1e-6):
-    """Single-vector BiCGSTAB, x0 = 0 (reference utils/bicgstab.py:126-247)."""
+def bicgstab(crow, col, val, b, matvec_max=None, abstol=1e-8, reltol=1e-6, precond_diag=None, x0=None):
+    """Single-vector BiCGSTAB (reference utils/bicgstab.py:126-247), optionally right-preconditioned by a diagonal
+    (`precond_diag`: q = M p, z = M s, :191-194, :216-219) and with an initial guess `x0` (the reference then starts from the
+    UNCORRECTED residual r0 = b and spends no matvec on it, :158-161)."""
     dt = b.dtype
     n = b.shape[0]
     mv = lambda v: csr_spmm(crow, col, val, v.reshape(-1, 1)).reshape(-1)
-    x = np.zeros(n, dtype=dt)
+    pre = (lambda v: v) if precond_diag is None else (lambda v: np.asarray(precond_diag, dtype=dt).reshape(-1) * v)
     matvec_max = 2 * n if matvec_max is None else matvec_max
-    r0 = b - mv(x)
-    n_mv = 1
+    if x0 is None:
+        x = np.zeros(n, dtype=dt)
+        r0 = b - mv(x)
+        n_mv = 1
+    else:
+        x = np.array(x0, dtype=dt)
+        r0 = b.copy()
+        n_mv = 0
     rho = alpha = omega = dt.type(1)
     rho_next = np.dot(r0, r0)
     resid = resid0 = np.abs(np.sqrt(rho_next))
@@ -274,23 +283,95 @@ def bicgstab(crow, col, val, b, matvec_max=None, abstol=1e-8, reltol=1e-6):
         beta = rho_next / rho * alpha / omega
         rho = rho_next
         p = p * beta - beta * omega * v + r
-        v = mv(p)
+        q = pre(p)
+        v = mv(q)
         n_mv += 1
         alpha = rho / np.dot(r0, v)
         s = r - alpha * v
         resid = np.linalg.norm(s)
         if resid <= thresh:
-            x = x + alpha * p
+            x = x + alpha * q
             break
         if n_mv >= matvec_max:
             break
-        t = mv(s)
+        z = pre(s)
+        t = mv(z)
         n_mv += 1
         omega = np.dot(t, s) / np.dot(t, t)
         rho_next = -omega * np.dot(r0, t)
         r = s - omega * t
-        x = x + omega * s + alpha * p
+        x = x + omega * z + alpha * q
         resid = np.linalg.norm(r)
         if resid <= thresh or n_mv >= matvec_max:
             break
     return x, n_mv
+
+
+def minres(crow, col, val, rhs, shifts=(0.0,), value=None, precond_diag=None, max_iter=1000, tolerance=1e-4, eps=1e-25):
+    """MINRES for (value·A + shift_s·I) x_s = b, all right-hand sides and shifts at once (reference utils/minres.py:140-311):
+    right-hand sides normalised (:221-233), max_iter capped at n + 1 (:236), Lanczos with an optional diagonal preconditioner
+    (:241-271), one Givens QR per shift (:273-289), solution update (:290-296), relative-update stopping test on every tenth
+    iteration, averaged over shifts and columns (:299-305).  Returns [n_shift][n][p]."""
+    dt = rhs.dtype
+    B = rhs.reshape(rhs.shape[0], -1).astype(dt)
+    n, p = B.shape
+    mm = lambda V: csr_spmm(crow, col, val, np.ascontiguousarray(V))
+    apply = (lambda V: mm(V)) if value is None else (lambda V: mm(V) * dt.type(value))
+    pre = (lambda V: V.copy()) if precond_diag is None else (lambda V: V * np.asarray(precond_diag, dtype=dt).reshape(-1, 1))
+    sh = np.asarray(shifts, dtype=dt).reshape(-1, 1, 1)
+    S = sh.shape[0]
+    nrm = np.linalg.norm(B, axis=0, keepdims=True)
+    zero = nrm < 1e-10
+    nrm = np.where(zero, dt.type(1), nrm)
+    B = B / nrm
+    max_iter = min(max_iter, n + 1)
+    sol = np.zeros((S, n, p), dtype=dt)
+    z_pp = np.zeros_like(B)
+    z_p = B.copy()
+    q_p = pre(z_p)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        beta_p = np.sqrt((z_p * q_p).sum(axis=0, keepdims=True))
+        z_p = z_p / beta_p
+        q_p = q_p / beta_p
+        c_pp = np.ones((S, 1, p), dtype=dt)
+        s_pp = np.zeros_like(c_pp)
+        c_p = np.ones_like(c_pp)
+        s_p = np.zeros_like(c_pp)
+        w_pp = np.zeros_like(sol)
+        w_p = np.zeros_like(sol)
+        scale_p = np.repeat(beta_p[None], S, axis=0)
+        for i in range(max_iter + 2):
+            prod = apply(q_p)
+            alpha = (prod * q_p).sum(axis=0, keepdims=True)
+            z_c = prod - alpha * z_p - beta_p * z_pp
+            q_c = pre(z_c)
+            beta_c = np.maximum(np.sqrt((z_c * q_c).sum(axis=0, keepdims=True)), dt.type(eps))
+            z_c = z_c / beta_c
+            q_c = q_c / beta_c
+            subsub = s_pp * beta_p
+            sub = c_pp * beta_p
+            alpha_s = alpha + sh
+            diag = alpha_s * c_p - s_p * sub
+            sub = sub * c_p + s_p * alpha_s
+            radius = np.sqrt(diag * diag + beta_c * beta_c)
+            c_c = diag / radius
+            s_c = beta_c / radius
+            diag = diag * c_c + s_c * beta_c
+            scale_c = -(scale_p * s_c)
+            scale_p = scale_p * c_c
+            w_c = (q_p - sub * w_p - subsub * w_pp) / diag
+            update = w_c * scale_p
+            sol = sol + update
+            if (i + 1) % 10 == 0:
+                ratio = np.linalg.norm(update, axis=-2) / np.linalg.norm(sol, axis=-2)
+                if ratio.mean() < tolerance:
+                    break
+            z_pp, z_p = z_p, z_c
+            q_p = q_c
+            beta_p = beta_c
+            c_pp, c_p = c_p, c_c
+            s_pp, s_p = s_p, s_c
+            w_pp, w_p = w_p, w_c
+            scale_p = scale_c
+    sol = np.where(zero[None], dt.type(0), sol)
+    return sol * nrm[None]

@@ -186,3 +186,58 @@ def test_c5_batched_bf16_inputs():
         assert G.rel_err(C, z["C_f32"][k]) < 3e-6
         assert G.rel_err(gA, z["gradA_f32"][k]) < 3e-6
         assert G.rel_err(gB, z["gradB_f32"][k]) < 3e-6
+
+
+@pytest.mark.parametrize("vn", ["f32", "f64"])
+def test_preconditioned_bicgstab_and_minres_oracles(vn):
+    """The oracle's preconditioned BiCGSTAB (matvec budgets, initial guess) and its MINRES (preconditioner, three shifts, `value`,
+    a zero column, an iteration cap that is not a multiple of ten) against iterates of the real reference
+    (tests/golden/precond_solvers.npz, make_golden_r3.py).  Tolerances as in tests/test_gpu_precond_solvers.py."""
+    z = G.load("precond_solvers.npz")
+    dt = np.float32 if vn == "f32" else np.float64
+    tol = 5e-4 if vn == "f32" else 1e-10
+    A = (z[vn + "_bi_crow"], z[vn + "_bi_col"], z[vn + "_bi_val"].astype(dt))
+    B, dinv = z[vn + "_bi_B"].astype(dt), z[vn + "_bi_dinv"].astype(dt)
+    for tag, budget in (("_bi_call_mv6", 6), ("_bi_call_mv13", 13), ("_bi_tensor_mv9", 9)):
+        X = np.stack([oracle.bicgstab(*A, B[:, j].copy(), matvec_max=budget, abstol=0.0, reltol=0.0, precond_diag=dinv)[0]
+                      for j in range(B.shape[1])], axis=1)
+        assert G.rel_err(X, z[vn + tag]) < tol, (tag, G.rel_err(X, z[vn + tag]))
+    x0 = z[vn + "_bi_x0"].astype(dt)
+    X = np.stack([oracle.bicgstab(*A, B[:, j].copy(), matvec_max=8, abstol=0.0, reltol=0.0, precond_diag=dinv, x0=x0[:, j])[0]
+                  for j in range(B.shape[1])], axis=1)
+    assert G.rel_err(X, z[vn + "_bi_guess_mv8"]) < tol
+
+    S = (z[vn + "_mr_crow"], z[vn + "_mr_col"], z[vn + "_mr_val"].astype(dt))
+    Bm, minv = z[vn + "_mr_B"].astype(dt), z[vn + "_mr_minv"].astype(dt)
+    sh = (0.0, 0.4, -0.9)
+    mtol = 5e-5 if vn == "f32" else 1e-10
+    fx = dict(max_iter=10, tolerance=1e-30)
+    got = {
+        "_mr_pre": oracle.minres(*S, Bm, precond_diag=minv, **fx)[0],
+        "_mr_pre_sh3": oracle.minres(*S, Bm, shifts=sh, precond_diag=minv, **fx),
+        "_mr_pre_sh3_val": oracle.minres(*S, Bm, shifts=sh, value=0.7, precond_diag=minv, **fx),
+        "_mr_sh3_val_17": oracle.minres(*S, Bm, shifts=sh, value=0.7, max_iter=17, tolerance=1e-30),
+        "_mr_pre_vec": oracle.minres(*S, Bm[:, :1], shifts=sh, precond_diag=minv, **fx)[:, :, 0],
+    }
+    for key, x in got.items():
+        ref = z[vn + key]
+        assert x.shape == ref.shape, (key, x.shape, ref.shape)
+        assert G.rel_err(x, ref) < (10 * mtol if key.endswith("_17") and vn == "f32" else mtol), (key, G.rel_err(x, ref))
+    assert np.abs(got["_mr_pre_sh3"][:, :, 1]).max() == 0.0
+    # the reference's own stopping rule: same iteration count → same iterate up to rounding amplified by the solve
+    conv = oracle.minres(*S, Bm, shifts=sh, precond_diag=minv, max_iter=400, tolerance=float(z[vn + "_mr_tol"]))
+    assert G.rel_err(conv[:, :, [0, 2]], z[vn + "_mr_pre_conv"][:, :, [0, 2]]) < (2e-2 if vn == "f32" else 1e-6)
+
+
+@pytest.mark.parametrize("vn", ["f32", "f64"])
+def test_preconditioned_cg_oracle(vn):
+    """The oracle's Jacobi-preconditioned linear_cg against iterates of the real reference (tests/golden/pcg.npz): 5 and 15
+    iterations with tolerance 0, a zero right-hand side column."""
+    z = G.load("pcg.npz")
+    dt = np.float32 if vn == "f32" else np.float64
+    tol = 1e-4 if vn == "f32" else 1e-10
+    for it in (5, 15):
+        x = oracle.linear_cg(z["crow"], z["col"], z["val"].astype(dt), z["rhs"].astype(dt), 0, max_iter=it, max_tridiag_iter=it,
+                             precond_diag=z["dinv"].astype(dt))[0]
+        assert G.rel_err(x, z[f"{vn}_it{it}"]) < tol, (it, G.rel_err(x, z[f"{vn}_it{it}"]))
+        assert np.abs(x[:, 3]).max() == 0.0
