@@ -344,3 +344,37 @@ def test_march_config_choice_is_within_limits():
             assert cfg.struct.ntap == 9 and cfg.struct.ident == cfg.tables.ident
         assert lt.march_config_for(plan, mode, 0, 8, be.march_lds_bytes) is None       # 8 columns: general sweep
         assert lt.march_config_for(plan, mode, 1, 32, be.march_lds_bytes) is None      # bf16: general sweep
+
+
+def test_measured_choice_takes_the_fastest_candidate_and_is_final():
+    """`tune_config` with a stand-in clock: the candidates are the best-ranked ones of every workgroup size, the configuration
+    the clock likes best replaces the ranked one, is marked final and keeps the record tables of its own tiling (CPU: the
+    tables come from the host builders, as for every other test of this file)."""
+    from torchsparsegradutils_amd import _backend as be
+
+    crow, col = synthetic.stencil27_periodic(8, 16, 32)
+    n = 8 * 16 * 32
+    plan = lt.build_lattice_plan(pt.RowGather(crow, col, n, n))
+    first = lt.config_for(plan, 0, 2, 16, 2, be.lattice_lds_bytes)
+    assert first is not None and not first.tuned
+    cands = lt.tune_candidates(plan, 0, 2, 16, 2, be.lattice_lds_bytes)
+    sizes = {}
+    for c in cands:
+        sizes[c[3]] = sizes.get(c[3], 0) + 1
+    assert cands[0] == (first.ty, first.tz, first.nseg, first.threads, first.ring, first.cpl)
+    assert len(sizes) >= 2 and max(sizes.values()) <= lt.TUNE_PER_SIZE
+    want = cands[-1]
+    seen = []
+
+    def clock(cfg):
+        key = (cfg.ty, cfg.tz, cfg.nseg, cfg.threads, cfg.ring, cfg.cpl)
+        seen.append(key)
+        return 1.0 if key == want else 2.0 + len(seen)
+
+    before = len(lt.TUNE_LOG)
+    best = lt.tune_config(plan, 0, 2, 16, 2, be.lattice_lds_bytes, None, clock)
+    assert (best.ty, best.tz, best.nseg, best.threads, best.ring, best.cpl) == want and best.tuned
+    assert lt.config_for(plan, 0, 2, 16, 2, be.lattice_lds_bytes) is best
+    assert len(lt.TUNE_LOG) == before + 1 and lt.TUNE_LOG[-1][5] == want and set(seen) <= set(cands)
+    # the tables of the chosen tiling lead to the stored columns like any other configuration's
+    assert best.rec.shape[0] > 0 and best.wlist.size(1) == best.nloc
