@@ -103,7 +103,10 @@ def _lattice_cfg(plan: RowGather, mode: int, dense: torch.Tensor, *others: torch
     if _lt.TUNE and not cfg.tuned:
         cfg.uses += 1
         if cfg.uses >= _lt.TUNE_AFTER_USES and not torch.cuda.is_current_stream_capturing():
-            cfg = _measured_cfg(lp, mode, dense, cfg)
+            try:
+                cfg = _measured_cfg(lp, mode, dense, cfg)
+            except torch.cuda.OutOfMemoryError:
+                cfg.tuned = True      # no room for the trial operands: the ranked configuration stays
     if memo is not None and (cfg.tuned or not _lt.TUNE):
         memo[key] = (lp, cfg)
     return lp, cfg
