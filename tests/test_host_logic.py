@@ -185,3 +185,44 @@ def test_product_never_imports_the_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f
                 assert "liboracle" not in src, f
+
+
+def test_ctypes_signatures_agree_with_the_header_prototypes():
+    """Every prototype of include/tsgu_hip.h against `_backend.SIGNATURES`: the same number of parameters, and for each one the
+    same class (pointer / 64-bit integer / int / double) — a mismatch would only show as stack garbage on the GPU box."""
+    import ctypes as C
+
+    from torchsparsegradutils_amd import _backend
+
+    header = open(os.path.join(ROOT, "include", "tsgu_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", " ", header, flags=re.S)
+    protos = re.findall(r"\b(?:int|int64_t|const char\s*\*|size_t)\s+(tsgu_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", header, flags=re.S)
+    assert len(protos) >= 40
+
+    def klass_of_decl(decl):
+        decl = " ".join(decl.split())
+        if decl == "void":
+            return None
+        if "*" in decl:
+            return "ptr"
+        if re.search(r"\bint64_t\b", decl):
+            return "i64"
+        if re.search(r"\bdouble\b", decl):
+            return "dbl"
+        if re.search(r"\b(int|tsgu_vtype|tsgu_itype)\b", decl):
+            return "int"
+        raise AssertionError(f"unclassified parameter {decl!r}")
+
+    def klass_of_ctype(t):
+        if t in (C.c_void_p, C.c_char_p) or hasattr(t, "_type_") and not isinstance(t._type_, str):
+            return "ptr"
+        return {C.c_int64: "i64", C.c_int: "int", C.c_double: "dbl"}[t]
+
+    seen = set()
+    for name, params in protos:
+        want = [k for k in (klass_of_decl(d) for d in params.split(",")) if k is not None]
+        _, argtypes = _backend.SIGNATURES[name]
+        got = [klass_of_ctype(t) for t in argtypes]
+        assert got == want, (name, got, want)
+        seen.add(name)
+    assert seen == set(_backend.SIGNATURES)
