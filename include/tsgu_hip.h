@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define TSGU_ABI_VERSION 2
+#define TSGU_ABI_VERSION 3
 
 typedef enum {
     TSGU_OK = 0,
@@ -295,20 +295,31 @@ int tsgu_csr_sddmm_lattice(int vtype, const tsgu_lattice_plan* plan, int64_t n_r
                            const void* Cm, int64_t ldc, void* out_vals, double alpha, int64_t p, int device, void* stream);
 
 /*
- * Plane-march kernels (csrc/march_impl.h): the plane sweep for FULL periodic box stencils — every row stores all 3·ntap
- * displacements (dx, dy, dz), |dx|, |dy|, |dz| <= 1 (periodic 27-point stencils: ntap = 9), in some order.  Same call sites as
- * the lattice kernels above.  The sums are taken source plane by source plane: the dense rows of a halo plane are read from LDS
- * once per in-plane displacement and serve the three output planes x-1, x, x+1 (accumulators in registers), so a row costs
- * ntap LDS row reads instead of 3·ntap, there are no record tables, and two halo planes are resident instead of four.
- *   ident        the class whose rows store their entries in ascending (dx, dy, dz) — the CANONICAL order (interior rows)
+ * Plane-march kernels (csrc/march_impl.h): the plane sweep for BOX stencils — every stored entry couples a lattice point with a
+ * neighbour at (dx, dy, dz), |dx|, |dy|, |dz| <= 1, and every row holds exactly the displacements of ONE set `mask` (the whole
+ * 27-point box, the 7-point cross, the lower / upper triangular half of either …) that lead to an existing neighbour: all of
+ * them on a periodic lattice, the ones that stay inside on a lattice truncated at its faces (what the reference's
+ * PairwiseEncoder emits, encoders/pairwise_encoder.py:562-849), per dimension (`periodic`).  Same call sites as the lattice
+ * kernels above.  The sums are taken source plane by source plane: the dense rows of a halo plane are read from LDS once per
+ * in-plane displacement and serve the three output planes x-1, x, x+1 (accumulators in registers), so a row costs at most ntap
+ * LDS row reads instead of 3·ntap, there are no record tables, and two halo planes are resident instead of four.
+ *   mask         bit (dx+1)·ntap + tap: the displacement occurs in the pattern (27 bits set: the kernels without per-displacement
+ *                tests; else products of absent displacements are skipped by wave-uniform branches)
+ *   periodic     bit 0 / 1 / 2: the lattice wraps in x / y / z.  In a truncated dimension the halo rows beyond a face are zero
+ *                in LDS and halo planes beyond an x face are skipped: no row touches a dense row it does not reference
+ *   ident        the class whose rows store ALL displacements of `mask` in ascending (dx, dy, dz) — the CANONICAL order (interior rows)
  *   tap_dy/dz    the in-plane displacements in that order
- *   kidx         [ncls][32] uint8: stored position of canonical slot (dx+1)·ntap + tap in a row of the class (a permutation)
+ *   kidx         [ncls][32] uint8: stored position of canonical slot (dx+1)·ntap + tap in a row of the class, 0xff when the row
+ *                has no such entry (a face of a truncated lattice; a displacement outside `mask`); byte 31: entries of the row
  *   rcls         [rows (+ padding)] uint8 class of each row (the lattice plan's)
- * Values are staged in canonical order (16-byte LDS-DMA for waves of `ident` rows, 4-byte LDS-DMA gathers through kidx for the
- * others); gradA is written in A's stored order.  Sums run in canonical order: bit-identical to the plan-free kernels for
- * `ident` rows, equal to rounding for rows that wrap around a lattice face.  The transposed product needs no transposed
- * pattern and no second plan: entry (i -> j) is read from canonical slot (dx+1)·ntap + tap(dy, dz) of source row i's staged values.
- * fp32 only; p in {16, 32, 64}.
+ *   uniform_len  > 0: every row stores this many entries (periodic lattices) and row r starts at r·uniform_len; 0: rows start at
+ *   rstart       [rows + 1] int32 (A's row pointer)
+ * Values are staged in canonical order (16-byte LDS-DMA for waves of `ident` rows of a full box, 4-byte LDS-DMA gathers through
+ * kidx for the others); gradA is written in A's stored order.  Sums run in canonical order: bit-identical to the plan-free
+ * kernels for rows that store their entries in ascending (dx, dy, dz) — all rows of a truncated lattice with sorted columns —
+ * equal to rounding for rows that wrap around a face.  The transposed product needs no transposed pattern and no second plan:
+ * entry (i -> j) is read from canonical slot (dx+1)·ntap + tap(dy, dz) of source row i's staged values.
+ * fp32 only; p in {16, 32, 64} per call (wider operands: column tiles of 64 by the caller, the SDDMM with `accumulate`).
  */
 typedef struct tsgu_march_plan {
     int32_t nb, nx, ny, nz;   /* items, planes per item, lines per plane, points per line (each of nx, ny, nz >= 3) */
@@ -319,8 +330,12 @@ typedef struct tsgu_march_plan {
     int32_t ty, tz;           /* tile */
     int32_t nseg;             /* x segments per item */
     int32_t threads;          /* workgroup size: 256 or 512 */
+    uint32_t mask;            /* displacement set (27 bits) */
+    int32_t periodic;         /* bit 0: x, bit 1: y, bit 2: z */
+    int32_t uniform_len;      /* entries per row when all rows have the same number, else 0 */
     const void* kidx;
     const void* rcls;
+    const void* rstart;       /* read when uniform_len == 0 */
 } tsgu_march_plan;
 
 /* Dynamic LDS bytes of a configuration (mode: 0 SpMM, 1 SDDMM, 2 transposed SpMM) or a negative tsgu_status. */
@@ -328,9 +343,11 @@ int tsgu_march_lds_bytes(int mode, int vtype, int64_t p, int ty, int tz, int ry,
 /* C = A·B (transposed == 0) or gradB = Aᵀ·G (transposed != 0; `val` is A's value array in A's own order, `B` is G). */
 int tsgu_csr_spmm_march(int vtype, const tsgu_march_plan* plan, int transposed, int64_t n_rows, int64_t nnz, const void* val,
                         const void* B, int64_t ldb, void* C, int64_t ldc, int64_t p, int device, void* stream);
-/* out_vals[k] = alpha·<R[row k,:], Cm[col k,:]> in A's stored order. */
+/* out_vals[k] = alpha·<R[row k,:], Cm[col k,:]> in A's stored order (accumulate != 0: added to out_vals — the later column
+ * tiles of operands wider than 64 columns). */
 int tsgu_csr_sddmm_march(int vtype, const tsgu_march_plan* plan, int64_t n_rows, int64_t nnz, const void* R, int64_t ldr,
-                         const void* Cm, int64_t ldc, void* out_vals, double alpha, int64_t p, int device, void* stream);
+                         const void* Cm, int64_t ldc, void* out_vals, double alpha, int accumulate, int64_t p, int device,
+                         void* stream);
 
 /*
  * Row analysis for lattice plans (plan building, once per sparsity pattern; no reference counterpart — the reference
@@ -347,13 +364,17 @@ int tsgu_csr_sddmm_march(int vtype, const tsgu_march_plan* plan, int64_t n_rows,
  *   tsgu_lattice_row_codes  sequences of `nrows` given rows (the class representatives) -> out [nrows][32] int32.
  *   tsgu_lattice_block_classes  mask[block][4] (uint64, zeroed by the caller): the set of classes among the rows of each
  *                           workgroup of a launch configuration (the lists a tsgu_lattice_plan carries in `wlist`).
- * status (device int32[4], zeroed by the caller): [0] rows that are not lattice rows (or differ from their class, or more than
- * tsgu_lattice_slots() distinct rows), [1] max |dy|, [2] max |dz|, [3] longest row.  Rows longer than 32 entries are not-lattice.
+ * status (device int32[8], zeroed by the caller): [0] rows that are not lattice rows (or differ from their class, or store a
+ * column twice, or more than tsgu_lattice_slots() distinct rows), [1] max |dy|, [2] max |dz|, [3] longest row, [4] (pass 2 of the
+ * stored-order walk with box_mask != 0) non-zero when some row is NOT "the displacements of box_mask — 27 bits, bit
+ * (dx+1)·9 + (dy+1)·3 + dz+1 — whose neighbour exists", existence per dimension by `periodic` (bit 0 / 1 / 2: x / y / z wrap;
+ * a truncated dimension has no neighbours beyond its faces): the condition of the plane-march kernels (tsgu_march_plan).
+ * Rows longer than 32 entries are not-lattice.
  */
 int tsgu_lattice_slots(void);
 int tsgu_lattice_rows(int itype, int64_t n_rows, const void* crow, const void* col, int nb, int nx, int ny, int nz, const void* disp, int nd,
                       void* slot, void* thash, void* trep, const void* remap, const void* ctable, const void* lens, void* rcls, void* status,
-                      int device, void* stream);
+                      int box_mask, int periodic, int device, void* stream);
 int tsgu_lattice_row_codes(int itype, int64_t n_rows, const void* crow, const void* col, int nb, int nx, int ny, int nz, const void* disp,
                            int nd, const void* rows, int nrows, void* out, int device, void* stream);
 int tsgu_lattice_block_classes(int64_t n_rows, const void* rcls, int nb, int nx, int ny, int nz, int ty, int tz, int nseg, void* mask,

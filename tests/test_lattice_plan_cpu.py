@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 import torch
 
+import _lattice_ref as ref
 from torchsparsegradutils_amd import _lattice as lt
 from torchsparsegradutils_amd import _pattern as pt
 from torchsparsegradutils_amd.utils import synthetic
@@ -161,7 +162,7 @@ def test_records_lead_to_the_stored_columns(nb, nx, ny, nz, periodic, points, lo
     crow, col = _stencil(nx, ny, nz, periodic, points, lower, nb)
     n = nb * nx * ny * nz
     g = pt.RowGather(crow, col, n, n)
-    plan = lt.build_lattice_plan(g, dims=(nb, nx, ny, nz))
+    plan = ref.build_lattice_plan(g, dims=(nb, nx, ny, nz))
     assert plan is not None and plan.kind == 0
     assert (plan.nb, plan.nx, plan.ny, plan.nz) == (nb, nx, ny, nz)
     assert plan.ncls <= 27 and plan.recw % 4 == 0
@@ -173,7 +174,7 @@ def test_records_lead_to_the_stored_columns(nb, nx, ny, nz, periodic, points, lo
         assert got == col.numel()
     # transposed walk: records must also name the value's slot inside its source row
     t = g.transposed
-    tplan = lt.build_lattice_plan(t, value_crow=crow, dims=(nb, nx, ny, nz))
+    tplan = ref.build_lattice_plan(t, value_crow=crow, dims=(nb, nx, ny, nz))
     assert tplan is not None and tplan.kind == 1 and tplan.ncls <= 125
     _check_workgroup_classes(tplan, tile[0], tile[1], nseg)
     for ring_slots, row_bytes in ((4, 128), (6, 128), (4, 64)):      # 128-byte rows: packed records; 64: two words
@@ -187,19 +188,19 @@ def test_detection_of_the_benchmark_lattices():
         crow, col = synthetic.stencil27_periodic(*shape)
         n = shape[0] * shape[1] * shape[2]
         g = pt.RowGather(crow, col, n, n)
-        plan = lt.build_lattice_plan(g)
+        plan = ref.build_lattice_plan(g)
         assert plan is not None
         assert (plan.nb, plan.nx, plan.ny, plan.nz) == (1,) + shape
         assert plan.ncls == 27 and plan.recw == 28 and plan.uniform_len == 27 and (plan.ry, plan.rz) == (1, 1)
     # block-diagonal batch of periodic items: the x period is recovered from the wrap-around offsets
     crow, col = _stencil(6, 8, 12, True, 27, False, nb=3)
     g = pt.RowGather(crow, col, 3 * 576, 3 * 576)
-    plan = lt.build_lattice_plan(g)
+    plan = ref.build_lattice_plan(g)
     assert plan is not None and (plan.nb, plan.nx, plan.ny, plan.nz) == (3, 6, 8, 12)
     # Dirichlet Laplacian (rows of different lengths), 2-D 9-point
     crow, col, _ = synthetic.laplacian7(7, 9, 12)
     g = pt.RowGather(crow, col, 756, 756)
-    plan = lt.build_lattice_plan(g)
+    plan = ref.build_lattice_plan(g)
     assert plan is not None and (plan.nx, plan.ny, plan.nz) == (7, 9, 12) and plan.uniform_len == 0 and plan.recw == 8
 
 
@@ -211,19 +212,19 @@ def test_irregular_patterns_are_rejected():
     crow = torch.zeros(n + 1, dtype=torch.int32)
     crow[1:] = torch.cumsum(dense.sum(1), 0)
     g = pt.RowGather(crow, col, n, n)
-    assert lt.build_lattice_plan(g) is None
+    assert ref.build_lattice_plan(g) is None
     # a stencil with one foreign entry
     crow, col = synthetic.stencil27_periodic(8, 8, 8)
     col = col.clone()
     col[5] = (col[5] + 200) % 512
     g = pt.RowGather(crow, col, 512, 512)
-    assert lt.build_lattice_plan(g, dims=(1, 8, 8, 8)) is None
+    assert ref.build_lattice_plan(g, dims=(1, 8, 8, 8)) is None
 
 
 def test_config_choice_is_within_limits():
     crow, col = synthetic.stencil27_periodic(12, 10, 16)
     g = pt.RowGather(crow, col, 1920, 1920)
-    plan = lt.build_lattice_plan(g)
+    plan = ref.build_lattice_plan(g)
 
     def fake_lds(mode, vtype, p, ty, tz, ry, rz, ncls, recw, threads, ring, cpl=1):
         hr = (ty + 2 * ry) * (tz + 2 * rz)
@@ -250,11 +251,47 @@ def test_bf16_transposed_walk_runs_its_lds_bound_tile_with_more_threads():
 
 
 # ---- plane-march kernels (csrc/march_impl.h): the tables the host derives from a stored-order plan ------------------------
+def _box_stencil(nx, ny, nz, per=(True, True, True), points=27, part=None, nb=1):
+    """CSR pattern of a box stencil: the displacements of the 27-point box / 7-point cross (`part`: its lower / upper triangular
+    half by displacement, with or without the diagonal) that lead to an existing neighbour — wrapped in the periodic dimensions
+    `per`, dropped beyond a face of a truncated one."""
+    n1 = nx * ny * nz
+    mask = np.zeros((n1, n1), dtype=bool)
+    for x in range(nx):
+        for y in range(ny):
+            for z in range(nz):
+                i = (x * ny + y) * nz + z
+                for dx in (-1, 0, 1):
+                    for dy in (-1, 0, 1):
+                        for dz in (-1, 0, 1):
+                            if points == 7 and abs(dx) + abs(dy) + abs(dz) > 1:
+                                continue
+                            d = (dx, dy, dz)
+                            if (part == "lower" and d > (0, 0, 0)) or (part == "strict_lower" and d >= (0, 0, 0)):
+                                continue
+                            if (part == "upper" and d < (0, 0, 0)) or (part == "strict_upper" and d <= (0, 0, 0)):
+                                continue
+                            xx, yy, zz = x + dx, y + dy, z + dz
+                            if (not per[0] and not 0 <= xx < nx) or (not per[1] and not 0 <= yy < ny) or (not per[2] and not 0 <= zz < nz):
+                                continue
+                            mask[i, ((xx % nx) * ny + yy % ny) * nz + zz % nz] = True
+    if nb > 1:
+        big = np.zeros((nb * n1, nb * n1), dtype=bool)
+        for b in range(nb):
+            big[b * n1:(b + 1) * n1, b * n1:(b + 1) * n1] = mask
+        mask = big
+    return _csr_from_dense_mask(mask)
+
+
 def _emulate_march(plan, mt, crow, col, ty, tz, nseg):
     """Walk every workgroup / source plane / row / tap like the march kernels: the value the kernel takes for (target row,
     part, tap) must be the entry whose column is the row at that displacement — for the stored-order product through
-    kidx of the TARGET row, for the transposed product through kidx of the SOURCE row.  Returns the entries checked (twice)."""
+    kidx of the TARGET row, for the transposed product through kidx of the SOURCE row.  Displacements outside the pattern's
+    set are skipped (the kernels branch on the mask); a neighbour beyond a face of a truncated lattice is a halo row / plane
+    the kernels keep at zero, and the row must then have NO such entry (kidx 0xff: the staged value is 0).  Returns the
+    entries checked (twice)."""
     nb, nx, ny, nz = plan.nb, plan.nx, plan.ny, plan.nz
+    per = [bool(mt.periodic >> d & 1) for d in range(3)]
     cr, cc = crow.numpy().astype(np.int64), col.numpy().astype(np.int64)
     rcls = plan.rcls.numpy()
     kidx = mt.kidx_host.numpy()
@@ -263,8 +300,13 @@ def _emulate_march(plan, mt, crow, col, ty, tz, nseg):
     seen_t = np.zeros(cc.size, dtype=np.int32)
 
     def row(item, x, y, z):
+        """the row at (x, y, z) of the item, or None beyond a face of a truncated dimension"""
+        if (not per[0] and not 0 <= x < nx) or (not per[1] and not 0 <= y < ny) or (not per[2] and not 0 <= z < nz):
+            return None
         return ((item * nx + x % nx) * ny + y % ny) * nz + z % nz
 
+    for r in range(plan.n_rows):
+        assert kidx[rcls[r]][31] == cr[r + 1] - cr[r]
     for item in range(nb):
         for seg in range(nseg):
             xs = seg * seg_len
@@ -284,16 +326,24 @@ def _emulate_march(plan, mt, crow, col, ty, tz, nseg):
                                     xt = xs - 1 + t
                                     j = row(item, xt, y, z)
                                     for i, (dy, dz) in enumerate(mt.taps):
+                                        src = row(item, xsrc, y + dy, z + dz)
                                         # stored-order product: entry of target j towards (p - 1, dy, dz)
-                                        k = cr[j] + kidx[rcls[j]][p * 9 + i]
-                                        assert cc[k] == row(item, xsrc, y + dy, z + dz)
-                                        seen_f[k] += 1
+                                        if mt.mask >> (p * 9 + i) & 1:
+                                            k = kidx[rcls[j]][p * 9 + i]
+                                            if src is None:
+                                                assert k == 0xFF
+                                            else:
+                                                assert k != 0xFF and cc[cr[j] + k] == src
+                                                seen_f[cr[j] + k] += 1
+                                        else:
+                                            assert kidx[rcls[j]][p * 9 + i] == 0xFF
                                         # transposed product: the source through tap i is the row at own + tap; its entry towards
                                         # the target (dx = t - s = 1 - p) sits at canonical slot (dx + 1)·9 + 8 - i of ITS row
-                                        src = row(item, xsrc, y + dy, z + dz)
-                                        k = cr[src] + kidx[rcls[src]][(2 - p) * 9 + 8 - i]
-                                        assert cc[k] == j
-                                        seen_t[k] += 1
+                                        sl = (2 - p) * 9 + 8 - i
+                                        if src is not None and mt.mask >> sl & 1:
+                                            k = kidx[rcls[src]][sl]
+                                            assert k != 0xFF and cc[cr[src] + k] == j
+                                            seen_t[cr[src] + k] += 1
     assert (seen_f == 1).all() and (seen_t == 1).all()
     return int(seen_f.sum() + seen_t.sum())
 
@@ -303,28 +353,121 @@ def test_march_tables_lead_to_the_stored_entries(nb, nx, ny, nz, tile, nseg):
     crow, col = _stencil(nx, ny, nz, True, 27, False, nb)
     n = nb * nx * ny * nz
     g = pt.RowGather(crow, col, n, n)
-    plan = lt.build_lattice_plan(g, dims=(nb, nx, ny, nz))
-    assert plan is not None and plan.uniform_len == 27
+    plan = ref.build_lattice_plan(g, dims=(nb, nx, ny, nz))
+    assert plan is not None and plan.uniform_len == 27 and plan.box == (lt.MARCH_FULL, 7)
     mt = lt.march_tables(plan)
-    assert mt is not None and lt.march_tables(plan) is mt
+    assert mt is not None and lt.march_tables(plan) is mt and mt.full
     assert mt.taps == [(dy, dz) for dy in (-1, 0, 1) for dz in (-1, 0, 1)]
     k = mt.kidx_host.numpy()
-    assert k.shape == (plan.ncls, 32) and (np.sort(k[:, :27], axis=1) == np.arange(27)).all() and (k[:, 27:] == 0xFF).all()
+    assert k.shape == (plan.ncls, 32) and (np.sort(k[:, :27], axis=1) == np.arange(27)).all() and (k[:, 27:31] == 0xFF).all()
+    assert (k[:, 31] == 27).all()
     assert (k[mt.ident, :27] == np.arange(27)).all()
     assert _emulate_march(plan, mt, crow, col, tile[0], tile[1], nseg) == 2 * col.numel()
 
 
-@pytest.mark.parametrize("what", ["truncated", "seven", "lower", "two_planes"])
-def test_march_tables_only_for_full_periodic_boxes(what):
+BOX_CASES = [
+    # per, points, part, nb, (nx, ny, nz), tile, nseg
+    ((False, False, False), 27, None, 1, (5, 6, 9), (4, 8), 2),          # truncated box: what PairwiseEncoder emits
+    ((False, False, False), 27, None, 2, (3, 4, 8), (2, 8), 3),          # ... batched items, one plane per segment
+    ((True, True, True), 7, None, 1, (4, 5, 8), (4, 8), 1),              # periodic 7-point
+    ((False, False, False), 7, None, 1, (5, 4, 9), (4, 8), 2),           # truncated 7-point (the Laplacian of config C4)
+    ((False, False, False), 27, "lower", 1, (4, 5, 8), (8, 8), 2),       # triangular parts of truncated stencils
+    ((False, False, False), 27, "strict_lower", 1, (4, 5, 8), (4, 8), 1),
+    ((False, False, False), 27, "upper", 1, (4, 5, 8), (4, 8), 4),
+    ((False, False, False), 7, "strict_upper", 1, (4, 5, 8), (4, 8), 2),
+    ((True, False, False), 27, None, 1, (4, 5, 8), (4, 8), 2),           # mixed: wraps in x only
+    ((False, True, False), 7, None, 1, (4, 5, 8), (4, 8), 2),
+    ((False, False, True), 27, None, 1, (4, 5, 8), (4, 8), 2),
+]
+
+
+@pytest.mark.parametrize("per,points,part,nb,grid,tile,nseg", BOX_CASES)
+def test_march_tables_of_truncated_and_partial_box_stencils(per, points, part, nb, grid, tile, nseg):
+    nx, ny, nz = grid
+    crow, col = _box_stencil(nx, ny, nz, per, points, part, nb)
+    n = nb * nx * ny * nz
+    plan = ref.build_lattice_plan(pt.RowGather(crow, col, n, n), dims=(nb, nx, ny, nz))
+    assert plan is not None and plan.box is not None
+    mask, periodic = plan.box
+    assert periodic == sum(1 << d for d in range(3) if per[d])
+    want = 0
+    for dx in (-1, 0, 1):
+        for dy in (-1, 0, 1):
+            for dz in (-1, 0, 1):
+                d = (dx, dy, dz)
+                if points == 7 and abs(dx) + abs(dy) + abs(dz) > 1:
+                    continue
+                if (part == "lower" and d > (0, 0, 0)) or (part == "strict_lower" and d >= (0, 0, 0)):
+                    continue
+                if (part == "upper" and d < (0, 0, 0)) or (part == "strict_upper" and d <= (0, 0, 0)):
+                    continue
+                want |= 1 << ((dx + 1) * 9 + (dy + 1) * 3 + dz + 1)
+    assert mask == want
+    mt = lt.march_tables(plan)
+    assert mt is not None and mt.full == (want == lt.MARCH_FULL) and mt.mask == want
+    assert (plan.uniform_len > 0) == all(per)
+    k = mt.kidx_host.numpy()
+    nset = bin(want).count("1")
+    assert k[mt.ident, 31] == nset and sorted(v for v in k[mt.ident, :27] if v != 0xFF) == list(range(nset))
+    assert _emulate_march(plan, mt, crow, col, tile[0], tile[1], nseg) == 2 * col.numel()
+
+
+@pytest.mark.parametrize("per", [(False, False, False), (True, False, False), (False, True, True), (True, True, True), (False, True, False)])
+@pytest.mark.parametrize("nb", [1, 2])
+def test_row_starts_of_a_truncated_box_are_arithmetic(per, nb):
+    """csrc/march_impl.h, kRowsBox: the whole box on a lattice truncated in some dimensions stores cx(x)·cy(y)·cz(z) entries in
+    the row at (x, y, z) — c = 2 at a face of a truncated dimension, else 3 — so the kernels compute where a row starts instead of
+    reading the row pointer: start = item·Ltot + Lyz·Px(x) + cx(x)·(Lz·Py(y) + cy(y)·Pz(z)).  The same arithmetic, against crow."""
+    def cnt1(t, n, p):
+        return 3 if p else 3 - (t == 0) - (t == n - 1)
+
+    def pre1(t, p):
+        return 3 * t if p else 3 * t - (t > 0)
+
+    nx, ny, nz = 4, 5, 6
+    crow, _ = _box_stencil(nx, ny, nz, per, 27, None, nb)
+    cr = crow.numpy()
+    Lz, Ly, Lx = (pre1(n, p) - (0 if p else 1) for n, p in ((nz, per[2]), (ny, per[1]), (nx, per[0])))
+    Lyz, Ltot = Ly * Lz, Lx * Ly * Lz
+    assert cr[-1] == nb * Ltot
+    for item in range(nb):
+        for x in range(nx):
+            for y in range(ny):
+                for z in range(nz):
+                    a = Lz * pre1(y, per[1]) + cnt1(y, ny, per[1]) * pre1(z, per[2])
+                    assert item * Ltot + Lyz * pre1(x, per[0]) + cnt1(x, nx, per[0]) * a == cr[((item * nx + x) * ny + y) * nz + z]
+
+
+@pytest.mark.parametrize("what", ["lower_periodic", "two_planes", "hole", "wide"])
+def test_march_tables_only_for_box_stencils(what):
+    """Not plane-march patterns: the triangular part of a PERIODIC stencil (the rows at a face keep wrapped neighbours that a
+    displacement rule would drop), lattices under three points in a dimension, a stencil with one entry missing somewhere, and
+    displacements of two lines."""
     if what == "two_planes":
         crow, col = _stencil(2, 6, 8, True)          # dx = -1 and +1 meet the same plane: rows hold 18 entries
         n = 96
-    else:
-        crow, col = _stencil(5, 6, 8, what != "truncated", 7 if what == "seven" else 27, what == "lower")
+    elif what == "lower_periodic":
+        crow, col = _stencil(5, 6, 8, True, 27, True)
         n = 240
-    plan = lt.build_lattice_plan(pt.RowGather(crow, col, n, n))
+    elif what == "hole":
+        crow, col = _box_stencil(5, 6, 8, (False, False, False))
+        n = 240
+        cr, cc = crow.numpy().copy(), col.numpy()
+        r = 100
+        cc = np.delete(cc, cr[r] + 3)
+        cr[r + 1:] -= 1
+        crow, col = torch.from_numpy(cr), torch.from_numpy(cc)
+    else:
+        n = 5 * 6 * 8
+        m = np.zeros((n, n), dtype=bool)
+        idx = np.arange(n)
+        for d in (0, 2, -2, 8, -8):                 # dz = ±2
+            ok = (idx + d >= 0) & (idx + d < n)
+            m[idx[ok], idx[ok] + d] = True
+        crow, col = _csr_from_dense_mask(m)
+    plan = ref.build_lattice_plan(pt.RowGather(crow, col, n, n))
     if plan is not None:
-        assert lt.march_tables(plan) is None
+        assert plan.box is None and lt.march_tables(plan) is None
 
 
 def test_march_config_choice_is_within_limits():
@@ -332,7 +475,7 @@ def test_march_config_choice_is_within_limits():
 
     be.load_library()      # the LDS layout is computed by the library (host code: no GPU needed)
     crow, col = _stencil(6, 9, 16, True)
-    plan = lt.build_lattice_plan(pt.RowGather(crow, col, 864, 864))
+    plan = ref.build_lattice_plan(pt.RowGather(crow, col, 864, 864))
     for mode in (0, 1, 2):
         for p in (16, 32, 64):
             cfg = lt.march_config_for(plan, mode, 0, p, be.march_lds_bytes)
@@ -354,7 +497,7 @@ def test_measured_choice_takes_the_fastest_candidate_and_is_final():
 
     crow, col = synthetic.stencil27_periodic(8, 16, 32)
     n = 8 * 16 * 32
-    plan = lt.build_lattice_plan(pt.RowGather(crow, col, n, n))
+    plan = ref.build_lattice_plan(pt.RowGather(crow, col, n, n))
     first = lt.config_for(plan, 0, 2, 16, 2, be.lattice_lds_bytes)
     assert first is not None and not first.tuned
     cands = lt.tune_candidates(plan, 0, 2, 16, 2, be.lattice_lds_bytes)

@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--modes", default="fwd,sddmm,spmmt")
     ap.add_argument("--stencil", type=int, default=27)
     ap.add_argument("--nocheck", action="store_true")
+    ap.add_argument("--pattern", default="", help="per27 | trunc27 | per7 | trunc7 | lower27 | upper27 | slower27 | lower7 (overrides --stencil)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     dt = {"f32": torch.float32, "bf16": torch.bfloat16, "f64": torch.float64}[a.dtype]
@@ -50,6 +51,12 @@ def main():
     n1, p, b = nx * ny * nz, a.rhs, a.batch
     gen = synthetic.stencil27_periodic if a.stencil == 27 else synthetic.stencil7_periodic
     crow, col = gen(nx, ny, nz, torch.int32, device=dev)
+    if a.pattern:
+        pats = {"per27": ((True,) * 3, 27, None), "trunc27": ((False,) * 3, 27, None), "per7": ((True,) * 3, 7, None),
+                "trunc7": ((False,) * 3, 7, None), "lower27": ((False,) * 3, 27, "lower"), "upper27": ((False,) * 3, 27, "upper"),
+                "slower27": ((False,) * 3, 27, "strict_lower"), "lower7": ((False,) * 3, 7, "lower")}
+        per, points, part = pats[a.pattern]
+        crow, col = synthetic.box_stencil(nx, ny, nz, per, points, part, torch.int32, device=dev)
     if b > 1:
         g1 = _pattern.RowGather(crow.unsqueeze(0).repeat(b, 1), col.unsqueeze(0).repeat(b, 1), n1, n1)
         plan = _pattern.flat_of(g1)

@@ -39,12 +39,18 @@ def main():
     ap.add_argument("--cfg", nargs="*", default=[])
     ap.add_argument("--modes", default="fwd,sddmm,spmmt")
     ap.add_argument("--nocheck", action="store_true")
+    ap.add_argument("--force-rstart", action="store_true", help="run the row-pointer (non-uniform) kernels on a uniform pattern")
+    ap.add_argument("--pattern", default="per27", help="per27 | trunc27 | per7 | trunc7 | lower27 | upper27 | slower27 | lower7 | xper27")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     dt = torch.float32
     nx, ny, nz = a.grid
     n1, p, b = nx * ny * nz, a.rhs, a.batch
-    crow, col = synthetic.stencil27_periodic(nx, ny, nz, torch.int32, device=dev)
+    pats = {"per27": ((True,) * 3, 27, None), "trunc27": ((False,) * 3, 27, None), "per7": ((True,) * 3, 7, None),
+            "trunc7": ((False,) * 3, 7, None), "lower27": ((False,) * 3, 27, "lower"), "upper27": ((False,) * 3, 27, "upper"),
+            "slower27": ((False,) * 3, 27, "strict_lower"), "lower7": ((False,) * 3, 7, "lower"), "xper27": ((True, False, False), 27, None)}
+    per, points, part = pats[a.pattern]
+    crow, col = synthetic.box_stencil(nx, ny, nz, per, points, part, torch.int32, device=dev)
     if b > 1:
         g1 = _pattern.RowGather(crow.unsqueeze(0).repeat(b, 1), col.unsqueeze(0).repeat(b, 1), n1, n1)
         plan = _pattern.flat_of(g1)
@@ -61,7 +67,7 @@ def main():
     modes = a.modes.split(",")
     lp = lt.build_lattice_plan_hip(plan, be)
     mt = lt.march_tables(lp) if lp is not None else None
-    print(f"plan: {None if lp is None else (lp.nb, lp.nx, lp.ny, lp.nz, lp.ncls, lp.uniform_len)} march: {None if mt is None else mt.ident}")
+    print(f"pattern {a.pattern}: nnz/row {nnz / n:.2f}  plan: {None if lp is None else (lp.nb, lp.nx, lp.ny, lp.nz, lp.ncls, lp.uniform_len, lp.box)} march: {None if mt is None else (mt.ident, mt.full)}")
     if mt is None:
         return
     ident_rows = (lp.rcls[:n] == mt.ident)
@@ -81,6 +87,10 @@ def main():
         for m in modes:
             mode = {"fwd": be.LAT_SPMM, "sddmm": be.LAT_SDDMM, "spmmt": be.LAT_SPMMT}[m]
             cfg = be.march_config(lp, mode, dt, p)
+            if cfg is not None and a.force_rstart and cfg.struct.uniform_len:
+                keep = crow.to(torch.int32).contiguous()
+                cfg.struct.uniform_len, cfg.struct.rstart = 0, keep.data_ptr()
+                globals().setdefault("_KEEP", []).append(keep)
             if cfg is None:
                 print(f"{m:6s} cfg={cs or 'auto'}: no configuration")
                 continue
@@ -98,7 +108,9 @@ def main():
                 d = (out - r).abs().max().item()
                 scale = r.abs().max().item()
                 if m == "sddmm":
-                    eq_rows = (out.view(n, 27) == r.view(n, 27)).all(1)
+                    rowid = torch.repeat_interleave(torch.arange(n, device=dev), (crow[1:] - crow[:-1]).long())
+                    eq_rows = torch.ones(n, dtype=torch.bool, device=dev)
+                    eq_rows[rowid[out != r]] = False
                 else:
                     eq_rows = (out == r).all(1)
                 err = (f" maxdiff={d:.3g} (scale {scale:.3g}) rows bit-equal: {eq_rows.float().mean().item():.4f}"

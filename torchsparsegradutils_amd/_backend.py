@@ -89,10 +89,10 @@ SIGNATURES = {
     "tsgu_csr_sddmm_lattice": (_int, [_int, _ptr, _i64, _i64, _ptr, _i64, _ptr, _i64, _ptr, _dbl, _i64, _int, _ptr]),
     "tsgu_march_lds_bytes": (_int, [_int, _int, _i64, _int, _int, _int, _int, _int, _int]),
     "tsgu_csr_spmm_march": (_int, [_int, _ptr, _int, _i64, _i64, _ptr, _ptr, _i64, _ptr, _i64, _i64, _int, _ptr]),
-    "tsgu_csr_sddmm_march": (_int, [_int, _ptr, _i64, _i64, _ptr, _i64, _ptr, _i64, _ptr, _dbl, _i64, _int, _ptr]),
+    "tsgu_csr_sddmm_march": (_int, [_int, _ptr, _i64, _i64, _ptr, _i64, _ptr, _i64, _ptr, _dbl, _int, _i64, _int, _ptr]),
     "tsgu_lattice_slots": (_int, []),
     "tsgu_lattice_rows": (_int, [_int, _i64, _ptr, _ptr, _int, _int, _int, _int, _ptr, _int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr,
-                                 _int, _ptr]),
+                                 _int, _int, _int, _ptr]),
     "tsgu_lattice_row_codes": (_int, [_int, _i64, _ptr, _ptr, _int, _int, _int, _int, _ptr, _int, _ptr, _int, _ptr, _int, _ptr]),
     "tsgu_lattice_block_classes": (_int, [_i64, _ptr, _int, _int, _int, _int, _int, _int, _int, _ptr, _int, _ptr]),
     "tsgu_csr_sptrsm": (
@@ -140,7 +140,7 @@ def load_library():
             fn = getattr(lib, name)  # AttributeError => header/library mismatch, fail loudly
             fn.restype = res
             fn.argtypes = args
-        if lib.tsgu_abi_version() != 2:
+        if lib.tsgu_abi_version() != 3:
             raise HipExtensionMissing("libtsgu_hip.so ABI version mismatch; rebuild the extension")
         _lib = lib
     return _lib
@@ -459,16 +459,18 @@ def lattice_tune(lp, mode: int, dtype: torch.dtype, p: int, time_ms):
     return _lattice.tune_config(lp, mode, _VTYPE[dtype], p, es, lattice_lds_bytes, sys.modules[__name__], time_ms)
 
 
-def lattice_rows(crow, col, dims, status, slot, thash=None, trep=None, remap=None, ctable=None, lens=None, rcls=None, disp=None):
+def lattice_rows(crow, col, dims, status, slot, thash=None, trep=None, remap=None, ctable=None, lens=None, rcls=None, disp=None,
+                 box_mask: int = 0, periodic: int = 0):
     """Row analysis kernels of csrc/lattice_plan.hip: pass 1 (hash -> slot table) when `ctable` is None, pass 2 (class
-    assignment + exact check) otherwise; the rows of the transposed pattern when `disp` is given."""
+    assignment + exact check) otherwise; the rows of the transposed pattern when `disp` is given.  `box_mask` / `periodic`
+    (pass 2 of the stored-order walk): also the plane-march condition, status[4]."""
     lib = _lib or load_library()
     dev = require_device(crow, col, status)
     nb, nx, ny, nz = dims
     with _on_device(dev):
         rc = lib.tsgu_lattice_rows(itype_of(crow), crow.numel() - 1, _p(crow), _p(col), nb, nx, ny, nz, _p(disp),
                                    0 if disp is None else disp.numel(), _p(slot), _p(thash), _p(trep), _p(remap), _p(ctable), _p(lens),
-                                   _p(rcls), _p(status), dev.index, _stream(dev))
+                                   _p(rcls), _p(status), int(box_mask), int(periodic), dev.index, _stream(dev))
     check(rc, "tsgu_lattice_rows")
 
 
@@ -575,8 +577,12 @@ def csr_spmm_lattice(lp, cfg, val, B, dot: bool = False):
     tok = _timed("lattice_spmm_t" if transposed else "lattice_spmm", dev) if KERNEL_EVENTS is not None else None
     with _on_device(dev):
         if march:
-            rc = lib.tsgu_csr_spmm_march(_VTYPE[val.dtype], cfg.struct_addr, int(transposed), lp.n_rows, lp.nnz, val.data_ptr(), B.data_ptr(),
-                                         _ld(B), out.data_ptr(), p, p, dev.index, _raw_stream(dev))
+            ct = cfg.col_tile          # operands wider than 64 columns: one launch per tile of 64 columns
+            for j in range(0, p, ct):
+                rc = lib.tsgu_csr_spmm_march(_VTYPE[val.dtype], cfg.struct_addr, int(transposed), lp.n_rows, lp.nnz, val.data_ptr(),
+                                             B.data_ptr() + j * 4, _ld(B), out.data_ptr() + j * 4, p, ct, dev.index, _raw_stream(dev))
+                if rc:
+                    break
         else:
             rc = lib.tsgu_csr_spmm_lattice(_VTYPE[val.dtype], cfg.struct_addr, lp.n_rows, lp.nnz, val.data_ptr(), B.data_ptr(), _ld(B),
                                            out.data_ptr(), p, p, dev.index, _raw_stream(dev))
@@ -598,10 +604,18 @@ def csr_sddmm_lattice(lp, cfg, R, Cm, alpha: float = 1.0):
     p = R.size(-1)
     out = torch.empty((lp.nnz,), dtype=R.dtype, device=dev)
     tok = _timed("lattice_sddmm", dev) if KERNEL_EVENTS is not None else None
-    fn = lib.tsgu_csr_sddmm_march if getattr(cfg, "march", False) else lib.tsgu_csr_sddmm_lattice
     with _on_device(dev):
-        rc = fn(_VTYPE[R.dtype], cfg.struct_addr, lp.n_rows, lp.nnz, R.data_ptr(), _ld(R), Cm.data_ptr(), _ld(Cm),
-                out.data_ptr(), float(alpha), p, dev.index, _raw_stream(dev))
+        if getattr(cfg, "march", False):
+            ct = cfg.col_tile          # operands wider than 64 columns: the dots of the later column tiles are added to the first
+            for j in range(0, p, ct):
+                rc = lib.tsgu_csr_sddmm_march(_VTYPE[R.dtype], cfg.struct_addr, lp.n_rows, lp.nnz, R.data_ptr() + j * 4, _ld(R),
+                                              Cm.data_ptr() + j * 4, _ld(Cm), out.data_ptr(), float(alpha), int(j > 0), ct, dev.index,
+                                              _raw_stream(dev))
+                if rc:
+                    break
+        else:
+            rc = lib.tsgu_csr_sddmm_lattice(_VTYPE[R.dtype], cfg.struct_addr, lp.n_rows, lp.nnz, R.data_ptr(), _ld(R), Cm.data_ptr(), _ld(Cm),
+                                            out.data_ptr(), float(alpha), p, dev.index, _raw_stream(dev))
     if tok is not None:
         _timed_end(tok, dev)
     if rc:

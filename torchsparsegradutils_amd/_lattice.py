@@ -27,7 +27,24 @@ MAX_LEN = 32
 PAD_LO = PAD_HI = 0x7FF00     # bytes: reads this far beyond the row's own LDS position are beyond the allocation and return 0
 _MODE_SPMM, _MODE_SDDMM, _MODE_SPMMT = 0, 1, 2
 PACKED_T = False    # one-word records for the transposed walk (must match kPacked in csrc/lattice_impl.h; measured slower)
-_NUM_CU = 256
+_CU_COUNT: Dict[int, int] = {}
+
+
+def num_cu(device=None) -> int:
+    """Compute units of `device` (cached per device; 256 on an MI355X — and when there is no GPU to ask: CPU-side tests of the
+    configuration ranking)."""
+    idx = -1
+    if device is not None and getattr(device, "type", "cpu") == "cuda":
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+    if idx not in _CU_COUNT:
+        n = 256
+        if idx >= 0:
+            try:
+                n = int(torch.cuda.get_device_properties(idx).multi_processor_count) or 256
+            except Exception:       # noqa: BLE001 - the count only steers a launch-configuration choice
+                n = 256
+        _CU_COUNT[idx] = n
+    return _CU_COUNT[idx]
 
 
 class LatticePlan:
@@ -35,11 +52,12 @@ class LatticePlan:
     live in the source rows of the owner's value array)."""
 
     __slots__ = ("kind", "nb", "nx", "ny", "nz", "ry", "rz", "ncls", "recw", "uniform_len", "codes", "ksrc", "lens",
-                 "lens_host", "rcls", "rstart", "n_rows", "nnz", "_cfg", "_march")
+                 "lens_host", "rcls", "rstart", "n_rows", "nnz", "box", "_cfg", "_march")
 
     def __init__(self):
         self._cfg: Dict[tuple, "LatticeConfig"] = {}
-        self._march = False          # False: not derived yet; None: not a full periodic box stencil; else MarchTables
+        self.box = None              # (mask, periodic bits) when the pattern meets the plane-march condition (checked per row)
+        self._march = False          # False: not derived yet; None: not a box stencil; else MarchTables
 
     def plan_bytes(self) -> int:
         total = 0
@@ -56,190 +74,6 @@ class LatticeConfig:
     """One launch configuration of a plan: tile, segments, workgroup size and the record tables built for them."""
 
     __slots__ = ("ty", "tz", "nseg", "threads", "rec", "lds_bytes", "struct", "struct_addr", "wlist", "nloc", "ring", "cpl", "uses", "tuned")
-
-
-def _frequent_offsets(cols64: torch.Tensor, rows64: torch.Tensor, nrows: int) -> Optional[list]:
-    off = (cols64 - rows64).abs()
-    uniq, cnt = torch.unique(off, return_counts=True)
-    if uniq.numel() > 8192:
-        return None
-    # a displacement of a stencil appears in (almost) every row; wrap-around images and boundary losses are rare
-    keep = uniq[(cnt * 2 > nrows) & (uniq > 0)]
-    return keep.tolist()
-
-
-def detect_dims(g, rows64: torch.Tensor, cols64: Optional[torch.Tensor] = None, nrows: Optional[int] = None) -> Optional[Tuple[int, int]]:
-    """(nz, ny·nz) of the lattice this square pattern looks like a stencil on, from the clusters of |col − row|:
-    {1 … rz}, {nz − rz … nz + rz}, {ny·nz − … }.  (nz, n_rows) for a 2-D lattice.  None for anything irregular.
-    `rows64` / `cols64` may be the entries of the first `nrows` rows only (a sample)."""
-    n = g.n_rows
-    pos = _frequent_offsets(g.col.to(torch.int64) if cols64 is None else cols64, rows64, n if nrows is None else nrows)
-    if not pos:
-        return None
-    clusters = [[pos[0]]]
-    reach = max(pos[0], MAX_RADIUS)
-    for o in pos[1:]:
-        if o - clusters[-1][-1] <= reach:
-            clusters[-1].append(o)
-        else:
-            reach = clusters[-1][-1] + MAX_RADIUS
-            clusters.append([o])
-    # the first cluster may be missing (stencils without in-line neighbours) only if it starts beyond the radius
-    if clusters[0][0] > MAX_RADIUS:
-        clusters.insert(0, [])
-    if len(clusters) not in (2, 3) or (clusters[0] and clusters[0][-1] > MAX_RADIUS):
-        return None
-    # line stride: a divisor of n within the in-line radius of every member of the second cluster
-    lo, hi = clusters[1][0], clusters[1][-1]
-    mid = (lo + hi) // 2
-    cands = sorted((c for c in range(max(hi - MAX_RADIUS, 2), lo + MAX_RADIUS + 1) if n % c == 0), key=lambda c: abs(c - mid))
-    if not cands:
-        return None
-    nz = cands[0]
-    if len(clusters) == 2:
-        return nz, nz
-    # plane stride: a multiple of nz dividing n inside the third cluster's span (members are d2 + dy·nz + dz)
-    lo, hi = clusters[2][0], clusters[2][-1]
-    mid = (lo + hi) // 2
-    first = (max(lo - MAX_RADIUS, 2 * nz) + nz - 1) // nz * nz
-    cands = sorted((c for c in range(first, hi + MAX_RADIUS + 1, nz) if n % c == 0), key=lambda c: abs(c - mid))
-    if not cands:
-        return None
-    return nz, cands[0]
-
-
-def _mix(a: torch.Tensor, b) -> torch.Tensor:
-    """64-bit mixing with wrap-around arithmetic (only has to spread well: classes are verified exactly)."""
-    if not torch.is_tensor(b):
-        b = torch.tensor(int(b), dtype=torch.int64, device=a.device)
-    x = a * -7046029254386353131 + b * -4417276706812531889 + 1609587929392839161
-    x = x ^ (x >> 29)
-    return x * -49064778989728563
-
-
-def build_lattice_plan(g, value_crow: Optional[torch.Tensor] = None, dims: Optional[Tuple[int, int, int, int]] = None):
-    """LatticePlan of the 2-D RowGather `g`, or None when the pattern is not a lattice stencil.
-    `value_crow` (A's row pointer) must be given for a transposed pattern (`g.perm` indexes A's value array).
-    `dims` = (nb, nx, ny, nz) skips the detection (tests)."""
-    if g.batch is not None or g.n_rows != g.n_cols or g.n_rows < 8 or not (1 <= g.nnz < 2**31):
-        return None
-    kind = 0 if g.perm is None else 1
-    if kind == 1 and value_crow is None:
-        return None
-    n, nnz = g.n_rows, g.nnz
-    dev = g.crow.device
-    rows = g.row_indices().to(torch.int64)
-    cols = g.col.to(torch.int64)
-    if dims is None:
-        found = detect_dims(g, rows)
-        if found is None:
-            return None
-        nz, d2 = found
-        if n % d2 or n % nz:
-            return None
-        ny = d2 // nz
-        planes = n // d2
-        nx_given = None
-    else:
-        nb_g, nx_given, ny, nz = (int(v) for v in dims)
-        d2 = ny * nz
-        if nb_g * nx_given * d2 != n:
-            return None
-        planes = n // d2
-    X = torch.div(rows, d2, rounding_mode="floor")
-    rem = rows - X * d2
-    y = torch.div(rem, nz, rounding_mode="floor")
-    z = rem - y * nz
-    Xc = torch.div(cols, d2, rounding_mode="floor")
-    remc = cols - Xc * d2
-    yc = torch.div(remc, nz, rounding_mode="floor")
-    zc = remc - yc * nz
-    del rem, remc
-    dX = Xc - X
-    if nx_given is None:
-        m = int(dX.abs().max())
-        nx = planes if m <= 1 else m + 1
-    else:
-        nx = nx_given
-    if nx < 1 or planes % nx:
-        return None
-    nb = planes // nx
-    if nx > 1:
-        dx = torch.where(dX.abs() <= 1, dX, torch.where(dX.abs() == nx - 1, -torch.sign(dX), torch.full_like(dX, 9)))
-    else:
-        dx = dX
-    if bool((dx.abs() > 1).any()):
-        return None
-    x = X - torch.div(X, nx, rounding_mode="floor") * nx
-    item = torch.div(X, nx, rounding_mode="floor")
-    dy = torch.remainder(yc - y + ny // 2, ny) - ny // 2
-    dz = torch.remainder(zc - z + nz // 2, nz) - nz // 2
-    ry, rz = int(dy.abs().max()), int(dz.abs().max())
-    if ry > MAX_RADIUS or rz > MAX_RADIUS:
-        return None
-    expect = ((item * nx + torch.remainder(x + dx, nx)) * ny + torch.remainder(y + dy, ny)) * nz + torch.remainder(z + dz, nz)
-    if not torch.equal(expect, cols):
-        return None
-    del expect, X, Xc, y, yc, z, zc, item, x, dX
-    code = ((dx + 1) * 5 + (dy + 2)) * 5 + (dz + 2)          # < 75
-    del dx, dy, dz
-    crow64 = g.crow.to(torch.int64)
-    lens_row = crow64[1:] - crow64[:-1]
-    maxlen = int(lens_row.max())
-    if maxlen > MAX_LEN or maxlen < 1:
-        return None
-    recw = (maxlen + 3) // 4 * 4
-    pos = torch.arange(nnz, device=dev, dtype=torch.int64) - crow64[rows]
-    if kind == 1:
-        vc = value_crow.to(torch.int64)
-        ksrc = g.perm.to(torch.int64) - vc[cols]
-        if bool(((ksrc < 0) | (ksrc >= MAX_LEN)).any()):
-            return None
-        vlen = vc[1:] - vc[:-1]
-        if int(vlen.max()) > MAX_LEN:
-            return None
-        code = code * 32 + ksrc
-        del ksrc
-        uniform = int(vlen[0]) if bool((vlen == vlen[0]).all()) else 0
-        rstart = value_crow if value_crow.dtype == torch.int32 else value_crow.to(torch.int32)
-    else:
-        uniform = maxlen if bool((lens_row == maxlen).all()) else 0
-        rstart = g.crow if g.crow.dtype == torch.int32 else g.crow.to(torch.int32)
-    # ---- row classes: rows with the same (code, position) sequence ----------------------------------------
-    h = torch.zeros(n, dtype=torch.int64, device=dev)
-    h.index_add_(0, rows, _mix(code, pos + 17))
-    h += _mix(lens_row, 3)
-    uniq, inv = torch.unique(h, return_inverse=True)
-    ncls = uniq.numel()
-    if ncls > MAX_CLASSES:
-        return None
-    rep = torch.full((ncls,), n, dtype=torch.int64, device=dev).scatter_reduce_(0, inv, torch.arange(n, device=dev), "amin")
-    table = torch.full((ncls, recw), -1, dtype=torch.int64, device=dev)
-    is_rep = rep[inv] == torch.arange(n, device=dev)
-    sel = is_rep[rows]
-    table[inv[rows[sel]], pos[sel]] = code[sel]
-    cls_len = lens_row[rep]
-    # exact check (a hash collision must not produce a wrong plan)
-    if not (torch.equal(table[inv[rows], pos], code) and torch.equal(cls_len[inv], lens_row)):
-        return None
-    plan = LatticePlan()
-    plan.kind, plan.nb, plan.nx, plan.ny, plan.nz, plan.ry, plan.rz = kind, nb, nx, ny, nz, ry, rz
-    plan.ncls, plan.recw, plan.uniform_len = ncls, recw, uniform
-    plan.n_rows, plan.nnz = n, nnz
-    tab = table.cpu()
-    if kind == 1:
-        plan.ksrc = torch.where(tab >= 0, tab % 32, tab)
-        plan.codes = torch.where(tab >= 0, torch.div(tab, 32, rounding_mode="floor"), tab)
-    else:
-        plan.codes, plan.ksrc = tab, None
-    plan.lens_host = cls_len.cpu()
-    plan.lens = cls_len.to(torch.uint8)
-    rcls = torch.zeros(n + 64, dtype=torch.uint8, device=dev)
-    rcls[:n] = inv.to(torch.uint8)
-    plan.rcls = rcls
-    # never the caller's own tensor: the pattern cache is evicted when the caller's index storages die
-    plan.rstart = torch.zeros(4, dtype=torch.int32, device=dev) if uniform > 0 else rstart.contiguous().clone()
-    return plan
 
 
 SAMPLE_ROWS = 256
@@ -352,20 +186,21 @@ def build_lattice_plan_hip(g, be, forward: Optional[LatticePlan] = None, dims=No
             return None
     crow, col = g.crow.contiguous(), g.col.contiguous()
     slots = be.load_library().tsgu_lattice_slots()
-    # one small work buffer: status[4] int32 | trep[slots] int32 | thash[slots] int64, pre-set by one copy from the host
-    init = np.empty(4 + slots + 2 * slots, dtype=np.int32)
-    init[:4] = 0
-    init[4:4 + slots] = np.iinfo(np.int32).max
-    init[4 + slots:].view(np.int64)[:] = np.iinfo(np.int64).min
+    # one small work buffer: status[8] int32 | trep[slots] int32 | thash[slots] int64, pre-set by one copy from the host
+    NST = 8
+    init = np.empty(NST + slots + 2 * slots, dtype=np.int32)
+    init[:NST] = 0
+    init[NST:NST + slots] = np.iinfo(np.int32).max
+    init[NST + slots:].view(np.int64)[:] = np.iinfo(np.int64).min
     work = torch.from_numpy(init).to(dev)
-    status, trep, thash = work[:4], work[4:4 + slots], work[4 + slots:].view(torch.int64)
+    status, trep, thash = work[:NST], work[NST:NST + slots], work[NST + slots:].view(torch.int64)
     slot = torch.empty(n, dtype=torch.int16, device=dev)
     be.lattice_rows(crow, col, dims, status, slot, thash=thash, trep=trep, disp=disp)
     host = work.cpu().numpy()
     bad, ry, rz, maxlen = (int(v) for v in host[:4])
     if bad or maxlen > MAX_LEN or maxlen < 1:
         return None
-    hh = host[4 + slots:].view(np.int64)
+    hh = host[NST + slots:].view(np.int64)
     used = np.nonzero(hh != np.iinfo(np.int64).min)[0]
     ncls = used.size
     if ncls > MAX_CLASSES or ncls == 0:
@@ -373,16 +208,23 @@ def build_lattice_plan_hip(g, be, forward: Optional[LatticePlan] = None, dims=No
     order = used[np.argsort(hh[used], kind="stable")]          # classes numbered by ascending hash, like torch.unique
     remap = np.zeros(slots, dtype=np.uint8)
     remap[order] = np.arange(ncls, dtype=np.uint8)
-    rep = torch.from_numpy(host[4:4 + slots][order].astype(np.int64)).to(dev)
+    rep_host = host[NST:NST + slots][order].astype(np.int64)
+    rep = torch.from_numpy(rep_host).to(dev)
     table = torch.empty((ncls, 32), dtype=torch.int32, device=dev)
     be.lattice_row_codes(crow, col, dims, rep, table, disp=disp)
     tab_host = table.cpu()                                   # [classes][32] words: the rest of the class bookkeeping is host work
     lens = torch.from_numpy((tab_host.numpy() >= 0).sum(1).astype(np.uint8)).to(dev)
     rcls = torch.zeros(n + 64, dtype=torch.uint8, device=dev)
     status.zero_()
-    be.lattice_rows(crow, col, dims, status, slot, remap=torch.from_numpy(remap).to(dev), ctable=table, lens=lens, rcls=rcls, disp=disp)
-    if int(status[:1].cpu()[0]) != 0:                        # exact check: hash collisions must not pass
+    # the plane-march condition (stored-order walk): proposed from the class representatives, checked per row by pass 2
+    box = box_candidate(tab_host.numpy(), rep_host, dims, ry, rz) if kind == 0 else None
+    be.lattice_rows(crow, col, dims, status, slot, remap=torch.from_numpy(remap).to(dev), ctable=table, lens=lens, rcls=rcls, disp=disp,
+                    box_mask=box[0] if box else 0, periodic=box[1] if box else 0)
+    st2 = status.cpu()
+    if int(st2[0]) != 0:                                     # exact check: hash collisions must not pass
         return None
+    if box is not None and int(st2[4]) != 0:
+        box = None
     tab = tab_host.to(torch.int64)
     cl = (tab >= 0).sum(1)
     if kind == 0:
@@ -411,7 +253,37 @@ def build_lattice_plan_hip(g, be, forward: Optional[LatticePlan] = None, dims=No
     plan.lens = lens
     plan.rcls = rcls
     plan.rstart = rstart
+    plan.box = box
     return plan
+
+
+def box_candidate(codes, rep_rows, dims, ry: int, rz: int):
+    """(mask, periodic) of the plane-march condition proposed for a stored-order pattern, or None when it cannot hold:
+    `codes` [classes][32] displacement codes of the class representatives `rep_rows` (-1 beyond a row).  mask = the displacements
+    that occur (27 bits, bit (dx+1)·9 + (dy+1)·3 + dz+1); periodic bit 0 / 1 / 2 = some representative reaches across the x / y / z
+    face it sits at.  Whether EVERY row holds exactly the displacements of `mask` whose neighbour exists is for the row kernel."""
+    nb, nx, ny, nz = (int(v) for v in dims)
+    if min(nx, ny, nz) < 3 or ry > 1 or rz > 1 or len(rep_rows) > MARCH_MAX_CLASSES:
+        return None
+    mask, periodic = 0, 0
+    for row, seq in zip(rep_rows, codes):
+        row = int(row)
+        z, y, x = row % nz, (row // nz) % ny, (row // (ny * nz)) % nx
+        for code in seq:
+            code = int(code)
+            if code < 0:
+                continue
+            dz, dy, dx = code % 5 - 2, (code // 5) % 5 - 2, code // 25 - 1
+            if abs(dy) > 1 or abs(dz) > 1:
+                return None
+            mask |= 1 << ((dx + 1) * 9 + (dy + 1) * 3 + dz + 1)
+            if not 0 <= x + dx < nx:
+                periodic |= 1
+            if not 0 <= y + dy < ny:
+                periodic |= 2
+            if not 0 <= z + dz < nz:
+                periodic |= 4
+    return (mask, periodic) if mask else None
 
 
 def workgroup_classes_hip(plan: LatticePlan, ty: int, tz: int, nseg: int, be) -> torch.Tensor:
@@ -538,7 +410,7 @@ def rank_configs(plan: LatticePlan, mode: int, vtype: int, p: int, elem_bytes: i
             tiles = -(-plan.ny // ty) * -(-plan.nz // tz)
             lane_util = (plan.ny * plan.nz) / (tiles * rpp)
             halo = (ty + 2 * plan.ry) * (tz + 2 * plan.rz) / nr
-            slots = _NUM_CU * per_cu
+            slots = num_cu(getattr(getattr(plan, 'rcls', None), 'device', None)) * per_cu
             # measured (C2, fp32): two independent workgroups per CU overlap each other's barrier / DMA waits (1.0); one
             # workgroup of 16 waves is ~15 % slower; 8 waves per CU cannot hide the LDS latency (~1.5x)
             waves = per_cu * threads // 64
@@ -680,16 +552,17 @@ _MARCH_HALO_COST = {0: 0.1, 1: 0.1, 2: 0.8}     # what a halo row costs relative
 
 
 class MarchTables:
-    """What the plane-march kernels need besides the lattice plan's `rcls`: the canonical class and the per-class map
-    canonical slot -> stored position (include/tsgu_hip.h, tsgu_march_plan)."""
+    """What the plane-march kernels need besides the lattice plan's `rcls` / `rstart`: the displacement set, the canonical class
+    and the per-class map canonical slot -> stored position (include/tsgu_hip.h, tsgu_march_plan)."""
 
-    __slots__ = ("ident", "taps", "kidx_host", "kidx", "_cfg")
+    __slots__ = ("ident", "taps", "mask", "periodic", "full", "kidx_host", "kidx", "_cfg")
 
 
 class MarchConfig:
-    """One launch configuration of the plane-march kernels (quacks like LatticeConfig where bench.py / tests look)."""
+    """One launch configuration of the plane-march kernels (quacks like LatticeConfig where bench.py / tests look).
+    `col_tile`: columns per launch (operands wider than 64 columns run as tiles of 64)."""
 
-    __slots__ = ("mode", "ty", "tz", "nseg", "threads", "lds_bytes", "struct", "struct_addr", "ring", "cpl", "nloc", "tables")
+    __slots__ = ("mode", "ty", "tz", "nseg", "threads", "lds_bytes", "struct", "struct_addr", "ring", "cpl", "nloc", "tables", "col_tile")
     march = True
 
 
@@ -697,35 +570,44 @@ class _MarchPlanStruct(ctypes.Structure):
     """``tsgu_march_plan`` of include/tsgu_hip.h."""
 
     _fields_ = ([(k, ctypes.c_int32) for k in ("nb", "nx", "ny", "nz", "ry", "rz", "ntap")] + [("tap_dy", ctypes.c_int32 * 9), ("tap_dz", ctypes.c_int32 * 9)]
-                + [(k, ctypes.c_int32) for k in ("ncls", "ident", "ty", "tz", "nseg", "threads")] + [(k, ctypes.c_void_p) for k in ("kidx", "rcls")])
+                + [(k, ctypes.c_int32) for k in ("ncls", "ident", "ty", "tz", "nseg", "threads")] + [("mask", ctypes.c_uint32)]
+                + [(k, ctypes.c_int32) for k in ("periodic", "uniform_len")] + [(k, ctypes.c_void_p) for k in ("kidx", "rcls", "rstart")])
+
+
+MARCH_FULL = (1 << 27) - 1
 
 
 def march_tables(plan: LatticePlan) -> Optional[MarchTables]:
-    """MarchTables of a stored-order lattice plan whose rows all hold the full 3 x 3 x 3 box (a periodic 27-point stencil on a
-    lattice of at least 3 points per dimension), else None.  Host work on the [classes][28] code table only."""
+    """MarchTables of a stored-order lattice plan that meets the plane-march condition (`plan.box`: every row holds exactly the
+    displacements of one subset of the 3 x 3 x 3 box whose neighbour exists — periodic or truncated 27- / 7-point stencils,
+    triangular parts of truncated ones … on a lattice of at least 3 points per dimension), else None.  Host work on the
+    [classes][28] code table only."""
     if plan._march is not False:
         return plan._march
     plan._march = None
-    ns = 3 * MARCH_TAPS
-    if (plan.kind != 0 or plan.uniform_len != ns or plan.ry != 1 or plan.rz != 1 or min(plan.nx, plan.ny, plan.nz) < 3
-            or plan.ncls > MARCH_MAX_CLASSES):
+    if plan.kind != 0 or plan.box is None or plan.ncls > MARCH_MAX_CLASSES or min(plan.nx, plan.ny, plan.nz) < 3:
         return None
-    canon = [((dx + 1) * 5 + dy + 2) * 5 + dz + 2 for dx in (-1, 0, 1) for dy in (-1, 0, 1) for dz in (-1, 0, 1)]   # ascending
-    codes = plan.codes[:, :ns].tolist()
+    mask, periodic = plan.box
+
+    def slot_of(code):
+        return (code // 25) * 9 + ((code // 5) % 5 - 1) * 3 + code % 5 - 1
+
+    canon = [s for s in range(27) if mask >> s & 1]                     # ascending (dx, dy, dz)
     ident = None
     kidx = [[0xFF] * 32 for _ in range(plan.ncls)]
-    for c, row in enumerate(codes):
-        if sorted(row) != canon:
+    for c, row in enumerate(plan.codes.tolist()):
+        slots = [slot_of(code) for code in row if code >= 0]
+        if len(set(slots)) != len(slots) or len(slots) > 27:
             return None
-        if row == canon:
+        if slots == canon:
             ident = c
-        pos = {code: k for k, code in enumerate(row)}
-        for slot, code in enumerate(canon):
-            kidx[c][slot] = pos[code]
+        for k, sl in enumerate(slots):
+            kidx[c][sl] = k
+        kidx[c][31] = len(slots)
     if ident is None:
         return None
     mt = MarchTables()
-    mt.ident = ident
+    mt.ident, mt.mask, mt.periodic, mt.full = ident, mask, periodic, mask == MARCH_FULL
     mt.taps = [(dy, dz) for dy in (-1, 0, 1) for dz in (-1, 0, 1)]
     mt.kidx_host = torch.tensor(kidx, dtype=torch.uint8)
     mt.kidx = mt.kidx_host.to(plan.rcls.device)
@@ -736,7 +618,7 @@ def march_tables(plan: LatticePlan) -> Optional[MarchTables]:
 
 def march_config_for(plan: LatticePlan, mode: int, vtype: int, p: int, lds_bytes_fn) -> Optional[MarchConfig]:
     """Cached launch configuration of the plane-march kernels for a stored-order plan, or None (pattern / operands not covered)."""
-    if not ENABLE_MARCH or vtype != 0 or p not in (16, 32, 64):
+    if not ENABLE_MARCH or vtype != 0 or not (p in (16, 32, 64) or (p > 64 and p % 64 == 0 and p <= 1024)):
         return None
     if p == 16 and mode == 0 and not _MARCH_CFG_ENV:
         return None      # 16 columns, forward: the general sweep is faster (measured at C2's lattice: 46 against 58 us; SDDMM 89 / 77, transposed 86 / 71)
@@ -746,7 +628,8 @@ def march_config_for(plan: LatticePlan, mode: int, vtype: int, p: int, lds_bytes
     key = (mode, p)
     if key in mt._cfg:
         return mt._cfg[key]
-    cl = p // 4
+    pt = min(p, 64)                 # columns per launch
+    cl = pt // 4
     best = None
     if _MARCH_CFG_ENV:
         v = [int(t) for t in _MARCH_CFG_ENV.split(",")]
@@ -760,15 +643,15 @@ def march_config_for(plan: LatticePlan, mode: int, vtype: int, p: int, lds_bytes
             if rpp // tz >= 1 and rpp // tz <= plan.ny and tz <= plan.nz:
                 cands.append((rpp // tz, tz, 0, threads))
     for ty, tz, nseg, threads in cands:
-        lds = lds_bytes_fn(mode, vtype, p, ty, tz, plan.ry, plan.rz, plan.ncls, threads)
+        lds = lds_bytes_fn(mode, vtype, pt, ty, tz, 1, 1, plan.ncls, threads)
         if lds <= 0:
             continue
         per_cu = max(1, min(160 * 1024 // lds, _MARCH_WAVES_PER_CU[mode] * 64 // threads))
-        slots = _NUM_CU * per_cu
+        slots = num_cu(getattr(getattr(plan, 'rcls', None), 'device', None)) * per_cu
         tiles = -(-plan.ny // ty) * -(-plan.nz // tz)
         base = plan.nb * tiles
         util = (plan.ny * plan.nz) / (tiles * ty * tz)
-        halo = (ty + 2 * plan.ry) * (tz + 2 * plan.rz) / (ty * tz)
+        halo = (ty + 2) * (tz + 2) / (ty * tz)
         util /= 1.0 + _MARCH_HALO_COST[mode] * (halo - 1.0)
         choices = [nseg] if nseg else range(1, min(plan.nx, 64) + 1)
         for ns_ in choices:
@@ -787,11 +670,12 @@ def march_config_for(plan: LatticePlan, mode: int, vtype: int, p: int, lds_bytes
         _, ty, tz, nseg, threads, lds = best
         cfg = MarchConfig()
         cfg.mode, cfg.ty, cfg.tz, cfg.nseg, cfg.threads, cfg.lds_bytes = mode, ty, tz, nseg, threads, lds
-        cfg.ring, cfg.cpl, cfg.nloc, cfg.tables = 2, 1, plan.ncls, mt
+        cfg.ring, cfg.cpl, cfg.nloc, cfg.tables, cfg.col_tile = 2, 1, plan.ncls, mt, pt
         dy = (ctypes.c_int32 * 9)(*[t[0] for t in mt.taps])
         dz = (ctypes.c_int32 * 9)(*[t[1] for t in mt.taps])
-        cfg.struct = _MarchPlanStruct(plan.nb, plan.nx, plan.ny, plan.nz, plan.ry, plan.rz, MARCH_TAPS, dy, dz, plan.ncls, mt.ident,
-                                      ty, tz, nseg, threads, mt.kidx.data_ptr(), plan.rcls.data_ptr())
+        cfg.struct = _MarchPlanStruct(plan.nb, plan.nx, plan.ny, plan.nz, 1, 1, MARCH_TAPS, dy, dz, plan.ncls, mt.ident,
+                                      ty, tz, nseg, threads, mt.mask, mt.periodic, plan.uniform_len, mt.kidx.data_ptr(),
+                                      plan.rcls.data_ptr(), plan.rstart.data_ptr())
         cfg.struct_addr = ctypes.addressof(cfg.struct)
     mt._cfg[key] = cfg
     return cfg

@@ -83,17 +83,21 @@ def _lattice_cfg(plan: RowGather, mode: int, dense: torch.Tensor, *others: torch
         return None
     row_bytes = dense.size(-1) * dense.element_size()
     lanes = row_bytes // 16
-    if row_bytes % 16 or lanes not in (1, 2, 4, 8, 16) or (lanes == 1 and not (mode == _be.LAT_SPMM and dense.dtype == torch.float32)):
+    wide = dense.dtype == torch.float32 and dense.size(-1) > 64 and dense.size(-1) % 64 == 0     # plane march only: column tiles of 64
+    if not wide and (row_bytes % 16 or lanes not in (1, 2, 4, 8, 16) or (lanes == 1 and not (mode == _be.LAT_SPMM and dense.dtype == torch.float32))):
         return None            # dense rows the sweeps are not compiled for: do not even analyse the pattern
     fwd = _lattice_plan(plan)
     if fwd is None:
         return None
-    # full periodic box stencils: the plane-march kernels (all three products from the stored-order plan alone)
+    # box stencils (periodic or truncated; 27-point, 7-point, triangular parts …): the plane-march kernels — all three products
+    # from the stored-order plan alone
     cfg = _be.march_config(fwd, mode, dense.dtype, dense.size(-1))
     if cfg is not None:
         if memo is not None:
             memo[key] = (fwd, cfg)
         return fwd, cfg
+    if wide:
+        return None
     lp = _lattice_plan(plan, transposed=True) if mode == _be.LAT_SPMMT else fwd
     if lp is None:
         return None

@@ -84,15 +84,23 @@ __device__ __forceinline__ int lat_slot_of(int64_t h, int64_t row, unsigned long
     return -1;
 }
 
-// status words: [0] rows that are not lattice rows / do not match their class, [1] max |dy|, [2] max |dz|, [3] longest row
+// status words: [0] rows that are not lattice rows / do not match their class, [1] max |dy|, [2] max |dz|, [3] longest row,
+//               [4] (pass 2, box_mask != 0) rows that are not "the displacements of box_mask that lead to an existing neighbour"
 // Pass 1 (ctable == NULL): hash of the row's code sequence -> slot[row] in the hash table (thash / trep = smallest row per slot).
+//                          A row that stores a column twice is not a lattice row (every plan assumes duplicate-free rows: the
+//                          transposed walk would find the column once and drop the second entry).
 // Pass 2 (ctable given):   rcls[row] = remap[slot[row]]; the row's codes and length are compared with its class (exact check).
+//   box_mask (27 bits, bit (dx+1)·9 + (dy+1)·3 + dz+1) and `periodic` (bit 0 / 1 / 2: x / y / z wrap) state the plane-march
+//   condition: the row holds exactly the displacements of the mask whose neighbour exists — all of them in a periodic dimension,
+//   the ones that stay inside the lattice in a truncated one.  Checked per row (the entries are distinct, lie in the mask by the
+//   class check and must not wrap in a truncated dimension; then equal counts mean equal sets).
 template <typename I>
 __global__ __launch_bounds__(256) void lat_rows_kernel(int64_t n_rows, const I* __restrict__ crow, const I* __restrict__ col, LatDims D,
                                                         unsigned short* __restrict__ slot, unsigned long long* __restrict__ thash,
                                                         int* __restrict__ trep, const unsigned char* __restrict__ remap,
                                                         const int* __restrict__ ctable, const unsigned char* __restrict__ lens,
-                                                        unsigned char* __restrict__ rcls, int* __restrict__ status) {
+                                                        unsigned char* __restrict__ rcls, int* __restrict__ status, unsigned box_mask,
+                                                        int periodic) {
     const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= n_rows) return;
     const int64_t e0 = (int64_t)crow[row], e1 = (int64_t)crow[row + 1];
@@ -107,7 +115,16 @@ __global__ __launch_bounds__(256) void lat_rows_kernel(int64_t n_rows, const I* 
         rcls[row] = (unsigned char)cls;
         trow = ctable + (int64_t)cls * kLatMaxLen;
     }
+    bool off_box = false;
     if (!bad) {
+        // position of the row (the plane-march condition)
+        const int64_t d2 = (int64_t)D.ny * D.nz;
+        const int64_t X = row / d2;
+        const int rem = (int)(row - X * d2);
+        const int y = rem / D.nz, z = rem - y * D.nz;
+        const int x = (int)(X % D.nx);
+        const bool px = periodic & 1, py = periodic & 2, pz = periodic & 4;
+        unsigned long long seen0 = 0, seen1 = 0;          // codes < 75
         for (int k = 0; k < len; ++k) {
             int ady = 0, adz = 0;
             const int code = lat_code(row, (int64_t)col[e0 + k], D, ady, adz);
@@ -117,11 +134,31 @@ __global__ __launch_bounds__(256) void lat_rows_kernel(int64_t n_rows, const I* 
             }
             my = ady > my ? ady : my;
             mz = adz > mz ? adz : mz;
+            const unsigned long long bit = 1ull << (code & 63);
+            unsigned long long& seen = code < 64 ? seen0 : seen1;
+            bad |= (seen & bit) != 0;                      // the same column twice
+            seen |= bit;
             if (trow) bad |= trow[k] != code;
             else h += lat_mix(code, k + 17);
+            if (box_mask) {
+                const int dz = code % 5 - 2, dy = (code / 5) % 5 - 2, dx = code / 25 - 1;
+                off_box |= dy < -1 || dy > 1 || dz < -1 || dz > 1;
+                off_box |= (!px && (unsigned)(x + dx) >= (unsigned)D.nx) || (!py && (unsigned)(y + dy) >= (unsigned)D.ny) ||
+                           (!pz && (unsigned)(z + dz) >= (unsigned)D.nz);
+            }
         }
         if (trow) bad |= lens[cls] != len;
         else h += lat_mix(len, 3);
+        if (box_mask) {
+            int expect = 0;
+            for (int b = 0; b < 27; ++b) {
+                if (!(box_mask >> b & 1u)) continue;
+                const int dx = b / 9 - 1, dy = (b / 3) % 3 - 1, dz = b % 3 - 1;
+                expect += (px || (unsigned)(x + dx) < (unsigned)D.nx) && (py || (unsigned)(y + dy) < (unsigned)D.ny) &&
+                          (pz || (unsigned)(z + dz) < (unsigned)D.nz);
+            }
+            off_box |= expect != len;
+        }
     }
     if (!ctable) {
         const int s = bad ? 0 : lat_slot_of(h, row, thash, trep);
@@ -132,6 +169,7 @@ __global__ __launch_bounds__(256) void lat_rows_kernel(int64_t n_rows, const I* 
     // 1e6 rows)
     volatile int* const st = status;
     if (bad) atomicAdd(status + 0, 1);
+    if (box_mask && (bad || off_box) && st[4] == 0) atomicAdd(status + 4, 1);
     if (my > st[1]) atomicMax(status + 1, my);
     if (mz > st[2]) atomicMax(status + 2, mz);
     if (len > st[3]) atomicMax(status + 3, len);
@@ -292,9 +330,10 @@ int tsgu_lattice_slots(void) { return kLatSlots; }
 
 int tsgu_lattice_rows(int itype, int64_t n_rows, const void* crow, const void* col, int nb, int nx, int ny, int nz, const void* disp, int nd,
                       void* slot, void* thash, void* trep, const void* remap, const void* ctable, const void* lens, void* rcls, void* status,
-                      int device, void* stream) {
+                      int box_mask, int periodic, int device, void* stream) {
     if (const int rc = dims_ok(n_rows, nb, nx, ny, nz)) return rc;
     if (!crow || !col || !status || !slot || (nd > 0 && !disp) || nd > 75) return TSGU_ERR_BAD_ARG;
+    if (box_mask < 0 || box_mask >= (1 << 27) || (box_mask && (nd > 0 || ctable == nullptr))) return TSGU_ERR_BAD_ARG;
     const bool pass2 = ctable != nullptr;
     if (pass2 ? (!remap || !lens || !rcls) : (!thash || !trep)) return TSGU_ERR_BAD_ARG;
     if (const int rc = set_device(device)) return rc;
@@ -314,10 +353,10 @@ int tsgu_lattice_rows(int itype, int64_t n_rows, const void* crow, const void* c
     if (nd <= 0) {
         if (itype == TSGU_I32)
             hipLaunchKernelGGL(lat_rows_kernel<int>, grid, block, 0, s, n_rows, static_cast<const int*>(crow), static_cast<const int*>(col), D, sl,
-                               th, tr, rm, ct, ln, rc_, st);
+                               th, tr, rm, ct, ln, rc_, st, (unsigned)box_mask, periodic);
         else
             hipLaunchKernelGGL(lat_rows_kernel<int64_t>, grid, block, 0, s, n_rows, static_cast<const int64_t*>(crow),
-                               static_cast<const int64_t*>(col), D, sl, th, tr, rm, ct, ln, rc_, st);
+                               static_cast<const int64_t*>(col), D, sl, th, tr, rm, ct, ln, rc_, st, (unsigned)box_mask, periodic);
     } else {
         if (itype == TSGU_I32)
             hipLaunchKernelGGL(lat_trows_kernel<int>, grid, block, 0, s, n_rows, static_cast<const int*>(crow), static_cast<const int*>(col), D,

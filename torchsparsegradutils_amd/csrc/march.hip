@@ -1,5 +1,5 @@
 // Plane-march kernels (march_impl.h): extern "C" entry points (declared in include/tsgu_hip.h) and the fp32 instantiations.
-#include "march_impl.h"
+#include "march_sets.h"
 
 using namespace tsgu;
 
@@ -17,7 +17,14 @@ int fill(MarchParams& P, const tsgu_march_plan* pl, int mode, int vtype, int64_t
     if (cl == 0) return TSGU_ERR_BAD_DTYPE;
     if (pl->ntap != 9 || pl->ry != 1 || pl->rz != 1) return TSGU_ERR_BAD_ARG;
     if (pl->nb <= 0 || pl->nx < 3 || pl->ny < 3 || pl->nz < 3 || pl->nseg <= 0 || pl->nseg > pl->nx) return TSGU_ERR_BAD_ARG;
-    if ((int64_t)pl->nb * pl->nx * pl->ny * pl->nz != n_rows || 3 * (int64_t)pl->ntap * n_rows != nnz) return TSGU_ERR_BAD_ARG;
+    if ((int64_t)pl->nb * pl->nx * pl->ny * pl->nz != n_rows) return TSGU_ERR_BAD_ARG;
+    if (pl->mask == 0 || pl->mask >= (1u << 27) || pl->uniform_len < 0 || pl->uniform_len > 27) return TSGU_ERR_BAD_ARG;
+    if (pl->uniform_len > 0 ? (int64_t)pl->uniform_len * n_rows != nnz : (pl->rstart == nullptr && pl->mask != kBoxAll)) return TSGU_ERR_BAD_ARG;
+    if (pl->mask == kBoxAll && pl->uniform_len == 0) {
+        // the whole box on a lattice truncated somewhere: row starts by arithmetic — 3 entries per point and dimension, 2 at a face
+        auto line = [](int n, int per) -> int64_t { return per ? 3 * (int64_t)n : 3 * (int64_t)n - 2; };
+        if (pl->nb * line(pl->nx, pl->periodic & 1) * line(pl->ny, pl->periodic & 2) * line(pl->nz, pl->periodic & 4) != nnz) return TSGU_ERR_BAD_ARG;
+    }
     if (pl->threads != 256 && pl->threads != 512) return TSGU_ERR_BAD_ARG;
     if (!pl->kidx || !pl->rcls || pl->ncls <= 0 || pl->ncls > kMarchMaxCls || pl->ident < 0 || pl->ident >= pl->ncls) return TSGU_ERR_BAD_ARG;
     if (nnz > 0x7fffffffLL || n_rows > 0x7fffffffLL || nnz * 4 + 16 > 0xffffffffLL) return TSGU_ERR_TOO_LARGE;
@@ -29,6 +36,10 @@ int fill(MarchParams& P, const tsgu_march_plan* pl, int mode, int vtype, int64_t
     P.seg_len = (pl->nx + pl->nseg - 1) / pl->nseg;
     if ((int64_t)(P.nseg - 1) * P.seg_len >= pl->nx) return TSGU_ERR_BAD_ARG;
     P.ncls = pl->ncls, P.ident = pl->ident;
+    P.mask = pl->mask;
+    P.per_x = pl->periodic & 1, P.per_y = pl->periodic >> 1 & 1, P.per_z = pl->periodic >> 2 & 1;
+    P.uniform = pl->uniform_len;
+    P.rstart = static_cast<const int*>(pl->rstart);
     const int hz = pl->tz + 2 * pl->rz;
     for (int i = 0; i < 9; ++i) {
         if (pl->tap_dy[i] < -1 || pl->tap_dy[i] > 1 || pl->tap_dz[i] < -1 || pl->tap_dz[i] > 1) return TSGU_ERR_BAD_ARG;
@@ -47,22 +58,19 @@ int fill(MarchParams& P, const tsgu_march_plan* pl, int mode, int vtype, int64_t
     return TSGU_OK;
 }
 
-template <int MODE, int NT>
-int go(int cl, const MarchParams& P, hipStream_t s) {
-    switch (cl) {
-        case 4: return march_launch<float, 4, MODE, NT>(P, s);
-        case 8: return march_launch<float, 8, MODE, NT>(P, s);
-        case 16: return march_launch<float, 16, MODE, NT>(P, s);
-    }
-    return TSGU_ERR_BAD_ARG;
-}
-
 template <int MODE>
 int dispatch(int cl, int threads, const MarchParams& P, void* stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (threads == 256) return go<MODE, 256>(cl, P, s);
-    if (threads == 512) return go<MODE, 512>(cl, P, s);
-    return TSGU_ERR_BAD_ARG;
+    const bool uni = P.uniform > 0;                   // rows of one length (periodic lattices): no row-pointer reads
+    if (P.mask == kBoxAll) return march_run_box(MODE, cl, threads, uni, P, s);
+    if (threads == march_subset_threads(MODE)) {      // the compiled subsets exist for one workgroup size per product
+        if (P.mask == kMarchCross) return march_run_cross(MODE, cl, uni, P, s);
+        if (!uni) {                                   // (a triangular part of a periodic stencil is not a box stencil)
+            const int rc = (P.mask & ~kMarchLowerIncl) == 0 ? march_run_lower(MODE, cl, P, s) : march_run_upper(MODE, cl, P, s);
+            if (rc != kMarchNotMine) return rc;
+        }
+    }
+    return march_run_any(MODE, cl, threads, uni, P, s);
 }
 
 }  // namespace
@@ -99,7 +107,7 @@ int tsgu_csr_spmm_march(int vtype, const tsgu_march_plan* plan, int transposed, 
 }
 
 int tsgu_csr_sddmm_march(int vtype, const tsgu_march_plan* plan, int64_t n_rows, int64_t nnz, const void* R, int64_t ldr, const void* Cm,
-                         int64_t ldc, void* out_vals, double alpha, int64_t p, int device, void* stream) {
+                         int64_t ldc, void* out_vals, double alpha, int accumulate, int64_t p, int device, void* stream) {
     MarchParams P{};
     int cl = 0;
     if (const int rc = fill(P, plan, kLatSddmm, vtype, p, n_rows, nnz, cl)) return rc;
@@ -115,6 +123,7 @@ int tsgu_csr_sddmm_march(int vtype, const tsgu_march_plan* plan, int64_t n_rows,
     P.lds_ = ldc;
     P.gvals = out_vals;
     P.alpha = (float)alpha;
+    P.accumulate = accumulate != 0;
     return dispatch<kLatSddmm>(cl, plan->threads, P, stream);
 }
 

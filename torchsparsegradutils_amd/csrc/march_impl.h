@@ -46,7 +46,12 @@ struct MarchParams {
     int nseg, seg_len;
     int ncls, ident;
     int tap_row[9];              // halo-row displacement dy·HZ + dz of tap i, ascending
-    const unsigned char* kidx;   // [ncls][32] stored position of canonical slot s
+    unsigned mask;               // bit p·NTAP + i: displacement (dx = p - 1, tap i) occurs in the pattern (all 27: a full box)
+    int per_x, per_y, per_z;     // the lattice is periodic in x / y / z (else: truncated — neighbours beyond a face do not exist)
+    int uniform;                 // > 0: every row stores this many entries (`rstart` is not read); 0: rows start at rstart[row]
+    const int* rstart;           // [rows + 1] first value position of each row (A's row pointer as int32)
+    int accumulate;              // SDDMM: add to gvals instead of overwriting (column tiles of wide dense operands)
+    const unsigned char* kidx;   // [ncls][32] stored position of canonical slot s (0xff: the row has no such entry); byte 31: row length
     const unsigned char* rcls;   // [rows] class of each row
     const void* val;
     int64_t nnz;
@@ -112,13 +117,44 @@ __device__ __forceinline__ float group_sum_t8(float d0, float d1, float d2, floa
     return b2 ? hi : lo;
 }
 
-template <typename V, int CL, int MODE, int NT, int NTAP>
-__global__ __launch_bounds__(NT, 4) void march_kernel(const MarchParams P) {
+// MASK: the pattern's displacement set when it is one of the sets the kernels are compiled for (march.hip: the whole box, the
+// 7-point cross, the triangular halves of both): straight-line code without per-displacement tests.  The whole box (FULL)
+// also copies the value rows of waves whose rows are all of the canonical class with the 16-byte DMA.  MASK = 0: any other
+// subset, P.mask at run time — the products of a (part, tap) pair are skipped by wave-uniform branches; subsets gather every
+// value row through kidx (waves of canonical rows: without a look-up).
+//
+// ROWS — where a row's values start:
+//   kRowsUniform  every row stores the same number of entries (P.uniform; periodic lattices): row r starts at r·P.uniform
+//   kRowsBox      the whole box on a lattice truncated in some dimension: a row at (x, y, z) stores cx(x)·cy(y)·cz(z) entries, c = 2
+//                 at a face of a truncated dimension, else 3 — so the start of a row is arithmetic: a per-row constant of the march
+//                 times cx(x) plus a per-plane scalar.  No row pointer is read
+//   kRowsPointer  P.rstart[row] — loaded a step ahead next to the class bytes (a load waited for where it is issued would also
+//                 wait for the DMAs in flight)
+//
+// Truncated lattices (P.per_* == 0).  A row at a face simply has no entry towards the neighbours beyond it; its canonical
+// slots for them hold 0.  The halo rows beyond a face are ZERO in LDS (never fetched, cleared once), halo planes beyond an x
+// face are skipped — so the only products that involve a staged zero value are 0 · 0, and no row touches a dense row it does
+// not reference (non-finite operands behave as in the reference).
+#ifndef TSGU_MARCH_SDDMM_WAVES
+#define TSGU_MARCH_SDDMM_WAVES 4
+#endif
+// waves per SIMD the register allocation aims at: 4 (at most 128 VGPRs); the SDDMM of a truncated box [experiment macro]
+constexpr int march_waves(int mode, bool full, bool uni) { return mode == kLatSddmm && full && !uni ? TSGU_MARCH_SDDMM_WAVES : 4; }
+constexpr uint32_t kBoxAll = (1u << 27) - 1u;      // every displacement of the 3 x 3 x 3 box
+
+enum MarchRows { kRowsPointer = 0, kRowsUniform = 1, kRowsBox = 2 };
+
+template <typename V, int CL, int MODE, int NT, int NTAP, uint32_t MASK, int ROWS>
+__global__ __launch_bounds__(NT, march_waves(MODE, MASK == kBoxAll, ROWS != kRowsPointer)) void march_kernel(const MarchParams P) {
+    constexpr bool PTR = ROWS == kRowsPointer, UNIF = ROWS == kRowsUniform, BOXA = ROWS == kRowsBox;
+    static_assert(!BOXA || MASK == kBoxAll, "row starts by box arithmetic: the whole box only");
+    constexpr bool FULL = MASK == kBoxAll;     // the whole box
+    constexpr bool CT = MASK != 0;             // the displacement set is known at compile time (else: P.mask)
     static_assert(sizeof(V) == 4, "fp32 values and operands");
     constexpr int RB = CL * 16;                 // bytes of a dense row
     constexpr int NG = NT / CL;                 // row groups of the workgroup
     constexpr int RPW = kWave / CL;             // rows per wave
-    constexpr int NS = 3 * NTAP;                // entries per row
+    constexpr int NS = 3 * NTAP;                // canonical slots per row
     constexpr int SLOTS = (NS + 3) / 4 * 4;     // slots of a staged value row
     constexpr int VP = SLOTS * 4;               // its pitch in bytes (112: the rows of a wave fall on different banks)
     constexpr int VL = SLOTS / 4;               // its 16-byte pieces
@@ -126,7 +162,7 @@ __global__ __launch_bounds__(NT, 4) void march_kernel(const MarchParams P) {
     constexpr int NPASS = MODE == kLatSpmmT ? 2 : 1;        // staged rows: tile rows (one per group) or halo rows (up to two)
     constexpr int RJ = (NS + CL - 1) / CL;      // SDDMM: dots a lane keeps per target
     constexpr int NF = (RPW * VL + kWave - 1) / kWave;       // 16-byte DMA instructions that copy the value rows of a wave (plain path)
-    static_assert(NT % kWave == 0 && kWave % CL == 0 && VP % 64 != 0, "geometry");
+    static_assert(NT % kWave == 0 && kWave % CL == 0 && VP % 64 != 0 && NS < 31, "geometry");
 
     extern __shared__ uint4 lat_smem[];
     char* const sm = reinterpret_cast<char*>(lat_smem);
@@ -142,6 +178,16 @@ __global__ __launch_bounds__(NT, 4) void march_kernel(const MarchParams P) {
     const int PB = HR * RB;
     const int plane_rows = P.ny * P.nz;
     auto wrap = [](int v, int m) { return v >= m ? v - m : v; };
+    auto has = [&](int bit) -> bool {           // displacement `bit` occurs in the pattern (wave-uniform for a uniform `bit`)
+        if constexpr (CT) return ((MASK >> bit) & 1u) != 0;
+        else return ((P.mask >> bit) & 1u) != 0;
+    };
+    const uint32_t mask = CT ? MASK : P.mask;
+    // run-time displacement sets: keeps the compiler from turning a skipped product into a computed-and-discarded one (a
+    // v_cndmask per accumulator register and product)
+    auto branchy = [&]() {
+        if constexpr (!CT) asm volatile("" ::: "memory");
+    };
 
     // ---- the tile and x segment of this workgroup (as lattice_kernel) ---------------------------------------------
     const int64_t vblock = xcd_chunked_block(blockIdx.x, P.nblocks);
@@ -157,6 +203,37 @@ __global__ __launch_bounds__(NT, 4) void march_kernel(const MarchParams P) {
     const int y0 = tyi * P.ty, z0 = tzi * P.tz;
     const int item_row0 = item * P.nx * plane_rows;
     auto row_of_x = [&](int x) -> int { return item_row0 + x * plane_rows; };
+    // ring index s of this segment is lattice plane xs - 1 + s of the item: beyond an x face of a truncated lattice there is none
+    auto x_ok = [&](int s) -> bool { return P.per_x || (unsigned)(xs - 1 + s) < (unsigned)P.nx; };
+    // halo row (hy, hz) of the tile: its row inside a plane, or -1 beyond a y / z face of a truncated lattice
+    auto halo_row = [&](int hy, int hz) -> int {
+        const int yy = y0 - P.ry + hy, zz = z0 - P.rz + hz;
+        const bool in = (P.per_y || (unsigned)yy < (unsigned)P.ny) && (P.per_z || (unsigned)zz < (unsigned)P.nz);
+        return in ? lat_mod(yy, P.ny) * P.nz + lat_mod(zz, P.nz) : -1;
+    };
+
+    // kRowsBox: entries per point along a dimension (3, or 2 at a face of a truncated dimension) and their prefix sums
+    auto cnt1 = [](int t, int n, int per) -> int { return per ? 3 : 3 - (t == 0) - (t == n - 1); };
+    auto pre1 = [](int t, int per) -> int { return per ? 3 * t : 3 * t - (t > 0); };
+    const int boxLz = pre1(P.nz, P.per_z) - (P.per_z ? 0 : 1), boxLy = pre1(P.ny, P.per_y) - (P.per_y ? 0 : 1);
+    const int boxLyz = boxLy * boxLz, boxLtot = (pre1(P.nx, P.per_x) - (P.per_x ? 0 : 1)) * boxLyz;
+    // the per-row constant of row r (inside its plane): its start is plane_base(x) + plane_cx(x)·row_const(r)
+    auto row_const = [&](int r) -> int {
+        if constexpr (BOXA) {
+            const int y = r / P.nz, z = r - y * P.nz;
+            return boxLz * pre1(y, P.per_y) + cnt1(y, P.ny, P.per_y) * pre1(z, P.per_z);
+        } else {
+            return r;
+        }
+    };
+    auto plane_cx = [&](int x) -> int {
+        if constexpr (BOXA) return cnt1(x, P.nx, P.per_x);
+        else return FULL ? NS : P.uniform;
+    };
+    auto plane_base = [&](int x) -> int {
+        if constexpr (BOXA) return item * boxLtot + boxLyz * pre1(x, P.per_x);
+        else return row_of_x(x) * (FULL ? NS : P.uniform);
+    };
 
     // ---- tables -> LDS: kidx, and the row-in-plane index of every staged row (-1: outside the lattice) ----------------
     const int staged_rows = MODE == kLatSpmmT ? HR : NR;
@@ -169,7 +246,7 @@ __global__ __launch_bounds__(NT, 4) void march_kernel(const MarchParams P) {
             int v;
             if constexpr (MODE == kLatSpmmT) {
                 const int hy = r / HZ, hz = r - hy * HZ;
-                v = lat_mod(y0 - P.ry + hy, P.ny) * P.nz + lat_mod(z0 - P.rz + hz, P.nz);
+                v = halo_row(hy, hz);
             } else {
                 const int ly = r / P.tz, lz = r - ly * P.tz;
                 v = (y0 + ly < P.ny && z0 + lz < P.nz) ? (y0 + ly) * P.nz + z0 + lz : -1;
@@ -190,7 +267,28 @@ __global__ __launch_bounds__(NT, 4) void march_kernel(const MarchParams P) {
         const int e = d * NT + tid;
         const int hr = e / CL;
         const int hy = hr / HZ, hz = hr - hy * HZ;
-        roff[d] = e < ring_pieces ? (uint32_t)(lat_mod(y0 - P.ry + hy, P.ny) * P.nz + lat_mod(z0 - P.rz + hz, P.nz)) * ldsb + (uint32_t)c * 16u : kLatNone;
+        const int hrow_in_plane = e < ring_pieces ? halo_row(hy, hz) : -1;
+        roff[d] = hrow_in_plane >= 0 ? (uint32_t)hrow_in_plane * ldsb + (uint32_t)c * 16u : kLatNone;
+    }
+    if (!(P.per_y && P.per_z)) {
+        // truncated in y or z: the halo rows beyond a face are zero in both ring slots (no DMA ever writes them); so are their
+        // staged value rows in the transposed product
+#pragma unroll
+        for (int d = 0; d < kMarchND; ++d) {
+            const int e = d * NT + tid;
+            if (e < ring_pieces && roff[d] == kLatNone) {
+                lat_smem[e] = make_uint4(0, 0, 0, 0);
+                lat_smem[HR * CL + e] = make_uint4(0, 0, 0, 0);
+            }
+        }
+        if constexpr (MODE == kLatSpmmT) {
+            for (int e = tid; e < HR * VL; e += NT) {
+                if (rows_s[e / VL] < 0) {
+                    *reinterpret_cast<uint4*>(sm + P.o_vals + e * 16) = make_uint4(0, 0, 0, 0);
+                    *reinterpret_cast<uint4*>(sm + P.o_vals + HR * VP + e * 16) = make_uint4(0, 0, 0, 0);
+                }
+            }
+        }
     }
     // the compute row of this lane group
     const int ly = g / P.tz, lz = g - ly * P.tz;
@@ -202,8 +300,9 @@ __global__ __launch_bounds__(NT, 4) void march_kernel(const MarchParams P) {
     const int cen = hrow * RB + c * 16;
 
     // staged value rows: pass q, wave w stages rows q·NG + w·RPW .. + RPW - 1 (tile rows, or halo rows for the transposed product)
-    //   srow[q]  the row whose class this lane loads (its group's row)
-    //   foff[q][f]  plain path: byte offset of this lane's f-th 16-byte piece inside the plane's values (kLatNone: nothing)
+    //   srow[q]  the row whose class / first value position this lane loads (its group's row)
+    //   foff[q][f]  plain path: this lane's f-th 16-byte piece — kLatNone: nothing to copy; else (rows of uniform length) its byte
+    //               offset inside the plane's values
     int srow[NPASS];
     uint32_t foff[NPASS][NF];
     if constexpr (MODE != kLatSddmm) {
@@ -216,7 +315,8 @@ __global__ __launch_bounds__(NT, 4) void march_kernel(const MarchParams P) {
                 const int piece = f * kWave + lane;
                 const int fr = q * NG + wave * RPW + piece / VL;
                 const int frow = (piece < RPW * VL && fr < staged_rows) ? rows_s[fr] : -1;
-                foff[q][f] = frow >= 0 ? (uint32_t)frow * (uint32_t)(NS * 4) + (uint32_t)(piece % VL) * 16u : kLatNone;
+                if constexpr (BOXA) foff[q][f] = frow >= 0 ? (uint32_t)row_const(frow) * 4u : kLatNone;
+                else foff[q][f] = frow >= 0 ? (uint32_t)frow * (uint32_t)(NS * 4) + (uint32_t)(piece % VL) * 16u : kLatNone;
             }
         }
     }
@@ -235,43 +335,67 @@ __global__ __launch_bounds__(NT, 4) void march_kernel(const MarchParams P) {
             }
         }
     };
-    // canonical value rows of the plane with first row `prow` into the buffer at byte `region`; cls[q] = class of srow[q]
-    auto stage_vals = [&](int prow, unsigned region, const int (&cls)[NPASS]) {
+    // canonical value rows of lattice plane `x` of the item into the buffer at byte `region`; cls[q] / stt[q] = class and (row
+    // pointers) first value position of srow[q]
+    auto stage_vals = [&](int x, unsigned region, const int (&cls)[NPASS], const int (&stt)[NPASS]) {
         if constexpr (MODE != kLatSddmm) {
-            const uint32_t plane0 = (uint32_t)prow * (uint32_t)(NS * 4);
-            const char* const pbase = valb + plane0;
+            const int pbase = PTR ? 0 : plane_base(x), pcx = PTR ? 0 : plane_cx(x);   // wave-uniform
 #pragma unroll
             for (int q = 0; q < NPASS; ++q) {
                 const int first = q * NG + wave * RPW;                       // wave-uniform
                 if (first < staged_rows) {
                     const unsigned wbase = sbase + region + (unsigned)(first * VP);
-                    const bool plain = __builtin_amdgcn_ballot_w64(srow[q] >= 0 && cls[q] != P.ident) == 0;
+                    const bool plain = FULL && __builtin_amdgcn_ballot_w64(srow[q] >= 0 && cls[q] != P.ident) == 0;
                     if (plain) {
+                        // rows of the canonical class hold all NS values in canonical order: a plain copy
 #pragma unroll
                         for (int f = 0; f < NF; ++f) {
-                            const uint32_t fo = foff[q][f];
+                            // foff = 4 · (the per-row constant of the piece's row) (+ the piece's offset inside the row: uniform rows)
+                            uint32_t fo = foff[q][f];
+                            if constexpr (UNIF) {
+                                if (fo != kLatNone) fo += (uint32_t)pbase * 4u;
+                            } else if constexpr (BOXA) {
+                                if (fo != kLatNone) fo = (uint32_t)pbase * 4u + (uint32_t)pcx * fo + (uint32_t)((f * kWave + lane) % VL) * 16u;
+                            } else {
+                                const int piece = f * kWave + lane;
+                                const int rw = piece / VL;
+                                const int rs = __builtin_amdgcn_ds_bpermute((rw < RPW ? rw * CL : 0) * 4, stt[q]);
+                                if (fo != kLatNone) fo = (uint32_t)rs * 4u + (uint32_t)(piece % VL) * 16u;
+                            }
                             if (fo != kLatNone) {
-                                if (__builtin_expect(plane0 + fo + 16u <= val_bytes, 1)) {
-                                    lat_dma16<MODE == kLatSpmm>(pbase, fo, wbase + (unsigned)(f * kWave * 16));
+                                if (__builtin_expect(fo + 16u <= val_bytes, 1)) {
+                                    lat_dma16<MODE == kLatSpmm>(valb, fo, wbase + (unsigned)(f * kWave * 16));
                                 } else {   // the last 16 bytes of the value array: element-wise, never reading beyond the array
                                     float* dst = reinterpret_cast<float*>(sm + region + first * VP + (f * kWave + lane) * 16);
 #pragma nounroll
                                     for (int e = 0; e < 4; ++e)
-                                        dst[e] = plane0 + fo + (e + 1) * 4 <= val_bytes ? *reinterpret_cast<const float*>(pbase + fo + e * 4) : 0.f;
+                                        dst[e] = fo + (e + 1) * 4 <= val_bytes ? *reinterpret_cast<const float*>(valb + fo + e * 4) : 0.f;
                                 }
                             }
                         }
                     } else {
+                        // gathered through kidx, one lane per canonical slot, one slot group after the other (finding all sources
+                        // first and then issuing the requests back to back measured 10-20 us SLOWER per launch at C2).  A wave
+                        // whose rows are all of the canonical class (the bulk of a pattern that is a SUBSET of the box) needs no
+                        // look-up: the stored position of a slot is the number of the pattern's displacements below it.
+                        const bool allid = !FULL && __builtin_amdgcn_ballot_w64(srow[q] >= 0 && cls[q] != P.ident) == 0;
 #pragma unroll
                         for (int n = 0; n < NGI; ++n) {
                             const int e = n * kWave + lane;
                             const int rw = e / SLOTS, slot = e - rw * SLOTS;
-                            // class of row rw of this wave: held by the lanes of its group
-                            const int rc = __builtin_amdgcn_ds_bpermute((rw < RPW ? rw * CL : 0) * 4, cls[q]);
+                            const int src_lane = (rw < RPW ? rw * CL : 0) * 4;
+                            const int rc = __builtin_amdgcn_ds_bpermute(src_lane, cls[q]);
                             const int rr = (rw < RPW && first + rw < staged_rows) ? rows_s[first + rw] : -1;
-                            if (rr >= 0 && slot < NS) {
-                                const int k = kidx_s[rc * 32 + slot];
-                                lat_dma4<MODE == kLatSpmm>(pbase, (uint32_t)rr * (uint32_t)(NS * 4) + (uint32_t)k * 4u, wbase + (unsigned)(n * kWave * 4));
+                            int rs;
+                            if constexpr (PTR) rs = __builtin_amdgcn_ds_bpermute(src_lane, stt[q]);
+                            else rs = pbase + pcx * row_const(rr > 0 ? rr : 0);
+                            if (rr >= 0 && slot < NS && has(slot)) {
+                                const int k = allid ? __builtin_popcount(mask & ((1u << slot) - 1u)) : (int)kidx_s[rc * 32 + slot];
+                                if (UNIF || k != 0xFF) {
+                                    lat_dma4<MODE == kLatSpmm>(valb, (uint32_t)rs * 4u + (uint32_t)k * 4u, wbase + (unsigned)(n * kWave * 4));
+                                } else {
+                                    *reinterpret_cast<float*>(sm + region + first * VP + e * 4) = 0.f;
+                                }
                             }
                         }
                     }
@@ -279,19 +403,26 @@ __global__ __launch_bounds__(NT, 4) void march_kernel(const MarchParams P) {
             }
         }
     };
-    auto load_cls = [&](int prow, int (&cls)[NPASS]) {
+    auto load_cls = [&](int prow, int (&cls)[NPASS], int (&stt)[NPASS]) {
         if constexpr (MODE != kLatSddmm) {
             const unsigned char* const cbase = P.rcls + prow;
 #pragma unroll
             for (int q = 0; q < NPASS; ++q) {
                 cls[q] = P.ident;
-                if (srow[q] >= 0) cls[q] = cbase[(uint32_t)srow[q]];
+                if constexpr (PTR) stt[q] = 0;
+                if (srow[q] >= 0) {
+                    cls[q] = cbase[(uint32_t)srow[q]];
+                    if constexpr (PTR) stt[q] = P.rstart[prow + srow[q]];
+                }
             }
         }
     };
-    auto pin_cls = [&](int (&cls)[NPASS]) {
+    auto pin_cls = [&](int (&cls)[NPASS], int (&stt)[NPASS]) {
 #pragma unroll
-        for (int q = 0; q < NPASS; ++q) lat_pin(cls[q]);
+        for (int q = 0; q < NPASS; ++q) {
+            lat_pin(cls[q]);
+            if constexpr (PTR) lat_pin(stt[q]);
+        }
     };
 
     int tapb[NTAP];   // byte offset of tap i from the row's own position in a halo plane (wave-uniform)
@@ -310,20 +441,21 @@ __global__ __launch_bounds__(NT, 4) void march_kernel(const MarchParams P) {
         const int vbuf = (MODE == kLatSpmm ? NR : HR) * VP;
         // SpMM stages the values of target plane s+2 at step s; SpMMT those of halo plane s+1 (with the dense plane)
         int x_val = MODE == kLatSpmm ? xs : x_ring;                         // lattice plane of the next value plane (ring 1 / ring 0)
-        int cls[NPASS], cld[NPASS];
-        load_cls(row_of_x(x_val), cls);
-        pin_cls(cls);
-        dma_ring(row_of_x(x_ring), 0);
-        stage_vals(row_of_x(x_val), (unsigned)(P.o_vals + (MODE == kLatSpmm ? 1 : 0) * vbuf), cls);
+        int cls[NPASS], cld[NPASS], stt[NPASS], std_[NPASS];
+        const int first_val = MODE == kLatSpmm ? 1 : 0;                     // ring index of the first value plane
+        const int last_val = MODE == kLatSpmm ? L : L + 1;
+#pragma unroll
+        for (int q = 0; q < NPASS; ++q) cls[q] = cld[q] = P.ident, stt[q] = std_[q] = 0;
+        if (x_ok(first_val)) {
+            load_cls(row_of_x(x_val), cls, stt);
+            pin_cls(cls, stt);
+        }
+        if (x_ok(0)) dma_ring(row_of_x(x_ring), 0);
+        if (x_ok(first_val)) stage_vals(x_val, (unsigned)(P.o_vals + (MODE == kLatSpmm ? 1 : 0) * vbuf), cls, stt);
         x_ring = wrap(x_ring + 1, P.nx);
         x_val = wrap(x_val + 1, P.nx);
-        const int first_next = MODE == kLatSpmm ? 2 : 1;                    // ring index of the next value plane
-        const int last_val = MODE == kLatSpmm ? L : L + 1;
-        if (first_next <= last_val) load_cls(row_of_x(x_val), cld);
-        else {
-#pragma unroll
-            for (int q = 0; q < NPASS; ++q) cld[q] = P.ident;
-        }
+        const int first_next = first_val + 1;                               // ring index of the next value plane
+        if (first_next <= last_val && x_ok(first_next)) load_cls(row_of_x(x_val), cld, std_);
         lat_step_sync();
 
         float accP[4], accC[4], accN[4], done[4];
@@ -342,23 +474,23 @@ __global__ __launch_bounds__(NT, 4) void march_kernel(const MarchParams P) {
         };
         for (int s = 0; s <= L + 1; ++s) {
             // 1. the class bytes loaded during the previous step; the results that were completed by it
-            pin_cls(cld);
+            pin_cls(cld, std_);
 #pragma unroll
-            for (int q = 0; q < NPASS; ++q) cls[q] = cld[q];
+            for (int q = 0; q < NPASS; ++q) cls[q] = cld[q], stt[q] = std_[q];
             if (s >= 3) flush();
             // 2. asynchronous fetches: the next halo plane, the next value plane
-            if (s + 1 <= L + 1) dma_ring(row_of_x(x_ring), (s + 1) & 1);
+            if (s + 1 <= L + 1 && x_ok(s + 1)) dma_ring(row_of_x(x_ring), (s + 1) & 1);
             const int vnext = MODE == kLatSpmm ? s + 2 : s + 1;
-            if (vnext <= last_val) stage_vals(row_of_x(x_val), (unsigned)(P.o_vals + (vnext & (VB - 1)) * vbuf), cls);
+            if (vnext <= last_val && x_ok(vnext)) stage_vals(x_val, (unsigned)(P.o_vals + (vnext & (VB - 1)) * vbuf), cls, stt);
             x_ring = wrap(x_ring + 1, P.nx);
             x_val = wrap(x_val + 1, P.nx);
             // 3. class bytes for the next step
-            if (vnext + 1 <= last_val) load_cls(row_of_x(x_val), cld);
+            if (vnext + 1 <= last_val && x_ok(vnext + 1)) load_cls(row_of_x(x_val), cld, std_);
             // 4. source plane s: targets s+1 (N, part 0), s (C, part 1), s-1 (P, part 2).  A target outside 1..L accumulates
             // whatever its value buffer holds: it is never stored
 #pragma unroll
             for (int v = 0; v < 4; ++v) accN[v] = 0.f;
-            if (crow >= 0) {
+            if (crow >= 0 && x_ok(s)) {
                 const char* const bb = sm + (s & 1) * PB + cen;
                 if constexpr (MODE == kLatSpmm) {
                     // values: part p of a row = slots p·NTAP .. p·NTAP + NTAP - 1 of its canonical row
@@ -378,22 +510,57 @@ __global__ __launch_bounds__(NT, 4) void march_kernel(const MarchParams P) {
                             a[p][4 * m + 2] = __uint_as_float(w.z), a[p][4 * m + 3] = __uint_as_float(w.w);
                         }
                     }
-                    uint4 b[NTAP];
-                    constexpr int kAhead = 3;
+                    if constexpr (FULL) {
+                        uint4 b[NTAP];
+                        constexpr int kAhead = 3;
 #pragma unroll
-                    for (int i = 0; i < kAhead && i < NTAP; ++i) b[i] = *reinterpret_cast<const uint4*>(bb + tapb[i]);
+                        for (int i = 0; i < kAhead && i < NTAP; ++i) b[i] = *reinterpret_cast<const uint4*>(bb + tapb[i]);
 #pragma unroll
-                    for (int i = 0; i < NTAP; ++i) {
-                        if (i + kAhead < NTAP) b[i + kAhead] = *reinterpret_cast<const uint4*>(bb + tapb[i + kAhead]);
-                        asm volatile("" ::: "memory");
-                        float f[4];
-                        as4(b[i], f);
-                        const float a0 = a[0][i - 4 * first[0]], a1 = a[1][NTAP + i - 4 * first[1]], a2 = a[2][2 * NTAP + i - 4 * first[2]];
+                        for (int i = 0; i < NTAP; ++i) {
+                            if (i + kAhead < NTAP) b[i + kAhead] = *reinterpret_cast<const uint4*>(bb + tapb[i + kAhead]);
+                            asm volatile("" ::: "memory");
+                            float f[4];
+                            as4(b[i], f);
+                            const float a0 = a[0][i - 4 * first[0]], a1 = a[1][NTAP + i - 4 * first[1]], a2 = a[2][2 * NTAP + i - 4 * first[2]];
 #pragma unroll
-                        for (int v = 0; v < 4; ++v) {
-                            accN[v] = fmaf(a0, f[v], accN[v]);
-                            accC[v] = fmaf(a1, f[v], accC[v]);
-                            accP[v] = fmaf(a2, f[v], accP[v]);
+                            for (int v = 0; v < 4; ++v) {
+                                accN[v] = fmaf(a0, f[v], accN[v]);
+                                accC[v] = fmaf(a1, f[v], accC[v]);
+                                accP[v] = fmaf(a2, f[v], accP[v]);
+                            }
+                        }
+                    } else {
+                        // a subset of the box: the dense row of a tap is read when any of its three parts occurs — all reads
+                        // first (one wait), then the products (wave-uniform branches on the pattern's displacement set)
+                        uint4 b[NTAP];
+#pragma unroll
+                        for (int i = 0; i < NTAP; ++i) {
+                            b[i] = make_uint4(0, 0, 0, 0);
+                            if (has(i) || has(NTAP + i) || has(2 * NTAP + i)) {
+                                branchy();
+                                b[i] = *reinterpret_cast<const uint4*>(bb + tapb[i]);
+                            }
+                        }
+#pragma unroll
+                        for (int i = 0; i < NTAP; ++i) {
+                            float f[4];
+                            as4(b[i], f);
+                            const float a0 = a[0][i - 4 * first[0]], a1 = a[1][NTAP + i - 4 * first[1]], a2 = a[2][2 * NTAP + i - 4 * first[2]];
+                            if (has(i)) {
+                                branchy();
+#pragma unroll
+                                for (int v = 0; v < 4; ++v) accN[v] = fmaf(a0, f[v], accN[v]);
+                            }
+                            if (has(NTAP + i)) {
+                                branchy();
+#pragma unroll
+                                for (int v = 0; v < 4; ++v) accC[v] = fmaf(a1, f[v], accC[v]);
+                            }
+                            if (has(2 * NTAP + i)) {
+                                branchy();
+#pragma unroll
+                                for (int v = 0; v < 4; ++v) accP[v] = fmaf(a2, f[v], accP[v]);
+                            }
                         }
                     }
                 } else {
@@ -403,30 +570,70 @@ __global__ __launch_bounds__(NT, 4) void march_kernel(const MarchParams P) {
                     int tapv[NTAP];
 #pragma unroll
                     for (int i = 0; i < NTAP; ++i) tapv[i] = P.tap_row[i] * VP;
-                    uint4 b[NTAP];
-                    float a[NTAP][3];
-                    constexpr int kAhead = 2;
-                    auto fetch = [&](int i) {
-                        b[i] = *reinterpret_cast<const uint4*>(bb + tapb[i]);
-                        const char* const vr = vb0 + tapv[i];
+                    if constexpr (FULL) {
+                        uint4 b[NTAP];
+                        float a[NTAP][3];
+                        constexpr int kAhead = 2;
+                        auto fetch = [&](int i) {
+                            b[i] = *reinterpret_cast<const uint4*>(bb + tapb[i]);
+                            const char* const vr = vb0 + tapv[i];
 #pragma unroll
-                        for (int p = 0; p < 3; ++p) a[i][p] = *reinterpret_cast<const float*>(vr + ((2 - p) * NTAP + NTAP - 1 - i) * 4);
-                    };
+                            for (int p = 0; p < 3; ++p) a[i][p] = *reinterpret_cast<const float*>(vr + ((2 - p) * NTAP + NTAP - 1 - i) * 4);
+                        };
 #pragma unroll
-                    for (int i = 0; i < kAhead && i < NTAP; ++i) fetch(i);
+                        for (int i = 0; i < kAhead && i < NTAP; ++i) fetch(i);
 #pragma unroll
-                    for (int i = 0; i < NTAP; ++i) {
-                        if (i + kAhead < NTAP) fetch(i + kAhead);
-                        asm volatile("" ::: "memory");
-                        float f[4];
-                        as4(b[i], f);
-                        // part index here counts the TARGET: N = s+1 (dx = +1), C = s (dx = 0), P = s-1 (dx = -1)
-                        const float aN = a[i][0], aC = a[i][1], aP = a[i][2];
+                        for (int i = 0; i < NTAP; ++i) {
+                            if (i + kAhead < NTAP) fetch(i + kAhead);
+                            asm volatile("" ::: "memory");
+                            float f[4];
+                            as4(b[i], f);
+                            // part index here counts the TARGET: N = s+1 (dx = +1), C = s (dx = 0), P = s-1 (dx = -1)
+                            const float aN = a[i][0], aC = a[i][1], aP = a[i][2];
 #pragma unroll
-                        for (int v = 0; v < 4; ++v) {
-                            accN[v] = fmaf(aN, f[v], accN[v]);
-                            accC[v] = fmaf(aC, f[v], accC[v]);
-                            accP[v] = fmaf(aP, f[v], accP[v]);
+                            for (int v = 0; v < 4; ++v) {
+                                accN[v] = fmaf(aN, f[v], accN[v]);
+                                accC[v] = fmaf(aC, f[v], accC[v]);
+                                accP[v] = fmaf(aP, f[v], accP[v]);
+                            }
+                        }
+                    } else {
+                        uint4 b[NTAP];
+                        float a[NTAP][3];
+#pragma unroll
+                        for (int i = 0; i < NTAP; ++i) {
+                            const int sN = 2 * NTAP + NTAP - 1 - i, sC = NTAP + NTAP - 1 - i, sP = NTAP - 1 - i;
+                            const char* const vr = vb0 + tapv[i];
+                            b[i] = make_uint4(0, 0, 0, 0);
+                            a[i][0] = a[i][1] = a[i][2] = 0.f;
+                            if (has(sN) || has(sC) || has(sP)) {
+                                branchy();
+                                b[i] = *reinterpret_cast<const uint4*>(bb + tapb[i]);
+                                if (has(sN)) a[i][0] = *reinterpret_cast<const float*>(vr + sN * 4);
+                                if (has(sC)) a[i][1] = *reinterpret_cast<const float*>(vr + sC * 4);
+                                if (has(sP)) a[i][2] = *reinterpret_cast<const float*>(vr + sP * 4);
+                            }
+                        }
+#pragma unroll
+                        for (int i = 0; i < NTAP; ++i) {
+                            const int sN = 2 * NTAP + NTAP - 1 - i, sC = NTAP + NTAP - 1 - i, sP = NTAP - 1 - i;
+                            float f[4];
+                            as4(b[i], f);
+                            if (has(sN)) {
+                                branchy();
+#pragma unroll
+                                for (int v = 0; v < 4; ++v) accN[v] = fmaf(a[i][0], f[v], accN[v]);
+                            }
+                            if (has(sC)) {
+                                branchy();
+#pragma unroll
+                                for (int v = 0; v < 4; ++v) accC[v] = fmaf(a[i][1], f[v], accC[v]);
+                            }
+                            if (has(sP)) {
+                                branchy();
+#pragma unroll
+                                for (int v = 0; v < 4; ++v) accP[v] = fmaf(a[i][2], f[v], accP[v]);
+                            }
                         }
                     }
                 }
@@ -445,18 +652,21 @@ __global__ __launch_bounds__(NT, 4) void march_kernel(const MarchParams P) {
         // ---- SDDMM -----------------------------------------------------------------------------------------------
         struct Own {
             uint4 row;
-            int cls;
+            int cls, start;
         };
         auto load_own = [&](int prow, Own& o) {
             o.cls = P.ident;
+            o.start = 0;
             o.row = make_uint4(0, 0, 0, 0);
             if (crow >= 0) {
                 o.cls = P.rcls[prow + crow];
+                if constexpr (PTR) o.start = P.rstart[prow + crow];
                 o.row = *reinterpret_cast<const uint4*>(static_cast<const char*>(P.Own) + (int64_t)prow * P.ldown * 4 + cown);
             }
         };
         auto pin_own = [&](Own& o) {
             lat_pin(o.cls);
+            if constexpr (PTR) lat_pin(o.start);
             lat_pin(o.row.x);
             lat_pin(o.row.y);
             lat_pin(o.row.z);
@@ -465,12 +675,13 @@ __global__ __launch_bounds__(NT, 4) void march_kernel(const MarchParams P) {
         Own oP, oC, oN, old;
         oP.row = oC.row = make_uint4(0, 0, 0, 0);
         oP.cls = oC.cls = P.ident;
+        oP.start = oC.start = 0;
         int x_own = xs;                                       // lattice plane of ring index 1
         load_own(row_of_x(x_own), oN);
         pin_own(oN);
         x_own = wrap(x_own + 1, P.nx);
         old = oN;
-        dma_ring(row_of_x(x_ring), 0);
+        if (x_ok(0)) dma_ring(row_of_x(x_ring), 0);
         x_ring = wrap(x_ring + 1, P.nx);
         lat_step_sync();
 
@@ -478,28 +689,33 @@ __global__ __launch_bounds__(NT, 4) void march_kernel(const MarchParams P) {
 #pragma unroll
         for (int j = 0; j < RJ; ++j) rP[j] = rC[j] = rN[j] = 0.f;
         float* const st = reinterpret_cast<float*>(sm + P.o_vals + g * VP);   // this row's stage row (wave-private)
-        int x_out = xs;
+        const int own_const = PTR ? 0 : row_const(crow > 0 ? crow : 0);   // start of this lane's row in plane x: plane_base(x) + plane_cx(x)·own_const
         bool staged = false;
+        int fl_start = 0, fl_len = 0;                          // first value position and length of the staged row
+        int x_out = xs;                                        // lattice plane of the next target to be staged (ring index 1)
         auto flush = [&]() {
             // the row's gradients in stored order: 16-byte pieces, single elements at the end
             if (crow >= 0) {
-                float* const go = static_cast<float*>(P.gvals) + (int64_t)(row_of_x(x_out) + crow) * NS;
+                float* const go = static_cast<float*>(P.gvals) + fl_start;
 #pragma nounroll
-                for (int k0 = c * 4; k0 < NS; k0 += CL * 4) {
-                    const float4 w = *reinterpret_cast<const float4*>(st + k0);
-                    if (k0 + 4 <= NS) {
+                for (int k0 = c * 4; k0 < fl_len; k0 += CL * 4) {
+                    float4 w = *reinterpret_cast<const float4*>(st + k0);
+                    if (k0 + 4 <= fl_len) {
                         typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+                        if (P.accumulate) {
+                            const f4u prev = *reinterpret_cast<const f4u*>(go + k0);
+                            w.x += prev.x, w.y += prev.y, w.z += prev.z, w.w += prev.w;
+                        }
                         const f4u o = {w.x, w.y, w.z, w.w};
                         __builtin_nontemporal_store(o, reinterpret_cast<f4u*>(go + k0));
                     } else {
                         const float wv[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
-                            if (k0 + j < NS) go[k0 + j] = wv[j];
+                            if (k0 + j < fl_len) go[k0 + j] = P.accumulate ? go[k0 + j] + wv[j] : wv[j];
                     }
                 }
             }
-            x_out = wrap(x_out + 1, P.nx);
         };
         for (int s = 0; s <= L + 1; ++s) {
             // 1. take over the rows loaded during the previous step: they are target s+1 now
@@ -510,12 +726,13 @@ __global__ __launch_bounds__(NT, 4) void march_kernel(const MarchParams P) {
             if (staged) flush();
             staged = false;
             // 2. the next halo plane; 3. own rows of target s+2
-            if (s + 1 <= L + 1) dma_ring(row_of_x(x_ring), (s + 1) & 1);
+            if (s + 1 <= L + 1 && x_ok(s + 1)) dma_ring(row_of_x(x_ring), (s + 1) & 1);
             x_ring = wrap(x_ring + 1, P.nx);
             if (s + 2 <= L) load_own(row_of_x(x_own), old);
             x_own = wrap(x_own + 1, P.nx);
             // 4. source plane s
             if (crow >= 0) {
+              if (x_ok(s)) {
                 const char* const bb = sm + (s & 1) * PB + cen;
                 // The dots of targets s+1 and s share every dense row: they run as the two halves of packed instructions (own
                 // columns paired {N, C}, the dense column broadcast by op_sel — each half is the same mul + fma chain as the
@@ -531,36 +748,78 @@ __global__ __launch_bounds__(NT, 4) void march_kernel(const MarchParams P) {
 #pragma unroll
                     for (int v = 0; v < 4; ++v) nc[v] = f2v{on[v], oc[v]};
                 }
-                uint4 b[NTAP];
                 float pd[3][NTAP];
-                constexpr int kAhead = 3;
+                if constexpr (FULL) {
+                    uint4 b[NTAP];
+                    constexpr int kAhead = 3;
 #pragma unroll
-                for (int i = 0; i < kAhead && i < NTAP; ++i) b[i] = *reinterpret_cast<const uint4*>(bb + tapb[i]);
+                    for (int i = 0; i < kAhead && i < NTAP; ++i) b[i] = *reinterpret_cast<const uint4*>(bb + tapb[i]);
 #pragma unroll
-                for (int i = 0; i < NTAP; ++i) {
-                    if (i + kAhead < NTAP) b[i + kAhead] = *reinterpret_cast<const uint4*>(bb + tapb[i + kAhead]);
-                    asm volatile("" ::: "memory");
-                    float f[4];
-                    as4(b[i], f);
-                    const f2v f01 = {f[0], f[1]}, f23 = {f[2], f[3]};
-                    f2v d2;
-                    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(d2) : "v"(nc[0]), "v"(f01));
-                    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(d2) : "v"(nc[1]), "v"(f01));
-                    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(d2) : "v"(nc[2]), "v"(f23));
-                    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(d2) : "v"(nc[3]), "v"(f23));
-                    // (as instructions: the vectoriser would pair the dots of neighbouring taps instead and pay two register
-                    // moves per pair to line their operands up)
-                    float d;
-                    asm("v_mul_f32 %0, %1, %2" : "=v"(d) : "v"(op[0]), "v"(f[0]));
+                    for (int i = 0; i < NTAP; ++i) {
+                        if (i + kAhead < NTAP) b[i + kAhead] = *reinterpret_cast<const uint4*>(bb + tapb[i + kAhead]);
+                        asm volatile("" ::: "memory");
+                        float f[4];
+                        as4(b[i], f);
+                        const f2v f01 = {f[0], f[1]}, f23 = {f[2], f[3]};
+                        f2v d2;
+                        asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(d2) : "v"(nc[0]), "v"(f01));
+                        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(d2) : "v"(nc[1]), "v"(f01));
+                        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(d2) : "v"(nc[2]), "v"(f23));
+                        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(d2) : "v"(nc[3]), "v"(f23));
+                        // (as instructions: the vectoriser would pair the dots of neighbouring taps instead and pay two register
+                        // moves per pair to line their operands up)
+                        float d;
+                        asm("v_mul_f32 %0, %1, %2" : "=v"(d) : "v"(op[0]), "v"(f[0]));
 #pragma unroll
-                    for (int v = 1; v < 4; ++v) asm("v_fmac_f32 %0, %1, %2" : "+v"(d) : "v"(op[v]), "v"(f[v]));
-                    pd[0][i] = d2.x, pd[1][i] = d2.y, pd[2][i] = d;
+                        for (int v = 1; v < 4; ++v) asm("v_fmac_f32 %0, %1, %2" : "+v"(d) : "v"(op[v]), "v"(f[v]));
+                        pd[0][i] = d2.x, pd[1][i] = d2.y, pd[2][i] = d;
+                    }
+                } else {
+                    // a subset of the box: the same mul + fma chain per dot, only for the displacements that occur (all dense
+                    // rows are read first)
+                    uint4 b[NTAP];
+#pragma unroll
+                    for (int i = 0; i < NTAP; ++i) {
+                        b[i] = make_uint4(0, 0, 0, 0);
+                        if (has(i) || has(NTAP + i) || has(2 * NTAP + i)) {
+                            branchy();
+                            b[i] = *reinterpret_cast<const uint4*>(bb + tapb[i]);
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < NTAP; ++i) {
+                        float f[4];
+                        as4(b[i], f);
+                        pd[0][i] = pd[1][i] = pd[2][i] = 0.f;
+                        if (has(i)) {
+                            float d;
+                            asm("v_mul_f32 %0, %1, %2" : "=v"(d) : "v"(nc[0].x), "v"(f[0]));
+#pragma unroll
+                            for (int v = 1; v < 4; ++v) asm("v_fmac_f32 %0, %1, %2" : "+v"(d) : "v"(nc[v].x), "v"(f[v]));
+                            pd[0][i] = d;
+                        }
+                        if (has(NTAP + i)) {
+                            float d;
+                            asm("v_mul_f32 %0, %1, %2" : "=v"(d) : "v"(nc[0].y), "v"(f[0]));
+#pragma unroll
+                            for (int v = 1; v < 4; ++v) asm("v_fmac_f32 %0, %1, %2" : "+v"(d) : "v"(nc[v].y), "v"(f[v]));
+                            pd[1][i] = d;
+                        }
+                        if (has(2 * NTAP + i)) {
+                            float d;
+                            asm("v_mul_f32 %0, %1, %2" : "=v"(d) : "v"(op[0]), "v"(f[0]));
+#pragma unroll
+                            for (int v = 1; v < 4; ++v) asm("v_fmac_f32 %0, %1, %2" : "+v"(d) : "v"(op[v]), "v"(f[v]));
+                            pd[2][i] = d;
+                        }
+                    }
                 }
                 // the 3·NTAP partial dots of this step, by canonical slot p·NTAP + i; slot j·CL + c belongs to lane c, register j
                 if constexpr (CL == 8) {
                     // eight slots at a time: the transposed reduction leaves the total of slot 8j + c in lane c
                     lat_static_for<0, RJ>([&](auto J) {
                         constexpr int j = decltype(J)::value;
+                        if (!FULL && ((mask >> (8 * j)) & 0xffu) == 0) return;   // none of these eight displacements occurs
                         auto sl = [&](auto E) -> float {      // partial dot of canonical slot 8j + e
                             constexpr int slot = 8 * j + decltype(E)::value;
                             if constexpr (slot < NS) return pd[slot / NTAP][slot % NTAP];
@@ -585,29 +844,34 @@ __global__ __launch_bounds__(NT, 4) void march_kernel(const MarchParams P) {
                     for (int p = 0; p < 3; ++p) {
 #pragma unroll
                         for (int i = 0; i < NTAP; ++i) {
-                            const float tot = group_sum<float, CL>(pd[p][i]);
-                            const int slot = p * NTAP + i;
-                            float& r = p == 0 ? rN[slot / CL] : (p == 1 ? rC[slot / CL] : rP[slot / CL]);
-                            r = c == slot % CL ? tot : r;
+                            if (has(p * NTAP + i)) {
+                                const float tot = group_sum<float, CL>(pd[p][i]);
+                                const int slot = p * NTAP + i;
+                                float& r = p == 0 ? rN[slot / CL] : (p == 1 ? rC[slot / CL] : rP[slot / CL]);
+                                r = c == slot % CL ? tot : r;
+                            }
                         }
                     }
                 }
+              }
                 // 5. target s-1 is complete: its dots go to the stage row at their STORED positions
                 if (s >= 2) {
-                    const bool plain = oP.cls == P.ident;
+                    const bool plain = FULL && oP.cls == P.ident;
 #pragma unroll
                     for (int j = 0; j < RJ; ++j) {
                         const int slot = j * CL + c;
-                        if (slot < NS) {
+                        if (slot < NS && has(slot)) {
                             const int k = plain ? slot : (int)kidx_s[oP.cls * 32 + slot];
-                            st[k] = P.alpha * rP[j];
+                            if (UNIF || k != 0xFF) st[k] = P.alpha * rP[j];
                         }
                     }
+                    if constexpr (PTR) fl_start = oP.start;
+                    else fl_start = plane_base(x_out) + plane_cx(x_out) * own_const;
+                    fl_len = (FULL && UNIF) ? NS : (int)kidx_s[oP.cls * 32 + 31];
                     staged = true;
                 }
-            } else if (s >= 2) {
-                staged = true;     // keeps x_out in step for lanes without a row (flush() only advances it)
             }
+            if (s >= 2) x_out = wrap(x_out + 1, P.nx);
 #pragma unroll
             for (int j = 0; j < RJ; ++j) {
                 rP[j] = rC[j];
@@ -643,18 +907,18 @@ inline int march_layout(MarchParams& P, int mode, int cl, int nt, int ntap) {
     return (int)o;
 }
 
-template <typename V, int CL, int MODE, int NT>
+template <typename V, int CL, int MODE, int NT, uint32_t MASK, int ROWS>
 int march_launch(const MarchParams& P, hipStream_t stream) {
     static std::atomic<uint64_t> allowed{0};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return TSGU_ERR_RUNTIME;
     if (!(allowed.load(std::memory_order_acquire) >> dev & 1ull)) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&march_kernel<V, CL, MODE, NT, 9>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&march_kernel<V, CL, MODE, NT, 9, MASK, ROWS>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 kLatMaxLds) != hipSuccess)
             return TSGU_ERR_RUNTIME;
         allowed.fetch_or(1ull << dev, std::memory_order_release);
     }
-    hipLaunchKernelGGL((march_kernel<V, CL, MODE, NT, 9>), dim3((unsigned)P.nblocks), dim3(NT), (size_t)P.lds_bytes, stream, P);
+    hipLaunchKernelGGL((march_kernel<V, CL, MODE, NT, 9, MASK, ROWS>), dim3((unsigned)P.nblocks), dim3(NT), (size_t)P.lds_bytes, stream, P);
     return check_launch();
 }
 

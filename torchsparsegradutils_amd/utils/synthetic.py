@@ -36,6 +36,49 @@ def stencil27_periodic(nx: int, ny: int, nz: int, index_dtype=torch.int32, devic
     return crow, col
 
 
+def box_stencil(nx: int, ny: int, nz: int, periodic=(True, True, True), points: int = 27, part: str = None, index_dtype=torch.int32,
+                device="cpu") -> Tuple[torch.Tensor, torch.Tensor]:
+    """Pattern of a box stencil on an nx×ny×nz grid: the displacements of the 27-point box or the 7-point cross (`part`: only its
+    "lower" / "upper" triangular half by displacement, "strict_lower" / "strict_upper" without the diagonal) that lead to an
+    existing neighbour — wrapped around in the dimensions flagged `periodic`, dropped beyond a face of the others (the
+    truncated neighbourhoods ``encoders/pairwise_encoder.py`` emits).  Column indices sorted inside each row.  Returns (crow, col)."""
+    if min(nx, ny, nz) < 3:
+        raise ValueError("box stencils need every grid dimension >= 3")
+    x, y, z = _grid(nx, ny, nz, device)
+    n = nx * ny * nz
+    cols, keeps = [], []
+    for dx in (-1, 0, 1):
+        for dy in (-1, 0, 1):
+            for dz in (-1, 0, 1):
+                d = (dx, dy, dz)
+                if points == 7 and abs(dx) + abs(dy) + abs(dz) > 1:
+                    continue
+                if (part == "lower" and d > (0, 0, 0)) or (part == "strict_lower" and d >= (0, 0, 0)):
+                    continue
+                if (part == "upper" and d < (0, 0, 0)) or (part == "strict_upper" and d <= (0, 0, 0)):
+                    continue
+                xx, yy, zz = x + dx, y + dy, z + dz
+                keep = torch.ones(n, dtype=torch.bool, device=x.device)
+                if not periodic[0]:
+                    keep &= (xx >= 0) & (xx < nx)
+                if not periodic[1]:
+                    keep &= (yy >= 0) & (yy < ny)
+                if not periodic[2]:
+                    keep &= (zz >= 0) & (zz < nz)
+                cols.append(((xx % nx) * ny + yy % ny) * nz + zz % nz)
+                keeps.append(keep)
+    cols = torch.stack(cols, dim=1)
+    keeps = torch.stack(keeps, dim=1)
+    big = torch.where(keeps, cols, torch.full_like(cols, n))           # dropped entries sort to the end of their row
+    order = torch.sort(big, dim=1)
+    counts = keeps.sum(dim=1)
+    kept = torch.arange(cols.size(1), device=x.device)[None, :] < counts[:, None]
+    col = order.values[kept].to(index_dtype)
+    crow = torch.zeros(n + 1, dtype=torch.int64, device=x.device)
+    crow[1:] = torch.cumsum(counts, 0)
+    return crow.to(index_dtype), col
+
+
 def stencil7_periodic(nx: int, ny: int, nz: int, index_dtype=torch.int32, device="cpu"):
     """Periodic 7-point stencil pattern (7 entries per row, sorted columns)."""
     if min(nx, ny, nz) < 3:
