@@ -116,13 +116,20 @@ def c5_leg(dev, world, rank, steps, warmup, barrier):
     crow1, col1 = synthetic.stencil27_periodic(nx, ny, nz, torch.int32, device=dev)
     nnz = col1.numel()
     lo, hi = parallel.shard_bounds(batch, world, rank)
-    g = torch.Generator(device=dev).manual_seed(1234)  # same full batch on every rank (only the local slice is used)
-    val = torch.randn((batch, nnz), device=dev, generator=g).to(torch.bfloat16)
-    B = torch.randn((batch, n, p), device=dev, generator=g).to(torch.bfloat16)
-    A = torch.sparse_csr_tensor(crow1.unsqueeze(0).repeat(batch, 1), col1.unsqueeze(0).repeat(batch, 1), val, (batch, n, n))
-    A_loc = parallel.shard_batched_csr(A, rank, world).requires_grad_(True)
-    B_loc = B[lo:hi].clone().requires_grad_(True)
-    G_loc = torch.randn((hi - lo, n, p), device=dev, generator=g).to(torch.bfloat16)
+    nloc = hi - lo
+    # a rank allocates ITS items only (item i is seeded by i: the job's data do not depend on the number of ranks)
+    val = torch.empty((nloc, nnz), device=dev, dtype=torch.bfloat16)
+    B_loc = torch.empty((nloc, n, p), device=dev, dtype=torch.bfloat16)
+    G_loc = torch.empty((nloc, n, p), device=dev, dtype=torch.bfloat16)
+    for i in range(lo, hi):
+        g = torch.Generator(device=dev).manual_seed(1234 + i)
+        val[i - lo] = torch.randn(nnz, device=dev, generator=g).to(torch.bfloat16)
+        B_loc[i - lo] = torch.randn((n, p), device=dev, generator=g).to(torch.bfloat16)
+        G_loc[i - lo] = torch.randn((n, p), device=dev, generator=g).to(torch.bfloat16)
+    A_own = torch.sparse_csr_tensor(crow1.unsqueeze(0).repeat(nloc, 1), col1.unsqueeze(0).repeat(nloc, 1), val, (nloc, n, n))
+    A_loc = A_own.detach().requires_grad_(True)
+    B_own = B_loc
+    B_loc = B_loc.detach().requires_grad_(True)
 
     def fwd_local():
         return sparse_mm(A_loc, B_loc)
@@ -132,10 +139,10 @@ def c5_leg(dev, world, rank, steps, warmup, barrier):
         torch.autograd.grad(C, (A_loc, B_loc), G_loc)
 
     def fwd_gathered():
-        return parallel.sharded_batched_apply(sparse_mm, A, B, gather=True)
+        return parallel.sharded_batched_apply(sparse_mm, A_own, B_own, gather=True, batch=batch)
 
     def fwd_gathered_overlap():
-        return parallel.sharded_batched_apply(sparse_mm, A, B, gather=True, overlap_chunks=min(4, hi - lo))
+        return parallel.sharded_batched_apply(sparse_mm, A_own, B_own, gather=True, overlap_chunks=min(4, hi - lo), batch=batch)
 
     def timed(fn):
         # a rank that fails in its warm-up must not leave the others waiting in the barrier below: agree first
@@ -172,7 +179,9 @@ def c5_leg(dev, world, rank, steps, warmup, barrier):
     ms_fb = timed(fwd_bwd_local)
     out = {
         "workload": f"C5: batched CSR SpMM, {batch} items of periodic 27-pt {nx}x{ny}x{nz} (N={n}, nnz={nnz}), {p} RHS, bf16 values / "
-                    f"int32 indices, {world} rank(s) x {hi - lo} items, sharded by parallel.sharded_batched_apply",
+                    f"int32 indices, {world} rank(s) x {hi - lo} items, sharded by parallel.sharded_batched_apply (every rank "
+                    "allocates its own items only)",
+        "resident_bytes_per_rank": int(val.numel() * 2 + 2 * B_loc.numel() * 2 + nloc * (crow1.numel() + col1.numel()) * 4),
         "algorithmic_bytes_fwd_whole_job": ab["spmm"],
         "bytes_note": "algorithmic bytes are those of a CSR kernel (crow, col, values, B in, C out: SURVEY 8d); the plane sweeps this "
                       "lattice pattern runs on read no column index (906 MB of the 1929 MB), so their HBM traffic is ~1.05 GB per "
@@ -191,6 +200,102 @@ def c5_leg(dev, world, rank, steps, warmup, barrier):
     return out
 
 
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port <free> bench.py <same arguments>` as a CHILD process (never an exec: the ranks are
+    fresh processes that initialise their GPU themselves) and return its exit code; rank 0's JSON line goes to our stdout."""
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # the host driver only supports dmabuf IPC (RCCL over xGMI needs it)
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.run(cmd, env=env).returncode
+
+
+PATTERNS = (
+    # name, generator, RHS columns, what it stands for
+    ("c2_7pt_periodic", lambda sy, dev: sy.box_stencil(100, 100, 100, (True,) * 3, 7, None, torch.int32, dev), 32,
+     "periodic 7-point stencil on 100^3 (BASELINE configs[1] names '7-pt/27-pt')"),
+    ("c2_27pt_truncated", lambda sy, dev: sy.box_stencil(100, 100, 100, (False,) * 3, 27, None, torch.int32, dev), 32,
+     "27-point neighbourhoods truncated at the faces of 100^3: what PairwiseEncoder emits (encoders/pairwise_encoder.py:562-849)"),
+    ("c2_27pt_truncated_lower", lambda sy, dev: sy.box_stencil(100, 100, 100, (False,) * 3, 27, "lower", torch.int32, dev), 32,
+     "lower triangular part of the truncated 27-point stencil: the factor pattern of distributions/sparse_multivariate_normal.py:370-387"),
+    ("mesh27_blocked", lambda sy, dev: sy.mesh27_blocked(100, 100, 100, 4, torch.int32, dev), 32,
+     "NOT a lattice: the truncated 27-point neighbourhood graph of 100^3 numbered brick by brick (4^3 points per brick), a partitioned-mesh ordering"),
+    ("cfd2_shaped", lambda sy, dev: sy.banded_random(123440, 25, 2048, torch.int32, dev, seed=0), 128,
+     "the shape of the reference's SuiteSparse benchmark: N=123,440, ~25 entries per row inside a band, 128 RHS "
+     "(benchmarks/results/sparse_mm_suite_results.csv:5-6)"),
+)
+
+
+def patterns_leg(dev, steps, warmup, headline):
+    """The same step (sparse_mm forward + backward through the autograd API, fp32 / int32) on the patterns the headline
+    workload does NOT cover: other stencils of the same lattice, a non-lattice mesh ordering and a banded random matrix.
+    Per pattern: ms per step, the algorithmic fraction of the 8 TB/s roofline (SURVEY 8d bytes: forward + minimum fused
+    backward) and — where profiles/hbm_traffic.json holds rocprofv3 PMC bytes for the pattern — the wire fraction."""
+    from torchsparsegradutils_amd import _ops, _pattern, sparse_mm, wait_for_plans
+    from torchsparsegradutils_amd.utils import synthetic
+
+    wire = {}
+    try:
+        wire = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json"))).get("patterns", {})
+    except Exception:  # noqa: BLE001
+        wire = {}
+    out = {"c2_27pt_periodic": headline}
+    for name, gen, p, what in PATTERNS:
+        try:
+            _pattern.clear_cache()
+            torch.cuda.empty_cache()
+            crow, col = gen(synthetic, dev)
+            n, nnz = crow.numel() - 1, col.numel()
+            g = torch.Generator(device=dev).manual_seed(7)
+            A = torch.sparse_csr_tensor(crow, col, torch.randn(nnz, device=dev, generator=g), (n, n)).requires_grad_(True)
+            B = torch.randn(n, p, device=dev, generator=g).requires_grad_(True)
+            G = torch.randn(n, p, device=dev, generator=g)
+
+            def step():
+                torch.autograd.grad(sparse_mm(A, B), (A, B), G)
+
+            for _ in range(max(warmup, 4)):
+                step()
+            wait_for_plans()
+            for _ in range(4):          # (structured plans are taken from the use after they are ready; tuned configurations from their third use)
+                step()
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step()
+            torch.cuda.synchronize(dev)
+            ms = (time.perf_counter() - t0) / steps * 1e3
+            ab = alg_bytes(n, nnz, p)["fwd_bwd"]
+            plan = _pattern.from_csr(A.detach())
+            lp = plan.core.own.get("lattice")
+            if lp is not None and lp._march and any(c is not None for c in lp._march._cfg.values()):
+                fam = "plane march"
+            elif lp is not None and any(c is not None for c in lp._cfg.values()):
+                fam = "plane sweep"
+            elif any(v is not None for v in plan.core.packs.values()) or (
+                    plan.core.t is not None and any(v is not None for v in plan.core.t.core.packs.values())):
+                fam = "row pairs"
+            else:
+                fam = "plan-free gather"
+            tr = wire.get(name)
+            out[name] = {"what": what, "n": n, "nnz": nnz, "rhs": p, "kernels": fam, "ms_per_step": round(ms, 5),
+                         "algorithmic_bytes_per_step": ab, "frac": round(ab / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         "traffic": tr, "frac_wire": None if tr is None else round(tr / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            del A, B, G, crow, col, plan, lp
+        except Exception as exc:  # noqa: BLE001  (never lose the headline line to a secondary leg)
+            out[name] = {"what": what, "error": repr(exc)}
+    _pattern.clear_cache()
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -200,14 +305,18 @@ def main():
     ap.add_argument("--rhs", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-c5", action="store_true")
+    ap.add_argument("--no-patterns", action="store_true")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # bare `python bench.py --gpus N`: this process has made no GPU call yet — it starts the N ranks as fresh child processes
+        # (torch.distributed.run, one rank per GPU, rendezvous on 127.0.0.1), passes their output through and leaves with their code
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"bench.py --gpus {args.gpus} was started inside a job of WORLD_SIZE={world}")
     # test hook (tools/bench_world2_one_gpu.sh): exercise the N > 1 code path on a ONE-GPU box — every rank on cuda:0, gloo
     # instead of RCCL (which refuses two ranks on one device).  Never set by the driver; the numbers of such a run mean nothing.
     test_backend = os.environ.get("TSGU_BENCH_TEST_BACKEND", "")
@@ -381,6 +490,7 @@ def main():
     lat_s = _ops._lattice_cfg(plan, be.LAT_SDDMM, Bd, G)
     lat_t = _ops._lattice_cfg(plan, be.LAT_SPMMT, G)
     lattice = lat_f is not None and lat_s is not None and lat_t is not None
+    lat_f_is_march = lat_f[1] if lat_f is not None else None
     rp_t = rp_f = rp_s = None
     kern_alone = None
 
@@ -442,16 +552,19 @@ def main():
     alt("csr_spmm_kernel perm (K2 alone, plan-free)", ab["spmm_t"], lambda: be.csr_spmm(pt.crow, pt.col, vd, G, n, n, perm=pt.perm))
     dominant = max(kern, key=kern.get)
     traffic = traffic_source = None
+    kern_traffic = {}
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.exists(tpath) and [nx, ny, nz, p] == [100, 100, 100, 32]:
         try:
             tj = json.load(open(tpath))
             traffic = tj.get(traffic_key[dominant])
+            kern_traffic = {nm: tj.get(key) for nm, key in traffic_key.items() if tj.get(key) is not None}
             if traffic is not None:
                 traffic_source = f"{tj.get('source')}@{tj.get('commit')} (rocprofv3 PMC passes; not measured in this run)"
         except Exception:  # noqa: BLE001
             traffic = None
     achieved = kbytes[dominant] / (kern[dominant] * 1e-3) / 1e9
+    step_traffic = sum(kern_traffic.values()) if len(kern_traffic) == len(kern) else None    # PMC bytes of all kernels of the step
     # device copy ceiling for context
     src = torch.empty(256 * 1024 * 1024 // 4, device=dev)
     dst = torch.empty_like(src)
@@ -481,6 +594,20 @@ def main():
             c5 = c5_leg(dev, world, rank, args.steps, args.warmup, barrier)
         except Exception as exc:  # noqa: BLE001  (never lose the headline line to the secondary leg)
             c5 = {"error": repr(exc)}
+
+    patterns = None
+    if rank == 0 and world == 1 and not args.no_patterns:
+        headline = {"what": "the headline workload (this line's value)", "n": n, "nnz": nnz, "rhs": p,
+                    "kernels": "plane march" if lattice and getattr(lat_f_is_march, "march", False) else ("plane sweep" if lattice else "row pairs / plan-free"),
+                    "ms_per_step": round(ms_per_step, 5), "algorithmic_bytes_per_step": ab["fwd_bwd"],
+                    "frac": round(ab["fwd_bwd"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": step_traffic,
+                    "frac_wire": None if step_traffic is None else round(step_traffic / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        if args.no_c5:      # (the C5 leg has already released the headline operands otherwise)
+            del A, B, G, val, crow, col, plan, pt, rp_t, rp_f, rp_s, Bd, vd, lat_f, lat_s, lat_t
+        try:
+            patterns = patterns_leg(dev, args.steps, args.warmup, headline)
+        except Exception as exc:  # noqa: BLE001
+            patterns = {"error": repr(exc)}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -537,6 +664,11 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic,
+                "frac_wire": None if traffic is None else round(traffic / (kern[dominant] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "frac_note": "frac = ALGORITHMIC bytes of a CSR kernel (SURVEY 8d: row pointer, column indices, values, dense operand in, "
+                             "result out) / launch duration / peak; frac_wire = HBM bytes the kernel really moved (rocprofv3 PMC: "
+                             "2*FETCH_SIZE + WRITE_SIZE, profiles/) / the same duration / peak.  The plane-march kernels read no "
+                             "column index, so their wire bytes are below the algorithmic ones",
                 "traffic_source": traffic_source,
                 "avg_launch_ms": round(kern[dominant], 5),
                 "algorithmic_bytes_per_launch": kbytes[dominant],
@@ -544,11 +676,17 @@ def main():
             "kernels_ms": {k: round(v, 5) for k, v in {**kern, **kern_alt}.items()},
             "kernels_ms_in_step": {k: round(v, 5) for k, v in in_step.items()},
             "kernels_ms_alone": None if kern_alone is None else {k: round(v, 5) for k, v in kern_alone.items()},
-            "kernels_GBps": {k: round(kbytes[k] / (v * 1e-3) / 1e9, 1) for k, v in {**kern, **kern_alt}.items()},
+            "kernels_GBps_algorithmic": {k: round(kbytes[k] / (v * 1e-3) / 1e9, 1) for k, v in {**kern, **kern_alt}.items()},
+            "kernels_GBps_wire": {k: round(kern_traffic[k] / (v * 1e-3) / 1e9, 1) for k, v in kern.items() if k in kern_traffic} or None,
+            "kernels_GBps_note": "algorithmic = SURVEY 8d bytes / duration (can exceed the copy ceiling below: a kernel that never reads "
+                                 "the column indices moves fewer bytes than a CSR kernel must); wire = PMC bytes / duration",
             "device_copy_GBps": round(copy_gbs, 1),
             "device_copy16_GBps": round(copy16_gbs, 1),
+            "step_traffic": step_traffic,
+            "frac_of_hbm_peak_wire": None if step_traffic is None else round(step_traffic / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             "cpu_baseline": cpu,
             "c5": c5,
+            "patterns": patterns,
         }
         if allgather is not None:
             line["allgather"] = allgather

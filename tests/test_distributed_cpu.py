@@ -55,7 +55,21 @@ def _worker(rank, world, port, batch, q):
         local = parallel.sharded_batched_apply(_oracle_batched_mm, A, B, gather=False)
         # run-by-run compute with asynchronous gathers (falls back to the single gather for ragged shards)
         piped = parallel.sharded_batched_apply(_oracle_batched_mm, A, B, overlap_chunks=2)
+        # rank-local shards: no rank holds the whole batch
+        A_own = stack_csr(items[lo:hi]) if hi > lo else None
+        own = own_piped = full
+        if A_own is not None:
+            own = parallel.sharded_batched_apply(_oracle_batched_mm, A_own, B[lo:hi].clone(), batch=batch)
+            own_piped = parallel.sharded_batched_apply(_oracle_batched_mm, A_own, B[lo:hi].clone(), batch=batch, overlap_chunks=2)
+            try:
+                parallel.sharded_batched_apply(_oracle_batched_mm, A_own, B[lo:hi], batch=batch + world)
+                wrong_size_raises = False
+            except ValueError:
+                wrong_size_raises = True
+        else:
+            wrong_size_raises = True
         ok = (
+            torch.equal(own, full) and torch.equal(own_piped, full) and wrong_size_raises and
             full.shape == want.shape
             and torch.allclose(full, want, atol=1e-12)
             and piped.shape == want.shape

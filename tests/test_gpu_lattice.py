@@ -7,7 +7,7 @@ import pytest
 import torch
 
 import _golden as G
-import _lattice_ref as ref
+import _lattice_ref as lref
 
 pytestmark = pytest.mark.gpu
 
@@ -74,8 +74,8 @@ def test_lattice_kernels_match_oracle_and_plan_free_kernels_fp32(nb, nx, ny, nz,
     Co, gAo, gBo = _oracle_mm(crow, col, val, B, Gd)
     crow_d, col_d, val_d, B_d, G_d = (t.to(dev) for t in (crow, col, val, B, Gd))
     plan = pt.RowGather(crow_d, col_d, n, n)
-    lp = ref.build_lattice_plan(plan, dims=(nb, nx, ny, nz))
-    ltp = ref.build_lattice_plan(plan.transposed, value_crow=crow_d, dims=(nb, nx, ny, nz))
+    lp = lref.build_lattice_plan(plan, dims=(nb, nx, ny, nz))
+    ltp = lref.build_lattice_plan(plan.transposed, value_crow=crow_d, dims=(nb, nx, ny, nz))
     assert lp is not None and ltp is not None
     C0 = be.csr_spmm(crow_d, col_d, val_d, B_d, n, n)
     gA0 = be.csr_sddmm(crow_d, col_d, G_d, B_d, n, n)
@@ -208,7 +208,7 @@ def test_two_dimensional_lattice():
     g = torch.Generator().manual_seed(5)
     val, B = torch.randn(col.numel(), generator=g), torch.randn(n, 32, generator=g)
     plan = pt.RowGather(crow.to(dev), col.to(dev), n, n)
-    lp = ref.build_lattice_plan(plan)
+    lp = lref.build_lattice_plan(plan)
     assert lp is not None and (lp.nx, lp.ny, lp.nz, lp.ry) == (n1, 1, n2, 0)
     C0 = be.csr_spmm(plan.crow, plan.col, val.to(dev), B.to(dev), n, n)
     for cs in ("1,8,2,256", "1,24,5,512"):
@@ -235,7 +235,7 @@ def test_bf16_forward_and_sddmm():
         Gd = torch.randn(n, p, generator=g).to(torch.bfloat16)
         Co, gAo, _ = _oracle_mm(crow, col, val.float(), B.float(), Gd.float())
         plan = pt.RowGather(crow.to(dev), col.to(dev), n, n)
-        lp = ref.build_lattice_plan(plan)
+        lp = lref.build_lattice_plan(plan)
         assert lp is not None and (lp.nb, lp.nx, lp.ny, lp.nz) == (nb, nx, ny, nz)
         for cs in ("8,8,2,256", "16,16,1,512"):
             lt._CFG_ENV = cs
@@ -293,8 +293,8 @@ def test_padded_entries_touch_nothing():
     val_p = val.clone()
     val_p[::97] = float("inf")      # non-finite VALUES must stay inside their own rows too
     plan = pt.RowGather(crow.to(dev), col.to(dev), n, n)
-    lp = ref.build_lattice_plan(plan, dims=(1, nx, ny, nz))
-    ltp = ref.build_lattice_plan(plan.transposed, value_crow=plan.crow, dims=(1, nx, ny, nz))
+    lp = lref.build_lattice_plan(plan, dims=(1, nx, ny, nz))
+    ltp = lref.build_lattice_plan(plan.transposed, value_crow=plan.crow, dims=(1, nx, ny, nz))
     assert lp is not None and ltp is not None and lp.uniform_len == 0
     lt._CFG_ENV = "4,5,2,256"
     try:
@@ -380,9 +380,9 @@ def test_row_kernels_build_the_same_plans_as_the_tensor_op_builder():
         for idt in (torch.int32, torch.int64):
             plan = pt.RowGather(crow.to(dev).to(idt), col.to(dev).to(idt), n, n)
             dims = (nb, nx, ny, nz)
-            ref = ref.build_lattice_plan(plan, dims=dims)
+            ref = lref.build_lattice_plan(plan, dims=dims)
             got = lt.build_lattice_plan_hip(plan, be, dims=dims)
-            reft = ref.build_lattice_plan(plan.transposed, value_crow=plan.crow, dims=dims)
+            reft = lref.build_lattice_plan(plan.transposed, value_crow=plan.crow, dims=dims)
             gott = lt.build_lattice_plan_hip(plan, be, forward=got)
             for a, b in ((ref, got), (reft, gott)):
                 assert a is not None and b is not None
@@ -390,6 +390,9 @@ def test_row_kernels_build_the_same_plans_as_the_tensor_op_builder():
                     assert getattr(a, f) == getattr(b, f), (f, getattr(a, f), getattr(b, f))
                 assert torch.equal(a.codes, b.codes) and torch.equal(a.lens_host, b.lens_host)
                 assert torch.equal(a.rcls, b.rcls) and torch.equal(a.lens, b.lens)
+                if a.kind == 0:
+                    # the plane-march condition: the row kernel's per-row check against the brute-force statement of the test builder
+                    assert a.box == b.box, (a.box, b.box)
                 if a.kind == 1:
                     assert torch.equal(a.ksrc, b.ksrc)
                 for ty, tz, nseg in ((4, 4, 2), (3, 5, 1), (8, 8, 3)):

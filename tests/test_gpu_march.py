@@ -145,9 +145,11 @@ BOX_GPU_CASES = [
 @pytest.mark.parametrize("per,points,part,nb,grid,configs", BOX_GPU_CASES)
 @pytest.mark.parametrize("p", [32, 64, 16])
 def test_box_variants_match_oracle_and_plan_free_kernels(per, points, part, nb, grid, configs, p):
-    """Truncated / 7-point / triangular / mixed-periodicity box stencils on the plane-march kernels: parity with the oracle;
-    gradA bit-identical to the plan-free SDDMM; C and gradB bit-identical to the plan-free kernels on every row that stores its
-    entries in ascending displacement order — ALL rows of a truncated lattice — and to rounding on rows that wrap."""
+    """Truncated / mixed-periodicity 27-point boxes on the plane-march kernels (all three products), the triangular halves on
+    the plane-march SDDMM: parity with the oracle; gradA bit-identical to the plan-free SDDMM; C and gradB bit-identical to the
+    plan-free kernels on every row that stores its entries in ascending displacement order — ALL rows of a truncated lattice —
+    and to rounding on rows that wrap.  7-point stencils have no plane-march kernels (the general sweep is faster); whatever the
+    selection takes per product gives the oracle's results."""
     from test_lattice_plan_cpu import _box_stencil
 
     be, lt, pt = _mods()
@@ -178,6 +180,8 @@ def test_box_variants_match_oracle_and_plan_free_kernels(per, points, part, nb, 
     t = plan.transposed
     gB0 = be.csr_spmm(t.crow, t.col, val_d, G_d, n, n, perm=t.perm)
     ran = 0
+    full = mt.full
+    tri = part is not None                      # triangular halves: the SDDMM has plane-march kernels (one workgroup size), the products do not
     for cs in configs:
         groups = cs[3] // (p // 4)
         if groups < cs[0] * cs[1] or 2 * groups < (cs[0] + 2) * (cs[1] + 2):
@@ -188,19 +192,39 @@ def test_box_variants_match_oracle_and_plan_free_kernels(per, points, part, nb, 
             cf = [be.march_config(lp, m, torch.float32, p) for m in (be.LAT_SPMM, be.LAT_SDDMM, be.LAT_SPMMT)]
         finally:
             lt._MARCH_CFG_ENV = ""
-        assert all(c is not None for c in cf), cs
-        C = be.csr_spmm_lattice(lp, cf[0], val_d, B_d)
-        gA = be.csr_sddmm_lattice(lp, cf[1], G_d, B_d)
-        gB = be.csr_spmm_lattice(lp, cf[2], val_d, G_d)
-        assert G.rel_err(C.cpu().numpy(), Co) < 1e-5, cs
-        assert G.rel_err(gA.cpu().numpy(), gAo) < 1e-5, cs
-        assert G.rel_err(gB.cpu().numpy(), gBo) < 1e-5, cs
-        if p >= 32:
-            assert torch.equal(gA, gA0), cs
-            assert torch.equal(C[inner], C0[inner]) and torch.equal(gB[inner], gB0[inner]), cs
-        ran += 1
+        if full:
+            assert all(c is not None for c in cf), cs
+        else:
+            assert cf[0] is None and cf[2] is None, cs              # (faster on the general sweep: no kernels compiled)
+            assert (cf[1] is not None) == (tri and be.march_supported(be.LAT_SDDMM, mt.mask, lp.uniform_len, cs[3])), cs
+        if cf[1] is not None:
+            gA = be.csr_sddmm_lattice(lp, cf[1], G_d, B_d)
+            assert G.rel_err(gA.cpu().numpy(), gAo) < 1e-5, cs
+            if p >= 32:
+                assert torch.equal(gA, gA0), cs
+            ran += 1
+        if full:
+            C = be.csr_spmm_lattice(lp, cf[0], val_d, B_d)
+            gB = be.csr_spmm_lattice(lp, cf[2], val_d, G_d)
+            assert G.rel_err(C.cpu().numpy(), Co) < 1e-5, cs
+            assert G.rel_err(gB.cpu().numpy(), gBo) < 1e-5, cs
+            if p >= 32:
+                assert torch.equal(C[inner], C0[inner]) and torch.equal(gB[inner], gB0[inner]), cs
     mt._cfg.clear()
-    assert ran >= 1 or p == 64          # (64 columns: 16 lanes per row, the smaller tiles of a case may be all there is room for)
+    # (64 columns: the smaller tiles of a case may be all there is room for; triangular halves: only the 512-thread SDDMM exists)
+    assert ran >= 1 or p == 64 or not full
+    # whatever the selection takes for this pattern (plane march / general sweep per product): the same results
+    from torchsparsegradutils_amd import _ops
+
+    keep = _ops.PACK_MIN_NNZ
+    _ops.PACK_MIN_NNZ = 1
+    try:
+        C = _ops.spmm(plan, val_d, B_d)
+        gA = _ops.sddmm(plan, G_d, B_d)
+        gB = _ops.spmm_t(plan, val_d, G_d)
+    finally:
+        _ops.PACK_MIN_NNZ = keep
+    assert G.rel_err(C.cpu().numpy(), Co) < 1e-5 and G.rel_err(gA.cpu().numpy(), gAo) < 1e-5 and G.rel_err(gB.cpu().numpy(), gBo) < 1e-5
 
 
 @pytest.mark.parametrize("per,points,part", [((False, False, False), 27, None), ((False, False, False), 7, None), ((True, True, True), 7, None),
@@ -224,13 +248,22 @@ def test_no_row_touches_a_dense_row_it_does_not_reference(per, points, part):
         B[r, r % p] = bad
         Gd[(r + 7) % n, (r + 1) % p] = bad
     B_d, G_d = B.to(dev), Gd.to(dev)
+    from torchsparsegradutils_amd import _ops
+
     plan = pt.RowGather(crow.to(dev), col.to(dev), n, n)
-    lp = lt.build_lattice_plan_hip(plan, be)
-    cf = [be.march_config(lp, m, torch.float32, p) for m in (be.LAT_SPMM, be.LAT_SDDMM, be.LAT_SPMMT)]
-    assert all(c is not None for c in cf)
-    C = be.csr_spmm_lattice(lp, cf[0], val, B_d)
-    gA = be.csr_sddmm_lattice(lp, cf[1], G_d, B_d)
-    gB = be.csr_spmm_lattice(lp, cf[2], val, G_d)
+    keep = _ops.PACK_MIN_NNZ
+    _ops.PACK_MIN_NNZ = 1
+    try:
+        # the kernels the selection takes for this pattern: plane march (whole box; the SDDMM of triangular halves), general sweep
+        C = _ops.spmm(plan, val, B_d)
+        gA = _ops.sddmm(plan, G_d, B_d)
+        gB = _ops.spmm_t(plan, val, G_d)
+    finally:
+        _ops.PACK_MIN_NNZ = keep
+    lp = plan.core.own.get("lattice")
+    assert lp is not None and lp.box is not None
+    if points == 27 and part is None:
+        assert lp._march and len([c for c in lp._march._cfg.values() if c is not None]) == 3
     C0 = be.csr_spmm(plan.crow, plan.col, val, B_d, n, n)
     gA0 = be.csr_sddmm(plan.crow, plan.col, G_d, B_d, n, n)
     t = plan.transposed
@@ -239,6 +272,59 @@ def test_no_row_touches_a_dense_row_it_does_not_reference(per, points, part):
         assert torch.equal(torch.isfinite(got), torch.isfinite(want))
         fin = torch.isfinite(want)
         assert float((got[fin] - want[fin]).abs().max()) < 1e-4
+
+
+FUSED_CASES = [
+    # per, nb, (nx, ny, nz), configs (ty, tz, nseg)
+    ((True, True, True), 1, (9, 10, 12), [(4, 8, 2), (4, 8, 9), (2, 8, 3)]),       # periodic, ragged tiles, one-plane segments
+    ((True, True, True), 1, (3, 3, 3), [(4, 8, 1), (4, 8, 3)]),                    # every row wraps
+    ((False, False, False), 1, (9, 10, 12), [(4, 8, 2), (4, 8, 9), (4, 8, 1)]),    # truncated box
+    ((False, False, False), 3, (5, 6, 8), [(4, 8, 2), (2, 8, 5)]),                 # ... batched items
+    ((True, False, False), 1, (5, 8, 8), [(4, 8, 2)]),                             # wraps in x only
+    ((False, True, True), 1, (6, 7, 9), [(4, 8, 3)]),                              # truncated in x only
+    ((False, False, False), 1, (3, 3, 3), [(4, 8, 1), (4, 8, 3)]),
+]
+
+
+@pytest.mark.parametrize("per,nb,grid,configs", FUSED_CASES)
+def test_fused_backward_march_equals_the_two_launches(per, nb, grid, configs):
+    """csrc/march_bwd_impl.h: both gradients of C = A·B in one march (the G ring serves the transposed product and the SDDMM's
+    own rows).  Same sums in the same order as the two plane-march launches: gradA and gradB bit for bit, and the oracle."""
+    from test_lattice_plan_cpu import _box_stencil
+
+    be, lt, pt = _mods()
+    dev = torch.device("cuda:0")
+    nx, ny, nz = grid
+    p = 32
+    crow, col = _box_stencil(nx, ny, nz, per, 27, None, nb)
+    n = nb * nx * ny * nz
+    g = torch.Generator().manual_seed(nx * 17 + nb)
+    val = torch.randn(col.numel(), generator=g)
+    B = torch.randn(n, p, generator=g)
+    Gd = torch.randn(n, p, generator=g)
+    _, gAo, gBo = _oracle_mm(crow, col, val, B, Gd)
+    val_d, B_d, G_d = val.to(dev), B.to(dev), Gd.to(dev)
+    plan = pt.RowGather(crow.to(dev), col.to(dev), n, n)
+    lp = lt.build_lattice_plan_hip(plan, be, dims=(nb, nx, ny, nz))
+    mt = lt.march_tables(lp)
+    assert mt is not None and mt.full
+    for cs in configs:
+        lt._MARCH_CFG_ENV = ",".join(str(v) for v in cs + (256,))
+        try:
+            mt._cfg.clear()
+            c_s = be.march_config(lp, be.LAT_SDDMM, torch.float32, p)
+            c_t = be.march_config(lp, be.LAT_SPMMT, torch.float32, p)
+            c_b = be.march_config(lp, be.MARCH_BWD, torch.float32, p)
+        finally:
+            lt._MARCH_CFG_ENV = ""
+        assert c_s is not None and c_t is not None and c_b is not None, cs
+        gA2 = be.csr_sddmm_lattice(lp, c_s, G_d, B_d, alpha=-0.75)
+        gB2 = be.csr_spmm_lattice(lp, c_t, val_d, G_d)
+        gA, gB = be.csr_mm_backward_march(lp, c_b, val_d, G_d, B_d, alpha=-0.75)
+        assert torch.equal(gA, gA2) and torch.equal(gB, gB2), cs
+        assert G.rel_err(gA.cpu().numpy(), -0.75 * gAo) < 1e-5 and G.rel_err(gB.cpu().numpy(), gBo) < 1e-5, cs
+    mt._cfg.clear()
+    assert be.march_config(lp, be.MARCH_BWD, torch.float32, 64) is None          # 32 columns only
 
 
 def test_wide_operands_run_as_column_tiles():
@@ -415,7 +501,8 @@ def test_full_size_c2_on_the_product_path(monkeypatch):
     core = _pattern.from_csr(A.detach()).core
     lp = core.own.get("lattice")
     assert lp is not None and lp._march and core.own.get("lattice_t") is None and core.t is None   # no transposed plan / pattern
-    assert all(c is not None for c in lp._march._cfg.values()) and len(lp._march._cfg) == 3
+    used = {k: c for k, c in lp._march._cfg.items() if c is not None}
+    assert {k[0] for k in used} == {0, 1, 2}      # forward, SDDMM, transposed product: all on the plane march
     C2 = sparse_mm(A.detach(), 2.0 * B.detach())
     assert float((C2 - 2 * C.detach()).abs().max()) == 0.0  # scaling by 2 is exact in fp32
     lhs = float((C.detach().double() * Gd.double()).sum())
@@ -500,7 +587,7 @@ def test_randomised_stencils_through_the_public_path(monkeypatch):
             Gdev = Gd.to(dt).to(dev)
         C = sparse_mm(A, Bd)
         C.backward(Gdev)
-        tol = {torch.float32: 2e-5, torch.float64: 1e-12, torch.bfloat16: 2e-2}[dt]
+        tol = {torch.float32: 2e-5, torch.float64: 1e-12, torch.bfloat16: 4e-3}[dt]      # bf16: its unit roundoff 2^-8 (the result is rounded once)
         what = (nb, nx, ny, nz, periodic, points, dt, p)
         assert G.rel_err(C.detach().double().cpu().reshape(Cref.shape).numpy(), Cref.numpy()) < tol, what
         assert G.rel_err(A.grad.values().double().cpu().reshape(gAref.shape).numpy(), gAref.numpy()) < tol, what
@@ -515,5 +602,5 @@ def test_randomised_stencils_through_the_public_path(monkeypatch):
         else:
             took["other"] += 1
         _pattern.clear_cache()
-    assert took["march"] >= 8 and took["sweep"] >= 8, took
+    assert took["march"] >= 2 and took["sweep"] >= 8, took
 

@@ -226,3 +226,47 @@ def test_ctypes_signatures_agree_with_the_header_prototypes():
         assert got == want, (name, got, want)
         seen.add(name)
     assert seen == set(_backend.SIGNATURES)
+
+
+def test_cpu_tensors_raise_the_documented_error():
+    """INTEGRATION.md, "CPU tensors": the package is the MI355X path and nothing else — operands on the CPU are refused with ONE
+    documented message by every entry point (never computed on a fallback; tests/test_host_logic.py::
+    test_product_never_imports_the_oracle keeps the oracle out of the package)."""
+    import warnings
+
+    import torchsparsegradutils_amd as m
+
+    A = torch.eye(4).to_sparse_csr()
+    B = torch.ones(4, 2)
+    msg = "torchsparsegradutils_amd runs on AMD MI355X (gfx950) only: got a tensor on 'cpu'. There is no CPU path; move the operands to the GPU."
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for call in (lambda: m.sparse_mm(A, B),
+                     lambda: m.sparse_mm(torch.eye(4).to_sparse_coo(), B),
+                     lambda: m.sparse_triangular_solve(A, B, upper=False),
+                     lambda: m.sparse_generic_solve(A, B),
+                     lambda: m.linalg_solve_triangular_compat(A, B, upper=False)):
+            with pytest.raises(RuntimeError) as e:
+                call()
+            assert str(e.value) == msg
+
+
+def test_compat_dense_branch_is_the_reference_dispatch():
+    """reference _compat.py:17-34: dense operands go to torch.linalg.solve_triangular, `transpose` as a transposed view with
+    `upper` flipped — all eight flag combinations, and the keyword-only signature."""
+    import inspect
+
+    from torchsparsegradutils_amd import linalg_solve_triangular_compat
+
+    sig = inspect.signature(linalg_solve_triangular_compat)
+    assert [p.kind for p in sig.parameters.values()][2:] == [inspect.Parameter.KEYWORD_ONLY] * 3
+    assert sig.parameters["unitriangular"].default is False and sig.parameters["transpose"].default is False
+    g = torch.Generator().manual_seed(0)
+    T = torch.randn(5, 5, generator=g, dtype=torch.float64) + 5 * torch.eye(5, dtype=torch.float64)
+    B = torch.randn(5, 2, generator=g, dtype=torch.float64)
+    for upper in (False, True):
+        for unit in (False, True):
+            for tr in (False, True):
+                x = linalg_solve_triangular_compat(T, B, upper=upper, unitriangular=unit, transpose=tr)
+                want = torch.linalg.solve_triangular(T.transpose(-2, -1) if tr else T, B, upper=(not upper) if tr else upper, unitriangular=unit)
+                assert torch.equal(x, want)

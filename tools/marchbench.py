@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--modes", default="fwd,sddmm,spmmt")
     ap.add_argument("--nocheck", action="store_true")
     ap.add_argument("--force-rstart", action="store_true", help="run the row-pointer (non-uniform) kernels on a uniform pattern")
+    ap.add_argument("--ab-rows", action="store_true", help="uniform pattern: alternate the uniform-row and the box-arithmetic kernels in one process")
     ap.add_argument("--pattern", default="per27", help="per27 | trunc27 | per7 | trunc7 | lower27 | upper27 | slower27 | lower7 | xper27")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -63,7 +64,7 @@ def main():
     B = torch.randn(n, p, device=dev).to(dt)
     G = torch.randn(n, p, device=dev).to(dt)
     by = {"fwd": (n + b) * 4 + nnz * 8 + 2 * n * p * 4, "spmmt": (n + b) * 4 + nnz * 8 + 2 * n * p * 4,
-          "sddmm": (n + b) * 4 + nnz * 4 + 2 * n * p * 4 + nnz * 4}
+          "sddmm": (n + b) * 4 + nnz * 4 + 2 * n * p * 4 + nnz * 4, "bwd": (n + b) * 4 + nnz * 8 + 2 * n * p * 4 + nnz * 4 + n * p * 4}
     modes = a.modes.split(",")
     lp = lt.build_lattice_plan_hip(plan, be)
     mt = lt.march_tables(lp) if lp is not None else None
@@ -76,16 +77,16 @@ def main():
     if not a.nocheck:
         if "fwd" in modes:
             ref["fwd"] = be.csr_spmm(crow, col, val, B, n, n)
-        if "sddmm" in modes:
+        if "sddmm" in modes or "bwd" in modes:
             ref["sddmm"] = be.csr_sddmm(crow, col, G, B, n, n)
-        if "spmmt" in modes:
+        if "spmmt" in modes or "bwd" in modes:
             pt = plan.transposed
             ref["spmmt"] = be.csr_spmm(pt.crow, pt.col, val, G, n, n, perm=pt.perm)
     for cs in a.cfg or [""]:
         lt._MARCH_CFG_ENV = cs
         mt._cfg.clear()
         for m in modes:
-            mode = {"fwd": be.LAT_SPMM, "sddmm": be.LAT_SDDMM, "spmmt": be.LAT_SPMMT}[m]
+            mode = {"fwd": be.LAT_SPMM, "sddmm": be.LAT_SDDMM, "spmmt": be.LAT_SPMMT, "bwd": be.MARCH_BWD}[m]
             cfg = be.march_config(lp, mode, dt, p)
             if cfg is not None and a.force_rstart and cfg.struct.uniform_len:
                 keep = crow.to(torch.int32).contiguous()
@@ -98,12 +99,18 @@ def main():
                 fn = lambda: be.csr_spmm_lattice(lp, cfg, val, B)  # noqa: E731
             elif m == "sddmm":
                 fn = lambda: be.csr_sddmm_lattice(lp, cfg, G, B)  # noqa: E731
+            elif m == "bwd":
+                fn = lambda: be.csr_mm_backward_march(lp, cfg, val, G, B)  # noqa: E731
             else:
                 fn = lambda: be.csr_spmm_lattice(lp, cfg, val, G)  # noqa: E731
             out = fn()
             torch.cuda.synchronize()
             err = ""
-            if m in ref:
+            if m == "bwd":
+                if "sddmm" in ref and "spmmt" in ref:
+                    err = (f" gradA equal: {torch.equal(out[0], ref['sddmm'])} gradB maxdiff {(out[1] - ref['spmmt']).abs().max().item():.3g}"
+                           f" rows bit-equal {(out[1] == ref['spmmt']).all(1).float().mean().item():.4f}")
+            elif m in ref:
                 r = ref[m]
                 d = (out - r).abs().max().item()
                 scale = r.abs().max().item()
@@ -115,6 +122,17 @@ def main():
                     eq_rows = (out == r).all(1)
                 err = (f" maxdiff={d:.3g} (scale {scale:.3g}) rows bit-equal: {eq_rows.float().mean().item():.4f}"
                        f" canonical rows bit-equal: {eq_rows[ident_rows].float().mean().item():.4f}")
+            if a.ab_rows and cfg.struct.uniform_len:
+                keep = crow.to(torch.int32).contiguous()
+                globals().setdefault("_KEEP", []).append(keep)
+                uni = cfg.struct.uniform_len
+                for rep in range(3):
+                    cfg.struct.uniform_len = uni
+                    t_u = ev(fn, a.reps)
+                    cfg.struct.uniform_len, cfg.struct.rstart = 0, keep.data_ptr()
+                    t_b = ev(fn, a.reps)
+                    print(f"{m:6s} alternation {rep}: uniform rows {t_u * 1e3:7.1f} us   box arithmetic {t_b * 1e3:7.1f} us", flush=True)
+                cfg.struct.uniform_len = uni
             ms = ev(fn, a.reps)
             print(f"{m:6s} cfg=({cfg.ty},{cfg.tz},{cfg.nseg},{cfg.threads}) lds={cfg.lds_bytes}: {ms * 1e3:8.1f} us  {by[m] / ms / 1e6:7.0f} GB/s{err}", flush=True)
 

@@ -6,6 +6,7 @@ kernels behind the C ABI in ``include/tsgu_hip.h``.  GPU only — there is no CP
 """
 
 from ._backend import poll_errors
+from ._compat import linalg_solve_triangular_compat
 from ._pattern import wait_for_plans
 from .sparse_lstsq import SparseGenericLstsq, sparse_generic_lstsq
 from .sparse_matmul import SparseMatMul, sparse_mm
@@ -27,6 +28,7 @@ __all__ = [
     "SparseMatMul",
     "SparseTriangularSolve",
     "SparseGenericSolve",
+    "linalg_solve_triangular_compat",
 ]
 
 __version__ = "0.1.0"

@@ -87,9 +87,11 @@ SIGNATURES = {
     "tsgu_csr_spmm_lattice": (_int, [_int, _ptr, _i64, _i64, _ptr, _ptr, _i64, _ptr, _i64, _i64, _int, _ptr]),
     "tsgu_csr_spmm_lattice_dot": (_int, [_int, _ptr, _i64, _i64, _ptr, _ptr, _i64, _ptr, _i64, _i64, _ptr, _i64, _int, _ptr]),
     "tsgu_csr_sddmm_lattice": (_int, [_int, _ptr, _i64, _i64, _ptr, _i64, _ptr, _i64, _ptr, _dbl, _i64, _int, _ptr]),
+    "tsgu_march_supported": (_int, [_int, _int, _int, _int]),
     "tsgu_march_lds_bytes": (_int, [_int, _int, _i64, _int, _int, _int, _int, _int, _int]),
     "tsgu_csr_spmm_march": (_int, [_int, _ptr, _int, _i64, _i64, _ptr, _ptr, _i64, _ptr, _i64, _i64, _int, _ptr]),
     "tsgu_csr_sddmm_march": (_int, [_int, _ptr, _i64, _i64, _ptr, _i64, _ptr, _i64, _ptr, _dbl, _int, _i64, _int, _ptr]),
+    "tsgu_csr_mm_backward_march": (_int, [_int, _ptr, _i64, _i64, _ptr, _ptr, _i64, _ptr, _i64, _ptr, _dbl, _ptr, _i64, _i64, _int, _ptr]),
     "tsgu_lattice_slots": (_int, []),
     "tsgu_lattice_rows": (_int, [_int, _i64, _ptr, _ptr, _int, _int, _int, _int, _ptr, _int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr,
                                  _int, _int, _int, _ptr]),
@@ -426,6 +428,7 @@ def csr_mm_backward_rowpack(tcrow, rp, val, G, B, n_rows_t: int):
 
 # ---- lattice plane-sweep kernels (csrc/lattice_impl.h; plans from _lattice.py) -------------------------------
 LAT_SPMM, LAT_SDDMM, LAT_SPMMT = 0, 1, 2
+MARCH_BWD = 3        # the fused backward of the plane march (SDDMM + transposed product in one launch)
 
 
 def lattice_lds_bytes(mode: int, vtype: int, p: int, ty: int, tz: int, ry: int, rz: int, nloc: int, recw: int, threads: int,
@@ -498,6 +501,11 @@ def march_lds_bytes(mode: int, vtype: int, p: int, ty: int, tz: int, ry: int, rz
     return int(load_library().tsgu_march_lds_bytes(mode, vtype, p, ty, tz, ry, rz, ncls, threads))
 
 
+def march_supported(mode: int, mask: int, uniform_len: int, threads: int) -> bool:
+    """Is there a plane-march kernel for this product / displacement set / row form / workgroup size (csrc/march_sets.h)?"""
+    return bool(load_library().tsgu_march_supported(mode, mask, uniform_len, threads))
+
+
 def march_config(lp, mode: int, dtype: torch.dtype, p: int):
     """Launch configuration of the plane-march kernels for the stored-order _lattice.LatticePlan `lp`, or None when the pattern
     is not a full periodic box stencil / the operands are not covered (fp32, 32 or 64 columns)."""
@@ -505,7 +513,7 @@ def march_config(lp, mode: int, dtype: torch.dtype, p: int):
 
     if dtype != torch.float32 or lp is None or lp.kind != 0:
         return None
-    return _lattice.march_config_for(lp, mode, _VTYPE[dtype], p, march_lds_bytes)
+    return _lattice.march_config_for(lp, mode, _VTYPE[dtype], p, march_lds_bytes, march_supported)
 
 
 # Per-kernel timing hook (bench.py): a list to which the lattice launchers append (name, start event, end event) recorded on the
@@ -623,6 +631,31 @@ def csr_sddmm_lattice(lp, cfg, R, Cm, alpha: float = 1.0):
     return out
 
 
+def csr_mm_backward_march(lp, cfg, val, G, B, alpha: float = 1.0):
+    """(gradA values in A's stored order, gradB = Aᵀ·G) of C = A·B by ONE plane march (csrc/march_bwd_impl.h)."""
+    lib = _lib or load_library()
+    dev = G.device
+    if not G.is_cuda or B.device != dev or val.device != dev:
+        require_device(val, G, B)
+        raise RuntimeError(f"all operands must be on the same device, got {val.device}, {G.device} and {B.device}")
+    G, B = rowmajor(G), rowmajor(B)
+    p = G.size(-1)
+    if not val.is_contiguous():
+        val = val.contiguous()
+    gvals = torch.empty((lp.nnz,), dtype=G.dtype, device=dev)
+    gradB = torch.empty((lp.n_rows, p), dtype=G.dtype, device=dev)
+    tok = _timed("march_backward", dev) if KERNEL_EVENTS is not None else None
+    with _on_device(dev):
+        rc = lib.tsgu_csr_mm_backward_march(_VTYPE[G.dtype], cfg.struct_addr, lp.n_rows, lp.nnz, val.data_ptr(), G.data_ptr(), _ld(G),
+                                            B.data_ptr(), _ld(B), gvals.data_ptr(), float(alpha), gradB.data_ptr(), p, p, dev.index,
+                                            _raw_stream(dev))
+    if tok is not None:
+        _timed_end(tok, dev)
+    if rc:
+        check(rc, "tsgu_csr_mm_backward_march")
+    return gvals, gradB
+
+
 def _tiled_ok(*dense) -> bool:
     return all(t.dim() == 2 and t.data_ptr() % 16 == 0 and (_ld(t) * t.element_size()) % 16 == 0 for t in dense)
 
@@ -671,9 +704,9 @@ def csr_sptrsm(ptr, idx, val, B, n: int, lower: bool, unit: bool, perm=None):
             "tsgu_csr_sptrsm",
         )
     # error word sits behind the 64 ticket counters (struct TrsmWork in csrc/sptrsm.hip).  It is only ever set by the
-    # 4 s device-side wait bound (a dependency that never arrives), so it is checked LAZILY: copied asynchronously to
-    # pinned memory here, examined at the next solve / `poll_errors()` once its event has completed — no host sync
-    # per solve.  TSGU_SPTRSM_CHECK=sync restores the blocking check.
+    # 4 s device-side wait bound (a dependency that never arrives).  Default: read back before X is handed out (one host
+    # sync per solve); TSGU_SPTRSM_CHECK=lazy — and any solve inside a stream capture, where a host read is not allowed —
+    # copies it asynchronously to pinned memory and examines it at the next solve / `poll_errors()`.
     _defer_error_check(work[512:516].view(torch.int32), dev)
     return X
 
@@ -687,10 +720,13 @@ _SYNC_CHECK = os.environ.get("TSGU_SPTRSM_CHECK", "sync") != "lazy"
 
 
 def _defer_error_check(word: torch.Tensor, dev: torch.device, what: str = "tsgu_csr_sptrsm (dependency wait)") -> None:
-    if _SYNC_CHECK:
+    capturing = torch.cuda.is_current_stream_capturing()
+    if _SYNC_CHECK and not capturing:
         if int(word.item()) != 0:
             check(-7, what)
         return
+    if capturing:
+        return      # (a graph replay cannot report through the host; the 4 s device-side bound still ends the wait)
     poll_errors()
     host = torch.empty(1, dtype=torch.int32, pin_memory=True)
     host.copy_(word, non_blocking=True)

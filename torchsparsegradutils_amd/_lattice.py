@@ -544,11 +544,13 @@ ENABLE_MARCH = os.environ.get("TSGU_ENABLE_MARCH", "1") == "1"
 _MARCH_CFG_ENV = os.environ.get("TSGU_MARCH_CFG", "")   # "ty,tz,nseg,threads" overrides the choice (experiments)
 MARCH_TAPS = 9
 MARCH_MAX_CLASSES = 64
-_MARCH_WAVES_PER_CU = {0: 20, 1: 16, 2: 16}     # resident waves per CU the segment count is planned for
+_MARCH_WAVES_PER_CU = {0: 20, 1: 20, 2: 16, 3: 12}     # resident waves per CU the segment count is planned for (3: the fused backward)
 # workgroup sizes in order of preference: the first that fits the lattice is taken (measured at C2, same box, us:
 # forward 4x8/256: 80.8-85.5, 8x8/512: 88.1;  SDDMM 8x8/512: 87.4, 4x8/256: 94.6-101.7;  transposed 8x8/512: 102.4, 4x8/256: 99.5-103.0)
-_MARCH_THREADS = {0: (256, 512), 1: (512, 256), 2: (512, 256)}
-_MARCH_HALO_COST = {0: 0.1, 1: 0.1, 2: 0.8}     # what a halo row costs relative to an own row
+# round 4 (three alternations per configuration in one process, C2, us): SDDMM 4x8/256 80.1-83.0 against 8x8/512 84.4-97.5 — the
+# smaller workgroups fill the SIMDs' register files evenly (80 registers: six 256-thread workgroups or three of 512 per CU)
+_MARCH_THREADS = {0: (256, 512), 1: (256, 512), 2: (512, 256), 3: (256,)}
+_MARCH_HALO_COST = {0: 0.1, 1: 0.1, 2: 0.8, 3: 0.8}     # what a halo row costs relative to an own row
 
 
 class MarchTables:
@@ -616,15 +618,21 @@ def march_tables(plan: LatticePlan) -> Optional[MarchTables]:
     return mt
 
 
-def march_config_for(plan: LatticePlan, mode: int, vtype: int, p: int, lds_bytes_fn) -> Optional[MarchConfig]:
-    """Cached launch configuration of the plane-march kernels for a stored-order plan, or None (pattern / operands not covered)."""
+def march_config_for(plan: LatticePlan, mode: int, vtype: int, p: int, lds_bytes_fn, supported_fn=None) -> Optional[MarchConfig]:
+    """Cached launch configuration of the plane-march kernels for a stored-order plan, or None (pattern / operands not covered;
+    `supported_fn(mode, mask, uniform_len, threads)`: which kernels the library holds — the whole box: all products; triangular
+    halves: the SDDMM)."""
     if not ENABLE_MARCH or vtype != 0 or not (p in (16, 32, 64) or (p > 64 and p % 64 == 0 and p <= 1024)):
         return None
+    if mode == 3 and p != 32:
+        return None      # the fused backward: 32 columns (8 lanes per row)
     if p == 16 and mode == 0 and not _MARCH_CFG_ENV:
         return None      # 16 columns, forward: the general sweep is faster (measured at C2's lattice: 46 against 58 us; SDDMM 89 / 77, transposed 86 / 71)
     mt = march_tables(plan)
     if mt is None:
         return None
+    if mt.full and not plan.uniform_len and 36 * plan.ny * plan.nz >= 1 << 24:
+        return None      # truncated box: the kernels' row-start arithmetic uses 24-bit multiplies (planes under ~466 000 points)
     key = (mode, p)
     if key in mt._cfg:
         return mt._cfg[key]
@@ -634,10 +642,14 @@ def march_config_for(plan: LatticePlan, mode: int, vtype: int, p: int, lds_bytes
     if _MARCH_CFG_ENV:
         v = [int(t) for t in _MARCH_CFG_ENV.split(",")]
         cands = [(v[0], v[1], min(v[2], plan.nx), v[3])]
+        if supported_fn is not None and not supported_fn(mode, mt.mask, plan.uniform_len, v[3]):
+            cands = []
     else:
         # a wave = 64 / cl consecutive rows of one z-line (conflict-free LDS row reads): tz = 8 rows (p = 32) or a multiple
         cands = []
         for threads in _MARCH_THREADS[mode]:
+            if supported_fn is not None and not supported_fn(mode, mt.mask, plan.uniform_len, threads):
+                continue
             rpp = threads // cl
             tz = 8
             if rpp // tz >= 1 and rpp // tz <= plan.ny and tz <= plan.nz:

@@ -38,6 +38,9 @@ PLAN_ASYNC = os.environ.get("TSGU_PLAN_ASYNC", "1") == "1"
 ENABLE_LATTICE = os.environ.get("TSGU_ENABLE_LATTICE", "1") == "1"
 # value types the sweeps are compiled for (fp32 accumulation for bf16)
 LATTICE_DTYPES = (torch.float32, torch.bfloat16, torch.float64)
+# both gradients of sparse_mm on a whole-box stencil by ONE plane march (fp32, 32 columns); TSGU_FUSED_BACKWARD=0: the SDDMM and
+# the transposed product as two launches
+FUSED_BACKWARD = os.environ.get("TSGU_FUSED_BACKWARD", "0") == "1"
 
 
 def _lattice_plan(plan: RowGather, transposed: bool = False):
@@ -48,12 +51,22 @@ def _lattice_plan(plan: RowGather, transposed: bool = False):
     if not ENABLE_LATTICE or plan.batch is not None or plan.perm is not None or plan.nnz < PACK_MIN_NNZ or plan.n_rows != plan.n_cols:
         return None
     own = plan.core.own
+    # a plan is built with host round trips (status words, class tables): never inside a stream capture — a pattern first
+    # seen there runs on the plan-free kernels and gets its plan from the first call outside the capture
+    capturing = None
     if "lattice" not in own:
+        capturing = plan.crow.is_cuda and torch.cuda.is_current_stream_capturing()
+        if capturing:
+            return None
         own["lattice"] = _lt.build_lattice_plan_hip(plan, _be)
     fwd = own["lattice"]
     if not transposed or fwd is None:
         return fwd
     if "lattice_t" not in own:
+        if capturing is None:
+            capturing = plan.crow.is_cuda and torch.cuda.is_current_stream_capturing()
+        if capturing:
+            return None
         own["lattice_t"] = _lt.build_lattice_plan_hip(plan, _be, forward=fwd)
     return own["lattice_t"]
 
@@ -89,6 +102,9 @@ def _lattice_cfg(plan: RowGather, mode: int, dense: torch.Tensor, *others: torch
     fwd = _lattice_plan(plan)
     if fwd is None:
         return None
+    capturing = torch.cuda.is_current_stream_capturing()
+    if capturing and fwd._march is False:
+        return None            # (the march tables are copied to the device when they are first derived: not inside a capture)
     # box stencils (periodic or truncated; 27-point, 7-point, triangular parts …): the plane-march kernels — all three products
     # from the stored-order plan alone
     cfg = _be.march_config(fwd, mode, dense.dtype, dense.size(-1))
@@ -96,22 +112,26 @@ def _lattice_cfg(plan: RowGather, mode: int, dense: torch.Tensor, *others: torch
         if memo is not None:
             memo[key] = (fwd, cfg)
         return fwd, cfg
-    if wide:
-        return None
+    if wide or mode == _be.MARCH_BWD:
+        return None            # (no general-sweep form of these)
     lp = _lattice_plan(plan, transposed=True) if mode == _be.LAT_SPMMT else fwd
     if lp is None:
         return None
+    if capturing and (mode, _be._VTYPE[dense.dtype], dense.size(-1)) not in lp._cfg:
+        return None            # (record tables and class lists of a configuration are built with host round trips)
     cfg = _be.lattice_config(lp, mode, dense.dtype, dense.size(-1))
     if cfg is None:
         return None
-    if _lt.TUNE and not cfg.tuned:
+    # (deterministic mode: the launch configuration — and with it the grouping of the Krylov loops' per-workgroup dot partials —
+    # must not depend on a wall-clock trial; the ranked configuration stays.  TSGU_LATTICE_TUNE=0 does the same for a process)
+    if _lt.TUNE and not cfg.tuned and not torch.are_deterministic_algorithms_enabled():
         cfg.uses += 1
         if cfg.uses >= _lt.TUNE_AFTER_USES and not torch.cuda.is_current_stream_capturing():
             try:
                 cfg = _measured_cfg(lp, mode, dense, cfg)
             except torch.cuda.OutOfMemoryError:
                 cfg.tuned = True      # no room for the trial operands: the ranked configuration stays
-    if memo is not None and (cfg.tuned or not _lt.TUNE):
+    if memo is not None and (cfg.tuned or not _lt.TUNE) and not torch.are_deterministic_algorithms_enabled():
         memo[key] = (lp, cfg)
     return lp, cfg
 
@@ -192,13 +212,20 @@ def _lattice_backward(plan: RowGather, values: torch.Tensor, G: torch.Tensor, B:
         if fl is None:
             return None
         fplan, (Gf, Bf) = fl
+    vals = values.reshape(-1)
+    if FUSED_BACKWARD and Gf.dtype == torch.float32 and Gf.size(-1) == 32:
+        # whole-box stencils: both gradients in ONE march — the halo ring of G serves the transposed product and, through its
+        # centre rows, the SDDMM's own rows (csrc/march_bwd_impl.h)
+        both = _lattice_cfg(fplan, _be.MARCH_BWD, Gf, Bf)
+        if both is not None:
+            ga, gb = _be.csr_mm_backward_march(both[0], both[1], vals, Gf, Bf)
+            return ga.view(values.shape), gb.view(B.shape)
     fwd = _lattice_cfg(fplan, _be.LAT_SDDMM, Bf, Gf)
     if fwd is None:
         return None
     bwd = _lattice_cfg(fplan, _be.LAT_SPMMT, Gf)
     if bwd is None:
         return None
-    vals = values.reshape(-1)
     ga = _be.csr_sddmm_lattice(fwd[0], fwd[1], Gf, Bf)
     gb = _be.csr_spmm_lattice(bwd[0], bwd[1], vals, Gf)
     return ga.view(values.shape), gb.view(B.shape)

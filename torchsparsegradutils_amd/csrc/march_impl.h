@@ -64,7 +64,7 @@ struct MarchParams {
     void* gvals;                 // SDDMM output [nnz]
     float alpha;
     int64_t nblocks;
-    int o_vals, o_tab, o_rows, lds_bytes;   // LDS layout (bytes), filled by march_layout
+    int o_vals, o_stage, o_tab, o_rows, lds_bytes;   // LDS layout (bytes), filled by march_layout / march_bwd_layout
 };
 
 // 4-byte LDS-DMA: lane l's dword lands at `lds_wave_base + 4*l`.  NT_POLICY: streaming (the values of a tile's own rows are read
@@ -288,6 +288,22 @@ __global__ __launch_bounds__(NT, march_waves(MODE, MASK == kBoxAll, ROWS != kRow
                     *reinterpret_cast<uint4*>(sm + P.o_vals + HR * VP + e * 16) = make_uint4(0, 0, 0, 0);
                 }
             }
+            // (a staged slot of an in-lattice halo row that holds no entry is never read: its reader would be a target beyond a face)
+        }
+        if constexpr (MODE == kLatSpmm) {
+            // The product multiplies the canonical slots of a row at a y / z face with the (zero) halo rows beyond that face: those
+            // slots hold 0 — cleared ONCE: a tile row keeps its (y, z) for the whole march, so no request ever writes them.  (Slots
+            // that are absent only at an x face are never read: the source plane beyond an x face is skipped.)
+            for (int e = tid; e < NR * SLOTS; e += NT) {
+                const int r = e / SLOTS, slot = e - r * SLOTS;
+                const int ry_ = r / P.tz, rz_ = r - ry_ * P.tz;
+                const int yy = y0 + ry_ + (slot / 3) % 3 - 1, zz = z0 + rz_ + slot % 3 - 1;
+                const bool beyond = (!P.per_y && (unsigned)yy >= (unsigned)P.ny) || (!P.per_z && (unsigned)zz >= (unsigned)P.nz);
+                if (slot < NS && beyond) {
+#pragma unroll
+                    for (int vbi = 0; vbi < 4; ++vbi) *reinterpret_cast<float*>(sm + P.o_vals + vbi * NR * VP + e * 4) = 0.f;
+                }
+            }
         }
     }
     // the compute row of this lane group
@@ -321,6 +337,25 @@ __global__ __launch_bounds__(NT, march_waves(MODE, MASK == kBoxAll, ROWS != kRow
         }
     }
 
+    // kRowsBox: the per-row constant of the row each gather lane serves (its start is plane_base + plane_cx · constant), once for
+    // the whole march — the face tiles gather at every step, and a launch takes as long as its slowest workgroup
+    uint32_t fpo[NF];          // kRowsBox: byte offset of this lane's f-th 16-byte piece inside its row (row constants < 2^24)
+#pragma unroll
+    for (int f = 0; f < NF; ++f) fpo[f] = (uint32_t)((f * kWave + lane) % VL) * 16u;
+    int gconst[BOXA ? NPASS : 1][BOXA ? NGI : 1];
+    if constexpr (BOXA && MODE != kLatSddmm) {
+#pragma unroll
+        for (int q = 0; q < NPASS; ++q) {
+#pragma unroll
+            for (int n = 0; n < NGI; ++n) {
+                const int rw = (n * kWave + lane) / SLOTS;
+                const int fr = q * NG + wave * RPW + rw;
+                const int rr = (rw < RPW && fr < staged_rows) ? rows_s[fr] : -1;
+                gconst[q][n] = row_const(rr > 0 ? rr : 0);
+            }
+        }
+    }
+
     const char* const Sb = static_cast<const char*>(P.S);
     const char* const valb = static_cast<const char*>(P.val);
     const uint32_t val_bytes = (uint32_t)(P.nnz * 4);
@@ -335,11 +370,11 @@ __global__ __launch_bounds__(NT, march_waves(MODE, MASK == kBoxAll, ROWS != kRow
             }
         }
     };
-    // canonical value rows of lattice plane `x` of the item into the buffer at byte `region`; cls[q] / stt[q] = class and (row
+    // canonical value rows of a lattice plane of the item into the buffer at byte `region`; cls[q] / stt[q] = class and (row
     // pointers) first value position of srow[q]
-    auto stage_vals = [&](int x, unsigned region, const int (&cls)[NPASS], const int (&stt)[NPASS]) {
+    // (pbase, pcx: plane_base / plane_cx of the plane — kept up to date by the march, below; unused with row pointers)
+    auto stage_vals = [&](int pbase, int pcx, unsigned region, const int (&cls)[NPASS], const int (&stt)[NPASS]) {
         if constexpr (MODE != kLatSddmm) {
-            const int pbase = PTR ? 0 : plane_base(x), pcx = PTR ? 0 : plane_cx(x);   // wave-uniform
 #pragma unroll
             for (int q = 0; q < NPASS; ++q) {
                 const int first = q * NG + wave * RPW;                       // wave-uniform
@@ -355,7 +390,7 @@ __global__ __launch_bounds__(NT, march_waves(MODE, MASK == kBoxAll, ROWS != kRow
                             if constexpr (UNIF) {
                                 if (fo != kLatNone) fo += (uint32_t)pbase * 4u;
                             } else if constexpr (BOXA) {
-                                if (fo != kLatNone) fo = (uint32_t)pbase * 4u + (uint32_t)pcx * fo + (uint32_t)((f * kWave + lane) % VL) * 16u;
+                                if (fo != kLatNone) fo = __umul24((uint32_t)pcx, fo) + ((uint32_t)pbase * 4u + fpo[f]);   // (one v_mad_u32_u24)
                             } else {
                                 const int piece = f * kWave + lane;
                                 const int rw = piece / VL;
@@ -388,15 +423,13 @@ __global__ __launch_bounds__(NT, march_waves(MODE, MASK == kBoxAll, ROWS != kRow
                             const int rr = (rw < RPW && first + rw < staged_rows) ? rows_s[first + rw] : -1;
                             int rs;
                             if constexpr (PTR) rs = __builtin_amdgcn_ds_bpermute(src_lane, stt[q]);
-                            else rs = pbase + pcx * row_const(rr > 0 ? rr : 0);
-                            if (rr >= 0 && slot < NS && has(slot)) {
-                                const int k = allid ? __builtin_popcount(mask & ((1u << slot) - 1u)) : (int)kidx_s[rc * 32 + slot];
-                                if (UNIF || k != 0xFF) {
-                                    lat_dma4<MODE == kLatSpmm>(valb, (uint32_t)rs * 4u + (uint32_t)k * 4u, wbase + (unsigned)(n * kWave * 4));
-                                } else {
-                                    *reinterpret_cast<float*>(sm + region + first * VP + e * 4) = 0.f;
-                                }
-                            }
+                            else if constexpr (BOXA) rs = pbase + (int)__umul24((uint32_t)pcx, (uint32_t)gconst[q][n]);
+                            else rs = pbase + pcx * (rr > 0 ? rr : 0);
+                            // (a row at a face of a truncated lattice has no entry towards the neighbours beyond it: k = 0xff,
+                            // nothing is requested — its slot was cleared once, below, or is never read)
+                            const int k = allid ? __builtin_popcount(mask & ((1u << (slot & 31)) - 1u)) : (int)kidx_s[rc * 32 + (slot & 31)];
+                            if (rr >= 0 && slot < NS && has(slot) && (UNIF || k != 0xFF))
+                                lat_dma4<MODE == kLatSpmm>(valb, (uint32_t)rs * 4u + (uint32_t)k * 4u, wbase + (unsigned)(n * kWave * 4));
                         }
                     }
                 }
@@ -441,6 +474,18 @@ __global__ __launch_bounds__(NT, march_waves(MODE, MASK == kBoxAll, ROWS != kRow
         const int vbuf = (MODE == kLatSpmm ? NR : HR) * VP;
         // SpMM stages the values of target plane s+2 at step s; SpMMT those of halo plane s+1 (with the dense plane)
         int x_val = MODE == kLatSpmm ? xs : x_ring;                         // lattice plane of the next value plane (ring 1 / ring 0)
+        // its plane_base / plane_cx, stepped with it: base(x + 1) = base(x) + (entries of plane x) — a handful of scalar
+        // instructions per step (the closed forms cost ~25, and these kernels are bound by instruction issue as much as by HBM)
+        int vbase = PTR ? 0 : plane_base(x_val), vcx = PTR ? 0 : plane_cx(x_val);
+        auto next_val_plane = [&]() {
+            if constexpr (BOXA) vbase += boxLyz * vcx;
+            else if constexpr (UNIF) vbase += plane_rows * (FULL ? NS : P.uniform);
+            x_val = wrap(x_val + 1, P.nx);
+            if constexpr (!PTR) {
+                if (x_val == 0) vbase = plane_base(0);
+                if constexpr (BOXA) vcx = cnt1(x_val, P.nx, P.per_x);
+            }
+        };
         int cls[NPASS], cld[NPASS], stt[NPASS], std_[NPASS];
         const int first_val = MODE == kLatSpmm ? 1 : 0;                     // ring index of the first value plane
         const int last_val = MODE == kLatSpmm ? L : L + 1;
@@ -451,9 +496,9 @@ __global__ __launch_bounds__(NT, march_waves(MODE, MASK == kBoxAll, ROWS != kRow
             pin_cls(cls, stt);
         }
         if (x_ok(0)) dma_ring(row_of_x(x_ring), 0);
-        if (x_ok(first_val)) stage_vals(x_val, (unsigned)(P.o_vals + (MODE == kLatSpmm ? 1 : 0) * vbuf), cls, stt);
+        if (x_ok(first_val)) stage_vals(vbase, vcx, (unsigned)(P.o_vals + (MODE == kLatSpmm ? 1 : 0) * vbuf), cls, stt);
         x_ring = wrap(x_ring + 1, P.nx);
-        x_val = wrap(x_val + 1, P.nx);
+        next_val_plane();
         const int first_next = first_val + 1;                               // ring index of the next value plane
         if (first_next <= last_val && x_ok(first_next)) load_cls(row_of_x(x_val), cld, std_);
         lat_step_sync();
@@ -481,9 +526,9 @@ __global__ __launch_bounds__(NT, march_waves(MODE, MASK == kBoxAll, ROWS != kRow
             // 2. asynchronous fetches: the next halo plane, the next value plane
             if (s + 1 <= L + 1 && x_ok(s + 1)) dma_ring(row_of_x(x_ring), (s + 1) & 1);
             const int vnext = MODE == kLatSpmm ? s + 2 : s + 1;
-            if (vnext <= last_val && x_ok(vnext)) stage_vals(x_val, (unsigned)(P.o_vals + (vnext & (VB - 1)) * vbuf), cls, stt);
+            if (vnext <= last_val && x_ok(vnext)) stage_vals(vbase, vcx, (unsigned)(P.o_vals + (vnext & (VB - 1)) * vbuf), cls, stt);
             x_ring = wrap(x_ring + 1, P.nx);
-            x_val = wrap(x_val + 1, P.nx);
+            next_val_plane();
             // 3. class bytes for the next step
             if (vnext + 1 <= last_val && x_ok(vnext + 1)) load_cls(row_of_x(x_val), cld, std_);
             // 4. source plane s: targets s+1 (N, part 0), s (C, part 1), s-1 (P, part 2).  A target outside 1..L accumulates
@@ -697,8 +742,7 @@ __global__ __launch_bounds__(NT, march_waves(MODE, MASK == kBoxAll, ROWS != kRow
             // the row's gradients in stored order: 16-byte pieces, single elements at the end
             if (crow >= 0) {
                 float* const go = static_cast<float*>(P.gvals) + fl_start;
-#pragma nounroll
-                for (int k0 = c * 4; k0 < fl_len; k0 += CL * 4) {
+                auto piece = [&](int k0) {
                     float4 w = *reinterpret_cast<const float4*>(st + k0);
                     if (k0 + 4 <= fl_len) {
                         typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
@@ -713,6 +757,20 @@ __global__ __launch_bounds__(NT, march_waves(MODE, MASK == kBoxAll, ROWS != kRow
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
                             if (k0 + j < fl_len) go[k0 + j] = P.accumulate ? go[k0 + j] + wv[j] : wv[j];
+                    }
+                };
+                if constexpr (UNIF) {
+                    // (rows of one length: the rolled loop costs one register less — 80, six waves per SIMD)
+#pragma nounroll
+                    for (int k0 = c * 4; k0 < fl_len; k0 += CL * 4) piece(k0);
+                } else {
+                    // a lane holds one 16-byte piece of a row (8 / 16 lanes) or two (4 lanes): unrolled, 17 registers less than the
+                    // loop with a run-time bound
+                    constexpr int kPieces = (SLOTS + CL * 4 - 1) / (CL * 4);
+#pragma unroll
+                    for (int it = 0; it < kPieces; ++it) {
+                        const int k0 = c * 4 + it * CL * 4;
+                        if (k0 < fl_len) piece(k0);
                     }
                 }
             }

@@ -148,6 +148,7 @@ __global__ __launch_bounds__(kBlock) void sptrsm_syncfree_kernel(const TrsmParam
         A acc = 0;
         A diag = 0;
         A inv = 1;            // 1 / diagonal: ready BEFORE the row's last dependency arrives (the diagonal is the last entry visited)
+        A dsum = 1;           // the diagonal itself (fp64 divides by it: the reciprocal saves nothing measurable there)
         bool dead = false;
         // the right-hand side is requested BEFORE the row waits for its dependencies: its latency is off the critical path
         A rhs = 0;
@@ -170,8 +171,8 @@ __global__ __launch_bounds__(kBlock) void sptrsm_syncfree_kernel(const TrsmParam
                 }
             }
             if (base + EP >= e && !P.unit) {       // last round: the diagonal is among these entries
-                const A d = entry_sum<A, EP>(diag);
-                inv = (A)1 / d;
+                dsum = entry_sum<A, EP>(diag);
+                inv = (A)1 / dsum;
             }
             Bits xb = S::kTag;
             // poll: back-to-back agent-scope loads (the hop latency of the solve's critical path is the
@@ -204,10 +205,17 @@ __global__ __launch_bounds__(kBlock) void sptrsm_syncfree_kernel(const TrsmParam
             if (lane == 0) __hip_atomic_store(&work->error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             break;
         }
+        if (s == e && !P.unit) {   // an empty row of a non-unit solve: a zero diagonal — inf / NaN like the reference's backend,
+            dsum = 0;              // not a silent x = rhs
+            inv = (A)1 / dsum;
+        }
         acc = entry_sum<A, EP>(acc);
         if (ep == 0 && col_ok) {
             A x = rhs - acc;
-            x = x * inv;       // (unit: inv = 1)
+            // fp32 / bf16: times the reciprocal that was ready before the last dependency arrived (within 1 ulp of the
+            // division per row; it rounds differently from the reference's division); fp64: the division itself
+            if constexpr (sizeof(A) == 8) x = x / dsum;
+            else x = x * inv;  // (unit: inv = dsum = 1)
             Bits xb = S::bits(x);
             if (x != x) xb = S::kCanon;
             __hip_atomic_store(X + row * P.ldx + c, xb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

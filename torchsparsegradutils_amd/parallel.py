@@ -96,20 +96,33 @@ def sharded_batched_apply(
     group: Optional[dist.ProcessGroup] = None,
     gather: bool = True,
     overlap_chunks: int = 1,
+    batch: Optional[int] = None,
 ) -> torch.Tensor:
     """Apply a batched op (``sparse_mm`` / ``sparse_triangular_solve``) to this rank's slice of the
     batch and (optionally) all-gather the dense results.
 
-    ``A``: batched CSR (b, n, m) and ``B``: dense (b, m, p), both holding the FULL batch on every
-    rank (or at least valid data in this rank's slice).  Gradients flow to the local slice only;
-    the gathered tensor is a detached copy, as a data-parallel step would consume it."""
+    ``batch`` given: ``A`` (batched CSR (b_local, n, m)) and ``B`` (dense (b_local, m, p)) hold ONLY this rank's
+    items — items ``shard_bounds(batch, world, rank)`` of a job of ``batch`` items; no rank ever holds the whole batch
+    (per-rank memory and start-up traffic are 1/world of the job's).
+    ``batch`` None: ``A`` and ``B`` hold the FULL batch on every rank (or at least valid data in this rank's
+    slice) and the rank takes its slice — convenient for small jobs and tests.
+    Gradients flow to the local items only; the gathered tensor is a detached copy, as a data-parallel step
+    would consume it."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    lo, hi = shard_bounds(A.size(0), world, rank)
-    A_local = shard_batched_csr(A, rank, world)
-    if gather and overlap_chunks > 1 and A.size(0) % world == 0 and hi - lo >= overlap_chunks:
-        return _apply_overlapped(op, A_local, B[lo:hi], A.size(0), overlap_chunks, group)
-    local = op(A_local, B[lo:hi])
+    if batch is None:
+        batch = A.size(0)
+        lo, hi = shard_bounds(batch, world, rank)
+        A_local, B_local = shard_batched_csr(A, rank, world), B[lo:hi]
+    else:
+        lo, hi = shard_bounds(batch, world, rank)
+        if A.size(0) != hi - lo or B.size(0) != hi - lo:
+            raise ValueError(f"rank {rank} of {world} owns items [{lo}, {hi}) of a batch of {batch}: expected {hi - lo} local items, "
+                             f"got A with {A.size(0)} and B with {B.size(0)}")
+        A_local, B_local = A, B
+    if gather and overlap_chunks > 1 and batch % world == 0 and hi - lo >= overlap_chunks:
+        return _apply_overlapped(op, A_local, B_local, batch, overlap_chunks, group)
+    local = op(A_local, B_local)
     if not gather:
         return local
-    return all_gather_batch(local.detach(), A.size(0), group)
+    return all_gather_batch(local.detach(), batch, group)

@@ -222,14 +222,30 @@ def _batched_rhs(matmul_closure, rhs, n_tridiag, tolerance, eps, stop_updating_a
     if not n_tridiag:
         out = linear_cg(op, fold(rhs).contiguous(), 0, tolerance, eps, stop_updating_after, max_iter, max_tridiag_iter, x0, pre, settings)
         return unfold(out)
-    # Lanczos coefficients of the first n_tridiag columns of EVERY batch item: tridiagonalise all folded columns, then pick
+    # Lanczos coefficients of the first n_tridiag columns of EVERY batch item (reference :303-310: its tridiagonal bookkeeping —
+    # the `t_mat[k-1, k].max() < 1e-6` rule that ends it early, and with it the size of T — looks at batch x n_tridiag columns
+    # only).  The folded columns are reordered so that those columns lead, the 2-D path tridiagonalises exactly them, and the
+    # solution is put back in the caller's column order.
     if n_tridiag > k:
         raise RuntimeError(f"n_tridiag must be between 0 and the number of right-hand sides ({k}), got {n_tridiag}")
-    out, t_all = linear_cg(op, fold(rhs).contiguous(), nb * k, tolerance, eps, stop_updating_after, max_iter, max_tridiag_iter, x0,
-                           pre, settings)
-    r = t_all.shape[-1]
-    t_sel = t_all.reshape(nb, k, r, r)[:, :n_tridiag]                       # (batch, n_tridiag, r, r)
-    return unfold(out), t_sel.permute(1, 0, 2, 3).reshape((n_tridiag,) + batch_shape + (r, r)).contiguous()
+    dev = rhs.device
+    col = torch.arange(nb * k, device=dev).reshape(nb, k)
+    order = torch.cat((col[:, :n_tridiag].reshape(-1), col[:, n_tridiag:].reshape(-1)))      # leading: (item, first n_tridiag columns)
+    back = torch.empty_like(order)
+    back[order] = torch.arange(nb * k, device=dev)
+
+    def lead(fn):     # an operator on folded columns in the reordered layout
+        return lambda v: fn(v[:, back])[:, order]
+
+    if op is not matmul_closure:
+        op = lead(op)
+    x0r = None if x0 is None else x0[:, order].contiguous()
+    prer = None if pre is None else lead(pre)
+    out, t_lead = linear_cg(op, fold(rhs)[:, order].contiguous(), nb * n_tridiag, tolerance, eps, stop_updating_after, max_iter,
+                            max_tridiag_iter, x0r, prer, settings)
+    r = t_lead.shape[-1]
+    t_sel = t_lead.reshape(nb, n_tridiag, r, r)                             # (batch, n_tridiag, r, r)
+    return unfold(out[:, back]), t_sel.permute(1, 0, 2, 3).reshape((n_tridiag,) + batch_shape + (r, r)).contiguous()
 
 
 def _fused_loop(op, rhs_is_zero, x, r, has_converged, n_iter, max_iter, tolerance, eps, stop_after, preconditioner=None):

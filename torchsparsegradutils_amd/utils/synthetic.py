@@ -79,6 +79,63 @@ def box_stencil(nx: int, ny: int, nz: int, periodic=(True, True, True), points: 
     return crow.to(index_dtype), col
 
 
+def _rows_from_candidates(cols: torch.Tensor, keeps: torch.Tensor, n: int, index_dtype):
+    """CSR (crow, col) from per-row candidate columns [n][k] and their keep flags: kept entries sorted inside each row."""
+    big = torch.where(keeps, cols, torch.full_like(cols, n))
+    order = torch.sort(big, dim=1)
+    counts = keeps.sum(dim=1)
+    kept = torch.arange(cols.size(1), device=cols.device)[None, :] < counts[:, None]
+    crow = torch.zeros(n + 1, dtype=torch.int64, device=cols.device)
+    crow[1:] = torch.cumsum(counts, 0)
+    return crow.to(index_dtype), order.values[kept].to(index_dtype)
+
+
+def mesh27_blocked(nx: int, ny: int, nz: int, block: int = 4, index_dtype=torch.int32, device="cpu"):
+    """A mesh-like pattern that is NOT a row-major lattice: the truncated 27-point neighbourhood graph of an nx×ny×nz grid
+    whose points are numbered brick by brick (block³ points per brick, bricks in row-major order) — the locality-preserving
+    but irregular numbering of a partitioned finite-element mesh.  Same entries per row as the truncated stencil, sorted
+    columns.  nx, ny, nz must be multiples of `block`.  Returns (crow, col)."""
+    if nx % block or ny % block or nz % block:
+        raise ValueError("grid dimensions must be multiples of the brick size")
+    b = block
+    nby, nbz = ny // b, nz // b
+    n = nx * ny * nz
+    r = torch.arange(n, device=device, dtype=torch.int64)
+    brick, o = r // (b * b * b), r % (b * b * b)
+    x = (brick // (nby * nbz)) * b + o // (b * b)
+    y = ((brick // nbz) % nby) * b + (o // b) % b
+    z = (brick % nbz) * b + o % b
+
+    def number(xx, yy, zz):
+        br = ((xx // b) * nby + yy // b) * nbz + zz // b
+        return br * (b * b * b) + ((xx % b) * b + yy % b) * b + zz % b
+
+    cols, keeps = [], []
+    for dx in (-1, 0, 1):
+        for dy in (-1, 0, 1):
+            for dz in (-1, 0, 1):
+                xx, yy, zz = x + dx, y + dy, z + dz
+                keep = (xx >= 0) & (xx < nx) & (yy >= 0) & (yy < ny) & (zz >= 0) & (zz < nz)
+                cols.append(number(xx.clamp(0, nx - 1), yy.clamp(0, ny - 1), zz.clamp(0, nz - 1)))
+                keeps.append(keep)
+    return _rows_from_candidates(torch.stack(cols, 1), torch.stack(keeps, 1), n, index_dtype)
+
+
+def banded_random(n: int, per_row: int = 25, band: int = 2048, index_dtype=torch.int32, device="cpu", seed: int = 0):
+    """Random banded pattern: the diagonal plus up to `per_row - 1` distinct random columns within `band` of it, sorted,
+    duplicate-free rows — the shape of the reference's SuiteSparse benchmark matrix (cfd2: N=123,440, 25 entries per row,
+    ``benchmarks/results/sparse_mm_suite_results.csv``).  Returns (crow, col)."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    i = torch.arange(n, dtype=torch.int64).unsqueeze(1)
+    off = torch.randint(-band, band + 1, (n, per_row - 1), generator=g, dtype=torch.int64)
+    cand = torch.cat([i + off, i], dim=1)
+    cand = torch.sort(cand, dim=1).values
+    keep = (cand >= 0) & (cand < n)
+    keep[:, 1:] &= cand[:, 1:] != cand[:, :-1]
+    crow, col = _rows_from_candidates(cand, keep, n, index_dtype)
+    return crow.to(device), col.to(device)
+
+
 def stencil7_periodic(nx: int, ny: int, nz: int, index_dtype=torch.int32, device="cpu"):
     """Periodic 7-point stencil pattern (7 entries per row, sorted columns)."""
     if min(nx, ny, nz) < 3:
