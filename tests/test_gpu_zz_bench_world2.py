@@ -16,11 +16,20 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_bench_runs_with_two_ranks():
+@pytest.mark.parametrize("form", ["launcher", "bare"])
+def test_bench_runs_with_two_ranks(form):
+    """`launcher`: started the way the driver starts N > 1 (python -m torch.distributed.run ... bench.py --gpus 2).
+    `bare`: `python bench.py --gpus 2` — bench.py starts its own ranks as child processes (no GPU call before that)."""
     assert torch.cuda.is_available(), "GPU tests need an MI355X"
     env = dict(os.environ, TSGU_BENCH_TEST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29519", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--no-cpu-baseline"]
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    tail = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--no-cpu-baseline"]
+    if form == "launcher":
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", "29519"] + tail
+    else:
+        cmd = [sys.executable] + tail
     try:
         out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
     except subprocess.TimeoutExpired:
@@ -39,3 +48,6 @@ def test_bench_runs_with_two_ranks():
     for key in ("fwd_compute_only", "fwd_bwd_compute_only", "fwd_end_to_end_with_allgather", "fwd_end_to_end_overlapped_chunks"):
         assert c5[key]["ms"] > 0, key
     assert "2 rank(s) x 32 items" in c5["workload"]
+    # every rank allocates its own items only: half of the job's 64 items
+    per_item = 2 * (3538944 + 2 * 131072 * 16) + 4 * (131073 + 3538944)
+    assert c5["resident_bytes_per_rank"] == 32 * per_item

@@ -4,6 +4,8 @@ The oracle is only trusted as a checker for the HIP kernels because every functi
 reproduces the reference's own outputs here (fp32 to 2e-6 relative — one reduction-order
 difference — and fp64 to 1e-12)."""
 
+import os
+
 import numpy as np
 import pytest
 
@@ -241,3 +243,25 @@ def test_preconditioned_cg_oracle(vn):
                              precond_diag=z["dinv"].astype(dt))[0]
         assert G.rel_err(x, z[f"{vn}_it{it}"]) < tol, (it, G.rel_err(x, z[f"{vn}_it{it}"]))
         assert np.abs(x[:, 3]).max() == 0.0
+
+
+def test_c_oracle_is_clean_under_address_and_undefined_sanitizers(tmp_path):
+    """oracle/csr_oracle.c built with -fsanitize=address,undefined and driven through every function (oracle/sanitize_main.c:
+    empty matrices, empty rows, zero columns, all triangular flag combinations) — on the CPU, never on the GPU box's device
+    (GPU AddressSanitizer is not available on the pool)."""
+    import shutil
+    import subprocess
+
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    exe = str(tmp_path / "oracle_san")
+    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "sanitize_main.c")
+    build = subprocess.run([gcc, "-O1", "-g", "-std=c99", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                            "-fno-omit-frame-pointer", "-ffp-contract=off", src, "-o", exe, "-lm"], capture_output=True, text=True)
+    if build.returncode != 0 and "sanitize" in build.stderr:
+        pytest.skip("this gcc has no sanitizer runtimes: " + build.stderr[-200:])
+    assert build.returncode == 0, build.stderr[-2000:]
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=120, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"))
+    assert run.returncode == 0, (run.stdout[-500:], run.stderr[-3000:])
+    assert "0 mismatches" in run.stdout

@@ -13,7 +13,7 @@ import subprocess
 import sys
 from collections import defaultdict
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(root, "profiles")
@@ -52,7 +52,9 @@ for kind in ("fetch", "write"):
 
 def role(kname):
     """forward / fused_backward / ... from the template arguments <V, I, CL, EP, MODE, PERM, SLOTS, SMALL>."""
-    if "march_kernel" in kname:     # <V, CL, MODE, NT, NTAP>: the bench's traffic keys are shared with the plane sweep
+    if "march_bwd_kernel" in kname:
+        return "march_fused_backward"
+    if "march_kernel" in kname:     # <V, CL, MODE, NT, NTAP, MASK, ROWS>: the bench's traffic keys are shared with the plane sweep
         args = kname.split("<", 1)[1].split(">")[0].replace(" ", "").split(",")
         return {"0": "lattice_spmm", "1": "lattice_sddmm", "2": "lattice_spmm_t"}.get(args[2])
     if "lattice_kernel" in kname:   # <V, CL, CPL, MODE, NT, NCH>
@@ -71,6 +73,37 @@ def role(kname):
     return None
 
 
+def pattern_step_bytes(pdir):
+    """HBM bytes of ONE forward+backward step of a pattern run (tools/pattern_steps.py under the two PMC passes): the launches of the
+    last step are the shortest suffix of the dispatch sequence that repeats the kernel names before it."""
+    per = {}
+    for kind, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+        hits = glob.glob(os.path.join(pdir, kind, "**", "*counter_collection.csv"), recursive=True)
+        if not hits:
+            return None
+        rows = [r for r in csv.DictReader(open(hits[0])) if r["Counter_Name"] == counter and "tsgu::" in r["Kernel_Name"]]
+        rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+        names = [r["Kernel_Name"] for r in rows]
+        m = next((m for m in range(1, 12) if len(names) >= 3 * m and names[-m:] == names[-2 * m:-m] == names[-3 * m:-2 * m]), None)
+        if m is None:
+            return None
+        per[kind] = ([float(r["Counter_Value"]) for r in rows[-m:]], names[-m:])
+    if per["fetch"][1] != per["write"][1]:
+        return None
+    total = int(sum(2 * f + w for f, w in zip(per["fetch"][0], per["write"][0])) * 1024)
+    return total, [n.split("(")[0][:90] for n in per["fetch"][1]]
+
+
+patterns, pattern_kernels = {}, {}
+for pdir in sorted(glob.glob(os.path.join(src, "pat_*"))):
+    if not os.path.isdir(pdir):
+        continue
+    got = pattern_step_bytes(pdir)
+    if got is not None:
+        key = os.path.basename(pdir)[4:]
+        patterns["c2_27pt_periodic" if key == "headline" else key] = got[0]
+        pattern_kernels[key] = got[1]
+
 traffic, raw = {}, {}
 for k, d in acc.items():
     r = role(k)
@@ -83,7 +116,7 @@ for k, d in acc.items():
         continue      # several instantiations share a role (bench.py's host-time leg steps a small problem with another column count): the C2 launches move the most bytes
     traffic[r] = t
     raw[r] = {"FETCH_SIZE_KB": round(fetch, 1), "WRITE_SIZE_KB": round(write, 1), "kernel": k[:120]}
-if traffic:
+if traffic or patterns:
     bench = {}
     try:
         bench = json.load(open(os.path.join(src, "bench.json")))
@@ -101,6 +134,8 @@ if traffic:
         "commit": commit,
         "plan_form": form,
         **traffic,
+        "patterns": patterns,
+        "_pattern_kernels": pattern_kernels,
         "_raw": raw,
         "_algorithmic": {"lattice_spmm": 476000004, "lattice_sddmm": 476000004, "lattice_spmm_t": 476000004, "forward": 476000004,
                          "fused_backward": 712000004, "sddmm_alone": 476000004, "transposed_spmm_alone": 476000004},

@@ -48,9 +48,6 @@ constexpr int kLatMaxLds = 160 * 1024;
 #ifndef TSGU_LAT_DOT2
 #define TSGU_LAT_DOT2 1     // 0: bf16 products by widening + fp32 FMAs (one entry at a time), the round-3 form before the pairs
 #endif
-#ifndef TSGU_LAT_PROBE
-#define TSGU_LAT_PROBE 0    // 1 / 2: timing probes of tools/build_variant_one.sh (never in the product build)
-#endif
 constexpr int kLatPadRec = 0x7ff00;  // record of a padded table entry: this many bytes beyond the row's own LDS position
 
 struct LatParams {
@@ -553,15 +550,9 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
         int cl_li[kLatNP];   // local class | length << 8 of the rows of this plane (one LDS read, waited for in the compute part)
 #pragma unroll
         for (int q = 0; q < kLatNP; ++q) cl_li[q] = (q * RPP < NR) ? cmap_s[cur.cls[q]] : 0;
-#if TSGU_LAT_PROBE != 2
         if (xo > 1) flush(prow_prev);
-#endif
         // 2. asynchronous fetches for later planes
-#if TSGU_LAT_PROBE == 1   // probe build (wrong results): no DMA inside the march
-        if (false) {
-#else
         if (xo + K <= L) {   // output plane xo + K exists: its last halo plane (ring index xo + K + 1) and its values are fetched now
-#endif
             const int tgt = wrap(ph + R - 2, R);                     // slot of ring index xo + K + 1 (free since the last barrier)
             const int prow_dma = row_of_x(x_run);
             dma_ring(prow_dma, tgt);
@@ -579,11 +570,7 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
         const char* const tabs = sm + P.o_tab + ph * P.nloc * P.recw * kRecB;
 #pragma unroll
         for (int q = 0; q < kLatNP; ++q) {
-#if TSGU_LAT_PROBE == 2   // probe build (wrong results): DMA and barriers only
-            if (false) {
-#else
             if (q * RPP < NR) {
-#endif
                 if (crow[q] >= 0) {
                     const int len = cl_li[q] >> 8;
                     const char* const tb = tabs + (cl_li[q] & 0xff) * (P.recw * kRecB);
@@ -699,9 +686,6 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
                             };
                             auto stage_b = [&](int i) {
                                 const int rv[4] = {ro[i % 3].x, ro[i % 3].y, ro[i % 3].z, ro[i % 3].w};
-#if TSGU_LAT_PROBE == 3   // probe build (wrong results): a third of the dense-row reads
-                                if (i >= 2) return;
-#endif
 #pragma unroll
                                 for (int j = 0; j < 4; ++j) load_b(rv[j], b[i & 1][j]);
                             };
@@ -794,9 +778,6 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
                             uint4 b[2][4][CPL];
                             auto stage_b = [&](int i) {
                                 const int rv[4] = {ro[i % 3].x, ro[i % 3].y, ro[i % 3].z, ro[i % 3].w};
-#if TSGU_LAT_PROBE == 3   // probe build (wrong results): a third of the dense-row reads
-                                if (i >= 2) return;
-#endif
 #pragma unroll
                                 for (int j = 0; j < 4; ++j) load_b(rv[j], b[i & 1][j]);
                             };
@@ -873,9 +854,6 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
                                 }
 #pragma unroll
                                 for (int j = 0; j < 4; ++j) {
-#if TSGU_LAT_PROBE == 3
-                                    if (i < 2)
-#endif
                                     load_b(go[j], b[i & 1][j]);
                                     a[i & 1][j] = load_val(vcb + vo[j]);
                                 }
@@ -932,9 +910,7 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
         x_run = wrap(x_run + 1, P.nx);
         lat_step_sync();
     }
-#if TSGU_LAT_PROBE != 2
     flush(prow_prev);
-#endif
     if constexpr (kCanDot) {
         if (want_dot) {
             // the workgroup's partial row: column cc = chunk·VEC + v summed over the lanes that own that chunk, in lane order

@@ -117,11 +117,10 @@ __device__ __forceinline__ float group_sum_t8(float d0, float d1, float d2, floa
     return b2 ? hi : lo;
 }
 
-// MASK: the pattern's displacement set when it is one of the sets the kernels are compiled for (march.hip: the whole box, the
-// 7-point cross, the triangular halves of both): straight-line code without per-displacement tests.  The whole box (FULL)
-// also copies the value rows of waves whose rows are all of the canonical class with the 16-byte DMA.  MASK = 0: any other
-// subset, P.mask at run time — the products of a (part, tap) pair are skipped by wave-uniform branches; subsets gather every
-// value row through kidx (waves of canonical rows: without a look-up).
+// MASK: the pattern's displacement set — one of the sets the kernels are compiled for (march_sets.h: the whole box; the SDDMM
+// of the triangular halves): straight-line code, the tests on MASK fold at compile time.  The whole box (FULL) also copies
+// the value rows of waves whose rows are all of the canonical class with the 16-byte DMA; subsets gather every value row
+// through kidx (waves of canonical rows: without a look-up).
 //
 // ROWS — where a row's values start:
 //   kRowsUniform  every row stores the same number of entries (P.uniform; periodic lattices): row r starts at r·P.uniform
@@ -135,21 +134,16 @@ __device__ __forceinline__ float group_sum_t8(float d0, float d1, float d2, floa
 // slots for them hold 0.  The halo rows beyond a face are ZERO in LDS (never fetched, cleared once), halo planes beyond an x
 // face are skipped — so the only products that involve a staged zero value are 0 · 0, and no row touches a dense row it does
 // not reference (non-finite operands behave as in the reference).
-#ifndef TSGU_MARCH_SDDMM_WAVES
-#define TSGU_MARCH_SDDMM_WAVES 4
-#endif
-// waves per SIMD the register allocation aims at: 4 (at most 128 VGPRs); the SDDMM of a truncated box [experiment macro]
-constexpr int march_waves(int mode, bool full, bool uni) { return mode == kLatSddmm && full && !uni ? TSGU_MARCH_SDDMM_WAVES : 4; }
 constexpr uint32_t kBoxAll = (1u << 27) - 1u;      // every displacement of the 3 x 3 x 3 box
 
 enum MarchRows { kRowsPointer = 0, kRowsUniform = 1, kRowsBox = 2 };
 
 template <typename V, int CL, int MODE, int NT, int NTAP, uint32_t MASK, int ROWS>
-__global__ __launch_bounds__(NT, march_waves(MODE, MASK == kBoxAll, ROWS != kRowsPointer)) void march_kernel(const MarchParams P) {
+__global__ __launch_bounds__(NT, 4) void march_kernel(const MarchParams P) {     // 4 waves per SIMD: at most 128 VGPRs
     constexpr bool PTR = ROWS == kRowsPointer, UNIF = ROWS == kRowsUniform, BOXA = ROWS == kRowsBox;
     static_assert(!BOXA || MASK == kBoxAll, "row starts by box arithmetic: the whole box only");
     constexpr bool FULL = MASK == kBoxAll;     // the whole box
-    constexpr bool CT = MASK != 0;             // the displacement set is known at compile time (else: P.mask)
+    static_assert(MASK != 0 && MASK <= kBoxAll, "a displacement set of the 3 x 3 x 3 box");
     static_assert(sizeof(V) == 4, "fp32 values and operands");
     constexpr int RB = CL * 16;                 // bytes of a dense row
     constexpr int NG = NT / CL;                 // row groups of the workgroup
@@ -178,16 +172,9 @@ __global__ __launch_bounds__(NT, march_waves(MODE, MASK == kBoxAll, ROWS != kRow
     const int PB = HR * RB;
     const int plane_rows = P.ny * P.nz;
     auto wrap = [](int v, int m) { return v >= m ? v - m : v; };
-    auto has = [&](int bit) -> bool {           // displacement `bit` occurs in the pattern (wave-uniform for a uniform `bit`)
-        if constexpr (CT) return ((MASK >> bit) & 1u) != 0;
-        else return ((P.mask >> bit) & 1u) != 0;
-    };
-    const uint32_t mask = CT ? MASK : P.mask;
-    // run-time displacement sets: keeps the compiler from turning a skipped product into a computed-and-discarded one (a
-    // v_cndmask per accumulator register and product)
-    auto branchy = [&]() {
-        if constexpr (!CT) asm volatile("" ::: "memory");
-    };
+    // displacement `bit` occurs in the pattern: a compile-time fact wherever `bit` is one (the unrolled tap loops)
+    auto has = [](int bit) -> bool { return ((MASK >> bit) & 1u) != 0; };
+    constexpr uint32_t mask = MASK;
 
     // ---- the tile and x segment of this workgroup (as lattice_kernel) ---------------------------------------------
     const int64_t vblock = xcd_chunked_block(blockIdx.x, P.nblocks);
@@ -582,7 +569,6 @@ __global__ __launch_bounds__(NT, march_waves(MODE, MASK == kBoxAll, ROWS != kRow
                         for (int i = 0; i < NTAP; ++i) {
                             b[i] = make_uint4(0, 0, 0, 0);
                             if (has(i) || has(NTAP + i) || has(2 * NTAP + i)) {
-                                branchy();
                                 b[i] = *reinterpret_cast<const uint4*>(bb + tapb[i]);
                             }
                         }
@@ -592,17 +578,14 @@ __global__ __launch_bounds__(NT, march_waves(MODE, MASK == kBoxAll, ROWS != kRow
                             as4(b[i], f);
                             const float a0 = a[0][i - 4 * first[0]], a1 = a[1][NTAP + i - 4 * first[1]], a2 = a[2][2 * NTAP + i - 4 * first[2]];
                             if (has(i)) {
-                                branchy();
 #pragma unroll
                                 for (int v = 0; v < 4; ++v) accN[v] = fmaf(a0, f[v], accN[v]);
                             }
                             if (has(NTAP + i)) {
-                                branchy();
 #pragma unroll
                                 for (int v = 0; v < 4; ++v) accC[v] = fmaf(a1, f[v], accC[v]);
                             }
                             if (has(2 * NTAP + i)) {
-                                branchy();
 #pragma unroll
                                 for (int v = 0; v < 4; ++v) accP[v] = fmaf(a2, f[v], accP[v]);
                             }
@@ -652,7 +635,6 @@ __global__ __launch_bounds__(NT, march_waves(MODE, MASK == kBoxAll, ROWS != kRow
                             b[i] = make_uint4(0, 0, 0, 0);
                             a[i][0] = a[i][1] = a[i][2] = 0.f;
                             if (has(sN) || has(sC) || has(sP)) {
-                                branchy();
                                 b[i] = *reinterpret_cast<const uint4*>(bb + tapb[i]);
                                 if (has(sN)) a[i][0] = *reinterpret_cast<const float*>(vr + sN * 4);
                                 if (has(sC)) a[i][1] = *reinterpret_cast<const float*>(vr + sC * 4);
@@ -665,17 +647,14 @@ __global__ __launch_bounds__(NT, march_waves(MODE, MASK == kBoxAll, ROWS != kRow
                             float f[4];
                             as4(b[i], f);
                             if (has(sN)) {
-                                branchy();
 #pragma unroll
                                 for (int v = 0; v < 4; ++v) accN[v] = fmaf(a[i][0], f[v], accN[v]);
                             }
                             if (has(sC)) {
-                                branchy();
 #pragma unroll
                                 for (int v = 0; v < 4; ++v) accC[v] = fmaf(a[i][1], f[v], accC[v]);
                             }
                             if (has(sP)) {
-                                branchy();
 #pragma unroll
                                 for (int v = 0; v < 4; ++v) accP[v] = fmaf(a[i][2], f[v], accP[v]);
                             }
@@ -840,7 +819,6 @@ __global__ __launch_bounds__(NT, march_waves(MODE, MASK == kBoxAll, ROWS != kRow
                     for (int i = 0; i < NTAP; ++i) {
                         b[i] = make_uint4(0, 0, 0, 0);
                         if (has(i) || has(NTAP + i) || has(2 * NTAP + i)) {
-                            branchy();
                             b[i] = *reinterpret_cast<const uint4*>(bb + tapb[i]);
                         }
                     }

@@ -78,25 +78,6 @@ constexpr int kRpAbsent = 0x8000;
 #ifndef TSGU_RP_U
 #define TSGU_RP_U 4
 #endif
-// Phase probes — compiled only with -DTSGU_RP_PROBES (never in the product build: without that guard every probe macro is
-// dropped right here).
-// (tools/build_variant_one.sh + tools/ab_kbench.sh; every one of them gives WRONG RESULTS and exists only
-// to time what is left when a part of the kernel is taken away — DESIGN.md §3 lists what they showed):
-//   TSGU_RP_NOGATHER  no dense-row loads            TSGU_RP_NOSTORE  no result rows written
-//   TSGU_RP_NOWALK    staging + epilogue only       TSGU_RP_NODOT    backward without its SDDMM half
-//   TSGU_RP_NOGRADA   backward without the gradA write
-//   TSGU_RP_FAKEVAL   value slice read from an L2-resident 16 KB
-//   TSGU_RP_FAKEPERM  consecutive value positions (coalesced value reads and gradA writes)
-#ifndef TSGU_RP_PROBES
-#undef TSGU_RP_NOGATHER
-#undef TSGU_RP_NOSTORE
-#undef TSGU_RP_NOWALK
-#undef TSGU_RP_NODOT
-#undef TSGU_RP_NOGRADA
-#undef TSGU_RP_FAKEVAL
-#undef TSGU_RP_FAKEPERM
-#endif
-
 // PERM : the values are addressed through the (workgroup-sorted) permutation `sperm`
 // SLOTS: union records carry explicit value slots (`upos`); otherwise ownership bits + running counters
 // R    : rows per lane group — 2 (pairs: every mode) or 4 (quads: stored-order walks without slots; the union of four
@@ -203,9 +184,6 @@ __global__ __launch_bounds__(kBlock) TSGU_RP_OCC void csr_rowpack_kernel(const R
             if (q * kBlock < ne) {
                 // dictionary tables are shared by many workgroups: keep them cacheable; streams are single-use
                 if (t < ne) qv[q] = (dict ? sp[t] : stream_load(sp + t)) + permbase;
-#if defined(TSGU_RP_FAKEPERM)
-                if (t < ne) qv[q] = (int)(((int64_t)vb * ne + t) % P.nnz);
-#endif
             }
         }
     }
@@ -232,11 +210,7 @@ __global__ __launch_bounds__(kBlock) TSGU_RP_OCC void csr_rowpack_kernel(const R
             const int t = q * kBlock + tid;
             if (q * kBlock < ne) {
                 if (t < ne) {
-#if defined(TSGU_RP_FAKEVAL)
-                    const V* vsrc = val + ((PERM ? qv[PERM ? q : 0] : (int)(e0 + t)) & 4095);
-#else
                     const V* vsrc = PERM ? val + qv[PERM ? q : 0] : val + e0 + t;
-#endif
                     if constexpr (kDma) {
                         __builtin_amdgcn_global_load_lds((rp_glb_ptr)vsrc, (rp_lds_ptr)(s_val + q * kBlock + wave * kWave), 4, 0, PERM ? 0 : 2);
                     } else {
@@ -280,11 +254,6 @@ __global__ __launch_bounds__(kBlock) TSGU_RP_OCC void csr_rowpack_kernel(const R
     const char* __restrict__ Sbase = reinterpret_cast<const char*>(Sv);
     const uint32_t ldbb = (uint32_t)P.lds_ * (uint32_t)sizeof(V), cl16 = (uint32_t)cl * 16u;
     auto gather = [&](int c, float (&g)[VEC]) {
-#if defined(TSGU_RP_NOGATHER)
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) g[v] = __int_as_float(c + v);
-        return;
-#endif
         if constexpr (SMALL) {
             const uint32_t boff = __umul24((uint32_t)c, ldbb) + cl16;
             load_vec<V, VEC>(reinterpret_cast<const V*>(Sbase + boff), g);
@@ -298,7 +267,6 @@ __global__ __launch_bounds__(kBlock) TSGU_RP_OCC void csr_rowpack_kernel(const R
             if (!(half & kRpAbsent)) {  // uniform inside the CL lanes of an entry lane, divergent across the wave: exec-masked
                 const float a = s_val[half];
                 axpy(a, g, a_);
-#if !defined(TSGU_RP_NODOT)
                 if constexpr (MODE == kRpBwd) {
                     float d = own_[0] * g[0];
 #pragma unroll
@@ -306,14 +274,10 @@ __global__ __launch_bounds__(kBlock) TSGU_RP_OCC void csr_rowpack_kernel(const R
                     d = group_sum<float, CL>(d);
                     if (cl == 0) s_val[half] = d;
                 }
-#endif
             }
         };
         constexpr int OB = MODE != kRpSpmm ? 1 : 0;  // own[] has one row only for SpMM (unused)
         int i = lo + ep;
-#if defined(TSGU_RP_NOWALK)
-        i = hi;
-#endif
         for (; i + (U - 1) * EP < hi; i += U * EP) {
             int c[U];
             uint32_t w[U];
@@ -375,9 +339,6 @@ __global__ __launch_bounds__(kBlock) TSGU_RP_OCC void csr_rowpack_kernel(const R
                 }
             }
         };
-#if defined(TSGU_RP_NOWALK)
-        i = hi;
-#endif
         for (; i + U <= hi; i += U) {
             uint32_t w[U];
             float g[U][VEC];
@@ -398,11 +359,7 @@ __global__ __launch_bounds__(kBlock) TSGU_RP_OCC void csr_rowpack_kernel(const R
 
     if constexpr (MODE != kRpSddmm) {
         V* __restrict__ out = static_cast<V*>(P.out);
-#if defined(TSGU_RP_NOSTORE)
-        if (ep == 0 && acc2[0][0].x == 12345.678f) {   // never true
-#else
         if (ep == 0) {
-#endif
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 if (row_ok[r]) {
@@ -440,11 +397,7 @@ __global__ __launch_bounds__(kBlock) TSGU_RP_OCC void csr_rowpack_kernel(const R
         for (int q = 0; q < MAXQ; ++q) {
             const int t = q * kBlock + tid;
             if (q * kBlock < ne) {
-#if defined(TSGU_RP_NOGRADA)
-                if (t < ne && s_val[t] == 12345.678f) gout[qv[q]] = T::down(s_val[t]);   // never true
-#else
                 if (t < ne) gout[qv[q]] = T::down(s_val[t]);
-#endif
             }
         }
     }
