@@ -148,14 +148,20 @@ def _measured_cfg(lp, mode: int, dense: torch.Tensor, cfg):
             _be.csr_spmm_lattice(lp, c, val, dense)
 
     def time_ms(c):
+        # the better of two timings of four launches: a single timing picked a 30 % slower configuration now and then (clock
+        # ramps, a neighbour's launch) and the choice is final for the pattern
         run(c)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(4):
-            run(c)
-        e1.record()
-        e1.synchronize()
-        return e0.elapsed_time(e1) / 4
+        best = None
+        for _ in range(2):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(4):
+                run(c)
+            e1.record()
+            e1.synchronize()
+            t = e0.elapsed_time(e1) / 4
+            best = t if best is None or t < best else best
+        return best
 
     events, _be.KERNEL_EVENTS = _be.KERNEL_EVENTS, None      # (bench.py's per-kernel hook does not see the trial launches)
     try:

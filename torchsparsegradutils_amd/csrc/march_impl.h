@@ -343,6 +343,37 @@ __global__ __launch_bounds__(NT, 4) void march_kernel(const MarchParams P) {    
         }
     }
 
+    // INTERIOR planes (1 <= x <= nx - 2): the class of the row at (x, y, z) depends on (y, z) only — whether it wraps / sits at a
+    // face in y or z — so everything a wave looks up to stage its value rows is the same at every step: found ONCE here.
+    //   mid_plain  bit q: the wave's rows of pass q are all of the canonical class (plain 16-byte copies)
+    //   gk[q][n]   the gather lane's source, relative to the plane: stored position of its slot (+ NS · row for rows of one
+    //              length), or -1: nothing to request
+    // The tiles at a y / z face gather at EVERY step, and a launch takes as long as its slowest workgroup: with the look-ups
+    // (two dependent LDS round trips per slot group) inside the march the C2 forward took 83 us, the transposed product 98 us;
+    // with every wave on the plain copy (wrong results) 69 / 78 us.  Only the two x-face planes still look up per step.
+    int mid_plain = 0;
+    int gk[PTR ? 1 : NPASS][PTR ? 1 : NGI];
+    if constexpr (MODE != kLatSddmm && !PTR) {
+        const int prow_mid = row_of_x(1);
+#pragma unroll
+        for (int q = 0; q < NPASS; ++q) {
+            const int first = q * NG + wave * RPW;
+            const int cm = srow[q] >= 0 ? (int)P.rcls[prow_mid + srow[q]] : P.ident;
+            if (FULL && __builtin_amdgcn_ballot_w64(srow[q] >= 0 && cm != P.ident) == 0) mid_plain |= 1 << q;
+            const bool allid = !FULL && __builtin_amdgcn_ballot_w64(srow[q] >= 0 && cm != P.ident) == 0;
+#pragma unroll
+            for (int n = 0; n < NGI; ++n) {
+                const int e = n * kWave + lane;
+                const int rw = e / SLOTS, slot = e - rw * SLOTS;
+                const int rc = __builtin_amdgcn_ds_bpermute((rw < RPW ? rw * CL : 0) * 4, cm);
+                const int rr = (rw < RPW && first + rw < staged_rows) ? rows_s[first + rw] : -1;
+                const int k = allid ? __builtin_popcount(mask & ((1u << (slot & 31)) - 1u)) : (int)kidx_s[rc * 32 + (slot & 31)];
+                const bool want = first < staged_rows && rr >= 0 && slot < NS && has(slot) && k != 0xFF;
+                gk[q][n] = !want ? -1 : (UNIF ? (FULL ? NS : P.uniform) * rr + k : k);
+            }
+        }
+    }
+
     const char* const Sb = static_cast<const char*>(P.S);
     const char* const valb = static_cast<const char*>(P.val);
     const uint32_t val_bytes = (uint32_t)(P.nnz * 4);
@@ -360,14 +391,16 @@ __global__ __launch_bounds__(NT, 4) void march_kernel(const MarchParams P) {    
     // canonical value rows of a lattice plane of the item into the buffer at byte `region`; cls[q] / stt[q] = class and (row
     // pointers) first value position of srow[q]
     // (pbase, pcx: plane_base / plane_cx of the plane — kept up to date by the march, below; unused with row pointers)
-    auto stage_vals = [&](int pbase, int pcx, unsigned region, const int (&cls)[NPASS], const int (&stt)[NPASS]) {
+    // mid: an interior plane — no look-ups (above)
+    auto stage_vals = [&](int pbase, int pcx, bool mid, unsigned region, const int (&cls)[NPASS], const int (&stt)[NPASS]) {
         if constexpr (MODE != kLatSddmm) {
 #pragma unroll
             for (int q = 0; q < NPASS; ++q) {
                 const int first = q * NG + wave * RPW;                       // wave-uniform
                 if (first < staged_rows) {
                     const unsigned wbase = sbase + region + (unsigned)(first * VP);
-                    const bool plain = FULL && __builtin_amdgcn_ballot_w64(srow[q] >= 0 && cls[q] != P.ident) == 0;
+                    const bool plain = FULL && (!PTR && mid ? (mid_plain >> q & 1) != 0
+                                                               : __builtin_amdgcn_ballot_w64(srow[q] >= 0 && cls[q] != P.ident) == 0);
                     if (plain) {
                         // rows of the canonical class hold all NS values in canonical order: a plain copy
 #pragma unroll
@@ -395,8 +428,18 @@ __global__ __launch_bounds__(NT, 4) void march_kernel(const MarchParams P) {    
                                 }
                             }
                         }
+                    } else if (!PTR && mid) {
+                        // an interior plane: every lane knows its source
+#pragma unroll
+                        for (int n = 0; n < NGI; ++n) {
+                            const int gkn = gk[PTR ? 0 : q][PTR ? 0 : n];
+                            uint32_t src;
+                            if constexpr (BOXA) src = (uint32_t)(pbase + gkn) * 4u + __umul24((uint32_t)pcx, (uint32_t)gconst[q][n]) * 4u;
+                            else src = (uint32_t)(pbase + gkn) * 4u;
+                            if (gkn >= 0) lat_dma4<MODE == kLatSpmm>(valb, src, wbase + (unsigned)(n * kWave * 4));
+                        }
                     } else {
-                        // gathered through kidx, one lane per canonical slot, one slot group after the other (finding all sources
+                        // (the planes at an x face) gathered through kidx, one lane per canonical slot, one slot group after the other (finding all sources
                         // first and then issuing the requests back to back measured 10-20 us SLOWER per launch at C2).  A wave
                         // whose rows are all of the canonical class (the bulk of a pattern that is a SUBSET of the box) needs no
                         // look-up: the stored position of a slot is the number of the pattern's displacements below it.
@@ -464,6 +507,7 @@ __global__ __launch_bounds__(NT, 4) void march_kernel(const MarchParams P) {    
         // its plane_base / plane_cx, stepped with it: base(x + 1) = base(x) + (entries of plane x) — a handful of scalar
         // instructions per step (the closed forms cost ~25, and these kernels are bound by instruction issue as much as by HBM)
         int vbase = PTR ? 0 : plane_base(x_val), vcx = PTR ? 0 : plane_cx(x_val);
+        auto is_mid = [&](int x) -> bool { return !PTR && x >= 1 && x <= P.nx - 2; };     // (wave-uniform)
         auto next_val_plane = [&]() {
             if constexpr (BOXA) vbase += boxLyz * vcx;
             else if constexpr (UNIF) vbase += plane_rows * (FULL ? NS : P.uniform);
@@ -478,16 +522,16 @@ __global__ __launch_bounds__(NT, 4) void march_kernel(const MarchParams P) {    
         const int last_val = MODE == kLatSpmm ? L : L + 1;
 #pragma unroll
         for (int q = 0; q < NPASS; ++q) cls[q] = cld[q] = P.ident, stt[q] = std_[q] = 0;
-        if (x_ok(first_val)) {
+        if (x_ok(first_val) && !is_mid(x_val)) {
             load_cls(row_of_x(x_val), cls, stt);
             pin_cls(cls, stt);
         }
         if (x_ok(0)) dma_ring(row_of_x(x_ring), 0);
-        if (x_ok(first_val)) stage_vals(vbase, vcx, (unsigned)(P.o_vals + (MODE == kLatSpmm ? 1 : 0) * vbuf), cls, stt);
+        if (x_ok(first_val)) stage_vals(vbase, vcx, is_mid(x_val), (unsigned)(P.o_vals + (MODE == kLatSpmm ? 1 : 0) * vbuf), cls, stt);
         x_ring = wrap(x_ring + 1, P.nx);
         next_val_plane();
         const int first_next = first_val + 1;                               // ring index of the next value plane
-        if (first_next <= last_val && x_ok(first_next)) load_cls(row_of_x(x_val), cld, std_);
+        if (first_next <= last_val && x_ok(first_next) && !is_mid(x_val)) load_cls(row_of_x(x_val), cld, std_);
         lat_step_sync();
 
         float accP[4], accC[4], accN[4], done[4];
@@ -513,11 +557,11 @@ __global__ __launch_bounds__(NT, 4) void march_kernel(const MarchParams P) {    
             // 2. asynchronous fetches: the next halo plane, the next value plane
             if (s + 1 <= L + 1 && x_ok(s + 1)) dma_ring(row_of_x(x_ring), (s + 1) & 1);
             const int vnext = MODE == kLatSpmm ? s + 2 : s + 1;
-            if (vnext <= last_val && x_ok(vnext)) stage_vals(vbase, vcx, (unsigned)(P.o_vals + (vnext & (VB - 1)) * vbuf), cls, stt);
+            if (vnext <= last_val && x_ok(vnext)) stage_vals(vbase, vcx, is_mid(x_val), (unsigned)(P.o_vals + (vnext & (VB - 1)) * vbuf), cls, stt);
             x_ring = wrap(x_ring + 1, P.nx);
             next_val_plane();
             // 3. class bytes for the next step
-            if (vnext + 1 <= last_val && x_ok(vnext + 1)) load_cls(row_of_x(x_val), cld, std_);
+            if (vnext + 1 <= last_val && x_ok(vnext + 1) && !is_mid(x_val)) load_cls(row_of_x(x_val), cld, std_);
             // 4. source plane s: targets s+1 (N, part 0), s (C, part 1), s-1 (P, part 2).  A target outside 1..L accumulates
             // whatever its value buffer holds: it is never stored
 #pragma unroll
@@ -678,12 +722,30 @@ __global__ __launch_bounds__(NT, 4) void march_kernel(const MarchParams P) {    
             uint4 row;
             int cls, start;
         };
-        auto load_own = [&](int prow, Own& o) {
+        // interior planes (1 <= x <= nx - 2): the row's class — and with it the stored positions of the dots this lane writes — is
+        // the same at every step (see the value staging above): looked up once, no class byte is loaded for those planes
+        auto is_mid = [&](int x) -> bool { return x >= 1 && x <= P.nx - 2; };
+        int kpk[(RJ + 3) / 4];
+        int len_mid;
+        {
+            const int cm = crow >= 0 ? (int)P.rcls[row_of_x(1) + crow] : P.ident;
+#pragma unroll
+            for (int w = 0; w < (RJ + 3) / 4; ++w) kpk[w] = -1;
+#pragma unroll
+            for (int j = 0; j < RJ; ++j) {
+                const int slot = j * CL + c;
+                const int k = (slot < NS && has(slot)) ? (int)kidx_s[cm * 32 + slot] : 0xFF;
+                kpk[j / 4] = (kpk[j / 4] & ~(0xFF << (8 * (j % 4)))) | (k << (8 * (j % 4)));
+            }
+            len_mid = kidx_s[cm * 32 + 31];
+        }
+        auto load_own = [&](int x, Own& o) {
+            const int prow = row_of_x(x);
             o.cls = P.ident;
             o.start = 0;
             o.row = make_uint4(0, 0, 0, 0);
             if (crow >= 0) {
-                o.cls = P.rcls[prow + crow];
+                if (!is_mid(x)) o.cls = P.rcls[prow + crow];
                 if constexpr (PTR) o.start = P.rstart[prow + crow];
                 o.row = *reinterpret_cast<const uint4*>(static_cast<const char*>(P.Own) + (int64_t)prow * P.ldown * 4 + cown);
             }
@@ -701,7 +763,7 @@ __global__ __launch_bounds__(NT, 4) void march_kernel(const MarchParams P) {    
         oP.cls = oC.cls = P.ident;
         oP.start = oC.start = 0;
         int x_own = xs;                                       // lattice plane of ring index 1
-        load_own(row_of_x(x_own), oN);
+        load_own(x_own, oN);
         pin_own(oN);
         x_own = wrap(x_own + 1, P.nx);
         old = oN;
@@ -765,7 +827,7 @@ __global__ __launch_bounds__(NT, 4) void march_kernel(const MarchParams P) {    
             // 2. the next halo plane; 3. own rows of target s+2
             if (s + 1 <= L + 1 && x_ok(s + 1)) dma_ring(row_of_x(x_ring), (s + 1) & 1);
             x_ring = wrap(x_ring + 1, P.nx);
-            if (s + 2 <= L) load_own(row_of_x(x_own), old);
+            if (s + 2 <= L) load_own(x_own, old);
             x_own = wrap(x_own + 1, P.nx);
             // 4. source plane s
             if (crow >= 0) {
@@ -892,18 +954,21 @@ __global__ __launch_bounds__(NT, 4) void march_kernel(const MarchParams P) {    
               }
                 // 5. target s-1 is complete: its dots go to the stage row at their STORED positions
                 if (s >= 2) {
+                    const bool mid = is_mid(x_out);                    // (wave-uniform)
                     const bool plain = FULL && oP.cls == P.ident;
 #pragma unroll
                     for (int j = 0; j < RJ; ++j) {
                         const int slot = j * CL + c;
                         if (slot < NS && has(slot)) {
-                            const int k = plain ? slot : (int)kidx_s[oP.cls * 32 + slot];
+                            int k;
+                            if (mid) k = (kpk[j / 4] >> (8 * (j % 4))) & 0xFF;
+                            else k = plain ? slot : (int)kidx_s[oP.cls * 32 + slot];
                             if (UNIF || k != 0xFF) st[k] = P.alpha * rP[j];
                         }
                     }
                     if constexpr (PTR) fl_start = oP.start;
                     else fl_start = plane_base(x_out) + plane_cx(x_out) * own_const;
-                    fl_len = (FULL && UNIF) ? NS : (int)kidx_s[oP.cls * 32 + 31];
+                    fl_len = (FULL && UNIF) ? NS : (mid ? len_mid : (int)kidx_s[oP.cls * 32 + 31]);
                     staged = true;
                 }
             }
