@@ -285,7 +285,15 @@ def patterns_leg(dev, steps, warmup, headline):
             else:
                 fam = "plan-free gather"
             tr = wire.get(name)
-            out[name] = {"what": what, "n": n, "nnz": nnz, "rhs": p, "kernels": fam, "ms_per_step": round(ms, 5),
+            cfgs = {}
+            for lpl in (lp, plan.core.own.get("lattice_t")):
+                if lpl is None:
+                    continue
+                for key, c in list(lpl._cfg.items()) + (list(lpl._march._cfg.items()) if getattr(lpl, "_march", None) else []):
+                    if c is not None:
+                        kind = ("march " if getattr(c, "march", False) else "sweep ") + {0: "fwd", 1: "sddmm", 2: "spmm_t", 3: "bwd"}.get(key[0], str(key[0]))
+                        cfgs[kind] = f"{c.ty}x{c.tz} tile, {c.nseg} x-segments, {c.threads} threads" + (", measured choice" if getattr(c, "tuned", False) else "")
+            out[name] = {"what": what, "n": n, "nnz": nnz, "rhs": p, "kernels": fam, "launch_configurations": cfgs or None, "ms_per_step": round(ms, 5),
                          "algorithmic_bytes_per_step": ab, "frac": round(ab / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                          "traffic": tr, "frac_wire": None if tr is None else round(tr / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
             del A, B, G, crow, col, plan, lp
@@ -453,6 +461,32 @@ def main():
         ms_single_thread = None
     finally:
         torch.autograd.set_multithreading_enabled(True)
+
+    # ---- the same step captured once in a HIP graph and replayed: what the step costs when the host is out of the way (a slow host
+    # makes the eager step host-bound: host_ms_per_step against the kernels' ~0.24 ms).  Reported next to ms_per_step, never as `value`.
+    ms_graph = graph_note = None
+    try:
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                step()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            Cg = sparse_mm(A, B)
+            gAg, gBg = torch.autograd.grad(Cg, (A, B), G)
+        for _ in range(5):
+            graph.replay()
+        ms_graph = timed_loop(graph.replay)
+        Ce = sparse_mm(A, B)
+        gAe, gBe = torch.autograd.grad(Ce, (A, B), G)
+        same = torch.equal(Cg, Ce.detach()) and torch.equal(gAg.values(), gAe.values()) and torch.equal(gBg, gBe)
+        graph_note = "forward + backward captured by torch.cuda.graph, results bit-identical to the eager step" if same else "MISMATCH against the eager step"
+        del graph, Cg, gAg, gBg, Ce, gAe, gBe
+    except Exception as exc:  # noqa: BLE001
+        graph_note = "capture failed: " + repr(exc)[:200]
 
     # ---- the step's two halves inside the autograd step (HIP events around the forward and around the backward) ----
     def step_halves():
@@ -628,6 +662,8 @@ def main():
             "ms_per_step_backward_call": round(ms_backward_call, 5),
             "ms_per_step_single_thread_autograd": None if ms_single_thread is None else round(ms_single_thread, 5),
             "host_ms_per_step": None if host_ms is None else round(host_ms, 5),
+            "ms_per_step_graph_replay": None if ms_graph is None else round(ms_graph, 5),
+            "graph_replay_note": graph_note,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,

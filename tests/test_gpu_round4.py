@@ -348,3 +348,45 @@ def test_batched_lanczos_matrices_when_fewer_columns_than_right_hand_sides():
             # a callable operator sees its own (batch, n, k) layout
             x2, T2 = linear_cg(lambda v: torch.stack([A @ v[i] for i in range(v.size(0))]), rhs.clone(), **kw)
             assert G.rel_err(T2.cpu().numpy(), z[tag + "_T"]) < 1e-9 and G.rel_err(x2.cpu().numpy(), z[tag + "_x"]) < 1e-9, tag
+
+
+def test_forward_backward_step_is_capturable_in_a_hip_graph(monkeypatch):
+    """sparse_mm forward + backward (plane-march kernels) under torch.cuda.graph: no plan is built, no host read-back and no
+    side allocation happens inside a capture once the pattern has been seen; the replayed step equals the eager one bit for
+    bit and follows new operand values (the plan does not depend on them)."""
+    from torchsparsegradutils_amd import _ops, sparse_mm
+    from torchsparsegradutils_amd.utils import synthetic
+
+    monkeypatch.setattr(_ops, "ENABLE_LATTICE", True)
+    monkeypatch.setattr(_ops, "PACK_MIN_NNZ", 1)
+    nx, ny, nz, p = 12, 16, 16, 32
+    n = nx * ny * nz
+    crow, col = synthetic.box_stencil(nx, ny, nz, (False, False, False), 27, None, torch.int32, DEV)
+    g = torch.Generator(device=DEV).manual_seed(3)
+    A = torch.sparse_csr_tensor(crow, col, torch.randn(col.numel(), device=DEV, generator=g), (n, n)).requires_grad_(True)
+    B = torch.randn(n, p, device=DEV, generator=g).requires_grad_(True)
+    Gd = torch.randn(n, p, device=DEV, generator=g)
+
+    def step():
+        C = sparse_mm(A, B)
+        gA, gB = torch.autograd.grad(C, (A, B), Gd)
+        return C, gA, gB
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        Cg, gAg, gBg = step()
+    for trial in range(2):
+        graph.replay()
+        torch.cuda.synchronize()
+        Ce, gAe, gBe = step()
+        assert torch.equal(Cg, Ce) and torch.equal(gAg.values(), gAe.values()) and torch.equal(gBg, gBe), trial
+        with torch.no_grad():       # new values in the same buffers: the next replay must see them
+            A.values().mul_(-1.5)
+            B.add_(0.25)

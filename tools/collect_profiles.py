@@ -142,3 +142,36 @@ if traffic or patterns:
     }
     json.dump(out, open(os.path.join(dst, "hbm_traffic.json"), "w"), indent=1)
     print(json.dumps({k: v for k, v in out.items() if not k.startswith("_")}, indent=1))
+
+
+# The bench line above was printed before this round's counters existed (its traffic fields quote the previous round's file):
+# re-derive the wire fields of the SAVED line from the counters just collected — durations are the line's own.
+saved = os.path.join(dst, f"{tag}_bench_c2.json")
+if os.path.exists(saved) and os.path.exists(os.path.join(dst, "hbm_traffic.json")):
+    line = json.load(open(saved))
+    tj = json.load(open(os.path.join(dst, "hbm_traffic.json")))
+    peak = 8000.0
+    key = {"SpMM (": "lattice_spmm", "SDDMM (": "lattice_sddmm", "SpMM-T (": "lattice_spmm_t"}
+    roof = line.get("roofline") or {}
+    for frag, k in key.items():
+        if frag in roof.get("kernel", "") and tj.get(k):
+            roof["traffic"] = tj[k]
+            roof["frac_wire"] = round(tj[k] / (roof["avg_launch_ms"] * 1e-3) / 1e9 / peak, 4)
+            roof["traffic_source"] = f"{tj['source']}@{tj['commit']} (rocprofv3 PMC passes of the same tree, tools/prof_round.sh; re-derived by tools/collect_profiles.py)"
+    pats = line.get("patterns") or {}
+    for name, bytes_ in (tj.get("patterns") or {}).items():
+        if name in pats and "ms_per_step" in pats[name]:
+            pats[name]["traffic"] = bytes_
+            pats[name]["frac_wire"] = round(bytes_ / (pats[name]["ms_per_step"] * 1e-3) / 1e9 / peak, 4)
+    if "c2_27pt_periodic" in (tj.get("patterns") or {}):
+        line["step_traffic"] = tj["patterns"]["c2_27pt_periodic"]
+        line["frac_of_hbm_peak_wire"] = round(line["step_traffic"] / (line["ms_per_step"] * 1e-3) / 1e9 / peak, 4)
+    if line.get("kernels_GBps_wire") is not None or True:
+        wire = {}
+        for kname, ms in (line.get("kernels_ms") or {}).items():
+            for frag, k in key.items():
+                if "march_kernel " + frag in kname and tj.get(k):
+                    wire[kname] = round(tj[k] / (ms * 1e-3) / 1e9, 1)
+        line["kernels_GBps_wire"] = wire or None
+    json.dump(line, open(saved, "w"))
+    print("re-derived the wire fields of", saved)
