@@ -466,6 +466,8 @@ def main():
     # makes the eager step host-bound: host_ms_per_step against the kernels' ~0.24 ms).  Reported next to ms_per_step, never as `value`.
     ms_graph = graph_note = None
     try:
+        if world > 1:
+            raise RuntimeError("single-GPU runs only (a rank that failed to capture would leave the others in the timing barrier)")
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
@@ -486,7 +488,7 @@ def main():
         graph_note = "forward + backward captured by torch.cuda.graph, results bit-identical to the eager step" if same else "MISMATCH against the eager step"
         del graph, Cg, gAg, gBg, Ce, gAe, gBe
     except Exception as exc:  # noqa: BLE001
-        graph_note = "capture failed: " + repr(exc)[:200]
+        graph_note = "not measured: " + repr(exc)[:200]
 
     # ---- the step's two halves inside the autograd step (HIP events around the forward and around the backward) ----
     def step_halves():

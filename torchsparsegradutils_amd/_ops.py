@@ -148,18 +148,18 @@ def _measured_cfg(lp, mode: int, dense: torch.Tensor, cfg):
             _be.csr_spmm_lattice(lp, c, val, dense)
 
     def time_ms(c):
-        # the better of two timings of four launches: a single timing picked a 30 % slower configuration now and then (clock
-        # ramps, a neighbour's launch) and the choice is final for the pattern
+        # the best of three timings of six launches: a single timing of four picked a 30 % slower configuration now and then
+        # (clock ramps, a neighbour's launch) and the choice is final for the pattern
         run(c)
         best = None
-        for _ in range(2):
+        for _ in range(3):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            for _ in range(4):
+            for _ in range(6):
                 run(c)
             e1.record()
             e1.synchronize()
-            t = e0.elapsed_time(e1) / 4
+            t = e0.elapsed_time(e1) / 6
             best = t if best is None or t < best else best
         return best
 
