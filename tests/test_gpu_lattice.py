@@ -573,7 +573,10 @@ def test_measured_configuration_choice_keeps_the_bits(dt, p, monkeypatch):
     assert len(log) == 3 and sorted(e[1] for e in log) == [0, 1, 2]     # forward, SDDMM, transposed product: once each
     for kind, mode, vtype, width, tried, chosen in log:
         assert width == p and len(tried) >= 2 and chosen in [c for c, _ in tried]
-        assert min(ms for _, ms in tried) == dict(tried)[chosen]
+        # the fastest candidate — or the ranked configuration (the first one tried) when nothing beat it by the margin the
+        # trial can resolve (`_lattice.TUNE_MARGIN`)
+        fastest = min(ms for _, ms in tried)
+        assert dict(tried)[chosen] == fastest or (chosen == tried[0][0] and fastest > lt.TUNE_MARGIN * tried[0][1])
     for out in later:
         for a, b in zip(first, out):
             assert torch.equal(a, b)

@@ -563,9 +563,11 @@ def csr_spmm_lattice(lp, cfg, val, B, dot: bool = False):
     if not B.is_cuda or val.device != dev:
         require_device(val, B)
         raise RuntimeError(f"all operands must be on the same device, got {val.device} and {dev}")
-    B = rowmajor(B)
+    if not B.is_contiguous():
+        B = rowmajor(B)
     p = B.size(-1)
-    out = torch.empty((lp.n_rows, p), dtype=B.dtype, device=dev)
+    n_rows = lp.n_rows
+    out = torch.empty((n_rows, p), dtype=B.dtype, device=dev)
     if not val.is_contiguous():
         val = val.contiguous()
     march = getattr(cfg, "march", False)
@@ -576,24 +578,36 @@ def csr_spmm_lattice(lp, cfg, val, B, dot: bool = False):
         nwg = lp.nb * cfg.nseg * -(-lp.ny // cfg.ty) * -(-lp.nz // cfg.tz)
         partial = torch.empty((nwg, p), dtype=B.dtype, device=dev)
         with _on_device(dev):
-            rc = lib.tsgu_csr_spmm_lattice_dot(_VTYPE[val.dtype], cfg.struct_addr, lp.n_rows, lp.nnz, val.data_ptr(), B.data_ptr(), _ld(B),
+            rc = lib.tsgu_csr_spmm_lattice_dot(_VTYPE[val.dtype], cfg.struct_addr, n_rows, lp.nnz, val.data_ptr(), B.data_ptr(), _ld(B),
                                                out.data_ptr(), p, p, partial.data_ptr(), nwg, dev.index,
                                                _raw_stream(dev))
         if rc:
             check(rc, "tsgu_csr_spmm_lattice_dot")
         return out, partial
     tok = _timed("lattice_spmm_t" if transposed else "lattice_spmm", dev) if KERNEL_EVENTS is not None else None
-    with _on_device(dev):
+    index = dev.index
+    ctx = None if torch.cuda.current_device() == index else torch.cuda.device(dev)      # (the context manager costs ~8 us: only when needed)
+    if ctx is not None:
+        ctx.__enter__()
+    try:
+        ldb = B.stride(0) if B.size(0) > 1 else max(p, 1)
+        stream = torch._C._cuda_getCurrentRawStream(index)
         if march:
             ct = cfg.col_tile          # operands wider than 64 columns: one launch per tile of 64 columns
-            for j in range(0, p, ct):
-                rc = lib.tsgu_csr_spmm_march(_VTYPE[val.dtype], cfg.struct_addr, int(transposed), lp.n_rows, lp.nnz, val.data_ptr(),
-                                             B.data_ptr() + j * 4, _ld(B), out.data_ptr() + j * 4, p, ct, dev.index, _raw_stream(dev))
+            vt, sa, nnz, vp, bp, op = _VTYPE[val.dtype], cfg.struct_addr, lp.nnz, val.data_ptr(), B.data_ptr(), out.data_ptr()
+            fn = lib.tsgu_csr_spmm_march
+            tr = int(transposed)
+            rc = fn(vt, sa, tr, n_rows, nnz, vp, bp, ldb, op, p, ct, index, stream)
+            for j in range(ct, p, ct):
                 if rc:
                     break
+                rc = fn(vt, sa, tr, n_rows, nnz, vp, bp + j * 4, ldb, op + j * 4, p, ct, index, stream)
         else:
-            rc = lib.tsgu_csr_spmm_lattice(_VTYPE[val.dtype], cfg.struct_addr, lp.n_rows, lp.nnz, val.data_ptr(), B.data_ptr(), _ld(B),
-                                           out.data_ptr(), p, p, dev.index, _raw_stream(dev))
+            rc = lib.tsgu_csr_spmm_lattice(_VTYPE[val.dtype], cfg.struct_addr, n_rows, lp.nnz, val.data_ptr(), B.data_ptr(), ldb,
+                                           out.data_ptr(), p, p, index, stream)
+    finally:
+        if ctx is not None:
+            ctx.__exit__(None, None, None)
     if tok is not None:
         _timed_end(tok, dev)
     if rc:
@@ -608,22 +622,35 @@ def csr_sddmm_lattice(lp, cfg, R, Cm, alpha: float = 1.0):
     if not R.is_cuda or Cm.device != dev:
         require_device(R, Cm)
         raise RuntimeError(f"all operands must be on the same device, got {Cm.device} and {dev}")
-    R, Cm = rowmajor(R), rowmajor(Cm)
+    if not R.is_contiguous():
+        R = rowmajor(R)
+    if not Cm.is_contiguous():
+        Cm = rowmajor(Cm)
     p = R.size(-1)
+    n_rows = lp.n_rows
     out = torch.empty((lp.nnz,), dtype=R.dtype, device=dev)
     tok = _timed("lattice_sddmm", dev) if KERNEL_EVENTS is not None else None
-    with _on_device(dev):
+    index = dev.index
+    ctx = None if torch.cuda.current_device() == index else torch.cuda.device(dev)
+    if ctx is not None:
+        ctx.__enter__()
+    try:
+        ldr = R.stride(0) if R.size(0) > 1 else max(p, 1)
+        ldc = Cm.stride(0) if Cm.size(0) > 1 else max(p, 1)
+        stream = torch._C._cuda_getCurrentRawStream(index)
         if getattr(cfg, "march", False):
             ct = cfg.col_tile          # operands wider than 64 columns: the dots of the later column tiles are added to the first
             for j in range(0, p, ct):
-                rc = lib.tsgu_csr_sddmm_march(_VTYPE[R.dtype], cfg.struct_addr, lp.n_rows, lp.nnz, R.data_ptr() + j * 4, _ld(R),
-                                              Cm.data_ptr() + j * 4, _ld(Cm), out.data_ptr(), float(alpha), int(j > 0), ct, dev.index,
-                                              _raw_stream(dev))
+                rc = lib.tsgu_csr_sddmm_march(_VTYPE[R.dtype], cfg.struct_addr, n_rows, lp.nnz, R.data_ptr() + j * 4, ldr,
+                                              Cm.data_ptr() + j * 4, ldc, out.data_ptr(), float(alpha), int(j > 0), ct, index, stream)
                 if rc:
                     break
         else:
-            rc = lib.tsgu_csr_sddmm_lattice(_VTYPE[R.dtype], cfg.struct_addr, lp.n_rows, lp.nnz, R.data_ptr(), _ld(R), Cm.data_ptr(), _ld(Cm),
-                                            out.data_ptr(), float(alpha), p, dev.index, _raw_stream(dev))
+            rc = lib.tsgu_csr_sddmm_lattice(_VTYPE[R.dtype], cfg.struct_addr, n_rows, lp.nnz, R.data_ptr(), ldr, Cm.data_ptr(), ldc,
+                                            out.data_ptr(), float(alpha), p, index, stream)
+    finally:
+        if ctx is not None:
+            ctx.__exit__(None, None, None)
     if tok is not None:
         _timed_end(tok, dev)
     if rc:

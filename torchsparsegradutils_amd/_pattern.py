@@ -649,8 +649,9 @@ _CACHE_MAX_BYTES = int(_os.environ.get("TSGU_PLAN_CACHE_BYTES", str(8 << 30)))
 
 
 def _key(kind: str, tensors, shape) -> tuple:
-    return (kind, tuple(shape)) + tuple(
-        (t.untyped_storage()._cdata, t.storage_offset(), tuple(t.shape), tuple(t.stride()), t.dtype, t._version, str(t.device))
+    # (torch.Size, the stride tuple and torch.device hash as they are: this runs once per product on the host's critical path)
+    return (kind, shape if isinstance(shape, tuple) else tuple(shape)) + tuple(
+        (t.untyped_storage()._cdata, t.storage_offset(), t.shape, t.stride(), t.dtype, t._version, t.device)
         for t in tensors)
 
 
