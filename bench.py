@@ -45,11 +45,41 @@ def alg_bytes(n, nnz, p, I=4, V=4, items=1):
     return {k: v * items for k, v in {"spmm": spmm, "sddmm": sddmm, "spmm_t": spmm, "bwd": fused_bwd, "fwd_bwd": spmm + fused_bwd}.items()}
 
 
-def time_events(fn, reps, dev):
-    """average duration (ms) of fn() over reps launches, HIP events on the launch stream."""
+_HOLD = {}
+
+
+def hold_gpu(dev, ms):
+    """Queue about `ms` milliseconds of device work (large device-to-device copies: the chip stays at its working clocks,
+    which a one-wave spin kernel does not do) on the launch stream, so that what the host queues next waits IN the stream
+    and the GPU never waits for the host: event pairs then time the kernels, not Python (on a slow host an event pair
+    around a launch otherwise includes the host's gap between `record` and the launch)."""
+    if ms <= 0:
+        return
+    if dev not in _HOLD:
+        src = torch.empty(64 << 20, dtype=torch.float32, device=dev)      # 256 MB each way
+        dst = torch.empty_like(src)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(3):
+            dst.copy_(src)
+        torch.cuda.synchronize(dev)
+        a.record()
+        for _ in range(10):
+            dst.copy_(src)
+        b.record()
+        b.synchronize()
+        _HOLD[dev] = (src, dst, max(a.elapsed_time(b) / 10, 1e-3))      # ms per copy
+    src, dst, per = _HOLD[dev]
+    for _ in range(int(min(ms, 200.0) / per) + 1):
+        dst.copy_(src)
+
+
+def time_events(fn, reps, dev, hold_ms=0.0):
+    """average duration (ms) of fn() over reps launches, HIP events on the launch stream.  `hold_ms` > 0: the launches
+    are queued behind that much device work (see hold_gpu), i.e. executed back to back whatever the host's speed."""
     start = torch.cuda.Event(enable_timing=True)
     stop = torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize(dev)
+    hold_gpu(dev, hold_ms)
     start.record()
     for _ in range(reps):
         fn()
@@ -270,8 +300,10 @@ def patterns_leg(dev, steps, warmup, headline):
             t0 = time.perf_counter()
             for _ in range(steps):
                 step()
+            host_ms = (time.perf_counter() - t0) / steps * 1e3      # the host's share: all launches queued, nothing waited for
             torch.cuda.synchronize(dev)
             ms = (time.perf_counter() - t0) / steps * 1e3
+            ms_dev = time_events(step, steps, dev, hold_ms=steps * 1.5 * max(host_ms, 0.15))   # queued behind device work: the GPU's own time
             ab = alg_bytes(n, nnz, p)["fwd_bwd"]
             plan = _pattern.from_csr(A.detach())
             lp = plan.core.own.get("lattice")
@@ -294,6 +326,8 @@ def patterns_leg(dev, steps, warmup, headline):
                         kind = ("march " if getattr(c, "march", False) else "sweep ") + {0: "fwd", 1: "sddmm", 2: "spmm_t", 3: "bwd"}.get(key[0], str(key[0]))
                         cfgs[kind] = f"{c.ty}x{c.tz} tile, {c.nseg} x-segments, {c.threads} threads" + (", measured choice" if getattr(c, "tuned", False) else "")
             out[name] = {"what": what, "n": n, "nnz": nnz, "rhs": p, "kernels": fam, "launch_configurations": cfgs or None, "ms_per_step": round(ms, 5),
+                         "host_ms_per_step": round(host_ms, 5), "host_bound": bool(host_ms > 0.9 * ms),
+                         "ms_per_step_device": round(ms_dev, 5), "frac_device": round(ab / (ms_dev * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                          "algorithmic_bytes_per_step": ab, "frac": round(ab / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                          "traffic": tr, "frac_wire": None if tr is None else round(tr / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
             del A, B, G, crow, col, plan, lp
@@ -500,12 +534,16 @@ def main():
         e[2].record()
         return e
 
-    evs = [step_halves() for _ in range(max(args.steps, 10))]
+    n_ev = max(args.steps, 10)
+    hold_ms = n_ev * 1.5 * max(host_ms or 0.3, 0.15)     # the host's time for n_ev steps, with margin: the launches wait in the stream
+    hold_gpu(dev, hold_ms)
+    evs = [step_halves() for _ in range(n_ev)]
     torch.cuda.synchronize(dev)
     in_step = {"forward": sum(e[0].elapsed_time(e[1]) for e in evs) / len(evs), "backward": sum(e[1].elapsed_time(e[2]) for e in evs) / len(evs)}
     # ... and every kernel of the step by itself: HIP events recorded on the launch stream around each launch, inside the steps
     be.KERNEL_EVENTS = []
-    for _ in range(max(args.steps, 10)):
+    hold_gpu(dev, hold_ms)
+    for _ in range(n_ev):
         step()
     torch.cuda.synchronize(dev)
     kern_in_step = {}
@@ -513,6 +551,8 @@ def main():
         kern_in_step.setdefault(name, []).append(e0.elapsed_time(e1))
     be.KERNEL_EVENTS = None
     kern_in_step = {k: sum(v) / len(v) for k, v in kern_in_step.items()}
+    # ... and the whole step as the GPU sees it: n_ev steps queued behind the held stream, one event pair around all of them
+    ms_device = time_events(step, n_ev, dev, hold_ms=hold_ms)
 
     # ---- per-kernel durations (HIP events on the launch stream), same resident operands ----
     plan = _pattern.from_csr(A.detach())
@@ -546,9 +586,9 @@ def main():
         sdd_name = f"{kname(lat_s[1])} SDDMM (K3 gradA, {cfgs(lat_s[1])})"
         bwd_name = f"{kname(lat_t[1])} SpMM-T (K2 gradB, {cfgs(lat_t[1])})"
         kern = {
-            fwd_name: time_events(lambda: _ops.spmm(plan, vd, Bd), reps, dev),
-            sdd_name: time_events(lambda: _ops.sddmm(plan, G, Bd), reps, dev),
-            bwd_name: time_events(lambda: _ops.spmm_t(plan, vd, G), reps, dev),
+            fwd_name: time_events(lambda: _ops.spmm(plan, vd, Bd), reps, dev, hold_ms=hold_ms / 2),
+            sdd_name: time_events(lambda: _ops.sddmm(plan, G, Bd), reps, dev, hold_ms=hold_ms / 2),
+            bwd_name: time_events(lambda: _ops.spmm_t(plan, vd, G), reps, dev, hold_ms=hold_ms / 2),
         }
         kbytes = {fwd_name: ab["spmm"], sdd_name: ab["sddmm"], bwd_name: ab["spmm_t"]}
         traffic_key = {fwd_name: "lattice_spmm", sdd_name: "lattice_sddmm", bwd_name: "lattice_spmm_t"}
@@ -635,7 +675,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_patterns:
         headline = {"what": "the headline workload (this line's value)", "n": n, "nnz": nnz, "rhs": p,
                     "kernels": "plane march" if lattice and getattr(lat_f_is_march, "march", False) else ("plane sweep" if lattice else "row pairs / plan-free"),
-                    "ms_per_step": round(ms_per_step, 5), "algorithmic_bytes_per_step": ab["fwd_bwd"],
+                    "ms_per_step": round(ms_per_step, 5), "ms_per_step_device": round(ms_device, 5),
+                    "frac_device": round(ab["fwd_bwd"] / (ms_device * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_step": ab["fwd_bwd"],
                     "frac": round(ab["fwd_bwd"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": step_traffic,
                     "frac_wire": None if step_traffic is None else round(step_traffic / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         if args.no_c5:      # (the C5 leg has already released the headline operands otherwise)
@@ -664,6 +705,12 @@ def main():
             "ms_per_step_backward_call": round(ms_backward_call, 5),
             "ms_per_step_single_thread_autograd": None if ms_single_thread is None else round(ms_single_thread, 5),
             "host_ms_per_step": None if host_ms is None else round(host_ms, 5),
+            "ms_per_step_device": round(ms_device, 5),
+            "ms_per_step_device_note": "the same steps queued behind large device copies so that the GPU never waits for Python, one HIP event "
+                                       "pair around all of them: what a step costs the GPU on a host too slow to keep the queue full (the copies "
+                                       "leave the chip at its power limit, so on a fast host the wall clock can be a few percent lower); "
+                                       "ms_per_step is the wall clock and is what `value` uses",
+            "frac_of_hbm_peak_device": round(ab["fwd_bwd"] / (ms_device * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             "ms_per_step_graph_replay": None if ms_graph is None else round(ms_graph, 5),
             "graph_replay_note": graph_note,
             "higher_is_better": True,
