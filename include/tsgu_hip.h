@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define TSGU_ABI_VERSION 3
+#define TSGU_ABI_VERSION 4
 
 typedef enum {
     TSGU_OK = 0,
@@ -286,10 +286,11 @@ int tsgu_csr_spmm_lattice(int vtype, const tsgu_lattice_plan* plan, int64_t n_ro
  * C[row, c]·B[row, c] (the own row of B is the centre of the halo plane in LDS; deterministic).  dot_rows must be the number of
  * workgroups of the configuration, nb·nseg·⌈ny/ty⌉·⌈nz/tz⌉; one chunk per lane.  This entry also takes 16-byte dense rows
  * (p = 4: one lane per row) — replaces tsgu_csr_spmm(..., dot_w = B, ...) inside utils/linear_cg.py:322 + :64-65 on lattice
- * stencils, without reading a column index. */
+ * stencils, without reading a column index.  `skip` (optional, device memory): when *skip != 0 the launch does nothing — the
+ * done word of a solver loop whose iterations are queued ahead of the host's polls. */
 int tsgu_csr_spmm_lattice_dot(int vtype, const tsgu_lattice_plan* plan, int64_t n_rows, int64_t nnz, const void* val,
                               const void* B, int64_t ldb, void* C, int64_t ldc, int64_t p, void* dot_partial, int64_t dot_rows,
-                              int device, void* stream);
+                              const int* skip, int device, void* stream);
 /* out_vals[k] = alpha·<R[row k,:], Cm[col k,:]> in stored order (plan kind 0). */
 int tsgu_csr_sddmm_lattice(int vtype, const tsgu_lattice_plan* plan, int64_t n_rows, int64_t nnz, const void* R, int64_t ldr,
                            const void* Cm, int64_t ldc, void* out_vals, double alpha, int64_t p, int device, void* stream);
@@ -448,6 +449,25 @@ int tsgu_cg_update1(int vtype, int64_t n, int64_t p,
  * tsgu_cg_alpha.  Same operands as the two calls it replaces; returns TSGU_ERR_TOO_LARGE beyond the limits. */
 int tsgu_cg_update1_alpha(int vtype, int64_t n, int64_t p, void* r, const void* Ap, void* x, const void* pvec, const void* pap_partial,
                           int64_t n_partial, void* scal, const int* flags, double eps, void* rr_partial, int device, void* stream);
+/* The two-launch form of an iteration after K1 (same recurrences, reference utils/linear_cg.py:27-95, :319-382; for
+ * n_partial <= 1024 partial rows of p'Ap and p <= 256, no preconditioner).  The single-workgroup step 3 disappears: every
+ * workgroup of the direction update sums the |r|^2 partial rows itself.  For that the values an iteration READS live in half
+ * `parity` (= iteration index & 1) of the state and the values it PRODUCES go to half `parity ^ 1`:
+ *   scal2  [5][p]: rr half 0 | rr half 1 | alpha | beta | rnorm
+ *   flags2 (int32): [0],[1] done by half, [2] iterations executed, [3] unused, [4..4+p) has_converged half 0, [4+p..4+2p) half 1,
+ *                   [4+2p..4+3p) rhs_is_zero
+ * tsgu_cg2_residual:  alpha = safe(rr / sum pAp_partial) (0 for converged columns) ; r -= alpha*Ap ; |r|^2 partials
+ *                     (tsgu_cg2_num_blocks() rows, <= 1024)
+ * tsgu_cg2_direction: beta = safe(rr_new / rr) ; x += alpha*p ; p = r + beta*p ; rr, rnorm, has_converged, the stop rule and the
+ *                     iteration counter into half parity ^ 1
+ * The caller starts with rr, has_converged in half 0, parity 0, and alternates; both are no-ops once done[parity] != 0 (the
+ * flag is carried to the other half), so a host may enqueue iterations ahead and poll flags2[0] | flags2[1]. */
+int64_t tsgu_cg2_num_blocks(int vtype, int64_t n, int64_t p);
+int tsgu_cg2_residual(int vtype, int64_t n, int64_t p, void* r, const void* Ap, const void* pap_partial, int64_t n_partial, void* scal2,
+                      const int* flags2, int parity, double eps, void* rr_partial, int device, void* stream);
+int tsgu_cg2_direction(int vtype, int64_t n, int64_t p, const void* r, void* pvec, void* x, const void* rr_partial, int64_t n_partial,
+                       void* scal2, int* flags2, int parity, double eps, double stop_updating_after, double tolerance,
+                       int min_iter_index, int device, void* stream);
 /* rows of rr_partial written by tsgu_cg_update1; r/Ap/x/pvec must be contiguous [n][p], 16-byte aligned */
 int64_t tsgu_cg_num_blocks(int vtype, int64_t n, int64_t p);
 int tsgu_cg_beta(int vtype, const void* rr_partial, int64_t n_partial, void* scal, int* flags,

@@ -390,3 +390,45 @@ def test_forward_backward_step_is_capturable_in_a_hip_graph(monkeypatch):
         with torch.no_grad():       # new values in the same buffers: the next replay must see them
             A.values().mul_(-1.5)
             B.add_(0.25)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("shape,p,iters", [((12, 11, 10), 4, 21), ((12, 11, 10), 4, 40), ((20, 20, 20), 3, 25), ((9, 9, 9), 8, 300)])
+def test_cg_two_launch_form_against_the_four_step_form_and_the_oracle(dtype, shape, p, iters):
+    """linear_cg on a lattice operator runs K1 -> tsgu_cg2_residual -> tsgu_cg2_direction (state in two halves alternating by
+    iteration parity, include/tsgu_hip.h) instead of K1 -> update1(+alpha) -> beta -> update2: same recurrences (reference
+    utils/linear_cg.py:27-95, :319-382), so the same iterates up to the rounding of the |r|^2 partial sums (their grouping
+    differs), the same iteration count when the cap ends the solve, and — run to convergence — the same stop."""
+    from oracle import oracle
+    from torchsparsegradutils_amd.utils import LinearCGSettings, last_solve_info, linear_cg, synthetic
+    import sys
+
+    mod = sys.modules["torchsparsegradutils_amd.utils.linear_cg"]
+    nx, ny, nz = shape
+    crow, col, val = synthetic.laplacian7(nx, ny, nz, torch.int32, shift=0.05)
+    n = crow.numel() - 1
+    g = torch.Generator().manual_seed(3)
+    B = torch.randn(n, p, generator=g, dtype=torch.float64)
+    B[:, 1] = 0                                             # a zero right-hand side column (rhs_is_zero mask, reference :373)
+    A = torch.sparse_csr_tensor(crow.to(DEV), col.to(DEV), val.to(DEV).to(dtype), (n, n))
+    Bd = B.to(DEV).to(dtype)
+    tol = 1e-30 if iters < 100 else (1e-5 if dtype == torch.float32 else 1e-10)
+    st = LinearCGSettings(cg_tolerance=tol, max_cg_iterations=iters)
+    out = {}
+    for two in (True, False):
+        mod.TWO_LAUNCH = two
+        try:
+            out[two] = (linear_cg(A, Bd, settings=st).clone(), last_solve_info("linear_cg")["iterations"])
+        finally:
+            mod.TWO_LAUNCH = True
+    assert out[True][1] == out[False][1]
+    eps = 2.0 ** -23 if dtype == torch.float32 else 2.0 ** -52
+    scale = float(out[False][0].abs().max())
+    assert float((out[True][0] - out[False][0]).abs().max()) <= 64 * iters * eps * scale
+    assert torch.equal(out[True][0][:, 1], torch.zeros_like(out[True][0][:, 1]))
+    xo, k, _ = oracle.linear_cg(crow.numpy(), col.numpy(), val.numpy().astype(np.float64), B.numpy(), tol, max_iter=iters)
+    if iters < 100:
+        assert k == out[True][1]
+    err = float((out[True][0].double().cpu() - torch.from_numpy(xo)).abs().max()) / max(float(np.abs(xo).max()), 1e-30)
+    assert err <= (2e-4 if dtype == torch.float32 else 1e-10)

@@ -85,7 +85,7 @@ SIGNATURES = {
         _int, [_int, _int, _i64, _i64, _i64, _ptr, _ptr, _ptr, _i64, _ptr, _i64, _ptr, _dbl, _i64, _int, _ptr]),
     "tsgu_lattice_lds_bytes": (_int, [_int, _int, _i64, _int, _int, _int, _int, _int, _int, _int, _int, _int]),
     "tsgu_csr_spmm_lattice": (_int, [_int, _ptr, _i64, _i64, _ptr, _ptr, _i64, _ptr, _i64, _i64, _int, _ptr]),
-    "tsgu_csr_spmm_lattice_dot": (_int, [_int, _ptr, _i64, _i64, _ptr, _ptr, _i64, _ptr, _i64, _i64, _ptr, _i64, _int, _ptr]),
+    "tsgu_csr_spmm_lattice_dot": (_int, [_int, _ptr, _i64, _i64, _ptr, _ptr, _i64, _ptr, _i64, _i64, _ptr, _i64, _ptr, _int, _ptr]),
     "tsgu_csr_sddmm_lattice": (_int, [_int, _ptr, _i64, _i64, _ptr, _i64, _ptr, _i64, _ptr, _dbl, _i64, _int, _ptr]),
     "tsgu_march_supported": (_int, [_int, _int, _int, _int]),
     "tsgu_march_lds_bytes": (_int, [_int, _int, _i64, _int, _int, _int, _int, _int, _int]),
@@ -109,6 +109,9 @@ SIGNATURES = {
     "tsgu_cg_beta": (_int, [_int, _ptr, _i64, _ptr, _ptr, _dbl, _dbl, _dbl, _int, _int, _i64, _int, _ptr]),
     "tsgu_cg_beta_precond": (_int, [_int, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _dbl, _dbl, _dbl, _int, _int, _i64, _int, _ptr]),
     "tsgu_cg_update2": (_int, [_int, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _int, _ptr]),
+    "tsgu_cg2_num_blocks": (_i64, [_int, _i64, _i64]),
+    "tsgu_cg2_residual": (_int, [_int, _i64, _i64, _ptr, _ptr, _ptr, _i64, _ptr, _ptr, _int, _dbl, _ptr, _int, _ptr]),
+    "tsgu_cg2_direction": (_int, [_int, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _i64, _ptr, _ptr, _int, _dbl, _dbl, _dbl, _int, _int, _ptr]),
     "tsgu_cg_update1_alpha": (_int, [_int, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _ptr, _ptr, _dbl, _ptr, _int, _ptr]),
     "tsgu_bicg_scalar": (_int, [_int, _int, _ptr, _i64, _i64, _ptr, _ptr, _ptr, _dbl, _dbl, _int, _int, _i64, _int, _ptr]),
     "tsgu_bicg_vector": (_int, [_int, _int, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _int, _ptr]),
@@ -142,7 +145,7 @@ def load_library():
             fn = getattr(lib, name)  # AttributeError => header/library mismatch, fail loudly
             fn.restype = res
             fn.argtypes = args
-        if lib.tsgu_abi_version() != 3:
+        if lib.tsgu_abi_version() != 4:
             raise HipExtensionMissing("libtsgu_hip.so ABI version mismatch; rebuild the extension")
         _lib = lib
     return _lib
@@ -554,10 +557,11 @@ def _raw_stream(dev: torch.device) -> int:
     return torch._C._cuda_getCurrentRawStream(dev.index)
 
 
-def csr_spmm_lattice(lp, cfg, val, B, dot: bool = False):
+def csr_spmm_lattice(lp, cfg, val, B, dot: bool = False, skip: int = 0):
     """C = A·B (plan kind 0) or Aᵀ·B for the transposed plan (kind 1; `val` in A's own order) by the plane sweep / plane march.
     `dot` (plane sweep, fp32, stored order): also the per-workgroup partial sums of <C[row], B[row]> per column — returns
-    (C, partial [workgroups][p]), the Krylov loops' fused dot epilogue."""
+    (C, partial [workgroups][p]), the Krylov loops' fused dot epilogue; `skip` (with `dot`): address of a device int32 — the launch
+    does nothing when it is non-zero (iterations queued past the end of a solve)."""
     lib = _lib or load_library()
     dev = B.device
     if not B.is_cuda or val.device != dev:
@@ -579,7 +583,7 @@ def csr_spmm_lattice(lp, cfg, val, B, dot: bool = False):
         partial = torch.empty((nwg, p), dtype=B.dtype, device=dev)
         with _on_device(dev):
             rc = lib.tsgu_csr_spmm_lattice_dot(_VTYPE[val.dtype], cfg.struct_addr, n_rows, lp.nnz, val.data_ptr(), B.data_ptr(), _ld(B),
-                                               out.data_ptr(), p, p, partial.data_ptr(), nwg, dev.index,
+                                               out.data_ptr(), p, p, partial.data_ptr(), nwg, skip or None, dev.index,
                                                _raw_stream(dev))
         if rc:
             check(rc, "tsgu_csr_spmm_lattice_dot")

@@ -85,7 +85,7 @@ int tsgu_lattice_lds_bytes(int mode, int vtype, int64_t p, int ty, int tz, int r
 }
 
 static int spmm_lattice(int vtype, const tsgu_lattice_plan* plan, int64_t n_rows, int64_t nnz, const void* val, const void* B, int64_t ldb,
-                        void* C, int64_t ldc, int64_t p, void* dot_partial, int64_t dot_rows, int device, void* stream) {
+                        void* C, int64_t ldc, int64_t p, void* dot_partial, int64_t dot_rows, const int* skip, int device, void* stream) {
     LatParams P{};
     int cl = 0;
     const int mode = plan && plan->kind != 0 ? kLatSpmmT : kLatSpmm;
@@ -104,19 +104,20 @@ static int spmm_lattice(int vtype, const tsgu_lattice_plan* plan, int64_t n_rows
     P.out = C;
     P.ldo = ldc;
     P.dot_partial = dot_partial;
+    P.skip = skip;
     return dispatch(vtype, mode, cl, plan->threads, P, stream);
 }
 
 int tsgu_csr_spmm_lattice(int vtype, const tsgu_lattice_plan* plan, int64_t n_rows, int64_t nnz, const void* val, const void* B,
                           int64_t ldb, void* C, int64_t ldc, int64_t p, int device, void* stream) {
-    return spmm_lattice(vtype, plan, n_rows, nnz, val, B, ldb, C, ldc, p, nullptr, 0, device, stream);
+    return spmm_lattice(vtype, plan, n_rows, nnz, val, B, ldb, C, ldc, p, nullptr, 0, nullptr, device, stream);
 }
 
 int tsgu_csr_spmm_lattice_dot(int vtype, const tsgu_lattice_plan* plan, int64_t n_rows, int64_t nnz, const void* val, const void* B,
-                              int64_t ldb, void* C, int64_t ldc, int64_t p, void* dot_partial, int64_t dot_rows, int device,
-                              void* stream) {
+                              int64_t ldb, void* C, int64_t ldc, int64_t p, void* dot_partial, int64_t dot_rows, const int* skip,
+                              int device, void* stream) {
     if (!dot_partial) return TSGU_ERR_BAD_ARG;
-    return spmm_lattice(vtype, plan, n_rows, nnz, val, B, ldb, C, ldc, p, dot_partial, dot_rows, device, stream);
+    return spmm_lattice(vtype, plan, n_rows, nnz, val, B, ldb, C, ldc, p, dot_partial, dot_rows, skip, device, stream);
 }
 
 int tsgu_csr_sddmm_lattice(int vtype, const tsgu_lattice_plan* plan, int64_t n_rows, int64_t nnz, const void* R, int64_t ldr,

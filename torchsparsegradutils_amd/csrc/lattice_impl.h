@@ -77,6 +77,7 @@ struct LatParams {
     void* gvals;             // SDDMM output [nnz]
     float alpha;
     void* dot_partial;       // SpMM, fp32 / fp64: [workgroups][p] partial sums of <out[row,:], S[row,:]> per column (Krylov loops), or null
+    const int* skip;         // when given and *skip != 0 the launch does nothing (a solver loop that has finished on the device)
     int64_t nblocks;
     // LDS layout (bytes from the start of the dynamic region; filled by lat_layout)
     int o_vals, o_zero, o_tab, o_len, o_map, lds_bytes;
@@ -141,6 +142,7 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
     extern __shared__ uint4 lat_smem[];
     char* const sm = reinterpret_cast<char*>(lat_smem);
     const unsigned sbase = lat_lds_addr(lat_smem);
+    if (P.skip != nullptr && *P.skip != 0) return;
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);

@@ -50,16 +50,17 @@ class SparseOperator:
 
     matmul = __call__
 
-    def matmul_with_dot(self, v: torch.Tensor, w: torch.Tensor = None, out: torch.Tensor = None):
+    def matmul_with_dot(self, v: torch.Tensor, w: torch.Tensor = None, out: torch.Tensor = None, skip: int = 0):
         """(A·v, per-block partial sums of <w, A·v> per column; w defaults to v) — K1 with the fused dot epilogue.
-        ``out`` (optional, must not alias ``v``) receives A·v in place."""
+        ``out`` (optional, must not alias ``v``) receives A·v in place.  ``skip``: address of a device int32; kernels that can
+        (the plane sweep) do nothing when it is non-zero — a hint, the result is then unspecified."""
         p = self.plan
         v = self._cast(v)
         if w is None and out is None and v.dtype in (torch.float32, torch.float64) and self.values.dtype == v.dtype and v.dim() == 2:
             # stencil on a lattice: the plane sweep needs no column indices, and the own row of v is already in LDS for the dot
             got = _ops._lattice_cfg(p, _be.LAT_SPMM, v) if p.perm is None and p.batch is None else None
             if got is not None and not getattr(got[1], "march", False) and got[1].cpl == 1:
-                return _be.csr_spmm_lattice(got[0], got[1], self.values, v, dot=True)
+                return _be.csr_spmm_lattice(got[0], got[1], self.values, v, dot=True, skip=skip)
         return _be.csr_spmm(p.crow, p.col, self.values, v, p.n_rows, p.n_cols, perm=p.perm, out=out,
                             dot_w=v if w is None else w, max_row_nnz=p.max_row_nnz)
 

@@ -19,6 +19,7 @@ no-ops once it is set, so running ahead is harmless).
 
 from __future__ import annotations
 
+import os
 import threading
 import warnings
 from typing import Callable, NamedTuple, Optional, Union
@@ -248,6 +249,91 @@ def _batched_rhs(matmul_closure, rhs, n_tridiag, tolerance, eps, stop_updating_a
     return unfold(out[:, back]), t_sel.permute(1, 0, 2, 3).reshape((n_tridiag,) + batch_shape + (r, r)).contiguous()
 
 
+TWO_LAUNCH = os.environ.get("TSGU_CG_TWO_LAUNCH", "1") != "0"
+
+
+def _two_launch_loop(lib, op, rhs_is_zero, x, r, has_converged, n_iter, max_iter, tolerance, eps, stop_after, stream):
+    """The iterations as K1 (+ p'Ap partials) -> tsgu_cg2_residual -> tsgu_cg2_direction (include/tsgu_hip.h): the state an
+    iteration reads sits in the half of its parity, what it produces goes to the other half, so no single-workgroup kernel is
+    left between the streaming ones.  Returns None when K1 leaves more partial rows than the kernels sum per workgroup (the
+    caller then runs the four-step form).  Same recurrences, same stop rule (reference :319-382)."""
+    n, p = r.shape
+    dev, dtype = r.device, r.dtype
+    vt = _be.vtype_of(r)
+    nb = lib.tsgu_cg2_num_blocks(vt, n, p)
+    if nb <= 0:
+        return None
+    pvec = r.clone()  # curr_conjugate_vec (reference :293)
+    Ap, pap = op.matmul_with_dot(pvec)            # the first product also tells how many partial rows K1 leaves
+    if pap.shape[0] > 1024 or not pap.is_contiguous():
+        return None
+    scal = torch.zeros(5 * p, dtype=dtype, device=dev)
+    scal[:p] = _be.coldot(r, r)  # residual_inner_prod (reference :294)
+    flags = torch.zeros(4 + 3 * p, dtype=torch.int32, device=dev)
+    flags[4 : 4 + p] = has_converged.reshape(-1).to(torch.int32)
+    flags[4 + 2 * p :] = rhs_is_zero.reshape(-1).to(torch.int32)
+    rr_partial = torch.empty((nb, p), dtype=dtype, device=dev)
+    min_iter_index = min(10, max_iter - 1)
+    state = {"parity": 0, "first": (Ap, pap)}
+
+    flags_addr = flags.data_ptr()
+
+    def iteration():
+        par = state["parity"]
+        if state["first"] is not None:
+            Ap, pap = state["first"]
+            state["first"] = None
+        else:
+            # K1 + p'Ap partials (reference :322, :64-65); it does nothing once this half's done word is set
+            Ap, pap = op.matmul_with_dot(pvec, skip=flags_addr + 4 * par)
+        s = stream()
+        _be.check(lib.tsgu_cg2_residual(vt, n, p, r.data_ptr(), Ap.data_ptr(), pap.data_ptr(), pap.shape[0], scal.data_ptr(),
+                                        flags_addr, par, eps, rr_partial.data_ptr(), dev.index, s), "tsgu_cg2_residual")
+        _be.check(lib.tsgu_cg2_direction(vt, n, p, r.data_ptr(), pvec.data_ptr(), x.data_ptr(), rr_partial.data_ptr(), nb,
+                                         scal.data_ptr(), flags_addr, par, eps, stop_after, float(tolerance), min_iter_index,
+                                         dev.index, s), "tsgu_cg2_direction")
+        state["parity"] = par ^ 1
+
+    # The host polls one chunk BEHIND the device: after queueing chunk j it copies the done words to pinned memory (asynchronously,
+    # behind chunk j in the stream), queues chunk j + 1 and only then waits for the copy of chunk j — the GPU always has the next
+    # chunk in its queue (a blocking read per chunk left it idle for a launch + a round trip: ~5 us per iteration at C4).
+    # Iterations queued past the end are no-ops on the device (K1 included: `skip`).
+    done = False
+    k = 0
+    graph = None
+    try_graph = _graph.enabled()
+    polls = [(torch.empty(2, dtype=torch.int32, pin_memory=True), torch.cuda.Event()) for _ in range(2)]
+    pending = None
+    which = 0
+    with torch.cuda.device(dev):
+        while k < n_iter and not done:
+            if try_graph and graph is None and k > min_iter_index and n_iter - k >= _graph.MIN_ITERS:
+                # (an even number of iterations per replay: the parities baked into the captured launches stay right)
+                graph = _graph.capture(iteration, _POLL)
+                try_graph = graph is not None
+            if graph is not None and k + _POLL <= n_iter:
+                _graph.replay(graph)
+                k += _POLL
+            else:
+                upto = min(n_iter, max(k + _POLL, min_iter_index + 1) if k <= min_iter_index else k + _POLL)
+                for _ in range(k, upto):
+                    iteration()
+                k = upto
+            buf, ev = polls[which]
+            buf.copy_(flags[:2], non_blocking=True)
+            ev.record()
+            if pending is not None:
+                pending[1].synchronize()
+                done = bool(pending[0][0] != 0 or pending[0][1] != 0)
+            pending = polls[which]
+            which ^= 1
+        head = flags[:2].tolist()   # (waits for everything queued)
+        done = head[0] != 0 or head[1] != 0
+    k_done = int(flags[2].item())
+    rnorm = scal[4 * p : 5 * p].unsqueeze(0)
+    return x, rnorm, k_done, done
+
+
 def _fused_loop(op, rhs_is_zero, x, r, has_converged, n_iter, max_iter, tolerance, eps, stop_after, preconditioner=None):
     """CG iterations on the fused gfx950 kernels (reference :319-382, :50-95).  A preconditioner is called between the
     residual update and the beta step (z = M r); the recurrences then run on <r, z>, the stop test on |r|."""
@@ -258,6 +344,13 @@ def _fused_loop(op, rhs_is_zero, x, r, has_converged, n_iter, max_iter, toleranc
     nb_upd = lib.tsgu_cg_num_blocks(vt, n, p)
     if nb_upd < 0:
         raise RuntimeError("linear_cg: more than 1024 simultaneous right-hand sides are not supported")
+
+    fused_dot = isinstance(op, SparseOperator) and op.dtype == dtype
+    stream = lambda: torch.cuda.current_stream(dev).cuda_stream  # noqa: E731
+    if preconditioner is None and fused_dot and p <= 256 and TWO_LAUNCH:
+        got = _two_launch_loop(lib, op, rhs_is_zero, x, r, has_converged, n_iter, max_iter, tolerance, eps, stop_after, stream)
+        if got is not None:
+            return got
 
     # device state: scal = [rr | alpha | beta | rnorm], flags = [done, iters, has_converged[p], rhs_is_zero[p]]
     scal = torch.zeros(4 * p, dtype=dtype, device=dev)
@@ -273,8 +366,6 @@ def _fused_loop(op, rhs_is_zero, x, r, has_converged, n_iter, max_iter, toleranc
     flags[2 + p :] = rhs_is_zero.reshape(-1).to(torch.int32)
     rr_partial = torch.empty((nb_upd, p), dtype=dtype, device=dev)
     fold = torch.empty((lib.tsgu_cg_fold_rows(), p), dtype=dtype, device=dev)
-    fused_dot = isinstance(op, SparseOperator) and op.dtype == dtype
-    stream = lambda: torch.cuda.current_stream(dev).cuda_stream  # noqa: E731
     min_iter_index = min(10, max_iter - 1)
 
     def iteration():
