@@ -73,13 +73,17 @@ def hold_gpu(dev, ms):
         dst.copy_(src)
 
 
-def time_events(fn, reps, dev, hold_ms=0.0):
+def time_events(fn, reps, dev, hold_ms=0.0, settle=0):
     """average duration (ms) of fn() over reps launches, HIP events on the launch stream.  `hold_ms` > 0: the launches
-    are queued behind that much device work (see hold_gpu), i.e. executed back to back whatever the host's speed."""
+    are queued behind that much device work (see hold_gpu), i.e. executed back to back whatever the host's speed;
+    `settle` untimed calls of fn() run between the held work and the first event (the copies leave the chip at its power
+    limit: the workload's own steady state comes back within a few ms)."""
     start = torch.cuda.Event(enable_timing=True)
     stop = torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize(dev)
-    hold_gpu(dev, hold_ms)
+    hold_gpu(dev, hold_ms * (reps + settle) / max(reps, 1) if hold_ms > 0 else 0.0)
+    for _ in range(settle):
+        fn()
     start.record()
     for _ in range(reps):
         fn()
@@ -311,7 +315,7 @@ def patterns_leg(dev, steps, warmup, headline):
             host_ms = (time.perf_counter() - t0) / steps * 1e3      # the host's share: all launches queued, nothing waited for
             torch.cuda.synchronize(dev)
             ms = (time.perf_counter() - t0) / steps * 1e3
-            ms_dev = time_events(step, steps, dev, hold_ms=steps * 1.5 * max(host_ms, 0.15))   # queued behind device work: the GPU's own time
+            ms_dev = time_events(step, steps, dev, hold_ms=steps * 1.5 * max(host_ms, 0.15), settle=30)   # queued behind device work: the GPU's own time
             ab = alg_bytes(n, nnz, p)["fwd_bwd"]
             plan = _pattern.from_csr(A.detach())
             lp = plan.core.own.get("lattice")
@@ -544,13 +548,17 @@ def main():
 
     n_ev = max(args.steps, 10)
     hold_ms = n_ev * 1.5 * max(host_ms or 0.3, 0.15)     # the host's time for n_ev steps, with margin: the launches wait in the stream
-    hold_gpu(dev, hold_ms)
+    hold_gpu(dev, hold_ms * (n_ev + 30) / n_ev)
+    for _ in range(30):
+        step()
     evs = [step_halves() for _ in range(n_ev)]
     torch.cuda.synchronize(dev)
     in_step = {"forward": sum(e[0].elapsed_time(e[1]) for e in evs) / len(evs), "backward": sum(e[1].elapsed_time(e[2]) for e in evs) / len(evs)}
     # ... and every kernel of the step by itself: HIP events recorded on the launch stream around each launch, inside the steps
+    hold_gpu(dev, hold_ms * (n_ev + 30) / n_ev)
+    for _ in range(30):         # (untimed: back to the workload's own clocks after the held copies)
+        step()
     be.KERNEL_EVENTS = []
-    hold_gpu(dev, hold_ms)
     for _ in range(n_ev):
         step()
     torch.cuda.synchronize(dev)
@@ -560,7 +568,7 @@ def main():
     be.KERNEL_EVENTS = None
     kern_in_step = {k: sum(v) / len(v) for k, v in kern_in_step.items()}
     # ... and the whole step as the GPU sees it: n_ev steps queued behind the held stream, one event pair around all of them
-    ms_device = time_events(step, n_ev, dev, hold_ms=hold_ms)
+    ms_device = time_events(step, n_ev, dev, hold_ms=hold_ms, settle=30)
 
     # ---- per-kernel durations (HIP events on the launch stream), same resident operands ----
     plan = _pattern.from_csr(A.detach())
@@ -594,9 +602,9 @@ def main():
         sdd_name = f"{kname(lat_s[1])} SDDMM (K3 gradA, {cfgs(lat_s[1])})"
         bwd_name = f"{kname(lat_t[1])} SpMM-T (K2 gradB, {cfgs(lat_t[1])})"
         kern = {
-            fwd_name: time_events(lambda: _ops.spmm(plan, vd, Bd), reps, dev, hold_ms=hold_ms / 2),
-            sdd_name: time_events(lambda: _ops.sddmm(plan, G, Bd), reps, dev, hold_ms=hold_ms / 2),
-            bwd_name: time_events(lambda: _ops.spmm_t(plan, vd, G), reps, dev, hold_ms=hold_ms / 2),
+            fwd_name: time_events(lambda: _ops.spmm(plan, vd, Bd), reps, dev, hold_ms=hold_ms / 2, settle=40),
+            sdd_name: time_events(lambda: _ops.sddmm(plan, G, Bd), reps, dev, hold_ms=hold_ms / 2, settle=40),
+            bwd_name: time_events(lambda: _ops.spmm_t(plan, vd, G), reps, dev, hold_ms=hold_ms / 2, settle=40),
         }
         kbytes = {fwd_name: ab["spmm"], sdd_name: ab["sddmm"], bwd_name: ab["spmm_t"]}
         traffic_key = {fwd_name: "lattice_spmm", sdd_name: "lattice_sddmm", bwd_name: "lattice_spmm_t"}
