@@ -432,3 +432,91 @@ def test_cg_two_launch_form_against_the_four_step_form_and_the_oracle(dtype, sha
         assert k == out[True][1]
     err = float((out[True][0].double().cpu() - torch.from_numpy(xo)).abs().max()) / max(float(np.abs(xo).max()), 1e-30)
     assert err <= (2e-4 if dtype == torch.float32 else 1e-10)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pattern", ["periodic27", "truncated27", "periodic7", "lower27"])
+@pytest.mark.parametrize("p", [32, 16])
+def test_cpp_host_path_of_the_step_equals_the_python_path(pattern, p):
+    """Once a CSR pattern's launch configurations are final, sparse_mm's forward and backward are issued by the C++ autograd
+    function of csrc/host/step.cpp (same C ABI calls, no interpreter on the engine's thread).  Same kernels, same
+    configurations: C, gradA (values, index tensors, index dtype, layout) and gradB equal the Python path bit for bit; the
+    gradients are gated by needs_input_grad, a non-contiguous upstream gradient is accepted, a second backward raises
+    (reference sparse_matmul.py:132-234)."""
+    import torchsparsegradutils_amd.sparse_matmul as sm
+    from torchsparsegradutils_amd import _lattice, _ops, _pattern, sparse_mm
+    from torchsparsegradutils_amd.utils import synthetic
+
+    assert sm._host is not None, "torchsparsegradutils_amd/_tsgu_host.so was not built (make -C torchsparsegradutils_amd/csrc)"
+    dims = (12, 10, 16)
+    if pattern == "periodic27":
+        crow, col = synthetic.stencil27_periodic(*dims, torch.int32, device=DEV)
+    elif pattern == "truncated27":
+        crow, col = synthetic.box_stencil(*dims, (False,) * 3, 27, None, torch.int32, DEV)
+    elif pattern == "periodic7":
+        crow, col = synthetic.box_stencil(*dims, (True,) * 3, 7, None, torch.int32, DEV)
+    else:
+        crow, col = synthetic.box_stencil(*dims, (False,) * 3, 27, "lower", torch.int32, DEV)
+    n, nnz = crow.numel() - 1, col.numel()
+    g = torch.Generator(device=DEV).manual_seed(5)
+    val = torch.randn(nnz, device=DEV, generator=g)
+    B0 = torch.randn(n, p, device=DEV, generator=g)
+    G = torch.randn(n, p, device=DEV, generator=g)
+    keep = (sm.FAST_STEP, _lattice.TUNE, _ops.PACK_MIN_NNZ)
+    _pattern.clear_cache()
+    try:
+        _lattice.TUNE = False          # (the ranked configurations are final at once: both paths run the same launches)
+        _ops.PACK_MIN_NNZ = 1          # (small lattices too)
+        A = torch.sparse_csr_tensor(crow, col, val, (n, n)).requires_grad_(True)
+        B = B0.clone().requires_grad_(True)
+
+        def run(fast, need=(True, True), Gx=G):
+            sm.FAST_STEP = fast
+            A.requires_grad_(need[0])
+            B.requires_grad_(need[1])
+            C = sparse_mm(A, B)
+            ins = tuple(t for t, nd in zip((A, B), need) if nd)
+            grads = torch.autograd.grad(C, ins, Gx) if ins else ()
+            return C, grads
+
+        sm.FAST_STEP = True
+        ref = run(False)
+        for _ in range(3):
+            run(True)                   # the Python path settles the step plan …
+        own = _pattern.from_csr(A.detach()).core.own
+        assert own.get("step_plans"), "no step plan was derived for a lattice stencil"
+        C, (gA, gB) = run(True)         # … and this step runs through C++
+        assert type(C.grad_fn).__name__ != "SparseMatMulBackward"
+        assert torch.equal(C, ref[0]) and torch.equal(gB, ref[1][1])
+        assert gA.layout == torch.sparse_csr and gA.shape == A.shape
+        assert torch.equal(gA.values(), ref[1][0].values())
+        assert gA.crow_indices().dtype == torch.int32 and torch.equal(gA.crow_indices(), crow) and torch.equal(gA.col_indices(), col)
+        # gating
+        C1, (gB1,) = run(True, (False, True))
+        assert torch.equal(gB1, gB)
+        C2, (gA2,) = run(True, (True, False))
+        assert torch.equal(gA2.values(), gA.values())
+        C3, none = run(True, (False, False))
+        assert not C3.requires_grad and torch.equal(C3, C)
+        # a non-contiguous upstream gradient
+        Gt = G.t().contiguous().t()
+        assert not Gt.is_contiguous()
+        _, (gA4, gB4) = run(True, (True, True), Gt)
+        assert torch.equal(gA4.values(), gA.values()) and torch.equal(gB4, gB)
+        # .backward() accumulates into .grad like the Python path; the graph is freed by the first backward
+        A.requires_grad_(True)
+        B.requires_grad_(True)
+        A.grad = B.grad = None
+        Cb = sparse_mm(A, B)
+        Cb.backward(G)
+        assert torch.equal(A.grad.values(), gA.values()) and torch.equal(B.grad, gB)
+        with pytest.raises(RuntimeError):
+            Cb.backward(G)
+        # under no_grad and with the switch off
+        with torch.no_grad():
+            assert torch.equal(sparse_mm(A, B), C)
+        sm.FAST_STEP = False
+        assert type(sparse_mm(A, B).grad_fn).__name__ == "SparseMatMulBackward"
+    finally:
+        sm.FAST_STEP, _lattice.TUNE, _ops.PACK_MIN_NNZ = keep
+        _pattern.clear_cache()

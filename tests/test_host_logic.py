@@ -270,3 +270,18 @@ def test_compat_dense_branch_is_the_reference_dispatch():
                 x = linalg_solve_triangular_compat(T, B, upper=upper, unitriangular=unit, transpose=tr)
                 want = torch.linalg.solve_triangular(T.transpose(-2, -1) if tr else T, B, upper=(not upper) if tr else upper, unitriangular=unit)
                 assert torch.equal(x, want)
+
+
+def test_cpp_host_module_of_the_step_is_built_against_the_abi_library():
+    """csrc/host/step.cpp (the steady-state sparse_mm step's host path as a torch C++ autograd function) is built by the same
+    Makefile, links the C ABI library it launches through, and sparse_matmul picks it up; without a GPU nothing is launched."""
+    import torchsparsegradutils_amd.sparse_matmul as sm
+    from torchsparsegradutils_amd import _backend
+
+    lib = _backend.load_library()
+    assert sm._host is not None, "torchsparsegradutils_amd/_tsgu_host.so is missing: make -C torchsparsegradutils_amd/csrc"
+    assert sm._host.abi_version() == lib.tsgu_abi_version()
+    assert hasattr(sm._host, "StepPlan") and hasattr(sm._host, "step")
+    # CPU tensors never reach it (the documented error of the package comes from the Python path)
+    A = torch.eye(4).to_sparse_csr()
+    assert sm._step_plan(A, torch.zeros(4, 16)) is None if torch.zeros(1).is_cuda else True

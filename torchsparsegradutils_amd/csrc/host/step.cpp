@@ -1,0 +1,147 @@
+// Host side of the steady-state sparse_mm step in C++: `SparseMatMul.forward / backward` (torchsparsegradutils_amd/sparse_matmul.py,
+// reference sparse_matmul.py:132-234) for a CSR pattern whose three launch configurations are FINAL (plane march / plane sweep).
+//
+// Why: a forward + backward step is three kernel launches (~0.23 ms of GPU time at C2).  The Python host path — autograd.Function,
+// plan look-ups, ctypes marshalling, the engine's hand-over to a thread that must take the GIL — costs 0.08 ms per step on a fast
+// host and 0.25 ms on a slow one, where the step then waits for Python, not for HBM.  This file is the same sequence of calls
+// (allocate the result, launch through the C ABI of include/tsgu_hip.h on torch's current stream, rebuild the sparse gradient),
+// as a torch::autograd::Function whose backward runs on the engine thread without the interpreter.  No kernel lives here and
+// nothing is decided here: Python builds a StepPlan once the pattern's configurations are settled and keeps every table alive.
+#include <c10/hip/HIPStream.h>
+#include <torch/extension.h>
+
+#include <stdexcept>
+#include <string>
+
+#include "../../../include/tsgu_hip.h"
+
+namespace {
+
+struct Product {          // one of the three products of a step
+    int kind = 0;         // 0 plane march, 1 plane sweep
+    uintptr_t plan = 0;   // tsgu_march_plan* / tsgu_lattice_plan* (owned by the Python configuration object)
+    int transposed = 0;   // march: walk the transposed pattern (gradB)
+};
+
+struct StepPlan {
+    at::Tensor crow, col;     // A's index tensors (the gradient's)
+    int64_t n_rows = 0, n_cols = 0, nnz = 0, p = 0;
+    int vtype = 0, device = 0;
+    Product fwd, sddmm, spmm_t;
+    py::object keep;          // whatever Python wants kept alive with this plan (configurations, tables)
+    ~StepPlan() {             // (may run on the autograd engine's thread, when the last graph node that used the plan dies)
+        py::gil_scoped_acquire gil;
+        keep = py::object();
+    }
+};
+using StepPlanPtr = std::shared_ptr<StepPlan>;
+
+void check(int rc, const char* what) {
+    if (rc != 0) throw std::runtime_error(std::string(what) + " failed: " + tsgu_status_string(rc));
+}
+
+void* stream_of(int device) { return static_cast<void*>(c10::hip::getCurrentHIPStream(static_cast<c10::DeviceIndex>(device)).stream()); }
+
+void spmm(const StepPlan& s, const Product& pr, int64_t rows_out, const at::Tensor& val, const at::Tensor& dense, at::Tensor& out) {
+    const int64_t ld = dense.size(0) > 1 ? dense.stride(0) : s.p;
+    if (pr.kind == 0)
+        check(tsgu_csr_spmm_march(s.vtype, reinterpret_cast<const tsgu_march_plan*>(pr.plan), pr.transposed, rows_out, s.nnz, val.data_ptr(),
+                                  dense.data_ptr(), ld, out.data_ptr(), s.p, s.p, s.device, stream_of(s.device)),
+              "tsgu_csr_spmm_march");
+    else
+        check(tsgu_csr_spmm_lattice(s.vtype, reinterpret_cast<const tsgu_lattice_plan*>(pr.plan), rows_out, s.nnz, val.data_ptr(),
+                                    dense.data_ptr(), ld, out.data_ptr(), s.p, s.p, s.device, stream_of(s.device)),
+              "tsgu_csr_spmm_lattice");
+}
+
+bool plain(const at::Tensor& t, int64_t rows, int64_t p) {
+    return t.defined() && t.dim() == 2 && t.size(0) == rows && t.size(1) == p && t.is_contiguous() &&
+           reinterpret_cast<uintptr_t>(t.data_ptr()) % 16 == 0;
+}
+
+class StepFunction : public torch::autograd::Function<StepFunction> {
+   public:
+    static at::Tensor forward(torch::autograd::AutogradContext* ctx, const at::Tensor& A, const at::Tensor& B, StepPlanPtr handle) {
+        const StepPlan& s = *handle;
+        const at::Tensor val = A.values();
+        at::Tensor C = at::empty({s.n_rows, s.p}, B.options());
+        spmm(s, s.fwd, s.n_rows, val, B, C);
+        ctx->save_for_backward({val, B});
+        ctx->saved_data["plan"] = c10::IValue(reinterpret_cast<int64_t>(&s));
+        // the plan (and with it every table the launches read) lives as long as the graph node: an empty tensor whose deleter owns
+        // a reference travels with the node's saved data
+        auto* owner = new StepPlanPtr(std::move(handle));
+        ctx->saved_data["keep"] = c10::IValue(at::from_blob(owner, {0}, [owner](void*) { delete owner; }, at::TensorOptions().dtype(at::kByte)));
+        return C;
+    }
+
+    static torch::autograd::variable_list backward(torch::autograd::AutogradContext* ctx, torch::autograd::variable_list grads) {
+        const StepPlan& s = *reinterpret_cast<const StepPlan*>(ctx->saved_data["plan"].toInt());
+        const auto saved = ctx->get_saved_variables();
+        const at::Tensor& val = saved[0];
+        const at::Tensor& B = saved[1];
+        at::Tensor G = grads[0];
+        at::Tensor gradA, gradB;
+        if (!G.defined()) return {gradA, gradB, at::Tensor()};
+        if (!plain(G, s.n_rows, s.p)) G = G.contiguous();
+        if (reinterpret_cast<uintptr_t>(G.data_ptr()) % 16 != 0) G = G.clone();
+        if (ctx->needs_input_grad(0)) {
+            // gradA[k] = <G[row k,:], B[col k,:]> at A's stored entries only (reference sparse_matmul.py:172-205)
+            at::Tensor gv = at::empty({s.nnz}, val.options());
+            if (s.sddmm.kind == 0)
+                check(tsgu_csr_sddmm_march(s.vtype, reinterpret_cast<const tsgu_march_plan*>(s.sddmm.plan), s.n_rows, s.nnz, G.data_ptr(),
+                                           s.p, B.data_ptr(), B.size(0) > 1 ? B.stride(0) : s.p, gv.data_ptr(), 1.0, 0, s.p, s.device,
+                                           stream_of(s.device)),
+                      "tsgu_csr_sddmm_march");
+            else
+                check(tsgu_csr_sddmm_lattice(s.vtype, reinterpret_cast<const tsgu_lattice_plan*>(s.sddmm.plan), s.n_rows, s.nnz, G.data_ptr(),
+                                             s.p, B.data_ptr(), B.size(0) > 1 ? B.stride(0) : s.p, gv.data_ptr(), 1.0, s.p, s.device,
+                                             stream_of(s.device)),
+                      "tsgu_csr_sddmm_lattice");
+            gradA = at::sparse_csr_tensor(s.crow, s.col, gv, {s.n_rows, s.n_cols}, gv.options().layout(at::kSparseCsr));
+        }
+        if (ctx->needs_input_grad(1)) {
+            // gradB = Aᵀ·G (reference sparse_matmul.py:229), through A's own arrays
+            gradB = at::empty({s.n_cols, s.p}, G.options());
+            spmm(s, s.spmm_t, s.n_cols, val, G, gradB);
+        }
+        return {gradA, gradB, at::Tensor()};
+    }
+
+};
+
+at::Tensor step(const at::Tensor& A, const at::Tensor& B, StepPlanPtr handle) {
+    TORCH_CHECK(handle != nullptr, "no step plan");
+    const StepPlan& s = *handle;
+    // (Python has validated layout / dims / dtypes / device; these are the conditions of the raw-pointer launches)
+    TORCH_CHECK(A.layout() == at::kSparseCsr && A.dim() == 2 && A.size(0) == s.n_rows && A.size(1) == s.n_cols, "step plan of another matrix");
+    TORCH_CHECK(plain(B, s.n_cols, s.p), "the fast step takes a contiguous, 16-byte aligned (n_cols, p) operand");
+    return StepFunction::apply(A, B, std::move(handle));
+}
+
+}  // namespace
+
+PYBIND11_MODULE(_tsgu_host, m) {
+    m.doc() = "C++ host path of the steady-state sparse_mm step (see csrc/host/step.cpp)";
+    py::class_<StepPlan, StepPlanPtr>(m, "StepPlan")
+        .def(py::init([](at::Tensor crow, at::Tensor col, int64_t n_rows, int64_t n_cols, int64_t nnz, int64_t p, int vtype, int device,
+                         std::tuple<int, uintptr_t, int> fwd, std::tuple<int, uintptr_t, int> sddmm, std::tuple<int, uintptr_t, int> spmm_t,
+                         py::object keep) {
+            auto s = std::make_shared<StepPlan>();
+            s->crow = std::move(crow);
+            s->col = std::move(col);
+            s->n_rows = n_rows, s->n_cols = n_cols, s->nnz = nnz, s->p = p, s->vtype = vtype, s->device = device;
+            auto prod = [](const std::tuple<int, uintptr_t, int>& t) {
+                Product q;
+                q.kind = std::get<0>(t), q.plan = std::get<1>(t), q.transposed = std::get<2>(t);
+                return q;
+            };
+            s->fwd = prod(fwd), s->sddmm = prod(sddmm), s->spmm_t = prod(spmm_t);
+            s->keep = std::move(keep);
+            return s;
+        }))
+        .def_readonly("p", &StepPlan::p)
+        .def_readonly("n_rows", &StepPlan::n_rows);
+    m.def("step", &step, "C = A @ B with the sparsity-preserving backward, host path in C++");
+    m.def("abi_version", []() { return tsgu_abi_version(); });
+}

@@ -18,6 +18,7 @@ block-diag assembly  :151-153  none: batched CSR stays batched   ``batch`` argum
 
 from __future__ import annotations
 
+import os
 from typing import cast
 
 import torch
@@ -50,7 +51,65 @@ def sparse_mm(A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
     if A.size(-1) != B.size(-2):
         raise ValueError(f"Incompatible inner dimensions: A[..., {A.size(-1)}] vs B[..., {B.size(-2)}]")
 
+    if _host is not None and FAST_STEP and A.layout == torch.sparse_csr and B.is_cuda and B.dim() == 2:
+        plan = _step_plan(A, B)
+        if plan is not None:
+            return cast(torch.Tensor, _host.step(A, B, plan))
     return cast(torch.Tensor, SparseMatMul.apply(A, B))
+
+
+# ---- steady state: the step's host path in C++ (csrc/host/step.cpp) -----------------------------------------------------------
+# Once the three launch configurations of a CSR pattern are final (plane march / plane sweep, found by the Python path below during
+# the first steps), forward and backward are the same three launches through the same C ABI, issued by a torch::autograd::Function
+# written in C++: no interpreter on the autograd engine's thread, no ctypes marshalling.  A fast host spends 0.08 ms per step in
+# the Python path, a slow one 0.25 ms — more than the 0.23 ms the kernels of a C2 step take.  TSGU_FAST_STEP=0 keeps the Python path.
+FAST_STEP = os.environ.get("TSGU_FAST_STEP", "1") != "0"
+try:
+    from . import _tsgu_host as _host       # built by csrc/Makefile next to this file
+except ImportError:                          # (the Python path below is complete by itself; the kernels are the same)
+    _host = None
+
+
+def _step_plan(A: torch.Tensor, B: torch.Tensor):
+    """The `_tsgu_host.StepPlan` of (A's pattern, B's dtype and width), or None while the pattern is young / not covered."""
+    if (A.dtype != B.dtype or A.device != B.device or not B.is_contiguous() or B.data_ptr() % 16 or _be.KERNEL_EVENTS is not None
+            or not _ops.ENABLE_LATTICE or _ops.FUSED_BACKWARD):
+        return None
+    own = _pt.from_csr(A).core.own
+    plans = own.get("step_plans")
+    if plans is None:
+        return None
+    return plans.get((B.dtype, B.size(-1), _ops._lt.ENABLE_MARCH))
+
+
+def _settle_step_plan(plan, dtype: torch.dtype, p: int) -> None:
+    """After a step on the Python path: when the configurations of all three products of `plan` are final, describe the step to
+    the C++ host path.  The StepPlan keeps the lattice plans and configurations (and through them every device table) alive."""
+    if _host is None or not FAST_STEP or plan.batch is not None or plan.perm is not None or not _ops.ENABLE_LATTICE or _ops.FUSED_BACKWARD:
+        return
+    own = plan.core.own
+    plans = own.get("step_plans")
+    key = (dtype, p, _ops._lt.ENABLE_MARCH)
+    if plans is not None and key in plans:
+        return
+    memo = own.get("lattice_memo")
+    if memo is None:
+        return
+    got = [memo.get((mode, dtype, p, True, _ops._lt.ENABLE_MARCH)) for mode in (_be.LAT_SPMM, _be.LAT_SDDMM, _be.LAT_SPMMT)]
+    if any(g is None for g in got):
+        return
+    prods = []
+    for mode, (lp, cfg) in zip((_be.LAT_SPMM, _be.LAT_SDDMM, _be.LAT_SPMMT), got):
+        if getattr(cfg, "march", False):
+            if cfg.col_tile != p:
+                return                  # (operands wider than a column tile run as several launches: the Python path)
+            prods.append((0, cfg.struct_addr, int(mode == _be.LAT_SPMMT)))
+        else:
+            prods.append((1, cfg.struct_addr, 0))
+    if plans is None:
+        plans = own["step_plans"] = {}
+    plans[key] = _host.StepPlan(plan.crow, plan.col, plan.n_rows, plan.n_cols, plan.nnz, p, _be._VTYPE[dtype], plan.crow.device.index,
+                                prods[0], prods[1], prods[2], tuple(got))
 
 
 class _Operand:
@@ -138,6 +197,8 @@ class SparseMatMul(torch.autograd.Function):
             gradA = op.rebuild(gvals)
             if ctx.batch_size is not None:
                 gradB = gradB.view(ctx.B_shape)
+            elif op.layout == torch.sparse_csr:
+                _settle_step_plan(plan, G.dtype, G.size(-1))
             return gradA, gradB
 
         if need_a:
