@@ -512,6 +512,20 @@ def test_cpp_host_path_of_the_step_equals_the_python_path(pattern, p):
         assert torch.equal(A.grad.values(), gA.values()) and torch.equal(B.grad, gB)
         with pytest.raises(RuntimeError):
             Cb.backward(G)
+        # a graph outlives the pattern cache: the node owns the plan structs and the device tables they point into
+        Cl = sparse_mm(A, B)
+        assert type(Cl.grad_fn).__name__ != "SparseMatMulBackward"
+        _pattern.clear_cache()
+        import gc
+
+        gc.collect()
+        torch.cuda.empty_cache()
+        junk = [torch.full((1 << 20,), float("nan"), device=DEV) for _ in range(8)]      # whatever was freed is overwritten
+        gAl, gBl = torch.autograd.grad(Cl, (A, B), G)
+        del junk
+        assert torch.equal(gAl.values(), gA.values()) and torch.equal(gBl, gB)
+        for _ in range(4):
+            run(True)                   # (the cache was cleared: settle again)
         # under no_grad and with the switch off
         with torch.no_grad():
             assert torch.equal(sparse_mm(A, B), C)

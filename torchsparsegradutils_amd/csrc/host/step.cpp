@@ -12,6 +12,7 @@
 
 #include <stdexcept>
 #include <string>
+#include <vector>
 
 #include "../../../include/tsgu_hip.h"
 
@@ -19,8 +20,10 @@ namespace {
 
 struct Product {          // one of the three products of a step
     int kind = 0;         // 0 plane march, 1 plane sweep
-    uintptr_t plan = 0;   // tsgu_march_plan* / tsgu_lattice_plan* (owned by the Python configuration object)
+    std::string blob;     // a copy of the tsgu_march_plan / tsgu_lattice_plan the Python configuration object built (plain struct of
+                          // sizes + device pointers; the tables it points to are the tensors the StepPlan holds)
     int transposed = 0;   // march: walk the transposed pattern (gradB)
+    const void* plan() const { return blob.data(); }
 };
 
 struct StepPlan {
@@ -28,11 +31,8 @@ struct StepPlan {
     int64_t n_rows = 0, n_cols = 0, nnz = 0, p = 0;
     int vtype = 0, device = 0;
     Product fwd, sddmm, spmm_t;
-    py::object keep;          // whatever Python wants kept alive with this plan (configurations, tables)
-    ~StepPlan() {             // (may run on the autograd engine's thread, when the last graph node that used the plan dies)
-        py::gil_scoped_acquire gil;
-        keep = py::object();
-    }
+    std::vector<at::Tensor> tables;   // every device table the three plan structs point into: no Python object is owned here, so the
+                                      // last reference may go away on the autograd engine's thread (with a graph node) without the GIL
 };
 using StepPlanPtr = std::shared_ptr<StepPlan>;
 
@@ -45,11 +45,11 @@ void* stream_of(int device) { return static_cast<void*>(c10::hip::getCurrentHIPS
 void spmm(const StepPlan& s, const Product& pr, int64_t rows_out, const at::Tensor& val, const at::Tensor& dense, at::Tensor& out) {
     const int64_t ld = dense.size(0) > 1 ? dense.stride(0) : s.p;
     if (pr.kind == 0)
-        check(tsgu_csr_spmm_march(s.vtype, reinterpret_cast<const tsgu_march_plan*>(pr.plan), pr.transposed, rows_out, s.nnz, val.data_ptr(),
+        check(tsgu_csr_spmm_march(s.vtype, static_cast<const tsgu_march_plan*>(pr.plan()), pr.transposed, rows_out, s.nnz, val.data_ptr(),
                                   dense.data_ptr(), ld, out.data_ptr(), s.p, s.p, s.device, stream_of(s.device)),
               "tsgu_csr_spmm_march");
     else
-        check(tsgu_csr_spmm_lattice(s.vtype, reinterpret_cast<const tsgu_lattice_plan*>(pr.plan), rows_out, s.nnz, val.data_ptr(),
+        check(tsgu_csr_spmm_lattice(s.vtype, static_cast<const tsgu_lattice_plan*>(pr.plan()), rows_out, s.nnz, val.data_ptr(),
                                     dense.data_ptr(), ld, out.data_ptr(), s.p, s.p, s.device, stream_of(s.device)),
               "tsgu_csr_spmm_lattice");
 }
@@ -89,12 +89,12 @@ class StepFunction : public torch::autograd::Function<StepFunction> {
             // gradA[k] = <G[row k,:], B[col k,:]> at A's stored entries only (reference sparse_matmul.py:172-205)
             at::Tensor gv = at::empty({s.nnz}, val.options());
             if (s.sddmm.kind == 0)
-                check(tsgu_csr_sddmm_march(s.vtype, reinterpret_cast<const tsgu_march_plan*>(s.sddmm.plan), s.n_rows, s.nnz, G.data_ptr(),
+                check(tsgu_csr_sddmm_march(s.vtype, static_cast<const tsgu_march_plan*>(s.sddmm.plan()), s.n_rows, s.nnz, G.data_ptr(),
                                            s.p, B.data_ptr(), B.size(0) > 1 ? B.stride(0) : s.p, gv.data_ptr(), 1.0, 0, s.p, s.device,
                                            stream_of(s.device)),
                       "tsgu_csr_sddmm_march");
             else
-                check(tsgu_csr_sddmm_lattice(s.vtype, reinterpret_cast<const tsgu_lattice_plan*>(s.sddmm.plan), s.n_rows, s.nnz, G.data_ptr(),
+                check(tsgu_csr_sddmm_lattice(s.vtype, static_cast<const tsgu_lattice_plan*>(s.sddmm.plan()), s.n_rows, s.nnz, G.data_ptr(),
                                              s.p, B.data_ptr(), B.size(0) > 1 ? B.stride(0) : s.p, gv.data_ptr(), 1.0, s.p, s.device,
                                              stream_of(s.device)),
                       "tsgu_csr_sddmm_lattice");
@@ -125,19 +125,22 @@ PYBIND11_MODULE(_tsgu_host, m) {
     m.doc() = "C++ host path of the steady-state sparse_mm step (see csrc/host/step.cpp)";
     py::class_<StepPlan, StepPlanPtr>(m, "StepPlan")
         .def(py::init([](at::Tensor crow, at::Tensor col, int64_t n_rows, int64_t n_cols, int64_t nnz, int64_t p, int vtype, int device,
-                         std::tuple<int, uintptr_t, int> fwd, std::tuple<int, uintptr_t, int> sddmm, std::tuple<int, uintptr_t, int> spmm_t,
-                         py::object keep) {
+                         std::tuple<int, py::bytes, int> fwd, std::tuple<int, py::bytes, int> sddmm, std::tuple<int, py::bytes, int> spmm_t,
+                         std::vector<at::Tensor> tables) {
             auto s = std::make_shared<StepPlan>();
             s->crow = std::move(crow);
             s->col = std::move(col);
             s->n_rows = n_rows, s->n_cols = n_cols, s->nnz = nnz, s->p = p, s->vtype = vtype, s->device = device;
-            auto prod = [](const std::tuple<int, uintptr_t, int>& t) {
+            auto prod = [](const std::tuple<int, py::bytes, int>& t) {
                 Product q;
-                q.kind = std::get<0>(t), q.plan = std::get<1>(t), q.transposed = std::get<2>(t);
+                q.kind = std::get<0>(t), q.blob = std::string(std::get<1>(t)), q.transposed = std::get<2>(t);
+                const size_t want = q.kind == 0 ? sizeof(tsgu_march_plan) : sizeof(tsgu_lattice_plan);
+                if (q.blob.size() != want) throw std::invalid_argument("plan struct of the wrong size");
+                q.blob.reserve(64);      // (heap storage: 16-byte aligned, never moved again)
                 return q;
             };
             s->fwd = prod(fwd), s->sddmm = prod(sddmm), s->spmm_t = prod(spmm_t);
-            s->keep = std::move(keep);
+            s->tables = std::move(tables);
             return s;
         }))
         .def_readonly("p", &StepPlan::p)

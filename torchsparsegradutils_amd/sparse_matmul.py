@@ -18,6 +18,7 @@ block-diag assembly  :151-153  none: batched CSR stays batched   ``batch`` argum
 
 from __future__ import annotations
 
+import ctypes
 import os
 from typing import cast
 
@@ -84,7 +85,7 @@ def _step_plan(A: torch.Tensor, B: torch.Tensor):
 
 def _settle_step_plan(plan, dtype: torch.dtype, p: int) -> None:
     """After a step on the Python path: when the configurations of all three products of `plan` are final, describe the step to
-    the C++ host path.  The StepPlan keeps the lattice plans and configurations (and through them every device table) alive."""
+    the C++ host path.  The StepPlan copies the plan structs and holds every device table they point into."""
     if _host is None or not FAST_STEP or plan.batch is not None or plan.perm is not None or not _ops.ENABLE_LATTICE or _ops.FUSED_BACKWARD:
         return
     own = plan.core.own
@@ -98,18 +99,35 @@ def _settle_step_plan(plan, dtype: torch.dtype, p: int) -> None:
     got = [memo.get((mode, dtype, p, True, _ops._lt.ENABLE_MARCH)) for mode in (_be.LAT_SPMM, _be.LAT_SDDMM, _be.LAT_SPMMT)]
     if any(g is None for g in got):
         return
-    prods = []
+    prods, tables = [], [plan.crow, plan.col]
     for mode, (lp, cfg) in zip((_be.LAT_SPMM, _be.LAT_SDDMM, _be.LAT_SPMMT), got):
+        blob = ctypes.string_at(cfg.struct_addr, ctypes.sizeof(cfg.struct))     # sizes + device pointers into the tables below
         if getattr(cfg, "march", False):
             if cfg.col_tile != p:
                 return                  # (operands wider than a column tile run as several launches: the Python path)
-            prods.append((0, cfg.struct_addr, int(mode == _be.LAT_SPMMT)))
+            prods.append((0, blob, int(mode == _be.LAT_SPMMT)))
         else:
-            prods.append((1, cfg.struct_addr, 0))
+            prods.append((1, blob, 0))
+        tables += _tensors_of(lp) + _tensors_of(cfg)
     if plans is None:
         plans = own["step_plans"] = {}
     plans[key] = _host.StepPlan(plan.crow, plan.col, plan.n_rows, plan.n_cols, plan.nnz, p, _be._VTYPE[dtype], plan.crow.device.index,
-                                prods[0], prods[1], prods[2], tuple(got))
+                                prods[0], prods[1], prods[2], tables)
+
+
+def _tensors_of(obj, depth: int = 2):
+    """Every tensor reachable from the attributes of a plan / configuration object (its device tables), `depth` levels deep."""
+    found = []
+    names = getattr(type(obj), "__slots__", None) or list(getattr(obj, "__dict__", {}))
+    for k in names:
+        v = getattr(obj, k, None)
+        if torch.is_tensor(v):
+            found.append(v)
+        elif depth > 1 and v is not None and not isinstance(v, (int, float, str, bytes, bool, tuple, list, dict, ctypes.Structure)):
+            found += _tensors_of(v, depth - 1)
+        elif isinstance(v, (tuple, list)):
+            found += [t for t in v if torch.is_tensor(t)]
+    return found
 
 
 class _Operand:
