@@ -435,7 +435,7 @@ def test_cg_two_launch_form_against_the_four_step_form_and_the_oracle(dtype, sha
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("pattern", ["periodic27", "truncated27", "periodic7", "lower27"])
+@pytest.mark.parametrize("pattern", ["periodic27", "truncated27", "periodic7", "lower27", "random_csr", "random_coo", "random_csr_f64"])
 @pytest.mark.parametrize("p", [32, 16])
 def test_cpp_host_path_of_the_step_equals_the_python_path(pattern, p):
     """Once a CSR pattern's launch configurations are final, sparse_mm's forward and backward are issued by the C++ autograd
@@ -444,7 +444,7 @@ def test_cpp_host_path_of_the_step_equals_the_python_path(pattern, p):
     gradients are gated by needs_input_grad, a non-contiguous upstream gradient is accepted, a second backward raises
     (reference sparse_matmul.py:132-234)."""
     import torchsparsegradutils_amd.sparse_matmul as sm
-    from torchsparsegradutils_amd import _lattice, _ops, _pattern, sparse_mm
+    from torchsparsegradutils_amd import _lattice, _ops, _pattern, sparse_mm, wait_for_plans
     from torchsparsegradutils_amd.utils import synthetic
 
     assert sm._host is not None, "torchsparsegradutils_amd/_tsgu_host.so was not built (make -C torchsparsegradutils_amd/csrc)"
@@ -455,20 +455,40 @@ def test_cpp_host_path_of_the_step_equals_the_python_path(pattern, p):
         crow, col = synthetic.box_stencil(*dims, (False,) * 3, 27, None, torch.int32, DEV)
     elif pattern == "periodic7":
         crow, col = synthetic.box_stencil(*dims, (True,) * 3, 7, None, torch.int32, DEV)
-    else:
+    elif pattern == "lower27":
         crow, col = synthetic.box_stencil(*dims, (False,) * 3, 27, "lower", torch.int32, DEV)
+    else:
+        # no structure: the plan-free kernels (forward + ONE fused backward walk; fp64: SDDMM + transposed product), CSR or COO
+        gi = torch.Generator().manual_seed(9)
+        flat = torch.randperm(1500 * 1500, generator=gi)[:30000].sort().values
+        rows_, cols_ = (flat // 1500).to(DEV), (flat % 1500).to(DEV)
+        crow = torch.zeros(1501, dtype=torch.int64, device=DEV)
+        crow[1:] = torch.cumsum(torch.bincount(rows_, minlength=1500), 0)
+        crow, col = crow.to(torch.int32), cols_.to(torch.int32)
     n, nnz = crow.numel() - 1, col.numel()
+    vdt = torch.float64 if pattern.endswith("f64") else torch.float32
     g = torch.Generator(device=DEV).manual_seed(5)
-    val = torch.randn(nnz, device=DEV, generator=g)
-    B0 = torch.randn(n, p, device=DEV, generator=g)
-    G = torch.randn(n, p, device=DEV, generator=g)
+    val = torch.randn(nnz, device=DEV, generator=g, dtype=vdt)
+    B0 = torch.randn(n, p, device=DEV, generator=g, dtype=vdt)
+    G = torch.randn(n, p, device=DEV, generator=g, dtype=vdt)
     keep = (sm.FAST_STEP, _lattice.TUNE, _ops.PACK_MIN_NNZ)
     _pattern.clear_cache()
     try:
         _lattice.TUNE = False          # (the ranked configurations are final at once: both paths run the same launches)
         _ops.PACK_MIN_NNZ = 1          # (small lattices too)
-        A = torch.sparse_csr_tensor(crow, col, val, (n, n)).requires_grad_(True)
+        if pattern == "random_coo":
+            A = torch.sparse_coo_tensor(torch.stack((rows_, cols_)), val, (n, n)).coalesce().requires_grad_(True)
+        else:
+            A = torch.sparse_csr_tensor(crow, col, val, (n, n)).requires_grad_(True)
         B = B0.clone().requires_grad_(True)
+        coo = A.layout == torch.sparse_coo
+
+        def vals(t):
+            return t._values() if coo else t.values()
+
+        def own_of():
+            pl = _pattern.from_coo_2d(A.detach()._indices(), A.shape, coalesced=True) if coo else _pattern.from_csr(A.detach())
+            return pl.core.own
 
         def run(fast, need=(True, True), Gx=G):
             sm.FAST_STEP = fast
@@ -481,35 +501,39 @@ def test_cpp_host_path_of_the_step_equals_the_python_path(pattern, p):
 
         sm.FAST_STEP = True
         ref = run(False)
-        for _ in range(3):
+        for _ in range(6):
             run(True)                   # the Python path settles the step plan …
-        own = _pattern.from_csr(A.detach()).core.own
-        assert own.get("step_plans"), "no step plan was derived for a lattice stencil"
+            wait_for_plans()
+        own = own_of()
+        assert own.get("step_plans"), "no step plan was derived"
         C, (gA, gB) = run(True)         # … and this step runs through C++
         assert type(C.grad_fn).__name__ != "SparseMatMulBackward"
         assert torch.equal(C, ref[0]) and torch.equal(gB, ref[1][1])
-        assert gA.layout == torch.sparse_csr and gA.shape == A.shape
-        assert torch.equal(gA.values(), ref[1][0].values())
-        assert gA.crow_indices().dtype == torch.int32 and torch.equal(gA.crow_indices(), crow) and torch.equal(gA.col_indices(), col)
+        assert gA.layout == A.layout and gA.shape == A.shape
+        assert torch.equal(vals(gA), vals(ref[1][0]))
+        if coo:
+            assert torch.equal(gA._indices(), A._indices()) and gA._indices().dtype == torch.int64
+        else:
+            assert gA.crow_indices().dtype == torch.int32 and torch.equal(gA.crow_indices(), crow) and torch.equal(gA.col_indices(), col)
         # gating
         C1, (gB1,) = run(True, (False, True))
         assert torch.equal(gB1, gB)
         C2, (gA2,) = run(True, (True, False))
-        assert torch.equal(gA2.values(), gA.values())
+        assert torch.equal(vals(gA2), vals(gA))
         C3, none = run(True, (False, False))
         assert not C3.requires_grad and torch.equal(C3, C)
         # a non-contiguous upstream gradient
         Gt = G.t().contiguous().t()
         assert not Gt.is_contiguous()
         _, (gA4, gB4) = run(True, (True, True), Gt)
-        assert torch.equal(gA4.values(), gA.values()) and torch.equal(gB4, gB)
+        assert torch.equal(vals(gA4), vals(gA)) and torch.equal(gB4, gB)
         # .backward() accumulates into .grad like the Python path; the graph is freed by the first backward
         A.requires_grad_(True)
         B.requires_grad_(True)
         A.grad = B.grad = None
         Cb = sparse_mm(A, B)
         Cb.backward(G)
-        assert torch.equal(A.grad.values(), gA.values()) and torch.equal(B.grad, gB)
+        assert torch.equal(vals(A.grad if not coo else A.grad.coalesce()), vals(gA)) and torch.equal(B.grad, gB)
         with pytest.raises(RuntimeError):
             Cb.backward(G)
         # a graph outlives the pattern cache: the node owns the plan structs and the device tables they point into
@@ -523,9 +547,10 @@ def test_cpp_host_path_of_the_step_equals_the_python_path(pattern, p):
         junk = [torch.full((1 << 20,), float("nan"), device=DEV) for _ in range(8)]      # whatever was freed is overwritten
         gAl, gBl = torch.autograd.grad(Cl, (A, B), G)
         del junk
-        assert torch.equal(gAl.values(), gA.values()) and torch.equal(gBl, gB)
-        for _ in range(4):
+        assert torch.equal(vals(gAl), vals(gA)) and torch.equal(gBl, gB)
+        for _ in range(6):
             run(True)                   # (the cache was cleared: settle again)
+            wait_for_plans()
         # under no_grad and with the switch off
         with torch.no_grad():
             assert torch.equal(sparse_mm(A, B), C)

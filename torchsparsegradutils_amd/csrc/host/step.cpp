@@ -18,8 +18,8 @@
 
 namespace {
 
-struct Product {          // one of the three products of a step
-    int kind = 0;         // 0 plane march, 1 plane sweep
+struct Product {          // one of the three products of a step (structured patterns; plan-free steps carry their arrays in StepPlan)
+    int kind = 0;         // 0 plane march, 1 plane sweep, 2 plan-free gather kernels
     std::string blob;     // a copy of the tsgu_march_plan / tsgu_lattice_plan the Python configuration object built (plain struct of
                           // sizes + device pointers; the tables it points to are the tensors the StepPlan holds)
     int transposed = 0;   // march: walk the transposed pattern (gradB)
@@ -31,6 +31,14 @@ struct StepPlan {
     int64_t n_rows = 0, n_cols = 0, nnz = 0, p = 0;
     int vtype = 0, device = 0;
     Product fwd, sddmm, spmm_t;
+    // plan-free steps (kind 2 in all three): the transposed pattern (row pointer over A's columns, A's row of each entry, position in
+    // A's value array), the longest row (a hint of tsgu_csr_spmm) and whether both gradients can come from ONE walk
+    at::Tensor t_ptr, t_idx, t_perm;
+    int64_t max_row_nnz = 0, t_max_row_nnz = 0;
+    int itype = 0, fused_backward = 0;
+    // layout of A: CSR (crow / col above) or 2-D coalesced COO (`indices`; crow / col are then the CSR arrays derived from it)
+    int coo = 0;
+    at::Tensor indices;
     std::vector<at::Tensor> tables;   // every device table the three plan structs point into: no Python object is owned here, so the
                                       // last reference may go away on the autograd engine's thread (with a graph node) without the GIL
 };
@@ -63,9 +71,15 @@ class StepFunction : public torch::autograd::Function<StepFunction> {
    public:
     static at::Tensor forward(torch::autograd::AutogradContext* ctx, const at::Tensor& A, const at::Tensor& B, StepPlanPtr handle) {
         const StepPlan& s = *handle;
-        const at::Tensor val = A.values();
+        const at::Tensor val = s.coo ? A._values() : A.values();
         at::Tensor C = at::empty({s.n_rows, s.p}, B.options());
-        spmm(s, s.fwd, s.n_rows, val, B, C);
+        if (s.fwd.kind == 2)
+            check(tsgu_csr_spmm(s.vtype, s.itype, s.n_rows, s.n_cols, s.nnz, s.crow.data_ptr(), s.col.data_ptr(), val.data_ptr(), nullptr,
+                                B.data_ptr(), B.size(0) > 1 ? B.stride(0) : s.p, 1, 0, C.data_ptr(), s.p, 1, 0, s.p, 1, s.max_row_nnz, nullptr, 0,
+                                nullptr, s.device, stream_of(s.device)),
+                  "tsgu_csr_spmm");
+        else
+            spmm(s, s.fwd, s.n_rows, val, B, C);
         ctx->save_for_backward({val, B});
         ctx->saved_data["plan"] = c10::IValue(reinterpret_cast<int64_t>(&s));
         // the plan (and with it every table the launches read) lives as long as the graph node: an empty tensor whose deleter owns
@@ -85,25 +99,56 @@ class StepFunction : public torch::autograd::Function<StepFunction> {
         if (!G.defined()) return {gradA, gradB, at::Tensor()};
         if (!plain(G, s.n_rows, s.p)) G = G.contiguous();
         if (reinterpret_cast<uintptr_t>(G.data_ptr()) % 16 != 0) G = G.clone();
-        if (ctx->needs_input_grad(0)) {
-            // gradA[k] = <G[row k,:], B[col k,:]> at A's stored entries only (reference sparse_matmul.py:172-205)
-            at::Tensor gv = at::empty({s.nnz}, val.options());
-            if (s.sddmm.kind == 0)
-                check(tsgu_csr_sddmm_march(s.vtype, static_cast<const tsgu_march_plan*>(s.sddmm.plan()), s.n_rows, s.nnz, G.data_ptr(),
-                                           s.p, B.data_ptr(), B.size(0) > 1 ? B.stride(0) : s.p, gv.data_ptr(), 1.0, 0, s.p, s.device,
-                                           stream_of(s.device)),
-                      "tsgu_csr_sddmm_march");
-            else
-                check(tsgu_csr_sddmm_lattice(s.vtype, static_cast<const tsgu_lattice_plan*>(s.sddmm.plan()), s.n_rows, s.nnz, G.data_ptr(),
-                                             s.p, B.data_ptr(), B.size(0) > 1 ? B.stride(0) : s.p, gv.data_ptr(), 1.0, s.p, s.device,
-                                             stream_of(s.device)),
-                      "tsgu_csr_sddmm_lattice");
-            gradA = at::sparse_csr_tensor(s.crow, s.col, gv, {s.n_rows, s.n_cols}, gv.options().layout(at::kSparseCsr));
+        const bool need_a = ctx->needs_input_grad(0), need_b = ctx->needs_input_grad(1);
+        const int64_t ldb = B.size(0) > 1 ? B.stride(0) : s.p;
+        at::Tensor gv;
+        if (s.fwd.kind == 2) {
+            if (need_a && need_b && s.fused_backward) {
+                // both gradients in one pass over the transposed pattern: every upstream row is gathered once (reference :172-229)
+                gv = at::empty({s.nnz}, val.options());
+                gradB = at::empty({s.n_cols, s.p}, G.options());
+                check(tsgu_csr_mm_backward(s.vtype, s.itype, s.n_rows, s.n_cols, s.nnz, s.t_ptr.data_ptr(), s.t_idx.data_ptr(), s.t_perm.data_ptr(),
+                                           val.data_ptr(), G.data_ptr(), s.p, 0, B.data_ptr(), ldb, 0, gv.data_ptr(), gradB.data_ptr(), s.p, 0, s.p, 1,
+                                           s.device, stream_of(s.device)),
+                      "tsgu_csr_mm_backward");
+            } else {
+                if (need_a) {
+                    gv = at::empty({s.nnz}, val.options());
+                    check(tsgu_csr_sddmm(s.vtype, s.itype, s.n_rows, s.n_cols, s.nnz, s.crow.data_ptr(), s.col.data_ptr(), G.data_ptr(), s.p, 0,
+                                         B.data_ptr(), ldb, 0, gv.data_ptr(), 1.0, 0, s.p, 1, s.device, stream_of(s.device)),
+                          "tsgu_csr_sddmm");
+                }
+                if (need_b) {
+                    gradB = at::empty({s.n_cols, s.p}, G.options());
+                    check(tsgu_csr_spmm(s.vtype, s.itype, s.n_cols, s.n_rows, s.nnz, s.t_ptr.data_ptr(), s.t_idx.data_ptr(), val.data_ptr(),
+                                        s.t_perm.data_ptr(), G.data_ptr(), s.p, 1, 0, gradB.data_ptr(), s.p, 1, 0, s.p, 1, s.t_max_row_nnz, nullptr, 0,
+                                        nullptr, s.device, stream_of(s.device)),
+                          "tsgu_csr_spmm");
+                }
+            }
+        } else {
+            if (need_a) {
+                // gradA[k] = <G[row k,:], B[col k,:]> at A's stored entries only (reference sparse_matmul.py:172-205)
+                gv = at::empty({s.nnz}, val.options());
+                if (s.sddmm.kind == 0)
+                    check(tsgu_csr_sddmm_march(s.vtype, static_cast<const tsgu_march_plan*>(s.sddmm.plan()), s.n_rows, s.nnz, G.data_ptr(), s.p,
+                                               B.data_ptr(), ldb, gv.data_ptr(), 1.0, 0, s.p, s.device, stream_of(s.device)),
+                          "tsgu_csr_sddmm_march");
+                else
+                    check(tsgu_csr_sddmm_lattice(s.vtype, static_cast<const tsgu_lattice_plan*>(s.sddmm.plan()), s.n_rows, s.nnz, G.data_ptr(), s.p,
+                                                 B.data_ptr(), ldb, gv.data_ptr(), 1.0, s.p, s.device, stream_of(s.device)),
+                          "tsgu_csr_sddmm_lattice");
+            }
+            if (need_b) {
+                // gradB = Aᵀ·G (reference sparse_matmul.py:229), through A's own arrays
+                gradB = at::empty({s.n_cols, s.p}, G.options());
+                spmm(s, s.spmm_t, s.n_cols, val, G, gradB);
+            }
         }
-        if (ctx->needs_input_grad(1)) {
-            // gradB = Aᵀ·G (reference sparse_matmul.py:229), through A's own arrays
-            gradB = at::empty({s.n_cols, s.p}, G.options());
-            spmm(s, s.spmm_t, s.n_cols, val, G, gradB);
+        if (need_a) {
+            // the sparse gradient in A's own layout, with A's index tensors (reference sparse_matmul.py:208-219)
+            if (s.coo) gradA = at::sparse_coo_tensor(s.indices, gv, {s.n_rows, s.n_cols}, gv.options().layout(at::kSparse));
+            else gradA = at::sparse_csr_tensor(s.crow, s.col, gv, {s.n_rows, s.n_cols}, gv.options().layout(at::kSparseCsr));
         }
         return {gradA, gradB, at::Tensor()};
     }
@@ -114,7 +159,8 @@ at::Tensor step(const at::Tensor& A, const at::Tensor& B, StepPlanPtr handle) {
     TORCH_CHECK(handle != nullptr, "no step plan");
     const StepPlan& s = *handle;
     // (Python has validated layout / dims / dtypes / device; these are the conditions of the raw-pointer launches)
-    TORCH_CHECK(A.layout() == at::kSparseCsr && A.dim() == 2 && A.size(0) == s.n_rows && A.size(1) == s.n_cols, "step plan of another matrix");
+    TORCH_CHECK(A.layout() == (s.coo ? at::kSparse : at::kSparseCsr) && A.dim() == 2 && A.size(0) == s.n_rows && A.size(1) == s.n_cols,
+                "step plan of another matrix");
     TORCH_CHECK(plain(B, s.n_cols, s.p), "the fast step takes a contiguous, 16-byte aligned (n_cols, p) operand");
     return StepFunction::apply(A, B, std::move(handle));
 }
@@ -134,7 +180,7 @@ PYBIND11_MODULE(_tsgu_host, m) {
             auto prod = [](const std::tuple<int, py::bytes, int>& t) {
                 Product q;
                 q.kind = std::get<0>(t), q.blob = std::string(std::get<1>(t)), q.transposed = std::get<2>(t);
-                const size_t want = q.kind == 0 ? sizeof(tsgu_march_plan) : sizeof(tsgu_lattice_plan);
+                const size_t want = q.kind == 0 ? sizeof(tsgu_march_plan) : (q.kind == 1 ? sizeof(tsgu_lattice_plan) : 0);
                 if (q.blob.size() != want) throw std::invalid_argument("plan struct of the wrong size");
                 q.blob.reserve(64);      // (heap storage: 16-byte aligned, never moved again)
                 return q;
@@ -143,6 +189,17 @@ PYBIND11_MODULE(_tsgu_host, m) {
             s->tables = std::move(tables);
             return s;
         }))
+        .def("set_plan_free", [](StepPlan& s, int itype, at::Tensor t_ptr, at::Tensor t_idx, at::Tensor t_perm, int64_t max_row_nnz,
+                                 int64_t t_max_row_nnz, bool fused_backward) {
+            s.fwd.kind = s.sddmm.kind = s.spmm_t.kind = 2;
+            s.itype = itype;
+            s.t_ptr = std::move(t_ptr), s.t_idx = std::move(t_idx), s.t_perm = std::move(t_perm);
+            s.max_row_nnz = max_row_nnz, s.t_max_row_nnz = t_max_row_nnz, s.fused_backward = fused_backward ? 1 : 0;
+        })
+        .def("set_coo", [](StepPlan& s, at::Tensor indices) {
+            s.coo = 1;
+            s.indices = std::move(indices);
+        })
         .def_readonly("p", &StepPlan::p)
         .def_readonly("n_rows", &StepPlan::n_rows);
     m.def("step", &step, "C = A @ B with the sparsity-preserving backward, host path in C++");

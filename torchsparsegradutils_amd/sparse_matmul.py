@@ -52,7 +52,7 @@ def sparse_mm(A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
     if A.size(-1) != B.size(-2):
         raise ValueError(f"Incompatible inner dimensions: A[..., {A.size(-1)}] vs B[..., {B.size(-2)}]")
 
-    if _host is not None and FAST_STEP and A.layout == torch.sparse_csr and B.is_cuda and B.dim() == 2:
+    if _host is not None and FAST_STEP and B.is_cuda and B.dim() == 2:
         plan = _step_plan(A, B)
         if plan is not None:
             return cast(torch.Tensor, _host.step(A, B, plan))
@@ -71,48 +71,81 @@ except ImportError:                          # (the Python path below is complet
     _host = None
 
 
+def _step_key(dtype, p: int):
+    return (dtype, p, _ops.ENABLE_LATTICE, _ops._lt.ENABLE_MARCH, _ops.ENABLE_PACK)
+
+
 def _step_plan(A: torch.Tensor, B: torch.Tensor):
     """The `_tsgu_host.StepPlan` of (A's pattern, B's dtype and width), or None while the pattern is young / not covered."""
     if (A.dtype != B.dtype or A.device != B.device or not B.is_contiguous() or B.data_ptr() % 16 or _be.KERNEL_EVENTS is not None
-            or not _ops.ENABLE_LATTICE or _ops.FUSED_BACKWARD):
+            or _ops.FUSED_BACKWARD):
         return None
-    own = _pt.from_csr(A).core.own
+    if A.layout == torch.sparse_csr:
+        own = _pt.from_csr(A).core.own
+    elif A.is_coalesced():
+        own = _pt.from_coo_2d(A._indices(), A.shape, coalesced=True).core.own
+    else:
+        return None
     plans = own.get("step_plans")
     if plans is None:
         return None
-    return plans.get((B.dtype, B.size(-1), _ops._lt.ENABLE_MARCH))
+    return plans.get(_step_key(B.dtype, B.size(-1)))
 
 
-def _settle_step_plan(plan, dtype: torch.dtype, p: int) -> None:
-    """After a step on the Python path: when the configurations of all three products of `plan` are final, describe the step to
-    the C++ host path.  The StepPlan copies the plan structs and holds every device table they point into."""
-    if _host is None or not FAST_STEP or plan.batch is not None or plan.perm is not None or not _ops.ENABLE_LATTICE or _ops.FUSED_BACKWARD:
+def _settle_step_plan(op: "_Operand", values: torch.Tensor, G: torch.Tensor, B: torch.Tensor) -> None:
+    """After a step on the Python path (2-D operand, both gradients): when what the step launches is FINAL, describe it to the C++
+    host path — the three configurations of a lattice stencil (the StepPlan copies the plan structs and holds every device table
+    they point into), or the plan-free kernels with the cached transposed pattern once the row-pair plans are known not to apply."""
+    plan = op.plan
+    if (_host is None or not FAST_STEP or plan.batch is not None or plan.perm is not None or _ops.FUSED_BACKWARD or B.dim() != 2
+            or not (values.dtype == G.dtype == B.dtype) or (op.layout != torch.sparse_csr and op.indices is None)):
         return
+    dtype, p = G.dtype, G.size(-1)
     own = plan.core.own
     plans = own.get("step_plans")
-    key = (dtype, p, _ops._lt.ENABLE_MARCH)
+    key = _step_key(dtype, p)
     if plans is not None and key in plans:
         return
-    memo = own.get("lattice_memo")
-    if memo is None:
-        return
-    got = [memo.get((mode, dtype, p, True, _ops._lt.ENABLE_MARCH)) for mode in (_be.LAT_SPMM, _be.LAT_SDDMM, _be.LAT_SPMMT)]
-    if any(g is None for g in got):
-        return
-    prods, tables = [], [plan.crow, plan.col]
-    for mode, (lp, cfg) in zip((_be.LAT_SPMM, _be.LAT_SDDMM, _be.LAT_SPMMT), got):
-        blob = ctypes.string_at(cfg.struct_addr, ctypes.sizeof(cfg.struct))     # sizes + device pointers into the tables below
-        if getattr(cfg, "march", False):
-            if cfg.col_tile != p:
-                return                  # (operands wider than a column tile run as several launches: the Python path)
-            prods.append((0, blob, int(mode == _be.LAT_SPMMT)))
-        else:
-            prods.append((1, blob, 0))
-        tables += _tensors_of(lp) + _tensors_of(cfg)
+    dev = plan.crow.device
+    memo = own.get("lattice_memo") if _ops.ENABLE_LATTICE else None
+    got = None if memo is None else [memo.get((mode, dtype, p, True, _ops._lt.ENABLE_MARCH)) for mode in (_be.LAT_SPMM, _be.LAT_SDDMM, _be.LAT_SPMMT)]
+    if got is not None and all(g is not None for g in got):
+        prods, tables = [], [plan.crow, plan.col]
+        for mode, (lp, cfg) in zip((_be.LAT_SPMM, _be.LAT_SDDMM, _be.LAT_SPMMT), got):
+            blob = ctypes.string_at(cfg.struct_addr, ctypes.sizeof(cfg.struct))     # sizes + device pointers into the tables below
+            if getattr(cfg, "march", False):
+                if cfg.col_tile != p:
+                    return                  # (operands wider than a column tile run as several launches: the Python path)
+                prods.append((0, blob, int(mode == _be.LAT_SPMMT)))
+            else:
+                prods.append((1, blob, 0))
+            tables += _tensors_of(lp) + _tensors_of(cfg)
+        sp = _host.StepPlan(plan.crow, plan.col, plan.n_rows, plan.n_cols, plan.nnz, p, _be._VTYPE[dtype], dev.index,
+                            prods[0], prods[1], prods[2], tables)
+    else:
+        # no lattice: is the step on the plan-free kernels for good?  (not while a row-pair plan may still arrive)
+        if got is not None and any(g is not None for g in got):
+            return                          # (a lattice whose configurations are still being chosen)
+        seen = own["step_settle_calls"] = own.get("step_settle_calls", 0) + 1
+        if dtype not in (torch.float32, torch.bfloat16, torch.float64) or seen <= _ops.PLAN_AFTER_USES + 2:
+            return                          # (the pattern has to come back a few times: its row-pair plans are asked for on the way)
+        if _ops.ENABLE_LATTICE and _ops._lattice_cfg(plan, _be.LAT_SPMM, B) is not None:
+            return
+        t = plan.transposed
+        if plan.core.pending or t.core.pending or _ops._pack_for(plan, B) is not None or _ops._pack_for(t, G, B) is not None:
+            return
+        if not (B.is_contiguous() and G.is_contiguous() and plan.crow.is_contiguous() and plan.col.is_contiguous()
+                and t.crow.is_contiguous() and t.col.is_contiguous() and t.perm is not None and t.perm.is_contiguous()):
+            return
+        none = (2, b"", 0)
+        sp = _host.StepPlan(plan.crow, plan.col, plan.n_rows, plan.n_cols, plan.nnz, p, _be._VTYPE[dtype], dev.index, none, none, none, [])
+        sp.set_plan_free(_be.itype_of(plan.crow), t.crow, t.col, t.perm, int(plan.max_row_nnz), int(t.max_row_nnz),
+                         bool(_be.fused_backward_supported(dtype, p)))
+    if op.layout != torch.sparse_csr:
+        sp.set_coo(op.indices)
     if plans is None:
         plans = own["step_plans"] = {}
-    plans[key] = _host.StepPlan(plan.crow, plan.col, plan.n_rows, plan.n_cols, plan.nnz, p, _be._VTYPE[dtype], plan.crow.device.index,
-                                prods[0], prods[1], prods[2], tables)
+    plans[key] = sp
 
 
 def _tensors_of(obj, depth: int = 2):
@@ -215,8 +248,8 @@ class SparseMatMul(torch.autograd.Function):
             gradA = op.rebuild(gvals)
             if ctx.batch_size is not None:
                 gradB = gradB.view(ctx.B_shape)
-            elif op.layout == torch.sparse_csr:
-                _settle_step_plan(plan, G.dtype, G.size(-1))
+            elif op.flat_batch is None:
+                _settle_step_plan(op, values, G, B)
             return gradA, gradB
 
         if need_a:
@@ -233,4 +266,6 @@ class SparseMatMul(torch.autograd.Function):
             if ctx.batch_size is not None:
                 gradB = gradB.view(ctx.B_shape)
 
+        if need_a and need_b and op.flat_batch is None and ctx.batch_size is None:
+            _settle_step_plan(op, values, G, B)
         return gradA, gradB
