@@ -32,6 +32,7 @@ sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
 
+LEGS_TIMEOUT_S = float(os.environ.get("TSGU_BENCH_LEGS_TIMEOUT", "300"))     # N > 1: budget of the legs after the timed region (RCCL all-gather, sharded C5)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
 
@@ -666,47 +667,8 @@ def main():
     copy16_gbs = 2 * src.numel() * 4 / (copy16_ms * 1e-3) / 1e9
     del src, dst
 
-    # ---- RCCL all-gather of the forward result (outside the timed region) ----
-    allgather = None
-    if world > 1:
-        C = step().detach()
-        out = torch.empty((world * C.size(0), C.size(1)), device=dev, dtype=C.dtype)   # rank-major rows
-        barrier()
-        ag_ms = time_events(lambda: dist.all_gather_into_tensor(out, C), 10, dev)
-        allgather = {"ms": round(ag_ms, 4), "bytes_per_rank": C.numel() * 4,
-                     "algbw_GB/s": round(world * C.numel() * 4 / (ag_ms * 1e-3) / 1e9, 1)}
-        del out, C
-
-    c5 = None
-    if not args.no_c5:
-        del A, B, G, val, crow, col, plan, pt, rp_t, rp_f, rp_s, Bd, vd, lat_f, lat_s, lat_t
-        _pattern.clear_cache()
-        torch.cuda.empty_cache()
-        try:
-            c5 = c5_leg(dev, world, rank, args.steps, args.warmup, barrier)
-        except Exception as exc:  # noqa: BLE001  (never lose the headline line to the secondary leg)
-            c5 = {"error": repr(exc)}
-
-    patterns = None
-    if rank == 0 and world == 1 and not args.no_patterns:
-        headline = {"what": "the headline workload (this line's value)", "n": n, "nnz": nnz, "rhs": p,
-                    "kernels": "plane march" if lattice and getattr(lat_f_is_march, "march", False) else ("plane sweep" if lattice else "row pairs / plan-free"),
-                    "ms_per_step": round(ms_per_step, 5), "ms_per_step_device": round(ms_device, 5),
-                    "frac_device": round(ab["fwd_bwd"] / (ms_device * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_step": ab["fwd_bwd"],
-                    "frac": round(ab["fwd_bwd"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": step_traffic,
-                    "frac_wire": None if step_traffic is None else round(step_traffic / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-        if args.no_c5:      # (the C5 leg has already released the headline operands otherwise)
-            del A, B, G, val, crow, col, plan, pt, rp_t, rp_f, rp_s, Bd, vd, lat_f, lat_s, lat_t
-        try:
-            patterns = patterns_leg(dev, args.steps, args.warmup, headline)
-        except Exception as exc:  # noqa: BLE001
-            patterns = {"error": repr(exc)}
-
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline_leg(nx, ny, nz, p)
-
-    if rank == 0:
+    def make_line(allgather, c5, patterns, cpu):
+        """The ONE JSON line of this run (rank 0) from what has been measured so far."""
         total_bytes = ab["fwd_bwd"] * world
         value = total_bytes / (ms_per_step * 1e-3) / 1e9
         flops = 3 * 2 * nnz * p * world
@@ -791,7 +753,71 @@ def main():
         }
         if allgather is not None:
             line["allgather"] = allgather
-        print(json.dumps(line), flush=True)
+        return line
+
+    # N > 1: everything below this point uses RCCL collectives beyond the barrier / max of the timed region (an all-gather, the
+    # sharded C5 leg).  If one of them stalls, the run must still end with its line: after LEGS_TIMEOUT_S every rank leaves, rank 0
+    # after printing the line without the secondary legs.
+    watchdog = None
+    if world > 1:
+        import threading
+
+        def bail():
+            if rank == 0:
+                note = {"error": f"not finished within {LEGS_TIMEOUT_S} s (a collective of the secondary legs stalled?)"}
+                print(json.dumps(make_line(None, note, None, None)), flush=True)
+            os._exit(0)
+
+        watchdog = threading.Timer(LEGS_TIMEOUT_S, bail)
+        watchdog.daemon = True
+        watchdog.start()
+        if os.environ.get("TSGU_BENCH_TEST_STALL"):        # test hook (tests/test_gpu_zz_bench_world2.py): a leg that never returns
+            time.sleep(1e6)
+
+    # ---- RCCL all-gather of the forward result (outside the timed region) ----
+    allgather = None
+    if world > 1:
+        C = step().detach()
+        out = torch.empty((world * C.size(0), C.size(1)), device=dev, dtype=C.dtype)   # rank-major rows
+        barrier()
+        ag_ms = time_events(lambda: dist.all_gather_into_tensor(out, C), 10, dev)
+        allgather = {"ms": round(ag_ms, 4), "bytes_per_rank": C.numel() * 4,
+                     "algbw_GB/s": round(world * C.numel() * 4 / (ag_ms * 1e-3) / 1e9, 1)}
+        del out, C
+
+    c5 = None
+    if not args.no_c5:
+        del A, B, G, val, crow, col, plan, pt, rp_t, rp_f, rp_s, Bd, vd, lat_f, lat_s, lat_t
+        _pattern.clear_cache()
+        torch.cuda.empty_cache()
+        try:
+            c5 = c5_leg(dev, world, rank, args.steps, args.warmup, barrier)
+        except Exception as exc:  # noqa: BLE001  (never lose the headline line to the secondary leg)
+            c5 = {"error": repr(exc)}
+
+    patterns = None
+    if rank == 0 and world == 1 and not args.no_patterns:
+        headline = {"what": "the headline workload (this line's value)", "n": n, "nnz": nnz, "rhs": p,
+                    "kernels": "plane march" if lattice and getattr(lat_f_is_march, "march", False) else ("plane sweep" if lattice else "row pairs / plan-free"),
+                    "ms_per_step": round(ms_per_step, 5), "ms_per_step_device": round(ms_device, 5),
+                    "frac_device": round(ab["fwd_bwd"] / (ms_device * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_step": ab["fwd_bwd"],
+                    "frac": round(ab["fwd_bwd"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": step_traffic,
+                    "frac_wire": None if step_traffic is None else round(step_traffic / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        if args.no_c5:      # (the C5 leg has already released the headline operands otherwise)
+            del A, B, G, val, crow, col, plan, pt, rp_t, rp_f, rp_s, Bd, vd, lat_f, lat_s, lat_t
+        try:
+            patterns = patterns_leg(dev, args.steps, args.warmup, headline)
+        except Exception as exc:  # noqa: BLE001
+            patterns = {"error": repr(exc)}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline_leg(nx, ny, nz, p)
+
+    if watchdog is not None:
+        watchdog.cancel()
+    if rank == 0:
+        print(json.dumps(make_line(allgather, c5, patterns, cpu)), flush=True)
 
     if world > 1:
         dist.destroy_process_group()
