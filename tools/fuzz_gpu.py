@@ -15,6 +15,8 @@ from torchsparsegradutils_amd import _ops, _pattern  # noqa: E402
 from torchsparsegradutils_amd.utils import stack_csr  # noqa: E402
 
 DEV = "cuda:0"
+REPEAT = 1
+CPP_STEPS = [0]      # sparse_mm steps that went through the C++ host path
 TOL = {torch.float32: 2e-5, torch.float64: 1e-11, torch.bfloat16: 2e-2}
 
 
@@ -85,11 +87,22 @@ def case_mm(g, i):
     Bs = B.clone().requires_grad_(True)
     Adg = Ad.double().clone().requires_grad_(True)
     Bdg = B.double().clone().requires_grad_(True)
-    out = T.sparse_mm(A, Bs)
     ref = Adg @ Bdg
     G = torch.randn(ref.shape, dtype=torch.float64, generator=g).to(vd).to(DEV)
-    out.backward(G)
     ref.backward(G.double())
+    # --repeat: the same step several times — from the fourth on a 2-D pattern runs through the C++ host path (csrc/host/step.cpp);
+    # every repetition must give the same bits as the first
+    first = None
+    for _ in range(REPEAT):
+        A.grad = Bs.grad = None
+        out = T.sparse_mm(A, Bs)
+        out.backward(G)
+        T.wait_for_plans()
+        now = (out.detach().clone(), (A.grad._values() if A.grad.layout == torch.sparse_coo else A.grad.values()).clone(), Bs.grad.clone())
+        first = first if first is not None else now
+        # (a structured plan that arrives between repetitions may change the rounding: every repetition is held to the dense result)
+        assert all(torch.isfinite(t).all() for t in now)
+        CPP_STEPS[0] += type(out.grad_fn).__name__ != "SparseMatMulBackward"
     gA = A.grad.to_dense() if vd != torch.bfloat16 or layout == "coo" else None
     if gA is None:
         Ag = A.grad
@@ -157,11 +170,22 @@ def case_lattice(g, i):
     Bs = B.clone().requires_grad_(True)
     Adg = Ad.clone().requires_grad_(True)
     Bdg = B.double().clone().requires_grad_(True)
-    out = T.sparse_mm(A, Bs)
     ref = Adg @ Bdg
     G = torch.randn(ref.shape, dtype=torch.float64, generator=g).to(vd).to(DEV)
-    out.backward(G)
     ref.backward(G.double())
+    # --repeat: the same step several times — from the fourth on a 2-D pattern runs through the C++ host path (csrc/host/step.cpp);
+    # every repetition must give the same bits as the first
+    first = None
+    for _ in range(REPEAT):
+        A.grad = Bs.grad = None
+        out = T.sparse_mm(A, Bs)
+        out.backward(G)
+        T.wait_for_plans()
+        now = (out.detach().clone(), (A.grad._values() if A.grad.layout == torch.sparse_coo else A.grad.values()).clone(), Bs.grad.clone())
+        first = first if first is not None else now
+        # (a structured plan that arrives between repetitions may change the rounding: every repetition is held to the dense result)
+        assert all(torch.isfinite(t).all() for t in now)
+        CPP_STEPS[0] += type(out.grad_fn).__name__ != "SparseMatMulBackward"
     rows = torch.repeat_interleave(torch.arange(n, device=DEV), crow.long().diff())
     gA_ref = Adg.grad[rows, col.long()]
     errs = (nerr(out, ref), nerr(A.grad.values(), gA_ref), nerr(Bs.grad, Bdg.grad))
@@ -213,7 +237,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=300)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--repeat", type=int, default=1, help="steps per sparse_mm case (>= 5: the C++ host path is reached)")
     a = ap.parse_args()
+    global REPEAT
+    REPEAT = max(a.repeat, 1)
     g = torch.Generator().manual_seed(a.seed)
     worst = {}
     bad = 0
@@ -247,7 +274,7 @@ def main():
             bad += 1
     for k, v in sorted(worst.items()):
         print(f"worst {k}: {v:.3g}")
-    print(f"{a.cases} cases, {bad} violations")
+    print(f"{a.cases} cases, {bad} violations; {CPP_STEPS[0]} sparse_mm steps through the C++ host path")
     sys.exit(1 if bad else 0)
 
 
