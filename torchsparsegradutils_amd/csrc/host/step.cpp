@@ -7,6 +7,7 @@
 // (allocate the result, launch through the C ABI of include/tsgu_hip.h on torch's current stream, rebuild the sparse gradient),
 // as a torch::autograd::Function whose backward runs on the engine thread without the interpreter.  No kernel lives here and
 // nothing is decided here: Python builds a StepPlan once the pattern's configurations are settled and keeps every table alive.
+#include <c10/hip/HIPGuard.h>
 #include <c10/hip/HIPStream.h>
 #include <torch/extension.h>
 
@@ -71,6 +72,7 @@ class StepFunction : public torch::autograd::Function<StepFunction> {
    public:
     static at::Tensor forward(torch::autograd::AutogradContext* ctx, const at::Tensor& A, const at::Tensor& B, StepPlanPtr handle) {
         const StepPlan& s = *handle;
+        const c10::hip::HIPGuard on_device(static_cast<c10::DeviceIndex>(s.device));   // (the launchers select the device: restore the caller's)
         const at::Tensor val = s.coo ? A._values() : A.values();
         at::Tensor C = at::empty({s.n_rows, s.p}, B.options());
         if (s.fwd.kind == 2)
@@ -91,6 +93,7 @@ class StepFunction : public torch::autograd::Function<StepFunction> {
 
     static torch::autograd::variable_list backward(torch::autograd::AutogradContext* ctx, torch::autograd::variable_list grads) {
         const StepPlan& s = *reinterpret_cast<const StepPlan*>(ctx->saved_data["plan"].toInt());
+        const c10::hip::HIPGuard on_device(static_cast<c10::DeviceIndex>(s.device));
         const auto saved = ctx->get_saved_variables();
         const at::Tensor& val = saved[0];
         const at::Tensor& B = saved[1];
