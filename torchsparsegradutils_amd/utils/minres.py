@@ -47,6 +47,30 @@ def minres(
 ) -> torch.Tensor:
     r"""Solve symmetric (possibly indefinite) systems :math:`(A + \sigma I) x = b` with MINRES."""
     _be.require_device(rhs)
+    if (ENABLE_FUSED and rhs.dim() > 2 and (shifts is None or shifts.dim() <= 1) and rhs.dtype in (torch.float32, torch.float64)
+            and rhs.numel() > 0):
+        # right-hand sides with batch dimensions (*batch, n, k) (reference utils/minres.py:221-233: norms per (batch, column), the
+        # stop rule is their mean): the batch is folded into the columns, (n, batch·k), and solved by the 2-D path on the fused
+        # kernels.  A 2-D sparse operator applies to every column alike; any other closure (and a preconditioner) sees its own
+        # (*batch, n, k) layout through a reshaping wrapper.
+        batch_shape = tuple(rhs.shape[:-2])
+        n, k = rhs.shape[-2:]
+        nb = rhs.numel() // (n * k)
+
+        def fold(t):      # (*batch, n, k) -> (n, batch*k)
+            return t.reshape(nb, n, k).permute(1, 0, 2).reshape(n, nb * k)
+
+        def unfold(t):    # (..., n, batch*k) -> (..., *batch, n, k)
+            lead = tuple(t.shape[:-2])
+            return t.reshape(lead + (n, nb, k)).movedim(-2, -3).reshape(lead + batch_shape + (n, k))
+
+        if torch.is_tensor(matmul_closure) and matmul_closure.dim() == 2 and matmul_closure.layout in (torch.sparse_csr, torch.sparse_coo):
+            op2 = matmul_closure
+        else:
+            inner = as_operator(matmul_closure)
+            op2 = lambda v: fold(inner(unfold(v)))  # noqa: E731
+        pre = None if preconditioner is None else (lambda v: fold(preconditioner(unfold(v))))
+        return unfold(minres(op2, fold(rhs).contiguous(), eps, shifts, value, max_iter, pre, settings))
     mm = as_operator(matmul_closure)
     precond = (lambda v: v.clone()) if preconditioner is None else preconditioner
 
