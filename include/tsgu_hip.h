@@ -460,6 +460,8 @@ int tsgu_cg_update1_alpha(int vtype, int64_t n, int64_t p, void* r, const void* 
  *                     (tsgu_cg2_num_blocks() rows, <= 1024)
  * tsgu_cg2_direction: beta = safe(rr_new / rr) ; x += alpha*p ; p = r + beta*p ; rr, rnorm, has_converged, the stop rule and the
  *                     iteration counter into half parity ^ 1
+ * `hist` (optional, [n_hist][2][p] values): alpha and beta of the first n_hist iterations, what the Lanczos tridiagonal matrices
+ * of linear_cg(n_tridiag > 0) are built from (reference :385-406).
  * The caller starts with rr, has_converged in half 0, parity 0, and alternates; both are no-ops once done[parity] != 0 (the
  * flag is carried to the other half), so a host may enqueue iterations ahead and poll flags2[0] | flags2[1]. */
 int64_t tsgu_cg2_num_blocks(int vtype, int64_t n, int64_t p);
@@ -467,7 +469,7 @@ int tsgu_cg2_residual(int vtype, int64_t n, int64_t p, void* r, const void* Ap, 
                       const int* flags2, int parity, double eps, void* rr_partial, int device, void* stream);
 int tsgu_cg2_direction(int vtype, int64_t n, int64_t p, const void* r, void* pvec, void* x, const void* rr_partial, int64_t n_partial,
                        void* scal2, int* flags2, int parity, double eps, double stop_updating_after, double tolerance,
-                       int min_iter_index, int device, void* stream);
+                       int min_iter_index, void* hist, int n_hist, int device, void* stream);
 /* rows of rr_partial written by tsgu_cg_update1; r/Ap/x/pvec must be contiguous [n][p], 16-byte aligned */
 int64_t tsgu_cg_num_blocks(int vtype, int64_t n, int64_t p);
 int tsgu_cg_beta(int vtype, const void* rr_partial, int64_t n_partial, void* scal, int* flags,

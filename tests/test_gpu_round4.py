@@ -605,3 +605,45 @@ def test_minres_with_batched_right_hand_sides_runs_on_the_fused_kernels(dtype, n
         x0 = out[True][0] if nshift else out[True]
         res = torch.stack([torch.stack([torch.sparse.mm(A, x0[i, j]) - rhs[i, j] for j in range(3)]) for i in range(2)])
         assert float(res.abs().max()) <= (5e-3 if dtype == torch.float32 else 1e-6) * float(rhs.abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_lanczos_matrices_come_from_the_fused_cg_kernels(dtype):
+    """linear_cg(n_tridiag > 0) without a preconditioner on a sparse operator: the fused kernels record alpha and beta of the first
+    iterations (tsgu_cg2_direction `hist`) and the matrices are built from them afterwards (reference utils/linear_cg.py:385-406) —
+    the tensor-op loop is not entered.  Same T (size included: the early end of the Lanczos bookkeeping) and x as that loop, and as
+    the golden vectors of the real reference (test_gpu_parity.py::test_cg_lanczos_tridiagonal_matrices_match_reference)."""
+    import sys
+    import warnings
+
+    from torchsparsegradutils_amd.utils import linear_cg
+
+    mod = sys.modules["torchsparsegradutils_amd.utils.linear_cg"]
+    z = G.load("cg_tridiag.npz")
+    n = z["rhs"].shape[0]
+    A = torch.sparse_csr_tensor(G.t(z["crow"], DEV), G.t(z["col"], DEV), G.t(z["val"], DEV).to(dtype), (n, n))
+    rhs = G.t(z["rhs"], DEV).to(dtype)
+    tol = 1e-9 if dtype == torch.float64 else 5e-4
+    keep = mod._pcg_loop
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for kw in (dict(n_tridiag=4, max_tridiag_iter=10, max_iter=n, tolerance=0, eps=1e-15),
+                   dict(n_tridiag=6, max_tridiag_iter=25, max_iter=40, tolerance=1e-3),
+                   dict(n_tridiag=2, max_tridiag_iter=5, max_iter=5, tolerance=0),
+                   dict(n_tridiag=1, max_tridiag_iter=20, max_iter=60, tolerance=1e-2)):
+            def boom(*a, **k):
+                raise AssertionError("the tensor-op loop was entered")
+
+            mod._pcg_loop = boom
+            try:
+                x, T = linear_cg(A, rhs, **kw)
+            finally:
+                mod._pcg_loop = keep
+            mod.TWO_LAUNCH = False
+            try:
+                x0, T0 = linear_cg(A, rhs, **kw)
+            finally:
+                mod.TWO_LAUNCH = True
+            assert T.shape == T0.shape, kw
+            assert float((T - T0).abs().max()) <= tol * float(T0.abs().max()) and float((x - x0).abs().max()) <= tol * float(x0.abs().max()), kw

@@ -111,7 +111,7 @@ SIGNATURES = {
     "tsgu_cg_update2": (_int, [_int, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _int, _ptr]),
     "tsgu_cg2_num_blocks": (_i64, [_int, _i64, _i64]),
     "tsgu_cg2_residual": (_int, [_int, _i64, _i64, _ptr, _ptr, _ptr, _i64, _ptr, _ptr, _int, _dbl, _ptr, _int, _ptr]),
-    "tsgu_cg2_direction": (_int, [_int, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _i64, _ptr, _ptr, _int, _dbl, _dbl, _dbl, _int, _int, _ptr]),
+    "tsgu_cg2_direction": (_int, [_int, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _i64, _ptr, _ptr, _int, _dbl, _dbl, _dbl, _int, _ptr, _int, _int, _ptr]),
     "tsgu_cg_update1_alpha": (_int, [_int, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _ptr, _ptr, _dbl, _ptr, _int, _ptr]),
     "tsgu_bicg_scalar": (_int, [_int, _int, _ptr, _i64, _i64, _ptr, _ptr, _ptr, _dbl, _dbl, _int, _int, _i64, _int, _ptr]),
     "tsgu_bicg_vector": (_int, [_int, _int, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _int, _ptr]),

@@ -369,7 +369,8 @@ template <typename V, int VEC>
 __global__ __launch_bounds__(kBlock) void cg_direction_beta_kernel(int64_t n, int64_t p, const V* __restrict__ r, V* __restrict__ pv,
                                                                    V* __restrict__ x, const V* __restrict__ rr_partial, int64_t n_partial,
                                                                    V* __restrict__ scal, int* __restrict__ flags, int par, V eps,
-                                                                   V stop_after, V tolerance, int min_iter_index, int lpr, int rpp) {
+                                                                   V stop_after, V tolerance, int min_iter_index, int lpr, int rpp,
+                                                                   V* __restrict__ hist, int n_hist) {
     __shared__ V red[kBlock];
     __shared__ V alpha_s[kBlock], beta_s[kBlock];
     __shared__ V normsum[64];
@@ -406,6 +407,12 @@ __global__ __launch_bounds__(kBlock) void cg_direction_beta_kernel(int64_t n, in
             alpha_s[c] = scal[2 * p + c];
             beta_s[c] = beta;
             if (first) {
+                // the coefficients of the first n_hist iterations, for the Lanczos tridiagonal matrices (linear_cg.py:385-406):
+                // hist[it][0][c] = alpha, hist[it][1][c] = beta
+                if (hist != nullptr && flags[2] < n_hist) {
+                    hist[((int64_t)flags[2] * 2 + 0) * p + c] = scal[2 * p + c];
+                    hist[((int64_t)flags[2] * 2 + 1) * p + c] = beta;
+                }
                 scal[(int64_t)(par ^ 1) * p + c] = rr_new;
                 scal[3 * p + c] = beta;
                 V nrm = sqrt(rr_new);                                  // |r|_2 (linear_cg.py:372)
@@ -680,7 +687,8 @@ int tsgu_cg2_residual(int vtype, int64_t n, int64_t p, void* r, const void* Ap, 
 
 int tsgu_cg2_direction(int vtype, int64_t n, int64_t p, const void* r, void* pvec, void* x, const void* rr_partial, int64_t n_partial,
                        void* scal2, int* flags2, int parity, double eps, double stop_updating_after, double tolerance,
-                       int min_iter_index, int device, void* stream) {
+                       int min_iter_index, void* hist, int n_hist, int device, void* stream) {
+    if ((hist != nullptr) != (n_hist > 0)) return TSGU_ERR_BAD_ARG;
     if (n <= 0 || p <= 0 || p > kBlock || !r || !pvec || !x || !rr_partial || n_partial <= 0 || !scal2 || !flags2 || (parity & ~1))
         return TSGU_ERR_BAD_ARG;
     if (n_partial > 1024) return TSGU_ERR_TOO_LARGE;
@@ -695,11 +703,13 @@ int tsgu_cg2_direction(int vtype, int64_t n, int64_t p, const void* r, void* pve
         if (g.vec == 1)                                                                                                    \
             hipLaunchKernelGGL((cg_direction_beta_kernel<V, 1>), dim3((unsigned)g.blocks), dim3(kBlock), 0, s, n, p,       \
                                (const V*)r, (V*)pvec, (V*)x, (const V*)rr_partial, n_partial, (V*)scal2, flags2, parity,   \
-                               (V)eps, (V)stop_updating_after, (V)tolerance, min_iter_index, g.lpr, g.rpp);                \
+                               (V)eps, (V)stop_updating_after, (V)tolerance, min_iter_index, g.lpr, g.rpp, (V*)hist,       \
+                               n_hist);                                                                                    \
         else                                                                                                               \
             hipLaunchKernelGGL((cg_direction_beta_kernel<V, wide>), dim3((unsigned)g.blocks), dim3(kBlock), 0, s, n, p,    \
                                (const V*)r, (V*)pvec, (V*)x, (const V*)rr_partial, n_partial, (V*)scal2, flags2, parity,   \
-                               (V)eps, (V)stop_updating_after, (V)tolerance, min_iter_index, g.lpr, g.rpp);                \
+                               (V)eps, (V)stop_updating_after, (V)tolerance, min_iter_index, g.lpr, g.rpp, (V*)hist,       \
+                               n_hist);                                                                                    \
         return check_launch();                                                                                             \
     }
     TSGU_VSWITCH(vtype, TSGU_BODY, TSGU_BODY);

@@ -137,7 +137,19 @@ def linear_cg(
     t_mat = None
     if n_tridiag:
         t_mat = torch.zeros(n_tridiag_iter, n_tridiag_iter, n_tridiag, dtype=dtype, device=dev)
-    if n_iter > 0:
+    fused_tridiag = None
+    if n_iter > 0 and n_tridiag and preconditioner is None and TWO_LAUNCH and p <= 256 and isinstance(op, SparseOperator) and op.dtype == dtype:
+        # the coefficients of the first n_tridiag_iter iterations are recorded by the fused kernels; the matrices are built afterwards
+        lib = _be.load_library()
+        fused_tridiag = _two_launch_loop(lib, op, rhs_is_zero, result, residual, has_converged, n_iter, max_iter, tolerance, eps,
+                                         stop_updating_after, lambda: torch.cuda.current_stream(dev).cuda_stream,
+                                         n_hist=min(n_tridiag_iter, n_iter), min_iter_floor=min(n_tridiag_iter, max_iter - 1))
+    if fused_tridiag is not None:
+        result, residual_norm, k_done, tolerance_reached, hist = fused_tridiag
+        # (reference: the iteration that meets the stop rule leaves before its own row is written)
+        rows = min(n_tridiag_iter, k_done - 1 if tolerance_reached else k_done)
+        last_tridiag_iter = _tridiag_from_history(hist, n_tridiag, rows, t_mat)
+    elif n_iter > 0:
         if n_tridiag or (preconditioner is not None and not ENABLE_FUSED_PRECOND):
             result, residual_norm, k_done, tolerance_reached, last_tridiag_iter = _pcg_loop(
                 op, preconditioner, rhs_is_zero, result, residual, has_converged, n_iter, max_iter, tolerance, eps,
@@ -252,11 +264,14 @@ def _batched_rhs(matmul_closure, rhs, n_tridiag, tolerance, eps, stop_updating_a
 TWO_LAUNCH = os.environ.get("TSGU_CG_TWO_LAUNCH", "1") != "0"
 
 
-def _two_launch_loop(lib, op, rhs_is_zero, x, r, has_converged, n_iter, max_iter, tolerance, eps, stop_after, stream):
+def _two_launch_loop(lib, op, rhs_is_zero, x, r, has_converged, n_iter, max_iter, tolerance, eps, stop_after, stream, n_hist=0,
+                     min_iter_floor=0):
     """The iterations as K1 (+ p'Ap partials) -> tsgu_cg2_residual -> tsgu_cg2_direction (include/tsgu_hip.h): the state an
     iteration reads sits in the half of its parity, what it produces goes to the other half, so no single-workgroup kernel is
     left between the streaming ones.  Returns None when K1 leaves more partial rows than the kernels sum per workgroup (the
-    caller then runs the four-step form).  Same recurrences, same stop rule (reference :319-382)."""
+    caller then runs the four-step form).  Same recurrences, same stop rule (reference :319-382).  `n_hist` > 0: alpha and beta of
+    the first n_hist iterations are kept ([n_hist][2][p], returned as a fifth value) — what the Lanczos tridiagonal matrices are
+    built from; `min_iter_floor`: no stop before that many iterations (reference :379: not while the matrices are being filled)."""
     n, p = r.shape
     dev, dtype = r.device, r.dtype
     vt = _be.vtype_of(r)
@@ -273,7 +288,9 @@ def _two_launch_loop(lib, op, rhs_is_zero, x, r, has_converged, n_iter, max_iter
     flags[4 : 4 + p] = has_converged.reshape(-1).to(torch.int32)
     flags[4 + 2 * p :] = rhs_is_zero.reshape(-1).to(torch.int32)
     rr_partial = torch.empty((nb, p), dtype=dtype, device=dev)
-    min_iter_index = min(10, max_iter - 1)
+    min_iter_index = max(min(10, max_iter - 1), min_iter_floor)
+    hist = torch.zeros((n_hist, 2, p), dtype=dtype, device=dev) if n_hist > 0 else None
+    hist_addr = hist.data_ptr() if hist is not None else None
     state = {"parity": 0, "first": (Ap, pap)}
 
     flags_addr = flags.data_ptr()
@@ -291,7 +308,7 @@ def _two_launch_loop(lib, op, rhs_is_zero, x, r, has_converged, n_iter, max_iter
                                         flags_addr, par, eps, rr_partial.data_ptr(), dev.index, s), "tsgu_cg2_residual")
         _be.check(lib.tsgu_cg2_direction(vt, n, p, r.data_ptr(), pvec.data_ptr(), x.data_ptr(), rr_partial.data_ptr(), nb,
                                          scal.data_ptr(), flags_addr, par, eps, stop_after, float(tolerance), min_iter_index,
-                                         dev.index, s), "tsgu_cg2_direction")
+                                         hist_addr, n_hist, dev.index, s), "tsgu_cg2_direction")
         state["parity"] = par ^ 1
 
     # The host polls one chunk BEHIND the device: after queueing chunk j it copies the done words to pinned memory (asynchronously,
@@ -331,7 +348,34 @@ def _two_launch_loop(lib, op, rhs_is_zero, x, r, has_converged, n_iter, max_iter
         done = head[0] != 0 or head[1] != 0
     k_done = int(flags[2].item())
     rnorm = scal[4 * p : 5 * p].unsqueeze(0)
+    if n_hist > 0:
+        return x, rnorm, k_done, done, hist
     return x, rnorm, k_done, done
+
+
+def _tridiag_from_history(hist: torch.Tensor, n_tridiag: int, rows: int, t_mat: torch.Tensor) -> int:
+    """Lanczos tridiagonal matrices from the CG coefficients of the first `rows` iterations (reference :385-406, the same
+    arithmetic on the recorded alpha / beta): fills `t_mat` [n_tridiag_iter][n_tridiag_iter][n_tridiag] and returns the last
+    row written.  The reference stops filling once an off-diagonal row falls below 1e-6 in every column — that row included."""
+    if rows <= 0:
+        return 0
+    alpha = hist[:rows, 0, :n_tridiag]
+    beta = hist[:rows, 1, :n_tridiag]
+    ar = torch.where(alpha == 0, torch.ones_like(alpha), alpha).reciprocal()
+    diag = ar.clone()
+    diag[1:] += beta[:-1] * ar[:-1]
+    off = beta[:-1].sqrt() * ar[:-1]                       # off[k-1] = t[k, k-1], k = 1 .. rows-1
+    last = rows - 1
+    if rows > 1:
+        small = (off.amax(dim=1) < 1e-6).nonzero()
+        if small.numel():
+            last = int(small[0]) + 1                        # (the row whose off-diagonal entry is small is still written)
+    k = torch.arange(last + 1, device=hist.device)
+    t_mat[k, k] = diag[: last + 1]
+    if last >= 1:
+        t_mat[k[1:], k[:-1]] = off[:last]
+        t_mat[k[:-1], k[1:]] = off[:last]
+    return last
 
 
 def _fused_loop(op, rhs_is_zero, x, r, has_converged, n_iter, max_iter, tolerance, eps, stop_after, preconditioner=None):
