@@ -199,6 +199,11 @@ typedef struct tsgu_rowpack_plan {
     const void* wcls;
     const void* wbase;
     const void* cne;
+    const void* srcstart;     /* dictionary form with sperm, optional: int32 [rows of the value array's owner] first value position of
+                                 every SOURCE row.  Then a record of sperm is (source row - the workgroup's first source row) << 8 |
+                                 offset inside the row, and wbase[b][2] is the workgroup's first source row: positions relative to
+                                 the source row are the same in translated workgroups even when rows of another length lie between
+                                 them (a mesh with shorter rows at its faces), positions relative to the workgroup's first are not. */
 } tsgu_rowpack_plan;
 
 /* Geometry for (vtype, p): rows per workgroup, entry lanes per pair (> 1: plans need upos), plan limits. */

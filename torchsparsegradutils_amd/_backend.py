@@ -347,7 +347,7 @@ class _RowpackPlanStruct(ctypes.Structure):
 
     _fields_ = [("nblocks", _i64), ("ecap", ctypes.c_int32), ("ucap", ctypes.c_int32), ("nclasses", ctypes.c_int32),
                 ("rows_per_group", ctypes.c_int32)] + [(k, _ptr) for k in ("uptr", "ucol", "upos", "sperm", "order", "vpair", "eptr",
-                                                                     "wcls", "wbase", "cne")]
+                                                                     "wcls", "wbase", "cne", "srcstart")]
 
 
 def _plan_struct(rp):
@@ -355,7 +355,7 @@ def _plan_struct(rp):
     st = rp._cstruct
     if st is None:
         st = _RowpackPlanStruct(rp.nblocks, rp.ecap, rp.ucap, rp.nclasses, rp.group, _p(rp.uptr), _p(rp.ucol), _p(rp.upos), _p(rp.sperm),
-                                _p(rp.order), _p(rp.vpair), _p(rp.eptr), _p(rp.wcls), _p(rp.wbase), _p(rp.cne))
+                                _p(rp.order), _p(rp.vpair), _p(rp.eptr), _p(rp.wcls), _p(rp.wbase), _p(rp.cne), _p(rp.srcstart))
         rp._cstruct = st
     return ctypes.addressof(st)
 

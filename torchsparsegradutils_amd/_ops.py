@@ -279,6 +279,10 @@ def mm_backward(plan: RowGather, values: torch.Tensor, G: torch.Tensor, B: torch
                 return ga.view(values.shape), gb.view(B.shape)
     t = plan.transposed
     rp = _pack_for(t, G, B) if same else None
+    if rp is not None and rp.srcstart is not None and plan.batch is None and plan.perm is None:
+        # the transposed plan reached the dictionary form through row-relative value positions (mesh orderings): the SDDMM on the
+        # stored-order plan + the transposed product beat the fused walk (mesh27_blocked: 124 + 208 us against 417 us)
+        return sddmm(plan, G, B), spmm(t, values, G, owner=plan)
     if rp is not None:
         return _be.csr_mm_backward_rowpack(t.crow, rp, values, G, B, t.n_rows)
     return _be.csr_mm_backward(t, values, G, B, plan.n_rows, plan.n_cols)

@@ -184,7 +184,7 @@ class RowGather:
         main = torch.cuda.current_stream(dev)
         main.wait_event(done)
         if plan is not None:
-            for t in (plan.uptr, plan.ucol, plan.upos, plan.sperm, plan.order, plan.vpair, plan.eptr, plan.wcls, plan.wbase, plan.cne):
+            for t in (plan.uptr, plan.ucol, plan.upos, plan.sperm, plan.order, plan.vpair, plan.eptr, plan.wcls, plan.wbase, plan.cne, plan.srcstart):
                 if t is not None:
                     t.record_stream(main)   # allocated on the side stream, used on the caller's from now on
         with _PENDING_LOCK:
@@ -259,7 +259,7 @@ class RowPackPlan:
       the index streams — a third of the kernels' HBM traffic — become L2-resident."""
 
     __slots__ = ("uptr", "ucol", "upos", "sperm", "order", "vpair", "eptr", "nblocks", "ecap", "ucap", "rpb", "reuse",
-                 "nnz", "lattice", "wcls", "wbase", "cne", "nclasses", "gpb", "group", "_cstruct")
+                 "nnz", "lattice", "wcls", "wbase", "cne", "nclasses", "gpb", "group", "srcstart", "_cstruct")
 
     def __init__(self, uptr, ucol, upos, sperm, ecap, ucap, rpb, reuse, nnz, order=None, vpair=None, eptr=None,
                  nblocks=0, lattice=None, gpb=None):
@@ -270,11 +270,12 @@ class RowPackPlan:
         self.group = 2          # rows per lane group (2 = pairs, 4 = quads)
         self.wcls = self.wbase = self.cne = None
         self.nclasses = 0
+        self.srcstart = None     # dictionary form of a permuted plan: first value position of every source row (see _dedup_classes)
         self._cstruct = None
 
     def plan_bytes(self) -> int:
         return sum(t.numel() * t.element_size() for t in (self.uptr, self.ucol, self.upos, self.sperm, self.order, self.vpair,
-                                                          self.eptr, self.wcls, self.wbase, self.cne) if t is not None)
+                                                          self.eptr, self.wcls, self.wbase, self.cne, self.srcstart) if t is not None)
 
 
 _PACK_MIN_REUSE = 1.2   # stored entries per union entry (2.0 = both rows of every pair share all columns)
@@ -355,6 +356,7 @@ def brick_pair_order(n: int, lattice, gpb: int, device, shape=None):
 DEDUP_MODE = _os.environ.get("TSGU_DEDUP", "auto")   # "auto" | "off" | "force" (tests: small matrices have few workgroups)
 DEDUP_MAX_FRACTION = 0.25    # dictionary form when the classes are at most this fraction of the workgroups ...
 DEDUP_MAX_BYTES = 8 << 20    # ... and the class tables stay cache-sized
+ROW_RELATIVE = _os.environ.get("TSGU_DEDUP_ROW_RELATIVE", "1") == "1"   # permuted plans: value positions relative to the source row
 
 
 def build_rowpack_plan(g: RowGather, rpb: int, limits, pair_order=None, lattice=None, explicit_slots=False, dedup=None,
@@ -437,12 +439,13 @@ def build_rowpack_plan(g: RowGather, rpb: int, limits, pair_order=None, lattice=
     if ucap > max_union or ucap * (8 if slots else 4) + ecap * 4 > lds_budget or (not slots and m >= 2 ** (32 - group)):
         return None
     k = torch.arange(nnz, device=dev, dtype=torch.int64)
-    sperm64 = None
+    sperm64 = srow64 = None
     if g.perm is None:
         slot = k - eptr[blk]                      # natural order: a workgroup's entries are one contiguous range
     else:
         order = torch.argsort(blk * nnz + g.perm.to(torch.int64))
         sperm64 = g.perm[order].to(torch.int64)
+        srow64 = g.col[order].to(torch.int64)      # the source row of every staged value (a permuted plan walks the transposed pattern)
         slot = torch.empty(nnz, dtype=torch.int64, device=dev)
         slot[order] = k - eptr[blk[order]]
     ucol64 = uniq - uslot * m
@@ -462,7 +465,7 @@ def build_rowpack_plan(g: RowGather, rpb: int, limits, pair_order=None, lattice=
     plan.group = group
     mode = DEDUP_MODE if dedup is None else dedup
     if mode != "off" and _dedup_classes(plan, mode == "force", natural, uptr, ub, ucol64, own, word64, sperm64, pair_order,
-                                        eptr, nb, gpb):
+                                        eptr, nb, gpb, srow64, m):
         return plan
     plan.uptr = uptr.to(torch.int32).contiguous()
     plan.ucol = _to_i32(ucol64 | own if own is not None else ucol64)
@@ -490,7 +493,7 @@ def _mix(a: torch.Tensor, b, pos) -> torch.Tensor:
 
 
 def _dedup_classes(plan: RowPackPlan, force: bool, natural: bool, uptr, ub, ucol64, own, word64, sperm64, pair_order, eptr,
-                   nb: int, gpb: int) -> bool:
+                   nb: int, gpb: int, srow64=None, n_src: int = 0) -> bool:
     """Translation-deduplicate the per-workgroup records of a row-pair plan (see RowPackPlan).  Fills the
     class-dictionary fields of `plan` and returns True when the dictionary form is used."""
     dev = uptr.device
@@ -523,8 +526,23 @@ def _dedup_classes(plan: RowPackPlan, force: bool, natural: bool, uptr, ub, ucol
         pos_e = torch.arange(nnz, device=dev) - eptr[wg_e]
         base_perm = torch.zeros(nb, dtype=i64, device=dev)
         has = ne_b > 0
-        base_perm[has] = sperm64[eptr[:-1][has]]   # sorted ascending inside a workgroup: the first is the smallest
-        rel_perm = sperm64 - base_perm[wg_e]
+        srcstart = None
+        if srow64 is not None and ROW_RELATIVE:
+            # Positions relative to the workgroup's first value differ between translated workgroups wherever rows of another length
+            # lie in between (a mesh with truncated rows at its faces: 445 classes for 1000 workgroups).  Relative to the START OF ITS
+            # SOURCE ROW a value's position is translation-invariant: the record is (source row - the workgroup's first source row,
+            # offset inside the row) and the kernel adds the row's first position, which the plan keeps per source row.
+            srcstart = torch.full((n_src,), nnz, dtype=i64, device=dev).scatter_reduce_(0, srow64, sperm64, "amin")
+            off = sperm64 - srcstart[srow64]
+            base_perm[has] = srow64[eptr[:-1][has]]      # (positions ascend inside a workgroup, and so do their rows)
+            rel_row = srow64 - base_perm[wg_e]
+            if int(off.max()) < 256 and int(rel_row.min()) >= 0 and int(rel_row.max()) < (1 << 23):
+                rel_perm = (rel_row << 8) | off
+            else:
+                srcstart = None
+        if srcstart is None:
+            base_perm[has] = sperm64[eptr[:-1][has]]   # sorted ascending inside a workgroup: the first is the smallest
+            rel_perm = sperm64 - base_perm[wg_e]
         h.index_add_(0, wg_e, _mix(rel_perm, pos_e, 3))
     uniq, inv = torch.unique(h, return_inverse=True)
     ncls = uniq.numel()
@@ -565,6 +583,7 @@ def _dedup_classes(plan: RowPackPlan, force: bool, natural: bool, uptr, ub, ucol
         csperm[inv[wg_e[me]], pos_e[me]] = rel_perm[me]
         plan.sperm = csperm.to(torch.int32).reshape(-1).contiguous()
         plan.cne = ne_b[rep].to(torch.int32).contiguous()
+        plan.srcstart = None if srcstart is None else srcstart.clamp_(max=nnz).to(torch.int32).contiguous()
     if not natural:
         plan.vpair = rel_pair[rep].to(torch.int32).reshape(-1).contiguous()
     wbase = torch.stack((base_pair, base_col, base_perm if base_perm is not None else torch.zeros_like(base_pair)), 1)
@@ -603,7 +622,11 @@ def expand_classes(plan: RowPackPlan):
         eptr = torch.zeros(nb + 1, dtype=torch.int64, device=cls.device)
         eptr[1:] = torch.cumsum(ne_b, 0)
         me = torch.arange(plan.ecap, device=cls.device)[None, :] < ne_b[:, None]
-        sperm = (plan.sperm.view(-1, plan.ecap).long()[cls] + wb[:, 2:3])[me]
+        code = plan.sperm.view(-1, plan.ecap).long()[cls]
+        if plan.srcstart is not None:      # (source row relative to the workgroup's first, offset inside the row)
+            sperm = (plan.srcstart.long()[((code >> 8) + wb[:, 2:3]).clamp_(max=plan.srcstart.numel() - 1)] + (code & 0xFF))[me]
+        else:
+            sperm = (code + wb[:, 2:3])[me]
     if plan.vpair is not None:
         rel = plan.vpair.view(-1, gpb).long()[cls]
         vpair = torch.where(rel >= 0, rel + wb[:, 0:1], rel).reshape(-1)

@@ -34,6 +34,8 @@ int fill(RpParams& P, int64_t n_rows, int64_t n_src, int64_t nnz, int64_t p, con
     P.ecap = pl->ecap;
     P.ucap = pl->ucap;
     P.rgroup = pl->rows_per_group;
+    P.srcstart = static_cast<const int*>(pl->srcstart);
+    if (pl->srcstart && (!pl->wcls || !pl->sperm)) return TSGU_ERR_BAD_ARG;
     return TSGU_OK;
 }
 

@@ -42,6 +42,8 @@ struct RpParams {
     const int* wcls;        // dictionary form: [nblocks] class of each workgroup (null = stream form)
     const int* wbase;       // dictionary form: [nblocks][3] = {base pair, base column, base value position}
     const int* cne;         // dictionary form, permuted plans: [nclasses] stored entries per workgroup of the class
+    const int* srcstart;    // dictionary form, permuted plans, optional: first value position of every source row — sperm records are
+                            // then (source row - wbase[b][2]) << 8 | offset inside the row
     const void* val;
     const void* S;          // gathered dense operand (B for SpMM, G for the backward)
     int64_t lds_;
@@ -183,7 +185,14 @@ __global__ __launch_bounds__(kBlock) TSGU_RP_OCC void csr_rowpack_kernel(const R
             qv[q] = 0;
             if (q * kBlock < ne) {
                 // dictionary tables are shared by many workgroups: keep them cacheable; streams are single-use
-                if (t < ne) qv[q] = (dict ? sp[t] : stream_load(sp + t)) + permbase;
+                if (t < ne) {
+                    if (dict && P.srcstart) {
+                        const int w = sp[t];
+                        qv[q] = P.srcstart[permbase + (w >> 8)] + (w & 0xff);
+                    } else {
+                        qv[q] = (dict ? sp[t] : stream_load(sp + t)) + permbase;
+                    }
+                }
             }
         }
     }
