@@ -260,3 +260,31 @@ def test_plan_cache_is_released_with_the_sparse_tensor():
     del C, idx, g1, g2
     gc.collect()
     assert P.cache_stats()[0] == 0
+
+
+def test_transposed_plan_of_a_mesh_reaches_the_dictionary_form():
+    """A permuted plan (the transposed pattern) of a mesh whose rows at the faces are shorter: relative to the workgroup's first
+    value position translated workgroups differ, relative to the SOURCE ROW of every value they do not (`srcstart`).  The
+    dictionary form is then taken without being forced, has a few dozen classes, and expands to exactly the stream form."""
+    crow, col = synthetic.mesh27_blocked(24, 20, 16, 4, torch.int32, "cpu")
+    n = crow.numel() - 1
+    t = P.RowGather(crow, col, n, n).transposed
+    limits = (2048, 3072, 64 * 1024)
+    stream = P.build_rowpack_plan(t, 64, limits, dedup="off")
+    d = P.build_rowpack_plan(t, 64, limits, dedup="auto")
+    assert stream is not None and stream.nclasses == 0 and stream.srcstart is None
+    assert d is not None and 0 < d.nclasses <= 64 and d.srcstart is not None and d.srcstart.shape == (n,)
+    # first value position of every source row = A's row pointer
+    assert torch.equal(d.srcstart.long(), crow.long()[:-1])
+    uptr, ucol, upos, sperm, vpair, eptr = P.expand_classes(d)
+    assert torch.equal(uptr, stream.uptr.long()) and torch.equal(ucol & 0xFFFFFFFF, stream.ucol.long() & 0xFFFFFFFF)
+    assert torch.equal(upos, stream.upos.long() & 0xFFFFFFFF) and torch.equal(sperm, stream.sperm.long())
+    assert d.plan_bytes() < stream.plan_bytes() // 2          # (120 workgroups here; 4.9 MB against 246 MB at N = 1e6)
+    # with positions relative to the workgroup's first value the same mesh needs many more classes
+    keep = P.ROW_RELATIVE
+    try:
+        P.ROW_RELATIVE = False
+        old = P.build_rowpack_plan(t, 64, limits, dedup="force")
+    finally:
+        P.ROW_RELATIVE = keep
+    assert old.srcstart is None and old.nclasses > 2 * d.nclasses
