@@ -69,6 +69,8 @@ try:
     from . import _tsgu_host as _host       # built by csrc/Makefile next to this file
 except ImportError:                          # (the Python path below is complete by itself; the kernels are the same)
     _host = None
+if os.environ.get("TSGU_LIB_PATH"):          # another build of the kernels is loaded (A/B experiments): _tsgu_host.so is linked against
+    _host = None                             # csrc/libtsgu_hip.so and would launch THAT build's kernels
 
 
 def _step_key(dtype, p: int):
