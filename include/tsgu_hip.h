@@ -292,10 +292,11 @@ int tsgu_csr_spmm_lattice(int vtype, const tsgu_lattice_plan* plan, int64_t n_ro
  * workgroups of the configuration, nb·nseg·⌈ny/ty⌉·⌈nz/tz⌉; one chunk per lane.  This entry also takes 16-byte dense rows
  * (p = 4: one lane per row) — replaces tsgu_csr_spmm(..., dot_w = B, ...) inside utils/linear_cg.py:322 + :64-65 on lattice
  * stencils, without reading a column index.  `skip` (optional, device memory): when *skip != 0 the launch does nothing — the
- * done word of a solver loop whose iterations are queued ahead of the host's polls. */
+ * done word of a solver loop whose iterations are queued ahead of the host's polls.  `dot_w` (optional): a second operand W [rows][p] with
+ * C's leading dimension — the partial sums are then of C[row, c]·W[row, c] (BiCGSTAB's <r0, A q>, reference utils/bicgstab.py:196-199). */
 int tsgu_csr_spmm_lattice_dot(int vtype, const tsgu_lattice_plan* plan, int64_t n_rows, int64_t nnz, const void* val,
                               const void* B, int64_t ldb, void* C, int64_t ldc, int64_t p, void* dot_partial, int64_t dot_rows,
-                              const int* skip, int device, void* stream);
+                              const int* skip, const void* dot_w, int device, void* stream);
 /* out_vals[k] = alpha·<R[row k,:], Cm[col k,:]> in stored order (plan kind 0). */
 int tsgu_csr_sddmm_lattice(int vtype, const tsgu_lattice_plan* plan, int64_t n_rows, int64_t nnz, const void* R, int64_t ldr,
                            const void* Cm, int64_t ldc, void* out_vals, double alpha, int64_t p, int device, void* stream);

@@ -500,6 +500,14 @@ def _dot_epilogue_case(periodic, points, dims, p, dt):
         assert float(((part0.double().sum(0) - want).abs() / scale).max()) < tol
         C2, part2 = be.csr_spmm_lattice(lp, cfg, val, v, dot=True)
         assert torch.equal(part, part2) and torch.equal(C, C2)
+        # a second operand (BiCGSTAB's <r0, A q>, reference utils/bicgstab.py:196-199) read from memory, the product written in place
+        w = torch.randn(n, p, generator=torch.Generator().manual_seed(3), dtype=dt).to(dev)
+        outbuf = torch.full((n, p), float("nan"), dtype=dt, device=dev)
+        Cw, partw = be.csr_spmm_lattice(lp, cfg, val, v, dot=True, dot_w=w, out=outbuf)
+        assert Cw.data_ptr() == outbuf.data_ptr() and torch.equal(Cw, C)
+        wantw = (C0.double() * w.double()).sum(0)
+        scalew = (C0.double().abs() * w.double().abs()).sum(0)
+        assert float(((partw.double().sum(0) - wantw).abs() / scalew).max()) < tol, cs
     lp._cfg.clear()
     # not offered where it does not exist: bf16, the transposed walk
     if dt != torch.float32:

@@ -85,7 +85,7 @@ SIGNATURES = {
         _int, [_int, _int, _i64, _i64, _i64, _ptr, _ptr, _ptr, _i64, _ptr, _i64, _ptr, _dbl, _i64, _int, _ptr]),
     "tsgu_lattice_lds_bytes": (_int, [_int, _int, _i64, _int, _int, _int, _int, _int, _int, _int, _int, _int]),
     "tsgu_csr_spmm_lattice": (_int, [_int, _ptr, _i64, _i64, _ptr, _ptr, _i64, _ptr, _i64, _i64, _int, _ptr]),
-    "tsgu_csr_spmm_lattice_dot": (_int, [_int, _ptr, _i64, _i64, _ptr, _ptr, _i64, _ptr, _i64, _i64, _ptr, _i64, _ptr, _int, _ptr]),
+    "tsgu_csr_spmm_lattice_dot": (_int, [_int, _ptr, _i64, _i64, _ptr, _ptr, _i64, _ptr, _i64, _i64, _ptr, _i64, _ptr, _ptr, _int, _ptr]),
     "tsgu_csr_sddmm_lattice": (_int, [_int, _ptr, _i64, _i64, _ptr, _i64, _ptr, _i64, _ptr, _dbl, _i64, _int, _ptr]),
     "tsgu_march_supported": (_int, [_int, _int, _int, _int]),
     "tsgu_march_lds_bytes": (_int, [_int, _int, _i64, _int, _int, _int, _int, _int, _int]),
@@ -557,11 +557,12 @@ def _raw_stream(dev: torch.device) -> int:
     return torch._C._cuda_getCurrentRawStream(dev.index)
 
 
-def csr_spmm_lattice(lp, cfg, val, B, dot: bool = False, skip: int = 0):
+def csr_spmm_lattice(lp, cfg, val, B, dot: bool = False, skip: int = 0, dot_w=None, out=None):
     """C = A·B (plan kind 0) or Aᵀ·B for the transposed plan (kind 1; `val` in A's own order) by the plane sweep / plane march.
     `dot` (plane sweep, fp32, stored order): also the per-workgroup partial sums of <C[row], B[row]> per column — returns
     (C, partial [workgroups][p]), the Krylov loops' fused dot epilogue; `skip` (with `dot`): address of a device int32 — the launch
-    does nothing when it is non-zero (iterations queued past the end of a solve)."""
+    does nothing when it is non-zero (iterations queued past the end of a solve); `dot_w` (with `dot`): the partial sums are of
+    <C[row], dot_w[row]> instead; `out` (with `dot`): a contiguous (n_rows, p) tensor that receives C."""
     lib = _lib or load_library()
     dev = B.device
     if not B.is_cuda or val.device != dev:
@@ -571,7 +572,8 @@ def csr_spmm_lattice(lp, cfg, val, B, dot: bool = False, skip: int = 0):
         B = rowmajor(B)
     p = B.size(-1)
     n_rows = lp.n_rows
-    out = torch.empty((n_rows, p), dtype=B.dtype, device=dev)
+    if out is None or not dot:
+        out = torch.empty((n_rows, p), dtype=B.dtype, device=dev)
     if not val.is_contiguous():
         val = val.contiguous()
     march = getattr(cfg, "march", False)
@@ -583,8 +585,8 @@ def csr_spmm_lattice(lp, cfg, val, B, dot: bool = False, skip: int = 0):
         partial = torch.empty((nwg, p), dtype=B.dtype, device=dev)
         with _on_device(dev):
             rc = lib.tsgu_csr_spmm_lattice_dot(_VTYPE[val.dtype], cfg.struct_addr, n_rows, lp.nnz, val.data_ptr(), B.data_ptr(), _ld(B),
-                                               out.data_ptr(), p, p, partial.data_ptr(), nwg, skip or None, dev.index,
-                                               _raw_stream(dev))
+                                               out.data_ptr(), p, p, partial.data_ptr(), nwg, skip or None,
+                                               None if dot_w is None else dot_w.data_ptr(), dev.index, _raw_stream(dev))
         if rc:
             check(rc, "tsgu_csr_spmm_lattice_dot")
         return out, partial

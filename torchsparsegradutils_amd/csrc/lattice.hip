@@ -85,7 +85,8 @@ int tsgu_lattice_lds_bytes(int mode, int vtype, int64_t p, int ty, int tz, int r
 }
 
 static int spmm_lattice(int vtype, const tsgu_lattice_plan* plan, int64_t n_rows, int64_t nnz, const void* val, const void* B, int64_t ldb,
-                        void* C, int64_t ldc, int64_t p, void* dot_partial, int64_t dot_rows, const int* skip, int device, void* stream) {
+                        void* C, int64_t ldc, int64_t p, void* dot_partial, int64_t dot_rows, const int* skip, const void* dot_w, int device,
+                        void* stream) {
     LatParams P{};
     int cl = 0;
     const int mode = plan && plan->kind != 0 ? kLatSpmmT : kLatSpmm;
@@ -105,19 +106,21 @@ static int spmm_lattice(int vtype, const tsgu_lattice_plan* plan, int64_t n_rows
     P.ldo = ldc;
     P.dot_partial = dot_partial;
     P.skip = skip;
+    P.dot_w = dot_w;
+    if (dot_w && (!dot_partial || !aligned16(dot_w))) return TSGU_ERR_BAD_ARG;
     return dispatch(vtype, mode, cl, plan->threads, P, stream);
 }
 
 int tsgu_csr_spmm_lattice(int vtype, const tsgu_lattice_plan* plan, int64_t n_rows, int64_t nnz, const void* val, const void* B,
                           int64_t ldb, void* C, int64_t ldc, int64_t p, int device, void* stream) {
-    return spmm_lattice(vtype, plan, n_rows, nnz, val, B, ldb, C, ldc, p, nullptr, 0, nullptr, device, stream);
+    return spmm_lattice(vtype, plan, n_rows, nnz, val, B, ldb, C, ldc, p, nullptr, 0, nullptr, nullptr, device, stream);
 }
 
 int tsgu_csr_spmm_lattice_dot(int vtype, const tsgu_lattice_plan* plan, int64_t n_rows, int64_t nnz, const void* val, const void* B,
                               int64_t ldb, void* C, int64_t ldc, int64_t p, void* dot_partial, int64_t dot_rows, const int* skip,
-                              int device, void* stream) {
+                              const void* dot_w, int device, void* stream) {
     if (!dot_partial) return TSGU_ERR_BAD_ARG;
-    return spmm_lattice(vtype, plan, n_rows, nnz, val, B, ldb, C, ldc, p, dot_partial, dot_rows, skip, device, stream);
+    return spmm_lattice(vtype, plan, n_rows, nnz, val, B, ldb, C, ldc, p, dot_partial, dot_rows, skip, dot_w, device, stream);
 }
 
 int tsgu_csr_sddmm_lattice(int vtype, const tsgu_lattice_plan* plan, int64_t n_rows, int64_t nnz, const void* R, int64_t ldr,

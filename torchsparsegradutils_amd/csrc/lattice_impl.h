@@ -78,6 +78,7 @@ struct LatParams {
     float alpha;
     void* dot_partial;       // SpMM, fp32 / fp64: [workgroups][p] partial sums of <out[row,:], S[row,:]> per column (Krylov loops), or null
     const int* skip;         // when given and *skip != 0 the launch does nothing (a solver loop that has finished on the device)
+    const void* dot_w;       // dot epilogue: the second operand W [rows][p] with the leading dimension of `out` (null: the gathered operand itself)
     int64_t nblocks;
     // LDS layout (bytes from the start of the dynamic region; filled by lat_layout)
     int o_vals, o_zero, o_tab, o_len, o_map, lds_bytes;
@@ -720,7 +721,11 @@ __global__ __launch_bounds__(NT, 4) void lattice_kernel(const LatParams P) {   /
                             if (want_dot) {
 #pragma unroll
                                 for (int cp = 0; cp < CPL; ++cp) {
-                                    const uint4 wr = *reinterpret_cast<const uint4*>(sm + ph * PB + cen[q][cp]);
+                                    // <C[row,:], W[row,:]>: W = the gathered operand (its own row is the centre of the halo plane in LDS) or a
+                                    // second operand read from memory (BiCGSTAB's <r0, A q>)
+                                    const uint4 wr = P.dot_w == nullptr
+                                                         ? *reinterpret_cast<const uint4*>(sm + ph * PB + cen[q][cp])
+                                                         : *reinterpret_cast<const uint4*>(static_cast<const char*>(P.dot_w) + (int64_t)prow_prev * ldob + coo[q][cp]);
                                     A f[VEC];
                                     widen(wr, f);
 #pragma unroll

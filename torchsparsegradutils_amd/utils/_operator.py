@@ -56,11 +56,15 @@ class SparseOperator:
         (the plane sweep) do nothing when it is non-zero — a hint, the result is then unspecified."""
         p = self.plan
         v = self._cast(v)
-        if w is None and out is None and v.dtype in (torch.float32, torch.float64) and self.values.dtype == v.dtype and v.dim() == 2:
-            # stencil on a lattice: the plane sweep needs no column indices, and the own row of v is already in LDS for the dot
-            got = _ops._lattice_cfg(p, _be.LAT_SPMM, v) if p.perm is None and p.batch is None else None
+        if v.dtype in (torch.float32, torch.float64) and self.values.dtype == v.dtype and v.dim() == 2:
+            # stencil on a lattice: the plane sweep needs no column indices, and the own row of v is already in LDS for the dot (a second
+            # operand w is read from memory; `out` receives the product in place)
+            plain = ((w is None or (w.shape == v.shape and w.dtype == v.dtype and w.is_contiguous() and w.data_ptr() % 16 == 0))
+                     and (out is None or (out.shape == (p.n_rows, v.size(-1)) and out.dtype == v.dtype and out.is_contiguous()
+                                          and out.data_ptr() % 16 == 0 and out.data_ptr() != v.data_ptr())))
+            got = _ops._lattice_cfg(p, _be.LAT_SPMM, v) if plain and p.perm is None and p.batch is None else None
             if got is not None and not getattr(got[1], "march", False) and got[1].cpl == 1:
-                return _be.csr_spmm_lattice(got[0], got[1], self.values, v, dot=True, skip=skip)
+                return _be.csr_spmm_lattice(got[0], got[1], self.values, v, dot=True, skip=skip, dot_w=w, out=out)
         return _be.csr_spmm(p.crow, p.col, self.values, v, p.n_rows, p.n_cols, perm=p.perm, out=out,
                             dot_w=v if w is None else w, max_row_nnz=p.max_row_nnz)
 
