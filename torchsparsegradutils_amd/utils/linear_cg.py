@@ -264,6 +264,25 @@ def _batched_rhs(matmul_closure, rhs, n_tridiag, tolerance, eps, stop_updating_a
 TWO_LAUNCH = os.environ.get("TSGU_CG_TWO_LAUNCH", "1") != "0"
 
 
+class _PollCache(threading.local):
+    bufs = None
+
+
+_POLL_CACHE = _PollCache()
+
+
+def _poll_buffers(dev):
+    """Two (pinned int32[2], event) pairs per thread and device for the host's polls (allocating pinned memory costs more than a
+    short solve's iterations)."""
+    if _POLL_CACHE.bufs is None:
+        _POLL_CACHE.bufs = {}
+    got = _POLL_CACHE.bufs.get(dev)
+    if got is None:
+        with torch.cuda.device(dev):
+            got = _POLL_CACHE.bufs[dev] = [(torch.empty(2, dtype=torch.int32, pin_memory=True), torch.cuda.Event()) for _ in range(2)]
+    return got
+
+
 def _two_launch_loop(lib, op, rhs_is_zero, x, r, has_converged, n_iter, max_iter, tolerance, eps, stop_after, stream, n_hist=0,
                      min_iter_floor=0):
     """The iterations as K1 (+ p'Ap partials) -> tsgu_cg2_residual -> tsgu_cg2_direction (include/tsgu_hip.h): the state an
@@ -319,7 +338,7 @@ def _two_launch_loop(lib, op, rhs_is_zero, x, r, has_converged, n_iter, max_iter
     k = 0
     graph = None
     try_graph = _graph.enabled()
-    polls = [(torch.empty(2, dtype=torch.int32, pin_memory=True), torch.cuda.Event()) for _ in range(2)]
+    polls = _poll_buffers(dev)
     pending = None
     which = 0
     with torch.cuda.device(dev):
