@@ -766,7 +766,7 @@ def main():
             if rank == 0:
                 note = {"error": f"not finished within {LEGS_TIMEOUT_S} s (a collective of the secondary legs stalled?)"}
                 print(json.dumps(make_line(None, note, None, None)), flush=True)
-            os._exit(0)
+            os._exit(3)         # a stalled run is not a success: the line is printed, the exit code says what happened
 
         watchdog = threading.Timer(LEGS_TIMEOUT_S, bail)
         watchdog.daemon = True

@@ -1,0 +1,112 @@
+"""Round-5 parity additions (GPU, through the public API / C ABI).
+
+* the C++ host path of the step with a STRIDED value tensor (a column of a 2-D parameter): same bits as the Python path;
+* `linalg_solve_triangular_compat`'s sparse branch refuses operands whose shapes do not fit (the sweep takes raw pointers);
+* further sections are added next to the features they pin (see the section comments).
+"""
+
+import numpy as np
+import pytest
+import torch
+
+import _golden as G
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+EPS32 = 2.0 ** -23
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    from torchsparsegradutils_amd import _backend
+
+    _backend.load_library()
+    yield
+
+
+def tsgu():
+    import torchsparsegradutils_amd as m
+
+    return m
+
+
+# ---- the step's C++ host path and strided values -------------------------------------------------------------------------------
+
+
+@pytest.mark.parametrize("pattern", ["periodic27", "random"])
+def test_cpp_host_path_takes_strided_values(pattern):
+    """`torch.sparse_csr_tensor` keeps a strided value view as given.  The Python path makes it contiguous per call; the C++ path
+    (csrc/host/step.cpp) handed the raw pointer to the kernels: once the step plan had settled the results were those of other
+    values.  Runs long enough to reach the C++ path and compares with the contiguous copy, bit for bit."""
+    import torchsparsegradutils_amd.sparse_matmul as sm
+    from torchsparsegradutils_amd import _lattice, _ops, _pattern, sparse_mm, wait_for_plans
+    from torchsparsegradutils_amd.utils import synthetic
+
+    assert sm._host is not None, "torchsparsegradutils_amd/_tsgu_host.so was not built (make -C torchsparsegradutils_amd/csrc)"
+    if pattern == "periodic27":
+        crow, col = synthetic.stencil27_periodic(12, 10, 16, torch.int32, device=DEV)
+    else:
+        gi = torch.Generator().manual_seed(3)
+        flat = torch.randperm(1200 * 1200, generator=gi)[:24000].sort().values
+        rows_, col = (flat // 1200).to(DEV), (flat % 1200).to(DEV).to(torch.int32)
+        crow = torch.zeros(1201, dtype=torch.int64, device=DEV)
+        crow[1:] = torch.cumsum(torch.bincount(rows_, minlength=1200), 0)
+        crow = crow.to(torch.int32)
+    n, nnz, p = crow.numel() - 1, col.numel(), 32
+    g = torch.Generator(device=DEV).manual_seed(11)
+    param = torch.randn(nnz, 2, device=DEV, generator=g)
+    strided = param[:, 0]
+    assert not strided.is_contiguous()
+    B0 = torch.randn(n, p, device=DEV, generator=g)
+    Gd = torch.randn(n, p, device=DEV, generator=g)
+    keep = (sm.FAST_STEP, _lattice.TUNE, _ops.PACK_MIN_NNZ)
+    _pattern.clear_cache()
+    try:
+        _lattice.TUNE = False
+        _ops.PACK_MIN_NNZ = 1
+
+        def run(values):
+            A = torch.sparse_csr_tensor(crow, col, values, (n, n)).requires_grad_(True)
+            B = B0.clone().requires_grad_(True)
+            C = sparse_mm(A, B)
+            gA, gB = torch.autograd.grad(C, (A, B), Gd)
+            return C, gA.values(), gB, type(C.grad_fn).__name__
+
+        sm.FAST_STEP = False
+        ref = run(strided.contiguous())
+        sm.FAST_STEP = True
+        for _ in range(8):
+            got = run(strided)
+            wait_for_plans()
+        assert got[3] != "SparseMatMulBackward", "the C++ host path was not reached"
+        for a, b, what in zip(got[:3], ref[:3], ("C", "gradA", "gradB")):
+            assert torch.equal(a, b), what
+    finally:
+        sm.FAST_STEP, _lattice.TUNE, _ops.PACK_MIN_NNZ = keep
+
+
+# ---- linalg_solve_triangular_compat: shapes ------------------------------------------------------------------------------------
+
+
+def test_compat_sparse_branch_validates_shapes():
+    """The legacy op behind reference _compat.py:42-48 checks its operands; the sweep reads raw pointers, so the sparse branch has
+    to refuse what does not fit before anything is launched (a short right-hand side was read past its end)."""
+    m = tsgu()
+    n = 64
+    idx = torch.arange(n, device=DEV)
+    A = torch.sparse_coo_tensor(torch.stack((idx, idx)), torch.full((n,), 2.0, device=DEV), (n, n)).coalesce().to_sparse_csr()
+    good = m.linalg_solve_triangular_compat(A, torch.ones(n, 3, device=DEV), upper=False)
+    assert torch.allclose(good, torch.full((n, 3), 0.5, device=DEV))
+    with pytest.raises(ValueError, match="Incompatible inner dimensions"):
+        m.linalg_solve_triangular_compat(A, torch.ones(n - 8, 3, device=DEV), upper=False)
+    with pytest.raises(ValueError, match="both be 2D or both be 3D"):
+        m.linalg_solve_triangular_compat(A, torch.ones(2, n, 3, device=DEV), upper=False)
+    rect = torch.sparse_coo_tensor(torch.stack((idx, idx)), torch.ones(n, device=DEV), (n, n + 1)).coalesce()
+    with pytest.raises(ValueError, match="square"):
+        m.linalg_solve_triangular_compat(rect, torch.ones(n, 3, device=DEV), upper=False)
+    from torchsparsegradutils_amd import _backend as be
+
+    with pytest.raises(RuntimeError, match="right-hand side"):
+        be.csr_sptrsm(A.crow_indices(), A.col_indices(), A.values(), torch.ones(n - 1, 3, device=DEV), n, lower=True, unit=False)

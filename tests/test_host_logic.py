@@ -125,23 +125,24 @@ def test_validation_messages_match_reference():
             fn()
         assert type(e.value).__name__ == want["type"], name
         assert str(e.value) == want["msg"], name
-    # dtype mismatch only warns (then the GPU-only product refuses the CPU operands)
+    # dtype mismatch only warns (reference sparse_solve.py:398-403); the solver's own product then raises torch's dtype error
     with pytest.warns(UserWarning) as w:
-        with pytest.raises(RuntimeError, match="no CPU path"):
+        with pytest.raises(RuntimeError, match="expected scalar type Float but found Double"):
             m.sparse_generic_solve(A, B.double())
     assert E["gs_dtype_warning"]["warnings"] == [str(w[0].message)]
 
 
-def test_cpu_tensors_are_refused_not_silently_computed():
-    import torchsparsegradutils_amd as m
-    from torchsparsegradutils_amd.utils import bicgstab, linear_cg, minres
+def test_cpu_solvers_run_on_tensor_ops():
+    """CPU operands of the Krylov entry points: the recurrences as tensor ops around the ATen product (the fused step kernels are
+    the MI355X path and are never entered with a CPU tensor)."""
+    from torchsparsegradutils_amd.utils import BICGSTABSettings, LinearCGSettings, MINRESSettings, bicgstab, linear_cg, minres
 
-    A = torch.eye(3).to_sparse_csr()
+    A = (2 * torch.eye(3)).to_sparse_csr()
     B = torch.ones(3, 2)
-    for fn in (lambda: m.sparse_mm(A, B), lambda: m.sparse_triangular_solve(A, B), lambda: linear_cg(A, B),
-               lambda: bicgstab(A, B), lambda: minres(A, B)):
-        with pytest.raises(RuntimeError, match="no CPU path"):
-            fn()
+    for fn in (lambda: linear_cg(A, B, settings=LinearCGSettings(cg_tolerance=1e-6)),
+               lambda: bicgstab(A, B, settings=BICGSTABSettings()), lambda: minres(A, B, settings=MINRESSettings())):
+        x = fn()
+        assert not x.is_cuda and torch.allclose(x, torch.full((3, 2), 0.5))
 
 
 def test_abi_library_exports_every_declared_symbol():
@@ -228,27 +229,30 @@ def test_ctypes_signatures_agree_with_the_header_prototypes():
     assert seen == set(_backend.SIGNATURES)
 
 
-def test_cpu_tensors_raise_the_documented_error():
-    """INTEGRATION.md, "CPU tensors": the package is the MI355X path and nothing else — operands on the CPU are refused with ONE
-    documented message by every entry point (never computed on a fallback; tests/test_host_logic.py::
-    test_product_never_imports_the_oracle keeps the oracle out of the package)."""
+def test_cpu_tensors_take_the_torch_op_path_and_mixed_devices_raise():
+    """INTEGRATION.md, "CPU tensors": operands that live on the CPU are computed by the package's torch-op path (_cpu.py: the ATen
+    calls the reference makes; tests/test_cpu_path.py pins it to the reference's golden vectors).  The switch is the operands'
+    device only: the HIP bindings themselves refuse a CPU tensor, so nothing computed for a GPU caller can come from the CPU
+    (test_product_never_imports_the_oracle keeps the oracle out of the package)."""
     import warnings
 
     import torchsparsegradutils_amd as m
+    from torchsparsegradutils_amd import _backend
 
-    A = torch.eye(4).to_sparse_csr()
+    A = (2 * torch.eye(4)).to_sparse_csr()
     B = torch.ones(4, 2)
-    msg = "torchsparsegradutils_amd runs on AMD MI355X (gfx950) only: got a tensor on 'cpu'. There is no CPU path; move the operands to the GPU."
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         for call in (lambda: m.sparse_mm(A, B),
-                     lambda: m.sparse_mm(torch.eye(4).to_sparse_coo(), B),
-                     lambda: m.sparse_triangular_solve(A, B, upper=False),
-                     lambda: m.sparse_generic_solve(A, B),
-                     lambda: m.linalg_solve_triangular_compat(A, B, upper=False)):
-            with pytest.raises(RuntimeError) as e:
-                call()
-            assert str(e.value) == msg
+                     lambda: m.sparse_mm((2 * torch.eye(4)).to_sparse_coo(), B),
+                     lambda: 4 * m.sparse_triangular_solve(A, B, upper=False),
+                     lambda: 4 * m.sparse_generic_solve(A, B, solve=m.utils.linear_cg),
+                     lambda: 4 * m.linalg_solve_triangular_compat(A, B, upper=False)):
+            out = call()
+            assert not out.is_cuda and torch.allclose(out, torch.full((4, 2), 2.0))
+    for fn in (_backend.csr_spmm, _backend.csr_sddmm):
+        with pytest.raises(RuntimeError, match="gfx950 kernels"):
+            fn(A.crow_indices(), A.col_indices(), A.values() if fn is _backend.csr_spmm else B, B, 4, 4)
 
 
 def test_compat_dense_branch_is_the_reference_dispatch():

@@ -171,6 +171,20 @@ def itype_of(t: torch.Tensor) -> int:
         raise RuntimeError(f"torchsparsegradutils_amd: unsupported index dtype {t.dtype}") from None
 
 
+def operand_device(*tensors: torch.Tensor) -> torch.device:
+    """The one device all operands of a call live on (CPU included: CPU operands are computed by the torch-op path, _cpu.py;
+    the HIP bindings below still refuse them through `require_device`)."""
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError(f"all operands must be on the same device, got {dev} and {t.device}")
+    return dev
+
+
 def require_device(*tensors: torch.Tensor) -> torch.device:
     dev = None
     for t in tensors:
@@ -178,8 +192,8 @@ def require_device(*tensors: torch.Tensor) -> torch.device:
             continue
         if not t.is_cuda:
             raise RuntimeError(
-                "torchsparsegradutils_amd runs on AMD MI355X (gfx950) only: got a tensor on "
-                f"'{t.device}'. There is no CPU path; move the operands to the GPU."
+                f"the gfx950 kernels of torchsparsegradutils_amd were handed a tensor on '{t.device}': CPU operands are served by "
+                "the torch-op path (_cpu.py) only when ALL operands of a call live on the CPU"
             )
         if dev is None:
             dev = t.device
@@ -694,6 +708,11 @@ def _tiled_ok(*dense) -> bool:
 
 
 def coo_sddmm(row, col, G, B, alpha: float = 1.0):
+    if not G.is_cuda and operand_device(row, col, G, B) is not None:
+        from . import _cpu
+
+        out = _cpu.coo_sddmm(row, col, G, B)
+        return out if alpha == 1.0 else out.mul_(alpha)
     lib = load_library()
     dev = require_device(row, col, G, B)
     if G.dtype != B.dtype:
@@ -719,6 +738,9 @@ def csr_sptrsm(ptr, idx, val, B, n: int, lower: bool, unit: bool, perm=None):
     dev = require_device(ptr, idx, val, B, perm)
     if val.dtype != B.dtype:
         raise RuntimeError(f"expected A and B to have the same dtype, got {val.dtype} and {B.dtype}")
+    if B.dim() != 2 or B.size(0) != n or ptr.numel() != n + 1:
+        raise RuntimeError(f"tsgu_csr_sptrsm: a system of {n} rows needs a right-hand side of {n} rows and a row pointer of {n + 1} "
+                           f"words, got {tuple(B.shape)} and {ptr.numel()}")
     B, ldb, b_cs = strided2d(B)
     p = B.size(-1)
     ptr, idx, val = ptr.contiguous(), idx.contiguous(), val.contiguous()
@@ -808,6 +830,10 @@ def poll_errors(block: bool = False) -> None:
 
 def coldot(X, Y):
     """Column-wise dot products of two (n, p) arrays -> (p,) tensor (deterministic)."""
+    if not X.is_cuda and not Y.is_cuda:
+        from . import _cpu
+
+        return _cpu.coldot(X, Y)
     lib = load_library()
     dev = require_device(X, Y)
     if X.dtype != Y.dtype:

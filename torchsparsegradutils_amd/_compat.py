@@ -28,13 +28,23 @@ def linalg_solve_triangular_compat(
             upper = not upper
         return torch.linalg.solve_triangular(A, B, upper=upper, unitriangular=unitriangular)
 
-    from . import _backend as _be
     from .sparse_solve import _solve, _TriOperand
 
     if A.layout not in (torch.sparse_coo, torch.sparse_csr):
         raise ValueError("A should be in either COO or CSR sparse format")
+    # the legacy op checks its operands' shapes itself (reference _compat.py:42-48 hands them to torch.triangular_solve); the sweep
+    # takes raw pointers, so the same conditions are checked here, in sparse_triangular_solve's words (sparse_solve.py:131-146)
+    if A.dim() not in (2, 3) or A.dim() != B.dim():
+        raise ValueError("A and B must both be 2D or both be 3D tensors")
+    if B.layout != torch.strided:
+        raise ValueError("B must be a dense (strided) tensor")
+    if A.shape[-2] != A.shape[-1]:
+        raise ValueError("A must be square on its last two dimensions")
+    if A.size(-1) != B.size(-2):
+        raise ValueError(f"Incompatible inner dimensions: A[..., {A.size(-2)}] vs B[..., {B.size(-2)}]")
+    if A.dim() == 3 and A.size(0) != B.size(0):
+        raise ValueError("If batched, A and B must have the same batch size")
     A, B = A.detach(), B.detach()
-    _be.require_device(B)
     if A.device != B.device:
         raise RuntimeError(f"A and B must be on the same device, got {A.device} and {B.device}")
     op = _TriOperand(A)

@@ -14,6 +14,7 @@ import os
 import torch
 
 from . import _backend as _be
+from . import _cpu
 from . import _lattice as _lt
 from . import _pattern as _pt
 from ._pattern import RowGather
@@ -264,6 +265,8 @@ def _lattice_backward(plan: RowGather, values: torch.Tensor, G: torch.Tensor, B:
 
 def mm_backward(plan: RowGather, values: torch.Tensor, G: torch.Tensor, B: torch.Tensor):
     """(gradA values in A's order, gradB) of C = A·B in one pass over the transposed pattern."""
+    if not G.is_cuda:       # CPU operands: the torch-op path (_cpu.py), chosen by the operands' device and nothing else
+        return _cpu.sddmm(plan, G, B), _cpu.spmm(plan.transposed, values, G)
     same = values.dtype == G.dtype == B.dtype
     if same and ENABLE_LATTICE and values.dtype in LATTICE_DTYPES:
         got = _lattice_backward(plan, values, G, B)
@@ -291,6 +294,8 @@ def mm_backward(plan: RowGather, values: torch.Tensor, G: torch.Tensor, B: torch
 def spmm(plan: RowGather, values: torch.Tensor, B: torch.Tensor, owner: RowGather = None) -> torch.Tensor:
     """A·B for the operand described by (plan, values); perm-aware (transposed / un-coalesced plans).  `owner`: when
     `plan` is `owner.transposed`, the pattern whose stored order the values are in (lets Aᵀ·G take the lattice sweep)."""
+    if not B.is_cuda:
+        return _cpu.spmm(plan, values, B)
     if values.dtype == B.dtype and not _be.is_transposed_view(B):  # transposed views: zero-copy column-strided K1
         stored = plan.perm is None
         if ENABLE_LATTICE and (stored or (owner is not None and owner.perm is None)):
@@ -322,6 +327,8 @@ def spmm(plan: RowGather, values: torch.Tensor, B: torch.Tensor, owner: RowGathe
 def spmm_t(owner: RowGather, values: torch.Tensor, G: torch.Tensor) -> torch.Tensor:
     """Aᵀ·G for the operand (owner, values): the lattice sweep walks the transposed pattern through the owner's own arrays;
     everything else goes through the cached transposed pattern (built on first use)."""
+    if not G.is_cuda:
+        return _cpu.spmm(owner.transposed, values, G)
     if ENABLE_LATTICE and owner.perm is None and values.dtype == G.dtype and not _be.is_transposed_view(G):
         fsrc, Gf = owner, G
         if owner.batch is not None:
@@ -336,6 +343,8 @@ def spmm_t(owner: RowGather, values: torch.Tensor, G: torch.Tensor) -> torch.Ten
 
 def sddmm(plan: RowGather, G: torch.Tensor, B: torch.Tensor, alpha: float = 1.0, swap_roles: bool = False) -> torch.Tensor:
     """alpha·<G[row k], B[col k]> (or roles swapped) at the plan's stored entries, in plan order."""
+    if not G.is_cuda:
+        return _cpu.sddmm(plan, G, B, alpha=alpha, swap_roles=swap_roles)
     gathered = G if swap_roles else B
     rowop = B if swap_roles else G
     if plan.perm is None and G.dtype == B.dtype:

@@ -73,7 +73,11 @@ class StepFunction : public torch::autograd::Function<StepFunction> {
     static at::Tensor forward(torch::autograd::AutogradContext* ctx, const at::Tensor& A, const at::Tensor& B, StepPlanPtr handle) {
         const StepPlan& s = *handle;
         const c10::hip::HIPGuard on_device(static_cast<c10::DeviceIndex>(s.device));   // (the launchers select the device: restore the caller's)
-        const at::Tensor val = s.coo ? A._values() : A.values();
+        // torch keeps the value tensor a sparse tensor was built from as given, strided views included (a column of a 2-D parameter):
+        // the launches below take a raw pointer to nnz consecutive values (the Python path: `val.contiguous()` in _backend.py)
+        at::Tensor val = s.coo ? A._values() : A.values();
+        if (!val.is_contiguous()) val = val.contiguous();
+        TORCH_CHECK(val.dim() == 1 && val.numel() == s.nnz, "step plan of another matrix (number of stored values)");
         at::Tensor C = at::empty({s.n_rows, s.p}, B.options());
         if (s.fwd.kind == 2)
             check(tsgu_csr_spmm(s.vtype, s.itype, s.n_rows, s.n_cols, s.nnz, s.crow.data_ptr(), s.col.data_ptr(), val.data_ptr(), nullptr,

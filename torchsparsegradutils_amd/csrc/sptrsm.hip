@@ -147,8 +147,9 @@ __global__ __launch_bounds__(kBlock) void sptrsm_syncfree_kernel(const TrsmParam
 
         A acc = 0;
         A diag = 0;
-        A inv = 1;            // 1 / diagonal: ready BEFORE the row's last dependency arrives (the diagonal is the last entry visited)
-        A dsum = 1;           // the diagonal itself (fp64 divides by it: the reciprocal saves nothing measurable there)
+        A dsum = 1;           // the diagonal (unit: 1): every value type DIVIDES by it, like the reference's backend (_compat.py:42-48) —
+                              // a reciprocal prepared ahead of the last dependency rounds differently (<= 1 ulp per row, compounding
+                              // along C3's 2 673-level chains) and buys nothing measurable on a 0.8 us hop
         bool dead = false;
         // the right-hand side is requested BEFORE the row waits for its dependencies: its latency is off the critical path
         A rhs = 0;
@@ -170,10 +171,7 @@ __global__ __launch_bounds__(kBlock) void sptrsm_syncfree_kernel(const TrsmParam
                     need = col_ok && (P.lower ? j < row : j > row);
                 }
             }
-            if (base + EP >= e && !P.unit) {       // last round: the diagonal is among these entries
-                dsum = entry_sum<A, EP>(diag);
-                inv = (A)1 / dsum;
-            }
+            if (base + EP >= e && !P.unit) dsum = entry_sum<A, EP>(diag);      // last round: the diagonal is among these entries
             Bits xb = S::kTag;
             // poll: back-to-back agent-scope loads (the hop latency of the solve's critical path is the
             // time between the producer's store and the first poll that sees it); the wall clock and the
@@ -205,17 +203,11 @@ __global__ __launch_bounds__(kBlock) void sptrsm_syncfree_kernel(const TrsmParam
             if (lane == 0) __hip_atomic_store(&work->error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             break;
         }
-        if (s == e && !P.unit) {   // an empty row of a non-unit solve: a zero diagonal — inf / NaN like the reference's backend,
-            dsum = 0;              // not a silent x = rhs
-            inv = (A)1 / dsum;
-        }
+        if (s == e && !P.unit) dsum = 0;   // an empty row of a non-unit solve: a zero diagonal — inf / NaN like the reference's backend,
+                                           // not a silent x = rhs
         acc = entry_sum<A, EP>(acc);
         if (ep == 0 && col_ok) {
-            A x = rhs - acc;
-            // fp32 / bf16: times the reciprocal that was ready before the last dependency arrived (within 1 ulp of the
-            // division per row; it rounds differently from the reference's division); fp64: the division itself
-            if constexpr (sizeof(A) == 8) x = x / dsum;
-            else x = x * inv;  // (unit: inv = dsum = 1)
+            const A x = (rhs - acc) / dsum;      // (correctly rounded division; unit: dsum = 1)
             Bits xb = S::bits(x);
             if (x != x) xb = S::kCanon;
             __hip_atomic_store(X + row * P.ldx + c, xb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -102,7 +102,7 @@ class SparseGenericLstsq(torch.autograd.Function):
             plan, values = _pt.from_coo_2d(coo_index, A.shape, coalesced=True), Ac.values()
         else:
             plan, values = _pt.from_csr(A), A.values()
-        _be.require_device(values, B, x)
+        _be.operand_device(values, B, x)
         residual = B - _ops.spmm(plan, values, x.contiguous())
         pinv_gb = _columns(lstsq(A, grad_b))
         row_side = torch.cat((-grad_b, residual), dim=1).contiguous()

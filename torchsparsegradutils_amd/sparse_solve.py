@@ -98,6 +98,10 @@ class _TriOperand:
 
 def _solve(plan: _pt.RowGather, values, rhs, upper: bool, unit: bool, transpose: bool):
     """X = op(A)^{-1} rhs on the 2-D plan (reference _compat.py:42-48 semantics)."""
+    if not rhs.is_cuda:     # CPU operands: the legacy ATen call itself, as the reference makes it (_cpu.py)
+        from . import _cpu
+
+        return _cpu.sptrsm(plan, values, rhs, upper, unit, transpose)
     if transpose:
         pt = plan.transposed  # rows of Aᵀ; the selected triangle flips side
         return _be.csr_sptrsm(pt.crow, pt.col, values, rhs, pt.n_rows, lower=upper, unit=unit, perm=pt.perm)
@@ -118,7 +122,6 @@ class SparseTriangularSolve(torch.autograd.Function):
         grad_flag = A.requires_grad or B.requires_grad
 
         A, B = A.detach(), B.detach()
-        _be.require_device(B)
         if A.device != B.device:
             raise RuntimeError(f"A and B must be on the same device, got {A.device} and {B.device}")
         op = _TriOperand(A)

@@ -20,7 +20,6 @@ class SparseOperator:
     def __init__(self, A: torch.Tensor):
         if A.dim() != 2:
             raise RuntimeError("sparse operator must be a 2-D sparse tensor")
-        _be.require_device(A)
         if A.layout == torch.sparse_csr:
             self.plan = _pt.from_csr(A)
             self.values = A.values()

@@ -55,10 +55,9 @@ def bicgstab(
 
     ``matmul_closure``: tensor (dense or sparse COO/CSR) or callable; ``rhs``: ``(n,)`` or ``(n, k)``
     on the GPU.  Returns the solution with the shape of ``rhs``."""
-    _be.require_device(rhs)
     if settings.precon is not None and not (torch.is_tensor(settings.precon) or callable(settings.precon)):
         raise RuntimeError("settings.precon must be a tensor, or a callable object!")
-    if ENABLE_FUSED and rhs.dtype in (torch.float32, torch.float64) and rhs.dim() in (1, 2) \
+    if ENABLE_FUSED and rhs.is_cuda and rhs.dtype in (torch.float32, torch.float64) and rhs.dim() in (1, 2) \
             and rhs.shape[-1 if rhs.dim() == 2 else 0] > 0 and (rhs.dim() == 1 or rhs.shape[1] <= 1024):
         return _bicgstab_fused(matmul_closure, rhs, initial_guess, settings)
     if rhs.dim() > 1:

@@ -74,7 +74,6 @@ def linear_cg(
     ``(n_tridiag, *batch, r, r)`` (reference :303-310, :385-406): those solves run the recurrences as tensor ops around the HIP
     SpMM and dot kernels (the coefficients of every iteration are needed on the way), not the fused step kernels.
     """
-    _be.require_device(rhs)
     if rhs.ndimension() > 2:
         return _batched_rhs(matmul_closure, rhs, n_tridiag, tolerance, eps, stop_updating_after, max_iter, max_tridiag_iter,
                             initial_guess, preconditioner, settings)
@@ -138,7 +137,8 @@ def linear_cg(
     if n_tridiag:
         t_mat = torch.zeros(n_tridiag_iter, n_tridiag_iter, n_tridiag, dtype=dtype, device=dev)
     fused_tridiag = None
-    if n_iter > 0 and n_tridiag and preconditioner is None and TWO_LAUNCH and p <= 256 and isinstance(op, SparseOperator) and op.dtype == dtype:
+    if (n_iter > 0 and n_tridiag and preconditioner is None and TWO_LAUNCH and p <= 256 and isinstance(op, SparseOperator) and op.dtype == dtype
+            and rhs.is_cuda):
         # the coefficients of the first n_tridiag_iter iterations are recorded by the fused kernels; the matrices are built afterwards
         lib = _be.load_library()
         fused_tridiag = _two_launch_loop(lib, op, rhs_is_zero, result, residual, has_converged, n_iter, max_iter, tolerance, eps,
@@ -150,7 +150,8 @@ def linear_cg(
         rows = min(n_tridiag_iter, k_done - 1 if tolerance_reached else k_done)
         last_tridiag_iter = _tridiag_from_history(hist, n_tridiag, rows, t_mat)
     elif n_iter > 0:
-        if n_tridiag or (preconditioner is not None and not ENABLE_FUSED_PRECOND):
+        # (CPU operands: the recurrences as tensor ops — the fused step kernels are the MI355X path)
+        if n_tridiag or (preconditioner is not None and not ENABLE_FUSED_PRECOND) or not rhs.is_cuda:
             result, residual_norm, k_done, tolerance_reached, last_tridiag_iter = _pcg_loop(
                 op, preconditioner, rhs_is_zero, result, residual, has_converged, n_iter, max_iter, tolerance, eps,
                 stop_updating_after, n_tridiag, n_tridiag_iter, t_mat,
@@ -345,8 +346,12 @@ def _two_launch_loop(lib, op, rhs_is_zero, x, r, has_converged, n_iter, max_iter
         while k < n_iter and not done:
             if try_graph and graph is None and k > min_iter_index and n_iter - k >= _graph.MIN_ITERS:
                 # (an even number of iterations per replay: the parities baked into the captured launches stay right)
+                # (a capture that fails part-way has run nothing on the device: the host's view of the parity must not move either)
+                saved = dict(state)
                 graph = _graph.capture(iteration, _POLL)
                 try_graph = graph is not None
+                if graph is None:
+                    state.update(saved)
             if graph is not None and k + _POLL <= n_iter:
                 _graph.replay(graph)
                 k += _POLL
@@ -476,8 +481,12 @@ def _fused_loop(op, rhs_is_zero, x, r, has_converged, n_iter, max_iter, toleranc
             if try_graph and graph is None and k > min_iter_index and n_iter - k >= _graph.MIN_ITERS:
                 # long solves: capture _POLL iterations once as a hipGraph and replay it (one host call per
                 # chunk instead of 6 launches per iteration; finished iterations are device-side no-ops)
+                # (a capture that fails part-way has run nothing on the device: the host's view of the parity must not move either)
+                saved = dict(state)
                 graph = _graph.capture(iteration, _POLL)
                 try_graph = graph is not None
+                if graph is None:
+                    state.update(saved)
             if graph is not None and k + _POLL <= n_iter:
                 _graph.replay(graph)
                 k += _POLL

@@ -101,7 +101,6 @@ def lsmr(
     the k systems are solved in lock-step, each with its own stopping point.  Returns ``(x, iterations)`` where
     ``iterations`` is the largest iteration count over the right-hand sides.  ``check_nonzero`` is accepted for
     signature parity (the β > 0 test costs nothing here: β is needed on the host anyway)."""
-    _be.require_device(b)
     user_mat, user_rmat = callable(A) and not torch.is_tensor(A), callable(Armat) and not torch.is_tensor(Armat)
     mat, rmat, n = _as_pair(A, Armat, n)
     if torch.atleast_1d(b).dim() == 1:

@@ -46,8 +46,7 @@ def minres(
     settings: MINRESSettings = MINRESSettings(),
 ) -> torch.Tensor:
     r"""Solve symmetric (possibly indefinite) systems :math:`(A + \sigma I) x = b` with MINRES."""
-    _be.require_device(rhs)
-    if (ENABLE_FUSED and rhs.dim() > 2 and (shifts is None or shifts.dim() <= 1) and rhs.dtype in (torch.float32, torch.float64)
+    if (ENABLE_FUSED and rhs.is_cuda and rhs.dim() > 2 and (shifts is None or shifts.dim() <= 1) and rhs.dtype in (torch.float32, torch.float64)
             and rhs.numel() > 0):
         # right-hand sides with batch dimensions (*batch, n, k) (reference utils/minres.py:221-233: norms per (batch, column), the
         # stop rule is their mean): the batch is folded into the columns, (n, batch·k), and solved by the 2-D path on the fused
@@ -95,7 +94,7 @@ def minres(
         return out.mul(value) if value is not None else out
 
     n_sh = shifts.numel()
-    if (ENABLE_FUSED and rhs.dim() == 2 and shifts.dim() <= 1 and 0 < n_sh <= 64 and shifts.device == rhs.device
+    if (ENABLE_FUSED and rhs.is_cuda and rhs.dim() == 2 and shifts.dim() <= 1 and 0 < n_sh <= 64 and shifts.device == rhs.device
             and rhs.dtype in (torch.float32, torch.float64) and 0 < rhs.size(-1) <= 1024 and rhs.size(-2) > 0):
         sol = _minres_fused(mm, rhs.contiguous(), shifts.reshape(-1).to(rhs.dtype).contiguous(), value, preconditioner, eps,
                             max_iter, settings)
