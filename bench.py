@@ -351,6 +351,146 @@ def patterns_leg(dev, steps, warmup, headline):
     return out
 
 
+def published_shapes_leg(dev, steps, with_cpu):
+    """The shapes of the reference's own published benchmark tables (benchmarks/results/*.csv — measured there on an RTX 4090, i.e.
+    other hardware: context, never `vs_baseline`), through the public API: ms forward and forward + backward, the algorithmic bytes
+     as a fraction of the HBM roofline, and the reference's ATen op chain on this box's host cores beside them
+    (oracle/aten_port.py; a bounded number of repeats)."""
+    from torchsparsegradutils_amd import _pattern, sparse_mm, sparse_triangular_solve, wait_for_plans
+    from torchsparsegradutils_amd.utils import synthetic
+
+    out = {}
+    reps = max(steps, 20)
+
+    def timed(fn):
+        for _ in range(6):
+            fn()
+        wait_for_plans()
+        for _ in range(6):
+            fn()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize(dev)
+        wall = (time.perf_counter() - t0) / reps * 1e3
+        return round(wall, 5), round(time_events(fn, reps, dev, hold_ms=reps * 1.5 * max(wall, 0.05), settle=4), 5)
+
+    def frac(nbytes, ms):
+        return round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+
+    def host(fn, budget_s=20.0):
+        if not with_cpu:
+            return None
+        ts, stop = [], time.perf_counter() + budget_s
+        for _ in range(4):
+            t0 = time.perf_counter()
+            fn()
+            ts.append((time.perf_counter() - t0) * 1e3)
+            if time.perf_counter() > stop:
+                break
+        return round(statistics.median(ts[1:] or ts), 3)
+
+    # ---- sparse_triangular_solve, rand, "large": N = 262144, nnz = 524288, 8 RHS, lower, fp32 / int32
+    try:
+        from oracle import aten_port
+
+        _pattern.clear_cache()
+        n, nnz, p = 262144, 524288, 8
+        crow, col, val = synthetic.rand_lower_triangular(n, nnz, torch.int32, torch.float32, dev, seed=0)
+        g = torch.Generator(device=dev).manual_seed(1)
+        A = torch.sparse_csr_tensor(crow, col, val, (n, n)).requires_grad_(True)
+        B = torch.randn(n, p, device=dev, generator=g).requires_grad_(True)
+        G = torch.randn(n, p, device=dev, generator=g)
+        fwd = timed(lambda: sparse_triangular_solve(A.detach(), B.detach(), upper=False))
+        fb = timed(lambda: torch.autograd.grad(sparse_triangular_solve(A, B, upper=False), (A, B), G))
+        solve_b = (n + 1) * 4 + nnz * 8 + 2 * n * p * 4
+        sddmm_b = (n + 1) * 4 + nnz * 4 + 2 * n * p * 4 + nnz * 4
+        Ac, Bc, Gc = A.detach().cpu(), B.detach().cpu(), G.cpu()
+        xc = aten_port.tri_forward(Ac, Bc, False, False, False) if with_cpu else None
+        out["sparse_triangular_solve_rand_large"] = {
+            "what": "lower CSR N=262144, nnz=524288 (diagonal + 262144 random strictly-lower entries, well conditioned), 8 RHS, fp32/int32",
+            "reference_table": "benchmarks/results/sparse_triangular_solve_rand_results.csv:72 (sparse_triangular_solve, RTX 4090: fwd 701.7 us, bwd 1460.3 us)",
+            "fwd_ms": fwd[0], "fwd_ms_device": fwd[1], "fwd_bwd_ms": fb[0], "fwd_bwd_ms_device": fb[1],
+            "algorithmic_bytes": {"fwd": solve_b, "fwd_bwd": 2 * solve_b + sddmm_b},
+            "frac": {"fwd": frac(solve_b, fwd[1]), "fwd_bwd": frac(2 * solve_b + sddmm_b, fb[1])},
+            "frac_note": "a dependency-bound solve: the fraction of the HBM roofline is reported for completeness, the time per dependency level is the figure of merit",
+            "host_reference_op_chain_ms": {"fwd": host(lambda: aten_port.tri_forward(Ac, Bc, False, False, False)),
+                                           "bwd": host(lambda: aten_port.tri_backward(Ac, xc, Gc, False, False, False))},
+        }
+        del A, B, G, crow, col, val
+    except Exception as exc:  # noqa: BLE001
+        out["sparse_triangular_solve_rand_large"] = {"error": repr(exc)}
+
+    # ---- sparse_mm, rand, "large": N = 262144, nnz = 65536, 512 dense columns, fp32 / int32 (most rows are empty)
+    try:
+        from oracle import aten_port
+
+        _pattern.clear_cache()
+        torch.cuda.empty_cache()
+        n, nnz, p = 262144, 65536, 512
+        crow, col = synthetic.rand_csr(n, n, nnz, torch.int32, dev, seed=0)
+        g = torch.Generator(device=dev).manual_seed(2)
+        A = torch.sparse_csr_tensor(crow, col, torch.randn(nnz, device=dev, generator=g), (n, n)).requires_grad_(True)
+        B = torch.randn(n, p, device=dev, generator=g).requires_grad_(True)
+        G = torch.randn(n, p, device=dev, generator=g)
+        fwd = timed(lambda: sparse_mm(A.detach(), B.detach()))
+        fb = timed(lambda: torch.autograd.grad(sparse_mm(A, B), (A, B), G))
+        ab = alg_bytes(n, nnz, p)
+        Ac, Bc, Gc = A.detach().cpu(), B.detach().cpu(), G.cpu()
+        out["sparse_mm_rand_large"] = {
+            "what": "CSR 262144 x 262144 with 65536 random entries, 512 dense columns, fp32/int32 (the product is dominated by writing the mostly-zero result)",
+            "reference_table": "benchmarks/results/sparse_mm_rand_results.csv:54 (sparse_mm CSR, RTX 4090: fwd 21973 us, bwd 42871 us)",
+            "fwd_ms": fwd[0], "fwd_ms_device": fwd[1], "fwd_bwd_ms": fb[0], "fwd_bwd_ms_device": fb[1],
+            "algorithmic_bytes": {"fwd": ab["spmm"], "fwd_bwd": ab["fwd_bwd"]},
+            "frac": {"fwd": frac(ab["spmm"], fwd[1]), "fwd_bwd": frac(ab["fwd_bwd"], fb[1])},
+            "host_reference_op_chain_ms": {"fwd": host(lambda: aten_port.mm_forward(Ac, Bc)), "bwd": host(lambda: aten_port.mm_backward(Ac, Bc, Gc))},
+        }
+        del A, B, G, crow, col, Ac, Bc, Gc
+    except Exception as exc:  # noqa: BLE001
+        out["sparse_mm_rand_large"] = {"error": repr(exc)}
+
+    # ---- batched sparse_mm, rand: 128 x (1024 x 1024, nnz 4096), 64 dense columns, fp32 / int32
+    try:
+        from oracle import aten_port
+
+        _pattern.clear_cache()
+        torch.cuda.empty_cache()
+        b, n, nnz, p = 128, 1024, 4096, 64
+        crow, col = synthetic.rand_batched_csr(b, n, n, nnz, torch.int32, dev, seed=0)
+        g = torch.Generator(device=dev).manual_seed(3)
+        A = torch.sparse_csr_tensor(crow, col, torch.randn(b, nnz, device=dev, generator=g), (b, n, n)).requires_grad_(True)
+        B = torch.randn(b, n, p, device=dev, generator=g).requires_grad_(True)
+        G = torch.randn(b, n, p, device=dev, generator=g)
+        fwd = timed(lambda: sparse_mm(A.detach(), B.detach()))
+        fb = timed(lambda: torch.autograd.grad(sparse_mm(A, B), (A, B), G))
+        ab = alg_bytes(n, nnz, p, items=b)
+        host_ms = None
+        if with_cpu:
+            # the reference's batched path: ONE block-diagonal matrix (sparse_matmul.py:151-153), then the same op chain
+            from torchsparsegradutils_amd.utils import sparse_block_diag
+
+            Ad = A.detach().cpu()
+            Abd = sparse_block_diag(*[Ad[i] for i in range(b)])
+            Bc, Gc = B.detach().cpu().reshape(-1, p), G.cpu().reshape(-1, p)
+            host_ms = {"fwd": host(lambda: aten_port.mm_forward(Abd, Bc)), "bwd": host(lambda: aten_port.mm_backward(Abd, Bc, Gc)),
+                       "note": "without the block-diagonal assembly the reference repeats per call"}
+        out["batched_sparse_mm_rand_b128"] = {
+            "what": "batched CSR, 128 items of 1024 x 1024 with 4096 random entries each, 64 dense columns, fp32/int32",
+            "reference_table": "benchmarks/results/batched_sparse_mm_rand_results.csv:31 (batched_sparse_mm CSR, RTX 4090: fwd 2954 us, bwd 11820 us)",
+            "fwd_ms": fwd[0], "fwd_ms_device": fwd[1], "fwd_bwd_ms": fb[0], "fwd_bwd_ms_device": fb[1],
+            "algorithmic_bytes": {"fwd": ab["spmm"], "fwd_bwd": ab["fwd_bwd"]},
+            "frac": {"fwd": frac(ab["spmm"], fwd[1]), "fwd_bwd": frac(ab["fwd_bwd"], fb[1])},
+            "frac_note": "71 MB per forward: launch-latency-bound (a few launches of ~10 us each), not HBM-bound",
+            "host_reference_op_chain_ms": host_ms,
+        }
+    except Exception as exc:  # noqa: BLE001
+        out["batched_sparse_mm_rand_b128"] = {"error": repr(exc)}
+    _pattern.clear_cache()
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -361,6 +501,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-c5", action="store_true")
     ap.add_argument("--no-patterns", action="store_true")
+    ap.add_argument("--no-published", action="store_true", help="skip the shapes of the reference's published tables")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -667,7 +808,7 @@ def main():
     copy16_gbs = 2 * src.numel() * 4 / (copy16_ms * 1e-3) / 1e9
     del src, dst
 
-    def make_line(allgather, c5, patterns, cpu):
+    def make_line(allgather, c5, patterns, cpu, published=None):
         """The ONE JSON line of this run (rank 0) from what has been measured so far."""
         total_bytes = ab["fwd_bwd"] * world
         value = total_bytes / (ms_per_step * 1e-3) / 1e9
@@ -750,6 +891,7 @@ def main():
             "cpu_baseline": cpu,
             "c5": c5,
             "patterns": patterns,
+            "published_shapes": published,
         }
         if allgather is not None:
             line["allgather"] = allgather
@@ -810,6 +952,13 @@ def main():
         except Exception as exc:  # noqa: BLE001
             patterns = {"error": repr(exc)}
 
+    published = None
+    if rank == 0 and world == 1 and not args.no_published:
+        try:
+            published = published_shapes_leg(dev, args.steps, not args.no_cpu_baseline)
+        except Exception as exc:  # noqa: BLE001
+            published = {"error": repr(exc)}
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline_leg(nx, ny, nz, p)
@@ -817,7 +966,7 @@ def main():
     if watchdog is not None:
         watchdog.cancel()
     if rank == 0:
-        print(json.dumps(make_line(allgather, c5, patterns, cpu)), flush=True)
+        print(json.dumps(make_line(allgather, c5, patterns, cpu, published)), flush=True)
 
     if world > 1:
         dist.destroy_process_group()

@@ -54,6 +54,14 @@ int tsgu_device_info(int device, char* name, int cap, int* n_cu, int* wave_size)
 int tsgu_device_copy(const void* src, void* dst, int64_t bytes, int device, void* stream);
 
 /*
+ * 128-bit content fingerprint of an index array x[n] (itype) into out2[2] (uint64, device): two position-weighted sums in wrapping
+ * 64-bit arithmetic, the same words whatever the launch geometry.  No reference counterpart: the reference keeps no per-pattern
+ * state (sparse_matmul.py:141-163 re-derives everything per call), so it has no cliff when a caller rebuilds its index tensors
+ * every step; the pattern cache here recognises such tensors by content (one pass over the indices) and adopts the existing plans.
+ */
+int tsgu_index_fingerprint(int itype, int64_t n, const void* x, void* out2, int device, void* stream);
+
+/*
  * K1  C = A · B            (CSR × dense, optional fused column-dot epilogue)
  * replaces: torch.sparse.mm(A, B)            torchsparsegradutils/sparse_matmul.py:155
  *           A.matmul(p) in the Krylov loops  torchsparsegradutils/utils/linear_cg.py:322,

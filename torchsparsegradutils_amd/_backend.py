@@ -39,6 +39,7 @@ SIGNATURES = {
     "tsgu_status_string": (ctypes.c_char_p, [_int]),
     "tsgu_device_info": (_int, [_int, ctypes.c_char_p, _int, ctypes.POINTER(_int), ctypes.POINTER(_int)]),
     "tsgu_device_copy": (_int, [_ptr, _ptr, _i64, _int, _ptr]),
+    "tsgu_index_fingerprint": (_int, [_int, _i64, _ptr, _ptr, _int, _ptr]),
     "tsgu_csr_spmm": (
         _int,
         [_int, _int, _i64, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _ptr, _i64, _i64, _i64, _i64, _i64, _i64,
@@ -826,6 +827,20 @@ def poll_errors(block: bool = False) -> None:
             _PENDING[:0] = keep
     if failed is not None:
         check(-7, failed)
+
+
+def index_fingerprint(*tensors: torch.Tensor) -> torch.Tensor:
+    """[len(tensors)][2] int64 device tensor: the 128-bit content fingerprint of each (contiguous) index tensor; queued on the
+    current stream, nothing is read back here."""
+    lib = load_library()
+    dev = require_device(*tensors)
+    out = torch.empty((len(tensors), 2), dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        for i, t in enumerate(tensors):
+            t = t.contiguous()
+            check(lib.tsgu_index_fingerprint(itype_of(t), t.numel(), _p(t), out[i].data_ptr(), dev.index, _stream(dev)),
+                  "tsgu_index_fingerprint")
+    return out
 
 
 def coldot(X, Y):

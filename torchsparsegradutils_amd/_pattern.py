@@ -57,9 +57,11 @@ class _Core:
     Holds only tensors this module allocated — never the caller's index tensors — so that dropping the sparse
     tensor releases its plans (the cache entry is evicted by a finalizer on the index storage)."""
 
-    __slots__ = ("t", "has_diag", "rows", "packs", "pending", "uses", "flat", "own", "__weakref__")
+    __slots__ = ("t", "has_diag", "rows", "packs", "pending", "uses", "flat", "own", "fp", "geom", "__weakref__")
 
     def __init__(self):
+        self.fp = None      # [tensors][2] int64 on the device: content fingerprint of the caller's index tensors (see _core_for)
+        self.geom = None    # (kind, shape, geometry of the index tensors): what a fingerprint is compared within
         self.t: Optional[RowGather] = None
         self.has_diag: Optional[bool] = None
         self.rows = None
@@ -683,34 +685,90 @@ def _evict(key) -> None:
         _CACHE.pop(key, None)
 
 
+# A caller that rebuilds its index tensors every step (`torch.sparse_csr_tensor(crow.clone(), col.clone(), …)`) misses the identity
+# key every time: without more, every step would pay the pattern analysis (~11 ms at C2) instead of the 0.7 ms plan-free step.
+# The reference has no per-pattern state and so no such cliff (sparse_matmul.py:141-163).  On a miss whose geometry (layout, shape,
+# index dtype, nnz, device) equals a live entry's, the CONTENT of the index tensors is compared through a 128-bit fingerprint
+# (one pass over the indices on the device, `tsgu_index_fingerprint`; the comparison is one host read) and the live entry's core is
+# adopted under the new key.  Geometries that keep arriving with NEW content are marked volatile after FRESH_LIMIT misses in a row:
+# their plans then wait until a pattern has come back (`_Core.own["volatile"]`, read by _ops._lattice_plan).
+FINGERPRINT = _os.environ.get("TSGU_PATTERN_FINGERPRINT", "1") != "0"
+FINGERPRINT_MIN = 1 << 16
+FRESH_LIMIT = 3
+_FRESH = {}
+STATS = {"adopted": 0, "fingerprints": 0, "volatile": 0}
+
+
+def _fingerprint(tensors):
+    if not FINGERPRINT or not all(t.is_cuda and t.dtype in (torch.int32, torch.int64) for t in tensors):
+        return None
+    if sum(t.numel() for t in tensors) < FINGERPRINT_MIN or torch.cuda.is_current_stream_capturing():
+        return None
+    from . import _backend
+
+    STATS["fingerprints"] += 1
+    return _backend.index_fingerprint(*tensors)
+
+
 def _core_for(kind: str, tensors, shape) -> _Core:
     key = _key(kind, tensors, shape)
     with _CACHE_LOCK:
         core = _CACHE.get(key)
         if core is not None:
             _CACHE.move_to_end(key)
+            if core.geom is not None:
+                _FRESH.pop(core.geom, None)
             return core
-        core = _Core()
+    geom = (kind, tuple(shape)) + tuple((t.shape, t.dtype, t.device) for t in tensors)
+    fp = _fingerprint(tensors)
+    adopted = None
+    if fp is not None:
+        with _CACHE_LOCK:
+            live = [c for c in _CACHE.values() if c.geom == geom and c.fp is not None]
+        seen = set()
+        for c in reversed(live):
+            if id(c) not in seen and torch.equal(c.fp, fp):      # (the host read: only when a live entry has this geometry)
+                adopted = c
+                break
+            seen.add(id(c))
+    with _CACHE_LOCK:
+        if adopted is not None:
+            core = adopted
+            STATS["adopted"] += 1
+            _FRESH.pop(geom, None)
+        else:
+            core = _Core()
+            core.fp, core.geom = fp, geom
+            if fp is not None and live:
+                fresh = _FRESH[geom] = _FRESH.get(geom, 0) + 1
+                if fresh >= FRESH_LIMIT:
+                    core.own["volatile"] = 0
+                    STATS["volatile"] += 1
         _CACHE[key] = core
         for t in tensors:
             weakref.finalize(t.untyped_storage(), _evict, key)
         while len(_CACHE) > _CACHE_MAX:
             _CACHE.popitem(last=False)
-        if len(_CACHE) > 1 and sum(c.nbytes() for c in _CACHE.values()) > _CACHE_MAX_BYTES:
-            while len(_CACHE) > 1 and sum(c.nbytes() for c in _CACHE.values()) > _CACHE_MAX_BYTES:
+        if len(_CACHE) > 1 and _cached_bytes() > _CACHE_MAX_BYTES:
+            while len(_CACHE) > 1 and _cached_bytes() > _CACHE_MAX_BYTES:
                 _CACHE.popitem(last=False)
     return core
+
+
+def _cached_bytes() -> int:
+    return sum(c.nbytes() for c in {id(c): c for c in _CACHE.values()}.values())      # (adopted cores sit under several keys)
 
 
 def clear_cache() -> None:
     with _CACHE_LOCK:
         _CACHE.clear()
+        _FRESH.clear()
 
 
 def cache_stats():
     """(entries, derived bytes) held by the pattern cache."""
     with _CACHE_LOCK:
-        return len(_CACHE), sum(c.nbytes() for c in _CACHE.values())
+        return len(_CACHE), _cached_bytes()
 
 
 def from_csr(A: torch.Tensor) -> RowGather:

@@ -19,6 +19,28 @@ int coo_sddmm_dispatch_bf16(int, const CooSddmmParams&, hipStream_t);
 
 using namespace tsgu;
 
+// 128-bit content fingerprint of an index array (see include/tsgu_hip.h): position-weighted sums in wrapping 64-bit integer
+// arithmetic — integer addition commutes, so the atomics of different workgroups give the same words in any order.
+template <typename I>
+__global__ __launch_bounds__(256) void tsgu_fingerprint_kernel(const I* __restrict__ x, int64_t n, unsigned long long* __restrict__ out) {
+    unsigned long long h1 = 0, h2 = 0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) {
+        const unsigned long long a = (unsigned long long)(long long)x[k] + 0x9e3779b97f4a7c15ull;
+        h1 += a * (unsigned long long)(k % 251 + 1);
+        h2 += (a ^ (a >> 29)) * (a | 1ull) * (unsigned long long)(k % 65521 + 1);
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        h1 += __shfl_xor(h1, m, 64);
+        h2 += __shfl_xor(h2, m, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(out, h1);
+        atomicAdd(out + 1, h2);
+    }
+}
+
 extern "C" {
 
 int tsgu_abi_version(void) { return TSGU_ABI_VERSION; }
@@ -67,6 +89,24 @@ int tsgu_device_copy(const void* src, void* dst, int64_t bytes, int device, void
     const unsigned blocks = (unsigned)(want < 256 * 32 ? want : 256 * 32);   // 32 workgroups per CU, grid-stride beyond that
     hipLaunchKernelGGL(tsgu_copy16_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const uint4*>(src),
                        static_cast<uint4*>(dst), n16);
+    return check_launch();
+}
+
+int tsgu_index_fingerprint(int itype, int64_t n, const void* x, void* out2, int device, void* stream) {
+    if (n < 0 || !out2 || (n > 0 && !x)) return TSGU_ERR_BAD_ARG;
+    if (itype != TSGU_I32 && itype != TSGU_I64) return TSGU_ERR_BAD_DTYPE;
+    if (const int rc = set_device(device)) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(out2, 0, 16, s) != hipSuccess) return TSGU_ERR_RUNTIME;
+    if (n == 0) return TSGU_OK;
+    const int64_t want = (n + 256 * 8 - 1) / (256 * 8);
+    const unsigned blocks = (unsigned)(want < 2048 ? want : 2048);
+    if (itype == TSGU_I32)
+        hipLaunchKernelGGL(tsgu_fingerprint_kernel<int32_t>, dim3(blocks), dim3(256), 0, s, static_cast<const int32_t*>(x), n,
+                           static_cast<unsigned long long*>(out2));
+    else
+        hipLaunchKernelGGL(tsgu_fingerprint_kernel<int64_t>, dim3(blocks), dim3(256), 0, s, static_cast<const int64_t*>(x), n,
+                           static_cast<unsigned long long*>(out2));
     return check_launch();
 }
 

@@ -87,6 +87,10 @@ class StepFunction : public torch::autograd::Function<StepFunction> {
         else
             spmm(s, s.fwd, s.n_rows, val, B, C);
         ctx->save_for_backward({val, B});
+        // the gradient carries THIS operand's index tensors (reference sparse_matmul.py:208-219) — the plan may have been adopted from
+        // an earlier tensor with the same content (pattern cache: content fingerprint), whose tensors the kernels may read instead
+        if (s.coo) ctx->saved_data["idx"] = A._indices();
+        else ctx->saved_data["crow"] = A.crow_indices(), ctx->saved_data["col"] = A.col_indices();
         ctx->saved_data["plan"] = c10::IValue(reinterpret_cast<int64_t>(&s));
         // the plan (and with it every table the launches read) lives as long as the graph node: an empty tensor whose deleter owns
         // a reference travels with the node's saved data
@@ -154,8 +158,11 @@ class StepFunction : public torch::autograd::Function<StepFunction> {
         }
         if (need_a) {
             // the sparse gradient in A's own layout, with A's index tensors (reference sparse_matmul.py:208-219)
-            if (s.coo) gradA = at::sparse_coo_tensor(s.indices, gv, {s.n_rows, s.n_cols}, gv.options().layout(at::kSparse));
-            else gradA = at::sparse_csr_tensor(s.crow, s.col, gv, {s.n_rows, s.n_cols}, gv.options().layout(at::kSparseCsr));
+            if (s.coo)
+                gradA = at::sparse_coo_tensor(ctx->saved_data["idx"].toTensor(), gv, {s.n_rows, s.n_cols}, gv.options().layout(at::kSparse));
+            else
+                gradA = at::sparse_csr_tensor(ctx->saved_data["crow"].toTensor(), ctx->saved_data["col"].toTensor(), gv, {s.n_rows, s.n_cols},
+                                              gv.options().layout(at::kSparseCsr));
         }
         return {gradA, gradB, at::Tensor()};
     }

@@ -207,3 +207,76 @@ def lower_of(crow: torch.Tensor, col: torch.Tensor, val: torch.Tensor):
     new_crow = torch.zeros(n + 1, dtype=torch.int64, device=col.device)
     new_crow[1:] = torch.cumsum(counts, 0)
     return new_crow.to(crow.dtype), col[keep], val[keep]
+
+
+# ---- the shapes of the reference's own published benchmark tables (benchmarks/results/*.csv) ------------------------------------
+
+
+def _distinct(sample, count: int, generator, device):
+    """`count` distinct int64 keys: draw, deduplicate, top up (the key spaces here are so much larger than `count` that a second
+    round is rare)."""
+    keys = torch.unique(sample(count))
+    while keys.numel() < count:
+        keys = torch.unique(torch.cat((keys, sample(count - keys.numel() + 16))))
+    if keys.numel() > count:
+        keep = torch.randperm(keys.numel(), generator=generator, device=device)[:count]
+        keys = keys[keep].sort().values
+    return keys
+
+
+def _crow_of(rows: torch.Tensor, n: int, index_dtype) -> torch.Tensor:
+    crow = torch.zeros(n + 1, dtype=torch.int64, device=rows.device)
+    crow[1:] = torch.cumsum(torch.bincount(rows, minlength=n), 0)
+    return crow.to(index_dtype)
+
+
+def rand_csr(n: int, m: int, nnz: int, index_dtype=torch.int32, device="cpu", seed: int = 0):
+    """`nnz` distinct uniformly random positions of an n × m matrix as CSR (crow, col), columns sorted per row — the matrices of the
+    reference's ``benchmarks/sparse_mm_rand.py`` (``rand_sparse``, utils/random_sparse.py; published: N = 262144, nnz = 65536, 512
+    dense columns, benchmarks/results/sparse_mm_rand_results.csv:54).  Most rows of that shape are empty."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    keys = _distinct(lambda k: torch.randint(0, n * m, (k,), generator=g, device=device, dtype=torch.int64), nnz, g, device)
+    rows, cols = keys // m, keys % m
+    return _crow_of(rows, n, index_dtype), cols.to(index_dtype)
+
+
+def rand_lower_triangular(n: int, nnz: int, index_dtype=torch.int32, dtype=torch.float32, device="cpu", seed: int = 0):
+    """Lower triangular CSR (crow, col, val) with every diagonal entry and nnz − n distinct uniformly random strictly-lower positions;
+    off-diagonal values ~ U(0, 1), diagonal ~ U(1, 2): the ``well_conditioned=True, min_diag_value=1.0`` matrices of the reference's
+    ``benchmarks/sparse_triangular_solve_rand.py:131-142`` (published: N = 262144, nnz = 524288, 8 right-hand sides,
+    benchmarks/results/sparse_triangular_solve_rand_results.csv:72)."""
+    if not n <= nnz <= n * (n + 1) // 2:
+        raise ValueError("nnz must be between n and n(n+1)/2")
+    g = torch.Generator(device=device).manual_seed(seed)
+    total = n * (n - 1) // 2
+
+    def sample(k):
+        t = torch.randint(0, max(total, 1), (k,), generator=g, device=device, dtype=torch.int64)
+        return t
+
+    keys = _distinct(sample, nnz - n, g, device) if nnz > n else torch.empty(0, dtype=torch.int64, device=device)
+    # key t of the strict lower triangle, row-major: row i holds keys i(i-1)/2 … i(i+1)/2 − 1
+    i = ((1.0 + torch.sqrt(1.0 + 8.0 * keys.double())) / 2.0).floor().to(torch.int64)
+    i = torch.where(i * (i - 1) // 2 > keys, i - 1, i)
+    i = torch.where((i + 1) * i // 2 <= keys, i + 1, i)
+    j = keys - i * (i - 1) // 2
+    diag = torch.arange(n, device=device, dtype=torch.int64)
+    rows = torch.cat((i, diag))
+    cols = torch.cat((j, diag))
+    order = torch.argsort(rows * n + cols)
+    rows, cols = rows[order], cols[order]
+    val = torch.rand(nnz, generator=g, device=device, dtype=dtype)
+    val = torch.where(rows == cols, val + 1.0, val)
+    return _crow_of(rows, n, index_dtype), cols.to(index_dtype), val
+
+
+def rand_batched_csr(batch: int, n: int, m: int, nnz: int, index_dtype=torch.int32, device="cpu", seed: int = 0):
+    """Batched CSR index arrays (crow [batch][n+1], col [batch][nnz]) with `nnz` distinct random positions per item (torch's batched
+    CSR needs equal nnz per item, reference utils/random_sparse.py:10-11): the operands of ``benchmarks/batched_sparse_mm_rand.py``
+    (published: 128 × (1024 × 1024, nnz 4096), 64 dense columns, benchmarks/results/batched_sparse_mm_rand_results.csv:31)."""
+    crows, cols = [], []
+    for b in range(batch):
+        cr, co = rand_csr(n, m, nnz, index_dtype, device, seed=seed * 100003 + b)
+        crows.append(cr)
+        cols.append(co)
+    return torch.stack(crows), torch.stack(cols)
