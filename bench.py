@@ -324,6 +324,8 @@ def patterns_leg(dev, steps, warmup, headline):
                 fam = "plane march"
             elif lp is not None and any(c is not None for c in lp._cfg.values()):
                 fam = "plane sweep"
+            elif any(type(v).__name__ == "TilePlan" for v in plan.core.packs.values()):
+                fam = "row-block tiles"
             elif any(v is not None for v in plan.core.packs.values()) or (
                     plan.core.t is not None and any(v is not None for v in plan.core.t.core.packs.values())):
                 fam = "row pairs"
@@ -808,7 +810,7 @@ def main():
     copy16_gbs = 2 * src.numel() * 4 / (copy16_ms * 1e-3) / 1e9
     del src, dst
 
-    def make_line(allgather, c5, patterns, cpu, published=None):
+    def make_line(allgather, c5, patterns, cpu, published=None, fresh=None):
         """The ONE JSON line of this run (rank 0) from what has been measured so far."""
         total_bytes = ab["fwd_bwd"] * world
         value = total_bytes / (ms_per_step * 1e-3) / 1e9
@@ -892,6 +894,7 @@ def main():
             "c5": c5,
             "patterns": patterns,
             "published_shapes": published,
+            "fresh_index_tensors": fresh,
         }
         if allgather is not None:
             line["allgather"] = allgather
@@ -952,6 +955,46 @@ def main():
         except Exception as exc:  # noqa: BLE001
             patterns = {"error": repr(exc)}
 
+    # ---- callers that rebuild their index tensors every step (fresh storages, known content): the pattern cache adopts the plans by
+    # content fingerprint (one pass over the indices + one host read per step) instead of analysing the pattern again
+    fresh = None
+    if rank == 0 and world == 1 and not args.no_patterns:
+        try:
+            nx2, ny2, nz2 = args.grid
+            crow2, col2 = synthetic.stencil27_periodic(nx2, ny2, nz2, torch.int32, device=dev)
+            g2 = torch.Generator(device=dev).manual_seed(5)
+            val2 = torch.randn(col2.numel(), device=dev, generator=g2)
+            B2 = torch.randn(n, p, device=dev, generator=g2).requires_grad_(True)
+            G2 = torch.randn(n, p, device=dev, generator=g2)
+
+            def fstep(cr, co):
+                A2 = torch.sparse_csr_tensor(cr, co, val2, (n, n)).requires_grad_(True)
+                torch.autograd.grad(sparse_mm(A2, B2), (A2, B2), G2)
+
+            for _ in range(12):
+                fstep(crow2, col2)
+                wait_for_plans()
+            k2 = 16
+            clones = [(crow2.clone(), col2.clone()) for _ in range(k2)]
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for cr, co in clones:
+                fstep(cr, co)
+            torch.cuda.synchronize(dev)
+            ms_fresh = (time.perf_counter() - t0) / k2 * 1e3
+            t0 = time.perf_counter()
+            for _ in range(k2):
+                fstep(crow2, col2)
+            torch.cuda.synchronize(dev)
+            ms_same = (time.perf_counter() - t0) / k2 * 1e3
+            fresh = {"what": "the C2 step with crow.clone(), col.clone() on every step (fresh storages, known content)", "ms_per_step": round(ms_fresh, 5),
+                     "ms_per_step_same_tensors": round(ms_same, 5), "adopted": _pattern.STATS["adopted"], "steps": k2}
+            del clones, crow2, col2, val2, B2, G2
+            _pattern.clear_cache()
+            torch.cuda.empty_cache()
+        except Exception as exc:  # noqa: BLE001
+            fresh = {"error": repr(exc)}
+
     published = None
     if rank == 0 and world == 1 and not args.no_published:
         try:
@@ -966,7 +1009,7 @@ def main():
     if watchdog is not None:
         watchdog.cancel()
     if rank == 0:
-        print(json.dumps(make_line(allgather, c5, patterns, cpu, published)), flush=True)
+        print(json.dumps(make_line(allgather, c5, patterns, cpu, published, fresh)), flush=True)
 
     if world > 1:
         dist.destroy_process_group()

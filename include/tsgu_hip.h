@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define TSGU_ABI_VERSION 4
+#define TSGU_ABI_VERSION 5
 
 typedef enum {
     TSGU_OK = 0,
@@ -233,6 +233,45 @@ int tsgu_csr_sddmm_rowpack(int vtype, int itype, int64_t n_rows, int64_t n_cols,
                            void* out_vals, double alpha, int64_t p, int device, void* stream);
 
 /*
+ * Row-block TILE kernels (general CSR patterns whose neighbouring rows share columns, no lattice needed: mesh orderings, banded
+ * factors, FEM matrices — what the reference itself benchmarks, benchmarks/results/sparse_mm_suite_results.csv:5-6).
+ * replaces: torch.sparse.mm(A, B) / torch.sparse.mm(A.t(), G)   torchsparsegradutils/sparse_matmul.py:155, :229
+ *           the gather·mul·sum chain                            torchsparsegradutils/sparse_matmul.py:186-205
+ * A persistent workgroup walks a run of row blocks (rows_per_block consecutive rows each).  The DISTINCT dense rows a block
+ * references — its tile — are copied to LDS by 16-byte LDS-DMA one block ahead of the walk (double buffer), next to the block's
+ * slice of the value array and ONE BYTE per entry naming the entry's dense row inside the tile; the walk reads a byte, a value and
+ * 16 bytes of LDS per entry and keeps the accumulators in registers.  Plan (value independent, built once per pattern):
+ *   desc [n_blocks + 4][4] int32 {u0, U, e0, E}: block b's tile is ucol[u0 .. u0 + U) (ascending distinct columns, padded to a multiple
+ *                          of 8 by repeating the last one; u0 a multiple of 8), its entries are e0 .. e0 + E of the walked pattern;
+ *                          four trailing all-zero descriptors (the pipeline reads ahead)
+ *   ucol                   int32 column numbers, U <= max_union per block
+ *   lidx [nnz + 16]        uint8: position of entry k's column inside its block's tile
+ *   rptr [n_rows + 1]      int32 row pointer of the walked pattern
+ *   perm [nnz]             optional int32: position of entry k in the value array — the plan of the TRANSPOSED pattern walks A's own
+ *                          values (Aᵀ·G, sparse_matmul.py:229); NULL: values in walked order
+ * fp32 values, p = 32 (dense rows of 128 bytes), 16-byte aligned dense operands, 2-D operands below 4 GiB.  Sums run in ascending
+ * entry order of the walked pattern: the same bits as tsgu_csr_spmm / tsgu_csr_sddmm.  A row never touches a dense row it does not
+ * reference.  tsgu_tile_geometry gives the limits a plan has to meet (or a negative status for an unsupported (vtype, p)).
+ */
+typedef struct tsgu_tile_plan {
+    int64_t n_rows, n_cols, nnz;   /* of the walked pattern */
+    int64_t n_blocks;
+    int32_t rows_per_block, max_union, max_entries, reserved;
+    const void* desc;
+    const void* ucol;
+    const void* lidx;
+    const void* rptr;
+    const void* perm;
+} tsgu_tile_plan;
+
+int tsgu_tile_geometry(int vtype, int64_t p, int* rows_per_block, int* max_union, int* max_entries);
+int tsgu_csr_spmm_tile(int vtype, const tsgu_tile_plan* plan, const void* val, const void* B, int64_t ldb, void* C, int64_t ldc,
+                       int64_t p, int device, void* stream);
+/* out_vals[k] = alpha·<R[row k,:], Cm[col k,:]> in the walked (stored) order; plan without perm. */
+int tsgu_csr_sddmm_tile(int vtype, const tsgu_tile_plan* plan, const void* R, int64_t ldr, const void* Cm, int64_t ldc, void* out_vals,
+                        double alpha, int64_t p, int device, void* stream);
+
+/*
  * Lattice plane-sweep kernels ("lattice"): same reference lines as tsgu_csr_spmm (sparse_matmul.py:155,229) and
  * tsgu_csr_sddmm (sparse_matmul.py:186-205, sparse_solve.py:216-235,487-504), for patterns that are stencils on a
  * row-major lattice:  row = ((item·nx + x)·ny + y)·nz + z,  every stored entry (row, col) has col = the lattice point at
@@ -421,13 +460,16 @@ int tsgu_lattice_block_classes(int64_t n_rows, const void* rcls, int nb, int nx,
  * (b_col_stride = 1: row-major; transposed views are read in place), X is row-major.
  * fp32, fp64 and bf16 (bf16 elements, fp32 arithmetic, x rounded once when it is published).
  * `work` : device scratch, tsgu_sptrsm_work_bytes() bytes, contents irrelevant on entry.
+ * `workgroups_per_cu` : persistent workgroups (4 waves each) per compute unit, 1 … 8 (0 = 1).  Speed only — every row sums its own
+ *          entries in a fixed order, the solution does not depend on it: deep dependency chains want few polling waves (1), shallow
+ *          wide patterns want many rows in flight (8).  (ABI 5: new argument.)
  */
 int tsgu_csr_sptrsm(int vtype, int itype,
                     int64_t n, int64_t nnz,
                     const void* ptr, const void* idx, const void* perm, const void* val,
                     int lower, int unit,
                     const void* B, int64_t ldb, int64_t b_col_stride, void* X, int64_t ldx, int64_t p,
-                    void* work, int device, void* stream);
+                    void* work, int workgroups_per_cu, int device, void* stream);
 int64_t tsgu_sptrsm_work_bytes(int64_t n, int64_t p);
 
 /*

@@ -621,7 +621,7 @@ def test_triangular_all_flags_layouts_batched():
         B = G.t(Bn, DEV).requires_grad_(True)
         x = tsgu().sparse_triangular_solve(A, B, upper=u == "u1", unitriangular=d == "d1", transpose=t == "t1")
         x.backward(G.t(z[name + "G"], DEV))
-        tol = 2e-5 if vn == "f32" else 1e-10
+        tol = 1e-5 if vn == "f32" else 1e-10      # north_star's bar (round 5: K4 divides by the diagonal; measured <= 2.3e-7)
         assert rel(x, z[name + "x"]) < tol, name
         assert rel(B.grad, z[name + "gradB"]) < tol, name
         gA = A.grad

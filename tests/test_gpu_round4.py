@@ -148,7 +148,7 @@ def _tri_bound(Td, x64, unit):
 def test_triangular_solutions_within_their_condition_bound():
     """All eight flag combinations x COO / CSR x batched of the reference's golden cases: every element of x and gradB within
     (n + 4)·eps of the componentwise bound M(T)^{-1}|T||x| — the reference's own fp32 output is held to the same bound, which is
-    what justifies comparing the two at 2e-5 normwise in tests/test_gpu_parity.py: the cases' conditioning, not the kernels."""
+    the condition-aware companion of the 1e-5 normwise comparison in tests/test_gpu_parity.py (round 5: K4 divides by the diagonal like the reference; the goldens agree to <= 2.3e-7)."""
     z = G.load("tri_flags.npz")
     checked = 0
     for name in z["names"]:
@@ -198,7 +198,7 @@ def test_compat_sparse_branch_matches_the_reference_for_all_flags():
         A = G.sparse_from(z, name + "A_", shape, DEV, requires_grad=True)
         x = linalg_solve_triangular_compat(A, G.t(Bn, DEV), upper=u == "u1", unitriangular=d == "d1", transpose=t == "t1")
         assert not x.requires_grad and x.shape == Bn.shape
-        assert G.rel_err(x.cpu().numpy(), z[name + "x"]) < (2e-5 if vn == "f32" else 1e-10), name
+        assert G.rel_err(x.cpu().numpy(), z[name + "x"]) < (1e-5 if vn == "f32" else 1e-10), name
     with pytest.raises(ValueError):
         linalg_solve_triangular_compat(torch.eye(3, device=DEV).to_sparse_csc(), torch.ones(3, 1, device=DEV), upper=True)
 

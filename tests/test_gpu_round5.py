@@ -144,6 +144,13 @@ def test_fresh_index_tensors_with_known_content_adopt_the_plan():
     for _ in range(8):                         # the original tensors: plans settle (C++ host path included)
         ref = step(crow, col)
         wait_for_plans()
+    base = []
+    for _ in range(4):                         # the same step, same tensors, timed the same way (a sync on either side)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        step(crow, col)
+        torch.cuda.synchronize()
+        base.append((time.perf_counter() - t0) * 1e3)
     before = dict(_pattern.STATS)
     times = []
     for i in range(6):
@@ -156,7 +163,9 @@ def test_fresh_index_tensors_with_known_content_adopt_the_plan():
         assert got[1].crow_indices().data_ptr() == cr.data_ptr() and got[1].col_indices().data_ptr() == co.data_ptr()
         assert torch.equal(got[0], ref[0]) and torch.equal(got[1].values(), ref[1].values()) and torch.equal(got[2], ref[2]), i
     assert _pattern.STATS["adopted"] - before["adopted"] == 6
-    assert min(times[2:]) < 0.6, times          # (the verdict's bar is 0.30 ms on an idle box: bench.py reports the figure; 11 ms without adoption)
+    # one pass over the indices + one host read on top of the same step with known tensors (bench.py reports the pipelined figure;
+    # without adoption every such step pays the ~11 ms analysis)
+    assert min(times[2:]) < min(base) + 0.2, (times, base)
     # different content of the same geometry is NOT adopted …
     co2 = col.clone()
     co2[:27] = col[:27].flip(0)
@@ -181,3 +190,127 @@ def test_index_fingerprint_is_a_function_of_content_only():
     assert not torch.equal(f2[0], f1[0]) and (x[5] == x[6] or not torch.equal(f2[1], f1[0]))
     assert torch.equal(f2[2], f1[0])          # the index dtype is geometry, not content
     assert torch.equal(be.index_fingerprint(x[:0])[0], torch.zeros(2, dtype=torch.int64, device=DEV))
+
+
+# ---- row-block tile kernels (csrc/tile_impl.h): general patterns whose neighbouring rows share columns ----------------------------
+
+
+def _tile_patterns():
+    from torchsparsegradutils_amd.utils import synthetic
+
+    out = {}
+    out["mesh27_blocked"] = synthetic.mesh27_blocked(12, 8, 16, 4, torch.int32, DEV)             # 4^3 bricks, truncated rows (8 … 27 entries)
+    out["mesh27_odd"] = synthetic.mesh27_blocked(9, 7, 11, 4, torch.int32, DEV)                    # rows not a multiple of 64, ragged bricks
+    cr, co = synthetic.box_stencil(10, 12, 14, (False, True, False), 7, None, torch.int64, DEV)    # int64 indices, short rows
+    out["stencil7_i64"] = (cr, co)
+    # a banded factor with empty rows and one long row
+    g = torch.Generator().manual_seed(5)
+    n = 1000
+    rows, cols = [], []
+    for i in range(n):
+        if i % 37 == 5:
+            continue
+        k = 60 if i == 500 else int(torch.randint(1, 9, (1,), generator=g))
+        c = torch.unique(torch.clamp(i - torch.randint(0, 24 if i != 500 else 120, (k,), generator=g), min=0))
+        rows.append(torch.full((c.numel(),), i))
+        cols.append(c)
+    rows, cols = torch.cat(rows), torch.cat(cols)
+    crow = torch.zeros(n + 1, dtype=torch.int64)
+    crow[1:] = torch.cumsum(torch.bincount(rows, minlength=n), 0)
+    out["banded_ragged"] = (crow.to(torch.int32).to(DEV), cols.to(torch.int32).to(DEV))
+    return out
+
+
+@pytest.mark.parametrize("name", ["mesh27_blocked", "mesh27_odd", "stencil7_i64", "banded_ragged"])
+def test_tile_kernels_equal_the_plan_free_kernels_bit_for_bit(name):
+    """All three products of the step on the row-block tile kernels — forward, SDDMM in stored order, Aᵀ·G on the transposed pattern's
+    tiles through A's own values — sum in ascending entry order of the walked pattern, like the plan-free kernels: the same bits.
+    Against the oracle at 1e-5 and every element within 8·eps·Σ|its terms| as well."""
+    from oracle import oracle
+    from torchsparsegradutils_amd import _backend as be
+    from torchsparsegradutils_amd import _pattern
+
+    crow, col = _tile_patterns()[name]
+    n, nnz, p = crow.numel() - 1, col.numel(), 32
+    g = torch.Generator(device=DEV).manual_seed(4)
+    val = torch.randn(nnz, device=DEV, generator=g)
+    B = torch.randn(n, p, device=DEV, generator=g)
+    Gd = torch.randn(n, p, device=DEV, generator=g)
+    geo = be.tile_geometry(torch.float32, p)
+    assert geo is not None
+    plan = _pattern.RowGather(crow, col, n, n)
+    tp = plan.tile_plan(geo)
+    tt = plan.transposed.tile_plan(geo)
+    assert tp is not None and tt is not None and tt.perm is not None, "the pattern should qualify for row-block tiles"
+    C = be.csr_spmm_tile(tp, val, B)
+    gA = be.csr_sddmm_tile(tp, Gd, B)
+    gB = be.csr_spmm_tile(tt, val, Gd)
+    pt = plan.transposed
+    assert torch.equal(C, be.csr_spmm(crow, col, val, B, n, n))
+    assert torch.equal(gA, be.csr_sddmm(crow, col, Gd, B, n, n))
+    assert torch.equal(gB, be.csr_spmm(pt.crow, pt.col, val, Gd, n, n, perm=pt.perm))
+    assert torch.equal(be.csr_sddmm_tile(tp, Gd, B, alpha=-1.0), -gA)
+    cn, on, vn = crow.cpu().numpy(), col.cpu().numpy(), val.cpu().numpy()
+    Co, gAo, gBo = oracle.sparse_mm_fwd_bwd(cn, on, vn, B.cpu().numpy(), Gd.cpu().numpy(), n)
+    for got, ref, what in ((C, Co, "C"), (gA, gAo, "gradA"), (gB, gBo, "gradB")):
+        assert G.rel_err(got.cpu().numpy(), ref) < 1e-5, what
+    v64, b64, g64 = vn.astype(np.float64), B.cpu().numpy().astype(np.float64), Gd.cpu().numpy().astype(np.float64)
+    exact = oracle.sparse_mm_fwd_bwd(cn, on, v64, b64, g64, n)
+    mags = oracle.sparse_mm_fwd_bwd(cn, on, np.abs(v64), np.abs(b64), np.abs(g64), n)
+    for got, ex, mg, what in zip((C, gA, gB), exact, mags, ("C", "gradA", "gradB")):
+        err = np.abs(got.double().cpu().numpy().reshape(ex.shape) - ex)
+        assert float((err / (8 * EPS32 * mg + 1e-300)).max()) <= 1.0, what
+
+
+def test_tile_kernels_never_touch_a_dense_row_a_row_does_not_reference():
+    """Non-finite operands behave as in the reference: a NaN / inf in a dense row only reaches the sparse rows that reference it
+    (the walk's tail runs under a predicate, padded tile slots repeat a referenced row and are never read)."""
+    from torchsparsegradutils_amd import _backend as be
+    from torchsparsegradutils_amd import _pattern
+
+    crow, col = _tile_patterns()["mesh27_odd"]
+    n, nnz, p = crow.numel() - 1, col.numel(), 32
+    g = torch.Generator(device=DEV).manual_seed(6)
+    val = torch.randn(nnz, device=DEV, generator=g)
+    B = torch.randn(n, p, device=DEV, generator=g)
+    bad = 123
+    B[bad] = float("nan")
+    plan = _pattern.RowGather(crow, col, n, n)
+    tp = plan.tile_plan(be.tile_geometry(torch.float32, p))
+    C = be.csr_spmm_tile(tp, val, B)
+    rows = plan.row_indices()
+    touched = torch.zeros(n, dtype=torch.bool, device=DEV)
+    touched[rows[col == bad].long()] = True
+    assert torch.equal(torch.isnan(C).any(dim=1), touched)
+
+
+def test_tile_kernels_through_the_public_api(monkeypatch):
+    """sparse_mm on a brick-numbered mesh (not a lattice): from the second use on the step runs on the tile kernels; C, gradA (A's own
+    index tensors, int32 kept) and gradB equal the plan-free first step bit for bit."""
+    from torchsparsegradutils_amd import _ops, _pattern, sparse_mm, wait_for_plans
+
+    monkeypatch.setattr(_ops, "PACK_MIN_NNZ", 1)
+    monkeypatch.setattr(_ops, "PLAN_ASYNC", False)
+    crow, col = _tile_patterns()["mesh27_blocked"]
+    n, nnz, p = crow.numel() - 1, col.numel(), 32
+    g = torch.Generator(device=DEV).manual_seed(8)
+    val = torch.randn(nnz, device=DEV, generator=g)
+    A = torch.sparse_csr_tensor(crow, col, val, (n, n)).requires_grad_(True)
+    B = torch.randn(n, p, device=DEV, generator=g).requires_grad_(True)
+    Gd = torch.randn(n, p, device=DEV, generator=g)
+    _pattern.clear_cache()
+
+    def step():
+        C = sparse_mm(A, B)
+        gA, gB = torch.autograd.grad(C, (A, B), Gd)
+        return C, gA, gB
+
+    first = step()                      # plan-free
+    for _ in range(3):
+        got = step()
+        wait_for_plans()
+    core = _pattern.from_csr(A.detach()).core
+    assert any(type(v).__name__ == "TilePlan" for v in core.packs.values()), "the tile plan was not built"
+    assert any(type(v).__name__ == "TilePlan" for v in core.t.core.packs.values()), "the transposed tile plan was not built"
+    assert torch.equal(got[0], first[0]) and torch.equal(got[1].values(), first[1].values()) and torch.equal(got[2], first[2])
+    assert got[1].crow_indices().dtype == torch.int32 and got[1].col_indices().data_ptr() == col.data_ptr()

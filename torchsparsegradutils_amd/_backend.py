@@ -34,12 +34,17 @@ _ptr = ctypes.c_void_p
 _dbl = ctypes.c_double
 
 # name -> (restype, argtypes); must list every symbol declared in include/tsgu_hip.h
+ABI_VERSION = 5          # TSGU_ABI_VERSION of include/tsgu_hip.h this binding was written against
+
 SIGNATURES = {
     "tsgu_abi_version": (_int, []),
     "tsgu_status_string": (ctypes.c_char_p, [_int]),
     "tsgu_device_info": (_int, [_int, ctypes.c_char_p, _int, ctypes.POINTER(_int), ctypes.POINTER(_int)]),
     "tsgu_device_copy": (_int, [_ptr, _ptr, _i64, _int, _ptr]),
     "tsgu_index_fingerprint": (_int, [_int, _i64, _ptr, _ptr, _int, _ptr]),
+    "tsgu_tile_geometry": (_int, [_int, _i64, ctypes.POINTER(_int), ctypes.POINTER(_int), ctypes.POINTER(_int)]),
+    "tsgu_csr_spmm_tile": (_int, [_int, _ptr, _ptr, _ptr, _i64, _ptr, _i64, _i64, _int, _ptr]),
+    "tsgu_csr_sddmm_tile": (_int, [_int, _ptr, _ptr, _i64, _ptr, _i64, _ptr, _dbl, _i64, _int, _ptr]),
     "tsgu_csr_spmm": (
         _int,
         [_int, _int, _i64, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _ptr, _i64, _i64, _i64, _i64, _i64, _i64,
@@ -100,7 +105,7 @@ SIGNATURES = {
     "tsgu_lattice_block_classes": (_int, [_i64, _ptr, _int, _int, _int, _int, _int, _int, _int, _ptr, _int, _ptr]),
     "tsgu_csr_sptrsm": (
         _int,
-        [_int, _int, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _int, _int, _ptr, _i64, _i64, _ptr, _i64, _i64, _ptr, _int, _ptr],
+        [_int, _int, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _int, _int, _ptr, _i64, _i64, _ptr, _i64, _i64, _ptr, _int, _int, _ptr],
     ),
     "tsgu_sptrsm_work_bytes": (_i64, [_i64, _i64]),
     "tsgu_cg_fold_rows": (_i64, []),
@@ -146,7 +151,7 @@ def load_library():
             fn = getattr(lib, name)  # AttributeError => header/library mismatch, fail loudly
             fn.restype = res
             fn.argtypes = args
-        if lib.tsgu_abi_version() != 4:
+        if lib.tsgu_abi_version() != ABI_VERSION:
             raise HipExtensionMissing("libtsgu_hip.so ABI version mismatch; rebuild the extension")
         _lib = lib
     return _lib
@@ -421,6 +426,56 @@ def csr_sddmm_rowpack(crow, rp, R, Cm, n_rows: int, alpha: float = 1.0):
             ),
             "tsgu_csr_sddmm_rowpack",
         )
+    return out
+
+
+# ---- row-block tile kernels (csrc/tile_impl.h) --------------------------------------------------------------------------------
+@functools.lru_cache(maxsize=None)
+def tile_geometry(dtype: torch.dtype, p: int):
+    """(rows_per_block, max_union, max_entries) of the tile kernels for (dtype, p), or None when they are not compiled for it."""
+    if dtype != torch.float32 or p <= 0:
+        return None
+    lib = load_library()
+    r, u, e = _int(0), _int(0), _int(0)
+    if lib.tsgu_tile_geometry(_VTYPE[dtype], p, ctypes.byref(r), ctypes.byref(u), ctypes.byref(e)) != 0:
+        return None
+    return r.value, u.value, e.value
+
+
+def _tile_struct(tp):
+    st = tp._cstruct
+    if st is None:
+        from ._tile import TilePlanStruct
+
+        st = TilePlanStruct(tp.n_rows, tp.n_cols, tp.nnz, tp.n_blocks, tp.rows_per_block, tp.max_union, tp.max_entries, 0, _p(tp.desc),
+                            _p(tp.ucol), _p(tp.lidx), _p(tp.rptr), _p(tp.perm))
+        tp._cstruct = st
+    return ctypes.addressof(st)
+
+
+def csr_spmm_tile(tp, val, B):
+    """C = A·B (a plan with `perm`: Aᵀ·G through A's own values) by the row-block tile walk."""
+    lib = load_library()
+    dev = require_device(val, B)
+    B = rowmajor(B)
+    p = B.size(-1)
+    out = torch.empty((tp.n_rows, p), dtype=B.dtype, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.tsgu_csr_spmm_tile(vtype_of(val), _tile_struct(tp), _p(val.contiguous()), _p(B), _ld(B), _p(out), _ld(out), p, dev.index,
+                                     _stream(dev)), "tsgu_csr_spmm_tile")
+    return out
+
+
+def csr_sddmm_tile(tp, R, Cm, alpha: float = 1.0):
+    """out[k] = alpha·<R[row k], Cm[col k]> in stored order by the row-block tile walk (plan of a stored-order pattern)."""
+    lib = load_library()
+    dev = require_device(R, Cm)
+    R, Cm = rowmajor(R), rowmajor(Cm)
+    p = R.size(-1)
+    out = torch.empty((tp.nnz,), dtype=R.dtype, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.tsgu_csr_sddmm_tile(vtype_of(R), _tile_struct(tp), _p(R), _ld(R), _p(Cm), _ld(Cm), _p(out), float(alpha), p, dev.index,
+                                      _stream(dev)), "tsgu_csr_sddmm_tile")
     return out
 
 
@@ -733,8 +788,9 @@ def coo_sddmm(row, col, G, B, alpha: float = 1.0):
     return out
 
 
-def csr_sptrsm(ptr, idx, val, B, n: int, lower: bool, unit: bool, perm=None):
-    """X = M^{-1} B for the row-gather structure (ptr, idx, [perm], val) of a triangular M."""
+def csr_sptrsm(ptr, idx, val, B, n: int, lower: bool, unit: bool, perm=None, wg_per_cu: int = 1):
+    """X = M^{-1} B for the row-gather structure (ptr, idx, [perm], val) of a triangular M.  `wg_per_cu`: persistent workgroups per
+    compute unit (1 … 8; speed only, see include/tsgu_hip.h)."""
     lib = load_library()
     dev = require_device(ptr, idx, val, B, perm)
     if val.dtype != B.dtype:
@@ -755,7 +811,7 @@ def csr_sptrsm(ptr, idx, val, B, n: int, lower: bool, unit: bool, perm=None):
         check(
             lib.tsgu_csr_sptrsm(
                 vtype_of(val), itype_of(ptr), n, idx.numel(), _p(ptr), _p(idx), _p(perm), _p(val),
-                int(bool(lower)), int(bool(unit)), _p(B), ldb, b_cs, _p(X), _ld(X), p, _p(work), dev.index, _stream(dev),
+                int(bool(lower)), int(bool(unit)), _p(B), ldb, b_cs, _p(X), _ld(X), p, _p(work), int(wg_per_cu), dev.index, _stream(dev),
             ),
             "tsgu_csr_sptrsm",
         )

@@ -33,6 +33,12 @@ PLAN_AFTER_USES = int(os.environ.get("TSGU_PLAN_AFTER_USES", "1"))
 PLAN_ASYNC = os.environ.get("TSGU_PLAN_ASYNC", "1") == "1"
 
 
+# Row-block tile kernels (csrc/tile_impl.h): general patterns whose neighbouring rows share columns (mesh orderings, banded factors,
+# FEM matrices): a block's distinct dense rows are staged in LDS one block ahead of the walk.  Chosen before the row pairs when the
+# pattern qualifies (every block's tile fits, entries share dense rows); TSGU_ENABLE_TILE=0 disables.
+ENABLE_TILE = os.environ.get("TSGU_ENABLE_TILE", "1") == "1"
+
+
 # Lattice plane-sweep kernels (csrc/lattice_impl.h): patterns that are stencils on a row-major lattice (what the
 # reference's PairwiseEncoder and its stencil benchmarks produce) are walked tile by tile with the halo of the dense
 # operand in LDS.  First choice when the pattern qualifies; anything else takes the row-pair / plan-free kernels.
@@ -223,6 +229,25 @@ def _pack_for(plan: RowGather, dense: torch.Tensor, *others: torch.Tensor, need_
     return plan.rowpack_plan(rpb, limits, explicit_slots=entry_lanes > 1)
 
 
+def _tile_for(plan: RowGather, dense: torch.Tensor, *others: torch.Tensor):
+    """TilePlan of the 2-D `plan` for these dense operands, or None (disabled / not compiled for them / the pattern does not qualify
+    or has not come back yet)."""
+    if (not ENABLE_TILE or plan.batch is not None or dense.dim() != 2 or plan.nnz < PACK_MIN_NNZ
+            or plan.crow.dtype not in (torch.int32, torch.int64)):
+        return None
+    geo = _be.tile_geometry(dense.dtype, dense.size(-1))
+    if geo is None:
+        return None
+    ops = tuple(_be.rowmajor(t) for t in (dense,) + others)
+    if not _be._tiled_ok(*ops) or any(t.dtype != dense.dtype or t.size(0) * max(t.stride(0), 1) * t.element_size() >= 2**32 for t in ops):
+        return None
+    if not plan.seen_enough(PLAN_AFTER_USES):
+        return None
+    if PLAN_ASYNC and PLAN_AFTER_USES > 0 and not torch.are_deterministic_algorithms_enabled():
+        return plan.tile_plan(geo, asynchronous=True)
+    return plan.tile_plan(geo)
+
+
 def _flat(plan: RowGather, *dense: torch.Tensor):
     """(block-diagonal 2-D plan, flattened dense operands) of a batched problem, or None when the operands are not
     batch-contiguous (the plain kernels then take the batch as gridDim.y)."""
@@ -287,6 +312,11 @@ def mm_backward(plan: RowGather, values: torch.Tensor, G: torch.Tensor, B: torch
                 ga, gb = _be.csr_mm_backward_rowpack(fplan.transposed.crow, rp, values.reshape(-1), Gf, Bf, fplan.n_cols)
                 return ga.view(values.shape), gb.view(B.shape)
     t = plan.transposed
+    if same and plan.batch is None and plan.perm is None:
+        # row-block tiles: the SDDMM in stored order + the transposed product on the transposed pattern's tiles (A's own values)
+        tp, tt = _tile_for(plan, B, G), _tile_for(t, G)
+        if tp is not None and tt is not None:
+            return _be.csr_sddmm_tile(tp, G, B), _be.csr_spmm_tile(tt, values, G)
     rp = _pack_for(t, G, B) if same else None
     if rp is not None and rp.srcstart is not None and plan.batch is None and plan.perm is None:
         # the transposed plan reached the dictionary form through row-relative value positions (mesh orderings): the SDDMM on the
@@ -324,6 +354,9 @@ def spmm(plan: RowGather, values: torch.Tensor, B: torch.Tensor, owner: RowGathe
                 if rp is not None:
                     out = _be.csr_spmm_rowpack(fplan.crow, values.reshape(-1), rp, Bf, fplan.n_rows)
                     return out.view(B.size(0), plan.n_rows, B.size(-1))
+        tp = _tile_for(plan, B)
+        if tp is not None:
+            return _be.csr_spmm_tile(tp, values, B)
         rp = _pack_for(plan, B)
         if rp is not None:
             return _be.csr_spmm_rowpack(plan.crow, values, rp, B, plan.n_rows)
@@ -357,6 +390,9 @@ def sddmm(plan: RowGather, G: torch.Tensor, B: torch.Tensor, alpha: float = 1.0,
         got = _lattice_cfg(plan, _be.LAT_SDDMM, gathered, rowop)
         if got is not None:
             return _be.csr_sddmm_lattice(got[0], got[1], rowop, gathered, alpha=alpha)
+        tp = _tile_for(plan, gathered, rowop)
+        if tp is not None:
+            return _be.csr_sddmm_tile(tp, rowop, gathered, alpha=alpha)
         rp = _pack_for(plan, gathered, rowop, need_plain_slots=True)
         if rp is not None and rp.upos is None:
             return _be.csr_sddmm_rowpack(plan.crow, rp, rowop, gathered, plan.n_rows, alpha=alpha)

@@ -139,6 +139,37 @@ class RowGather:
         step for the plan's device sorts).  Results do not depend on when the switch happens beyond the documented
         difference between the two kernel families."""
         key = (rows_per_block, tuple(limits), bool(explicit_slots) or self.perm is not None, group)
+        return self._plan_async(key, lambda view: view._build_rowpack(rows_per_block, limits, explicit_slots, group),
+                                lambda plan: (plan.uptr, plan.ucol, plan.upos, plan.sperm, plan.order, plan.vpair, plan.eptr, plan.wcls,
+                                              plan.wbase, plan.cne, plan.srcstart))
+
+    def tile_plan(self, geo, asynchronous: bool = False):
+        """Plan of the row-block tile kernels (csrc/tile_impl.h; `geo` = (rows per block, max distinct columns, max entries) from
+        tsgu_tile_geometry), None when the pattern does not qualify; cached with the pattern.  `asynchronous`: built on the worker
+        thread + side stream, None until it is ready (see rowpack_plan_async)."""
+        key = ("tile",) + tuple(geo)
+        if asynchronous:
+            return self._plan_async(key, lambda view: view._build_tile(geo), lambda plan: (plan.desc, plan.ucol, plan.lidx, plan.rptr, plan.perm))
+        packs = self.core.packs
+        if key not in packs:
+            fut = self.core.pending.get(key)
+            if fut is not None:
+                fut.result()
+                return self.tile_plan(geo, asynchronous=True)
+            packs[key] = self._build_tile(geo)
+        return packs[key]
+
+    def _build_tile(self, geo):
+        from . import _tile
+
+        if self.batch is not None or self.crow.dtype not in (torch.int32, torch.int64):
+            return None
+        return _tile.build_tile_plan(self.crow, self.col, self.n_rows, self.n_cols, geo[0], geo[1], geo[2], perm=self.perm,
+                                     rows=self.row_indices())
+
+    def _plan_async(self, key, build, tensors_of):
+        """Generic asynchronous plan build: `build(view)` runs on the worker thread's side stream, the plan is handed out (and its
+        tensors `tensors_of(plan)` are handed to the caller's stream) by the first call after it has finished."""
         core = self.core
         if key in core.packs:
             return core.packs[key]
@@ -159,7 +190,7 @@ class RowGather:
                     side = _side_stream(dev)
                     with torch.cuda.stream(side):
                         side.wait_event(ready)
-                        plan = view._build_rowpack(rows_per_block, limits, explicit_slots, group)
+                        plan = build(view)
                         done = torch.cuda.Event()
                         done.record(side)
                 return plan, done
@@ -173,7 +204,7 @@ class RowGather:
         try:
             plan, done = fut.result()
         except Exception as exc:  # noqa: BLE001  (a failed background build must never break the caller's step)
-            warnings.warn(f"torchsparsegradutils_amd: asynchronous row-pair plan build failed ({exc!r}); "
+            warnings.warn(f"torchsparsegradutils_amd: asynchronous plan build failed ({exc!r}); "
                           "this pattern stays on the plan-free kernels", RuntimeWarning, stacklevel=2)
             with _PENDING_LOCK:
                 core.packs[key] = None
@@ -186,7 +217,7 @@ class RowGather:
         main = torch.cuda.current_stream(dev)
         main.wait_event(done)
         if plan is not None:
-            for t in (plan.uptr, plan.ucol, plan.upos, plan.sperm, plan.order, plan.vpair, plan.eptr, plan.wcls, plan.wbase, plan.cne, plan.srcstart):
+            for t in tensors_of(plan):
                 if t is not None:
                     t.record_stream(main)   # allocated on the side stream, used on the caller's from now on
         with _PENDING_LOCK:
@@ -725,12 +756,18 @@ def _core_for(kind: str, tensors, shape) -> _Core:
     if fp is not None:
         with _CACHE_LOCK:
             live = [c for c in _CACHE.values() if c.geom == geom and c.fp is not None]
-        seen = set()
-        for c in reversed(live):
-            if id(c) not in seen and torch.equal(c.fp, fp):      # (the host read: only when a live entry has this geometry)
-                adopted = c
-                break
-            seen.add(id(c))
+        uniq = list({id(c): c for c in reversed(live)}.values())
+        if uniq:
+            # ONE device-to-host copy (the only host read, and only when a live entry has this geometry): the new fingerprint and
+            # those of the candidates whose words are not on the host yet
+            missing = [c for c in uniq if "fp_host" not in c.own]
+            words = torch.stack([fp] + [c.fp for c in missing]).cpu().reshape(len(missing) + 1, -1).tolist()
+            for c, w in zip(missing, words[1:]):
+                c.own["fp_host"] = w
+            for c in uniq:
+                if c.own["fp_host"] == words[0]:
+                    adopted = c
+                    break
     with _CACHE_LOCK:
         if adopted is not None:
             core = adopted

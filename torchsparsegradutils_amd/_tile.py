@@ -1,0 +1,96 @@
+"""Plans of the row-block tile kernels (csrc/tile_impl.h, ``tsgu_tile_plan`` in include/tsgu_hip.h).
+
+A plan is value independent and built once per sparsity pattern (cached with it): for every block of ``rows_per_block`` consecutive
+rows the ascending list of DISTINCT columns its rows reference (the block's tile, copied to LDS by the kernel one block ahead of the
+walk) and, per stored entry, one byte naming the entry's column inside that list.  The reference re-derives its structure on every
+call (``repeat_interleave`` of the row pointer, the CSC→CSR sort inside ``torch.sparse.mm(A.t(), ·)``; sparse_matmul.py:186-192,229).
+
+A pattern qualifies when every block's tile fits the kernel's LDS budget (``max_union`` rows) and the tiles are worth staging:
+on average an entry must share its dense row with others of its block (``REUSE_MIN``) — a random band matrix, whose rows share
+nothing, stays on the gather kernels.
+"""
+
+from __future__ import annotations
+
+import ctypes
+from typing import Optional
+
+import torch
+
+# stored entries per distinct dense row of a block below which a tile is not worth staging (a 27-point mesh numbered in 4^3 bricks: 8.0;
+# a banded random matrix: ~1.0)
+REUSE_MIN = 2.0
+
+
+class TilePlan:
+    """Device arrays of one ``tsgu_tile_plan`` (+ its ctypes image, cached by _backend)."""
+
+    __slots__ = ("n_rows", "n_cols", "nnz", "n_blocks", "rows_per_block", "max_union", "max_entries", "desc", "ucol", "lidx", "rptr", "perm",
+                 "reuse", "_cstruct")
+
+    def __init__(self, **kw):
+        for k in self.__slots__:
+            setattr(self, k, kw.get(k))
+
+    def plan_bytes(self) -> int:
+        return sum(t.numel() * t.element_size() for t in (self.desc, self.ucol, self.lidx, self.rptr) if t is not None)
+
+
+def build_tile_plan(crow: torch.Tensor, col: torch.Tensor, n_rows: int, n_cols: int, rows_per_block: int, max_union: int, max_entries: int,
+                    perm: Optional[torch.Tensor] = None, rows: Optional[torch.Tensor] = None, reuse_min: float = REUSE_MIN) -> Optional[TilePlan]:
+    """TilePlan of the 2-D pattern (crow, col) or None when it does not qualify.  Tensor ops on the pattern's device: one sort of
+    (block, column) keys + a few scans; the only host reads are the two limits and the reuse figure."""
+    nnz = col.numel()
+    if n_rows <= 0 or nnz <= 0 or nnz >= 2**31 or n_rows >= 2**31 or n_cols >= 2**31:
+        return None
+    dev = col.device
+    R = rows_per_block
+    nb = (n_rows + R - 1) // R
+    crow64 = crow.to(torch.int64)
+    if rows is None:
+        rows = torch.repeat_interleave(torch.arange(n_rows, device=dev, dtype=torch.int64), crow64[1:] - crow64[:-1], output_size=nnz)
+    blk = rows.to(torch.int64) // R
+    e0 = crow64[0:n_rows:R]                                             # first entry of every block
+    e1 = torch.cat((e0[1:], crow64[n_rows:n_rows + 1]))
+    if int((e1 - e0).max()) > max_entries:
+        return None
+    key = blk * n_cols + col.to(torch.int64)
+    ukey, inv = torch.unique(key, sorted=True, return_inverse=True)
+    ublk = ukey // n_cols
+    cnt = torch.bincount(ublk, minlength=nb)                            # distinct columns per block
+    if int(cnt.max()) > max_union:
+        return None
+    reuse = nnz / max(int(ukey.numel()), 1)
+    if reuse < reuse_min:
+        return None
+    first = torch.zeros(nb + 1, dtype=torch.int64, device=dev)
+    first[1:] = torch.cumsum(cnt, 0)                                    # unpadded offsets of the blocks' lists in ukey
+    padded = (cnt + 7) // 8 * 8                                         # lists padded to whole 8-row DMA instructions
+    u0 = torch.zeros(nb + 1, dtype=torch.int64, device=dev)
+    u0[1:] = torch.cumsum(padded, 0)
+    total = int(u0[-1])
+    if total >= 2**31:
+        return None
+    # ucol: every padded slot holds the block's LAST column (a harmless duplicate request), then the real lists are scattered in
+    last_col = (ukey % n_cols)[first[1:] - 1]
+    ucol = torch.repeat_interleave(last_col, padded, output_size=total)
+    pos = u0[ublk] + (torch.arange(ukey.numel(), device=dev, dtype=torch.int64) - first[ublk])
+    ucol[pos] = ukey % n_cols
+    lidx = torch.zeros(nnz + 16, dtype=torch.uint8, device=dev)
+    lidx[:nnz] = (inv - first[blk]).to(torch.uint8)
+    desc = torch.zeros((nb + 4, 4), dtype=torch.int32, device=dev)
+    desc[:nb, 0] = u0[:-1].to(torch.int32)
+    desc[:nb, 1] = padded.to(torch.int32)
+    desc[:nb, 2] = e0.to(torch.int32)
+    desc[:nb, 3] = (e1 - e0).to(torch.int32)
+    return TilePlan(n_rows=n_rows, n_cols=n_cols, nnz=nnz, n_blocks=nb, rows_per_block=R, max_union=max_union, max_entries=max_entries,
+                    desc=desc.contiguous(), ucol=ucol.to(torch.int32).contiguous(), lidx=lidx, rptr=crow.to(torch.int32).contiguous(),
+                    perm=None if perm is None else perm.to(torch.int32).contiguous(), reuse=reuse, _cstruct=None)
+
+
+class TilePlanStruct(ctypes.Structure):
+    """``tsgu_tile_plan`` of include/tsgu_hip.h."""
+
+    _fields_ = [("n_rows", ctypes.c_int64), ("n_cols", ctypes.c_int64), ("nnz", ctypes.c_int64), ("n_blocks", ctypes.c_int64),
+                ("rows_per_block", ctypes.c_int32), ("max_union", ctypes.c_int32), ("max_entries", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("desc", ctypes.c_void_p), ("ucol", ctypes.c_void_p), ("lidx", ctypes.c_void_p), ("rptr", ctypes.c_void_p), ("perm", ctypes.c_void_p)]

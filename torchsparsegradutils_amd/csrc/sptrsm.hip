@@ -216,7 +216,7 @@ __global__ __launch_bounds__(kBlock) void sptrsm_syncfree_kernel(const TrsmParam
 }
 
 template <typename V, typename I>
-int sptrsm_launch(const TrsmParams& P, int n_cu, hipStream_t stream) {
+int sptrsm_launch(const TrsmParams& P, int n_cu, int wg_per_cu, hipStream_t stream) {
     // fill X with the "not ready" tag and reset tickets
     {
         int64_t nb = (P.n * P.p + kBlock - 1) / kBlock;
@@ -227,13 +227,15 @@ int sptrsm_launch(const TrsmParams& P, int n_cu, hipStream_t stream) {
     const int cl = P.p >= 64 ? 64 : next_pow2(P.p);
     const int64_t tiles = (P.p + cl - 1) / cl;
     if (tiles > 64) return TSGU_ERR_TOO_LARGE;
-    // persistent grid: ONE workgroup (4 waves) per CU.  Every resident wave polls, and the hop latency is
-    // paid in the consumer CU's memory queue: 32 polling waves per CU measured 1.46 us per dependency
-    // level at C3, 4 per CU 1.21 us.  Never more waves than rows.
-#ifndef TSGU_TRSM_BLOCKS_PER_CU
-#define TSGU_TRSM_BLOCKS_PER_CU 1
-#endif
-    int64_t blocks = (int64_t)n_cu * TSGU_TRSM_BLOCKS_PER_CU;
+    // persistent grid, `wg_per_cu` workgroups (4 waves each) per CU, default ONE.  Every resident wave polls, and the hop latency is
+    // paid in the consumer CU's memory queue: 32 polling waves per CU measured 1.46 us per dependency level at C3 (2 673 levels,
+    // ~100 rows each), 4 per CU 1.21 us.  A SHALLOW pattern (the reference's published shape: one random off-diagonal entry per
+    // row, a few dozen levels of thousands of rows) is bound by the rows in flight instead — a wave spends ~3 us of dependent
+    // loads per row — and wants every wave the CU can hold.  The caller chooses (a measured choice per pattern in
+    // sparse_solve.py); the result does not depend on it.  Never more waves than rows.
+    if (wg_per_cu < 1) wg_per_cu = 1;
+    if (wg_per_cu > 8) wg_per_cu = 8;
+    int64_t blocks = (int64_t)n_cu * wg_per_cu;
 
     const int64_t need = (P.n + 3) / 4;
     if (blocks > need) blocks = need;
@@ -271,7 +273,7 @@ int tsgu_csr_sptrsm(int vtype, int itype, int64_t n, int64_t nnz,
                     const void* ptr, const void* idx, const void* perm, const void* val,
                     int lower, int unit,
                     const void* B, int64_t ldb, int64_t b_col_stride, void* X, int64_t ldx, int64_t p,
-                    void* work, int device, void* stream) {
+                    void* work, int workgroups_per_cu, int device, void* stream) {
     if (n < 0 || nnz < 0 || p < 0) return TSGU_ERR_BAD_ARG;
     if (n == 0 || p == 0) return TSGU_OK;
     if (!ptr || !B || !X || !work || (nnz > 0 && (!idx || !val))) return TSGU_ERR_BAD_ARG;
@@ -302,14 +304,14 @@ int tsgu_csr_sptrsm(int vtype, int itype, int64_t n, int64_t nnz,
     P.timeout_ticks = 400000000LL;  // 4 s at the 100 MHz wall clock
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (vtype == TSGU_F32) {
-        if (itype == TSGU_I32) return sptrsm_launch<float, int32_t>(P, n_cu, s);
-        if (itype == TSGU_I64) return sptrsm_launch<float, int64_t>(P, n_cu, s);
+        if (itype == TSGU_I32) return sptrsm_launch<float, int32_t>(P, n_cu, workgroups_per_cu, s);
+        if (itype == TSGU_I64) return sptrsm_launch<float, int64_t>(P, n_cu, workgroups_per_cu, s);
     } else if (vtype == TSGU_F64) {
-        if (itype == TSGU_I32) return sptrsm_launch<double, int32_t>(P, n_cu, s);
-        if (itype == TSGU_I64) return sptrsm_launch<double, int64_t>(P, n_cu, s);
+        if (itype == TSGU_I32) return sptrsm_launch<double, int32_t>(P, n_cu, workgroups_per_cu, s);
+        if (itype == TSGU_I64) return sptrsm_launch<double, int64_t>(P, n_cu, workgroups_per_cu, s);
     } else if (vtype == TSGU_BF16) {
-        if (itype == TSGU_I32) return sptrsm_launch<bf16_t, int32_t>(P, n_cu, s);
-        if (itype == TSGU_I64) return sptrsm_launch<bf16_t, int64_t>(P, n_cu, s);
+        if (itype == TSGU_I32) return sptrsm_launch<bf16_t, int32_t>(P, n_cu, workgroups_per_cu, s);
+        if (itype == TSGU_I64) return sptrsm_launch<bf16_t, int64_t>(P, n_cu, workgroups_per_cu, s);
     }
     return TSGU_ERR_BAD_DTYPE;
 }

@@ -1,0 +1,333 @@
+// Row-block tile kernels ("tile"): general CSR patterns whose neighbouring rows share columns, WITHOUT a lattice — mesh orderings,
+// banded factors, FEM matrices (the matrices the reference itself benchmarks: benchmarks/results/sparse_mm_suite_results.csv).
+//
+// Why: the gather kernels (spmm_impl.h, rowpack_impl.h) pull every referenced dense row through the vector L1 — 18-27 requests of
+// 128 B per sparse row — and the row-pair walk spends ~25 VALU + 4 LDS instructions per union entry (EXPERIMENTS.md §9): on a
+// brick-numbered mesh they reach 29 % of the roofline where the plane sweep reaches 60 %.  This family gives such patterns the
+// sweep's STRUCTURE: a persistent workgroup walks a run of row blocks (R = 64 consecutive rows); the DISTINCT dense rows a block
+// references (its "tile": 216 rows for a 4^3 brick of a 27-point mesh, listed once per pattern in the plan) arrive in LDS by 16-byte
+// LDS-DMA one block AHEAD of the walk (double buffer), next to the block's slice of the value array and one byte per entry that
+// names the entry's dense row inside the tile.  The walk is then: one byte + one value + one 16-byte LDS read + the FMAs per entry,
+// accumulators in registers, no per-entry records, no ownership tests.
+//
+// Plan (built once per pattern by _tile.py, layout in include/tsgu_hip.h):
+//   desc[b] = {u0, U, e0, E}   block b: its tile is ucol[u0 .. u0+U) (ascending distinct columns, padded to a multiple of 8 with
+//                              repeats of the last one), its entries are e0 .. e0+E of the walked pattern
+//   lidx[k]                    position of entry k's column inside its block's tile (one byte: U <= 256)
+//   rptr                       int32 row pointer of the walked pattern
+//   perm (optional)            position of entry k in the value array (the transposed pattern walks A's own values: Aᵀ·G)
+//
+// Modes: kTileSpmm  C = A·B (perm: Aᵀ·G on the transposed pattern); kTileSddmm  out[k] = alpha·<R[row k], Cm[col k]> in stored order.
+// Sums run in ascending entry order of the walked pattern: the same order — and the same bits — as the plan-free kernels.
+//
+// Synchronisation: the bulk streams (tile rows, values, entry bytes, row pointer slice) are LDS-DMA issued from inline asm — invisible
+// to hipcc's s_waitcnt bookkeeping, which would otherwise drain them at the first LDS read — and a step ends with `s_waitcnt
+// vmcnt(0)` + `s_barrier`.  The few words a thread needs to ISSUE the next DMAs (its tile rows' column numbers, its value
+// positions, the SDDMM's own rows) are ordinary loads issued right after the DMAs of a step and first used at the top of the next
+// one, i.e. behind that wait: hipcc's own wait for them never drains a DMA.
+#pragma once
+
+#include "march_impl.h"      // lat_dma16 / lat_dma4 / lat_step_sync / lat_lds_addr
+
+namespace tsgu {
+
+enum TileMode { kTileSpmm = 0, kTileSddmm = 1 };
+
+constexpr int kTileRows = 64;       // rows per block
+constexpr int kTileUMax = 224;      // distinct dense rows per block (multiple of 8)
+constexpr int kTileEMax = 2048;     // entries per block
+constexpr int kTileThreads = 256;
+constexpr int kTileUP = kTileUMax * 8 / kTileThreads;      // 16-byte tile pieces per thread at 8 chunks per dense row (CL = 8)
+constexpr int kTileEP = kTileEMax / kTileThreads;          // value dwords per thread
+
+struct TileDesc {
+    int u0, U, e0, E;
+};
+
+struct TileParams {
+    int64_t n_rows, n_cols, nnz, n_blocks;
+    const TileDesc* desc;        // [n_blocks + 4] (four trailing empty blocks: the pipeline reads ahead)
+    const int* ucol;
+    const unsigned char* lidx;   // [nnz + 16]
+    const int* rptr;             // [n_rows + 1]
+    const int* perm;             // optional [nnz]
+    const void* val;             // SpMM: values
+    const void* S;               // gathered dense operand (B; Cm for the SDDMM)
+    int64_t lds_;
+    const void* Own;             // SDDMM: row operand R
+    int64_t ldown;
+    void* out;                   // C [n_rows][p]
+    int64_t ldo;
+    void* gvals;                 // SDDMM output [nnz]
+    float alpha;
+    int blocks_per_wg;
+};
+
+// LDS layout (bytes): two buffers of {tile | values | entry bytes | row pointer slice} + one zero row
+template <int RB>
+struct TileLds {
+    static constexpr int kTile = kTileUMax * RB;
+    static constexpr int kVals = kTileEMax * 4;
+    static constexpr int kLidx = kTileEMax + 16;
+    static constexpr int kRs = (kTileRows + 8) * 4;
+    static constexpr int kBuf = kTile + kVals + kLidx + kRs;
+    static constexpr int oVals = kTile, oLidx = kTile + kVals, oRs = kTile + kVals + kLidx;
+    static constexpr int kTotal = 2 * kBuf;
+};
+
+// wave-uniform copy of a descriptor (scalar registers: its fields go into lane predicates and M0-relative addresses)
+__device__ __forceinline__ TileDesc tile_uniform(const TileDesc d) {
+    return TileDesc{__builtin_amdgcn_readfirstlane(d.u0), __builtin_amdgcn_readfirstlane(d.U), __builtin_amdgcn_readfirstlane(d.e0),
+                    __builtin_amdgcn_readfirstlane(d.E)};
+}
+
+// smallest value over the wave of a per-row quantity (all lanes of a row's group hold the same value)
+template <int CL>
+__device__ __forceinline__ int tile_wave_min(int x) {
+#pragma unroll
+    for (int m = CL; m < kWave; m <<= 1) {
+        const int y = __shfl_xor(x, m, kWave);
+        x = y < x ? y : x;
+    }
+    return __builtin_amdgcn_readfirstlane(x);
+}
+
+template <typename V, int CL, int MODE, bool PERM>
+__global__ __launch_bounds__(kTileThreads, 2) void tile_kernel(const TileParams P) {
+    static_assert(std::is_same<V, float>::value, "fp32 only (so far)");
+    constexpr int RB = CL * 16;                    // bytes of a dense row
+    constexpr int RPW = kWave / CL;                // rows per wave and pass
+    constexpr int NW = kTileThreads / kWave;
+    constexpr int PASSES = kTileRows / (RPW * NW);
+    constexpr int UP = kTileUMax * CL / kTileThreads;
+    using L = TileLds<RB>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char tile_lds[];
+    const unsigned lds0 = lat_lds_addr(tile_lds);
+
+    const int t = threadIdx.x, lane = t & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(t / kWave);      // (a scalar: it goes into M0 for the DMA destinations)
+    const int sub = lane % CL, grp = lane / CL;
+    const int64_t vb = xcd_chunked_block(blockIdx.x, gridDim.x);
+    const int64_t b_first = vb * P.blocks_per_wg;
+    const int nloc = (int)((P.n_blocks - b_first) < P.blocks_per_wg ? (P.n_blocks - b_first) : P.blocks_per_wg);
+    if (nloc <= 0) return;
+    const TileDesc* __restrict__ desc = P.desc + b_first;
+    const float* __restrict__ S = static_cast<const float*>(P.S);
+    const uint32_t ld_bytes = (uint32_t)P.lds_ * 4u;
+    const unsigned wave_piece = (unsigned)(wave * kWave);
+
+    // Every compiler-visible global load of the loop below is FIRST USED behind the `s_waitcnt vmcnt(0)` that ends the step it was
+    // issued in (hipcc's own wait for it is then free); a load consumed inside the same step would make hipcc drain the DMAs.
+    int ucolr[UP];                                       // column numbers of this thread's tile pieces of the block staged next
+    int permr[PERM ? kTileEP : 1];                       // value positions of this thread's entries of the block staged next
+    uint4 own_cur[MODE == kTileSddmm ? PASSES : 1];      // SDDMM: own rows of the block being walked …
+    uint4 own_nxt[MODE == kTileSddmm ? PASSES : 1];      // … and of the next one
+#pragma unroll
+    for (int i = 0; i < UP; ++i) ucolr[i] = 0;
+
+    auto load_words = [&](const TileDesc d) {            // for the block staged one step later
+#pragma unroll
+        for (int i = 0; i < UP; ++i) {
+            const int u = (t / CL) + i * (kTileThreads / CL);
+            if (u < d.U) ucolr[i] = P.ucol[d.u0 + u];
+        }
+        if constexpr (PERM) {
+#pragma unroll
+            for (int i = 0; i < kTileEP; ++i) {
+                const int e = t + i * kTileThreads;
+                if (e < d.E) permr[i] = P.perm[(int64_t)d.e0 + e];
+            }
+        }
+    };
+
+    auto stage = [&](int k, const TileDesc d) {          // issue the DMAs of block k into buffer k & 1
+        const unsigned buf = lds0 + (unsigned)(k & 1) * L::kBuf;
+#pragma unroll
+        for (int i = 0; i < UP; ++i) {
+            const int u = (t / CL) + i * (kTileThreads / CL);
+            if (u < d.U)
+                lat_dma16<false>(S, (uint32_t)ucolr[i] * ld_bytes + (uint32_t)sub * 16u, buf + (wave_piece + (unsigned)i * kTileThreads) * 16u);
+        }
+        if constexpr (MODE == kTileSpmm) {
+#pragma unroll
+            for (int i = 0; i < kTileEP; ++i) {
+                const int e = t + i * kTileThreads;
+                if (e < d.E) {
+                    if constexpr (PERM) lat_dma4<false>(P.val, (uint32_t)permr[i] * 4u, buf + L::oVals + (wave_piece + (unsigned)i * kTileThreads) * 4u);
+                    else lat_dma4<true>(P.val, (uint32_t)(d.e0 + e) * 4u, buf + L::oVals + (wave_piece + (unsigned)i * kTileThreads) * 4u);
+                }
+            }
+        }
+        {   // entry bytes: dwords from the 4-byte aligned address below e0 (the walk adds e0 & 3)
+            const int a0 = d.e0 & ~3, nd = (d.e0 + d.E - a0 + 3) >> 2;
+#pragma unroll
+            for (int i = 0; i < (kTileEMax / 4 + 1 + kTileThreads - 1) / kTileThreads; ++i) {
+                const int q = t + i * kTileThreads;
+                if (q < nd) lat_dma4<true>(P.lidx, (uint32_t)(a0 + q * 4), buf + L::oLidx + (wave_piece + (unsigned)i * kTileThreads) * 4u);
+            }
+        }
+        {   // row pointer slice: rptr[r0 .. r0 + R]
+            const int64_t r0 = (b_first + k) * kTileRows;
+            const int nr = (int)((P.n_rows - r0) < kTileRows ? (P.n_rows - r0) : kTileRows) + 1;
+            if (t < nr) lat_dma4<true>(P.rptr, (uint32_t)(r0 + t) * 4u, buf + L::oRs + wave_piece * 4u);
+        }
+    };
+
+    auto load_own = [&](int k) {                         // SDDMM: the own rows of block k
+        if constexpr (MODE == kTileSddmm) {
+            const float* Own = static_cast<const float*>(P.Own);
+            const int64_t r0 = (b_first + k) * kTileRows;
+#pragma unroll
+            for (int ps = 0; ps < PASSES; ++ps) {
+                const int64_t r = r0 + (ps * NW + wave) * RPW + grp;
+                own_nxt[ps] = r < P.n_rows ? *reinterpret_cast<const uint4*>(Own + r * P.ldown + sub * 4) : uint4{0, 0, 0, 0};
+            }
+        }
+    };
+
+    auto walk = [&](int k, const TileDesc d) {
+        const unsigned char* buf = tile_lds + (k & 1) * L::kBuf;
+        const float* vals = reinterpret_cast<const float*>(buf + L::oVals);
+        const unsigned char* lid = buf + L::oLidx + (d.e0 & 3);
+        const int* rs = reinterpret_cast<const int*>(buf + L::oRs);
+        const int64_t r0 = (b_first + k) * kTileRows;
+        const unsigned char* trow = buf + sub * 16;
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) {
+            const int rl = (ps * NW + wave) * RPW + grp;
+            const int64_t r = r0 + rl;
+            const bool live = r < P.n_rows;
+            const int s = live ? rs[rl] - d.e0 : 0, e = live ? rs[rl + 1] - d.e0 : 0;
+            if constexpr (MODE == kTileSpmm) {
+                float acc[4] = {0.f, 0.f, 0.f, 0.f};
+                // four entries at a time for as long as EVERY row of the wave has four left (a scalar trip count: no predicates), …
+                const int nfull = tile_wave_min<CL>((e - s) >> 2);
+                int kk = s;
+                for (int it = 0; it < nfull; ++it) {
+                    float v[4];
+                    unsigned li[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        li[j] = lid[kk + j];
+                        v[j] = vals[kk + j];
+                    }
+                    float4 bj[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) bj[j] = *reinterpret_cast<const float4*>(trow + li[j] * RB);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        acc[0] = fmaf(v[j], bj[j].x, acc[0]);
+                        acc[1] = fmaf(v[j], bj[j].y, acc[1]);
+                        acc[2] = fmaf(v[j], bj[j].z, acc[2]);
+                        acc[3] = fmaf(v[j], bj[j].w, acc[3]);
+                    }
+                    kk += 4;
+                }
+                // … then entry by entry under a predicate (a row never touches a dense row it does not reference)
+                while (__any(kk < e)) {
+                    if (kk < e) {
+                        const unsigned li = lid[kk];
+                        const float v = vals[kk];
+                        const float4 bj = *reinterpret_cast<const float4*>(trow + li * RB);
+                        acc[0] = fmaf(v, bj.x, acc[0]);
+                        acc[1] = fmaf(v, bj.y, acc[1]);
+                        acc[2] = fmaf(v, bj.z, acc[2]);
+                        acc[3] = fmaf(v, bj.w, acc[3]);
+                    }
+                    ++kk;
+                }
+                if (live) store_vec<float, 4, true>(static_cast<float*>(P.out) + r * P.ldo + sub * 4, acc);
+            } else {
+                static_assert(MODE != kTileSddmm || CL == 8, "the transposed reduction below is written for 8 lanes per row");
+                const float g0 = __uint_as_float(own_cur[ps].x), g1 = __uint_as_float(own_cur[ps].y), g2 = __uint_as_float(own_cur[ps].z),
+                            g3 = __uint_as_float(own_cur[ps].w);
+                float* gv = static_cast<float*>(P.gvals) + d.e0;
+                // eight entries per round: lane `sub` of the row's group ends with the dot of entry kk + sub (transposed tree: after the step
+                // over lane bit m a lane keeps the entries whose bit m equals its own).  Partner sub ^ 4 = half mirror + quad reversal.
+                auto reduce8 = [&](const float (&part)[8]) -> float {
+                    float h4[4], h2[2];
+                    const bool up4 = (sub & 4) != 0, up2 = (sub & 2) != 0, up1 = (sub & 1) != 0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float keep = up4 ? part[j + 4] : part[j], give = up4 ? part[j] : part[j + 4];
+                        h4[j] = keep + dpp_move<0x1B>(dpp_move<0x141>(give));
+                    }
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const float keep = up2 ? h4[j + 2] : h4[j], give = up2 ? h4[j] : h4[j + 2];
+                        h2[j] = keep + dpp_move<0x4E>(give);
+                    }
+                    const float keep = up1 ? h2[1] : h2[0], give = up1 ? h2[0] : h2[1];
+                    return keep + dpp_move<0xB1>(give);
+                };
+                const int nfull = tile_wave_min<CL>((e - s) >> 3);
+                int kk = s;
+                for (int it = 0; it < nfull; ++it) {
+                    unsigned li[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) li[j] = lid[kk + j];
+                    float part[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float4 bj = *reinterpret_cast<const float4*>(trow + li[j] * RB);
+                        part[j] = fmaf(g3, bj.w, fmaf(g2, bj.z, fmaf(g1, bj.y, g0 * bj.x)));
+                    }
+                    gv[kk + sub] = P.alpha * reduce8(part);
+                    kk += 8;
+                }
+                while (__any(kk < e)) {
+                    float part[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        part[j] = 0.f;
+                        if (kk + j < e) {
+                            const unsigned li = lid[kk + j];
+                            const float4 bj = *reinterpret_cast<const float4*>(trow + li * RB);
+                            part[j] = fmaf(g3, bj.w, fmaf(g2, bj.z, fmaf(g1, bj.y, g0 * bj.x)));
+                        }
+                    }
+                    const float h = reduce8(part);
+                    if (kk + sub < e) gv[kk + sub] = P.alpha * h;
+                    kk += 8;
+                }
+            }
+        }
+    };
+
+    // ---- pipeline: descriptors three blocks ahead, a thread's words two, DMA one, walk ---------------------------------------
+    TileDesc d0 = tile_uniform(desc[0]), d1 = tile_uniform(desc[1]), d2 = tile_uniform(desc[2]);
+    TileDesc raw = desc[3];
+    load_words(d0);
+#pragma unroll
+    for (int i = 0; i < UP; ++i) lat_pin(ucolr[i]);
+    if constexpr (PERM) {
+#pragma unroll
+        for (int i = 0; i < kTileEP; ++i) lat_pin(permr[i]);
+    }
+    stage(0, d0);
+    load_own(0);
+    load_words(d1);
+    lat_step_sync();
+    for (int k = 0; k < nloc; ++k) {
+        const TileDesc d3 = tile_uniform(raw);          // (loaded during the previous step)
+        // every word loaded during the previous step is pinned HERE, in straight-line code, before the first DMA of this step: hipcc
+        // otherwise places its wait for ucolr[i] inside the predicated block of piece i — behind the DMA of piece i - 1
+#pragma unroll
+        for (int i = 0; i < UP; ++i) lat_pin(ucolr[i]);
+        if constexpr (PERM) {
+#pragma unroll
+            for (int i = 0; i < kTileEP; ++i) lat_pin(permr[i]);
+        }
+#pragma unroll
+        for (int ps = 0; ps < (MODE == kTileSddmm ? PASSES : 1); ++ps) own_cur[ps] = own_nxt[ps];
+        if (k + 1 < nloc) stage(k + 1, d1);             // (uses the words loaded during step k - 1)
+        if (k + 2 < nloc) load_words(d2);
+        if (k + 1 < nloc) load_own(k + 1);
+        raw = desc[k + 4];
+        walk(k, d0);
+        lat_step_sync();
+        d0 = d1, d1 = d2, d2 = d3;
+    }
+}
+
+}  // namespace tsgu

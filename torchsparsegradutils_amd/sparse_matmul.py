@@ -134,7 +134,8 @@ def _settle_step_plan(op: "_Operand", values: torch.Tensor, G: torch.Tensor, B: 
         if _ops.ENABLE_LATTICE and _ops._lattice_cfg(plan, _be.LAT_SPMM, B) is not None:
             return
         t = plan.transposed
-        if plan.core.pending or t.core.pending or _ops._pack_for(plan, B) is not None or _ops._pack_for(t, G, B) is not None:
+        if (plan.core.pending or t.core.pending or _ops._pack_for(plan, B) is not None or _ops._pack_for(t, G, B) is not None
+                or _ops._tile_for(plan, B, G) is not None):
             return
         if not (B.is_contiguous() and G.is_contiguous() and plan.crow.is_contiguous() and plan.col.is_contiguous()
                 and t.crow.is_contiguous() and t.col.is_contiguous() and t.perm is not None and t.perm.is_contiguous()):

@@ -13,6 +13,7 @@ autograd contract), computing on the gfx950 kernels:
 
 from __future__ import annotations
 
+import os
 import warnings
 from typing import Callable, Optional, cast
 
@@ -102,10 +103,53 @@ def _solve(plan: _pt.RowGather, values, rhs, upper: bool, unit: bool, transpose:
         from . import _cpu
 
         return _cpu.sptrsm(plan, values, rhs, upper, unit, transpose)
-    if transpose:
-        pt = plan.transposed  # rows of Aᵀ; the selected triangle flips side
-        return _be.csr_sptrsm(pt.crow, pt.col, values, rhs, pt.n_rows, lower=upper, unit=unit, perm=pt.perm)
-    return _be.csr_sptrsm(plan.crow, plan.col, values, rhs, plan.n_rows, lower=not upper, unit=unit, perm=plan.perm)
+    pt = plan.transposed if transpose else plan      # transposed: rows of Aᵀ; the selected triangle flips side
+    lower = upper if transpose else not upper
+
+    def run(wg_per_cu):
+        return _be.csr_sptrsm(pt.crow, pt.col, values, rhs, pt.n_rows, lower=lower, unit=unit, perm=pt.perm, wg_per_cu=wg_per_cu)
+
+    return run(_sweep_width(pt, lower, unit, rhs, run))
+
+
+# Persistent workgroups per CU of the sync-free sweep: a measured choice per (pattern, triangle, width), made at the pattern's
+# third solve.  Deep dependency chains (C3: 2 673 levels) are fastest with ONE workgroup per CU — every extra polling wave lengthens
+# the hop; shallow patterns (the reference's published shape, benchmarks/sparse_triangular_solve_rand.py: one random off-diagonal
+# entry per row) are bound by the rows in flight and want all eight.  The solution does not depend on it (every row sums its own
+# entries in a fixed order), so the choice is speed only; TSGU_SPTRSM_TUNE=0 keeps one workgroup per CU.
+SWEEP_TUNE = os.environ.get("TSGU_SPTRSM_TUNE", "1") != "0"
+SWEEP_TUNE_AFTER = 2
+SWEEP_WIDTHS = (1, 2, 4, 8)
+
+
+def _sweep_width(pt: _pt.RowGather, lower: bool, unit: bool, rhs: torch.Tensor, run) -> int:
+    if not SWEEP_TUNE or pt.n_rows < 4096:
+        return 1
+    memo = pt.core.own.get("sweep_width")
+    if memo is None:
+        memo = pt.core.own["sweep_width"] = {}
+    key = (bool(lower), bool(unit), rhs.dtype, rhs.size(-1))
+    got = memo.get(key)
+    if isinstance(got, int) and got > 0:
+        return got
+    seen = memo[key] = (got or 0) - 1          # (negative: solves seen so far)
+    if -seen <= SWEEP_TUNE_AFTER or torch.cuda.is_current_stream_capturing():
+        return 1
+    best, best_ms = 1, None
+    for w in SWEEP_WIDTHS:
+        run(w)
+        ts = []
+        for _ in range(2):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            run(w)
+            e1.record()
+            e1.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        if best_ms is None or min(ts) < 0.95 * best_ms:      # (a wider sweep has to win by 5 %: ties keep the fewer polling waves)
+            best, best_ms = w, min(ts)
+    memo[key] = best
+    return best
 
 
 class SparseTriangularSolve(torch.autograd.Function):

@@ -481,12 +481,8 @@ def _fused_loop(op, rhs_is_zero, x, r, has_converged, n_iter, max_iter, toleranc
             if try_graph and graph is None and k > min_iter_index and n_iter - k >= _graph.MIN_ITERS:
                 # long solves: capture _POLL iterations once as a hipGraph and replay it (one host call per
                 # chunk instead of 6 launches per iteration; finished iterations are device-side no-ops)
-                # (a capture that fails part-way has run nothing on the device: the host's view of the parity must not move either)
-                saved = dict(state)
                 graph = _graph.capture(iteration, _POLL)
                 try_graph = graph is not None
-                if graph is None:
-                    state.update(saved)
             if graph is not None and k + _POLL <= n_iter:
                 _graph.replay(graph)
                 k += _POLL
