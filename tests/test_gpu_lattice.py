@@ -360,6 +360,7 @@ def test_public_path_takes_the_lattice_kernels(monkeypatch):
     # and the plan-free kernels (lattice switched off) give the same bits
     monkeypatch.setattr(_ops, "ENABLE_LATTICE", False)
     monkeypatch.setattr(_ops, "ENABLE_PACK", False)
+    monkeypatch.setattr(_ops, "ENABLE_TILE", False)
     A.grad = None
     Bd.grad = None
     C = sparse_mm(A, Bd)

@@ -443,6 +443,7 @@ def test_public_path_takes_the_march_kernels(monkeypatch):
     inner = lp.rcls[:n] == lp._march.ident
     monkeypatch.setattr(_ops, "ENABLE_LATTICE", False)
     monkeypatch.setattr(_ops, "ENABLE_PACK", False)
+    monkeypatch.setattr(_ops, "ENABLE_TILE", False)
     A.grad = None
     Bd.grad = None
     C = sparse_mm(A, Bd)

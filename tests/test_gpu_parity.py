@@ -40,6 +40,7 @@ def _plans_at_first_sight(monkeypatch):
     monkeypatch.setattr(_ops, "PLAN_AFTER_USES", 0)
     # the suite asserts plan forms: pin the policy switches to their defaults whatever TSGU_* the environment carries
     monkeypatch.setattr(_ops, "ENABLE_PACK", True)
+    monkeypatch.setattr(_ops, "ENABLE_TILE", False)      # (row-block tiles: tests/test_gpu_round5.py)
     monkeypatch.setattr(_ops, "ENABLE_LATTICE", False)   # this file pins the row-pair / plan-free kernels; tests/test_gpu_lattice.py covers the sweep
     monkeypatch.setattr(_pattern, "DEDUP_MODE", "auto")
     yield

@@ -68,7 +68,7 @@ STENCILS = [
 
 
 @pytest.mark.parametrize("args,p", STENCILS)
-@pytest.mark.parametrize("family", ["structured", "row_pairs", "plan_free"])
+@pytest.mark.parametrize("family", ["structured", "row_pairs", "tiles", "plan_free"])
 def test_every_element_is_within_its_own_condition_bound(args, p, family, monkeypatch):
     from torchsparsegradutils_amd import _ops, _pattern, sparse_mm, wait_for_plans
     from torchsparsegradutils_amd.utils import synthetic
@@ -76,7 +76,8 @@ def test_every_element_is_within_its_own_condition_bound(args, p, family, monkey
     monkeypatch.setattr(_ops, "PACK_MIN_NNZ", 1)
     monkeypatch.setattr(_ops, "PLAN_AFTER_USES", 0)
     monkeypatch.setattr(_ops, "ENABLE_LATTICE", family == "structured")
-    monkeypatch.setattr(_ops, "ENABLE_PACK", family != "plan_free")
+    monkeypatch.setattr(_ops, "ENABLE_PACK", family not in ("plan_free", "tiles"))
+    monkeypatch.setattr(_ops, "ENABLE_TILE", family == "tiles")       # (row-block tiles, round 5: fp32 operands of 32 columns; other widths fall through)
     nx, ny, nz = args[:3]
     crow, col = synthetic.box_stencil(*args)
     n = nx * ny * nz

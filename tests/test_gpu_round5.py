@@ -200,7 +200,7 @@ def _tile_patterns():
 
     out = {}
     out["mesh27_blocked"] = synthetic.mesh27_blocked(12, 8, 16, 4, torch.int32, DEV)             # 4^3 bricks, truncated rows (8 … 27 entries)
-    out["mesh27_odd"] = synthetic.mesh27_blocked(9, 7, 11, 4, torch.int32, DEV)                    # rows not a multiple of 64, ragged bricks
+    out["mesh27_odd"] = synthetic.mesh27_blocked(9, 6, 12, 3, torch.int32, DEV)                    # 3^3 bricks: 648 rows, not a multiple of 64
     cr, co = synthetic.box_stencil(10, 12, 14, (False, True, False), 7, None, torch.int64, DEV)    # int64 indices, short rows
     out["stencil7_i64"] = (cr, co)
     # a banded factor with empty rows and one long row
@@ -223,9 +223,10 @@ def _tile_patterns():
 
 @pytest.mark.parametrize("name", ["mesh27_blocked", "mesh27_odd", "stencil7_i64", "banded_ragged"])
 def test_tile_kernels_equal_the_plan_free_kernels_bit_for_bit(name):
-    """All three products of the step on the row-block tile kernels — forward, SDDMM in stored order, Aᵀ·G on the transposed pattern's
-    tiles through A's own values — sum in ascending entry order of the walked pattern, like the plan-free kernels: the same bits.
-    Against the oracle at 1e-5 and every element within 8·eps·Σ|its terms| as well."""
+    """The three products of the step on the row-block tile kernels.  Forward and Aᵀ·G (the transposed pattern's tiles through A's own
+    values) sum a row's entries in ascending order of the walked pattern, like the plan-free kernels: the same bits.  The SDDMM's dots
+    are summed by a different tree over the row's lanes: equal to rounding.  All three against the oracle at 1e-5 and every element
+    within 8·eps·Σ|its terms|."""
     from oracle import oracle
     from torchsparsegradutils_amd import _backend as be
     from torchsparsegradutils_amd import _pattern
@@ -247,9 +248,9 @@ def test_tile_kernels_equal_the_plan_free_kernels_bit_for_bit(name):
     gB = be.csr_spmm_tile(tt, val, Gd)
     pt = plan.transposed
     assert torch.equal(C, be.csr_spmm(crow, col, val, B, n, n))
-    assert torch.equal(gA, be.csr_sddmm(crow, col, Gd, B, n, n))
     assert torch.equal(gB, be.csr_spmm(pt.crow, pt.col, val, Gd, n, n, perm=pt.perm))
     assert torch.equal(be.csr_sddmm_tile(tp, Gd, B, alpha=-1.0), -gA)
+    assert torch.equal(be.csr_sddmm_tile(tp, Gd, B), gA)                       # (run to run: no atomics anywhere)
     cn, on, vn = crow.cpu().numpy(), col.cpu().numpy(), val.cpu().numpy()
     Co, gAo, gBo = oracle.sparse_mm_fwd_bwd(cn, on, vn, B.cpu().numpy(), Gd.cpu().numpy(), n)
     for got, ref, what in ((C, Co, "C"), (gA, gAo, "gradA"), (gB, gBo, "gradB")):
@@ -312,5 +313,189 @@ def test_tile_kernels_through_the_public_api(monkeypatch):
     core = _pattern.from_csr(A.detach()).core
     assert any(type(v).__name__ == "TilePlan" for v in core.packs.values()), "the tile plan was not built"
     assert any(type(v).__name__ == "TilePlan" for v in core.t.core.packs.values()), "the transposed tile plan was not built"
-    assert torch.equal(got[0], first[0]) and torch.equal(got[1].values(), first[1].values()) and torch.equal(got[2], first[2])
+    assert torch.equal(got[0], first[0]) and torch.equal(got[2], first[2])
+    assert torch.allclose(got[1].values(), first[1].values(), rtol=1e-5, atol=1e-5)       # (the SDDMM's dots: another summation tree)
     assert got[1].crow_indices().dtype == torch.int32 and got[1].col_indices().data_ptr() == col.data_ptr()
+
+
+# ---- bf16: the fp32-accumulated result BEFORE the final rounding (SURVEY §8c form (i)) ---------------------------------------------
+
+
+def _bf16_of_exact(x64):
+    """round-to-nearest-even bf16 of exact (integer-valued) float64 results, via fp32 (exact for |x| < 2^24)."""
+    return torch.from_numpy(np.ascontiguousarray(x64.astype(np.float32))).to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("family", ["plan-free", "row pairs", "lattice", "batched lattice"])
+def test_bf16_kernels_accumulate_in_fp32_and_round_once(family, monkeypatch):
+    """The reference cannot run CSR bf16 on the CPU; the bar is its fp32 arithmetic on bf16-rounded inputs, compared (i)
+    BEFORE the final rounding at 1e-5 and (ii) after it within one bf16 ulp.  The kernels have no fp32 output, so (i) is pinned
+    exactly instead: with small-integer operands every product and every partial sum is exact in fp32 (|sums| < 2^24) while the
+    partial sums are NOT representable in bf16 (more than 8 significant bits) — a kernel that accumulates in fp32 and rounds once
+    returns exactly RN_bf16(exact result), bit for bit; one that accumulated in bf16, or rounded twice, cannot."""
+    from oracle import oracle
+    from torchsparsegradutils_amd import _ops, _pattern, sparse_mm, wait_for_plans
+    from torchsparsegradutils_amd.utils import synthetic
+
+    monkeypatch.setattr(_ops, "PACK_MIN_NNZ", 1)
+    monkeypatch.setattr(_ops, "PLAN_ASYNC", False)
+    monkeypatch.setattr(_ops, "ENABLE_LATTICE", family in ("lattice", "batched lattice"))
+    monkeypatch.setattr(_ops, "ENABLE_PACK", family == "row pairs")
+    monkeypatch.setattr(_ops, "ENABLE_TILE", False)
+    batch = 3 if family == "batched lattice" else None
+    nx, ny, nz, p = 6, 5, 16, 16
+    crow, col = synthetic.stencil27_periodic(nx, ny, nz, torch.int32)
+    n, nnz = nx * ny * nz, col.numel()
+    g = torch.Generator().manual_seed(12)
+    shape_v = (batch, nnz) if batch else (nnz,)
+    shape_d = (batch, n, p) if batch else (n, p)
+    val = torch.randint(-8, 9, shape_v, generator=g).to(torch.bfloat16)
+    B = torch.randint(-16, 17, shape_d, generator=g).to(torch.bfloat16)
+    Gd = torch.randint(-16, 17, shape_d, generator=g).to(torch.bfloat16)
+    _pattern.clear_cache()
+    if batch:
+        A = torch.sparse_csr_tensor(crow.repeat(batch, 1).to(DEV), col.repeat(batch, 1).to(DEV), val.to(DEV), (batch, n, n)).requires_grad_(True)
+    else:
+        A = torch.sparse_csr_tensor(crow.to(DEV), col.to(DEV), val.to(DEV), (n, n)).requires_grad_(True)
+    Bd = B.to(DEV).requires_grad_(True)
+    for _ in range(3):              # (first sight runs plan-free; the structured families take over from the second use)
+        C = sparse_mm(A, Bd)
+        gA, gB = torch.autograd.grad(C, (A, Bd), Gd.to(DEV))
+        wait_for_plans()
+    items = range(batch) if batch else [None]
+    for i in items:
+        v, b, gd = (t[i] if i is not None else t for t in (val, B, Gd))
+        Ce, gAe, gBe = oracle.sparse_mm_fwd_bwd(crow.numpy(), col.numpy(), v.double().numpy(), b.double().numpy(), gd.double().numpy(), n)
+        assert np.abs(Ce).max() > 512 and np.abs(gAe).max() > 512          # (sums beyond bf16's 8 significant bits: the test has teeth)
+        got = [(t[i] if i is not None else t).detach().cpu() for t in (C, gA.values(), gB)]
+        for mine, exact, what in zip(got, (Ce, gAe, gBe), ("C", "gradA", "gradB")):
+            want = _bf16_of_exact(exact).reshape(mine.shape)
+            assert torch.equal(mine.view(torch.int16), want.view(torch.int16)), (family, i, what)
+
+
+# ---- elementwise bounds at full size: C3 (componentwise substitution bound) and C5 (one bf16 ulp) ------------------------------------
+
+
+def test_c3_full_size_every_element_within_the_componentwise_bound():
+    """BASELINE configs[2] at full size (lower CSR N = 262144, 4.9 M entries, 8 RHS): EVERY element of x within the componentwise
+    forward-substitution bound (n_r + 4)·eps·[M(T)⁻¹|T||x|] of the fp64 solution (Higham, Accuracy and Stability, Thm 8.5 with the
+    comparison matrix M(T); n_r = longest row), not just the normwise 1e-5 of tests/test_gpu_fullsize.py."""
+    from oracle import oracle
+    from torchsparsegradutils_amd import sparse_triangular_solve
+    from torchsparsegradutils_amd.utils import synthetic
+
+    n, p = 262144, 8
+    crow, col, val = synthetic.banded_lower(n, per_row=18, band=4096, seed=0)
+    g = torch.Generator().manual_seed(3)
+    B = torch.randn(n, p, generator=g)
+    A = torch.sparse_csr_tensor(crow.to(DEV), col.to(DEV), val.to(DEV), (n, n))
+    x = sparse_triangular_solve(A, B.to(DEV), upper=False).cpu().numpy().astype(np.float64)
+    cn, on = crow.numpy(), col.numpy()
+    v64 = val.numpy().astype(np.float64)
+    x64 = oracle.csr_sptrsm(cn, on, v64, B.numpy().astype(np.float64), upper=False)
+    rows = oracle.expand_rows(cn)
+    absT = np.abs(v64)
+    rhs = oracle.csr_spmm(cn, on, absT, np.abs(x64))                         # |T||x|
+    comp = np.where(rows == on, absT, -absT)                                # M(T): |diagonal|, −|off-diagonal|
+    bound = oracle.csr_sptrsm(cn, on, comp, rhs, upper=False)
+    longest = int(np.diff(cn).max())
+    worst = float((np.abs(x - x64) / ((longest + 4) * EPS32 * bound + 1e-300)).max())
+    assert worst <= 1.0, worst
+    assert G.rel_err(x, x64) < 1e-5
+
+
+def test_c5_one_gpu_share_every_element_within_one_bf16_ulp():
+    """BASELINE configs[4], one GPU's share of the 8-GPU job at full size (8 items of N = 131072, 27 entries per row, 16 RHS, bf16):
+    EVERY element of C, gradA and gradB within bf16's unit roundoff (2^-8) of the exact result of the reference's arithmetic on the
+    same bf16 inputs + the fp32 accumulation bound — the full-size companion of the sampled rows in tests/test_gpu_fullsize.py."""
+    from oracle import oracle
+    from torchsparsegradutils_amd import sparse_mm, wait_for_plans
+    from torchsparsegradutils_amd.utils import synthetic
+
+    nx, ny, nz, p, batch = 64, 64, 32, 16, 8
+    n = nx * ny * nz
+    crow1, col1 = synthetic.stencil27_periodic(nx, ny, nz, torch.int32, device=DEV)
+    nnz = col1.numel()
+    g = torch.Generator(device=DEV).manual_seed(78)
+    val = torch.randn((batch, nnz), device=DEV, generator=g).to(torch.bfloat16)
+    B = torch.randn((batch, n, p), device=DEV, generator=g).to(torch.bfloat16).requires_grad_(True)
+    Gd = torch.randn((batch, n, p), device=DEV, generator=g).to(torch.bfloat16)
+    A = torch.sparse_csr_tensor(crow1.unsqueeze(0).repeat(batch, 1), col1.unsqueeze(0).repeat(batch, 1), val, (batch, n, n)).requires_grad_(True)
+    for _ in range(3):
+        C = sparse_mm(A, B)
+        gA, gB = torch.autograd.grad(C, (A, B), Gd)
+        wait_for_plans()
+    cr, cc = crow1.cpu().numpy(), col1.cpu().numpy()
+    for b in (0, batch - 1, 3):
+        v, bb, gd = val[b].double().cpu().numpy(), B[b].detach().double().cpu().numpy(), Gd[b].double().cpu().numpy()
+        exact = oracle.sparse_mm_fwd_bwd(cr, cc, v, bb, gd, n)
+        mags = oracle.sparse_mm_fwd_bwd(cr, cc, np.abs(v), np.abs(bb), np.abs(gd), n)
+        for got, ex, mg, what in zip((C[b], gA.values()[b], gB[b]), exact, mags, ("C", "gradA", "gradB")):
+            gf = got.detach().double().cpu().numpy().reshape(ex.shape)
+            ulp = np.maximum(np.abs(ex), 2.0 ** -126) * 2.0 ** -8
+            assert float((np.abs(gf - ex) / (ulp + 8 * EPS32 * mg + 1e-300)).max()) <= 1.0, (b, what)
+
+
+# ---- the step's C++ host path with batched CSR operands (BASELINE configs[4]) ------------------------------------------------------
+
+
+@pytest.mark.parametrize("dt,p", [(torch.bfloat16, 16), (torch.float32, 32)])
+def test_cpp_host_path_of_a_batched_csr_step_equals_the_python_path(dt, p):
+    """Batched CSR on a lattice (C5's shape, scaled down): once the three launch configurations of the block-diagonal problem are
+    final, forward and backward are issued by csrc/host/step.cpp — same launches, same bits; C (b, n, p), gradA batched CSR with
+    A's own index tensors (int32 kept), gradB (b, n, p); gating by needs_input_grad; a second backward raises."""
+    import torchsparsegradutils_amd.sparse_matmul as sm
+    from torchsparsegradutils_amd import _lattice, _ops, _pattern, sparse_mm, wait_for_plans
+    from torchsparsegradutils_amd.utils import synthetic
+
+    assert sm._host is not None
+    b, dims = 3, (8, 6, 16)
+    crow1, col1 = synthetic.stencil27_periodic(*dims, torch.int32, device=DEV)
+    n, nnz = crow1.numel() - 1, col1.numel()
+    crow, col = crow1.unsqueeze(0).repeat(b, 1), col1.unsqueeze(0).repeat(b, 1)
+    g = torch.Generator(device=DEV).manual_seed(21)
+    val = torch.randn(b, nnz, device=DEV, generator=g).to(dt)
+    B0 = torch.randn(b, n, p, device=DEV, generator=g).to(dt)
+    Gd = torch.randn(b, n, p, device=DEV, generator=g).to(dt)
+    keep = (sm.FAST_STEP, _lattice.TUNE, _ops.PACK_MIN_NNZ)
+    _pattern.clear_cache()
+    try:
+        _lattice.TUNE = False
+        _ops.PACK_MIN_NNZ = 1
+        A = torch.sparse_csr_tensor(crow, col, val, (b, n, n)).requires_grad_(True)
+        B = B0.clone().requires_grad_(True)
+
+        def run(fast, need=(True, True)):
+            sm.FAST_STEP = fast
+            A.requires_grad_(need[0])
+            B.requires_grad_(need[1])
+            C = sparse_mm(A, B)
+            ins = tuple(t for t, nd in zip((A, B), need) if nd)
+            return C, (torch.autograd.grad(C, ins, Gd) if ins else ())
+
+        ref = run(False)
+        for _ in range(6):
+            got = run(True)
+            wait_for_plans()
+        C, (gA, gB) = got
+        assert type(C.grad_fn).__name__ != "SparseMatMulBackward", "the C++ host path was not reached"
+        assert C.shape == (b, n, p) and gB.shape == (b, n, p) and gA.shape == (b, n, n) and gA.layout == torch.sparse_csr
+        assert torch.equal(C, ref[0]) and torch.equal(gB, ref[1][1]) and torch.equal(gA.values(), ref[1][0].values())
+        assert gA.crow_indices().dtype == torch.int32 and torch.equal(gA.crow_indices(), crow) and torch.equal(gA.col_indices(), col)
+        _, (gB1,) = run(True, (False, True))
+        assert torch.equal(gB1, gB)
+        _, (gA1,) = run(True, (True, False))
+        assert torch.equal(gA1.values(), gA.values())
+        A.requires_grad_(True)
+        B.requires_grad_(True)
+        Cb = sparse_mm(A, B)
+        Cb.backward(Gd)
+        with pytest.raises(RuntimeError):
+            Cb.backward(Gd)
+        # a non-contiguous operand keeps the Python path (same results)
+        Bt = B0.transpose(1, 2).contiguous().transpose(1, 2).requires_grad_(True)
+        assert not Bt.is_contiguous()
+        Cn = sparse_mm(A, Bt)
+        assert type(Cn.grad_fn).__name__ == "SparseMatMulBackward" and torch.equal(Cn, C)
+    finally:
+        sm.FAST_STEP, _lattice.TUNE, _ops.PACK_MIN_NNZ = keep

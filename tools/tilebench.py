@@ -60,7 +60,8 @@ def main():
     # correctness first (bit-identity with the plan-free kernels)
     if tp is not None and tt is not None:
         print("check spmm ", torch.equal(fns["spmm  tile"](), fns["spmm  plan-free"]()))
-        print("check sddmm", torch.equal(fns["sddmm tile"](), fns["sddmm plan-free"]()))
+        a_, b_ = fns["sddmm tile"](), fns["sddmm plan-free"]()
+        print("check sddmm", torch.equal(a_, b_), "max abs diff", float((a_ - b_).abs().max()), "of", float(b_.abs().max()))
         print("check spmmT", torch.equal(fns["spmmT tile"](), fns["spmmT plan-free"]()))
     alg = (n + 1) * 4 + nnz * 8 + 2 * n * p * 4
     for rnd in range(2):

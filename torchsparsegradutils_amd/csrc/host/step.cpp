@@ -40,6 +40,9 @@ struct StepPlan {
     // layout of A: CSR (crow / col above) or 2-D coalesced COO (`indices`; crow / col are then the CSR arrays derived from it)
     int coo = 0;
     at::Tensor indices;
+    // batched CSR (torch layout: crow [b][n+1], col / values [b][nnz]; equal nnz per item): the launches see the block-diagonal 2-D
+    // problem (n_rows = b·n …, what the Python path hands the structured kernels: _pattern.flat_of), the tensors keep their batch shape
+    int64_t batch = 0, item_rows = 0, item_cols = 0, item_nnz = 0;
     std::vector<at::Tensor> tables;   // every device table the three plan structs point into: no Python object is owned here, so the
                                       // last reference may go away on the autograd engine's thread (with a graph node) without the GIL
 };
@@ -52,7 +55,7 @@ void check(int rc, const char* what) {
 void* stream_of(int device) { return static_cast<void*>(c10::hip::getCurrentHIPStream(static_cast<c10::DeviceIndex>(device)).stream()); }
 
 void spmm(const StepPlan& s, const Product& pr, int64_t rows_out, const at::Tensor& val, const at::Tensor& dense, at::Tensor& out) {
-    const int64_t ld = dense.size(0) > 1 ? dense.stride(0) : s.p;
+    const int64_t ld = s.p;      // (contiguous operands only: checked by step() / made so in backward)
     if (pr.kind == 0)
         check(tsgu_csr_spmm_march(s.vtype, static_cast<const tsgu_march_plan*>(pr.plan()), pr.transposed, rows_out, s.nnz, val.data_ptr(),
                                   dense.data_ptr(), ld, out.data_ptr(), s.p, s.p, s.device, stream_of(s.device)),
@@ -68,6 +71,12 @@ bool plain(const at::Tensor& t, int64_t rows, int64_t p) {
            reinterpret_cast<uintptr_t>(t.data_ptr()) % 16 == 0;
 }
 
+// a dense operand of a batched step: (b, rows, p), contiguous, 16-byte aligned — the same memory as the (b·rows, p) operand of the flat problem
+bool plain3(const at::Tensor& t, int64_t b, int64_t rows, int64_t p) {
+    return t.defined() && t.dim() == 3 && t.size(0) == b && t.size(1) == rows && t.size(2) == p && t.is_contiguous() &&
+           reinterpret_cast<uintptr_t>(t.data_ptr()) % 16 == 0;
+}
+
 class StepFunction : public torch::autograd::Function<StepFunction> {
    public:
     static at::Tensor forward(torch::autograd::AutogradContext* ctx, const at::Tensor& A, const at::Tensor& B, StepPlanPtr handle) {
@@ -77,8 +86,8 @@ class StepFunction : public torch::autograd::Function<StepFunction> {
         // the launches below take a raw pointer to nnz consecutive values (the Python path: `val.contiguous()` in _backend.py)
         at::Tensor val = s.coo ? A._values() : A.values();
         if (!val.is_contiguous()) val = val.contiguous();
-        TORCH_CHECK(val.dim() == 1 && val.numel() == s.nnz, "step plan of another matrix (number of stored values)");
-        at::Tensor C = at::empty({s.n_rows, s.p}, B.options());
+        TORCH_CHECK(val.numel() == s.nnz && val.dim() == (s.batch ? 2 : 1), "step plan of another matrix (number of stored values)");
+        at::Tensor C = s.batch ? at::empty({s.batch, s.item_rows, s.p}, B.options()) : at::empty({s.n_rows, s.p}, B.options());
         if (s.fwd.kind == 2)
             check(tsgu_csr_spmm(s.vtype, s.itype, s.n_rows, s.n_cols, s.nnz, s.crow.data_ptr(), s.col.data_ptr(), val.data_ptr(), nullptr,
                                 B.data_ptr(), B.size(0) > 1 ? B.stride(0) : s.p, 1, 0, C.data_ptr(), s.p, 1, 0, s.p, 1, s.max_row_nnz, nullptr, 0,
@@ -108,10 +117,10 @@ class StepFunction : public torch::autograd::Function<StepFunction> {
         at::Tensor G = grads[0];
         at::Tensor gradA, gradB;
         if (!G.defined()) return {gradA, gradB, at::Tensor()};
-        if (!plain(G, s.n_rows, s.p)) G = G.contiguous();
+        if (s.batch ? !plain3(G, s.batch, s.item_rows, s.p) : !plain(G, s.n_rows, s.p)) G = G.contiguous();
         if (reinterpret_cast<uintptr_t>(G.data_ptr()) % 16 != 0) G = G.clone();
         const bool need_a = ctx->needs_input_grad(0), need_b = ctx->needs_input_grad(1);
-        const int64_t ldb = B.size(0) > 1 ? B.stride(0) : s.p;
+        const int64_t ldb = s.batch ? s.p : (B.size(0) > 1 ? B.stride(0) : s.p);
         at::Tensor gv;
         if (s.fwd.kind == 2) {
             if (need_a && need_b && s.fused_backward) {
@@ -140,7 +149,7 @@ class StepFunction : public torch::autograd::Function<StepFunction> {
         } else {
             if (need_a) {
                 // gradA[k] = <G[row k,:], B[col k,:]> at A's stored entries only (reference sparse_matmul.py:172-205)
-                gv = at::empty({s.nnz}, val.options());
+                gv = s.batch ? at::empty({s.batch, s.item_nnz}, val.options()) : at::empty({s.nnz}, val.options());
                 if (s.sddmm.kind == 0)
                     check(tsgu_csr_sddmm_march(s.vtype, static_cast<const tsgu_march_plan*>(s.sddmm.plan()), s.n_rows, s.nnz, G.data_ptr(), s.p,
                                                B.data_ptr(), ldb, gv.data_ptr(), 1.0, 0, s.p, s.device, stream_of(s.device)),
@@ -152,7 +161,7 @@ class StepFunction : public torch::autograd::Function<StepFunction> {
             }
             if (need_b) {
                 // gradB = Aᵀ·G (reference sparse_matmul.py:229), through A's own arrays
-                gradB = at::empty({s.n_cols, s.p}, G.options());
+                gradB = s.batch ? at::empty({s.batch, s.item_cols, s.p}, G.options()) : at::empty({s.n_cols, s.p}, G.options());
                 spmm(s, s.spmm_t, s.n_cols, val, G, gradB);
             }
         }
@@ -160,6 +169,9 @@ class StepFunction : public torch::autograd::Function<StepFunction> {
             // the sparse gradient in A's own layout, with A's index tensors (reference sparse_matmul.py:208-219)
             if (s.coo)
                 gradA = at::sparse_coo_tensor(ctx->saved_data["idx"].toTensor(), gv, {s.n_rows, s.n_cols}, gv.options().layout(at::kSparse));
+            else if (s.batch)
+                gradA = at::sparse_csr_tensor(ctx->saved_data["crow"].toTensor(), ctx->saved_data["col"].toTensor(), gv,
+                                              {s.batch, s.item_rows, s.item_cols}, gv.options().layout(at::kSparseCsr));
             else
                 gradA = at::sparse_csr_tensor(ctx->saved_data["crow"].toTensor(), ctx->saved_data["col"].toTensor(), gv, {s.n_rows, s.n_cols},
                                               gv.options().layout(at::kSparseCsr));
@@ -173,6 +185,12 @@ at::Tensor step(const at::Tensor& A, const at::Tensor& B, StepPlanPtr handle) {
     TORCH_CHECK(handle != nullptr, "no step plan");
     const StepPlan& s = *handle;
     // (Python has validated layout / dims / dtypes / device; these are the conditions of the raw-pointer launches)
+    if (s.batch) {
+        TORCH_CHECK(A.layout() == at::kSparseCsr && A.dim() == 3 && A.size(0) == s.batch && A.size(1) == s.item_rows && A.size(2) == s.item_cols &&
+                        s.fwd.kind != 2, "step plan of another (batched) matrix");
+        TORCH_CHECK(plain3(B, s.batch, s.item_cols, s.p), "the fast step takes a contiguous, 16-byte aligned (batch, n_cols, p) operand");
+        return StepFunction::apply(A, B, std::move(handle));
+    }
     TORCH_CHECK(A.layout() == (s.coo ? at::kSparse : at::kSparseCsr) && A.dim() == 2 && A.size(0) == s.n_rows && A.size(1) == s.n_cols,
                 "step plan of another matrix");
     TORCH_CHECK(plain(B, s.n_cols, s.p), "the fast step takes a contiguous, 16-byte aligned (n_cols, p) operand");
@@ -209,6 +227,11 @@ PYBIND11_MODULE(_tsgu_host, m) {
             s.itype = itype;
             s.t_ptr = std::move(t_ptr), s.t_idx = std::move(t_idx), s.t_perm = std::move(t_perm);
             s.max_row_nnz = max_row_nnz, s.t_max_row_nnz = t_max_row_nnz, s.fused_backward = fused_backward ? 1 : 0;
+        })
+        .def("set_batch", [](StepPlan& s, int64_t batch, int64_t item_rows, int64_t item_cols, int64_t item_nnz) {
+            if (batch < 1 || batch * item_rows != s.n_rows || batch * item_cols != s.n_cols || batch * item_nnz != s.nnz)
+                throw std::invalid_argument("batch geometry does not match the flat problem");
+            s.batch = batch, s.item_rows = item_rows, s.item_cols = item_cols, s.item_nnz = item_nnz;
         })
         .def("set_coo", [](StepPlan& s, at::Tensor indices) {
             s.coo = 1;

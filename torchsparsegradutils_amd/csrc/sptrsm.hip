@@ -25,13 +25,15 @@ struct TrsmWork {
     unsigned long long ticket[64];  // (kept for the layout: the error word stays at byte 512)
     int error;
     int pad[15];
-    // Row tickets: one counter per (wave slot of a workgroup, column tile), 512 bytes apart per slot.  Wave slot w of every
-    // workgroup draws the rows ≡ w (mod 4) in order from counter w.  ONE counter for all rows serves ~80 M same-address atomics
-    // per second — with an atomic per row that was the solve time of C3 (262144 rows: 3.2 ms whatever the pollers did; rows
-    // dealt round-robin without atomics: 2.27 ms).  Forward progress as before, per class: counter w hands its rows out in
-    // order, so every class-w row below the lowest unfinished one is finished and its waves are free to take that row; any one
-    // resident workgroup has a wave of every class.
-    unsigned long long class_ticket[kTrsmWaves][64];
+    // Row tickets: rows are dealt to CLASSES, class c draws the rows ≡ c (mod classes) in order from its own counter (128 bytes
+    // apart).  A class is (wave slot of a workgroup, workgroup index mod `wgc`) — up to 4 x 64 classes; with several column tiles
+    // (p > 64) it is (wave slot, tile) as before.  ONE counter serves ~80 M same-address atomics per second: with one counter for
+    // all rows that was the solve time of C3 (262144 rows: 3.2 ms whatever the pollers did), with four it still is the solve time
+    // of a SHALLOW pattern (the reference's published shape, one off-diagonal entry per row: 65536 atomics per counter = 0.84 ms
+    // whatever the number of waves).  Forward progress, per class: a counter hands its rows out in order, so every row of the class
+    // below the lowest unfinished one is finished and the waves that held them are free to take it; every class has a resident wave
+    // (the grid is persistent and never smaller than `wgc` workgroups).
+    unsigned long long class_ticket[kTrsmWaves * 64 * 16];
 };
 
 struct TrsmParams {
@@ -46,6 +48,7 @@ struct TrsmParams {
     int64_t ldx;
     TrsmWork* work;
     int lower, unit;
+    int wgc;                  // workgroup classes (1 … 64; 1 when there are several column tiles)
     long long timeout_ticks;  // wall_clock64 ticks (100 MHz)
 };
 
@@ -89,7 +92,7 @@ __global__ __launch_bounds__(kBlock) void sptrsm_fill_kernel(void* X, int64_t ld
     }
     if (blockIdx.x == 0) {
         for (int i = threadIdx.x; i < kTrsmWaves * 64; i += kBlock)
-            __hip_atomic_store(&work->class_ticket[0][0] + i, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&work->class_ticket[i * 16], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (blockIdx.x == 0 && threadIdx.x < 64) {
         __hip_atomic_store(&work->ticket[threadIdx.x], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -135,11 +138,15 @@ __global__ __launch_bounds__(kBlock) void sptrsm_syncfree_kernel(const TrsmParam
     Bits* X = static_cast<Bits*>(P.X);
     TrsmWork* work = P.work;
 
+    const int slot = threadIdx.x / kWave;
+    const int wg = P.wgc > 1 ? (int)(blockIdx.x % (unsigned)P.wgc) : 0;
+    const int cls = wg * kTrsmWaves + slot;                  // this wave's class: rows ≡ cls (mod classes)
+    const int ncls = P.wgc * kTrsmWaves;
+    unsigned long long* const counter = &work->class_ticket[(slot * 64 + (P.wgc > 1 ? wg : tile)) * 16];
     for (;;) {
         unsigned long long t = 0;
-        const int slot = threadIdx.x / kWave;             // this wave's class: rows ≡ slot (mod kTrsmWaves)
-        if (lane == 0) t = __hip_atomic_fetch_add(&work->class_ticket[slot][tile], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        t = __shfl(t, 0, kWave) * kTrsmWaves + slot;
+        if (lane == 0) t = __hip_atomic_fetch_add(counter, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        t = __shfl(t, 0, kWave) * ncls + cls;
         if (t >= (unsigned long long)P.n) break;
         const int64_t row = P.lower ? (int64_t)t : P.n - 1 - (int64_t)t;
         const int64_t s = (int64_t)ptr[row];
@@ -243,10 +250,12 @@ int sptrsm_launch(const TrsmParams& P, int n_cu, int wg_per_cu, hipStream_t stre
         blocks = blocks / tiles;
         if (blocks < 1) blocks = 1;
     }
+    TrsmParams Q = P;
+    Q.wgc = tiles == 1 ? (int)(blocks < 64 ? blocks : 64) : 1;
     const dim3 grid((unsigned)blocks, (unsigned)tiles, 1);
 #define TSGU_TRSM_CASE(N)                                                                                 \
     case N:                                                                                               \
-        hipLaunchKernelGGL((sptrsm_syncfree_kernel<V, I, N>), grid, dim3(kBlock), 0, stream, P);          \
+        hipLaunchKernelGGL((sptrsm_syncfree_kernel<V, I, N>), grid, dim3(kBlock), 0, stream, Q);          \
         break;
     switch (cl) {
         TSGU_TRSM_CASE(1)

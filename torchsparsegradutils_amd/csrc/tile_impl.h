@@ -36,8 +36,7 @@ enum TileMode { kTileSpmm = 0, kTileSddmm = 1 };
 constexpr int kTileRows = 64;       // rows per block
 constexpr int kTileUMax = 224;      // distinct dense rows per block (multiple of 8)
 constexpr int kTileEMax = 2048;     // entries per block
-constexpr int kTileThreads = 256;
-constexpr int kTileUP = kTileUMax * 8 / kTileThreads;      // 16-byte tile pieces per thread at 8 chunks per dense row (CL = 8)
+constexpr int kTileThreads = 512;   // eight waves: with 8 lanes per row every wave owns 8 of the block's 64 rows
 constexpr int kTileEP = kTileEMax / kTileThreads;          // value dwords per thread
 
 struct TileDesc {
@@ -63,7 +62,7 @@ struct TileParams {
     int blocks_per_wg;
 };
 
-// LDS layout (bytes): two buffers of {tile | values | entry bytes | row pointer slice} + one zero row
+// LDS layout (bytes): two buffers of {tile | values | entry bytes | row pointer slice} + one zero row behind them
 template <int RB>
 struct TileLds {
     static constexpr int kTile = kTileUMax * RB;
@@ -72,7 +71,8 @@ struct TileLds {
     static constexpr int kRs = (kTileRows + 8) * 4;
     static constexpr int kBuf = kTile + kVals + kLidx + kRs;
     static constexpr int oVals = kTile, oLidx = kTile + kVals, oRs = kTile + kVals + kLidx;
-    static constexpr int kTotal = 2 * kBuf;
+    static constexpr int oZero = 2 * kBuf;
+    static constexpr int kTotal = 2 * kBuf + RB;
 };
 
 // wave-uniform copy of a descriptor (scalar registers: its fields go into lane predicates and M0-relative addresses)
@@ -93,13 +93,13 @@ __device__ __forceinline__ int tile_wave_min(int x) {
 }
 
 template <typename V, int CL, int MODE, bool PERM>
-__global__ __launch_bounds__(kTileThreads, 2) void tile_kernel(const TileParams P) {
-    static_assert(std::is_same<V, float>::value, "fp32 only (so far)");
+__global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(const TileParams P) {
+    static_assert(std::is_same<V, float>::value && CL == 8, "fp32 operands of 32 columns (so far)");
     constexpr int RB = CL * 16;                    // bytes of a dense row
-    constexpr int RPW = kWave / CL;                // rows per wave and pass
+    constexpr int RPW = kWave / CL;                // rows per wave
     constexpr int NW = kTileThreads / kWave;
-    constexpr int PASSES = kTileRows / (RPW * NW);
-    constexpr int UP = kTileUMax * CL / kTileThreads;
+    static_assert(RPW * NW == kTileRows, "one pass: every wave owns RPW rows of the block");
+    constexpr int UP = (kTileUMax * CL + kTileThreads - 1) / kTileThreads;      // 16-byte tile pieces per thread
     using L = TileLds<RB>;
     extern __shared__ __attribute__((aligned(16))) unsigned char tile_lds[];
     const unsigned lds0 = lat_lds_addr(tile_lds);
@@ -115,13 +115,13 @@ __global__ __launch_bounds__(kTileThreads, 2) void tile_kernel(const TileParams 
     const float* __restrict__ S = static_cast<const float*>(P.S);
     const uint32_t ld_bytes = (uint32_t)P.lds_ * 4u;
     const unsigned wave_piece = (unsigned)(wave * kWave);
+    if (t < RB / 4) reinterpret_cast<float*>(tile_lds + L::oZero)[t] = 0.f;       // the zero row (visible after the first step sync)
 
     // Every compiler-visible global load of the loop below is FIRST USED behind the `s_waitcnt vmcnt(0)` that ends the step it was
     // issued in (hipcc's own wait for it is then free); a load consumed inside the same step would make hipcc drain the DMAs.
     int ucolr[UP];                                       // column numbers of this thread's tile pieces of the block staged next
     int permr[PERM ? kTileEP : 1];                       // value positions of this thread's entries of the block staged next
-    uint4 own_cur[MODE == kTileSddmm ? PASSES : 1];      // SDDMM: own rows of the block being walked …
-    uint4 own_nxt[MODE == kTileSddmm ? PASSES : 1];      // … and of the next one
+    uint4 own_cur = {0, 0, 0, 0}, own_nxt = {0, 0, 0, 0};      // SDDMM: this lane's 16 bytes of its row of R, block walked / next block
 #pragma unroll
     for (int i = 0; i < UP; ++i) ucolr[i] = 0;
 
@@ -137,6 +137,16 @@ __global__ __launch_bounds__(kTileThreads, 2) void tile_kernel(const TileParams 
                 const int e = t + i * kTileThreads;
                 if (e < d.E) permr[i] = P.perm[(int64_t)d.e0 + e];
             }
+        }
+    };
+    auto pin_words = [&]() {
+        // pinned in straight-line code before the first DMA of a step: hipcc otherwise places its wait for ucolr[i] inside the
+        // predicated block of piece i — behind the DMA of piece i - 1
+#pragma unroll
+        for (int i = 0; i < UP; ++i) lat_pin(ucolr[i]);
+        if constexpr (PERM) {
+#pragma unroll
+            for (int i = 0; i < kTileEP; ++i) lat_pin(permr[i]);
         }
     };
 
@@ -173,15 +183,11 @@ __global__ __launch_bounds__(kTileThreads, 2) void tile_kernel(const TileParams 
         }
     };
 
-    auto load_own = [&](int k) {                         // SDDMM: the own rows of block k
+    auto load_own = [&](int k) {                         // SDDMM: this lane's part of its row of R in block k
         if constexpr (MODE == kTileSddmm) {
             const float* Own = static_cast<const float*>(P.Own);
-            const int64_t r0 = (b_first + k) * kTileRows;
-#pragma unroll
-            for (int ps = 0; ps < PASSES; ++ps) {
-                const int64_t r = r0 + (ps * NW + wave) * RPW + grp;
-                own_nxt[ps] = r < P.n_rows ? *reinterpret_cast<const uint4*>(Own + r * P.ldown + sub * 4) : uint4{0, 0, 0, 0};
-            }
+            const int64_t r = (b_first + k) * kTileRows + wave * RPW + grp;
+            own_nxt = r < P.n_rows ? *reinterpret_cast<const uint4*>(Own + r * P.ldown + sub * 4) : uint4{0, 0, 0, 0};
         }
     };
 
@@ -190,106 +196,108 @@ __global__ __launch_bounds__(kTileThreads, 2) void tile_kernel(const TileParams 
         const float* vals = reinterpret_cast<const float*>(buf + L::oVals);
         const unsigned char* lid = buf + L::oLidx + (d.e0 & 3);
         const int* rs = reinterpret_cast<const int*>(buf + L::oRs);
-        const int64_t r0 = (b_first + k) * kTileRows;
         const unsigned char* trow = buf + sub * 16;
-#pragma unroll
-        for (int ps = 0; ps < PASSES; ++ps) {
-            const int rl = (ps * NW + wave) * RPW + grp;
-            const int64_t r = r0 + rl;
-            const bool live = r < P.n_rows;
-            const int s = live ? rs[rl] - d.e0 : 0, e = live ? rs[rl + 1] - d.e0 : 0;
-            if constexpr (MODE == kTileSpmm) {
-                float acc[4] = {0.f, 0.f, 0.f, 0.f};
-                // four entries at a time for as long as EVERY row of the wave has four left (a scalar trip count: no predicates), …
-                const int nfull = tile_wave_min<CL>((e - s) >> 2);
-                int kk = s;
-                for (int it = 0; it < nfull; ++it) {
-                    float v[4];
-                    unsigned li[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        li[j] = lid[kk + j];
-                        v[j] = vals[kk + j];
-                    }
-                    float4 bj[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) bj[j] = *reinterpret_cast<const float4*>(trow + li[j] * RB);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        acc[0] = fmaf(v[j], bj[j].x, acc[0]);
-                        acc[1] = fmaf(v[j], bj[j].y, acc[1]);
-                        acc[2] = fmaf(v[j], bj[j].z, acc[2]);
-                        acc[3] = fmaf(v[j], bj[j].w, acc[3]);
-                    }
-                    kk += 4;
+        const unsigned char* zrow = tile_lds + L::oZero + sub * 16;
+        const int rl = wave * RPW + grp;
+        const int64_t r = (b_first + k) * kTileRows + rl;
+        const bool live = r < P.n_rows;
+        const int s = live ? rs[rl] - d.e0 : 0, e = live ? rs[rl + 1] - d.e0 : 0;
+        // eight entries per round; the rounds every row of the wave has in full run without predicates (a scalar trip count)
+        const int nfull = tile_wave_min<CL>((e - s) >> 3);
+        int kk = s;
+        if constexpr (MODE == kTileSpmm) {
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+            unsigned li[8];
+            float v[8];
+            auto fetch = [&](int at) {                   // entry bytes and values of the round that starts at `at` (reads beyond a row's
+#pragma unroll                                           // end stay inside the LDS buffer: harmless)
+                for (int j = 0; j < 8; ++j) {
+                    li[j] = lid[at + j];
+                    v[j] = vals[at + j];
                 }
-                // … then entry by entry under a predicate (a row never touches a dense row it does not reference)
-                while (__any(kk < e)) {
-                    if (kk < e) {
-                        const unsigned li = lid[kk];
-                        const float v = vals[kk];
-                        const float4 bj = *reinterpret_cast<const float4*>(trow + li * RB);
-                        acc[0] = fmaf(v, bj.x, acc[0]);
-                        acc[1] = fmaf(v, bj.y, acc[1]);
-                        acc[2] = fmaf(v, bj.z, acc[2]);
-                        acc[3] = fmaf(v, bj.w, acc[3]);
-                    }
-                    ++kk;
+            };
+            fetch(kk);
+            for (int it = 0; it < nfull; ++it) {
+                float4 bj[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) bj[j] = *reinterpret_cast<const float4*>(trow + li[j] * RB);
+                float vv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) vv[j] = v[j];
+                kk += 8;
+                fetch(kk);                               // the next round's bytes and values travel while this round is summed
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    acc[0] = fmaf(vv[j], bj[j].x, acc[0]);
+                    acc[1] = fmaf(vv[j], bj[j].y, acc[1]);
+                    acc[2] = fmaf(vv[j], bj[j].z, acc[2]);
+                    acc[3] = fmaf(vv[j], bj[j].w, acc[3]);
                 }
-                if (live) store_vec<float, 4, true>(static_cast<float*>(P.out) + r * P.ldo + sub * 4, acc);
-            } else {
-                static_assert(MODE != kTileSddmm || CL == 8, "the transposed reduction below is written for 8 lanes per row");
-                const float g0 = __uint_as_float(own_cur[ps].x), g1 = __uint_as_float(own_cur[ps].y), g2 = __uint_as_float(own_cur[ps].z),
-                            g3 = __uint_as_float(own_cur[ps].w);
-                float* gv = static_cast<float*>(P.gvals) + d.e0;
-                // eight entries per round: lane `sub` of the row's group ends with the dot of entry kk + sub (transposed tree: after the step
-                // over lane bit m a lane keeps the entries whose bit m equals its own).  Partner sub ^ 4 = half mirror + quad reversal.
-                auto reduce8 = [&](const float (&part)[8]) -> float {
-                    float h4[4], h2[2];
-                    const bool up4 = (sub & 4) != 0, up2 = (sub & 2) != 0, up1 = (sub & 1) != 0;
+            }
+            // what is left of the rows (fewer than eight entries where the rows are equally long): a missing entry reads the zero row
+            // with a zero value — a row never touches a dense row it does not reference, 0·0 adds nothing
+            while (__any(kk < e)) {
+                float4 bj[8];
+                float vv[8];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float keep = up4 ? part[j + 4] : part[j], give = up4 ? part[j] : part[j + 4];
-                        h4[j] = keep + dpp_move<0x1B>(dpp_move<0x141>(give));
-                    }
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const float keep = up2 ? h4[j + 2] : h4[j], give = up2 ? h4[j] : h4[j + 2];
-                        h2[j] = keep + dpp_move<0x4E>(give);
-                    }
-                    const float keep = up1 ? h2[1] : h2[0], give = up1 ? h2[0] : h2[1];
-                    return keep + dpp_move<0xB1>(give);
-                };
-                const int nfull = tile_wave_min<CL>((e - s) >> 3);
-                int kk = s;
-                for (int it = 0; it < nfull; ++it) {
-                    unsigned li[8];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) li[j] = lid[kk + j];
-                    float part[8];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const float4 bj = *reinterpret_cast<const float4*>(trow + li[j] * RB);
-                        part[j] = fmaf(g3, bj.w, fmaf(g2, bj.z, fmaf(g1, bj.y, g0 * bj.x)));
-                    }
-                    gv[kk + sub] = P.alpha * reduce8(part);
-                    kk += 8;
+                for (int j = 0; j < 8; ++j) {
+                    const bool ok = kk + j < e;
+                    bj[j] = *reinterpret_cast<const float4*>(ok ? trow + li[j] * RB : zrow);
+                    vv[j] = ok ? v[j] : 0.f;
                 }
-                while (__any(kk < e)) {
-                    float part[8];
+                kk += 8;
+                if (__any(kk < e)) fetch(kk);
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        part[j] = 0.f;
-                        if (kk + j < e) {
-                            const unsigned li = lid[kk + j];
-                            const float4 bj = *reinterpret_cast<const float4*>(trow + li * RB);
-                            part[j] = fmaf(g3, bj.w, fmaf(g2, bj.z, fmaf(g1, bj.y, g0 * bj.x)));
-                        }
-                    }
-                    const float h = reduce8(part);
-                    if (kk + sub < e) gv[kk + sub] = P.alpha * h;
-                    kk += 8;
+                for (int j = 0; j < 8; ++j) {
+                    acc[0] = fmaf(vv[j], bj[j].x, acc[0]);
+                    acc[1] = fmaf(vv[j], bj[j].y, acc[1]);
+                    acc[2] = fmaf(vv[j], bj[j].z, acc[2]);
+                    acc[3] = fmaf(vv[j], bj[j].w, acc[3]);
                 }
+            }
+            if (live) store_vec<float, 4, true>(static_cast<float*>(P.out) + r * P.ldo + sub * 4, acc);
+        } else {
+            const float g0 = __uint_as_float(own_cur.x), g1 = __uint_as_float(own_cur.y), g2 = __uint_as_float(own_cur.z),
+                        g3 = __uint_as_float(own_cur.w);
+            float* gv = static_cast<float*>(P.gvals) + d.e0;
+            // Eight entries per round, slot j of lane `sub` holds entry kk + (j ^ sub): the 8 lanes of a row then read 8 different
+            // dense rows at once (each its own 16-byte column chunk, conflict-free) and the cross-lane sums form a TRANSPOSED tree with
+            // fixed slots — after the step over lane bit m a lane keeps the entries whose bit m equals its own:
+            //   partner sub ^ 7 (half mirror):  h4[j] = part[j] + partner's part[7 - j]      (both are entry j ^ sub)
+            //   partner sub ^ 2:                h2[j] = h4[j]   + partner's h4[j + 2]
+            //   partner sub ^ 1:                h     = h2[0]   + partner's h2[1]            = the dot of entry kk + sub
+            // 7 DPP additions per 8 entries, no selects.
+            const unsigned char* lidx = lid + sub;       // slot j reads lid[kk + (j ^ sub)] = lidx[kk + (j ^ sub) - sub]
+            int xo[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xo[j] = (j ^ sub) - sub;
+            auto round = [&]() -> float {
+                unsigned li[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) li[j] = lidx[kk + xo[j]];
+                float part[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float4 bj = *reinterpret_cast<const float4*>(trow + li[j] * RB);
+                    part[j] = fmaf(g3, bj.w, fmaf(g2, bj.z, fmaf(g1, bj.y, g0 * bj.x)));
+                }
+                float h4[4], h2[2];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) h4[j] = part[j] + dpp_move<0x141>(part[7 - j]);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) h2[j] = h4[j] + dpp_move<0x4E>(h4[j + 2]);
+                return h2[0] + dpp_move<0xB1>(h2[1]);
+            };
+            for (int it = 0; it < nfull; ++it) {
+                gv[kk + sub] = P.alpha * round();
+                kk += 8;
+            }
+            // the rest under a store predicate only: the slots of entries beyond a row's end hold whatever dense row the byte behind the
+            // row names (inside the LDS buffer); their sums stay in their own slots of the tree and are never stored
+            while (__any(kk < e)) {
+                const float h = round();
+                if (kk + sub < e) gv[kk + sub] = P.alpha * h;
+                kk += 8;
             }
         }
     };
@@ -298,28 +306,15 @@ __global__ __launch_bounds__(kTileThreads, 2) void tile_kernel(const TileParams 
     TileDesc d0 = tile_uniform(desc[0]), d1 = tile_uniform(desc[1]), d2 = tile_uniform(desc[2]);
     TileDesc raw = desc[3];
     load_words(d0);
-#pragma unroll
-    for (int i = 0; i < UP; ++i) lat_pin(ucolr[i]);
-    if constexpr (PERM) {
-#pragma unroll
-        for (int i = 0; i < kTileEP; ++i) lat_pin(permr[i]);
-    }
+    pin_words();
     stage(0, d0);
     load_own(0);
     load_words(d1);
     lat_step_sync();
     for (int k = 0; k < nloc; ++k) {
         const TileDesc d3 = tile_uniform(raw);          // (loaded during the previous step)
-        // every word loaded during the previous step is pinned HERE, in straight-line code, before the first DMA of this step: hipcc
-        // otherwise places its wait for ucolr[i] inside the predicated block of piece i — behind the DMA of piece i - 1
-#pragma unroll
-        for (int i = 0; i < UP; ++i) lat_pin(ucolr[i]);
-        if constexpr (PERM) {
-#pragma unroll
-            for (int i = 0; i < kTileEP; ++i) lat_pin(permr[i]);
-        }
-#pragma unroll
-        for (int ps = 0; ps < (MODE == kTileSddmm ? PASSES : 1); ++ps) own_cur[ps] = own_nxt[ps];
+        pin_words();
+        own_cur = own_nxt;
         if (k + 1 < nloc) stage(k + 1, d1);             // (uses the words loaded during step k - 1)
         if (k + 2 < nloc) load_words(d2);
         if (k + 1 < nloc) load_own(k + 1);

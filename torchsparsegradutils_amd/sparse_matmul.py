@@ -52,7 +52,7 @@ def sparse_mm(A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
     if A.size(-1) != B.size(-2):
         raise ValueError(f"Incompatible inner dimensions: A[..., {A.size(-1)}] vs B[..., {B.size(-2)}]")
 
-    if _host is not None and FAST_STEP and B.is_cuda and B.dim() == 2:
+    if _host is not None and FAST_STEP and B.is_cuda and (B.dim() == 2 or A.layout == torch.sparse_csr):
         plan = _step_plan(A, B)
         if plan is not None:
             return cast(torch.Tensor, _host.step(A, B, plan))
@@ -99,17 +99,27 @@ def _settle_step_plan(op: "_Operand", values: torch.Tensor, G: torch.Tensor, B: 
     host path — the three configurations of a lattice stencil (the StepPlan copies the plan structs and holds every device table
     they point into), or the plan-free kernels with the cached transposed pattern once the row-pair plans are known not to apply."""
     plan = op.plan
-    if (_host is None or not FAST_STEP or plan.batch is not None or plan.perm is not None or _ops.FUSED_BACKWARD or B.dim() != 2
+    if (_host is None or not FAST_STEP or plan.perm is not None or _ops.FUSED_BACKWARD or op.flat_batch is not None
             or not (values.dtype == G.dtype == B.dtype) or (op.layout != torch.sparse_csr and op.indices is None)):
         return
     dtype, p = G.dtype, G.size(-1)
     own = plan.core.own
+    batched = plan.batch is not None
+    if batched:
+        # batched CSR (torch layout, equal nnz per item): the structured kernels see ONE block-diagonal problem (_pattern.flat_of);
+        # the step plan describes that problem and keeps the batch shape of the tensors (one GPU's share of BASELINE configs[4] is
+        # 0.14 ms of kernels per step: a Python host path of 0.08-0.26 ms would be what the sharded job waits for)
+        if B.dim() != 3 or not (B.is_contiguous() and G.is_contiguous()):
+            return
+        plan = _pt.flat_of(plan)
+    elif B.dim() != 2:
+        return
     plans = own.get("step_plans")
     key = _step_key(dtype, p)
     if plans is not None and key in plans:
         return
     dev = plan.crow.device
-    memo = own.get("lattice_memo") if _ops.ENABLE_LATTICE else None
+    memo = plan.core.own.get("lattice_memo") if _ops.ENABLE_LATTICE else None      # (of the flat problem when batched)
     got = None if memo is None else [memo.get((mode, dtype, p, True, _ops._lt.ENABLE_MARCH)) for mode in (_be.LAT_SPMM, _be.LAT_SDDMM, _be.LAT_SPMMT)]
     if got is not None and all(g is not None for g in got):
         prods, tables = [], [plan.crow, plan.col]
@@ -124,6 +134,11 @@ def _settle_step_plan(op: "_Operand", values: torch.Tensor, G: torch.Tensor, B: 
             tables += _tensors_of(lp) + _tensors_of(cfg)
         sp = _host.StepPlan(plan.crow, plan.col, plan.n_rows, plan.n_cols, plan.nnz, p, _be._VTYPE[dtype], dev.index,
                             prods[0], prods[1], prods[2], tables)
+        if batched:
+            b = op.plan.batch
+            sp.set_batch(b, op.plan.n_rows, op.plan.n_cols, op.plan.nnz)
+    elif batched:
+        return                              # (batched operands off a lattice: the Python path)
     else:
         # no lattice: is the step on the plan-free kernels for good?  (not while a row-pair plan may still arrive)
         if got is not None and any(g is not None for g in got):
@@ -250,7 +265,7 @@ class SparseMatMul(torch.autograd.Function):
             gradA = op.rebuild(gvals)
             if ctx.batch_size is not None:
                 gradB = gradB.view(ctx.B_shape)
-            elif op.flat_batch is None:
+            if op.flat_batch is None:
                 _settle_step_plan(op, values, G, B)
             return gradA, gradB
 
@@ -268,6 +283,6 @@ class SparseMatMul(torch.autograd.Function):
             if ctx.batch_size is not None:
                 gradB = gradB.view(ctx.B_shape)
 
-        if need_a and need_b and op.flat_batch is None and ctx.batch_size is None:
+        if need_a and need_b and op.flat_batch is None:
             _settle_step_plan(op, values, G, B)
         return gradA, gradB
