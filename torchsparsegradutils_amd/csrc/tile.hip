@@ -1,6 +1,8 @@
 // Row-block tile kernels: extern "C" entry points (declared in include/tsgu_hip.h) and launch configuration.
 #include "tile_impl.h"
 
+#include <cstdlib>
+
 using namespace tsgu;
 
 namespace {
@@ -45,6 +47,12 @@ int launch(const TileParams& P0, int device, hipStream_t s) {
     if (per < 1) per = 1;
     const int64_t grid = (P.n_blocks + per - 1) / per;
     P.blocks_per_wg = (int)per;
+    // block schedule: cyclic by default (TSGU_TILE_CYCLIC=0: a run of consecutive blocks per workgroup) — see tile_impl.h
+    static const int cyclic = [] {
+        const char* e = getenv("TSGU_TILE_CYCLIC");
+        return e ? (e[0] != '0') : 1;
+    }();
+    P.cyclic = cyclic;
     using L = TileLds<128>;
     static std::atomic<int> attr_set[4] = {{0}, {0}, {0}, {0}};
     const bool perm = P.perm != nullptr;

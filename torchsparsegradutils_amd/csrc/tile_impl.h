@@ -60,6 +60,7 @@ struct TileParams {
     void* gvals;                 // SDDMM output [nnz]
     float alpha;
     int blocks_per_wg;
+    int cyclic;                  // block of (workgroup w, step k): 0: w·blocks_per_wg + k (a run per workgroup); 1: k·workgroups + w
 };
 
 // LDS layout (bytes): two buffers of {tile | values | entry bytes | row pointer slice} + one zero row behind them
@@ -107,11 +108,24 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(const TileParams 
     const int t = threadIdx.x, lane = t & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(t / kWave);      // (a scalar: it goes into M0 for the DMA destinations)
     const int sub = lane % CL, grp = lane / CL;
+    // Which blocks a workgroup walks.  Neighbouring blocks share dense rows; an XCD's L2 (4 MB) only catches that when they are
+    // worked on at about the same time BY THE SAME XCD.  `cyclic`: at step k the whole chip works on blocks k·G … k·G + G - 1 and —
+    // virtual workgroup ids are XCD-contiguous (xcd_chunked_block) — every XCD on a run of G / 8 consecutive blocks.  Otherwise a
+    // workgroup owns a run of consecutive blocks (its own successive tiles overlap, the tiles of its XCD's other workgroups do not).
     const int64_t vb = xcd_chunked_block(blockIdx.x, gridDim.x);
-    const int64_t b_first = vb * P.blocks_per_wg;
-    const int nloc = (int)((P.n_blocks - b_first) < P.blocks_per_wg ? (P.n_blocks - b_first) : P.blocks_per_wg);
+    const int64_t b_first = P.cyclic ? vb : vb * P.blocks_per_wg;
+    const int64_t b_step = P.cyclic ? (int64_t)gridDim.x : 1;
+    int nloc;
+    if (P.cyclic) nloc = b_first < P.n_blocks ? (int)((P.n_blocks - b_first + b_step - 1) / b_step) : 0;
+    else nloc = (int)((P.n_blocks - b_first) < P.blocks_per_wg ? (P.n_blocks - b_first) : P.blocks_per_wg);
     if (nloc <= 0) return;
-    const TileDesc* __restrict__ desc = P.desc + b_first;
+    // descriptor of local step k (steps beyond the last block read the trailing empty descriptors)
+    const TileDesc* __restrict__ desc_all = P.desc;
+    auto desc_at = [&](int k) -> TileDesc {
+        int64_t b = b_first + (int64_t)k * b_step;
+        if (b > P.n_blocks) b = P.n_blocks;
+        return desc_all[b];
+    };
     const float* __restrict__ S = static_cast<const float*>(P.S);
     const uint32_t ld_bytes = (uint32_t)P.lds_ * 4u;
     const unsigned wave_piece = (unsigned)(wave * kWave);
@@ -177,7 +191,7 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(const TileParams 
             }
         }
         {   // row pointer slice: rptr[r0 .. r0 + R]
-            const int64_t r0 = (b_first + k) * kTileRows;
+            const int64_t r0 = (b_first + (int64_t)k * b_step) * kTileRows;
             const int nr = (int)((P.n_rows - r0) < kTileRows ? (P.n_rows - r0) : kTileRows) + 1;
             if (t < nr) lat_dma4<true>(P.rptr, (uint32_t)(r0 + t) * 4u, buf + L::oRs + wave_piece * 4u);
         }
@@ -186,7 +200,7 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(const TileParams 
     auto load_own = [&](int k) {                         // SDDMM: this lane's part of its row of R in block k
         if constexpr (MODE == kTileSddmm) {
             const float* Own = static_cast<const float*>(P.Own);
-            const int64_t r = (b_first + k) * kTileRows + wave * RPW + grp;
+            const int64_t r = (b_first + (int64_t)k * b_step) * kTileRows + wave * RPW + grp;
             own_nxt = r < P.n_rows ? *reinterpret_cast<const uint4*>(Own + r * P.ldown + sub * 4) : uint4{0, 0, 0, 0};
         }
     };
@@ -199,7 +213,7 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(const TileParams 
         const unsigned char* trow = buf + sub * 16;
         const unsigned char* zrow = tile_lds + L::oZero + sub * 16;
         const int rl = wave * RPW + grp;
-        const int64_t r = (b_first + k) * kTileRows + rl;
+        const int64_t r = (b_first + (int64_t)k * b_step) * kTileRows + rl;
         const bool live = r < P.n_rows;
         const int s = live ? rs[rl] - d.e0 : 0, e = live ? rs[rl + 1] - d.e0 : 0;
         // eight entries per round; the rounds every row of the wave has in full run without predicates (a scalar trip count)
@@ -303,8 +317,8 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(const TileParams 
     };
 
     // ---- pipeline: descriptors three blocks ahead, a thread's words two, DMA one, walk ---------------------------------------
-    TileDesc d0 = tile_uniform(desc[0]), d1 = tile_uniform(desc[1]), d2 = tile_uniform(desc[2]);
-    TileDesc raw = desc[3];
+    TileDesc d0 = tile_uniform(desc_at(0)), d1 = tile_uniform(desc_at(1)), d2 = tile_uniform(desc_at(2));
+    TileDesc raw = desc_at(3);
     load_words(d0);
     pin_words();
     stage(0, d0);
@@ -318,7 +332,7 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(const TileParams 
         if (k + 1 < nloc) stage(k + 1, d1);             // (uses the words loaded during step k - 1)
         if (k + 2 < nloc) load_words(d2);
         if (k + 1 < nloc) load_own(k + 1);
-        raw = desc[k + 4];
+        raw = desc_at(k + 4);
         walk(k, d0);
         lat_step_sync();
         d0 = d1, d1 = d2, d2 = d3;

@@ -109,9 +109,9 @@ def _settle_step_plan(op: "_Operand", values: torch.Tensor, G: torch.Tensor, B: 
         # batched CSR (torch layout, equal nnz per item): the structured kernels see ONE block-diagonal problem (_pattern.flat_of);
         # the step plan describes that problem and keeps the batch shape of the tensors (one GPU's share of BASELINE configs[4] is
         # 0.14 ms of kernels per step: a Python host path of 0.08-0.26 ms would be what the sharded job waits for)
-        if B.dim() != 3 or not (B.is_contiguous() and G.is_contiguous()):
-            return
-        plan = _pt.flat_of(plan)
+        if B.dim() != 3 or not (B.is_contiguous() and G.is_contiguous()) or plan.core.flat is None:
+            return                          # (the flat view exists when the structured kernels have taken the batch; never made here)
+        plan = plan.core.flat
     elif B.dim() != 2:
         return
     plans = own.get("step_plans")
