@@ -37,7 +37,10 @@ __global__ __launch_bounds__(kBlock) void csr_mm_backward_kernel(const BwdParams
     using Acc = typename VT<V>::Acc;
     constexpr int GROUP = CL * EP;
     constexpr int RPB = kBlock / GROUP;
-    constexpr int U = 4;
+#ifndef TSGU_BWD_U
+#define TSGU_BWD_U 4
+#endif
+    constexpr int U = TSGU_BWD_U;      // gathers issued back to back per lane
     static_assert(sizeof(V) <= 4, "fused backward is instantiated for 4-byte-or-narrower values");
 
     __shared__ uint2 s_ia[kBwdCap];    // {row index in A, value bits}

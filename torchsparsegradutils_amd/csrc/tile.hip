@@ -94,6 +94,7 @@ int tsgu_csr_spmm_tile(int vtype, const tsgu_tile_plan* plan, const void* val, c
     if (!B || !C || (P.nnz > 0 && !val) || ldb < p || ldc < p) return TSGU_ERR_BAD_ARG;
     if (!aligned16(B) || !aligned16(C) || ldb % 4 || ldc % 4) return TSGU_ERR_BAD_ARG;
     if ((uint64_t)plan->n_cols * (uint64_t)ldb * 4u > 0xffffffffull || (uint64_t)P.nnz * 4u > 0xffffffffull) return TSGU_ERR_TOO_LARGE;
+    if (plan->n_cols >= (1 << 24) || ldb * 4 >= (1 << 24)) return TSGU_ERR_TOO_LARGE;      // (tile row offsets are 24-bit products)
     if (const int rc = set_device(device)) return rc;
     P.val = val;
     P.S = B;
@@ -112,6 +113,7 @@ int tsgu_csr_sddmm_tile(int vtype, const tsgu_tile_plan* plan, const void* R, in
     if (plan->perm || !R || !Cm || !out_vals || ldr < p || ldc < p) return TSGU_ERR_BAD_ARG;
     if (!aligned16(R) || !aligned16(Cm) || ldr % 4 || ldc % 4) return TSGU_ERR_BAD_ARG;
     if ((uint64_t)plan->n_cols * (uint64_t)ldc * 4u > 0xffffffffull) return TSGU_ERR_TOO_LARGE;
+    if (plan->n_cols >= (1 << 24) || ldc * 4 >= (1 << 24)) return TSGU_ERR_TOO_LARGE;
     if (const int rc = set_device(device)) return rc;
     P.Own = R;
     P.ldown = ldr;

@@ -82,15 +82,24 @@ __device__ __forceinline__ TileDesc tile_uniform(const TileDesc d) {
                     __builtin_amdgcn_readfirstlane(d.E)};
 }
 
-// smallest value over the wave of a per-row quantity (all lanes of a row's group hold the same value)
+// smallest and largest value over the wave of a per-row length (< 65536; all lanes of a row's group hold the same value): one packed
+// 16-bit minimum per exchange — the high half carries 65535 - x
+typedef unsigned short tile_u16x2 __attribute__((ext_vector_type(2)));
 template <int CL>
-__device__ __forceinline__ int tile_wave_min(int x) {
+__device__ __forceinline__ void tile_wave_minmax(int x, int& lo, int& hi) {
+    unsigned int w = (unsigned int)x | ((65535u - (unsigned int)x) << 16);
 #pragma unroll
     for (int m = CL; m < kWave; m <<= 1) {
-        const int y = __shfl_xor(x, m, kWave);
-        x = y < x ? y : x;
+        const unsigned int y = (unsigned int)__shfl_xor((int)w, m, kWave);
+        tile_u16x2 a, b;
+        __builtin_memcpy(&a, &w, 4);
+        __builtin_memcpy(&b, &y, 4);
+        a = __builtin_elementwise_min(a, b);
+        __builtin_memcpy(&w, &a, 4);
     }
-    return __builtin_amdgcn_readfirstlane(x);
+    w = (unsigned int)__builtin_amdgcn_readfirstlane((int)w);
+    lo = (int)(w & 0xffffu);
+    hi = 65535 - (int)(w >> 16);
 }
 
 template <typename V, int CL, int MODE, bool PERM>
@@ -134,22 +143,32 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(const TileParams 
     // Every compiler-visible global load of the loop below is FIRST USED behind the `s_waitcnt vmcnt(0)` that ends the step it was
     // issued in (hipcc's own wait for it is then free); a load consumed inside the same step would make hipcc drain the DMAs.
     int ucolr[UP];                                       // column numbers of this thread's tile pieces of the block staged next
+    unsigned toff[UP];                                   // … and their byte offsets in the gathered operand
     int permr[PERM ? kTileEP : 1];                       // value positions of this thread's entries of the block staged next
     uint4 own_cur = {0, 0, 0, 0}, own_nxt = {0, 0, 0, 0};      // SDDMM: this lane's 16 bytes of its row of R, block walked / next block
 #pragma unroll
     for (int i = 0; i < UP; ++i) ucolr[i] = 0;
 
-    auto load_words = [&](const TileDesc d) {            // for the block staged one step later
+    // Staging predicates are WAVE-UNIFORM (scalar branches, no exec masks): a wave instruction of tile pieces covers 8 whole rows
+    // and U is a multiple of 8; value / byte instructions run when their first lane has work, lanes beyond the end repeat the last
+    // element (into slots nobody reads).
+    const int wave_row = wave * RPW;                     // first tile row of this wave's piece 0
+    const int wave_e = wave * kWave;                     // first entry / dword of this wave's instruction 0
+    auto load_words = [&](const TileDesc d) {            // for the block staged one step later: byte offsets of its tile rows, value positions
 #pragma unroll
         for (int i = 0; i < UP; ++i) {
-            const int u = (t / CL) + i * (kTileThreads / CL);
-            if (u < d.U) ucolr[i] = P.ucol[d.u0 + u];
+            if (wave_row + i * (kTileThreads / CL) < d.U) {
+                ucolr[i] = P.ucol[d.u0 + (t / CL) + i * (kTileThreads / CL)];      // (multiplied by the row bytes when it is pinned: NOT here)
+            }
         }
         if constexpr (PERM) {
 #pragma unroll
             for (int i = 0; i < kTileEP; ++i) {
-                const int e = t + i * kTileThreads;
-                if (e < d.E) permr[i] = P.perm[(int64_t)d.e0 + e];
+                if (wave_e + i * kTileThreads < d.E) {
+                    int e = t + i * kTileThreads;
+                    e = e < d.E ? e : d.E - 1;
+                    permr[i] = P.perm[(int64_t)d.e0 + e];
+                }
             }
         }
     };
@@ -157,7 +176,10 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(const TileParams 
         // pinned in straight-line code before the first DMA of a step: hipcc otherwise places its wait for ucolr[i] inside the
         // predicated block of piece i — behind the DMA of piece i - 1
 #pragma unroll
-        for (int i = 0; i < UP; ++i) lat_pin(ucolr[i]);
+        for (int i = 0; i < UP; ++i) {
+            lat_pin(ucolr[i]);
+            toff[i] = __umul24((unsigned)ucolr[i], ld_bytes) + (unsigned)sub * 16u;      // (launcher: columns and row bytes below 2^24)
+        }
         if constexpr (PERM) {
 #pragma unroll
             for (int i = 0; i < kTileEP; ++i) lat_pin(permr[i]);
@@ -168,17 +190,20 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(const TileParams 
         const unsigned buf = lds0 + (unsigned)(k & 1) * L::kBuf;
 #pragma unroll
         for (int i = 0; i < UP; ++i) {
-            const int u = (t / CL) + i * (kTileThreads / CL);
-            if (u < d.U)
-                lat_dma16<false>(S, (uint32_t)ucolr[i] * ld_bytes + (uint32_t)sub * 16u, buf + (wave_piece + (unsigned)i * kTileThreads) * 16u);
+            if (wave_row + i * (kTileThreads / CL) < d.U)
+                lat_dma16<false>(S, toff[i], buf + (wave_piece + (unsigned)i * kTileThreads) * 16u);
         }
         if constexpr (MODE == kTileSpmm) {
 #pragma unroll
             for (int i = 0; i < kTileEP; ++i) {
-                const int e = t + i * kTileThreads;
-                if (e < d.E) {
-                    if constexpr (PERM) lat_dma4<false>(P.val, (uint32_t)permr[i] * 4u, buf + L::oVals + (wave_piece + (unsigned)i * kTileThreads) * 4u);
-                    else lat_dma4<true>(P.val, (uint32_t)(d.e0 + e) * 4u, buf + L::oVals + (wave_piece + (unsigned)i * kTileThreads) * 4u);
+                if (wave_e + i * kTileThreads < d.E) {
+                    if constexpr (PERM) {
+                        lat_dma4<false>(P.val, (uint32_t)permr[i] * 4u, buf + L::oVals + (wave_piece + (unsigned)i * kTileThreads) * 4u);
+                    } else {
+                        int e = t + i * kTileThreads;
+                        e = e < d.E ? e : d.E - 1;
+                        lat_dma4<true>(P.val, (uint32_t)(d.e0 + e) * 4u, buf + L::oVals + (wave_piece + (unsigned)i * kTileThreads) * 4u);
+                    }
                 }
             }
         }
@@ -186,14 +211,20 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(const TileParams 
             const int a0 = d.e0 & ~3, nd = (d.e0 + d.E - a0 + 3) >> 2;
 #pragma unroll
             for (int i = 0; i < (kTileEMax / 4 + 1 + kTileThreads - 1) / kTileThreads; ++i) {
-                const int q = t + i * kTileThreads;
-                if (q < nd) lat_dma4<true>(P.lidx, (uint32_t)(a0 + q * 4), buf + L::oLidx + (wave_piece + (unsigned)i * kTileThreads) * 4u);
+                if (wave_e + i * kTileThreads < nd) {
+                    int q = t + i * kTileThreads;
+                    q = q < nd ? q : nd - 1;
+                    lat_dma4<true>(P.lidx, (uint32_t)(a0 + q * 4), buf + L::oLidx + (wave_piece + (unsigned)i * kTileThreads) * 4u);
+                }
             }
         }
-        {   // row pointer slice: rptr[r0 .. r0 + R]
+        {   // row pointer slice: rptr[r0 .. r0 + R] (waves 0 and 1)
             const int64_t r0 = (b_first + (int64_t)k * b_step) * kTileRows;
             const int nr = (int)((P.n_rows - r0) < kTileRows ? (P.n_rows - r0) : kTileRows) + 1;
-            if (t < nr) lat_dma4<true>(P.rptr, (uint32_t)(r0 + t) * 4u, buf + L::oRs + wave_piece * 4u);
+            if (wave_e < nr) {
+                const int q = t < nr ? t : nr - 1;
+                lat_dma4<true>(P.rptr, (uint32_t)(r0 + q) * 4u, buf + L::oRs + wave_piece * 4u);
+            }
         }
     };
 
@@ -217,7 +248,9 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(const TileParams 
         const bool live = r < P.n_rows;
         const int s = live ? rs[rl] - d.e0 : 0, e = live ? rs[rl + 1] - d.e0 : 0;
         // eight entries per round; the rounds every row of the wave has in full run without predicates (a scalar trip count)
-        const int nfull = tile_wave_min<CL>((e - s) >> 3);
+        int len_lo, len_hi;
+        tile_wave_minmax<CL>(e - s, len_lo, len_hi);
+        const int nfull = len_lo >> 3;
         int kk = s;
         if constexpr (MODE == kTileSpmm) {
             float acc[4] = {0.f, 0.f, 0.f, 0.f};
@@ -248,8 +281,26 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(const TileParams 
                     acc[3] = fmaf(vv[j], bj[j].w, acc[3]);
                 }
             }
-            // what is left of the rows (fewer than eight entries where the rows are equally long): a missing entry reads the zero row
-            // with a zero value — a row never touches a dense row it does not reference, 0·0 adds nothing
+            // what is left of the rows.  Rows of ONE length (the common case): fewer than eight entries, a scalar count, no predicates …
+            if (len_lo == len_hi) {
+                const int rem = len_lo & 7;
+                float4 bj[7];
+#pragma unroll
+                for (int j = 0; j < 7; ++j)
+                    if (j < rem) bj[j] = *reinterpret_cast<const float4*>(trow + li[j] * RB);
+#pragma unroll
+                for (int j = 0; j < 7; ++j) {
+                    if (j < rem) {
+                        acc[0] = fmaf(v[j], bj[j].x, acc[0]);
+                        acc[1] = fmaf(v[j], bj[j].y, acc[1]);
+                        acc[2] = fmaf(v[j], bj[j].z, acc[2]);
+                        acc[3] = fmaf(v[j], bj[j].w, acc[3]);
+                    }
+                }
+                kk = e;
+            }
+            // … otherwise whole rounds in which a missing entry reads the zero row with a zero value: a row never touches a dense row
+            // it does not reference, 0·0 adds nothing
             while (__any(kk < e)) {
                 float4 bj[8];
                 float vv[8];
@@ -281,20 +332,23 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(const TileParams 
             //   partner sub ^ 2:                h2[j] = h4[j]   + partner's h4[j + 2]
             //   partner sub ^ 1:                h     = h2[0]   + partner's h2[1]            = the dot of entry kk + sub
             // 7 DPP additions per 8 entries, no selects.
-            const unsigned char* lidx = lid + sub;       // slot j reads lid[kk + (j ^ sub)] = lidx[kk + (j ^ sub) - sub]
-            int xo[8];
+            unsigned sel[8];                             // v_perm selectors: byte (j ^ sub) of the round's 8 entry bytes into bits 0..7, zeros above
 #pragma unroll
-            for (int j = 0; j < 8; ++j) xo[j] = (j ^ sub) - sub;
+            for (int j = 0; j < 8; ++j) sel[j] = 0x0c0c0c00u | (unsigned)(j ^ sub);
             auto round = [&]() -> float {
+                unsigned lo8, hi8;
+                __builtin_memcpy(&lo8, lid + kk, 4);
+                __builtin_memcpy(&hi8, lid + kk + 4, 4);
                 unsigned li[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) li[j] = lidx[kk + xo[j]];
+                for (int j = 0; j < 8; ++j) li[j] = __builtin_amdgcn_perm(hi8, lo8, sel[j]);
+                float4 bj[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) bj[j] = *reinterpret_cast<const float4*>(trow + li[j] * RB);
+                asm volatile("" ::: "memory");           // (all eight LDS requests leave before the first dot waits for one)
                 float part[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float4 bj = *reinterpret_cast<const float4*>(trow + li[j] * RB);
-                    part[j] = fmaf(g3, bj.w, fmaf(g2, bj.z, fmaf(g1, bj.y, g0 * bj.x)));
-                }
+                for (int j = 0; j < 8; ++j) part[j] = fmaf(g3, bj[j].w, fmaf(g2, bj[j].z, fmaf(g1, bj[j].y, g0 * bj[j].x)));
                 float h4[4], h2[2];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) h4[j] = part[j] + dpp_move<0x141>(part[7 - j]);
@@ -303,7 +357,7 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(const TileParams 
                 return h2[0] + dpp_move<0xB1>(h2[1]);
             };
             for (int it = 0; it < nfull; ++it) {
-                gv[kk + sub] = P.alpha * round();
+                gv[(unsigned)(kk + sub)] = P.alpha * round();
                 kk += 8;
             }
             // the rest under a store predicate only: the slots of entries beyond a row's end hold whatever dense row the byte behind the
