@@ -391,24 +391,16 @@ typedef struct tsgu_march_plan {
     const void* rstart;       /* read when uniform_len == 0 */
 } tsgu_march_plan;
 
-/* 1 when there is a plane-march kernel for (mode: 0 SpMM, 1 SDDMM, 2 transposed SpMM, 3 fused backward; displacement set `mask`; rows of one length
+/* 1 when there is a plane-march kernel for (mode: 0 SpMM, 1 SDDMM, 2 transposed SpMM; displacement set `mask`; rows of one length
  * or not; workgroup size): the whole box — all three products, 256 / 512 threads; the triangular halves of the box and of the
  * 7-point cross (by displacement, with / without the centre) on truncated lattices — the SDDMM, 256 threads.  Everything else
  * is faster on the general plane sweep (tsgu_csr_*_lattice) and has no plane-march kernel. */
 int tsgu_march_supported(int mode, int mask, int uniform_len, int threads);
-/* Dynamic LDS bytes of a configuration (mode: 0 SpMM, 1 SDDMM, 2 transposed SpMM, 3 fused backward) or a negative tsgu_status. */
+/* Dynamic LDS bytes of a configuration (mode: 0 SpMM, 1 SDDMM, 2 transposed SpMM) or a negative tsgu_status. */
 int tsgu_march_lds_bytes(int mode, int vtype, int64_t p, int ty, int tz, int ry, int rz, int ncls, int threads);
 /* C = A·B (transposed == 0) or gradB = Aᵀ·G (transposed != 0; `val` is A's value array in A's own order, `B` is G). */
 int tsgu_csr_spmm_march(int vtype, const tsgu_march_plan* plan, int transposed, int64_t n_rows, int64_t nnz, const void* val,
                         const void* B, int64_t ldb, void* C, int64_t ldc, int64_t p, int device, void* stream);
-/* Both gradients of C = A·B in ONE march (csrc/march_bwd_impl.h; the whole box, p = 32, plan->threads = 256, mode 3 of
- * tsgu_march_lds_bytes / tsgu_march_supported): grad_vals[k] = alpha·<G[row k,:], B[col k,:]> in A's stored order and
- * gradB = Aᵀ·G.  The halo ring of G serves the transposed product AND, through its centre rows, the SDDMM's own rows: G is read
- * once.  Replaces the pair tsgu_csr_sddmm_march + tsgu_csr_spmm_march(transposed) (reference sparse_matmul.py:186-205 + :229);
- * the same sums in the same order as the pair. */
-int tsgu_csr_mm_backward_march(int vtype, const tsgu_march_plan* plan, int64_t n_rows, int64_t nnz, const void* val, const void* G,
-                               int64_t ldg, const void* B, int64_t ldb, void* grad_vals, double alpha, void* gradB, int64_t ldgb,
-                               int64_t p, int device, void* stream);
 /* out_vals[k] = alpha·<R[row k,:], Cm[col k,:]> in A's stored order (accumulate != 0: added to out_vals — the later column
  * tiles of operands wider than 64 columns). */
 int tsgu_csr_sddmm_march(int vtype, const tsgu_march_plan* plan, int64_t n_rows, int64_t nnz, const void* R, int64_t ldr,

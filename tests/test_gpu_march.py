@@ -274,59 +274,6 @@ def test_no_row_touches_a_dense_row_it_does_not_reference(per, points, part):
         assert float((got[fin] - want[fin]).abs().max()) < 1e-4
 
 
-FUSED_CASES = [
-    # per, nb, (nx, ny, nz), configs (ty, tz, nseg)
-    ((True, True, True), 1, (9, 10, 12), [(4, 8, 2), (4, 8, 9), (2, 8, 3)]),       # periodic, ragged tiles, one-plane segments
-    ((True, True, True), 1, (3, 3, 3), [(4, 8, 1), (4, 8, 3)]),                    # every row wraps
-    ((False, False, False), 1, (9, 10, 12), [(4, 8, 2), (4, 8, 9), (4, 8, 1)]),    # truncated box
-    ((False, False, False), 3, (5, 6, 8), [(4, 8, 2), (2, 8, 5)]),                 # ... batched items
-    ((True, False, False), 1, (5, 8, 8), [(4, 8, 2)]),                             # wraps in x only
-    ((False, True, True), 1, (6, 7, 9), [(4, 8, 3)]),                              # truncated in x only
-    ((False, False, False), 1, (3, 3, 3), [(4, 8, 1), (4, 8, 3)]),
-]
-
-
-@pytest.mark.parametrize("per,nb,grid,configs", FUSED_CASES)
-def test_fused_backward_march_equals_the_two_launches(per, nb, grid, configs):
-    """csrc/march_bwd_impl.h: both gradients of C = A·B in one march (the G ring serves the transposed product and the SDDMM's
-    own rows).  Same sums in the same order as the two plane-march launches: gradA and gradB bit for bit, and the oracle."""
-    from test_lattice_plan_cpu import _box_stencil
-
-    be, lt, pt = _mods()
-    dev = torch.device("cuda:0")
-    nx, ny, nz = grid
-    p = 32
-    crow, col = _box_stencil(nx, ny, nz, per, 27, None, nb)
-    n = nb * nx * ny * nz
-    g = torch.Generator().manual_seed(nx * 17 + nb)
-    val = torch.randn(col.numel(), generator=g)
-    B = torch.randn(n, p, generator=g)
-    Gd = torch.randn(n, p, generator=g)
-    _, gAo, gBo = _oracle_mm(crow, col, val, B, Gd)
-    val_d, B_d, G_d = val.to(dev), B.to(dev), Gd.to(dev)
-    plan = pt.RowGather(crow.to(dev), col.to(dev), n, n)
-    lp = lt.build_lattice_plan_hip(plan, be, dims=(nb, nx, ny, nz))
-    mt = lt.march_tables(lp)
-    assert mt is not None and mt.full
-    for cs in configs:
-        lt._MARCH_CFG_ENV = ",".join(str(v) for v in cs + (256,))
-        try:
-            mt._cfg.clear()
-            c_s = be.march_config(lp, be.LAT_SDDMM, torch.float32, p)
-            c_t = be.march_config(lp, be.LAT_SPMMT, torch.float32, p)
-            c_b = be.march_config(lp, be.MARCH_BWD, torch.float32, p)
-        finally:
-            lt._MARCH_CFG_ENV = ""
-        assert c_s is not None and c_t is not None and c_b is not None, cs
-        gA2 = be.csr_sddmm_lattice(lp, c_s, G_d, B_d, alpha=-0.75)
-        gB2 = be.csr_spmm_lattice(lp, c_t, val_d, G_d)
-        gA, gB = be.csr_mm_backward_march(lp, c_b, val_d, G_d, B_d, alpha=-0.75)
-        assert torch.equal(gA, gA2) and torch.equal(gB, gB2), cs
-        assert G.rel_err(gA.cpu().numpy(), -0.75 * gAo) < 1e-5 and G.rel_err(gB.cpu().numpy(), gBo) < 1e-5, cs
-    mt._cfg.clear()
-    assert be.march_config(lp, be.MARCH_BWD, torch.float32, 64) is None          # 32 columns only
-
-
 def test_wide_operands_run_as_column_tiles():
     """128 RHS columns (the width of the reference's SuiteSparse benchmark): two launches over tiles of 64 columns; the SDDMM
     adds the dots of the second tile to the first."""

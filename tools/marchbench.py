@@ -86,7 +86,7 @@ def main():
         lt._MARCH_CFG_ENV = cs
         mt._cfg.clear()
         for m in modes:
-            mode = {"fwd": be.LAT_SPMM, "sddmm": be.LAT_SDDMM, "spmmt": be.LAT_SPMMT, "bwd": be.MARCH_BWD}[m]
+            mode = {"fwd": be.LAT_SPMM, "sddmm": be.LAT_SDDMM, "spmmt": be.LAT_SPMMT}[m]
             cfg = be.march_config(lp, mode, dt, p)
             if cfg is not None and a.force_rstart and cfg.struct.uniform_len:
                 keep = crow.to(torch.int32).contiguous()

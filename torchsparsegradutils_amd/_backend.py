@@ -97,8 +97,6 @@ SIGNATURES = {
     "tsgu_march_lds_bytes": (_int, [_int, _int, _i64, _int, _int, _int, _int, _int, _int]),
     "tsgu_csr_spmm_march": (_int, [_int, _ptr, _int, _i64, _i64, _ptr, _ptr, _i64, _ptr, _i64, _i64, _int, _ptr]),
     "tsgu_csr_sddmm_march": (_int, [_int, _ptr, _i64, _i64, _ptr, _i64, _ptr, _i64, _ptr, _dbl, _int, _i64, _int, _ptr]),
-    "tsgu_csr_mm_backward_march": (_int, [_int, _ptr, _i64, _i64, _ptr, _ptr, _i64, _ptr, _i64, _ptr, _dbl, _ptr, _i64, _i64, _int, _ptr]),
-    "tsgu_lattice_slots": (_int, []),
     "tsgu_lattice_rows": (_int, [_int, _i64, _ptr, _ptr, _int, _int, _int, _int, _ptr, _int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr,
                                  _int, _int, _int, _ptr]),
     "tsgu_lattice_row_codes": (_int, [_int, _i64, _ptr, _ptr, _int, _int, _int, _int, _ptr, _int, _ptr, _int, _ptr, _int, _ptr]),
@@ -501,7 +499,6 @@ def csr_mm_backward_rowpack(tcrow, rp, val, G, B, n_rows_t: int):
 
 # ---- lattice plane-sweep kernels (csrc/lattice_impl.h; plans from _lattice.py) -------------------------------
 LAT_SPMM, LAT_SDDMM, LAT_SPMMT = 0, 1, 2
-MARCH_BWD = 3        # the fused backward of the plane march (SDDMM + transposed product in one launch)
 
 
 def lattice_lds_bytes(mode: int, vtype: int, p: int, ty: int, tz: int, ry: int, rz: int, nloc: int, recw: int, threads: int,
@@ -732,31 +729,6 @@ def csr_sddmm_lattice(lp, cfg, R, Cm, alpha: float = 1.0):
     if rc:
         check(rc, "tsgu_csr_sddmm_lattice")
     return out
-
-
-def csr_mm_backward_march(lp, cfg, val, G, B, alpha: float = 1.0):
-    """(gradA values in A's stored order, gradB = Aᵀ·G) of C = A·B by ONE plane march (csrc/march_bwd_impl.h)."""
-    lib = _lib or load_library()
-    dev = G.device
-    if not G.is_cuda or B.device != dev or val.device != dev:
-        require_device(val, G, B)
-        raise RuntimeError(f"all operands must be on the same device, got {val.device}, {G.device} and {B.device}")
-    G, B = rowmajor(G), rowmajor(B)
-    p = G.size(-1)
-    if not val.is_contiguous():
-        val = val.contiguous()
-    gvals = torch.empty((lp.nnz,), dtype=G.dtype, device=dev)
-    gradB = torch.empty((lp.n_rows, p), dtype=G.dtype, device=dev)
-    tok = _timed("march_backward", dev) if KERNEL_EVENTS is not None else None
-    with _on_device(dev):
-        rc = lib.tsgu_csr_mm_backward_march(_VTYPE[G.dtype], cfg.struct_addr, lp.n_rows, lp.nnz, val.data_ptr(), G.data_ptr(), _ld(G),
-                                            B.data_ptr(), _ld(B), gvals.data_ptr(), float(alpha), gradB.data_ptr(), p, p, dev.index,
-                                            _raw_stream(dev))
-    if tok is not None:
-        _timed_end(tok, dev)
-    if rc:
-        check(rc, "tsgu_csr_mm_backward_march")
-    return gvals, gradB
 
 
 def _tiled_ok(*dense) -> bool:

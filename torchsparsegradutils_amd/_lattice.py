@@ -551,7 +551,7 @@ ENABLE_MARCH = os.environ.get("TSGU_ENABLE_MARCH", "1") == "1"
 _MARCH_CFG_ENV = os.environ.get("TSGU_MARCH_CFG", "")   # "ty,tz,nseg,threads" overrides the choice (experiments)
 MARCH_TAPS = 9
 MARCH_MAX_CLASSES = 64
-_MARCH_WAVES_PER_CU = {0: 20, 1: 20, 2: 16, 3: 12}     # resident waves per CU the segment count is planned for (3: the fused backward)
+_MARCH_WAVES_PER_CU = {0: 20, 1: 20, 2: 16}     # resident waves per CU the segment count is planned for
 # workgroup sizes in order of preference: the first that fits the lattice is taken (measured at C2, same box, us:
 # forward 4x8/256: 80.8-85.5, 8x8/512: 88.1;  SDDMM 8x8/512: 87.4, 4x8/256: 94.6-101.7;  transposed 8x8/512: 102.4, 4x8/256: 99.5-103.0)
 # round 4 (three alternations per configuration in one process, C2, us): SDDMM 4x8/256 80.1-83.0 against 8x8/512 84.4-97.5 — the
@@ -631,8 +631,6 @@ def march_config_for(plan: LatticePlan, mode: int, vtype: int, p: int, lds_bytes
     halves: the SDDMM)."""
     if not ENABLE_MARCH or vtype != 0 or not (p in (16, 32, 64) or (p > 64 and p % 64 == 0 and p <= 1024)):
         return None
-    if mode == 3 and p != 32:
-        return None      # the fused backward: 32 columns (8 lanes per row)
     if p == 16 and mode == 0 and not _MARCH_CFG_ENV:
         return None      # 16 columns, forward: the general sweep is faster (measured at C2's lattice: 46 against 58 us; SDDMM 89 / 77, transposed 86 / 71)
     mt = march_tables(plan)

@@ -45,9 +45,6 @@ ENABLE_TILE = os.environ.get("TSGU_ENABLE_TILE", "1") == "1"
 ENABLE_LATTICE = os.environ.get("TSGU_ENABLE_LATTICE", "1") == "1"
 # value types the sweeps are compiled for (fp32 accumulation for bf16)
 LATTICE_DTYPES = (torch.float32, torch.bfloat16, torch.float64)
-# both gradients of sparse_mm on a whole-box stencil by ONE plane march (fp32, 32 columns); TSGU_FUSED_BACKWARD=0: the SDDMM and
-# the transposed product as two launches
-FUSED_BACKWARD = os.environ.get("TSGU_FUSED_BACKWARD", "0") == "1"
 # measured launch configurations: every trial launch follows a 256 MB device copy (the cache state of a step, not of a back-to-back loop)
 TUNE_COLD = os.environ.get("TSGU_TUNE_COLD", "1") != "0"
 
@@ -127,7 +124,7 @@ def _lattice_cfg(plan: RowGather, mode: int, dense: torch.Tensor, *others: torch
         if memo is not None:
             memo[key] = (fwd, cfg)
         return fwd, cfg
-    if wide or mode == _be.MARCH_BWD:
+    if wide:
         return None            # (no general-sweep form of these)
     lp = _lattice_plan(plan, transposed=True) if mode == _be.LAT_SPMMT else fwd
     if lp is None:
@@ -276,13 +273,6 @@ def _lattice_backward(plan: RowGather, values: torch.Tensor, G: torch.Tensor, B:
             return None
         fplan, (Gf, Bf) = fl
     vals = values.reshape(-1)
-    if FUSED_BACKWARD and Gf.dtype == torch.float32 and Gf.size(-1) == 32:
-        # whole-box stencils: both gradients in ONE march — the halo ring of G serves the transposed product and, through its
-        # centre rows, the SDDMM's own rows (csrc/march_bwd_impl.h)
-        both = _lattice_cfg(fplan, _be.MARCH_BWD, Gf, Bf)
-        if both is not None:
-            ga, gb = _be.csr_mm_backward_march(both[0], both[1], vals, Gf, Bf)
-            return ga.view(values.shape), gb.view(B.shape)
     fwd = _lattice_cfg(fplan, _be.LAT_SDDMM, Bf, Gf)
     if fwd is None:
         return None

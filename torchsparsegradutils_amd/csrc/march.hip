@@ -1,12 +1,9 @@
 // Plane-march kernels (march_impl.h): extern "C" entry points (declared in include/tsgu_hip.h) and the fp32 instantiations.
 #include "march_sets.h"
-#include "march_bwd_impl.h"
 
 using namespace tsgu;
 
 namespace {
-
-constexpr int kMarchBwd = 3;      // mode number of the fused backward in the layout / support queries
 
 int march_lanes(int vtype, int64_t p) {
     if (vtype != TSGU_F32 || p <= 0 || (p * 4) % 16) return 0;
@@ -54,7 +51,7 @@ int fill(MarchParams& P, const tsgu_march_plan* pl, int mode, int vtype, int64_t
     P.kidx = static_cast<const unsigned char*>(pl->kidx);
     P.rcls = static_cast<const unsigned char*>(pl->rcls);
     P.nnz = nnz;
-    const int rc = mode == kMarchBwd ? march_bwd_layout(P, cl, pl->threads) : march_layout(P, mode, cl, pl->threads, pl->ntap);
+    const int rc = march_layout(P, mode, cl, pl->threads, pl->ntap);
     if (rc < 0) return rc;
     const int64_t nblocks = (int64_t)P.nb * P.nseg * P.tiles_y * P.tiles_z;
     if (nblocks > 0x7fffffffLL) return TSGU_ERR_TOO_LARGE;
@@ -77,45 +74,17 @@ int dispatch(int cl, int threads, const MarchParams& P, void* stream) {
 extern "C" {
 
 int tsgu_march_supported(int mode, int mask, int uniform_len, int threads) {
-    if (mode < 0 || mode > kMarchBwd || mask <= 0 || mask > (int)kBoxAll) return 0;
-    if (mode == kMarchBwd) return (uint32_t)mask == kBoxAll && threads == 256;     // the fused backward: the whole box, 4 x 8 tiles
+    if (mode < 0 || mode > kLatSpmmT || mask <= 0 || mask > (int)kBoxAll) return 0;
     return march_supported(mode, (uint32_t)mask, uniform_len > 0, threads) ? 1 : 0;
 }
 
 int tsgu_march_lds_bytes(int mode, int vtype, int64_t p, int ty, int tz, int ry, int rz, int ncls, int threads) {
     const int cl = march_lanes(vtype, p);
-    if (cl == 0 || mode < 0 || mode > kMarchBwd) return TSGU_ERR_BAD_DTYPE;
+    if (cl == 0 || mode < 0 || mode > kLatSpmmT) return TSGU_ERR_BAD_DTYPE;
     if (threads != 256 && threads != 512) return TSGU_ERR_BAD_ARG;
     MarchParams P{};
     P.ty = ty, P.tz = tz, P.ry = ry, P.rz = rz, P.ncls = ncls;
-    if (mode == kMarchBwd) return cl == 8 && threads == 256 ? march_bwd_layout(P, cl, threads) : TSGU_ERR_BAD_ARG;
     return march_layout(P, mode, cl, threads, 9);
-}
-
-int tsgu_csr_mm_backward_march(int vtype, const tsgu_march_plan* plan, int64_t n_rows, int64_t nnz, const void* val, const void* G,
-                               int64_t ldg, const void* B, int64_t ldb, void* grad_vals, double alpha, void* gradB, int64_t ldgb, int64_t p,
-                               int device, void* stream) {
-    MarchParams P{};
-    int cl = 0;
-    if (const int rc = fill(P, plan, kMarchBwd, vtype, p, n_rows, nnz, cl)) return rc;
-    if (cl != 8 || plan->threads != 256 || plan->mask != kBoxAll) return TSGU_ERR_BAD_ARG;
-    if (n_rows == 0) return TSGU_OK;
-    if (!val || !G || !B || !grad_vals || !gradB || ldg < p || ldb < p || ldgb < p) return TSGU_ERR_BAD_ARG;
-    if (ldg % 4 || ldb % 4 || ldgb % 4 || !aligned16(G) || !aligned16(B) || !aligned16(gradB)) return TSGU_ERR_BAD_ARG;
-    if (const int rc = set_device(device)) return rc;
-    const int64_t plane = (int64_t)plan->ny * plan->nz * 4;
-    if (plane * ldg > 0x7fffffffLL || plane * ldb > 0x7fffffffLL || plane * ldgb > 0x7fffffffLL) return TSGU_ERR_TOO_LARGE;
-    P.val = val;
-    P.S = B;
-    P.lds_ = ldb;
-    P.Own = G;
-    P.ldown = ldg;
-    P.out = gradB;
-    P.ldo = ldgb;
-    P.gvals = grad_vals;
-    P.alpha = (float)alpha;
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    return P.uniform > 0 ? march_bwd_launch<8, 256, kRowsUniform>(P, s) : march_bwd_launch<8, 256, kRowsBox>(P, s);
 }
 
 int tsgu_csr_spmm_march(int vtype, const tsgu_march_plan* plan, int transposed, int64_t n_rows, int64_t nnz, const void* val,

@@ -211,19 +211,17 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(const TileParams 
             const int a0 = d.e0 & ~3, nd = (d.e0 + d.E - a0 + 3) >> 2;
 #pragma unroll
             for (int i = 0; i < (kTileEMax / 4 + 1 + kTileThreads - 1) / kTileThreads; ++i) {
-                if (wave_e + i * kTileThreads < nd) {
-                    int q = t + i * kTileThreads;
-                    q = q < nd ? q : nd - 1;
-                    lat_dma4<true>(P.lidx, (uint32_t)(a0 + q * 4), buf + L::oLidx + (wave_piece + (unsigned)i * kTileThreads) * 4u);
+                if (wave_e + i * kTileThreads < nd) {       // (lane predicate: a repeated dword would land beyond the byte region)
+                    const int q = t + i * kTileThreads;
+                    if (q < nd) lat_dma4<true>(P.lidx, (uint32_t)(a0 + q * 4), buf + L::oLidx + (wave_piece + (unsigned)i * kTileThreads) * 4u);
                 }
             }
         }
         {   // row pointer slice: rptr[r0 .. r0 + R] (waves 0 and 1)
             const int64_t r0 = (b_first + (int64_t)k * b_step) * kTileRows;
             const int nr = (int)((P.n_rows - r0) < kTileRows ? (P.n_rows - r0) : kTileRows) + 1;
-            if (wave_e < nr) {
-                const int q = t < nr ? t : nr - 1;
-                lat_dma4<true>(P.rptr, (uint32_t)(r0 + q) * 4u, buf + L::oRs + wave_piece * 4u);
+            if (wave_e < nr) {                              // (waves 0 and 1; lane predicate: the slice is 65 words, the region 72)
+                if (t < nr) lat_dma4<true>(P.rptr, (uint32_t)(r0 + t) * 4u, buf + L::oRs + wave_piece * 4u);
             }
         }
     };
@@ -345,7 +343,12 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(const TileParams 
                 float4 bj[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) bj[j] = *reinterpret_cast<const float4*>(trow + li[j] * RB);
+#ifndef TSGU_TILE_SDDMM_GROUPED
+#define TSGU_TILE_SDDMM_GROUPED 1
+#endif
+#if TSGU_TILE_SDDMM_GROUPED
                 asm volatile("" ::: "memory");           // (all eight LDS requests leave before the first dot waits for one)
+#endif
                 float part[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) part[j] = fmaf(g3, bj[j].w, fmaf(g2, bj[j].z, fmaf(g1, bj[j].y, g0 * bj[j].x)));

@@ -74,13 +74,12 @@ if os.environ.get("TSGU_LIB_PATH"):          # another build of the kernels is l
 
 
 def _step_key(dtype, p: int):
-    return (dtype, p, _ops.ENABLE_LATTICE, _ops._lt.ENABLE_MARCH, _ops.ENABLE_PACK)
+    return (dtype, p, _ops.ENABLE_LATTICE, _ops._lt.ENABLE_MARCH, _ops.ENABLE_PACK, _ops.ENABLE_TILE)
 
 
 def _step_plan(A: torch.Tensor, B: torch.Tensor):
     """The `_tsgu_host.StepPlan` of (A's pattern, B's dtype and width), or None while the pattern is young / not covered."""
-    if (A.dtype != B.dtype or A.device != B.device or not B.is_contiguous() or B.data_ptr() % 16 or _be.KERNEL_EVENTS is not None
-            or _ops.FUSED_BACKWARD):
+    if A.dtype != B.dtype or A.device != B.device or not B.is_contiguous() or B.data_ptr() % 16 or _be.KERNEL_EVENTS is not None:
         return None
     if A.layout == torch.sparse_csr:
         own = _pt.from_csr(A).core.own
@@ -99,7 +98,7 @@ def _settle_step_plan(op: "_Operand", values: torch.Tensor, G: torch.Tensor, B: 
     host path — the three configurations of a lattice stencil (the StepPlan copies the plan structs and holds every device table
     they point into), or the plan-free kernels with the cached transposed pattern once the row-pair plans are known not to apply."""
     plan = op.plan
-    if (_host is None or not FAST_STEP or plan.perm is not None or _ops.FUSED_BACKWARD or op.flat_batch is not None
+    if (_host is None or not FAST_STEP or plan.perm is not None or op.flat_batch is not None
             or not (values.dtype == G.dtype == B.dtype) or (op.layout != torch.sparse_csr and op.indices is None)):
         return
     dtype, p = G.dtype, G.size(-1)
