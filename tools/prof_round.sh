@@ -5,7 +5,7 @@
 #   3. the un-profiled bench line and the secondary configurations               -> gpurun_out/prof_<tag>/*.json(l)
 # Copy the summaries into profiles/ with tools/collect_profiles.py afterwards.
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
@@ -14,7 +14,7 @@ timeout 900 python3 $ROOT/bench.py > $OUT/bench.json 2> $OUT/bench.err
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python3 $ROOT/bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-c5 --no-patterns > $OUT/stats.log 2>&1
 for pass in "fetch FETCH_SIZE" "write WRITE_SIZE"; do
   set -- $pass
-  timeout 900 rocprofv3 --kernel-trace --pmc $2 --kernel-include-regex "tsgu::(march_kernel|march_bwd_kernel|lattice_kernel|csr_(spmm|sddmm|rowpack|mm_backward))" --output-format csv \
+  timeout 900 rocprofv3 --kernel-trace --pmc $2 --kernel-include-regex "tsgu::(march_kernel|lattice_kernel|tile_kernel|csr_(spmm|sddmm|rowpack|mm_backward))" --output-format csv \
      -d $OUT/$1 -o p -- python3 $ROOT/bench.py --steps 3 --warmup 3 --no-cpu-baseline --no-c5 --no-patterns > $OUT/$1.log 2>&1
 done
 # per-pattern HBM bytes per step (bench.py's `patterns` block): the same two passes around a few steps of each pattern

@@ -237,7 +237,17 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(const TileParams 
     auto walk = [&](int k, const TileDesc d) {
         const unsigned char* buf = tile_lds + (k & 1) * L::kBuf;
         const float* vals = reinterpret_cast<const float*>(buf + L::oVals);
-        const unsigned char* lid = buf + L::oLidx + (d.e0 & 3);
+        // entry bytes: entry k of the block sits at byte (e0 & 3) + k of the byte region.  They are read as ALIGNED dwords and shifted
+        // into place (v_alignbyte): a byte-misaligned 8- or 16-byte LDS read is slow (the SDDMM with one misaligned 8-byte read per round
+        // ran 141 us against 120 us with eight byte reads)
+        const unsigned* lidw = reinterpret_cast<const unsigned*>(buf + L::oLidx);
+        auto bytes8 = [&](int at, unsigned& lo, unsigned& hi) {      // the 8 entry bytes of the round that starts at entry `at`
+            const int b = (d.e0 & 3) + at;
+            const unsigned* w = lidw + (b >> 2);
+            const unsigned w0 = w[0], w1 = w[1], w2 = w[2];
+            lo = __builtin_amdgcn_alignbyte(w1, w0, (unsigned)b & 3u);
+            hi = __builtin_amdgcn_alignbyte(w2, w1, (unsigned)b & 3u);
+        };
         const int* rs = reinterpret_cast<const int*>(buf + L::oRs);
         const unsigned char* trow = buf + sub * 16;
         const unsigned char* zrow = tile_lds + L::oZero + sub * 16;
@@ -255,9 +265,11 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(const TileParams 
             unsigned li[8];
             float v[8];
             auto fetch = [&](int at) {                   // entry bytes and values of the round that starts at `at` (reads beyond a row's
-#pragma unroll                                           // end stay inside the LDS buffer: harmless)
+                unsigned lo, hi;                         // end stay inside the LDS buffer: harmless)
+                bytes8(at, lo, hi);
+#pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    li[j] = lid[at + j];
+                    li[j] = ((j < 4 ? lo : hi) >> (8 * (j & 3))) & 0xffu;
                     v[j] = vals[at + j];
                 }
             };
@@ -335,8 +347,7 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(const TileParams 
             for (int j = 0; j < 8; ++j) sel[j] = 0x0c0c0c00u | (unsigned)(j ^ sub);
             auto round = [&]() -> float {
                 unsigned lo8, hi8;
-                __builtin_memcpy(&lo8, lid + kk, 4);
-                __builtin_memcpy(&hi8, lid + kk + 4, 4);
+                bytes8(kk, lo8, hi8);
                 unsigned li[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) li[j] = __builtin_amdgcn_perm(hi8, lo8, sel[j]);
