@@ -179,6 +179,8 @@ def c5_leg(dev, world, rank, steps, warmup, barrier):
     def fwd_gathered_overlap():
         return parallel.sharded_batched_apply(sparse_mm, A_own, B_own, gather=True, overlap_chunks=min(4, hi - lo), batch=batch)
 
+    host_ms = {}
+
     def timed(fn):
         # a rank that fails in its warm-up must not leave the others waiting in the barrier below: agree first
         err = None
@@ -201,6 +203,7 @@ def c5_leg(dev, world, rank, steps, warmup, barrier):
         t0 = time.perf_counter()
         for _ in range(steps):
             fn()
+        host_ms[fn.__name__] = (time.perf_counter() - t0) / steps * 1e3      # the host's share: all launches queued, nothing waited for
         barrier()
         el = time.perf_counter() - t0
         if world > 1:
@@ -225,7 +228,27 @@ def c5_leg(dev, world, rank, steps, warmup, barrier):
                              "frac_of_hbm_peak_per_gpu": round(ab["spmm"] / world / (ms_fwd * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
         "fwd_bwd_compute_only": {"ms": round(ms_fb, 4), "GBps_whole_job": round(ab["fwd_bwd"] / (ms_fb * 1e-3) / 1e9, 1),
                                  "frac_of_hbm_peak_per_gpu": round(ab["fwd_bwd"] / world / (ms_fb * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+        "host_ms_per_step": {"fwd": round(host_ms.get("fwd_local", 0.0), 4), "fwd_bwd": round(host_ms.get("fwd_bwd_local", 0.0), 4),
+                             "note": "time the host needs to queue one step (round 5: batched CSR steps go through csrc/host/step.cpp)"},
     }
+    if world == 1 and nloc >= 8:
+        # one GPU's share of the 8-GPU job (8 items): what each rank of the sharded run steps — kernels and host time per step
+        try:
+            A8 = torch.sparse_csr_tensor(crow1.unsqueeze(0).repeat(8, 1), col1.unsqueeze(0).repeat(8, 1), val[:8].clone(), (8, n, n)).requires_grad_(True)
+            B8 = B_own[:8].clone().requires_grad_(True)
+            G8 = G_loc[:8].clone()
+
+            def share_fwd_bwd():
+                C = sparse_mm(A8, B8)
+                torch.autograd.grad(C, (A8, B8), G8)
+
+            ms8 = timed(share_fwd_bwd)
+            ab8 = alg_bytes(n, nnz, p, I=4, V=2, items=8)
+            out["one_gpu_share_of_8"] = {"items": 8, "fwd_bwd_ms": round(ms8, 4), "host_ms_per_step": round(host_ms.get("share_fwd_bwd", 0.0), 4),
+                                         "frac_of_hbm_peak": round(ab8["fwd_bwd"] / (ms8 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            del A8, B8, G8
+        except Exception as exc:  # noqa: BLE001
+            out["one_gpu_share_of_8"] = {"error": repr(exc)}
     if world > 1:
         ms_e2e = timed(fwd_gathered)
         ms_ovl = timed(fwd_gathered_overlap)

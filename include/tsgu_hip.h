@@ -267,14 +267,6 @@ typedef struct tsgu_tile_plan {
 int tsgu_tile_geometry(int vtype, int64_t p, int* rows_per_block, int* max_union, int* max_entries);
 int tsgu_csr_spmm_tile(int vtype, const tsgu_tile_plan* plan, const void* val, const void* B, int64_t ldb, void* C, int64_t ldc,
                        int64_t p, int device, void* stream);
-/* Both gradients of C = A·B in ONE walk of the TRANSPOSED pattern's plan (plan_t: rows = columns of A, with perm): the tile holds the
- * rows of G a block of 64 columns references, a lane group owns column j with B[j] in registers —
- *   gradB[j,:] = Σ_i A(i,j)·G[i,:]   (torchsparsegradutils/sparse_matmul.py:229)   and
- *   gradA_vals[perm[k]] = alpha·<G[i,:], B[j,:]>   (sparse_matmul.py:186-205), in A's own value order —
- * from the same tile row: G is staged once for both (the two-launch form stages a tile of B for the SDDMM as well).  gradB sums a
- * column's entries eight at a time in a lane-dependent order (deterministic; equal to tsgu_csr_spmm to rounding). */
-int tsgu_csr_mm_backward_tile(int vtype, const tsgu_tile_plan* plan_t, const void* val, const void* G, int64_t ldg, const void* B, int64_t ldb,
-                              void* gradA_vals, double alpha, void* gradB, int64_t ldgb, int64_t p, int device, void* stream);
 /* out_vals[k] = alpha·<R[row k,:], Cm[col k,:]> in the walked (stored) order; plan without perm. */
 int tsgu_csr_sddmm_tile(int vtype, const tsgu_tile_plan* plan, const void* R, int64_t ldr, const void* Cm, int64_t ldc, void* out_vals,
                         double alpha, int64_t p, int device, void* stream);

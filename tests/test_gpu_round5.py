@@ -251,20 +251,14 @@ def test_tile_kernels_equal_the_plan_free_kernels_bit_for_bit(name):
     assert torch.equal(gB, be.csr_spmm(pt.crow, pt.col, val, Gd, n, n, perm=pt.perm))
     assert torch.equal(be.csr_sddmm_tile(tp, Gd, B, alpha=-1.0), -gA)
     assert torch.equal(be.csr_sddmm_tile(tp, Gd, B), gA)                       # (run to run: no atomics anywhere)
-    # both gradients in ONE walk of the transposed pattern's tiles: gradA by the same dots and the same tree as the SDDMM (same bits),
-    # gradB summed eight entries at a time in a lane-dependent order (equal to rounding, deterministic)
-    gA2, gB2 = be.csr_mm_backward_tile(tt, val, Gd, B)
-    assert torch.equal(gA2, gA) and torch.allclose(gB2, gB, rtol=1e-5, atol=1e-5)
-    gA3, gB3 = be.csr_mm_backward_tile(tt, val, Gd, B, alpha=-1.0)
-    assert torch.equal(gA3, -gA) and torch.equal(gB3, gB2)
     cn, on, vn = crow.cpu().numpy(), col.cpu().numpy(), val.cpu().numpy()
     Co, gAo, gBo = oracle.sparse_mm_fwd_bwd(cn, on, vn, B.cpu().numpy(), Gd.cpu().numpy(), n)
-    for got, ref, what in ((C, Co, "C"), (gA, gAo, "gradA"), (gB, gBo, "gradB"), (gB2, gBo, "gradB (fused walk)")):
+    for got, ref, what in ((C, Co, "C"), (gA, gAo, "gradA"), (gB, gBo, "gradB")):
         assert G.rel_err(got.cpu().numpy(), ref) < 1e-5, what
     v64, b64, g64 = vn.astype(np.float64), B.cpu().numpy().astype(np.float64), Gd.cpu().numpy().astype(np.float64)
     exact = oracle.sparse_mm_fwd_bwd(cn, on, v64, b64, g64, n)
     mags = oracle.sparse_mm_fwd_bwd(cn, on, np.abs(v64), np.abs(b64), np.abs(g64), n)
-    for got, ex, mg, what in zip((C, gA, gB, gB2), exact + (exact[2],), mags + (mags[2],), ("C", "gradA", "gradB", "gradB (fused walk)")):
+    for got, ex, mg, what in zip((C, gA, gB), exact, mags, ("C", "gradA", "gradB")):
         err = np.abs(got.double().cpu().numpy().reshape(ex.shape) - ex)
         assert float((err / (8 * EPS32 * mg + 1e-300)).max()) <= 1.0, what
 
@@ -289,16 +283,14 @@ def test_tile_kernels_never_touch_a_dense_row_a_row_does_not_reference():
     touched = torch.zeros(n, dtype=torch.bool, device=DEV)
     touched[rows[col == bad].long()] = True
     assert torch.equal(torch.isnan(C).any(dim=1), touched)
-    # the fused backward walk: a NaN row of G reaches gradB[j] for the columns j of A's row `bad` and the gradA entries of that row only
+    # the transposed product on the transposed pattern's tiles: a NaN row of G reaches gradB[j] for the columns j of A's row `bad` only
     Gd = torch.randn(n, p, device=DEV, generator=g)
     Gd[bad] = float("nan")
-    B[bad] = 1.0
     tt = plan.transposed.tile_plan(be.tile_geometry(torch.float32, p))
-    gA, gB = be.csr_mm_backward_tile(tt, val, Gd, B)
-    in_row = rows == bad
+    gB = be.csr_spmm_tile(tt, val, Gd)
     hit = torch.zeros(n, dtype=torch.bool, device=DEV)
-    hit[col[in_row].long()] = True
-    assert torch.equal(torch.isnan(gB).any(dim=1), hit) and torch.equal(torch.isnan(gA), in_row)
+    hit[col[rows == bad].long()] = True
+    assert torch.equal(torch.isnan(gB).any(dim=1), hit)
 
 
 def test_tile_kernels_through_the_public_api(monkeypatch):

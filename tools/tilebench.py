@@ -54,7 +54,6 @@ def main():
         "spmmT tile": lambda: be.csr_spmm_tile(tt, val, G),
         "spmmT rowpack": (lambda: be.csr_spmm_rowpack(pt.crow, val, rpt, G, n)) if rpt is not None else None,
         "spmmT plan-free": lambda: be.csr_spmm(pt.crow, pt.col, val, G, n, n, perm=pt.perm),
-        "bwd   tile fused": lambda: be.csr_mm_backward_tile(tt, val, G, B),
     }
     if tp is None or tt is None:
         fns = {k: v for k, v in fns.items() if "tile" not in k}
@@ -64,8 +63,6 @@ def main():
         a_, b_ = fns["sddmm tile"](), fns["sddmm plan-free"]()
         print("check sddmm", torch.equal(a_, b_), "max abs diff", float((a_ - b_).abs().max()), "of", float(b_.abs().max()))
         print("check spmmT", torch.equal(fns["spmmT tile"](), fns["spmmT plan-free"]()))
-        ga_, gb_ = fns["bwd   tile fused"]()
-        print("check fused gradA == tile sddmm", torch.equal(ga_, a_), "| gradB max abs diff vs tile spmmT", float((gb_ - fns["spmmT tile"]()).abs().max()))
     alg = (n + 1) * 4 + nnz * 8 + 2 * n * p * 4
     for rnd in range(2):
         for name, fn in fns.items():

@@ -45,7 +45,6 @@ SIGNATURES = {
     "tsgu_tile_geometry": (_int, [_int, _i64, ctypes.POINTER(_int), ctypes.POINTER(_int), ctypes.POINTER(_int)]),
     "tsgu_csr_spmm_tile": (_int, [_int, _ptr, _ptr, _ptr, _i64, _ptr, _i64, _i64, _int, _ptr]),
     "tsgu_csr_sddmm_tile": (_int, [_int, _ptr, _ptr, _i64, _ptr, _i64, _ptr, _dbl, _i64, _int, _ptr]),
-    "tsgu_csr_mm_backward_tile": (_int, [_int, _ptr, _ptr, _ptr, _i64, _ptr, _i64, _ptr, _dbl, _ptr, _i64, _i64, _int, _ptr]),
     "tsgu_csr_spmm": (
         _int,
         [_int, _int, _i64, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _ptr, _i64, _i64, _i64, _i64, _i64, _i64,
@@ -477,20 +476,6 @@ def csr_sddmm_tile(tp, R, Cm, alpha: float = 1.0):
         check(lib.tsgu_csr_sddmm_tile(vtype_of(R), _tile_struct(tp), _p(R), _ld(R), _p(Cm), _ld(Cm), _p(out), float(alpha), p, dev.index,
                                       _stream(dev)), "tsgu_csr_sddmm_tile")
     return out
-
-
-def csr_mm_backward_tile(tt, val, G, B, alpha: float = 1.0):
-    """(gradA values in A's order, gradB = Aᵀ·G) of C = A·B in one walk of the transposed pattern's tile plan `tt` (with perm)."""
-    lib = load_library()
-    dev = require_device(val, G, B)
-    G, B = rowmajor(G), rowmajor(B)
-    p = G.size(-1)
-    gvals = torch.empty((tt.nnz,), dtype=G.dtype, device=dev)
-    gradB = torch.empty((tt.n_rows, p), dtype=G.dtype, device=dev)
-    with torch.cuda.device(dev):
-        check(lib.tsgu_csr_mm_backward_tile(vtype_of(val), _tile_struct(tt), _p(val.contiguous()), _p(G), _ld(G), _p(B), _ld(B), _p(gvals),
-                                            float(alpha), _p(gradB), _ld(gradB), p, dev.index, _stream(dev)), "tsgu_csr_mm_backward_tile")
-    return gvals, gradB
 
 
 def csr_mm_backward_rowpack(tcrow, rp, val, G, B, n_rows_t: int):

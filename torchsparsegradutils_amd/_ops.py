@@ -37,8 +37,6 @@ PLAN_ASYNC = os.environ.get("TSGU_PLAN_ASYNC", "1") == "1"
 # FEM matrices): a block's distinct dense rows are staged in LDS one block ahead of the walk.  Chosen before the row pairs when the
 # pattern qualifies (every block's tile fits, entries share dense rows); TSGU_ENABLE_TILE=0 disables.
 ENABLE_TILE = os.environ.get("TSGU_ENABLE_TILE", "1") == "1"
-# both gradients of sparse_mm in ONE walk of the transposed pattern's tiles (TSGU_TILE_FUSED_BACKWARD=0: SDDMM + transposed product)
-TILE_FUSED_BACKWARD = os.environ.get("TSGU_TILE_FUSED_BACKWARD", "1") == "1"
 
 
 # Lattice plane-sweep kernels (csrc/lattice_impl.h): patterns that are stencils on a row-major lattice (what the
@@ -306,13 +304,9 @@ def mm_backward(plan: RowGather, values: torch.Tensor, G: torch.Tensor, B: torch
     t = plan.transposed
     if same and plan.batch is None and plan.perm is None:
         # row-block tiles: the SDDMM in stored order + the transposed product on the transposed pattern's tiles (A's own values)
-        tt = _tile_for(t, G, B)
-        if tt is not None:
-            if TILE_FUSED_BACKWARD:      # one walk of the transposed pattern's tiles: G staged once for both gradients
-                return _be.csr_mm_backward_tile(tt, values, G, B)
-            tp = _tile_for(plan, B, G)
-            if tp is not None:
-                return _be.csr_sddmm_tile(tp, G, B), _be.csr_spmm_tile(tt, values, G)
+        tp, tt = _tile_for(plan, B, G), _tile_for(t, G)
+        if tp is not None and tt is not None:
+            return _be.csr_sddmm_tile(tp, G, B), _be.csr_spmm_tile(tt, values, G)
     rp = _pack_for(t, G, B) if same else None
     if rp is not None and rp.srcstart is not None and plan.batch is None and plan.perm is None:
         # the transposed plan reached the dictionary form through row-relative value positions (mesh orderings): the SDDMM on the

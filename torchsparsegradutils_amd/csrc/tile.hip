@@ -68,8 +68,6 @@ int launch(const TileParams& P0, int device, hipStream_t s) {
     if constexpr (MODE == kTileSpmm) {
         if (perm) return go(tile_kernel<float, 8, kTileSpmm, true>, 0);
         return go(tile_kernel<float, 8, kTileSpmm, false>, 1);
-    } else if constexpr (MODE == kTileBwd) {
-        return go(tile_kernel<float, 8, kTileBwd, true>, 3);
     } else {
         return go(tile_kernel<float, 8, kTileSddmm, false>, 2);
     }
@@ -124,29 +122,6 @@ int tsgu_csr_sddmm_tile(int vtype, const tsgu_tile_plan* plan, const void* R, in
     P.gvals = out_vals;
     P.alpha = (float)alpha;
     return launch<kTileSddmm>(P, device, static_cast<hipStream_t>(stream));
-}
-
-int tsgu_csr_mm_backward_tile(int vtype, const tsgu_tile_plan* plan_t, const void* val, const void* G, int64_t ldg, const void* B, int64_t ldb,
-                              void* gradA_vals, double alpha, void* gradB, int64_t ldgb, int64_t p, int device, void* stream) {
-    if (vtype != TSGU_F32) return TSGU_ERR_BAD_DTYPE;
-    TileParams P{};
-    if (const int rc = fill(P, plan_t, p)) return rc;
-    if (P.n_rows == 0) return TSGU_OK;
-    if (!plan_t->perm || !G || !B || !gradB || (P.nnz > 0 && (!val || !gradA_vals)) || ldg < p || ldb < p || ldgb < p) return TSGU_ERR_BAD_ARG;
-    if (!aligned16(G) || !aligned16(B) || !aligned16(gradB) || ldg % 4 || ldb % 4 || ldgb % 4) return TSGU_ERR_BAD_ARG;
-    if ((uint64_t)plan_t->n_cols * (uint64_t)ldg * 4u > 0xffffffffull || (uint64_t)P.nnz * 4u > 0xffffffffull) return TSGU_ERR_TOO_LARGE;
-    if (plan_t->n_cols >= (1 << 24) || ldg * 4 >= (1 << 24)) return TSGU_ERR_TOO_LARGE;
-    if (const int rc = set_device(device)) return rc;
-    P.val = val;
-    P.S = G;
-    P.lds_ = ldg;
-    P.Own = B;
-    P.ldown = ldb;
-    P.out = gradB;
-    P.ldo = ldgb;
-    P.gvals = gradA_vals;
-    P.alpha = (float)alpha;
-    return launch<kTileBwd>(P, device, static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

@@ -17,11 +17,11 @@
 //   rptr                       int32 row pointer of the walked pattern
 //   perm (optional)            position of entry k in the value array (the transposed pattern walks A's own values: Aᵀ·G)
 //
-// Modes: kTileSpmm  C = A·B (perm: Aᵀ·G on the transposed pattern); kTileSddmm  out[k] = alpha·<R[row k], Cm[col k]> in stored order;
-// kTileBwd  BOTH gradients of C = A·B in one walk of the transposed pattern's plan (perm required): the tile holds rows of G, a lane
-// group owns column j of A (row j of Aᵀ) with its 16 bytes of B[j] in registers — gradB[j] += val·G[i] and gradA(i, j) = <G[i], B[j]>
-// from the SAME tile row.  The dots go back through LDS (into the value slot of their entry) to the threads that hold the entries'
-// positions in A's value array (they issued the value DMAs) and leave as 4-byte stores one step later.
+// Modes: kTileSpmm  C = A·B (perm: Aᵀ·G on the transposed pattern); kTileSddmm  out[k] = alpha·<R[row k], Cm[col k]> in stored order.
+// (Round 5 also built BOTH gradients in one walk of the transposed pattern's plan — G staged once, B[j] in registers, dots back through
+// LDS to the threads that hold the value positions: bit-identical gradA, 1052 MB instead of 1263 MB of traffic, but 300 us against
+// 115 + 173 us: the gradients of A leave as 26 M scattered 4-byte stores and the store path, not HBM, is what the walk then waits for.
+// Removed; EXPERIMENTS.md §10.)
 // kTileSpmm sums run in ascending entry order of the walked pattern: the same order — and the same bits — as the plan-free kernels.
 //
 // Synchronisation: the bulk streams (tile rows, values, entry bytes, row pointer slice) are LDS-DMA issued from inline asm — invisible
@@ -35,7 +35,7 @@
 
 namespace tsgu {
 
-enum TileMode { kTileSpmm = 0, kTileSddmm = 1, kTileBwd = 2 };
+enum TileMode { kTileSpmm = 0, kTileSddmm = 1 };
 
 constexpr int kTileRows = 64;       // rows per block
 constexpr int kTileUMax = 224;      // distinct dense rows per block (multiple of 8)
@@ -79,12 +79,6 @@ struct TileLds {
     static constexpr int oZero = 2 * kBuf;
     static constexpr int kTotal = 2 * kBuf + RB;
 };
-
-// DPP move of a 32-bit value of any type
-template <int CTRL>
-__device__ __forceinline__ float dpp_any(float x) { return dpp_f32<CTRL>(x); }
-template <int CTRL>
-__device__ __forceinline__ unsigned dpp_any(unsigned x) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xf, 0xf, true); }
 
 // wave-uniform copy of a descriptor (scalar registers: its fields go into lane predicates and M0-relative addresses)
 __device__ __forceinline__ TileDesc tile_uniform(const TileDesc d) {
@@ -155,8 +149,7 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(const TileParams 
     int ucolr[UP];                                       // column numbers of this thread's tile pieces of the block staged next
     unsigned toff[UP];                                   // … and their byte offsets in the gathered operand
     int permr[PERM ? kTileEP : 1];                       // value positions of this thread's entries of the block staged next
-    uint4 own_cur = {0, 0, 0, 0}, own_nxt = {0, 0, 0, 0};      // SDDMM / backward: this lane's 16 bytes of its row of R, block walked / next block
-    int perm1[MODE == kTileBwd ? kTileEP : 1], perm2[MODE == kTileBwd ? kTileEP : 1];      // backward: value positions of the block staged / walked last
+    uint4 own_cur = {0, 0, 0, 0}, own_nxt = {0, 0, 0, 0};      // SDDMM: this lane's 16 bytes of its row of R, block walked / next block
 #pragma unroll
     for (int i = 0; i < UP; ++i) ucolr[i] = 0;
 
@@ -204,7 +197,7 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(const TileParams 
             if (wave_row + i * (kTileThreads / CL) < d.U)
                 lat_dma16<false>(S, toff[i], buf + (wave_piece + (unsigned)i * kTileThreads) * 16u);
         }
-        if constexpr (MODE != kTileSddmm) {
+        if constexpr (MODE == kTileSpmm) {
 #pragma unroll
             for (int i = 0; i < kTileEP; ++i) {
                 if (wave_e + i * kTileThreads < d.E) {
@@ -238,7 +231,7 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(const TileParams 
     };
 
     auto load_own = [&](int k) {                         // SDDMM: this lane's part of its row of R in block k
-        if constexpr (MODE != kTileSpmm) {
+        if constexpr (MODE == kTileSddmm) {
             const float* Own = static_cast<const float*>(P.Own);
             const int64_t r = (b_first + (int64_t)k * b_step) * kTileRows + wave * RPW + grp;
             own_nxt = r < P.n_rows ? *reinterpret_cast<const uint4*>(Own + r * P.ldown + sub * 4) : uint4{0, 0, 0, 0};
@@ -342,77 +335,6 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(const TileParams 
                 }
             }
             if (live) store_vec<float, 4, true>(static_cast<float*>(P.out) + r * P.ldo + sub * 4, acc);
-        } else if constexpr (MODE == kTileBwd) {
-            // slot j of lane `sub` is entry kk + (j ^ sub) (see the SDDMM below): the lane adds val·G[i] of all eight entries into ITS
-            // 16 bytes of gradB[j] and the dots <G[i], B[j]> are summed over the row's lanes by the transposed tree
-            const float b0 = __uint_as_float(own_cur.x), b1 = __uint_as_float(own_cur.y), b2 = __uint_as_float(own_cur.z),
-                        b3 = __uint_as_float(own_cur.w);
-            float* dots = const_cast<float*>(vals);      // the dot of entry k replaces its value in LDS once the row's lanes have read it
-            float acc[4] = {0.f, 0.f, 0.f, 0.f};
-            // What lane `sub` holds of its OWN entry kk + sub — the entry's byte and value — reaches the other lanes of the row by DPP
-            // (slot j needs the data of entry j ^ sub, i.e. of lane sub ^ j): no per-slot address or selector registers.
-            const unsigned own_sel = 0x0c0c0c00u | (unsigned)sub;
-            auto xor_lane = [&](auto x, auto hm, int j) {       // value of lane (sub ^ j) of the row's 8 lanes; hm = the half-mirrored copy (sub ^ 7)
-                switch (j) {
-                    case 0: return x;
-                    case 1: return dpp_any<0xB1>(x);
-                    case 2: return dpp_any<0x4E>(x);
-                    case 3: return dpp_any<0x1B>(x);
-                    case 4: return dpp_any<0x1B>(hm);
-                    case 5: return dpp_any<0x4E>(hm);
-                    case 6: return dpp_any<0xB1>(hm);
-                    default: return hm;
-                }
-            };
-            auto round = [&](bool partial) {
-                unsigned lo8, hi8;
-                bytes8(kk, lo8, hi8);
-                const unsigned li_own = __builtin_amdgcn_perm(hi8, lo8, own_sel);
-                float v_own = vals[kk + sub];
-                if (partial && !(kk + sub < e)) v_own = 0.f;           // (a missing entry: value 0 and, below, the zero row)
-                const unsigned li_hm = dpp_any<0x141>(li_own);
-                const float v_hm = dpp_any<0x141>(v_own);
-                float part[8];
-                // two halves of four slots: four tile rows (16 registers) in flight at a time — the kernel has 128 registers at four waves per SIMD
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    float v[4];
-                    float4 gj[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int j = 4 * h + q;
-                        const unsigned li = xor_lane(li_own, li_hm, j);
-                        v[q] = xor_lane(v_own, v_hm, j);
-                        const bool ok = !partial || kk + (j ^ sub) < e;
-                        gj[q] = *reinterpret_cast<const float4*>(ok ? trow + li * RB : zrow);
-                    }
-                    asm volatile("" ::: "memory");
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        acc[0] = fmaf(v[q], gj[q].x, acc[0]);
-                        acc[1] = fmaf(v[q], gj[q].y, acc[1]);
-                        acc[2] = fmaf(v[q], gj[q].z, acc[2]);
-                        acc[3] = fmaf(v[q], gj[q].w, acc[3]);
-                        part[4 * h + q] = fmaf(b3, gj[q].w, fmaf(b2, gj[q].z, fmaf(b1, gj[q].y, b0 * gj[q].x)));
-                    }
-                }
-                float h4[4], h2[2];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) h4[j] = part[j] + dpp_move<0x141>(part[7 - j]);
-#pragma unroll
-                for (int j = 0; j < 2; ++j) h2[j] = h4[j] + dpp_move<0x4E>(h4[j + 2]);
-                const float h = h2[0] + dpp_move<0xB1>(h2[1]);
-                if (!partial || kk + sub < e) dots[kk + sub] = P.alpha * h;
-            };
-            for (int it = 0; it < nfull; ++it) {
-                round(false);
-                kk += 8;
-            }
-            while (__any(kk < e)) {
-                round(true);
-                kk += 8;
-            }
-            if (live) store_vec<float, 4, true>(static_cast<float*>(P.out) + r * P.ldo + sub * 4, acc);
         } else {
             const float g0 = __uint_as_float(own_cur.x), g1 = __uint_as_float(own_cur.y), g2 = __uint_as_float(own_cur.z),
                         g3 = __uint_as_float(own_cur.w);
@@ -466,42 +388,18 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(const TileParams 
         }
     };
 
-    // backward: the dots of block k (in its buffer's value slots) leave for gradA[position of the entry in A's value array]: by the
-    // threads that issued the entries' value DMAs — they hold those positions
-    auto flush_dots = [&](int k, const TileDesc d) {
-        if constexpr (MODE == kTileBwd) {
-            const float* dots = reinterpret_cast<const float*>(tile_lds + (k & 1) * L::kBuf + L::oVals);
-            float* gv = static_cast<float*>(P.gvals);
-#pragma unroll
-            for (int i = 0; i < kTileEP; ++i) {
-                const int e = t + i * kTileThreads;
-                if (e < d.E) gv[(unsigned)perm2[i]] = dots[e];
-            }
-        }
-    };
-
     // ---- pipeline: descriptors three blocks ahead, a thread's words two, DMA one, walk ---------------------------------------
     TileDesc d0 = tile_uniform(desc_at(0)), d1 = tile_uniform(desc_at(1)), d2 = tile_uniform(desc_at(2));
     TileDesc raw = desc_at(3);
     load_words(d0);
     pin_words();
-    if constexpr (MODE == kTileBwd) {
-#pragma unroll
-        for (int i = 0; i < kTileEP; ++i) perm1[i] = permr[i], perm2[i] = 0;
-    }
     stage(0, d0);
     load_own(0);
     load_words(d1);
     lat_step_sync();
-    TileDesc dprev = d0;
     for (int k = 0; k < nloc; ++k) {
         const TileDesc d3 = tile_uniform(raw);          // (loaded during the previous step)
         pin_words();
-        if constexpr (MODE == kTileBwd) {
-            if (k > 0) flush_dots(k - 1, dprev);        // (before the DMAs of block k + 1 go into the same buffer)
-#pragma unroll
-            for (int i = 0; i < kTileEP; ++i) perm2[i] = perm1[i], perm1[i] = permr[i];      // perm2: block k, perm1: block k + 1
-        }
         own_cur = own_nxt;
         if (k + 1 < nloc) stage(k + 1, d1);             // (uses the words loaded during step k - 1)
         if (k + 2 < nloc) load_words(d2);
@@ -509,10 +407,8 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(const TileParams 
         raw = desc_at(k + 4);
         walk(k, d0);
         lat_step_sync();
-        dprev = d0;
         d0 = d1, d1 = d2, d2 = d3;
     }
-    if constexpr (MODE == kTileBwd) flush_dots(nloc - 1, dprev);
 }
 
 }  // namespace tsgu
