@@ -249,7 +249,8 @@ int tsgu_csr_sddmm_rowpack(int vtype, int itype, int64_t n_rows, int64_t n_cols,
  *   rptr [n_rows + 1]      int32 row pointer of the walked pattern
  *   perm [nnz]             optional int32: position of entry k in the value array — the plan of the TRANSPOSED pattern walks A's own
  *                          values (Aᵀ·G, sparse_matmul.py:229); NULL: values in walked order
- * fp32 values, p = 32 (dense rows of 128 bytes), 16-byte aligned dense operands, 2-D operands below 4 GiB.  Sums run in ascending
+ * fp32 values, p a multiple of 32 up to 1024 (one launch per tile of 32 columns = 128 bytes of a dense row; the SDDMM adds the dots of
+ * the later tiles to the first), 16-byte aligned dense operands, 2-D operands below 4 GiB.  Sums run in ascending
  * entry order of the walked pattern: the same bits as tsgu_csr_spmm / tsgu_csr_sddmm.  A row never touches a dense row it does not
  * reference.  tsgu_tile_geometry gives the limits a plan has to meet (or a negative status for an unsupported (vtype, p)).
  */

@@ -221,8 +221,9 @@ def _tile_patterns():
     return out
 
 
-@pytest.mark.parametrize("name", ["mesh27_blocked", "mesh27_odd", "stencil7_i64", "banded_ragged"])
-def test_tile_kernels_equal_the_plan_free_kernels_bit_for_bit(name):
+@pytest.mark.parametrize("name,p", [("mesh27_blocked", 32), ("mesh27_odd", 32), ("stencil7_i64", 32), ("banded_ragged", 32),
+                                    ("mesh27_odd", 128), ("banded_ragged", 64)])
+def test_tile_kernels_equal_the_plan_free_kernels_bit_for_bit(name, p):
     """The three products of the step on the row-block tile kernels.  Forward and Aᵀ·G (the transposed pattern's tiles through A's own
     values) sum a row's entries in ascending order of the walked pattern, like the plan-free kernels: the same bits.  The SDDMM's dots
     are summed by a different tree over the row's lanes: equal to rounding.  All three against the oracle at 1e-5 and every element
@@ -232,7 +233,7 @@ def test_tile_kernels_equal_the_plan_free_kernels_bit_for_bit(name):
     from torchsparsegradutils_amd import _pattern
 
     crow, col = _tile_patterns()[name]
-    n, nnz, p = crow.numel() - 1, col.numel(), 32
+    n, nnz = crow.numel() - 1, col.numel()          # (p > 32: one launch per tile of 32 columns, the SDDMM adds the later tiles' dots)
     g = torch.Generator(device=DEV).manual_seed(4)
     val = torch.randn(nnz, device=DEV, generator=g)
     B = torch.randn(n, p, device=DEV, generator=g)

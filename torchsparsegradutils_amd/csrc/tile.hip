@@ -22,7 +22,7 @@ int fill(TileParams& P, const tsgu_tile_plan* pl, int64_t p) {
     if (pl->rows_per_block != kTileRows || pl->max_union > kTileUMax || pl->max_entries > kTileEMax) return TSGU_ERR_BAD_ARG;
     if (pl->n_blocks > 0 && (!pl->desc || !pl->ucol || !pl->lidx || !pl->rptr)) return TSGU_ERR_BAD_ARG;
     if (pl->n_rows > 0x7fffffffLL || pl->nnz > 0x7fffffffLL) return TSGU_ERR_TOO_LARGE;
-    if (p != 32) return TSGU_ERR_BAD_ARG;        // (dense rows of 128 bytes; other widths take the other kernel families)
+    if (p <= 0 || p % 32) return TSGU_ERR_BAD_ARG;        // (column tiles of 32: dense rows of 128 bytes per launch)
     P.n_rows = pl->n_rows;
     P.n_cols = pl->n_cols;
     P.nnz = pl->nnz;
@@ -78,7 +78,7 @@ int launch(const TileParams& P0, int device, hipStream_t s) {
 extern "C" {
 
 int tsgu_tile_geometry(int vtype, int64_t p, int* rows_per_block, int* max_union, int* max_entries) {
-    if (vtype != TSGU_F32 || p != 32) return TSGU_ERR_BAD_DTYPE;
+    if (vtype != TSGU_F32 || p <= 0 || p % 32 || p > 1024) return TSGU_ERR_BAD_DTYPE;
     if (rows_per_block) *rows_per_block = kTileRows;
     if (max_union) *max_union = kTileUMax;
     if (max_entries) *max_entries = kTileEMax;
@@ -97,11 +97,14 @@ int tsgu_csr_spmm_tile(int vtype, const tsgu_tile_plan* plan, const void* val, c
     if (plan->n_cols >= (1 << 24) || ldb * 4 >= (1 << 24)) return TSGU_ERR_TOO_LARGE;      // (tile row offsets are 24-bit products)
     if (const int rc = set_device(device)) return rc;
     P.val = val;
-    P.S = B;
     P.lds_ = ldb;
-    P.out = C;
     P.ldo = ldc;
-    return launch<kTileSpmm>(P, device, static_cast<hipStream_t>(stream));
+    for (int64_t c = 0; c < p; c += 32) {        // wide operands: one launch per tile of 32 columns (the reference's SuiteSparse width is 128)
+        P.S = static_cast<const float*>(B) + c;
+        P.out = static_cast<float*>(C) + c;
+        if (const int rc = launch<kTileSpmm>(P, device, static_cast<hipStream_t>(stream))) return rc;
+    }
+    return TSGU_OK;
 }
 
 int tsgu_csr_sddmm_tile(int vtype, const tsgu_tile_plan* plan, const void* R, int64_t ldr, const void* Cm, int64_t ldc, void* out_vals,
@@ -115,13 +118,17 @@ int tsgu_csr_sddmm_tile(int vtype, const tsgu_tile_plan* plan, const void* R, in
     if ((uint64_t)plan->n_cols * (uint64_t)ldc * 4u > 0xffffffffull) return TSGU_ERR_TOO_LARGE;
     if (plan->n_cols >= (1 << 24) || ldc * 4 >= (1 << 24)) return TSGU_ERR_TOO_LARGE;
     if (const int rc = set_device(device)) return rc;
-    P.Own = R;
     P.ldown = ldr;
-    P.S = Cm;
     P.lds_ = ldc;
     P.gvals = out_vals;
     P.alpha = (float)alpha;
-    return launch<kTileSddmm>(P, device, static_cast<hipStream_t>(stream));
+    for (int64_t c = 0; c < p; c += 32) {        // the dots of the later column tiles are added to those of the first
+        P.Own = static_cast<const float*>(R) + c;
+        P.S = static_cast<const float*>(Cm) + c;
+        P.accumulate = c > 0;
+        if (const int rc = launch<kTileSddmm>(P, device, static_cast<hipStream_t>(stream))) return rc;
+    }
+    return TSGU_OK;
 }
 
 }  // extern "C"

@@ -64,6 +64,7 @@ struct TileParams {
     void* gvals;                 // SDDMM output [nnz]
     float alpha;
     int blocks_per_wg;
+    int accumulate;              // SDDMM: add to gvals (the later column tiles of a wide operand)
     int cyclic;                  // block of (workgroup w, step k): 0: w·blocks_per_wg + k (a run per workgroup); 1: k·workgroups + w
 };
 
@@ -375,14 +376,15 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(const TileParams 
                 return h2[0] + dpp_move<0xB1>(h2[1]);
             };
             for (int it = 0; it < nfull; ++it) {
-                gv[(unsigned)(kk + sub)] = P.alpha * round();
+                const float h = P.alpha * round();
+                gv[(unsigned)(kk + sub)] = P.accumulate ? gv[(unsigned)(kk + sub)] + h : h;
                 kk += 8;
             }
             // the rest under a store predicate only: the slots of entries beyond a row's end hold whatever dense row the byte behind the
             // row names (inside the LDS buffer); their sums stay in their own slots of the tree and are never stored
             while (__any(kk < e)) {
                 const float h = round();
-                if (kk + sub < e) gv[kk + sub] = P.alpha * h;
+                if (kk + sub < e) gv[kk + sub] = P.accumulate ? gv[kk + sub] + P.alpha * h : P.alpha * h;
                 kk += 8;
             }
         }
