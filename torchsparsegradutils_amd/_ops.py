@@ -238,6 +238,8 @@ def _tile_for(plan: RowGather, dense: torch.Tensor, *others: torch.Tensor):
     ops = tuple(_be.rowmajor(t) for t in (dense,) + others)
     if not _be._tiled_ok(*ops) or any(t.dtype != dense.dtype or t.size(0) * max(t.stride(0), 1) * t.element_size() >= 2**32 for t in ops):
         return None
+    if max(plan.n_cols, plan.n_rows) >= 1 << 24 or any(t.stride(0) * t.element_size() >= 1 << 24 for t in ops):
+        return None          # (the kernels' tile row offsets are 24-bit products)
     if not plan.seen_enough(PLAN_AFTER_USES):
         return None
     if PLAN_ASYNC and PLAN_AFTER_USES > 0 and not torch.are_deterministic_algorithms_enabled():

@@ -172,7 +172,14 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(const TileParams 
                 if (wave_e + i * kTileThreads < d.E) {
                     int e = t + i * kTileThreads;
                     e = e < d.E ? e : d.E - 1;
+#ifndef TSGU_TILE_NT_WORDS
+#define TSGU_TILE_NT_WORDS 0
+#endif
+#if TSGU_TILE_NT_WORDS
+                    permr[i] = __builtin_nontemporal_load(P.perm + ((int64_t)d.e0 + e));      // (a single-use stream)
+#else
                     permr[i] = P.perm[(int64_t)d.e0 + e];
+#endif
                 }
             }
         }
