@@ -394,11 +394,14 @@ def published_shapes_leg(dev, steps, with_cpu):
         for _ in range(6):
             fn()
         torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            fn()
-        torch.cuda.synchronize(dev)
-        wall = (time.perf_counter() - t0) / reps * 1e3
+        walls = []
+        for _ in range(3):          # (the best of three loops: the first loop after another leg's allocations has been seen 10x slower)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize(dev)
+            walls.append((time.perf_counter() - t0) / reps * 1e3)
+        wall = min(walls)
         return round(wall, 5), round(time_events(fn, reps, dev, hold_ms=reps * 1.5 * max(wall, 0.05), settle=4), 5)
 
     def frac(nbytes, ms):

@@ -513,22 +513,23 @@ def test_cpp_host_path_of_a_batched_csr_step_equals_the_python_path(dt, p):
 
 def test_tile_kernels_on_random_block_patterns_against_the_plan_free_kernels():
     """Randomised patterns in the tile kernels' domain — blocks of 64 rows that draw their columns from a small pool (so that a tile
-    fits), ragged rows from 0 to 70 entries, int32 / int64, rectangular — forward and transposed product bit-identical to the
+    fits), ragged rows from 0 to 30 entries, int32 / int64, rectangular — forward and transposed product bit-identical to the
     plan-free kernels, SDDMM equal to rounding."""
     from torchsparsegradutils_amd import _backend as be
     from torchsparsegradutils_amd import _pattern
 
     rng = np.random.default_rng(11)
     geo = be.tile_geometry(torch.float32, 32)
-    done = 0
+    done = transposed = 0
     for case in range(12):
         n = int(rng.integers(65, 1500))
         m = int(rng.integers(200, 3000))
         rows, cols = [], []
         for b0 in range(0, n, 64):
-            pool = np.unique(rng.integers(0, m, int(rng.integers(8, 200))))
+            lo = max(0, min(m - 180, b0 * m // n - 60))          # (a window around the block: the transposed pattern's blocks have few distinct rows too)
+            pool = np.unique(rng.integers(lo, min(m, lo + 180), int(rng.integers(8, 200))))
             for r in range(b0, min(n, b0 + 64)):
-                k = int(rng.integers(0, min(71, pool.size + 1))) if rng.random() > 0.1 else 0
+                k = int(rng.integers(0, min(31, pool.size + 1))) if rng.random() > 0.1 else 0
                 c = np.sort(rng.choice(pool, size=k, replace=False))
                 rows.append(np.full(k, r))
                 cols.append(c)
@@ -541,7 +542,7 @@ def test_tile_kernels_on_random_block_patterns_against_the_plan_free_kernels():
         crow, col = crow.to(idt).to(DEV), torch.from_numpy(cols).to(idt).to(DEV)
         plan = _pattern.RowGather(crow, col, n, m)
         tp, tt = plan.tile_plan(geo), plan.transposed.tile_plan(geo)
-        if tp is None or tt is None:
+        if tp is None:
             continue
         g = torch.Generator(device=DEV).manual_seed(case)
         val = torch.randn(col.numel(), device=DEV, generator=g)
@@ -549,8 +550,10 @@ def test_tile_kernels_on_random_block_patterns_against_the_plan_free_kernels():
         Gd = torch.randn(n, 32, device=DEV, generator=g)
         pt = plan.transposed
         assert torch.equal(be.csr_spmm_tile(tp, val, B), be.csr_spmm(crow, col, val, B, n, m)), case
-        assert torch.equal(be.csr_spmm_tile(tt, val, Gd), be.csr_spmm(pt.crow, pt.col, val, Gd, m, n, perm=pt.perm)), case
+        if tt is not None:
+            assert torch.equal(be.csr_spmm_tile(tt, val, Gd), be.csr_spmm(pt.crow, pt.col, val, Gd, m, n, perm=pt.perm)), case
+            transposed += 1
         ref = be.csr_sddmm(crow, col, Gd, B, n, m)
         assert torch.allclose(be.csr_sddmm_tile(tp, Gd, B), ref, rtol=1e-5, atol=1e-5), case
         done += 1
-    assert done >= 6
+    assert done >= 6 and transposed >= 3
