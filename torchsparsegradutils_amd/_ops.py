@@ -242,6 +242,11 @@ def _tile_for(plan: RowGather, dense: torch.Tensor, *others: torch.Tensor):
         return None          # (the kernels' tile row offsets are 24-bit products)
     if not plan.seen_enough(PLAN_AFTER_USES):
         return None
+    key = ("tile",) + tuple(geo)
+    if key in plan.core.packs:
+        return plan.core.packs[key]
+    if torch.cuda.is_current_stream_capturing():
+        return None          # (a plan is built with host reads: never inside a stream capture — asked for again after it)
     if PLAN_ASYNC and PLAN_AFTER_USES > 0 and not torch.are_deterministic_algorithms_enabled():
         return plan.tile_plan(geo, asynchronous=True)
     return plan.tile_plan(geo)
