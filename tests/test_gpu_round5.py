@@ -557,3 +557,29 @@ def test_tile_kernels_on_random_block_patterns_against_the_plan_free_kernels():
         assert torch.allclose(be.csr_sddmm_tile(tp, Gd, B), ref, rtol=1e-5, atol=1e-5), case
         done += 1
     assert done >= 6 and transposed >= 3
+
+
+def test_tile_kernels_full_size_mesh_against_the_plan_free_kernels():
+    """The brick-numbered mesh of bench.py's `patterns` block at full size (N = 1e6, 26.5 M entries, 15 625 blocks walked by ~500
+    persistent workgroups, 31 steps each): forward and transposed product bit-identical to the plan-free kernels, SDDMM to rounding.
+    (Round 5: an LDS overflow of the staging code corrupted tile rows only when a workgroup walks many blocks — every small test passed.)"""
+    from torchsparsegradutils_amd import _backend as be
+    from torchsparsegradutils_amd import _pattern
+    from torchsparsegradutils_amd.utils import synthetic
+
+    crow, col = synthetic.mesh27_blocked(100, 100, 100, 4, torch.int32, DEV)
+    n, nnz, p = crow.numel() - 1, col.numel(), 32
+    g = torch.Generator(device=DEV).manual_seed(31)
+    val = torch.randn(nnz, device=DEV, generator=g)
+    B = torch.randn(n, p, device=DEV, generator=g)
+    Gd = torch.randn(n, p, device=DEV, generator=g)
+    plan = _pattern.RowGather(crow, col, n, n)
+    geo = be.tile_geometry(torch.float32, p)
+    tp, tt = plan.tile_plan(geo), plan.transposed.tile_plan(geo)
+    assert tp is not None and tt is not None and tp.n_blocks == 15625
+    pt = plan.transposed
+    for _ in range(2):          # (twice: the second launch finds the first one's data in L2 / MALL — other timing, same bits)
+        assert torch.equal(be.csr_spmm_tile(tp, val, B), be.csr_spmm(crow, col, val, B, n, n))
+        assert torch.equal(be.csr_spmm_tile(tt, val, Gd), be.csr_spmm(pt.crow, pt.col, val, Gd, n, n, perm=pt.perm))
+        got, ref = be.csr_sddmm_tile(tp, Gd, B), be.csr_sddmm(crow, col, Gd, B, n, n)
+        assert float((got - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
