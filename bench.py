@@ -287,7 +287,10 @@ PATTERNS = (
      "NOT a lattice: the truncated 27-point neighbourhood graph of 100^3 numbered brick by brick (4^3 points per brick), a partitioned-mesh ordering"),
     ("cfd2_shaped", lambda sy, dev: sy.banded_random(123440, 25, 2048, torch.int32, dev, seed=0), 128,
      "the shape of the reference's SuiteSparse benchmark: N=123,440, ~25 entries per row inside a band, 128 RHS "
-     "(benchmarks/results/sparse_mm_suite_results.csv:5-6)"),
+     "(benchmarks/results/sparse_mm_suite_results.csv:5-6) with RANDOM columns: neighbouring rows share nothing, the adversarial reading of that shape"),
+    ("cfd2_mesh", lambda sy, dev: sy.mesh27_blocked(40, 52, 60, 4, torch.int32, dev), 128,
+     "the same shape as a MESH, which is what the SuiteSparse matrix is (cfd2: a CFD pressure matrix): N=124,800, ~25.6 entries per row "
+     "(the truncated 27-point graph of 40x52x60 numbered in 4^3 bricks, a partition ordering - not a lattice), 128 RHS"),
 )
 
 
