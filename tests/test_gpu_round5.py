@@ -328,6 +328,60 @@ def test_tile_kernels_through_the_public_api(monkeypatch):
     assert got[1].crow_indices().dtype == torch.int32 and got[1].col_indices().data_ptr() == col.data_ptr()
 
 
+def test_tile_step_through_the_cpp_host_path(monkeypatch):
+    """Once both tile plans of a pattern are there, the step is described to csrc/host/step.cpp (product kind 3): the C++ path launches
+    the same three tile kernels — results equal the Python path's bit for bit, the gradient carries A's own index tensors."""
+    from torchsparsegradutils_amd import _ops, _pattern, sparse_matmul as sm, sparse_mm, wait_for_plans
+
+    assert sm._host is not None, "torchsparsegradutils_amd/_tsgu_host.so was not built (make -C torchsparsegradutils_amd/csrc)"
+    monkeypatch.setattr(_ops, "PACK_MIN_NNZ", 1)
+    monkeypatch.setattr(_ops, "PLAN_ASYNC", False)
+    crow, col = _tile_patterns()["mesh27_blocked"]
+    n, nnz, p = crow.numel() - 1, col.numel(), 32
+    g = torch.Generator(device=DEV).manual_seed(18)
+    A = torch.sparse_csr_tensor(crow, col, torch.randn(nnz, device=DEV, generator=g), (n, n)).requires_grad_(True)
+    B = torch.randn(n, p, device=DEV, generator=g).requires_grad_(True)
+    Gd = torch.randn(n, p, device=DEV, generator=g)
+    _pattern.clear_cache()
+
+    def step():
+        C = sparse_mm(A, B)
+        gA, gB = torch.autograd.grad(C, (A, B), Gd)
+        return C, gA, gB
+
+    monkeypatch.setattr(sm, "FAST_STEP", False)
+    for _ in range(4):
+        slow = step()
+        wait_for_plans()
+    monkeypatch.setattr(sm, "FAST_STEP", True)
+    for _ in range(6):
+        fast = step()
+        wait_for_plans()
+    own = _pattern.from_csr(A.detach()).core.own
+    assert own.get("step_plans"), "no step plan was derived for the tile kernels"
+    assert sm._step_plan(A.detach(), B.detach()) is not None
+    assert torch.equal(fast[0], slow[0]) and torch.equal(fast[1].values(), slow[1].values()) and torch.equal(fast[2], slow[2])
+    assert fast[1].crow_indices().data_ptr() == crow.data_ptr() and fast[1].col_indices().data_ptr() == col.data_ptr()
+
+
+def test_wide_operands_over_few_blocks_stay_off_the_tiles(monkeypatch):
+    """Operands wider than a column tile on a pattern of few blocks take the plan-free / row-pair kernels (_ops.TILE_WIDE_MIN_BLOCKS)."""
+    from torchsparsegradutils_amd import _ops, _pattern
+
+    monkeypatch.setattr(_ops, "PACK_MIN_NNZ", 1)
+    monkeypatch.setattr(_ops, "PLAN_ASYNC", False)
+    crow, col = _tile_patterns()["mesh27_blocked"]
+    n = crow.numel() - 1
+    _pattern.clear_cache()
+    plan = _pattern.RowGather(crow, col, n, n)
+    for _ in range(3):
+        plan.seen_enough(1)
+    assert _ops._tile_for(plan, torch.zeros(n, 32, device=DEV)) is not None
+    assert _ops._tile_for(plan, torch.zeros(n, 64, device=DEV)) is None
+    monkeypatch.setattr(_ops, "TILE_WIDE_MIN_BLOCKS", 0)
+    assert _ops._tile_for(plan, torch.zeros(n, 64, device=DEV)) is not None
+
+
 # ---- bf16: the fp32-accumulated result BEFORE the final rounding (SURVEY §8c form (i)) ---------------------------------------------
 
 

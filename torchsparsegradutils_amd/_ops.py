@@ -37,6 +37,12 @@ PLAN_ASYNC = os.environ.get("TSGU_PLAN_ASYNC", "1") == "1"
 # FEM matrices): a block's distinct dense rows are staged in LDS one block ahead of the walk.  Chosen before the row pairs when the
 # pattern qualifies (every block's tile fits, entries share dense rows); TSGU_ENABLE_TILE=0 disables.
 ENABLE_TILE = os.environ.get("TSGU_ENABLE_TILE", "1") == "1"
+# Operands wider than one column tile (32 fp32 columns) run one launch per tile, each re-reading the plan and the values.  With few
+# blocks per resident workgroup the walk's two-block pipeline never fills and the plan-free kernels win (brick mesh, step on one
+# box: 1 950 blocks: 0.060 / 0.122 / 0.238 ms on tiles against 0.072 / 0.114 / 0.198 plan-free at 32 / 64 / 128 columns; 15 625
+# blocks at 128 columns: 1.59 against 1.89 ms)
+TILE_COLUMNS = 32
+TILE_WIDE_MIN_BLOCKS = int(os.environ.get("TSGU_TILE_WIDE_MIN_BLOCKS", "8192"))
 
 
 # Lattice plane-sweep kernels (csrc/lattice_impl.h): patterns that are stencils on a row-major lattice (what the
@@ -240,6 +246,8 @@ def _tile_for(plan: RowGather, dense: torch.Tensor, *others: torch.Tensor):
         return None
     if max(plan.n_cols, plan.n_rows) >= 1 << 24 or any(t.stride(0) * t.element_size() >= 1 << 24 for t in ops):
         return None          # (the kernels' tile row offsets are 24-bit products)
+    if dense.size(-1) > TILE_COLUMNS and (plan.n_rows + geo[0] - 1) // geo[0] < TILE_WIDE_MIN_BLOCKS:
+        return None          # (several column tiles over few blocks: see TILE_WIDE_MIN_BLOCKS)
     if not plan.seen_enough(PLAN_AFTER_USES):
         return None
     key = ("tile",) + tuple(geo)

@@ -20,8 +20,8 @@
 namespace {
 
 struct Product {          // one of the three products of a step (structured patterns; plan-free steps carry their arrays in StepPlan)
-    int kind = 0;         // 0 plane march, 1 plane sweep, 2 plan-free gather kernels
-    std::string blob;     // a copy of the tsgu_march_plan / tsgu_lattice_plan the Python configuration object built (plain struct of
+    int kind = 0;         // 0 plane march, 1 plane sweep, 2 plan-free gather kernels, 3 row-block tiles
+    std::string blob;     // a copy of the tsgu_march_plan / tsgu_lattice_plan / tsgu_tile_plan the Python object built (plain struct of
                           // sizes + device pointers; the tables it points to are the tensors the StepPlan holds)
     int transposed = 0;   // march: walk the transposed pattern (gradB)
     const void* plan() const { return blob.data(); }
@@ -56,7 +56,11 @@ void* stream_of(int device) { return static_cast<void*>(c10::hip::getCurrentHIPS
 
 void spmm(const StepPlan& s, const Product& pr, int64_t rows_out, const at::Tensor& val, const at::Tensor& dense, at::Tensor& out) {
     const int64_t ld = s.p;      // (contiguous operands only: checked by step() / made so in backward)
-    if (pr.kind == 0)
+    if (pr.kind == 3)      // (a plan with `perm` walks the transposed pattern through A's own values)
+        check(tsgu_csr_spmm_tile(s.vtype, static_cast<const tsgu_tile_plan*>(pr.plan()), val.data_ptr(), dense.data_ptr(), ld, out.data_ptr(), s.p,
+                                 s.p, s.device, stream_of(s.device)),
+              "tsgu_csr_spmm_tile");
+    else if (pr.kind == 0)
         check(tsgu_csr_spmm_march(s.vtype, static_cast<const tsgu_march_plan*>(pr.plan()), pr.transposed, rows_out, s.nnz, val.data_ptr(),
                                   dense.data_ptr(), ld, out.data_ptr(), s.p, s.p, s.device, stream_of(s.device)),
               "tsgu_csr_spmm_march");
@@ -150,7 +154,11 @@ class StepFunction : public torch::autograd::Function<StepFunction> {
             if (need_a) {
                 // gradA[k] = <G[row k,:], B[col k,:]> at A's stored entries only (reference sparse_matmul.py:172-205)
                 gv = s.batch ? at::empty({s.batch, s.item_nnz}, val.options()) : at::empty({s.nnz}, val.options());
-                if (s.sddmm.kind == 0)
+                if (s.sddmm.kind == 3)
+                    check(tsgu_csr_sddmm_tile(s.vtype, static_cast<const tsgu_tile_plan*>(s.sddmm.plan()), G.data_ptr(), s.p, B.data_ptr(), ldb,
+                                              gv.data_ptr(), 1.0, s.p, s.device, stream_of(s.device)),
+                          "tsgu_csr_sddmm_tile");
+                else if (s.sddmm.kind == 0)
                     check(tsgu_csr_sddmm_march(s.vtype, static_cast<const tsgu_march_plan*>(s.sddmm.plan()), s.n_rows, s.nnz, G.data_ptr(), s.p,
                                                B.data_ptr(), ldb, gv.data_ptr(), 1.0, 0, s.p, s.device, stream_of(s.device)),
                           "tsgu_csr_sddmm_march");
@@ -212,7 +220,8 @@ PYBIND11_MODULE(_tsgu_host, m) {
             auto prod = [](const std::tuple<int, py::bytes, int>& t) {
                 Product q;
                 q.kind = std::get<0>(t), q.blob = std::string(std::get<1>(t)), q.transposed = std::get<2>(t);
-                const size_t want = q.kind == 0 ? sizeof(tsgu_march_plan) : (q.kind == 1 ? sizeof(tsgu_lattice_plan) : 0);
+                const size_t want = q.kind == 0 ? sizeof(tsgu_march_plan)
+                                    : (q.kind == 1 ? sizeof(tsgu_lattice_plan) : (q.kind == 3 ? sizeof(tsgu_tile_plan) : 0));
                 if (q.blob.size() != want) throw std::invalid_argument("plan struct of the wrong size");
                 q.blob.reserve(64);      // (heap storage: 16-byte aligned, never moved again)
                 return q;

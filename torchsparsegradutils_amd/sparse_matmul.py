@@ -27,6 +27,7 @@ import torch
 from . import _backend as _be
 from . import _ops
 from . import _pattern as _pt
+from ._tile import TilePlanStruct as _TilePlanStruct
 
 
 def sparse_mm(A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
@@ -148,16 +149,27 @@ def _settle_step_plan(op: "_Operand", values: torch.Tensor, G: torch.Tensor, B: 
         if _ops.ENABLE_LATTICE and _ops._lattice_cfg(plan, _be.LAT_SPMM, B) is not None:
             return
         t = plan.transposed
-        if (plan.core.pending or t.core.pending or _ops._pack_for(plan, B) is not None or _ops._pack_for(t, G, B) is not None
-                or _ops._tile_for(plan, B, G) is not None):
+        if any(not f.done() for f in list(plan.core.pending.values()) + list(t.core.pending.values())):
+            return                          # (a plan is still being built; finished ones wait in `pending` until somebody asks for them)
+        tp, tt = _ops._tile_for(plan, B, G), _ops._tile_for(t, G)
+        if tp is not None and tt is not None:
+            # row-block tiles (what _ops.spmm / _ops.mm_backward launch for this pattern): forward and SDDMM on the stored pattern's
+            # plan, Aᵀ·G on the transposed pattern's (its `perm` reads A's own values)
+            if not (B.is_contiguous() and G.is_contiguous()):
+                return
+            blob = lambda q: ctypes.string_at(_be._tile_struct(q), ctypes.sizeof(_TilePlanStruct))      # noqa: E731
+            sp = _host.StepPlan(plan.crow, plan.col, plan.n_rows, plan.n_cols, plan.nnz, p, _be._VTYPE[dtype], dev.index,
+                                (3, blob(tp), 0), (3, blob(tp), 0), (3, blob(tt), 1), [plan.crow, plan.col] + _tensors_of(tp) + _tensors_of(tt))
+        elif tp is not None or tt is not None or _ops._pack_for(plan, B) is not None or _ops._pack_for(t, G, B) is not None:
             return
-        if not (B.is_contiguous() and G.is_contiguous() and plan.crow.is_contiguous() and plan.col.is_contiguous()
-                and t.crow.is_contiguous() and t.col.is_contiguous() and t.perm is not None and t.perm.is_contiguous()):
-            return
-        none = (2, b"", 0)
-        sp = _host.StepPlan(plan.crow, plan.col, plan.n_rows, plan.n_cols, plan.nnz, p, _be._VTYPE[dtype], dev.index, none, none, none, [])
-        sp.set_plan_free(_be.itype_of(plan.crow), t.crow, t.col, t.perm, int(plan.max_row_nnz), int(t.max_row_nnz),
-                         bool(_be.fused_backward_supported(dtype, p)))
+        else:
+            if not (B.is_contiguous() and G.is_contiguous() and plan.crow.is_contiguous() and plan.col.is_contiguous()
+                    and t.crow.is_contiguous() and t.col.is_contiguous() and t.perm is not None and t.perm.is_contiguous()):
+                return
+            none = (2, b"", 0)
+            sp = _host.StepPlan(plan.crow, plan.col, plan.n_rows, plan.n_cols, plan.nnz, p, _be._VTYPE[dtype], dev.index, none, none, none, [])
+            sp.set_plan_free(_be.itype_of(plan.crow), t.crow, t.col, t.perm, int(plan.max_row_nnz), int(t.max_row_nnz),
+                             bool(_be.fused_backward_supported(dtype, p)))
     if op.layout != torch.sparse_csr:
         sp.set_coo(op.indices)
     if plans is None:
