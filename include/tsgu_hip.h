@@ -247,8 +247,11 @@ int tsgu_csr_sddmm_rowpack(int vtype, int itype, int64_t n_rows, int64_t n_cols,
  *   ucol                   int32 column numbers, U <= max_union per block
  *   lidx [nnz + 16]        uint8: position of entry k's column inside its block's tile
  *   rptr [n_rows + 1]      int32 row pointer of the walked pattern
- *   perm [nnz]             optional int32: position of entry k in the value array — the plan of the TRANSPOSED pattern walks A's own
- *                          values (Aᵀ·G, sparse_matmul.py:229); NULL: values in walked order
+ *   perm [nnz], slot [nnz] optional (both or neither; NULL: values in walked order) — the plan of the TRANSPOSED pattern walks A's own
+ *                          values (Aᵀ·G, sparse_matmul.py:229).  Per block (entries e0 .. e0 + E), in ascending order of the position
+ *                          in the value array: perm[e0 + i] int32 = that position, slot[e0 + i] uint16 = the entry of the block
+ *                          (0 .. E - 1) whose value it is.  The kernel fetches a block's values in this SOURCE order (neighbouring
+ *                          lanes read neighbouring values) and scatters them into the block's value buffer in LDS.
  * fp32 values, p a multiple of 32 up to 1024 (one launch per tile of 32 columns = 128 bytes of a dense row; the SDDMM adds the dots of
  * the later tiles to the first), 16-byte aligned dense operands, 2-D operands below 4 GiB.  Sums run in ascending
  * entry order of the walked pattern: the same bits as tsgu_csr_spmm / tsgu_csr_sddmm.  A row never touches a dense row it does not
@@ -263,6 +266,7 @@ typedef struct tsgu_tile_plan {
     const void* lidx;
     const void* rptr;
     const void* perm;
+    const void* slot;
 } tsgu_tile_plan;
 
 int tsgu_tile_geometry(int vtype, int64_t p, int* rows_per_block, int* max_union, int* max_entries);

@@ -38,8 +38,16 @@ def test_tile_plan_of_a_brick_numbered_mesh_and_its_transpose():
     _check(crow, col, tp, 64)
     t = g.transposed
     tt = t.tile_plan((64, 224, 2048))
-    assert tt is not None and tt.perm is not None and torch.equal(tt.perm.long(), t.perm.long())
+    assert tt is not None and tt.perm is not None and tt.slot is not None
     _check(t.crow, t.col, tt, 64)
+    # the values of a transposed block in SOURCE order: per block the positions in A's value array ascending, and for each the entry of
+    # the block it belongs to — together the transposed pattern's own permutation
+    src, slot, want = tt.perm.numpy().astype(np.int64), tt.slot.numpy().astype(np.int64) & 0xFFFF, t.perm.numpy().astype(np.int64)
+    for b in range(tt.n_blocks):
+        _, _, e0, E = tt.desc[b].tolist()
+        s_, d_ = src[e0:e0 + E], slot[e0:e0 + E]
+        assert (np.diff(s_) > 0).all() and np.array_equal(np.sort(d_), np.arange(E))
+        assert np.array_equal(want[e0:e0 + E][d_], s_)
     assert g.tile_plan((64, 224, 2048)) is tp          # cached with the pattern
 
 

@@ -26,14 +26,14 @@ class TilePlan:
     """Device arrays of one ``tsgu_tile_plan`` (+ its ctypes image, cached by _backend)."""
 
     __slots__ = ("n_rows", "n_cols", "nnz", "n_blocks", "rows_per_block", "max_union", "max_entries", "desc", "ucol", "lidx", "rptr", "perm",
-                 "reuse", "_cstruct")
+                 "slot", "reuse", "_cstruct")
 
     def __init__(self, **kw):
         for k in self.__slots__:
             setattr(self, k, kw.get(k))
 
     def plan_bytes(self) -> int:
-        return sum(t.numel() * t.element_size() for t in (self.desc, self.ucol, self.lidx, self.rptr) if t is not None)
+        return sum(t.numel() * t.element_size() for t in (self.desc, self.ucol, self.lidx, self.rptr, self.perm, self.slot) if t is not None)
 
 
 def build_tile_plan(crow: torch.Tensor, col: torch.Tensor, n_rows: int, n_cols: int, rows_per_block: int, max_union: int, max_entries: int,
@@ -83,9 +83,20 @@ def build_tile_plan(crow: torch.Tensor, col: torch.Tensor, n_rows: int, n_cols: 
     desc[:nb, 1] = padded.to(torch.int32)
     desc[:nb, 2] = e0.to(torch.int32)
     desc[:nb, 3] = (e1 - e0).to(torch.int32)
+    gsrc = gslot = None
+    if perm is not None:
+        # The walked pattern's values live elsewhere (a transposed pattern read through A's own value array): entry e of the walk is
+        # val[perm[e]].  The kernel fetches a block's values in SOURCE order — `perm` sorted inside every block, so that neighbouring
+        # lanes read neighbouring values (a block of a transposed mesh pattern draws runs of ~8 values from ~200 rows of A: in walk
+        # order every lane of a 4-byte gather touches its own cache line) — and `slot` says where each fetched value goes in the
+        # block's value buffer (its entry number inside the block).
+        perm64 = perm.to(torch.int64)
+        order = torch.argsort(blk * nnz + perm64)                        # (perm is a permutation: the keys are distinct; < 2^31 · 2^31)
+        gsrc = perm64[order].to(torch.int32).contiguous()
+        gslot = (order - e0[blk[order]]).to(torch.int16).contiguous()                     # < max_entries <= 2048
     return TilePlan(n_rows=n_rows, n_cols=n_cols, nnz=nnz, n_blocks=nb, rows_per_block=R, max_union=max_union, max_entries=max_entries,
                     desc=desc.contiguous(), ucol=ucol.to(torch.int32).contiguous(), lidx=lidx, rptr=crow.to(torch.int32).contiguous(),
-                    perm=None if perm is None else perm.to(torch.int32).contiguous(), reuse=reuse, _cstruct=None)
+                    perm=gsrc, slot=gslot, reuse=reuse, _cstruct=None)
 
 
 class TilePlanStruct(ctypes.Structure):
@@ -93,4 +104,5 @@ class TilePlanStruct(ctypes.Structure):
 
     _fields_ = [("n_rows", ctypes.c_int64), ("n_cols", ctypes.c_int64), ("nnz", ctypes.c_int64), ("n_blocks", ctypes.c_int64),
                 ("rows_per_block", ctypes.c_int32), ("max_union", ctypes.c_int32), ("max_entries", ctypes.c_int32), ("reserved", ctypes.c_int32),
-                ("desc", ctypes.c_void_p), ("ucol", ctypes.c_void_p), ("lidx", ctypes.c_void_p), ("rptr", ctypes.c_void_p), ("perm", ctypes.c_void_p)]
+                ("desc", ctypes.c_void_p), ("ucol", ctypes.c_void_p), ("lidx", ctypes.c_void_p), ("rptr", ctypes.c_void_p), ("perm", ctypes.c_void_p),
+                ("slot", ctypes.c_void_p)]

@@ -21,6 +21,7 @@ int fill(TileParams& P, const tsgu_tile_plan* pl, int64_t p) {
     if (!pl || pl->n_rows < 0 || pl->n_cols < 0 || pl->nnz < 0 || pl->n_blocks < 0) return TSGU_ERR_BAD_ARG;
     if (pl->rows_per_block != kTileRows || pl->max_union > kTileUMax || pl->max_entries > kTileEMax) return TSGU_ERR_BAD_ARG;
     if (pl->n_blocks > 0 && (!pl->desc || !pl->ucol || !pl->lidx || !pl->rptr)) return TSGU_ERR_BAD_ARG;
+    if ((pl->perm == nullptr) != (pl->slot == nullptr)) return TSGU_ERR_BAD_ARG;        // (source positions and their slots: both or neither)
     if (pl->n_rows > 0x7fffffffLL || pl->nnz > 0x7fffffffLL) return TSGU_ERR_TOO_LARGE;
     if (p <= 0 || p % 32) return TSGU_ERR_BAD_ARG;        // (column tiles of 32: dense rows of 128 bytes per launch)
     P.n_rows = pl->n_rows;
@@ -32,6 +33,7 @@ int fill(TileParams& P, const tsgu_tile_plan* pl, int64_t p) {
     P.lidx = static_cast<const unsigned char*>(pl->lidx);
     P.rptr = static_cast<const int*>(pl->rptr);
     P.perm = static_cast<const int*>(pl->perm);
+    P.slot = static_cast<const unsigned short*>(pl->slot);
     return TSGU_OK;
 }
 

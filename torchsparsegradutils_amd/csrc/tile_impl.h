@@ -53,7 +53,8 @@ struct TileParams {
     const int* ucol;
     const unsigned char* lidx;   // [nnz + 16]
     const int* rptr;             // [n_rows + 1]
-    const int* perm;             // optional [nnz]
+    const int* perm;             // optional [nnz]: per block, positions in the value array in ascending order …
+    const unsigned short* slot;  // … and the entry of the block each of them belongs to
     const void* val;             // SpMM: values
     const void* S;               // gathered dense operand (B; Cm for the SDDMM)
     int64_t lds_;
@@ -149,7 +150,10 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(const TileParams 
     // issued in (hipcc's own wait for it is then free); a load consumed inside the same step would make hipcc drain the DMAs.
     int ucolr[UP];                                       // column numbers of this thread's tile pieces of the block staged next
     unsigned toff[UP];                                   // … and their byte offsets in the gathered operand
-    int permr[PERM ? kTileEP : 1];                       // value positions of this thread's entries of the block staged next
+    int permr[PERM ? kTileEP : 1];                       // value positions this thread fetches for the block staged next …
+    unsigned slotr[PERM ? kTileEP : 1];                  // … the entries of that block they belong to …
+    unsigned slotw[PERM ? kTileEP : 1];                  // … (of the block whose values are in flight)
+    float valr[PERM ? kTileEP : 1];                      // values in flight: loaded while block k is walked, written to LDS at the end of the step
     uint4 own_cur = {0, 0, 0, 0}, own_nxt = {0, 0, 0, 0};      // SDDMM: this lane's 16 bytes of its row of R, block walked / next block
 #pragma unroll
     for (int i = 0; i < UP; ++i) ucolr[i] = 0;
@@ -180,6 +184,7 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(const TileParams 
 #else
                     permr[i] = P.perm[(int64_t)d.e0 + e];
 #endif
+                    slotr[i] = P.slot[(int64_t)d.e0 + e];
                 }
             }
         }
@@ -194,7 +199,10 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(const TileParams 
         }
         if constexpr (PERM) {
 #pragma unroll
-            for (int i = 0; i < kTileEP; ++i) lat_pin(permr[i]);
+            for (int i = 0; i < kTileEP; ++i) {
+                lat_pin(permr[i]);
+                lat_pin(slotr[i]);
+            }
         }
     };
 
@@ -210,7 +218,9 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(const TileParams 
             for (int i = 0; i < kTileEP; ++i) {
                 if (wave_e + i * kTileThreads < d.E) {
                     if constexpr (PERM) {
-                        lat_dma4<false>(P.val, (uint32_t)permr[i] * 4u, buf + L::oVals + (wave_piece + (unsigned)i * kTileThreads) * 4u);
+                        // (an ordinary load, issued behind the step's DMAs and first used behind its `s_waitcnt vmcnt(0)`: put_values)
+                        valr[i] = static_cast<const float*>(P.val)[(uint32_t)permr[i]];
+                        slotw[i] = slotr[i];
                     } else {
                         int e = t + i * kTileThreads;
                         e = e < d.E ? e : d.E - 1;
@@ -234,6 +244,16 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(const TileParams 
             const int nr = (int)((P.n_rows - r0) < kTileRows ? (P.n_rows - r0) : kTileRows) + 1;
             if (wave_e < nr) {                              // (waves 0 and 1; lane predicate: the slice is 65 words, the region 72)
                 if (t < nr) lat_dma4<true>(P.rptr, (uint32_t)(r0 + t) * 4u, buf + L::oRs + wave_piece * 4u);
+            }
+        }
+    };
+
+    auto put_values = [&](int k, const TileDesc d) {     // the fetched values of block k into its value buffer (behind the step's vmcnt(0))
+        if constexpr (PERM) {
+            float* const vb = reinterpret_cast<float*>(tile_lds + (k & 1) * L::kBuf + L::oVals);
+#pragma unroll
+            for (int i = 0; i < kTileEP; ++i) {
+                if (wave_e + i * kTileThreads < d.E) vb[slotw[i]] = valr[i];      // (lanes beyond the end repeat the last pair)
             }
         }
     };
@@ -405,6 +425,10 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(const TileParams 
     stage(0, d0);
     load_own(0);
     load_words(d1);
+    if constexpr (PERM) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        put_values(0, d0);
+    }
     lat_step_sync();
     for (int k = 0; k < nloc; ++k) {
         const TileDesc d3 = tile_uniform(raw);          // (loaded during the previous step)
@@ -415,6 +439,10 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(const TileParams 
         if (k + 1 < nloc) load_own(k + 1);
         raw = desc_at(k + 4);
         walk(k, d0);
+        if constexpr (PERM) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (k + 1 < nloc) put_values(k + 1, d1);
+        }
         lat_step_sync();
         d0 = d1, d1 = d2, d2 = d3;
     }
