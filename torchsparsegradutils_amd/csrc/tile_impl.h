@@ -88,24 +88,18 @@ __device__ __forceinline__ TileDesc tile_uniform(const TileDesc d) {
                     __builtin_amdgcn_readfirstlane(d.E)};
 }
 
-// smallest and largest value over the wave of a per-row length (< 65536; all lanes of a row's group hold the same value): one packed
-// 16-bit minimum per exchange — the high half carries 65535 - x
-typedef unsigned short tile_u16x2 __attribute__((ext_vector_type(2)));
+// smallest and largest value over the wave of a per-row length (all lanes of a row's group hold the same value): one v_readlane per
+// row and scalar min / max — three dependent ds_bpermute round trips (what __shfl_xor compiles to) at the head of every walk cost
+// more than the whole scalar chain
 template <int CL>
 __device__ __forceinline__ void tile_wave_minmax(int x, int& lo, int& hi) {
-    unsigned int w = (unsigned int)x | ((65535u - (unsigned int)x) << 16);
+    lo = hi = __builtin_amdgcn_readlane(x, 0);
 #pragma unroll
-    for (int m = CL; m < kWave; m <<= 1) {
-        const unsigned int y = (unsigned int)__shfl_xor((int)w, m, kWave);
-        tile_u16x2 a, b;
-        __builtin_memcpy(&a, &w, 4);
-        __builtin_memcpy(&b, &y, 4);
-        a = __builtin_elementwise_min(a, b);
-        __builtin_memcpy(&w, &a, 4);
+    for (int g = 1; g < kWave / CL; ++g) {
+        const int y = __builtin_amdgcn_readlane(x, g * CL);
+        lo = y < lo ? y : lo;
+        hi = y > hi ? y : hi;
     }
-    w = (unsigned int)__builtin_amdgcn_readfirstlane((int)w);
-    lo = (int)(w & 0xffffu);
-    hi = 65535 - (int)(w >> 16);
 }
 
 template <typename V, int CL, int MODE, bool PERM>
