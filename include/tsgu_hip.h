@@ -58,8 +58,10 @@ int tsgu_device_copy(const void* src, void* dst, int64_t bytes, int device, void
  * 64-bit arithmetic, the same words whatever the launch geometry.  No reference counterpart: the reference keeps no per-pattern
  * state (sparse_matmul.py:141-163 re-derives everything per call), so it has no cliff when a caller rebuilds its index tensors
  * every step; the pattern cache here recognises such tensors by content (one pass over the indices) and adopts the existing plans.
+ * accumulate = 0: out2 is zeroed first (one more device operation on the stream); 1: the sums are ADDED to what out2 holds (a caller
+ * fingerprinting several arrays zeroes all their words with one fill).
  */
-int tsgu_index_fingerprint(int itype, int64_t n, const void* x, void* out2, int device, void* stream);
+int tsgu_index_fingerprint(int itype, int64_t n, const void* x, void* out2, int accumulate, int device, void* stream);
 
 /*
  * K1  C = A · B            (CSR × dense, optional fused column-dot epilogue)

@@ -190,6 +190,13 @@ def test_index_fingerprint_is_a_function_of_content_only():
     assert not torch.equal(f2[0], f1[0]) and (x[5] == x[6] or not torch.equal(f2[1], f1[0]))
     assert torch.equal(f2[2], f1[0])          # the index dtype is geometry, not content
     assert torch.equal(be.index_fingerprint(x[:0])[0], torch.zeros(2, dtype=torch.int64, device=DEV))
+    # the kernel reads 16-byte vectors where the pointer allows it: a view that starts 4 bytes into its storage (scalar path), every
+    # tail length, and a size that takes the unrolled loop must agree with the aligned copies of the same content
+    big = torch.randint(0, 1 << 30, (5_000_003,), device=DEV, generator=g, dtype=torch.int32)
+    for view in (x[1:], x[3:77], x[:16], big, big[1:], big.to(torch.int64)[1:]):
+        assert view.is_contiguous()
+        assert torch.equal(be.index_fingerprint(view)[0], be.index_fingerprint(view.clone())[0])
+    assert torch.equal(be.index_fingerprint(big)[0], be.index_fingerprint(big.to(torch.int64))[0])
 
 
 # ---- row-block tile kernels (csrc/tile_impl.h): general patterns whose neighbouring rows share columns ----------------------------

@@ -41,7 +41,7 @@ SIGNATURES = {
     "tsgu_status_string": (ctypes.c_char_p, [_int]),
     "tsgu_device_info": (_int, [_int, ctypes.c_char_p, _int, ctypes.POINTER(_int), ctypes.POINTER(_int)]),
     "tsgu_device_copy": (_int, [_ptr, _ptr, _i64, _int, _ptr]),
-    "tsgu_index_fingerprint": (_int, [_int, _i64, _ptr, _ptr, _int, _ptr]),
+    "tsgu_index_fingerprint": (_int, [_int, _i64, _ptr, _ptr, _int, _int, _ptr]),
     "tsgu_tile_geometry": (_int, [_int, _i64, ctypes.POINTER(_int), ctypes.POINTER(_int), ctypes.POINTER(_int)]),
     "tsgu_csr_spmm_tile": (_int, [_int, _ptr, _ptr, _ptr, _i64, _ptr, _i64, _i64, _int, _ptr]),
     "tsgu_csr_sddmm_tile": (_int, [_int, _ptr, _ptr, _i64, _ptr, _i64, _ptr, _dbl, _i64, _int, _ptr]),
@@ -863,11 +863,11 @@ def index_fingerprint(*tensors: torch.Tensor) -> torch.Tensor:
     current stream, nothing is read back here."""
     lib = load_library()
     dev = require_device(*tensors)
-    out = torch.empty((len(tensors), 2), dtype=torch.int64, device=dev)
+    out = torch.zeros((len(tensors), 2), dtype=torch.int64, device=dev)      # (one fill for all the words; the launches accumulate)
     with torch.cuda.device(dev):
         for i, t in enumerate(tensors):
             t = t.contiguous()
-            check(lib.tsgu_index_fingerprint(itype_of(t), t.numel(), _p(t), out[i].data_ptr(), dev.index, _stream(dev)),
+            check(lib.tsgu_index_fingerprint(itype_of(t), t.numel(), _p(t), out[i].data_ptr(), 1, dev.index, _stream(dev)),
                   "tsgu_index_fingerprint")
     return out
 

@@ -730,6 +730,29 @@ _FRESH = {}
 STATS = {"adopted": 0, "fingerprints": 0, "volatile": 0}
 
 
+_READ_BUFS = threading.local()
+
+
+def _read_words(t: torch.Tensor) -> torch.Tensor:
+    """Host copy of a small int64 device tensor: asynchronous copy into pinned memory + a polled event.  `.cpu()` parks the thread in
+    the runtime's blocking wait, whose wake-up took ~0.25 ms longer than the GPU needed (measured: 0.35 ms in `.cpu()` per step for
+    0.26 ms of queued kernels) — the step of a caller with fresh index tensors waits for exactly this read."""
+    n = t.numel()
+    bufs = getattr(_READ_BUFS, "bufs", None)
+    if bufs is None:
+        bufs = _READ_BUFS.bufs = {}
+    dev = t.device
+    got = bufs.get(dev)
+    if got is None or got[0].numel() < n:
+        got = bufs[dev] = (torch.empty(max(n, 64), dtype=torch.int64, pin_memory=True), torch.cuda.Event())
+    host, ev = got
+    host[:n].copy_(t.reshape(-1), non_blocking=True)
+    ev.record(torch.cuda.current_stream(dev))
+    while not ev.query():
+        pass
+    return host[:n].clone().reshape(t.shape)
+
+
 def _fingerprint(tensors):
     if not FINGERPRINT or not all(t.is_cuda and t.dtype in (torch.int32, torch.int64) for t in tensors):
         return None
@@ -761,7 +784,8 @@ def _core_for(kind: str, tensors, shape) -> _Core:
             # ONE device-to-host copy (the only host read, and only when a live entry has this geometry): the new fingerprint and
             # those of the candidates whose words are not on the host yet
             missing = [c for c in uniq if "fp_host" not in c.own]
-            words = torch.stack([fp] + [c.fp for c in missing]).cpu().reshape(len(missing) + 1, -1).tolist()
+            stacked = torch.stack([fp] + [c.fp for c in missing]) if missing else fp.unsqueeze(0)
+            words = _read_words(stacked).reshape(len(missing) + 1, -1).tolist()
             for c, w in zip(missing, words[1:]):
                 c.own["fp_host"] = w
             for c in uniq:

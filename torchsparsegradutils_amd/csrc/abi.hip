@@ -23,25 +23,55 @@ using namespace tsgu;
 // arithmetic — integer addition commutes, so the atomics of different workgroups give the same words in any order.
 template <typename I>
 __global__ __launch_bounds__(256) void tsgu_fingerprint_kernel(const I* __restrict__ x, int64_t n, unsigned long long* __restrict__ out) {
+    constexpr int V = 16 / (int)sizeof(I);               // indices per 16-byte load
+    struct alignas(16) Vec {
+        I v[V];
+    };
     unsigned long long h1 = 0, h2 = 0;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) {
-        // position weights from 32-bit multiplicative hashes of the index (a 64-bit `%` costs ~100 instructions per element: the
-        // first version of this kernel took 0.3 ms for C2's 27 M column indices instead of the 25 us its 112 MB take to read)
-        const unsigned long long a = (unsigned long long)(long long)x[k] + 0x9e3779b97f4a7c15ull;
+    // position weights from 32-bit multiplicative hashes of the index (a 64-bit `%` costs ~100 instructions per element: the
+    // first version of this kernel took 0.3 ms for C2's 27 M column indices)
+    auto add = [&](int64_t k, I xv) {
+        const unsigned long long a = (unsigned long long)(long long)xv + 0x9e3779b97f4a7c15ull;
         const unsigned int kl = (unsigned int)k;
         const unsigned int w1 = (kl * 2654435761u) | 1u, w2 = ((kl ^ (kl >> 15)) * 2246822519u) | 1u;
         h1 += a * (unsigned long long)w1;
         h2 += (a ^ (a >> 29)) * (unsigned long long)w2;
+    };
+    // 16-byte loads, four of them in flight per thread: with one 4-byte load per thread and trip the second version was bound by
+    // memory latency (0.27 ms for 108 MB = 0.4 TB/s; the whole step of a caller with fresh index tensors waits for this kernel)
+    const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t nv = reinterpret_cast<uintptr_t>(x) % 16 == 0 ? n / V : 0;
+    const Vec* const xv = reinterpret_cast<const Vec*>(x);
+    int64_t c = gtid;
+    for (; c + 3 * stride < nv; c += 4 * stride) {
+        Vec a[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a[u] = xv[c + u * stride];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int j = 0; j < V; ++j) add((c + u * stride) * V + j, a[u].v[j]);
+        }
     }
+    for (; c < nv; c += stride) {
+        const Vec a = xv[c];
+#pragma unroll
+        for (int j = 0; j < V; ++j) add(c * V + j, a.v[j]);
+    }
+    for (int64_t k = nv * V + gtid; k < n; k += stride) add(k, x[k]);      // the tail (everything, for a pointer that is not 16-byte aligned)
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {
         h1 += __shfl_xor(h1, m, 64);
         h2 += __shfl_xor(h2, m, 64);
     }
-    if ((threadIdx.x & 63) == 0) {
-        atomicAdd(out, h1);
-        atomicAdd(out + 1, h2);
+    // ONE pair of atomics per workgroup: same-address 64-bit atomics retire at ~80 M/s, and with a pair per wave of 2048 workgroups
+    // the 16 384 atomics (0.2 ms) — not the 108 MB — were the kernel's duration
+    __shared__ unsigned long long part[2][4];
+    if ((threadIdx.x & 63) == 0) part[0][threadIdx.x >> 6] = h1, part[1][threadIdx.x >> 6] = h2;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(out, part[0][0] + part[0][1] + part[0][2] + part[0][3]);
+        atomicAdd(out + 1, part[1][0] + part[1][1] + part[1][2] + part[1][3]);
     }
 }
 
@@ -96,15 +126,15 @@ int tsgu_device_copy(const void* src, void* dst, int64_t bytes, int device, void
     return check_launch();
 }
 
-int tsgu_index_fingerprint(int itype, int64_t n, const void* x, void* out2, int device, void* stream) {
+int tsgu_index_fingerprint(int itype, int64_t n, const void* x, void* out2, int accumulate, int device, void* stream) {
     if (n < 0 || !out2 || (n > 0 && !x)) return TSGU_ERR_BAD_ARG;
     if (itype != TSGU_I32 && itype != TSGU_I64) return TSGU_ERR_BAD_DTYPE;
     if (const int rc = set_device(device)) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (hipMemsetAsync(out2, 0, 16, s) != hipSuccess) return TSGU_ERR_RUNTIME;
+    if (!accumulate && hipMemsetAsync(out2, 0, 16, s) != hipSuccess) return TSGU_ERR_RUNTIME;
     if (n == 0) return TSGU_OK;
-    const int64_t want = (n + 256 * 8 - 1) / (256 * 8);
-    const unsigned blocks = (unsigned)(want < 2048 ? want : 2048);
+    const int64_t want = (n + 256 * 16 - 1) / (256 * 16);
+    const unsigned blocks = (unsigned)(want < 512 ? want : 512);      // (two workgroups per CU: 64 bytes x 512 threads in flight on each)
     if (itype == TSGU_I32)
         hipLaunchKernelGGL(tsgu_fingerprint_kernel<int32_t>, dim3(blocks), dim3(256), 0, s, static_cast<const int32_t*>(x), n,
                            static_cast<unsigned long long*>(out2));
