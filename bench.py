@@ -1022,10 +1022,12 @@ def main():
                 fstep(crow2, col2)
                 wait_for_plans()
             k2 = 16
-            clones = [(crow2.clone(), col2.clone()) for _ in range(k2)]
+            clones = [(crow2.clone(), col2.clone()) for _ in range(k2 + 2)]
+            for cr, co in clones[:2]:          # (the first fresh step pays the one-time set-up of the host read: pinned buffer, event)
+                fstep(cr, co)
             torch.cuda.synchronize(dev)
             t0 = time.perf_counter()
-            for cr, co in clones:
+            for cr, co in clones[2:]:
                 fstep(cr, co)
             torch.cuda.synchronize(dev)
             ms_fresh = (time.perf_counter() - t0) / k2 * 1e3
@@ -1035,7 +1037,8 @@ def main():
             torch.cuda.synchronize(dev)
             ms_same = (time.perf_counter() - t0) / k2 * 1e3
             fresh = {"what": "the C2 step with crow.clone(), col.clone() on every step (fresh storages, known content)", "ms_per_step": round(ms_fresh, 5),
-                     "ms_per_step_same_tensors": round(ms_same, 5), "adopted": _pattern.STATS["adopted"], "steps": k2}
+                     "ms_per_step_same_tensors": round(ms_same, 5), "adopted": _pattern.STATS["adopted"], "steps": k2,
+                     "note": "timed from the third fresh step on"}
             del clones, crow2, col2, val2, B2, G2
             _pattern.clear_cache()
             torch.cuda.empty_cache()
