@@ -15,7 +15,11 @@
 //                              repeats of the last one), its entries are e0 .. e0+E of the walked pattern
 //   lidx[k]                    position of entry k's column inside its block's tile (one byte: U <= 256)
 //   rptr                       int32 row pointer of the walked pattern
-//   perm (optional)            position of entry k in the value array (the transposed pattern walks A's own values: Aᵀ·G)
+//   perm, slot (optional)      the transposed pattern walks A's own values (Aᵀ·G): per block, perm = the positions in the value array in
+//                              ASCENDING order, slot = the entry of the block each belongs to.  Their values travel through registers
+//                              (ordinary loads in source order, neighbouring lanes on neighbouring values; written to the LDS value
+//                              buffer between the step's `s_waitcnt vmcnt(0)` and its barrier) — in walk order every lane of a 4-byte
+//                              gather touched its own cache line and the staging, not the walk, bounded the kernel
 //
 // Modes: kTileSpmm  C = A·B (perm: Aᵀ·G on the transposed pattern); kTileSddmm  out[k] = alpha·<R[row k], Cm[col k]> in stored order.
 // (Round 5 also built BOTH gradients in one walk of the transposed pattern's plan — G staged once, B[j] in registers, dots back through
