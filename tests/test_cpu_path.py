@@ -181,3 +181,31 @@ def test_device_is_the_only_switch():
 
     with pytest.raises(RuntimeError, match="gfx950 kernels"):
         _backend.require_device(torch.ones(2))      # the HIP bindings themselves still refuse CPU tensors
+
+
+@pytest.mark.parametrize("fresh", [False, True], ids=["reused_A", "fresh_A"])
+@pytest.mark.parametrize("layout", ["coo", "csr"])
+def test_many_steps_on_cpu_never_reach_the_gpu_plan_builders(fresh, layout):
+    """Six forward+backward steps of configs[0] (nnz 167 772 ≥ PACK_MIN_NNZ: large enough for every plan builder to be asked):
+    the step-plan / row-pair / tile / lattice bookkeeping behind the backward exists for GPU operands only and must not be entered
+    for CPU tensors (it asks torch.cuda for the current stream).  Every step returns the reference's golden gradients."""
+    from torchsparsegradutils_amd import _ops
+
+    z = G.load("mm_c1_coo.npz")
+    assert z["val"].size >= _ops.PACK_MIN_NNZ
+    idx = torch.from_numpy(np.stack([z["rows"].astype(np.int64), z["cols"].astype(np.int64)]))
+
+    def operand():
+        A = torch.sparse_coo_tensor(idx.clone() if fresh else idx, G.t(z["val"]), (4096, 4096), is_coalesced=True)
+        return (A.to_sparse_csr() if layout == "csr" else A).requires_grad_(True)
+
+    A = operand()
+    B = G.t(z["B"]).requires_grad_(True)
+    for step in range(6):
+        if fresh:
+            A = operand()
+        A.grad = B.grad = None
+        C = tsgu().sparse_mm(A, B)
+        C.backward(G.t(z["G"]))
+        gv = A.grad.values() if layout == "csr" else A.grad._values()
+        assert rel(C, z["C"]) < 1e-6 and rel(gv, z["gradA_val"]) < 1e-6 and rel(B.grad, z["gradB"]) < 1e-6, step

@@ -60,8 +60,9 @@ def _lattice_plan(plan: RowGather, transposed: bool = False):
     values stay in `plan`'s stored order), None when the pattern is not a lattice stencil.  Cached with the pattern.
     Built at FIRST sight: the row kernels of csrc/lattice_plan.hip make it a few milliseconds (two passes over the
     pattern + a sort of one word per row), and the transposed walk needs no transposed pattern."""
-    if not ENABLE_LATTICE or plan.batch is not None or plan.perm is not None or plan.nnz < PACK_MIN_NNZ or plan.n_rows != plan.n_cols:
-        return None
+    if (not ENABLE_LATTICE or not plan.crow.is_cuda or plan.batch is not None or plan.perm is not None or plan.nnz < PACK_MIN_NNZ
+            or plan.n_rows != plan.n_cols):
+        return None          # (plans exist for GPU operands only: CPU operands take _cpu.py)
     own = plan.core.own
     # a plan is built with host round trips (status words, class tables): never inside a stream capture — a pattern first
     # seen there runs on the plan-free kernels and gets its plan from the first call outside the capture
@@ -215,8 +216,8 @@ def _measured_cfg(lp, mode: int, dense: torch.Tensor, cfg):
 def _pack_for(plan: RowGather, dense: torch.Tensor, *others: torch.Tensor, need_plain_slots: bool = False):
     """RowPackPlan of the 2-D `plan` for these dense operands, or None (disabled / not supported / not profitable /
     pattern not seen often enough yet)."""
-    if (not ENABLE_PACK or plan.batch is not None or dense.dim() != 2 or plan.nnz < PACK_MIN_NNZ
-            or plan.crow.dtype not in (torch.int32, torch.int64)):
+    if (not ENABLE_PACK or not plan.crow.is_cuda or not dense.is_cuda or plan.batch is not None or dense.dim() != 2
+            or plan.nnz < PACK_MIN_NNZ or plan.crow.dtype not in (torch.int32, torch.int64)):
         return None
     geo = _be.rowpack_geometry(dense.dtype, dense.size(-1))
     if geo is None or not _be._tiled_ok(*(_be.rowmajor(t) for t in (dense,) + others)):
@@ -235,8 +236,8 @@ def _pack_for(plan: RowGather, dense: torch.Tensor, *others: torch.Tensor, need_
 def _tile_for(plan: RowGather, dense: torch.Tensor, *others: torch.Tensor):
     """TilePlan of the 2-D `plan` for these dense operands, or None (disabled / not compiled for them / the pattern does not qualify
     or has not come back yet)."""
-    if (not ENABLE_TILE or plan.batch is not None or dense.dim() != 2 or plan.nnz < PACK_MIN_NNZ
-            or plan.crow.dtype not in (torch.int32, torch.int64)):
+    if (not ENABLE_TILE or not plan.crow.is_cuda or not dense.is_cuda or plan.batch is not None or dense.dim() != 2
+            or plan.nnz < PACK_MIN_NNZ or plan.crow.dtype not in (torch.int32, torch.int64)):
         return None
     geo = _be.tile_geometry(dense.dtype, dense.size(-1))
     if geo is None:

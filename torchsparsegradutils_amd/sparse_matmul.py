@@ -99,7 +99,7 @@ def _settle_step_plan(op: "_Operand", values: torch.Tensor, G: torch.Tensor, B: 
     host path — the three configurations of a lattice stencil (the StepPlan copies the plan structs and holds every device table
     they point into), or the plan-free kernels with the cached transposed pattern once the row-pair plans are known not to apply."""
     plan = op.plan
-    if (_host is None or not FAST_STEP or plan.perm is not None or op.flat_batch is not None
+    if (_host is None or not FAST_STEP or not B.is_cuda or not plan.crow.is_cuda or plan.perm is not None or op.flat_batch is not None
             or not (values.dtype == G.dtype == B.dtype) or (op.layout != torch.sparse_csr and op.indices is None)):
         return
     dtype, p = G.dtype, G.size(-1)
