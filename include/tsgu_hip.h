@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define TSGU_ABI_VERSION 5
+#define TSGU_ABI_VERSION 6
 
 typedef enum {
     TSGU_OK = 0,
@@ -62,6 +62,15 @@ int tsgu_device_copy(const void* src, void* dst, int64_t bytes, int device, void
  * fingerprinting several arrays zeroes all their words with one fill).
  */
 int tsgu_index_fingerprint(int itype, int64_t n, const void* x, void* out2, int accumulate, int device, void* stream);
+/*
+ * The same pass with an EXACT comparison and / or a copy: out3[0..1] += the fingerprint of x; when `ref` is given, out3[2] += a
+ * count that is non-zero iff x[k] != ref[k] for some k; when `copy` is given, copy[k] = x[k].  The fingerprint only selects which
+ * cached pattern a fresh index tensor is compared with — plans are adopted on out3[2] == 0, never on equal fingerprints alone
+ * (a collision would silently compute with another matrix' pattern); `copy` is how the cache keeps the content it compares with
+ * (it never holds the caller's tensors).  accumulate as above (0: the three words are zeroed first).
+ */
+int tsgu_index_fingerprint_match(int itype, int64_t n, const void* x, const void* ref, void* copy, void* out3, int accumulate,
+                                 int device, void* stream);
 
 /*
  * K1  C = A · B            (CSR × dense, optional fused column-dot epilogue)

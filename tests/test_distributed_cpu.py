@@ -34,7 +34,7 @@ def _oracle_batched_mm(A, B):
     return torch.stack(out) if out else torch.empty((0,) + tuple(B.shape[1:]))
 
 
-def _worker(rank, world, port, batch, q):
+def _worker(rank, world, port, batch, q, chunks=(2,)):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -54,13 +54,16 @@ def _worker(rank, world, port, batch, q):
         lo, hi = parallel.shard_bounds(batch, world, rank)
         local = parallel.sharded_batched_apply(_oracle_batched_mm, A, B, gather=False)
         # run-by-run compute with asynchronous gathers (falls back to the single gather for ragged shards)
-        piped = parallel.sharded_batched_apply(_oracle_batched_mm, A, B, overlap_chunks=2)
+        piped = parallel.sharded_batched_apply(_oracle_batched_mm, A, B, overlap_chunks=chunks[0])
+        for c in chunks[1:]:
+            if not torch.equal(parallel.sharded_batched_apply(_oracle_batched_mm, A, B, overlap_chunks=c), piped):
+                piped = piped[:0]
         # rank-local shards: no rank holds the whole batch
         A_own = stack_csr(items[lo:hi]) if hi > lo else None
         own = own_piped = full
         if A_own is not None:
             own = parallel.sharded_batched_apply(_oracle_batched_mm, A_own, B[lo:hi].clone(), batch=batch)
-            own_piped = parallel.sharded_batched_apply(_oracle_batched_mm, A_own, B[lo:hi].clone(), batch=batch, overlap_chunks=2)
+            own_piped = parallel.sharded_batched_apply(_oracle_batched_mm, A_own, B[lo:hi].clone(), batch=batch, overlap_chunks=chunks[-1])
             try:
                 parallel.sharded_batched_apply(_oracle_batched_mm, A_own, B[lo:hi], batch=batch + world)
                 wrong_size_raises = False
@@ -95,6 +98,24 @@ def test_sharded_batched_apply_gloo_world2(batch):
         assert p.exitcode == 0
     results = dict(q.get(timeout=10) for _ in range(2))
     assert results == {0: True, 1: True}
+
+
+def test_sharded_batched_apply_gloo_world8_c5_split():
+    """The split of BASELINE configs[4] on one node: 64 batch items over 8 ranks = 8 per rank (the index arithmetic of the driver's
+    `bench.py --gpus 8` run: contiguous shards, one all-gather, chunked overlap 1 / 2 / 4, rank-local shards) — on gloo, with tiny
+    items, because no 8-GPU node has ever been available to this build (every SCALE_r0*.json is a `skipped` record)."""
+    world, batch = 8, 64
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, batch, q, (1, 2, 4))) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    results = dict(q.get(timeout=10) for _ in range(world))
+    assert results == {r: True for r in range(world)}
 
 
 def test_shard_bounds_cover_the_batch_exactly():

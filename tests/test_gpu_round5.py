@@ -117,7 +117,8 @@ def test_compat_sparse_branch_validates_shapes():
 
 def test_fresh_index_tensors_with_known_content_adopt_the_plan():
     """`torch.sparse_csr_tensor(crow.clone(), col.clone(), …)` every step: the identity key misses every time.  The cache compares the
-    CONTENT (128-bit fingerprint, `tsgu_index_fingerprint`) with live entries of the same geometry and adopts their plans: the third
+    CONTENT (an exact comparison with the cache's own copy, selected by a 128-bit fingerprint: `tsgu_index_fingerprint_match`) with live
+    entries of the same geometry and adopts their plans: the third
     step already runs on the plane-march kernels (same bits as a step on the original tensors), the gradient carries the NEW tensors,
     and a C2-sized step stays near the kernels' 0.23 ms instead of paying the ~11 ms analysis per step."""
     import time
@@ -163,9 +164,9 @@ def test_fresh_index_tensors_with_known_content_adopt_the_plan():
         assert got[1].crow_indices().data_ptr() == cr.data_ptr() and got[1].col_indices().data_ptr() == co.data_ptr()
         assert torch.equal(got[0], ref[0]) and torch.equal(got[1].values(), ref[1].values()) and torch.equal(got[2], ref[2]), i
     assert _pattern.STATS["adopted"] - before["adopted"] == 6
-    # one pass over the indices + one host read on top of the same step with known tensors (bench.py reports the pipelined figure;
-    # without adoption every such step pays the ~11 ms analysis)
-    assert min(times[2:]) < min(base) + 0.45, (times, base)
+    # (what such a step costs is bench.py's `fresh_index_tensors` leg: a wall clock has no place in a parity suite.  That the plans were
+    # ADOPTED — not rebuilt — is what is asserted: six adoptions above, and no new pattern analysis below)
+    del times, base
     # different content of the same geometry is NOT adopted …
     co2 = col.clone()
     co2[:27] = col[:27].flip(0)

@@ -34,7 +34,7 @@ _ptr = ctypes.c_void_p
 _dbl = ctypes.c_double
 
 # name -> (restype, argtypes); must list every symbol declared in include/tsgu_hip.h
-ABI_VERSION = 5          # TSGU_ABI_VERSION of include/tsgu_hip.h this binding was written against
+ABI_VERSION = 6          # TSGU_ABI_VERSION of include/tsgu_hip.h this binding was written against
 
 SIGNATURES = {
     "tsgu_abi_version": (_int, []),
@@ -42,6 +42,7 @@ SIGNATURES = {
     "tsgu_device_info": (_int, [_int, ctypes.c_char_p, _int, ctypes.POINTER(_int), ctypes.POINTER(_int)]),
     "tsgu_device_copy": (_int, [_ptr, _ptr, _i64, _int, _ptr]),
     "tsgu_index_fingerprint": (_int, [_int, _i64, _ptr, _ptr, _int, _int, _ptr]),
+    "tsgu_index_fingerprint_match": (_int, [_int, _i64, _ptr, _ptr, _ptr, _ptr, _int, _int, _ptr]),
     "tsgu_tile_geometry": (_int, [_int, _i64, ctypes.POINTER(_int), ctypes.POINTER(_int), ctypes.POINTER(_int)]),
     "tsgu_csr_spmm_tile": (_int, [_int, _ptr, _ptr, _ptr, _i64, _ptr, _i64, _i64, _int, _ptr]),
     "tsgu_csr_sddmm_tile": (_int, [_int, _ptr, _ptr, _i64, _ptr, _i64, _ptr, _dbl, _i64, _int, _ptr]),
@@ -870,6 +871,31 @@ def index_fingerprint(*tensors: torch.Tensor) -> torch.Tensor:
             check(lib.tsgu_index_fingerprint(itype_of(t), t.numel(), _p(t), out[i].data_ptr(), 1, dev.index, _stream(dev)),
                   "tsgu_index_fingerprint")
     return out
+
+
+def index_fingerprint_match(tensors, refs=None, copy: bool = False):
+    """One pass per index tensor (see tsgu_index_fingerprint_match): returns (words, copies) — `words` a [len(tensors)][3] int64
+    device tensor {fingerprint word 0, word 1, non-zero iff the tensor differs from its `refs` entry}, `copies` fresh contiguous
+    copies of the tensors (None unless `copy`).  Queued on the current stream, nothing is read back here."""
+    lib = load_library()
+    dev = require_device(*tensors)
+    out = torch.zeros((len(tensors), 3), dtype=torch.int64, device=dev)
+    copies = [] if copy else None
+    with torch.cuda.device(dev):
+        for i, t in enumerate(tensors):
+            t = t.contiguous()
+            r = None
+            if refs is not None:
+                r = refs[i]
+                if r.dtype != t.dtype or r.numel() != t.numel() or r.device != t.device or not r.is_contiguous():
+                    raise ValueError("index_fingerprint_match: a reference tensor does not have the geometry of its index tensor")
+            c = torch.empty_like(t) if copy else None
+            check(lib.tsgu_index_fingerprint_match(itype_of(t), t.numel(), _p(t), _p(r) if r is not None else None,
+                                                   _p(c) if c is not None else None, out[i].data_ptr(), 1, dev.index, _stream(dev)),
+                  "tsgu_index_fingerprint_match")
+            if copy:
+                copies.append(c)
+    return out, copies
 
 
 def coldot(X, Y):

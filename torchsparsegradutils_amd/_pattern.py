@@ -52,6 +52,14 @@ def wait_for_plans() -> None:
     _backend.poll_errors(block=True)     # deferred device-side error words (lazy triangular-solve checks), if any
 
 
+def _wait_quietly(fut) -> None:
+    """Join an asynchronous plan build without re-raising what it raised."""
+    try:
+        fut.result()
+    except Exception:  # noqa: BLE001
+        pass
+
+
 class _Core:
     """Everything derived from one sparsity pattern (shared by all RowGather views of it, owned by the cache).
     Holds only tensors this module allocated — never the caller's index tensors — so that dropping the sparse
@@ -60,7 +68,7 @@ class _Core:
     __slots__ = ("t", "has_diag", "rows", "packs", "pending", "uses", "flat", "own", "fp", "geom", "__weakref__")
 
     def __init__(self):
-        self.fp = None      # [tensors][2] int64 on the device: content fingerprint of the caller's index tensors (see _core_for)
+        self.fp = None      # [tensors][2] int64 on the device: content fingerprint of the index tensors (see _core_for), until read to the host
         self.geom = None    # (kind, shape, geometry of the index tensors): what a fingerprint is compared within
         self.t: Optional[RowGather] = None
         self.has_diag: Optional[bool] = None
@@ -82,7 +90,11 @@ class _Core:
 
         add(self.rows)
         for t in self.own.values():
-            add(t)  # (non-tensor entries are ignored)
+            if isinstance(t, tuple):
+                for u in t:
+                    add(u)  # (the core's copy of its index tensors)
+            else:
+                add(t)  # (non-tensor entries are ignored)
         for rp in self.packs.values():
             if rp is not None:
                 total += rp.plan_bytes()
@@ -128,7 +140,7 @@ class RowGather:
         if key not in packs:
             fut = self.core.pending.get(key)
             if fut is not None:           # an asynchronous build is in flight: wait for it rather than build twice
-                fut.result()
+                _wait_quietly(fut)        # (a failed build is reported — as a warning — by _plan_async, which pins the pattern plan-free)
                 return self.rowpack_plan_async(rows_per_block, limits, explicit_slots, group)
             packs[key] = self._build_rowpack(rows_per_block, limits, explicit_slots, group)
         return packs[key]
@@ -154,7 +166,7 @@ class RowGather:
         if key not in packs:
             fut = self.core.pending.get(key)
             if fut is not None:
-                fut.result()
+                _wait_quietly(fut)        # (see rowpack_plan: the worker's exception must not reach the caller's step)
                 return self.tile_plan(geo, asynchronous=True)
             packs[key] = self._build_tile(geo)
         return packs[key]
@@ -719,15 +731,22 @@ def _evict(key) -> None:
 # A caller that rebuilds its index tensors every step (`torch.sparse_csr_tensor(crow.clone(), col.clone(), …)`) misses the identity
 # key every time: without more, every step would pay the pattern analysis (~11 ms at C2) instead of the 0.7 ms plan-free step.
 # The reference has no per-pattern state and so no such cliff (sparse_matmul.py:141-163).  On a miss whose geometry (layout, shape,
-# index dtype, nnz, device) equals a live entry's, the CONTENT of the index tensors is compared through a 128-bit fingerprint
-# (one pass over the indices on the device, `tsgu_index_fingerprint`; the comparison is one host read) and the live entry's core is
-# adopted under the new key.  Geometries that keep arriving with NEW content are marked volatile after FRESH_LIMIT misses in a row:
-# their plans then wait until a pattern has come back (`_Core.own["volatile"]`, read by _ops._lattice_plan).
+# index dtype, nnz, device) equals a live entry's, the CONTENT of the index tensors is compared with that entry's — EXACTLY: every
+# core keeps its own copy of the index tensors it was built from (`own["index_copy"]`, written by the pass that fingerprints them),
+# and one pass over the new tensors (`tsgu_index_fingerprint_match`) yields their 128-bit fingerprint AND whether they equal the most
+# recently used candidate's copy; the answer is one host read.  Equal → the live core is adopted under the new key.  Otherwise the
+# fingerprint selects among the other candidates, and the selected one is compared exactly before it is adopted: equal fingerprints
+# alone never adopt (a collision would silently compute with another matrix' pattern).  Geometries that keep arriving with NEW content
+# are marked volatile after FRESH_LIMIT misses in a row: their plans then wait until a pattern has come back
+# (`_Core.own["volatile"]`, read by _ops._lattice_plan).  What a core's fingerprint words and copies were written by is recorded
+# as an event: a miss on another stream waits for it before it reads them.
 FINGERPRINT = _os.environ.get("TSGU_PATTERN_FINGERPRINT", "1") != "0"
 FINGERPRINT_MIN = 1 << 16
+# index tensors above this many bytes are not copied (and their patterns never adopted): the copy lives as long as the cache entry
+INDEX_COPY_MAX_BYTES = int(_os.environ.get("TSGU_INDEX_COPY_MAX_BYTES", str(2 << 30)))
 FRESH_LIMIT = 3
 _FRESH = {}
-STATS = {"adopted": 0, "fingerprints": 0, "volatile": 0}
+STATS = {"adopted": 0, "fingerprints": 0, "volatile": 0, "verified": 0, "collisions": 0}
 
 
 _READ_BUFS = threading.local()
@@ -753,15 +772,59 @@ def _read_words(t: torch.Tensor) -> list:
     return host[:n].tolist()
 
 
-def _fingerprint(tensors):
+def _fingerprint_applies(tensors) -> bool:
     if not FINGERPRINT or not all(t.is_cuda and t.dtype in (torch.int32, torch.int64) for t in tensors):
-        return None
-    if sum(t.numel() for t in tensors) < FINGERPRINT_MIN or torch.cuda.is_current_stream_capturing():
-        return None
+        return False
+    total = sum(t.numel() for t in tensors)
+    if total < FINGERPRINT_MIN or sum(t.numel() * t.element_size() for t in tensors) > INDEX_COPY_MAX_BYTES:
+        return False
+    return not torch.cuda.is_current_stream_capturing()
+
+
+def _after_its_writer(core: _Core, stream) -> None:
+    """Order `stream` behind the launches that wrote the core's fingerprint words and index copies (queued on another stream)."""
+    ev = core.own.get("fp_event")
+    if ev is not None and core.own.get("fp_stream") != stream.cuda_stream:
+        stream.wait_event(ev)
+
+
+def _match_candidates(tensors, uniq):
+    """(adopted core or None, fingerprint words of `tensors` as a flat host list).  One pass over the tensors + one host read when
+    they equal the most recently used candidate; one more pass + read per candidate the fingerprint selects otherwise."""
     from . import _backend
 
+    dev = tensors[0].device
+    cur = torch.cuda.current_stream(dev)
+    first = uniq[0]
+    _after_its_writer(first, cur)
     STATS["fingerprints"] += 1
-    return _backend.index_fingerprint(*tensors)
+    out, _ = _backend.index_fingerprint_match(tensors, refs=first.own["index_copy"])
+    # ONE device-to-host copy: the new words and the fingerprints of the candidates whose words are not on the host yet
+    missing = [c for c in uniq if "fp_host" not in c.own]
+    for c in missing:
+        _after_its_writer(c, cur)
+    k = len(tensors)
+    stacked = torch.cat([out.reshape(-1)] + [c.fp.reshape(-1) for c in missing]) if missing else out.reshape(-1)
+    flat = _read_words(stacked)
+    mine = flat[:3 * k]
+    for i, c in enumerate(missing):
+        c.own["fp_host"] = flat[3 * k + 2 * k * i:3 * k + 2 * k * (i + 1)]
+    words = [w for j in range(k) for w in mine[3 * j:3 * j + 2]]
+    STATS["verified"] += 1
+    if all(mine[3 * j + 2] == 0 for j in range(k)):
+        return first, words
+    if first.own["fp_host"] == words:
+        STATS["collisions"] += 1          # equal fingerprints, different content: exactly what the comparison is for
+    for c in uniq[1:]:
+        if c.own["fp_host"] != words:
+            continue
+        _after_its_writer(c, cur)
+        out2, _ = _backend.index_fingerprint_match(tensors, refs=c.own["index_copy"])
+        STATS["verified"] += 1
+        if all(w == 0 for w in _read_words(out2[:, 2])):
+            return c, words
+        STATS["collisions"] += 1
+    return None, words
 
 
 def _core_for(kind: str, tensors, shape) -> _Core:
@@ -774,39 +837,44 @@ def _core_for(kind: str, tensors, shape) -> _Core:
                 _FRESH.pop(core.geom, None)
             return core
     geom = (kind, tuple(shape)) + tuple((t.shape, t.dtype, t.device) for t in tensors)
-    fp = _fingerprint(tensors)
-    adopted = None
-    if fp is not None:
+    adopted, words, live = None, None, []
+    applies = _fingerprint_applies(tensors)
+    if applies:
         with _CACHE_LOCK:
-            live = [c for c in _CACHE.values() if c.geom == geom and c.fp is not None]
-        uniq = list({id(c): c for c in reversed(live)}.values())
+            live = [c for c in _CACHE.values() if c.geom == geom and "index_copy" in c.own]
+        uniq = list({id(c): c for c in reversed(live)}.values())          # most recently used first
         if uniq:
-            # ONE device-to-host copy (the only host read, and only when a live entry has this geometry): the new fingerprint and
-            # those of the candidates whose words are not on the host yet
-            missing = [c for c in uniq if "fp_host" not in c.own]
-            stacked = torch.stack([fp] + [c.fp for c in missing]) if missing else fp.unsqueeze(0)
-            flat = _read_words(stacked)
-            per = len(flat) // (len(missing) + 1)
-            words = [flat[i * per:(i + 1) * per] for i in range(len(missing) + 1)]
-            for c, w in zip(missing, words[1:]):
-                c.own["fp_host"] = w
-            for c in uniq:
-                if c.own["fp_host"] == words[0]:
-                    adopted = c
-                    break
+            adopted, words = _match_candidates(tensors, uniq)
+    if adopted is None:
+        core = _Core()
+        core.geom = geom
+        if applies:
+            # the core's own copy of the content it is built from (what later misses are compared with) — and its fingerprint, by the
+            # same pass, unless the candidates' comparison has produced the words already
+            from . import _backend
+
+            cur = torch.cuda.current_stream(tensors[0].device)
+            if words is None:
+                STATS["fingerprints"] += 1
+                out, copies = _backend.index_fingerprint_match(tensors, copy=True)
+                core.fp = out[:, :2].contiguous()
+            else:
+                copies = [t.contiguous().clone() for t in tensors]
+                core.own["fp_host"] = words
+            core.own["index_copy"] = tuple(copies)
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            core.own["fp_event"], core.own["fp_stream"] = ev, cur.cuda_stream
     with _CACHE_LOCK:
         if adopted is not None:
             core = adopted
             STATS["adopted"] += 1
             _FRESH.pop(geom, None)
-        else:
-            core = _Core()
-            core.fp, core.geom = fp, geom
-            if fp is not None and live:
-                fresh = _FRESH[geom] = _FRESH.get(geom, 0) + 1
-                if fresh >= FRESH_LIMIT:
-                    core.own["volatile"] = 0
-                    STATS["volatile"] += 1
+        elif applies and live:
+            fresh = _FRESH[geom] = _FRESH.get(geom, 0) + 1
+            if fresh >= FRESH_LIMIT:
+                core.own["volatile"] = 0
+                STATS["volatile"] += 1
         _CACHE[key] = core
         for t in tensors:
             weakref.finalize(t.untyped_storage(), _evict, key)

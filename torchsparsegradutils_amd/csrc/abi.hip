@@ -20,14 +20,19 @@ int coo_sddmm_dispatch_bf16(int, const CooSddmmParams&, hipStream_t);
 using namespace tsgu;
 
 // 128-bit content fingerprint of an index array (see include/tsgu_hip.h): position-weighted sums in wrapping 64-bit integer
-// arithmetic — integer addition commutes, so the atomics of different workgroups give the same words in any order.
-template <typename I>
-__global__ __launch_bounds__(256) void tsgu_fingerprint_kernel(const I* __restrict__ x, int64_t n, unsigned long long* __restrict__ out) {
+// arithmetic — integer addition commutes, so the atomics of different workgroups give the same words in any order.  The fingerprint
+// only SELECTS a candidate pattern; what decides an adoption is the exact comparison (CMP: the number of elements that differ from
+// `ref` is added to out[2]) the same pass makes.  COPY: the pass also writes the array to `copy` (the cache's own copy, what later
+// comparisons read).
+template <typename I, bool CMP, bool COPY>
+__global__ __launch_bounds__(256) void tsgu_fingerprint_kernel(const I* __restrict__ x, const I* __restrict__ ref, I* __restrict__ copy,
+                                                                int64_t n, unsigned long long* __restrict__ out) {
     constexpr int V = 16 / (int)sizeof(I);               // indices per 16-byte load
     struct alignas(16) Vec {
         I v[V];
     };
     unsigned long long h1 = 0, h2 = 0;
+    unsigned int diff = 0;
     // position weights from 32-bit multiplicative hashes of the index (a 64-bit `%` costs ~100 instructions per element: the
     // first version of this kernel took 0.3 ms for C2's 27 M column indices)
     auto add = [&](int64_t k, I xv) {
@@ -40,39 +45,84 @@ __global__ __launch_bounds__(256) void tsgu_fingerprint_kernel(const I* __restri
     // 16-byte loads, four of them in flight per thread: with one 4-byte load per thread and trip the second version was bound by
     // memory latency (0.27 ms for 108 MB = 0.4 TB/s; the whole step of a caller with fresh index tensors waits for this kernel)
     const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
-    const int64_t nv = reinterpret_cast<uintptr_t>(x) % 16 == 0 ? n / V : 0;
+    bool vec = reinterpret_cast<uintptr_t>(x) % 16 == 0;
+    if (CMP) vec = vec && reinterpret_cast<uintptr_t>(ref) % 16 == 0;
+    if (COPY) vec = vec && reinterpret_cast<uintptr_t>(copy) % 16 == 0;
+    const int64_t nv = vec ? n / V : 0;
     const Vec* const xv = reinterpret_cast<const Vec*>(x);
+    const Vec* const rv = reinterpret_cast<const Vec*>(ref);
+    Vec* const cv = reinterpret_cast<Vec*>(copy);
     int64_t c = gtid;
     for (; c + 3 * stride < nv; c += 4 * stride) {
-        Vec a[4];
+        Vec a[4], r[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) a[u] = xv[c + u * stride];
+        if (CMP) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) r[u] = rv[c + u * stride];
+        }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
 #pragma unroll
-            for (int j = 0; j < V; ++j) add((c + u * stride) * V + j, a[u].v[j]);
+            for (int j = 0; j < V; ++j) {
+                add((c + u * stride) * V + j, a[u].v[j]);
+                if (CMP) diff += a[u].v[j] != r[u].v[j];
+            }
+            if (COPY) cv[c + u * stride] = a[u];
         }
     }
     for (; c < nv; c += stride) {
         const Vec a = xv[c];
 #pragma unroll
         for (int j = 0; j < V; ++j) add(c * V + j, a.v[j]);
+        if (CMP) {
+            const Vec r = rv[c];
+#pragma unroll
+            for (int j = 0; j < V; ++j) diff += a.v[j] != r.v[j];
+        }
+        if (COPY) cv[c] = a;
     }
-    for (int64_t k = nv * V + gtid; k < n; k += stride) add(k, x[k]);      // the tail (everything, for a pointer that is not 16-byte aligned)
+    for (int64_t k = nv * V + gtid; k < n; k += stride) {      // the tail (everything, for pointers that are not 16-byte aligned)
+        const I a = x[k];
+        add(k, a);
+        if (CMP) diff += a != ref[k];
+        if (COPY) copy[k] = a;
+    }
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {
         h1 += __shfl_xor(h1, m, 64);
         h2 += __shfl_xor(h2, m, 64);
     }
-    // ONE pair of atomics per workgroup: same-address 64-bit atomics retire at ~80 M/s, and with a pair per wave of 2048 workgroups
+    const unsigned long long wave_diff = CMP ? __popcll(__ballot(diff != 0)) : 0;      // (a count of lanes: non-zero iff anything differs)
+    // ONE set of atomics per workgroup: same-address 64-bit atomics retire at ~80 M/s, and with a pair per wave of 2048 workgroups
     // the 16 384 atomics (0.2 ms) — not the 108 MB — were the kernel's duration
-    __shared__ unsigned long long part[2][4];
-    if ((threadIdx.x & 63) == 0) part[0][threadIdx.x >> 6] = h1, part[1][threadIdx.x >> 6] = h2;
+    __shared__ unsigned long long part[3][4];
+    if ((threadIdx.x & 63) == 0) part[0][threadIdx.x >> 6] = h1, part[1][threadIdx.x >> 6] = h2, part[2][threadIdx.x >> 6] = wave_diff;
     __syncthreads();
     if (threadIdx.x == 0) {
         atomicAdd(out, part[0][0] + part[0][1] + part[0][2] + part[0][3]);
         atomicAdd(out + 1, part[1][0] + part[1][1] + part[1][2] + part[1][3]);
+        if (CMP) {
+            const unsigned long long d = part[2][0] + part[2][1] + part[2][2] + part[2][3];
+            if (d) atomicAdd(out + 2, d);
+        }
     }
+}
+
+template <typename I>
+static void fingerprint_launch(unsigned blocks, hipStream_t s, const void* x, const void* ref, void* copy, int64_t n, void* out) {
+    const I* const xi = static_cast<const I*>(x);
+    const I* const ri = static_cast<const I*>(ref);
+    I* const ci = static_cast<I*>(copy);
+    unsigned long long* const o = static_cast<unsigned long long*>(out);
+    if (ref && copy)
+        hipLaunchKernelGGL((tsgu_fingerprint_kernel<I, true, true>), dim3(blocks), dim3(256), 0, s, xi, ri, ci, n, o);
+    else if (ref)
+        hipLaunchKernelGGL((tsgu_fingerprint_kernel<I, true, false>), dim3(blocks), dim3(256), 0, s, xi, ri, ci, n, o);
+    else if (copy)
+        hipLaunchKernelGGL((tsgu_fingerprint_kernel<I, false, true>), dim3(blocks), dim3(256), 0, s, xi, ri, ci, n, o);
+    else
+        hipLaunchKernelGGL((tsgu_fingerprint_kernel<I, false, false>), dim3(blocks), dim3(256), 0, s, xi, ri, ci, n, o);
 }
 
 extern "C" {
@@ -126,22 +176,31 @@ int tsgu_device_copy(const void* src, void* dst, int64_t bytes, int device, void
     return check_launch();
 }
 
-int tsgu_index_fingerprint(int itype, int64_t n, const void* x, void* out2, int accumulate, int device, void* stream) {
-    if (n < 0 || !out2 || (n > 0 && !x)) return TSGU_ERR_BAD_ARG;
+int tsgu_index_fingerprint_match(int itype, int64_t n, const void* x, const void* ref, void* copy, void* out3, int accumulate,
+                                 int device, void* stream) {
+    if (n < 0 || !out3 || (n > 0 && !x)) return TSGU_ERR_BAD_ARG;
     if (itype != TSGU_I32 && itype != TSGU_I64) return TSGU_ERR_BAD_DTYPE;
     if (const int rc = set_device(device)) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (!accumulate && hipMemsetAsync(out2, 0, 16, s) != hipSuccess) return TSGU_ERR_RUNTIME;
+    if (!accumulate && hipMemsetAsync(out3, 0, 24, s) != hipSuccess) return TSGU_ERR_RUNTIME;
     if (n == 0) return TSGU_OK;
     const int64_t want = (n + 256 * 16 - 1) / (256 * 16);
     const unsigned blocks = (unsigned)(want < 512 ? want : 512);      // (two workgroups per CU: 64 bytes x 512 threads in flight on each)
     if (itype == TSGU_I32)
-        hipLaunchKernelGGL(tsgu_fingerprint_kernel<int32_t>, dim3(blocks), dim3(256), 0, s, static_cast<const int32_t*>(x), n,
-                           static_cast<unsigned long long*>(out2));
+        fingerprint_launch<int32_t>(blocks, s, x, ref, copy, n, out3);
     else
-        hipLaunchKernelGGL(tsgu_fingerprint_kernel<int64_t>, dim3(blocks), dim3(256), 0, s, static_cast<const int64_t*>(x), n,
-                           static_cast<unsigned long long*>(out2));
+        fingerprint_launch<int64_t>(blocks, s, x, ref, copy, n, out3);
     return check_launch();
+}
+
+int tsgu_index_fingerprint(int itype, int64_t n, const void* x, void* out2, int accumulate, int device, void* stream) {
+    if (n < 0 || !out2 || (n > 0 && !x)) return TSGU_ERR_BAD_ARG;
+    if (itype != TSGU_I32 && itype != TSGU_I64) return TSGU_ERR_BAD_DTYPE;
+    if (!accumulate) {
+        if (const int rc = set_device(device)) return rc;
+        if (hipMemsetAsync(out2, 0, 16, static_cast<hipStream_t>(stream)) != hipSuccess) return TSGU_ERR_RUNTIME;
+    }
+    return tsgu_index_fingerprint_match(itype, n, x, nullptr, nullptr, out2, 1, device, stream);      // (no ref: out2[2] is never touched)
 }
 
 int64_t tsgu_spmm_num_blocks(int vtype, int64_t n_rows, int64_t nnz_per_item, int64_t p, int64_t max_row_nnz) {

@@ -116,14 +116,17 @@ def _solve(plan: _pt.RowGather, values, rhs, upper: bool, unit: bool, transpose:
 # third solve.  Deep dependency chains (C3: 2 673 levels) are fastest with ONE workgroup per CU — every extra polling wave lengthens
 # the hop; shallow patterns (the reference's published shape, benchmarks/sparse_triangular_solve_rand.py: one random off-diagonal
 # entry per row) are bound by the rows in flight and want all eight.  The solution does not depend on it (every row sums its own
-# entries in a fixed order), so the choice is speed only; TSGU_SPTRSM_TUNE=0 keeps one workgroup per CU.
+# entries in a fixed order), so the choice is speed only; TSGU_SPTRSM_TUNE=0 keeps one workgroup per CU.  The trial is a ONE-OFF host
+# synchronisation inside that third forward solve (12 extra solves, each awaited); it is skipped under
+# torch.use_deterministic_algorithms (nothing is chosen by a wall clock there — as for the lattice configurations, _ops._lattice_cfg)
+# and inside a stream capture.
 SWEEP_TUNE = os.environ.get("TSGU_SPTRSM_TUNE", "1") != "0"
 SWEEP_TUNE_AFTER = 2
 SWEEP_WIDTHS = (1, 2, 4, 8)
 
 
 def _sweep_width(pt: _pt.RowGather, lower: bool, unit: bool, rhs: torch.Tensor, run) -> int:
-    if not SWEEP_TUNE or pt.n_rows < 4096:
+    if not SWEEP_TUNE or pt.n_rows < 4096 or torch.are_deterministic_algorithms_enabled():
         return 1
     memo = pt.core.own.get("sweep_width")
     if memo is None:
