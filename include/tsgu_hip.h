@@ -252,19 +252,22 @@ int tsgu_csr_sddmm_rowpack(int vtype, int itype, int64_t n_rows, int64_t n_cols,
  * references — its tile — are copied to LDS by 16-byte LDS-DMA one block ahead of the walk (double buffer), next to the block's
  * slice of the value array and ONE BYTE per entry naming the entry's dense row inside the tile; the walk reads a byte, a value and
  * 16 bytes of LDS per entry and keeps the accumulators in registers.  Plan (value independent, built once per pattern):
- *   desc [n_blocks + 4][4] int32 {u0, U, e0, E}: block b's tile is ucol[u0 .. u0 + U) (ascending distinct columns, padded to a multiple
- *                          of 8 by repeating the last one; u0 a multiple of 8), its entries are e0 .. e0 + E of the walked pattern;
- *                          four trailing all-zero descriptors (the pipeline reads ahead)
+ *   desc [n_blocks + 4][8] int32 {u0, U, e0, E, c0, NC, 0, 0}: block b's tile is ucol[u0 .. u0 + U) (ascending distinct columns, padded to
+ *                          a multiple of 8 by repeating the last one; u0 a multiple of 8), its entries are e0 .. e0 + E of the walked
+ *                          pattern, its value chunks (below) c0 .. c0 + NC; four trailing all-zero descriptors (the pipeline reads ahead)
  *   ucol                   int32 column numbers, U <= max_union per block
  *   lidx [nnz + 16]        uint8: position of entry k's column inside its block's tile
  *   rptr [n_rows + 1]      int32 row pointer of the walked pattern
- *   perm [nnz], slot [nnz] optional (both or neither; NULL: values in walked order) — the plan of the TRANSPOSED pattern walks A's own
- *                          values (Aᵀ·G, sparse_matmul.py:229).  Per block (entries e0 .. e0 + E), in ascending order of the position
- *                          in the value array: perm[e0 + i] int32 = that position, slot[e0 + i] uint16 = the entry of the block
- *                          (0 .. E - 1) whose value it is.  The kernel fetches a block's values in this SOURCE order (neighbouring
- *                          lanes read neighbouring values) and scatters them into the block's value buffer in LDS.
- * fp32 values, p a multiple of 32 up to 1024 (one launch per tile of 32 columns = 128 bytes of a dense row; the SDDMM adds the dots of
- * the later tiles to the first), 16-byte aligned dense operands, 2-D operands below 4 GiB.  Sums run in ascending
+ *   cpos, cslot            optional (both or neither; NULL: values in walked order) — the plan of the TRANSPOSED pattern walks A's own
+ *                          values (Aᵀ·G, sparse_matmul.py:229).  A block's values are fetched as CHUNKS of four consecutive values of
+ *                          the value array, in ascending order of position: cpos[q] int32 = position of the chunk's first value
+ *                          (cpos[q] + 4 <= nnz), cslot[q][0..3] uint16 = the entry of the block (0 .. E - 1) each of the four values
+ *                          belongs to, 0xffff = none.  At most 1024 chunks per block.  The kernel loads a chunk with one 16-byte
+ *                          load per lane (neighbouring lanes on neighbouring chunks) and scatters its values into the block's value
+ *                          buffer in LDS.
+ * fp32 values, p a multiple of 32 up to 1024 — ONE launch whatever the width: the pipeline's steps are (block, tile of 32 columns = 128
+ * bytes of a dense row) pairs, a block's values / entry bytes / row pointers are staged once, and the SDDMM adds up the dots of a
+ * block's column tiles on chip.  16-byte aligned dense operands, 2-D operands below 4 GiB.  Sums run in ascending
  * entry order of the walked pattern: the same bits as tsgu_csr_spmm / tsgu_csr_sddmm.  A row never touches a dense row it does not
  * reference.  tsgu_tile_geometry gives the limits a plan has to meet (or a negative status for an unsupported (vtype, p)).
  */
@@ -276,8 +279,8 @@ typedef struct tsgu_tile_plan {
     const void* ucol;
     const void* lidx;
     const void* rptr;
-    const void* perm;
-    const void* slot;
+    const void* cpos;
+    const void* cslot;
 } tsgu_tile_plan;
 
 int tsgu_tile_geometry(int vtype, int64_t p, int* rows_per_block, int* max_union, int* max_entries);

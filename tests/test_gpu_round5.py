@@ -251,7 +251,7 @@ def test_tile_kernels_equal_the_plan_free_kernels_bit_for_bit(name, p):
     plan = _pattern.RowGather(crow, col, n, n)
     tp = plan.tile_plan(geo)
     tt = plan.transposed.tile_plan(geo)
-    assert tp is not None and tt is not None and tt.perm is not None, "the pattern should qualify for row-block tiles"
+    assert tp is not None and tt is not None and tt.cpos is not None, "the pattern should qualify for row-block tiles"
     C = be.csr_spmm_tile(tp, val, B)
     gA = be.csr_sddmm_tile(tp, Gd, B)
     gB = be.csr_spmm_tile(tt, val, Gd)
@@ -375,8 +375,9 @@ def test_tile_step_through_the_cpp_host_path(name, p, monkeypatch):
     assert fast[1].crow_indices().data_ptr() == crow.data_ptr() and fast[1].col_indices().data_ptr() == col.data_ptr()
 
 
-def test_wide_operands_over_few_blocks_stay_off_the_tiles(monkeypatch):
-    """Operands wider than a column tile on a pattern of few blocks take the plan-free / row-pair kernels (_ops.TILE_WIDE_MIN_BLOCKS)."""
+def test_wide_operands_take_the_tiles_in_one_launch(monkeypatch):
+    """Round 6: operands wider than a column tile run in ONE launch on the tile kernels whatever the number of blocks (round 5 kept them
+    off the tiles below 8192 blocks); `_ops.TILE_WIDE_MIN_BLOCKS` can restore such a threshold for A/B measurements."""
     from torchsparsegradutils_amd import _ops, _pattern
 
     monkeypatch.setattr(_ops, "PACK_MIN_NNZ", 1)
@@ -387,10 +388,12 @@ def test_wide_operands_over_few_blocks_stay_off_the_tiles(monkeypatch):
     plan = _pattern.RowGather(crow, col, n, n)
     for _ in range(3):
         plan.seen_enough(1)
+    assert _ops.TILE_WIDE_MIN_BLOCKS == 0
     assert _ops._tile_for(plan, torch.zeros(n, 32, device=DEV)) is not None
-    assert _ops._tile_for(plan, torch.zeros(n, 64, device=DEV)) is None
-    monkeypatch.setattr(_ops, "TILE_WIDE_MIN_BLOCKS", 0)
     assert _ops._tile_for(plan, torch.zeros(n, 64, device=DEV)) is not None
+    assert _ops._tile_for(plan, torch.zeros(n, 128, device=DEV)) is not None
+    monkeypatch.setattr(_ops, "TILE_WIDE_MIN_BLOCKS", 8192)
+    assert _ops._tile_for(plan, torch.zeros(n, 64, device=DEV)) is None
 
 
 # ---- bf16: the fp32-accumulated result BEFORE the final rounding (SURVEY §8c form (i)) ---------------------------------------------

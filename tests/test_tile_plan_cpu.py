@@ -13,12 +13,12 @@ def _check(crow, col, tp, R):
     n = crow.numel() - 1
     cr, co = crow.numpy().astype(np.int64), col.numpy().astype(np.int64)
     desc, ucol, lidx = tp.desc.numpy(), tp.ucol.numpy(), tp.lidx.numpy()
-    assert tp.n_blocks == (n + R - 1) // R and desc.shape == (tp.n_blocks + 4, 4) and not desc[tp.n_blocks:].any()
+    assert tp.n_blocks == (n + R - 1) // R and desc.shape == (tp.n_blocks + 4, 8) and not desc[tp.n_blocks:].any()
     assert lidx.size == co.size + 16 and np.array_equal(tp.rptr.numpy(), cr)
     for b in range(tp.n_blocks):
         r0, r1 = b * R, min(n, (b + 1) * R)
         ents = co[cr[r0]:cr[r1]]
-        u0, U, e0, E = desc[b]
+        u0, U, e0, E = desc[b][:4]
         assert e0 == cr[r0] and E == cr[r1] - cr[r0] and U % 8 == 0 and u0 % 8 == 0
         if E == 0:
             continue
@@ -29,25 +29,41 @@ def _check(crow, col, tp, R):
         assert (lst[lidx[e0:e0 + E]] == ents).all()
 
 
+def _check_chunks(tt, want):
+    """The values of a transposed block as 16-byte chunks of A's value array: per block the chunks ascend, stay inside the array,
+    and their slots name every entry of the block exactly once — chunk position + lane = the transposed pattern's own permutation."""
+    cpos, cslot = tt.cpos.numpy().astype(np.int64), tt.cslot.numpy().astype(np.int64) & 0xFFFF
+    assert cslot.shape == (cpos.size, 4) and (cpos >= 0).all() and (cpos + 4 <= tt.nnz).all()
+    used = 0
+    for b in range(tt.n_blocks):
+        _, _, e0, E, c0, NC = tt.desc[b].tolist()[:6]
+        assert c0 == used and NC <= _tile.MAX_CHUNKS
+        used += NC
+        pos, sl = cpos[c0:c0 + NC], cslot[c0:c0 + NC]
+        assert (np.diff(pos) > 0).all()
+        got = np.full(E, -1, dtype=np.int64)
+        for j in range(4):
+            live = sl[:, j] != 0xFFFF
+            assert (got[sl[live, j]] == -1).all()
+            got[sl[live, j]] = pos[live] + j
+        assert np.array_equal(got, want[e0:e0 + E])
+        if E:
+            assert NC <= (E + 3) // 4 + int(tt.desc[b, 1])          # (a run of L values: ceil(L / 4) chunks; one run per source row)
+    assert used == cpos.size
+
+
 def test_tile_plan_of_a_brick_numbered_mesh_and_its_transpose():
     crow, col = synthetic.mesh27_blocked(12, 8, 16, 4, torch.int32)
     n = crow.numel() - 1
     g = _pattern.RowGather(crow, col, n, n)
     tp = g.tile_plan((64, 224, 2048))
-    assert tp is not None and tp.perm is None and tp.reuse > 6 and int(tp.desc[:, 1].max()) <= 216
+    assert tp is not None and tp.cpos is None and tp.reuse > 6 and int(tp.desc[:, 1].max()) <= 216
     _check(crow, col, tp, 64)
     t = g.transposed
     tt = t.tile_plan((64, 224, 2048))
-    assert tt is not None and tt.perm is not None and tt.slot is not None
+    assert tt is not None and tt.cpos is not None and tt.cslot is not None
     _check(t.crow, t.col, tt, 64)
-    # the values of a transposed block in SOURCE order: per block the positions in A's value array ascending, and for each the entry of
-    # the block it belongs to — together the transposed pattern's own permutation
-    src, slot, want = tt.perm.numpy().astype(np.int64), tt.slot.numpy().astype(np.int64) & 0xFFFF, t.perm.numpy().astype(np.int64)
-    for b in range(tt.n_blocks):
-        _, _, e0, E = tt.desc[b].tolist()
-        s_, d_ = src[e0:e0 + E], slot[e0:e0 + E]
-        assert (np.diff(s_) > 0).all() and np.array_equal(np.sort(d_), np.arange(E))
-        assert np.array_equal(want[e0:e0 + E][d_], s_)
+    _check_chunks(tt, t.perm.numpy().astype(np.int64))
     assert g.tile_plan((64, 224, 2048)) is tp          # cached with the pattern
 
 
@@ -67,6 +83,14 @@ def test_tile_plan_with_ragged_and_empty_rows_int64_and_a_partial_last_block():
     tp = _tile.build_tile_plan(crow, cols, n, n, 64, 224, 2048)
     assert tp is not None and tp.rptr.dtype == torch.int32
     _check(crow, cols, tp, 64)
+    # … and its transposed pattern (values read through a permutation): chunks whose last one is pulled back inside the value array
+    g = _pattern.RowGather(crow, cols, n, n)
+    t = g.transposed
+    tt = _tile.build_tile_plan(t.crow, t.col, n, n, 64, 224, 2048, perm=t.perm, reuse_min=0.0)
+    assert tt is not None
+    _check(t.crow, t.col, tt, 64)
+    _check_chunks(tt, t.perm.numpy().astype(np.int64))
+    assert int(tt.cpos.max()) == tt.nnz - 4
 
 
 def test_patterns_that_do_not_qualify():

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--reps", type=int, default=30)
     ap.add_argument("--cold", action="store_true")
     ap.add_argument("--pattern", default="mesh27_blocked")
+    ap.add_argument("--rhs", type=int, default=32)
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     if a.pattern == "mesh27_blocked":
@@ -30,7 +31,7 @@ def main():
         crow, col, _ = synthetic.banded_lower(a.grid[0] * a.grid[1] * a.grid[2], per_row=18, band=4096, device=dev)
     else:
         raise SystemExit("unknown pattern")
-    n, nnz, p = crow.numel() - 1, col.numel(), 32
+    n, nnz, p = crow.numel() - 1, col.numel(), a.rhs
     val = torch.randn(nnz, device=dev)
     B = torch.randn(n, p, device=dev)
     G = torch.randn(n, p, device=dev)

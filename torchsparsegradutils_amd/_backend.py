@@ -448,13 +448,13 @@ def _tile_struct(tp):
         from ._tile import TilePlanStruct
 
         st = TilePlanStruct(tp.n_rows, tp.n_cols, tp.nnz, tp.n_blocks, tp.rows_per_block, tp.max_union, tp.max_entries, 0, _p(tp.desc),
-                            _p(tp.ucol), _p(tp.lidx), _p(tp.rptr), _p(tp.perm), _p(tp.slot))
+                            _p(tp.ucol), _p(tp.lidx), _p(tp.rptr), _p(tp.cpos), _p(tp.cslot))
         tp._cstruct = st
     return ctypes.addressof(st)
 
 
 def csr_spmm_tile(tp, val, B):
-    """C = A·B (a plan with `perm`: Aᵀ·G through A's own values) by the row-block tile walk."""
+    """C = A·B (a plan with value chunks `cpos` / `cslot`: Aᵀ·G through A's own values) by the row-block tile walk."""
     lib = load_library()
     dev = require_device(val, B)
     B = rowmajor(B)

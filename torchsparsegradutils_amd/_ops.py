@@ -37,12 +37,11 @@ PLAN_ASYNC = os.environ.get("TSGU_PLAN_ASYNC", "1") == "1"
 # FEM matrices): a block's distinct dense rows are staged in LDS one block ahead of the walk.  Chosen before the row pairs when the
 # pattern qualifies (every block's tile fits, entries share dense rows); TSGU_ENABLE_TILE=0 disables.
 ENABLE_TILE = os.environ.get("TSGU_ENABLE_TILE", "1") == "1"
-# Operands wider than one column tile (32 fp32 columns) run one launch per tile, each re-reading the plan and the values.  With few
-# blocks per resident workgroup the walk's two-block pipeline never fills and the plan-free kernels win (brick mesh, step on one
-# box: 1 950 blocks: 0.060 / 0.122 / 0.238 ms on tiles against 0.072 / 0.114 / 0.198 plan-free at 32 / 64 / 128 columns; 15 625
-# blocks at 128 columns: 1.59 against 1.89 ms)
+# Operands wider than one column tile (32 fp32 columns) run in ONE launch (round 6: the pipeline's steps are (block, column tile) pairs,
+# a block's values / entry bytes / row pointers are staged once).  Round 5 ran one launch per column tile and kept wide operands over
+# fewer than 8192 blocks on the plan-free kernels; TSGU_TILE_WIDE_MIN_BLOCKS restores such a threshold for A/B measurements.
 TILE_COLUMNS = 32
-TILE_WIDE_MIN_BLOCKS = int(os.environ.get("TSGU_TILE_WIDE_MIN_BLOCKS", "8192"))
+TILE_WIDE_MIN_BLOCKS = int(os.environ.get("TSGU_TILE_WIDE_MIN_BLOCKS", "0"))
 
 
 # Lattice plane-sweep kernels (csrc/lattice_impl.h): patterns that are stencils on a row-major lattice (what the

@@ -20,20 +20,22 @@ import torch
 # stored entries per distinct dense row of a block below which a tile is not worth staging (a 27-point mesh numbered in 4^3 bricks: 8.0;
 # a banded random matrix: ~1.0)
 REUSE_MIN = 2.0
+# value chunks per block the kernels can fetch (csrc/tile_impl.h: kTileCMax)
+MAX_CHUNKS = 1024
 
 
 class TilePlan:
     """Device arrays of one ``tsgu_tile_plan`` (+ its ctypes image, cached by _backend)."""
 
-    __slots__ = ("n_rows", "n_cols", "nnz", "n_blocks", "rows_per_block", "max_union", "max_entries", "desc", "ucol", "lidx", "rptr", "perm",
-                 "slot", "reuse", "_cstruct")
+    __slots__ = ("n_rows", "n_cols", "nnz", "n_blocks", "rows_per_block", "max_union", "max_entries", "desc", "ucol", "lidx", "rptr", "cpos",
+                 "cslot", "reuse", "_cstruct")
 
     def __init__(self, **kw):
         for k in self.__slots__:
             setattr(self, k, kw.get(k))
 
     def plan_bytes(self) -> int:
-        return sum(t.numel() * t.element_size() for t in (self.desc, self.ucol, self.lidx, self.rptr, self.perm, self.slot) if t is not None)
+        return sum(t.numel() * t.element_size() for t in (self.desc, self.ucol, self.lidx, self.rptr, self.cpos, self.cslot) if t is not None)
 
 
 def build_tile_plan(crow: torch.Tensor, col: torch.Tensor, n_rows: int, n_cols: int, rows_per_block: int, max_union: int, max_entries: int,
@@ -78,25 +80,51 @@ def build_tile_plan(crow: torch.Tensor, col: torch.Tensor, n_rows: int, n_cols: 
     ucol[pos] = ukey % n_cols
     lidx = torch.zeros(nnz + 16, dtype=torch.uint8, device=dev)
     lidx[:nnz] = (inv - first[blk]).to(torch.uint8)
-    desc = torch.zeros((nb + 4, 4), dtype=torch.int32, device=dev)
+    desc = torch.zeros((nb + 4, 8), dtype=torch.int32, device=dev)
     desc[:nb, 0] = u0[:-1].to(torch.int32)
     desc[:nb, 1] = padded.to(torch.int32)
     desc[:nb, 2] = e0.to(torch.int32)
     desc[:nb, 3] = (e1 - e0).to(torch.int32)
-    gsrc = gslot = None
+    cpos = cslot = None
     if perm is not None:
         # The walked pattern's values live elsewhere (a transposed pattern read through A's own value array): entry e of the walk is
-        # val[perm[e]].  The kernel fetches a block's values in SOURCE order — `perm` sorted inside every block, so that neighbouring
-        # lanes read neighbouring values (a block of a transposed mesh pattern draws runs of ~8 values from ~200 rows of A: in walk
-        # order every lane of a 4-byte gather touches its own cache line) — and `slot` says where each fetched value goes in the
-        # block's value buffer (its entry number inside the block).
+        # val[perm[e]].  A block of a transposed mesh pattern draws RUNS of consecutive values (one run per source row that touches the
+        # block, ~8 values each) from the value array.  The kernel fetches them as 16-byte CHUNKS in ascending source order — one load per
+        # lane, neighbouring lanes on neighbouring chunks — and `cslot` says which entry of the block each of a chunk's four values is
+        # (0xffff: a value that is not the block's).  Round 5 kept a 4-byte position + a 2-byte slot per ENTRY (6 bytes, 159 MB per
+        # launch at N = 1e6); a chunk record is 12 bytes for ~3.3 entries.
+        if nnz < 4:
+            return None
         perm64 = perm.to(torch.int64)
         order = torch.argsort(blk * nnz + perm64)                        # (perm is a permutation: the keys are distinct; < 2^31 · 2^31)
-        gsrc = perm64[order].to(torch.int32).contiguous()
-        gslot = (order - e0[blk[order]]).to(torch.int16).contiguous()                     # < max_entries <= 2048
+        src = perm64[order]                                              # positions in the value array, ascending inside every block
+        sblk = blk[order]
+        slot = order - e0[sblk]                                          # the entry of its block every fetched value belongs to
+        ar = torch.arange(nnz, device=dev, dtype=torch.int64)
+        new_run = torch.ones(nnz, dtype=torch.bool, device=dev)
+        new_run[1:] = (src[1:] != src[:-1] + 1) | (sblk[1:] != sblk[:-1])
+        run_first = torch.cummax(torch.where(new_run, ar, torch.zeros_like(ar)), 0).values      # index of the first value of the run
+        in_run = ar - run_first
+        new_chunk = in_run % 4 == 0                                      # a run of L values: ceil(L / 4) chunks
+        chunk = torch.cumsum(new_chunk.to(torch.int64), 0) - 1
+        nchunks = int(chunk[-1]) + 1
+        first_pos = src[new_chunk]                                       # (chunks are numbered in the order of their first values)
+        start = torch.clamp(first_pos, max=nnz - 4)                      # a chunk never reads beyond the value array
+        cs = torch.full((nchunks, 4), 0xFFFF, dtype=torch.int64, device=dev)
+        cs[chunk, src - start[chunk]] = slot
+        cblk = sblk[new_chunk]
+        ccnt = torch.bincount(cblk, minlength=nb)
+        if int(ccnt.max()) > MAX_CHUNKS:
+            return None
+        c0 = torch.zeros(nb + 1, dtype=torch.int64, device=dev)
+        c0[1:] = torch.cumsum(ccnt, 0)
+        desc[:nb, 4] = c0[:-1].to(torch.int32)
+        desc[:nb, 5] = ccnt.to(torch.int32)
+        cpos = start.to(torch.int32).contiguous()
+        cslot = cs.to(torch.int16).contiguous()                          # [chunks][4] uint16 bit patterns
     return TilePlan(n_rows=n_rows, n_cols=n_cols, nnz=nnz, n_blocks=nb, rows_per_block=R, max_union=max_union, max_entries=max_entries,
                     desc=desc.contiguous(), ucol=ucol.to(torch.int32).contiguous(), lidx=lidx, rptr=crow.to(torch.int32).contiguous(),
-                    perm=gsrc, slot=gslot, reuse=reuse, _cstruct=None)
+                    cpos=cpos, cslot=cslot, reuse=reuse, _cstruct=None)
 
 
 class TilePlanStruct(ctypes.Structure):
@@ -104,5 +132,5 @@ class TilePlanStruct(ctypes.Structure):
 
     _fields_ = [("n_rows", ctypes.c_int64), ("n_cols", ctypes.c_int64), ("nnz", ctypes.c_int64), ("n_blocks", ctypes.c_int64),
                 ("rows_per_block", ctypes.c_int32), ("max_union", ctypes.c_int32), ("max_entries", ctypes.c_int32), ("reserved", ctypes.c_int32),
-                ("desc", ctypes.c_void_p), ("ucol", ctypes.c_void_p), ("lidx", ctypes.c_void_p), ("rptr", ctypes.c_void_p), ("perm", ctypes.c_void_p),
-                ("slot", ctypes.c_void_p)]
+                ("desc", ctypes.c_void_p), ("ucol", ctypes.c_void_p), ("lidx", ctypes.c_void_p), ("rptr", ctypes.c_void_p), ("cpos", ctypes.c_void_p),
+                ("cslot", ctypes.c_void_p)]

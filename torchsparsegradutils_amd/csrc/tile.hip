@@ -21,7 +21,8 @@ int fill(TileParams& P, const tsgu_tile_plan* pl, int64_t p) {
     if (!pl || pl->n_rows < 0 || pl->n_cols < 0 || pl->nnz < 0 || pl->n_blocks < 0) return TSGU_ERR_BAD_ARG;
     if (pl->rows_per_block != kTileRows || pl->max_union > kTileUMax || pl->max_entries > kTileEMax) return TSGU_ERR_BAD_ARG;
     if (pl->n_blocks > 0 && (!pl->desc || !pl->ucol || !pl->lidx || !pl->rptr)) return TSGU_ERR_BAD_ARG;
-    if ((pl->perm == nullptr) != (pl->slot == nullptr)) return TSGU_ERR_BAD_ARG;        // (source positions and their slots: both or neither)
+    if ((pl->cpos == nullptr) != (pl->cslot == nullptr)) return TSGU_ERR_BAD_ARG;       // (value chunks and their slots: both or neither)
+    if (pl->cpos && pl->nnz > 0 && pl->nnz < 4) return TSGU_ERR_BAD_ARG;                // (a chunk is four values inside the value array)
     if (pl->n_rows > 0x7fffffffLL || pl->nnz > 0x7fffffffLL) return TSGU_ERR_TOO_LARGE;
     if (p <= 0 || p % 32) return TSGU_ERR_BAD_ARG;        // (column tiles of 32: dense rows of 128 bytes per launch)
     P.n_rows = pl->n_rows;
@@ -32,8 +33,9 @@ int fill(TileParams& P, const tsgu_tile_plan* pl, int64_t p) {
     P.ucol = static_cast<const int*>(pl->ucol);
     P.lidx = static_cast<const unsigned char*>(pl->lidx);
     P.rptr = static_cast<const int*>(pl->rptr);
-    P.perm = static_cast<const int*>(pl->perm);
-    P.slot = static_cast<const unsigned short*>(pl->slot);
+    P.cpos = static_cast<const int*>(pl->cpos);
+    P.cslot = static_cast<const uint2*>(pl->cslot);
+    P.ncol = (int)(p / 32);
     return TSGU_OK;
 }
 
@@ -42,8 +44,8 @@ int launch(const TileParams& P0, int device, hipStream_t s) {
     TileParams P = P0;
     const int n_cu = n_cu_of(device);
     if (n_cu <= 0) return TSGU_ERR_RUNTIME;
-    // persistent workgroups, two per CU (76 KB of LDS each), every one a run of consecutive blocks: neighbouring blocks share tile
-    // rows, consecutive workgroups share an XCD's L2 (xcd_chunked_block)
+    // persistent workgroups, two per CU (76 KB of LDS each): neighbouring blocks share tile rows, consecutive workgroups share an
+    // XCD's L2 (xcd_chunked_block)
     const int64_t slots = (int64_t)n_cu * 2;
     int64_t per = (P.n_blocks + slots - 1) / slots;
     if (per < 1) per = 1;
@@ -56,22 +58,25 @@ int launch(const TileParams& P0, int device, hipStream_t s) {
     }();
     P.cyclic = cyclic;
     using L = TileLds<128>;
-    static std::atomic<int> attr_set[4] = {{0}, {0}, {0}, {0}};
-    const bool perm = P.perm != nullptr;
+    // the opt-in to more than 64 KB of dynamic LDS is a per-DEVICE attribute of the kernel: one bit per (variant, device)
+    static std::atomic<uint64_t> attr_set[6] = {{0}, {0}, {0}, {0}, {0}, {0}};
+    if (device < 0 || device >= 64) return TSGU_ERR_BAD_ARG;
+    const bool perm = P.cpos != nullptr;
     auto go = [&](auto kern, int slot) -> int {
-        if (!attr_set[slot].load(std::memory_order_relaxed)) {
+        if (!(attr_set[slot].load(std::memory_order_acquire) >> device & 1ull)) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, L::kTotal) != hipSuccess)
                 return TSGU_ERR_RUNTIME;
-            attr_set[slot].store(1, std::memory_order_relaxed);
+            attr_set[slot].fetch_or(1ull << device, std::memory_order_release);
         }
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kTileThreads), L::kTotal, s, P);
         return check_launch();
     };
+    const bool wide = P.ncol > 1;
     if constexpr (MODE == kTileSpmm) {
-        if (perm) return go(tile_kernel<float, 8, kTileSpmm, true>, 0);
-        return go(tile_kernel<float, 8, kTileSpmm, false>, 1);
+        if (perm) return wide ? go(tile_kernel<float, 8, kTileSpmm, true, true>, 0) : go(tile_kernel<float, 8, kTileSpmm, true, false>, 1);
+        return wide ? go(tile_kernel<float, 8, kTileSpmm, false, true>, 2) : go(tile_kernel<float, 8, kTileSpmm, false, false>, 3);
     } else {
-        return go(tile_kernel<float, 8, kTileSddmm, false>, 2);
+        return wide ? go(tile_kernel<float, 8, kTileSddmm, false, true>, 4) : go(tile_kernel<float, 8, kTileSddmm, false, false>, 5);
     }
 }
 
@@ -101,12 +106,9 @@ int tsgu_csr_spmm_tile(int vtype, const tsgu_tile_plan* plan, const void* val, c
     P.val = val;
     P.lds_ = ldb;
     P.ldo = ldc;
-    for (int64_t c = 0; c < p; c += 32) {        // wide operands: one launch per tile of 32 columns (the reference's SuiteSparse width is 128)
-        P.S = static_cast<const float*>(B) + c;
-        P.out = static_cast<float*>(C) + c;
-        if (const int rc = launch<kTileSpmm>(P, device, static_cast<hipStream_t>(stream))) return rc;
-    }
-    return TSGU_OK;
+    P.S = B;                                      // wide operands (the reference's SuiteSparse width is 128): the column tiles of 32 are steps
+    P.out = C;                                    // of ONE launch — a block's values, entry bytes and row pointers are staged once
+    return launch<kTileSpmm>(P, device, static_cast<hipStream_t>(stream));
 }
 
 int tsgu_csr_sddmm_tile(int vtype, const tsgu_tile_plan* plan, const void* R, int64_t ldr, const void* Cm, int64_t ldc, void* out_vals,
@@ -115,7 +117,7 @@ int tsgu_csr_sddmm_tile(int vtype, const tsgu_tile_plan* plan, const void* R, in
     TileParams P{};
     if (const int rc = fill(P, plan, p)) return rc;
     if (P.n_rows == 0 || P.nnz == 0) return TSGU_OK;
-    if (plan->perm || !R || !Cm || !out_vals || ldr < p || ldc < p) return TSGU_ERR_BAD_ARG;
+    if (plan->cpos || !R || !Cm || !out_vals || ldr < p || ldc < p) return TSGU_ERR_BAD_ARG;
     if (!aligned16(R) || !aligned16(Cm) || ldr % 4 || ldc % 4) return TSGU_ERR_BAD_ARG;
     if ((uint64_t)plan->n_cols * (uint64_t)ldc * 4u > 0xffffffffull) return TSGU_ERR_TOO_LARGE;
     if (plan->n_cols >= (1 << 24) || ldc * 4 >= (1 << 24)) return TSGU_ERR_TOO_LARGE;
@@ -124,13 +126,9 @@ int tsgu_csr_sddmm_tile(int vtype, const tsgu_tile_plan* plan, const void* R, in
     P.lds_ = ldc;
     P.gvals = out_vals;
     P.alpha = (float)alpha;
-    for (int64_t c = 0; c < p; c += 32) {        // the dots of the later column tiles are added to those of the first
-        P.Own = static_cast<const float*>(R) + c;
-        P.S = static_cast<const float*>(Cm) + c;
-        P.accumulate = c > 0;
-        if (const int rc = launch<kTileSddmm>(P, device, static_cast<hipStream_t>(stream))) return rc;
-    }
-    return TSGU_OK;
+    P.Own = R;                                    // (the dots of the column tiles are added up inside the kernel)
+    P.S = Cm;
+    return launch<kTileSddmm>(P, device, static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

@@ -15,11 +15,17 @@
 //                              repeats of the last one), its entries are e0 .. e0+E of the walked pattern
 //   lidx[k]                    position of entry k's column inside its block's tile (one byte: U <= 256)
 //   rptr                       int32 row pointer of the walked pattern
-//   perm, slot (optional)      the transposed pattern walks A's own values (Aᵀ·G): per block, perm = the positions in the value array in
-//                              ASCENDING order, slot = the entry of the block each belongs to.  Their values travel through registers
-//                              (ordinary loads in source order, neighbouring lanes on neighbouring values; written to the LDS value
-//                              buffer between the step's `s_waitcnt vmcnt(0)` and its barrier) — in walk order every lane of a 4-byte
-//                              gather touched its own cache line and the staging, not the walk, bounded the kernel
+//   cpos, cslot (optional)     the transposed pattern walks A's own values (Aᵀ·G): a block's values are runs of consecutive positions in
+//                              the value array (one run per source row); they are fetched as 16-BYTE CHUNKS in ascending source order —
+//                              chunk q of the plan: cpos[q] = position of its first value, cslot[q][0..3] = the entry of the block each
+//                              of its four values belongs to (0xffff: not this block's).  5-6 bytes per entry of round 5's perm + slot
+//                              become ~3.6.  The values travel through registers (one 16-byte load per lane, neighbouring lanes on
+//                              neighbouring chunks; written to the LDS value buffer between the step's `s_waitcnt vmcnt(0)` and its
+//                              barrier) — in walk order every lane of a 4-byte gather touched its own cache line
+//
+// Operands wider than one column tile (32 fp32 columns): ONE launch.  A block's entry bytes, values and row pointer slice are staged
+// once; the pipeline's steps are (block, column tile) pairs and only the dense tile is staged per step; the SDDMM keeps the dots of
+// the earlier column tiles in the (otherwise unused) value region of the block's buffer.
 //
 // Modes: kTileSpmm  C = A·B (perm: Aᵀ·G on the transposed pattern); kTileSddmm  out[k] = alpha·<R[row k], Cm[col k]> in stored order.
 // (Round 5 also built BOTH gradients in one walk of the transposed pattern's plan — G staged once, B[j] in registers, dots back through
@@ -45,10 +51,12 @@ constexpr int kTileRows = 64;       // rows per block
 constexpr int kTileUMax = 224;      // distinct dense rows per block (multiple of 8)
 constexpr int kTileEMax = 2048;     // entries per block
 constexpr int kTileThreads = 512;   // eight waves: with 8 lanes per row every wave owns 8 of the block's 64 rows
-constexpr int kTileEP = kTileEMax / kTileThreads;          // value dwords per thread
+constexpr int kTileCP = 2;                                 // value chunks (16 bytes) per thread: at most 1024 chunks per block
+constexpr int kTileCMax = kTileCP * kTileThreads;
 
 struct TileDesc {
     int u0, U, e0, E;
+    int c0, NC, pad0, pad1;      // value chunks of the block (plans with cpos / cslot): cpos[c0 .. c0 + NC)
 };
 
 struct TileParams {
@@ -57,8 +65,8 @@ struct TileParams {
     const int* ucol;
     const unsigned char* lidx;   // [nnz + 16]
     const int* rptr;             // [n_rows + 1]
-    const int* perm;             // optional [nnz]: per block, positions in the value array in ascending order …
-    const unsigned short* slot;  // … and the entry of the block each of them belongs to
+    const int* cpos;             // optional: per value chunk, the position of its first value in the value array …
+    const uint2* cslot;          // … and the entries of the block its four values belong to (4 x uint16, 0xffff: none)
     const void* val;             // SpMM: values
     const void* S;               // gathered dense operand (B; Cm for the SDDMM)
     int64_t lds_;
@@ -69,27 +77,36 @@ struct TileParams {
     void* gvals;                 // SDDMM output [nnz]
     float alpha;
     int blocks_per_wg;
-    int accumulate;              // SDDMM: add to gvals (the later column tiles of a wide operand)
+    int ncol;                    // column tiles of 32 (p / 32)
     int cyclic;                  // block of (workgroup w, step k): 0: w·blocks_per_wg + k (a run per workgroup); 1: k·workgroups + w
 };
 
-// LDS layout (bytes): two buffers of {tile | values | entry bytes | row pointer slice} + one zero row behind them
+// LDS layout (bytes): two tile buffers (filled per pipeline step = per (block, column tile)), two plan buffers {values | entry bytes |
+// row pointer slice} (filled per block) and one zero row behind them
 template <int RB>
 struct TileLds {
     static constexpr int kTile = kTileUMax * RB;
     static constexpr int kVals = kTileEMax * 4;
     static constexpr int kLidx = kTileEMax + 16;
     static constexpr int kRs = (kTileRows + 8) * 4;
-    static constexpr int kBuf = kTile + kVals + kLidx + kRs;
-    static constexpr int oVals = kTile, oLidx = kTile + kVals, oRs = kTile + kVals + kLidx;
-    static constexpr int oZero = 2 * kBuf;
-    static constexpr int kTotal = 2 * kBuf + RB;
+    static constexpr int kPlan = kVals + kLidx + kRs;
+    static constexpr int kTileStride = kTile, kPlanStride = kPlan;
+    static constexpr int oPlan = 2 * kTile;
+    static constexpr int oVals = 0, oLidx = kVals, oRs = kVals + kLidx;      // inside a plan buffer
+    static constexpr int oZero = 2 * kTile + 2 * kPlan;
+    static constexpr int kTotal = oZero + RB;
 };
 
 // wave-uniform copy of a descriptor (scalar registers: its fields go into lane predicates and M0-relative addresses)
+template <bool CHUNKS>
 __device__ __forceinline__ TileDesc tile_uniform(const TileDesc d) {
-    return TileDesc{__builtin_amdgcn_readfirstlane(d.u0), __builtin_amdgcn_readfirstlane(d.U), __builtin_amdgcn_readfirstlane(d.e0),
-                    __builtin_amdgcn_readfirstlane(d.E)};
+    TileDesc u{__builtin_amdgcn_readfirstlane(d.u0), __builtin_amdgcn_readfirstlane(d.U), __builtin_amdgcn_readfirstlane(d.e0),
+               __builtin_amdgcn_readfirstlane(d.E), 0, 0, 0, 0};
+    if constexpr (CHUNKS) {
+        u.c0 = __builtin_amdgcn_readfirstlane(d.c0);
+        u.NC = __builtin_amdgcn_readfirstlane(d.NC);
+    }
+    return u;
 }
 
 // smallest and largest value over the wave of a per-row length (all lanes of a row's group hold the same value): one v_readlane per
@@ -106,10 +123,12 @@ __device__ __forceinline__ void tile_wave_minmax(int x, int& lo, int& hi) {
     }
 }
 
-template <typename V, int CL, int MODE, bool PERM>
+// WIDE = false: one column tile (ncol == 1, known at compile time: every step is a crossing — the loop of round 5, and its speed:
+// with a run-time ncol the 32-column SDDMM ran 122 us against 110)
+template <typename V, int CL, int MODE, bool PERM, bool WIDE>
 __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(const TileParams P) {
-    static_assert(std::is_same<V, float>::value && CL == 8, "fp32 operands of 32 columns (so far)");
-    constexpr int RB = CL * 16;                    // bytes of a dense row
+    static_assert(std::is_same<V, float>::value && CL == 8, "fp32 operands, column tiles of 32 (so far)");
+    constexpr int RB = CL * 16;                    // bytes of a dense row of one column tile
     constexpr int RPW = kWave / CL;                // rows per wave
     constexpr int NW = kTileThreads / kWave;
     static_assert(RPW * NW == kTileRows, "one pass: every wave owns RPW rows of the block");
@@ -121,6 +140,7 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(const TileParams 
     const int t = threadIdx.x, lane = t & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(t / kWave);      // (a scalar: it goes into M0 for the DMA destinations)
     const int sub = lane % CL, grp = lane / CL;
+    const int ncol = WIDE ? P.ncol : 1;            // column tiles per block (p / 32)
     // Which blocks a workgroup walks.  Neighbouring blocks share dense rows; an XCD's L2 (4 MB) only catches that when they are
     // worked on at about the same time BY THE SAME XCD.  `cyclic`: at step k the whole chip works on blocks k·G … k·G + G - 1 and —
     // virtual workgroup ids are XCD-contiguous (xcd_chunked_block) — every XCD on a run of G / 8 consecutive blocks.  Otherwise a
@@ -132,13 +152,14 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(const TileParams 
     if (P.cyclic) nloc = b_first < P.n_blocks ? (int)((P.n_blocks - b_first + b_step - 1) / b_step) : 0;
     else nloc = (int)((P.n_blocks - b_first) < P.blocks_per_wg ? (P.n_blocks - b_first) : P.blocks_per_wg);
     if (nloc <= 0) return;
-    // descriptor of local step k (steps beyond the last block read the trailing empty descriptors)
+    // descriptor of local block k (blocks beyond the last read the trailing empty descriptors)
     const TileDesc* __restrict__ desc_all = P.desc;
     auto desc_at = [&](int k) -> TileDesc {
         int64_t b = b_first + (int64_t)k * b_step;
         if (b > P.n_blocks) b = P.n_blocks;
         return desc_all[b];
     };
+    auto uni = [](const TileDesc d) { return tile_uniform<PERM>(d); };
     const float* __restrict__ S = static_cast<const float*>(P.S);
     const uint32_t ld_bytes = (uint32_t)P.lds_ * 4u;
     const unsigned wave_piece = (unsigned)(wave * kWave);
@@ -147,12 +168,12 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(const TileParams 
     // Every compiler-visible global load of the loop below is FIRST USED behind the `s_waitcnt vmcnt(0)` that ends the step it was
     // issued in (hipcc's own wait for it is then free); a load consumed inside the same step would make hipcc drain the DMAs.
     int ucolr[UP];                                       // column numbers of this thread's tile pieces of the block staged next
-    unsigned toff[UP];                                   // … and their byte offsets in the gathered operand
-    int permr[PERM ? kTileEP : 1];                       // value positions this thread fetches for the block staged next …
-    unsigned slotr[PERM ? kTileEP : 1];                  // … the entries of that block they belong to …
-    unsigned slotw[PERM ? kTileEP : 1];                  // … (of the block whose values are in flight)
-    float valr[PERM ? kTileEP : 1];                      // values in flight: loaded while block k is walked, written to LDS at the end of the step
-    uint4 own_cur = {0, 0, 0, 0}, own_nxt = {0, 0, 0, 0};      // SDDMM: this lane's 16 bytes of its row of R, block walked / next block
+    unsigned toff[UP];                                   // byte offsets in the gathered operand of the tile pieces of the block being staged
+    int cposr[PERM ? kTileCP : 1];                       // value chunks this thread fetches for the block staged next: first position …
+    uint2 cslotr[PERM ? kTileCP : 1];                    // … and the entries of that block their four values belong to
+    uint2 cslotw[PERM ? kTileCP : 1];                    // … (of the block whose values are in flight)
+    u32x4_t valr[PERM ? kTileCP : 1];                    // values in flight: loaded while a block is walked, written to LDS at the end of the step
+    uint4 own_cur = {0, 0, 0, 0}, own_nxt = {0, 0, 0, 0};      // SDDMM: this lane's 16 bytes of its row of R, step walked / next step
 #pragma unroll
     for (int i = 0; i < UP; ++i) ucolr[i] = 0;
 
@@ -160,8 +181,8 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(const TileParams 
     // and U is a multiple of 8; value / byte instructions run when their first lane has work, lanes beyond the end repeat the last
     // element (into slots nobody reads).
     const int wave_row = wave * RPW;                     // first tile row of this wave's piece 0
-    const int wave_e = wave * kWave;                     // first entry / dword of this wave's instruction 0
-    auto load_words = [&](const TileDesc d) {            // for the block staged one step later: byte offsets of its tile rows, value positions
+    const int wave_e = wave * kWave;                     // first entry / dword / chunk of this wave's instruction 0
+    auto load_words = [&](const TileDesc d) {            // for the block staged one crossing later: its tile rows' columns, its value chunks
 #pragma unroll
         for (int i = 0; i < UP; ++i) {
             if (wave_row + i * (kTileThreads / CL) < d.U) {
@@ -170,60 +191,76 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(const TileParams 
         }
         if constexpr (PERM) {
 #pragma unroll
-            for (int i = 0; i < kTileEP; ++i) {
-                if (wave_e + i * kTileThreads < d.E) {
-                    int e = t + i * kTileThreads;
-                    e = e < d.E ? e : d.E - 1;
-#ifndef TSGU_TILE_NT_WORDS
-#define TSGU_TILE_NT_WORDS 0
-#endif
-#if TSGU_TILE_NT_WORDS
-                    permr[i] = __builtin_nontemporal_load(P.perm + ((int64_t)d.e0 + e));      // (a single-use stream)
-#else
-                    permr[i] = P.perm[(int64_t)d.e0 + e];
-#endif
-                    slotr[i] = P.slot[(int64_t)d.e0 + e];
+            for (int i = 0; i < kTileCP; ++i) {
+                if (wave_e + i * kTileThreads < d.NC) {
+                    int q = t + i * kTileThreads;
+                    q = q < d.NC ? q : d.NC - 1;
+                    cposr[i] = P.cpos[(int64_t)d.c0 + q];
+                    cslotr[i] = P.cslot[(int64_t)d.c0 + q];
                 }
             }
         }
     };
-    auto pin_words = [&]() {
-        // pinned in straight-line code before the first DMA of a step: hipcc otherwise places its wait for ucolr[i] inside the
-        // predicated block of piece i — behind the DMA of piece i - 1
+    auto pin_loaded = [&](TileDesc& rawd) {
+        // Everything a step loaded for later steps is pinned at the TOP of the next step, in straight-line code before its first DMA —
+        // on crossing and non-crossing steps alike: hipcc's wait for a load sits where it first sees the value used, and a use it
+        // meets on only one path of a branch, or behind a DMA, becomes `s_waitcnt vmcnt(0)` in the middle of the step (draining the
+        // DMAs: the walk then starts with its tile still on the way).  After the pins its scoreboard is clean.
 #pragma unroll
-        for (int i = 0; i < UP; ++i) {
-            lat_pin(ucolr[i]);
-            toff[i] = __umul24((unsigned)ucolr[i], ld_bytes) + (unsigned)sub * 16u;      // (launcher: columns and row bytes below 2^24)
-        }
+        for (int i = 0; i < UP; ++i) lat_pin(ucolr[i]);
         if constexpr (PERM) {
 #pragma unroll
-            for (int i = 0; i < kTileEP; ++i) {
-                lat_pin(permr[i]);
-                lat_pin(slotr[i]);
+            for (int i = 0; i < kTileCP; ++i) {
+                lat_pin(cposr[i]);
+                lat_pin(cslotr[i].x);
+                lat_pin(cslotr[i].y);
             }
         }
+        lat_pin(rawd.u0), lat_pin(rawd.U), lat_pin(rawd.e0), lat_pin(rawd.E);
+        if constexpr (PERM) lat_pin(rawd.c0), lat_pin(rawd.NC);
+        if constexpr (MODE == kTileSddmm) lat_pin(own_cur.x), lat_pin(own_cur.y), lat_pin(own_cur.z), lat_pin(own_cur.w);
+    };
+    auto set_offsets = [&]() {                           // `toff` of the block whose columns `ucolr` holds
+#pragma unroll
+        for (int i = 0; i < UP; ++i) toff[i] = __umul24((unsigned)ucolr[i], ld_bytes) + (unsigned)sub * 16u;      // (launcher: columns and row bytes below 2^24)
     };
 
-    auto stage = [&](int k, const TileDesc d) {          // issue the DMAs of block k into buffer k & 1
-        const unsigned buf = lds0 + (unsigned)(k & 1) * L::kBuf;
+    auto stage_tile = [&](int tb, int c, const TileDesc d) {      // the DMAs of column tile c of the block `toff` belongs to, into tile buffer tb
+        const unsigned buf = lds0 + (unsigned)tb * L::kTileStride;
+        const float* const Sc = S + c * (RB / 4);
 #pragma unroll
         for (int i = 0; i < UP; ++i) {
             if (wave_row + i * (kTileThreads / CL) < d.U)
-                lat_dma16<false>(S, toff[i], buf + (wave_piece + (unsigned)i * kTileThreads) * 16u);
+                lat_dma16<false>(Sc, toff[i], buf + (wave_piece + (unsigned)i * kTileThreads) * 16u);
         }
-        if constexpr (MODE == kTileSpmm) {
+    };
+    auto stage_plan = [&](int pb, int k, const TileDesc d) {      // values, entry bytes and row pointer slice of local block k into plan buffer pb
+        const unsigned buf = lds0 + L::oPlan + (unsigned)pb * L::kPlanStride;
+        if constexpr (MODE == kTileSpmm && !PERM) {
+            // values in stored order: 16-byte pieces (four values per lane; the source is only 4-byte aligned, which the LDS-DMA takes at
+            // full speed).  A piece that would read beyond the end of the value array (the last block only) is copied value by value.
+            const int nq = (d.E + 3) >> 2;
+            if (wave_e < nq) {
+                const int q = t < nq ? t : nq - 1;
+                const uint32_t g = (uint32_t)d.e0 + 4u * (uint32_t)q;
+                if (__builtin_expect((int64_t)g + 4 <= P.nnz, 1)) {
+                    lat_dma16<true>(P.val, g * 4u, buf + L::oVals + wave_piece * 16u);
+                } else {
+                    float* dst = reinterpret_cast<float*>(tile_lds + L::oPlan + pb * L::kPlanStride + L::oVals) + 4 * q;
+                    for (int e = 0; e < 4; ++e) dst[e] = (int64_t)g + e < P.nnz ? static_cast<const float*>(P.val)[g + e] : 0.f;
+                }
+            }
+        } else if constexpr (MODE == kTileSpmm) {
 #pragma unroll
-            for (int i = 0; i < kTileEP; ++i) {
-                if (wave_e + i * kTileThreads < d.E) {
-                    if constexpr (PERM) {
-                        // (an ordinary load, issued behind the step's DMAs and first used behind its `s_waitcnt vmcnt(0)`: put_values)
-                        valr[i] = static_cast<const float*>(P.val)[(uint32_t)permr[i]];
-                        slotw[i] = slotr[i];
-                    } else {
-                        int e = t + i * kTileThreads;
-                        e = e < d.E ? e : d.E - 1;
-                        lat_dma4<true>(P.val, (uint32_t)(d.e0 + e) * 4u, buf + L::oVals + (wave_piece + (unsigned)i * kTileThreads) * 4u);
-                    }
+            for (int i = 0; i < kTileCP; ++i) {
+                if (wave_e + i * kTileThreads < d.NC) {
+                    // (an ordinary 16-byte load, issued behind the step's DMAs and first used behind its `s_waitcnt vmcnt(0)`: put_values;
+                    // the plan keeps every chunk inside the value array)
+                    struct __attribute__((packed, aligned(4))) Chunk {
+                        u32x4_t v;
+                    };
+                    valr[i] = reinterpret_cast<const Chunk*>(static_cast<const float*>(P.val) + (uint32_t)cposr[i])->v;
+                    cslotw[i] = cslotr[i];
                 }
             }
         }
@@ -246,31 +283,38 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(const TileParams 
         }
     };
 
-    auto put_values = [&](int k, const TileDesc d) {     // the fetched values of block k into its value buffer (behind the step's vmcnt(0))
+    auto put_values = [&](int pb, const TileDesc d) {    // the fetched values of a block into its value buffer (behind the step's vmcnt(0))
         if constexpr (PERM) {
-            float* const vb = reinterpret_cast<float*>(tile_lds + (k & 1) * L::kBuf + L::oVals);
+            unsigned* const vbuf = reinterpret_cast<unsigned*>(tile_lds + L::oPlan + pb * L::kPlanStride + L::oVals);
 #pragma unroll
-            for (int i = 0; i < kTileEP; ++i) {
-                if (wave_e + i * kTileThreads < d.E) vb[slotw[i]] = valr[i];      // (lanes beyond the end repeat the last pair)
+            for (int i = 0; i < kTileCP; ++i) {
+                if (wave_e + i * kTileThreads < d.NC) {     // (lanes beyond the end repeat the last chunk: the same values into the same slots)
+                    const unsigned s0 = cslotw[i].x & 0xffffu, s1 = cslotw[i].x >> 16, s2 = cslotw[i].y & 0xffffu, s3 = cslotw[i].y >> 16;
+                    if (s0 != 0xffffu) vbuf[s0] = valr[i][0];
+                    if (s1 != 0xffffu) vbuf[s1] = valr[i][1];
+                    if (s2 != 0xffffu) vbuf[s2] = valr[i][2];
+                    if (s3 != 0xffffu) vbuf[s3] = valr[i][3];
+                }
             }
         }
     };
 
-    auto load_own = [&](int k) {                         // SDDMM: this lane's part of its row of R in block k
+    auto load_own = [&](int k, int c) {                  // SDDMM: this lane's part of its row of R in column tile c of local block k
         if constexpr (MODE == kTileSddmm) {
-            const float* Own = static_cast<const float*>(P.Own);
+            const float* Own = static_cast<const float*>(P.Own) + c * (RB / 4);
             const int64_t r = (b_first + (int64_t)k * b_step) * kTileRows + wave * RPW + grp;
             own_nxt = r < P.n_rows ? *reinterpret_cast<const uint4*>(Own + r * P.ldown + sub * 4) : uint4{0, 0, 0, 0};
         }
     };
 
-    auto walk = [&](int k, const TileDesc d) {
-        const unsigned char* buf = tile_lds + (k & 1) * L::kBuf;
-        const float* vals = reinterpret_cast<const float*>(buf + L::oVals);
+    auto walk = [&](int tb, int pb, int k, int c, const TileDesc d) {
+        const unsigned char* tbuf = tile_lds + tb * L::kTileStride;
+        unsigned char* pbuf = tile_lds + L::oPlan + pb * L::kPlanStride;
+        const float* vals = reinterpret_cast<const float*>(pbuf + L::oVals);
         // entry bytes: entry k of the block sits at byte (e0 & 3) + k of the byte region.  They are read as ALIGNED dwords and shifted
         // into place (v_alignbyte): a byte-misaligned 8- or 16-byte LDS read is slow (the SDDMM with one misaligned 8-byte read per round
         // ran 141 us against 120 us with eight byte reads)
-        const unsigned* lidw = reinterpret_cast<const unsigned*>(buf + L::oLidx);
+        const unsigned* lidw = reinterpret_cast<const unsigned*>(pbuf + L::oLidx);
         auto bytes8 = [&](int at, unsigned& lo, unsigned& hi) {      // the 8 entry bytes of the round that starts at entry `at`
             const int b = (d.e0 & 3) + at;
             const unsigned* w = lidw + (b >> 2);
@@ -278,8 +322,8 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(const TileParams 
             lo = __builtin_amdgcn_alignbyte(w1, w0, (unsigned)b & 3u);
             hi = __builtin_amdgcn_alignbyte(w2, w1, (unsigned)b & 3u);
         };
-        const int* rs = reinterpret_cast<const int*>(buf + L::oRs);
-        const unsigned char* trow = buf + sub * 16;
+        const int* rs = reinterpret_cast<const int*>(pbuf + L::oRs);
+        const unsigned char* trow = tbuf + sub * 16;
         const unsigned char* zrow = tile_lds + L::oZero + sub * 16;
         const int rl = wave * RPW + grp;
         const int64_t r = (b_first + (int64_t)k * b_step) * kTileRows + rl;
@@ -360,11 +404,15 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(const TileParams 
                     acc[3] = fmaf(vv[j], bj[j].w, acc[3]);
                 }
             }
-            if (live) store_vec<float, 4, true>(static_cast<float*>(P.out) + r * P.ldo + sub * 4, acc);
+            if (live) store_vec<float, 4, true>(static_cast<float*>(P.out) + r * P.ldo + c * (RB / 4) + sub * 4, acc);
         } else {
             const float g0 = __uint_as_float(own_cur.x), g1 = __uint_as_float(own_cur.y), g2 = __uint_as_float(own_cur.z),
                         g3 = __uint_as_float(own_cur.w);
             float* gv = static_cast<float*>(P.gvals) + d.e0;
+            // wide operands: the dots of the column tiles are added up in the block's (otherwise unused) value region — every entry
+            // belongs to one lane, the same lane in every column tile — and leave for HBM with the last tile
+            float* gacc = reinterpret_cast<float*>(pbuf + L::oVals);
+            const bool first_tile = c == 0, last_tile = c + 1 == ncol;
             // Eight entries per round, slot j of lane `sub` holds entry kk + (j ^ sub): the 8 lanes of a row then read 8 different
             // dense rows at once (each its own 16-byte column chunk, conflict-free) and the cross-lane sums form a TRANSPOSED tree with
             // fixed slots — after the step over lane bit m a lane keeps the entries whose bit m equals its own:
@@ -384,12 +432,7 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(const TileParams 
                 float4 bj[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) bj[j] = *reinterpret_cast<const float4*>(trow + li[j] * RB);
-#ifndef TSGU_TILE_SDDMM_GROUPED
-#define TSGU_TILE_SDDMM_GROUPED 1
-#endif
-#if TSGU_TILE_SDDMM_GROUPED
                 asm volatile("" ::: "memory");           // (all eight LDS requests leave before the first dot waits for one)
-#endif
                 float part[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) part[j] = fmaf(g3, bj[j].w, fmaf(g2, bj[j].z, fmaf(g1, bj[j].y, g0 * bj[j].x)));
@@ -400,49 +443,87 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(const TileParams 
                 for (int j = 0; j < 2; ++j) h2[j] = h4[j] + dpp_move<0x4E>(h4[j + 2]);
                 return h2[0] + dpp_move<0xB1>(h2[1]);
             };
-            for (int it = 0; it < nfull; ++it) {
-                const float h = P.alpha * round();
-                gv[(unsigned)(kk + sub)] = P.accumulate ? gv[(unsigned)(kk + sub)] + h : h;
-                kk += 8;
-            }
-            // the rest under a store predicate only: the slots of entries beyond a row's end hold whatever dense row the byte behind the
-            // row names (inside the LDS buffer); their sums stay in their own slots of the tree and are never stored
-            while (__any(kk < e)) {
-                const float h = round();
-                if (kk + sub < e) gv[kk + sub] = P.accumulate ? gv[kk + sub] + P.alpha * h : P.alpha * h;
-                kk += 8;
-            }
+            // (one branch-free loop per case: a scalar branch inside the round loop kept hipcc from overlapping the rounds — 112 -> 140 us)
+            auto rounds = [&](auto emit) {
+                for (int it = 0; it < nfull; ++it) {
+                    emit(kk + sub, P.alpha * round());
+                    kk += 8;
+                }
+                // the rest under a store predicate only: the slots of entries beyond a row's end hold whatever dense row the byte behind
+                // the row names (inside the LDS buffer); their sums stay in their own slots of the tree and are never stored
+                while (__any(kk < e)) {
+                    const float h = P.alpha * round();
+                    if (kk + sub < e) emit(kk + sub, h);
+                    kk += 8;
+                }
+            };
+            if (first_tile && last_tile) rounds([&](int idx, float a) { gv[(unsigned)idx] = a; });
+            else if (first_tile) rounds([&](int idx, float a) { gacc[idx] = a; });
+            else if (!last_tile) rounds([&](int idx, float a) { gacc[idx] = gacc[idx] + a; });
+            else rounds([&](int idx, float a) { gv[(unsigned)idx] = gacc[idx] + a; });
         }
     };
 
-    // ---- pipeline: descriptors three blocks ahead, a thread's words two, DMA one, walk ---------------------------------------
-    TileDesc d0 = tile_uniform(desc_at(0)), d1 = tile_uniform(desc_at(1)), d2 = tile_uniform(desc_at(2));
+    // ---- pipeline.  A STEP is one (block, column tile) pair: the dense tile of the next step arrives while this one is walked.  The
+    // last step of a block ("crossing") also stages the next block's values, entry bytes and row pointer slice; descriptors run three
+    // blocks ahead, a thread's words (tile columns, value chunks) two ------------------------------------------------------------
+    TileDesc d0 = uni(desc_at(0)), d1 = uni(desc_at(1)), d2 = uni(desc_at(2));
     TileDesc raw = desc_at(3);
     load_words(d0);
-    pin_words();
-    stage(0, d0);
-    load_own(0);
+    pin_loaded(raw);
+    set_offsets();
+    stage_tile(0, 0, d0);
+    stage_plan(0, 0, d0);
+    load_own(0, 0);
     load_words(d1);
     if constexpr (PERM) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         put_values(0, d0);
     }
     lat_step_sync();
-    for (int k = 0; k < nloc; ++k) {
-        const TileDesc d3 = tile_uniform(raw);          // (loaded during the previous step)
-        pin_words();
+    // (ONE flat loop over the steps — with the column tiles as an inner loop hipcc hoisted the walk's per-block address arithmetic out of
+    // it and paid 25 more registers, a spill in the chunk variant)
+    const int nsteps = nloc * ncol;
+    int k = 0, c = 0;
+#pragma nounroll
+    for (int step = 0; step < nsteps; ++step) {
+        const bool crossing = c + 1 == ncol;
         own_cur = own_nxt;
-        if (k + 1 < nloc) stage(k + 1, d1);             // (uses the words loaded during step k - 1)
-        if (k + 2 < nloc) load_words(d2);
-        if (k + 1 < nloc) load_own(k + 1);
-        raw = desc_at(k + 4);
-        walk(k, d0);
+        pin_loaded(raw);
+        TileDesc d3 = d2;
+        // what the NEXT step walks: the next column tile of this block, or (crossing) the first one of the next block.  ONE own-row
+        // load and ONE set of tile DMAs in common code: with a copy in each branch hipcc gave the two loads different registers and
+        // resolved them with a move behind `s_waitcnt vmcnt(0)` — between the DMAs and the walk, draining them
+        const bool has_next = crossing ? k + 1 < nloc : true;
+        const int kn = crossing ? k + 1 : k, cn = crossing ? 0 : c + 1;
+        if (crossing) {
+            d3 = uni(raw);                              // (loaded during the previous crossing step)
+            set_offsets();                              // (the words loaded one crossing ago: `toff` now belongs to block k + 1)
+        }
+        if (has_next) stage_tile((step + 1) & 1, cn, crossing ? d1 : d0);      // (`toff` belongs to block k until its crossing)
+        if (crossing) {
+            if (k + 1 < nloc) stage_plan((k + 1) & 1, k + 1, d1);
+            if (k + 2 < nloc) load_words(d2);
+        }
+        // (BEHIND the DMAs: the row of R misses to HBM, the tile rows mostly hit in L2, and VMEM returns in order — issued first it held
+        // the tile back: SDDMM 111 -> 122 us)
+        if (has_next) load_own(kn, cn);
+        if (crossing) raw = desc_at(k + 4);
+        walk(step & 1, k & 1, k, c, d0);
         if constexpr (PERM) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (k + 1 < nloc) put_values(k + 1, d1);
+            if (crossing) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (k + 1 < nloc) put_values((k + 1) & 1, d1);
+            }
         }
         lat_step_sync();
-        d0 = d1, d1 = d2, d2 = d3;
+        if (crossing) {
+            d0 = d1, d1 = d2, d2 = d3;
+            c = 0;
+            ++k;
+        } else {
+            ++c;
+        }
     }
 }
 
