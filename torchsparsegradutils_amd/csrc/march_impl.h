@@ -774,12 +774,37 @@ __global__ __launch_bounds__(NT, 4) void march_kernel(const MarchParams P) {    
         float rP[RJ], rC[RJ], rN[RJ];
 #pragma unroll
         for (int j = 0; j < RJ; ++j) rP[j] = rC[j] = rN[j] = 0.f;
-        float* const st = reinterpret_cast<float*>(sm + P.o_vals + g * VP);   // this row's stage row (wave-private)
+        // Stage rows (wave-private).  Rows of ONE length on the whole box (PACKED): the pitch is the row itself (NS values), so the
+        // RPW rows of a wave — consecutive rows of one z-line, i.e. one contiguous run of gradA — are one contiguous run in LDS too and
+        // leave as 16-byte pieces of the RUN: RPW·NS / 4 lanes, one store instruction, every piece 16-byte aligned when the run is
+        // (round 5: six 16-byte pieces at 4-byte alignment + three single words per ROW — four store instructions per wave).
+        constexpr bool PACKED = FULL && UNIF && (RPW * NS) % 4 == 0;
+        constexpr int SP = PACKED ? NS * 4 : VP;
+        const bool wave_packed = PACKED && P.tz % RPW == 0 && __all(crow >= 0);      // (wave-uniform: all RPW rows of the wave exist)
+        float* const st = reinterpret_cast<float*>(sm + P.o_vals + g * SP);   // this row's stage row
         const int own_const = PTR ? 0 : row_const(crow > 0 ? crow : 0);   // start of this lane's row in plane x: plane_base(x) + plane_cx(x)·own_const
         bool staged = false;
         int fl_start = 0, fl_len = 0;                          // first value position and length of the staged row
         int x_out = xs;                                        // lattice plane of the next target to be staged (ring index 1)
         auto flush = [&]() {
+            if constexpr (PACKED) {
+                if (wave_packed) {
+                    // (all lanes of the wave are here: `staged` depends on the step only once every row exists)
+                    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+                    const int first = __builtin_amdgcn_readfirstlane(fl_start);          // lane 0: the wave's first row
+                    if (lane < RPW * NS / 4) {
+                        const float4 w4 = *reinterpret_cast<const float4*>(sm + P.o_vals + (wave * RPW) * SP + lane * 16);
+                        f4u* const dst = reinterpret_cast<f4u*>(static_cast<float*>(P.gvals) + first) + lane;
+                        f4u o = {w4.x, w4.y, w4.z, w4.w};
+                        if (P.accumulate) {
+                            const f4u prev = *dst;
+                            o += prev;
+                        }
+                        __builtin_nontemporal_store(o, dst);
+                    }
+                    return;
+                }
+            }
             // the row's gradients in stored order: 16-byte pieces, single elements at the end
             if (crow >= 0) {
                 float* const go = static_cast<float*>(P.gvals) + fl_start;
