@@ -123,3 +123,109 @@ def test_fresh_index_tensors_on_another_stream_wait_for_the_copy():
     assert _pattern.STATS["adopted"] == before["adopted"] + 1
     assert torch.equal(got, ref)
     _pattern.clear_cache()
+
+
+# ---- row-block tiles at full size against the ORACLE ---------------------------------------------------------------------------------
+
+
+@pytest.mark.parametrize("grid,p", [((100, 100, 100), 32), ((40, 52, 60), 128)], ids=["mesh27_blocked_N1e6_p32", "cfd2_mesh_p128"])
+def test_tile_step_full_size_every_element_against_the_oracle(grid, p):
+    """bench.py's non-lattice patterns at FULL size through the public API (the step settles on the row-block tiles: at N = 1e6
+    15 625 blocks over ~500 persistent workgroups, at 128 columns four column tiles per block in one launch): ALL elements of C,
+    gradA and gradB against the oracle's C loops — normwise at 1e-5 (north_star) and elementwise within 8 eps of the sum of the
+    magnitudes of each element's own terms (both sides carry fp32 rounding: 16 eps).  Round 5 held the full-size mesh to the
+    plan-free kernels only; the LDS overflow it found lived exactly where the small oracle tests do not reach."""
+    from oracle import oracle
+    from torchsparsegradutils_amd import _ops, _pattern, sparse_mm, wait_for_plans
+    from torchsparsegradutils_amd.utils import synthetic
+
+    crow, col = synthetic.mesh27_blocked(*grid, 4, torch.int32)
+    n = crow.numel() - 1
+    g = torch.Generator().manual_seed(7)
+    val = torch.randn(col.numel(), generator=g)
+    B = torch.randn(n, p, generator=g)
+    Gd = torch.randn(n, p, generator=g)
+    _pattern.clear_cache()
+    A = torch.sparse_csr_tensor(crow.to(DEV), col.to(DEV), val.to(DEV), (n, n)).requires_grad_(True)
+    Bd = B.to(DEV).requires_grad_(True)
+    for _ in range(_ops.PLAN_AFTER_USES + 3):          # first sight: plan-free; the tile plans arrive from the worker thread
+        C = sparse_mm(A, Bd)
+        gA, gB = torch.autograd.grad(C, (A, Bd), Gd.to(DEV))
+        wait_for_plans()
+    plan = _pattern.from_csr(A.detach())
+    keys = [k for k, v in plan.core.packs.items() if k[0] == "tile" and v is not None]
+    tkeys = [k for k, v in plan.transposed.core.packs.items() if k[0] == "tile" and v is not None]
+    assert keys and tkeys, "the step should have settled on the row-block tiles"
+    cr, cc, v, b, gd = crow.numpy(), col.numpy(), val.numpy(), B.numpy(), Gd.numpy()
+    Co, gAo, gBo = oracle.sparse_mm_fwd_bwd(cr, cc, v, b, gd, n)
+    Cm, gAm, gBm = oracle.sparse_mm_fwd_bwd(cr, cc, np.abs(v), np.abs(b), np.abs(gd), n)
+    for got, ref, mag, what in ((C, Co, Cm, "C"), (gA.values(), gAo, gAm, "gradA"), (gB, gBo, gBm, "gradB")):
+        got = got.detach().cpu().numpy()
+        assert G.rel_err(got, ref) < 1e-5, what
+        err = np.abs(got.astype(np.float64).reshape(ref.shape) - ref.astype(np.float64))
+        worst = float((err / (16.0 * EPS32 * mag.astype(np.float64) + 1e-300)).max())
+        assert worst <= 1.0, (what, worst)
+    assert gA.crow_indices().data_ptr() == A.crow_indices().data_ptr() and gA.col_indices().dtype == torch.int32
+    _pattern.clear_cache()
+
+
+# ---- the step's C++ host path for batched CSR operands OFF a lattice -----------------------------------------------------------------
+
+
+@pytest.mark.parametrize("dt,p,idt", [(torch.float32, 64, torch.int32), (torch.float32, 20, torch.int64), (torch.bfloat16, 16, torch.int32),
+                                      (torch.float64, 8, torch.int32)])
+def test_cpp_host_path_of_a_batched_plan_free_step_equals_the_python_path(dt, p, idt):
+    """Batched CSR with random items (the reference's batched benchmark shape, scaled down: no lattice, no shared columns): once no
+    structured plan can arrive, forward and backward are the plan-free batched kernels issued by csrc/host/step.cpp — same launches,
+    same bits as the Python path; C (b, n, p), gradA batched CSR with A's own index tensors, gradB (b, m, p); gating by
+    needs_input_grad; every item against torch's dense product."""
+    import torchsparsegradutils_amd.sparse_matmul as sm
+    from torchsparsegradutils_amd import _ops, _pattern, sparse_mm, wait_for_plans
+    from torchsparsegradutils_amd.utils import synthetic
+
+    assert sm._host is not None
+    b, n, m, nnz = 5, 96, 80, 400
+    crow, col = synthetic.rand_batched_csr(b, n, m, nnz, idt, DEV, seed=3)
+    g = torch.Generator(device=DEV).manual_seed(22)
+    val = torch.randn(b, nnz, device=DEV, generator=g).to(dt)
+    B0 = torch.randn(b, m, p, device=DEV, generator=g).to(dt)
+    Gd = torch.randn(b, n, p, device=DEV, generator=g).to(dt)
+    keep = (sm.FAST_STEP, _ops.PACK_MIN_NNZ)
+    _pattern.clear_cache()
+    try:
+        _ops.PACK_MIN_NNZ = 1
+        A = torch.sparse_csr_tensor(crow, col, val, (b, n, m)).requires_grad_(True)
+        B = B0.clone().requires_grad_(True)
+
+        def run(fast, need=(True, True)):
+            sm.FAST_STEP = fast
+            A.requires_grad_(need[0])
+            B.requires_grad_(need[1])
+            C = sparse_mm(A, B)
+            ins = tuple(t for t, nd in zip((A, B), need) if nd)
+            return C, (torch.autograd.grad(C, ins, Gd) if ins else ())
+
+        ref = run(False)
+        for _ in range(8):
+            got = run(True)
+            wait_for_plans()
+        C, (gA, gB) = got
+        assert type(C.grad_fn).__name__ != "SparseMatMulBackward", "the C++ host path was not reached"
+        assert C.shape == (b, n, p) and gB.shape == (b, m, p) and gA.shape == (b, n, m) and gA.layout == torch.sparse_csr
+        assert torch.equal(C, ref[0]) and torch.equal(gB, ref[1][1]) and torch.equal(gA.values(), ref[1][0].values())
+        assert gA.crow_indices().dtype == idt and gA.crow_indices().data_ptr() == A.crow_indices().data_ptr()
+        assert gA.col_indices().data_ptr() == A.col_indices().data_ptr()
+        _, (gB1,) = run(True, (False, True))
+        assert torch.equal(gB1, gB)
+        _, (gA1,) = run(True, (True, False))
+        assert torch.equal(gA1.values(), gA.values())
+        A.requires_grad_(True)
+        B.requires_grad_(True)
+        tol = {torch.float32: 2e-5, torch.float64: 1e-12, torch.bfloat16: 2e-2}[dt]
+        for i in range(b):
+            Ad = torch.sparse_csr_tensor(crow[i], col[i], val[i].double(), (n, m)).to_dense()
+            assert torch.allclose(C[i].double(), Ad @ B0[i].double(), rtol=tol, atol=tol * 10)
+            assert torch.allclose(gB[i].double(), Ad.t() @ Gd[i].double(), rtol=tol, atol=tol * 10)
+    finally:
+        sm.FAST_STEP, _ops.PACK_MIN_NNZ = keep
+        _pattern.clear_cache()

@@ -1,5 +1,6 @@
 // Host side of the steady-state sparse_mm step in C++: `SparseMatMul.forward / backward` (torchsparsegradutils_amd/sparse_matmul.py,
-// reference sparse_matmul.py:132-234) for a CSR pattern whose three launch configurations are FINAL (plane march / plane sweep).
+// reference sparse_matmul.py:132-234) for a CSR pattern whose launches are FINAL (plane march / plane sweep / row-block tiles /
+// plan-free kernels; 2-D, coalesced COO, or batched CSR).
 //
 // Why: a forward + backward step is three kernel launches (~0.23 ms of GPU time at C2).  The Python host path — autograd.Function,
 // plan look-ups, ctypes marshalling, the engine's hand-over to a thread that must take the GIL — costs 0.08 ms per step on a fast
@@ -92,7 +93,13 @@ class StepFunction : public torch::autograd::Function<StepFunction> {
         if (!val.is_contiguous()) val = val.contiguous();
         TORCH_CHECK(val.numel() == s.nnz && val.dim() == (s.batch ? 2 : 1), "step plan of another matrix (number of stored values)");
         at::Tensor C = s.batch ? at::empty({s.batch, s.item_rows, s.p}, B.options()) : at::empty({s.n_rows, s.p}, B.options());
-        if (s.fwd.kind == 2)
+        if (s.fwd.kind == 2 && s.batch)
+            // batched operands off a lattice: the plan-free kernels take the batch as it is (item strides; crow [b][n+1], col / val [b][nnz])
+            check(tsgu_csr_spmm(s.vtype, s.itype, s.item_rows, s.item_cols, s.item_nnz, s.crow.data_ptr(), s.col.data_ptr(), val.data_ptr(), nullptr,
+                                B.data_ptr(), s.p, 1, s.item_cols * s.p, C.data_ptr(), s.p, 1, s.item_rows * s.p, s.p, s.batch, s.max_row_nnz, nullptr, 0,
+                                nullptr, s.device, stream_of(s.device)),
+                  "tsgu_csr_spmm");
+        else if (s.fwd.kind == 2)
             check(tsgu_csr_spmm(s.vtype, s.itype, s.n_rows, s.n_cols, s.nnz, s.crow.data_ptr(), s.col.data_ptr(), val.data_ptr(), nullptr,
                                 B.data_ptr(), B.size(0) > 1 ? B.stride(0) : s.p, 1, 0, C.data_ptr(), s.p, 1, 0, s.p, 1, s.max_row_nnz, nullptr, 0,
                                 nullptr, s.device, stream_of(s.device)),
@@ -126,7 +133,32 @@ class StepFunction : public torch::autograd::Function<StepFunction> {
         const bool need_a = ctx->needs_input_grad(0), need_b = ctx->needs_input_grad(1);
         const int64_t ldb = s.batch ? s.p : (B.size(0) > 1 ? B.stride(0) : s.p);
         at::Tensor gv;
-        if (s.fwd.kind == 2) {
+        if (s.fwd.kind == 2 && s.batch) {
+            // the same launches with item sizes and batch strides (the transposed pattern is per item: t_ptr [b][m+1], t_idx / t_perm [b][nnz])
+            const int64_t gs = s.item_rows * s.p, bs = s.item_cols * s.p;
+            if (need_a && need_b && s.fused_backward) {
+                gv = at::empty({s.batch, s.item_nnz}, val.options());
+                gradB = at::empty({s.batch, s.item_cols, s.p}, G.options());
+                check(tsgu_csr_mm_backward(s.vtype, s.itype, s.item_rows, s.item_cols, s.item_nnz, s.t_ptr.data_ptr(), s.t_idx.data_ptr(),
+                                           s.t_perm.data_ptr(), val.data_ptr(), G.data_ptr(), s.p, gs, B.data_ptr(), s.p, bs, gv.data_ptr(),
+                                           gradB.data_ptr(), s.p, bs, s.p, s.batch, s.device, stream_of(s.device)),
+                      "tsgu_csr_mm_backward");
+            } else {
+                if (need_a) {
+                    gv = at::empty({s.batch, s.item_nnz}, val.options());
+                    check(tsgu_csr_sddmm(s.vtype, s.itype, s.item_rows, s.item_cols, s.item_nnz, s.crow.data_ptr(), s.col.data_ptr(), G.data_ptr(), s.p,
+                                         gs, B.data_ptr(), s.p, bs, gv.data_ptr(), 1.0, 0, s.p, s.batch, s.device, stream_of(s.device)),
+                          "tsgu_csr_sddmm");
+                }
+                if (need_b) {
+                    gradB = at::empty({s.batch, s.item_cols, s.p}, G.options());
+                    check(tsgu_csr_spmm(s.vtype, s.itype, s.item_cols, s.item_rows, s.item_nnz, s.t_ptr.data_ptr(), s.t_idx.data_ptr(), val.data_ptr(),
+                                        s.t_perm.data_ptr(), G.data_ptr(), s.p, 1, gs, gradB.data_ptr(), s.p, 1, bs, s.p, s.batch, s.t_max_row_nnz,
+                                        nullptr, 0, nullptr, s.device, stream_of(s.device)),
+                          "tsgu_csr_spmm");
+                }
+            }
+        } else if (s.fwd.kind == 2) {
             if (need_a && need_b && s.fused_backward) {
                 // both gradients in one pass over the transposed pattern: every upstream row is gathered once (reference :172-229)
                 gv = at::empty({s.nnz}, val.options());
@@ -194,8 +226,8 @@ at::Tensor step(const at::Tensor& A, const at::Tensor& B, StepPlanPtr handle) {
     const StepPlan& s = *handle;
     // (Python has validated layout / dims / dtypes / device; these are the conditions of the raw-pointer launches)
     if (s.batch) {
-        TORCH_CHECK(A.layout() == at::kSparseCsr && A.dim() == 3 && A.size(0) == s.batch && A.size(1) == s.item_rows && A.size(2) == s.item_cols &&
-                        s.fwd.kind != 2, "step plan of another (batched) matrix");
+        TORCH_CHECK(A.layout() == at::kSparseCsr && A.dim() == 3 && A.size(0) == s.batch && A.size(1) == s.item_rows && A.size(2) == s.item_cols,
+                    "step plan of another (batched) matrix");
         TORCH_CHECK(plain3(B, s.batch, s.item_cols, s.p), "the fast step takes a contiguous, 16-byte aligned (batch, n_cols, p) operand");
         return StepFunction::apply(A, B, std::move(handle));
     }

@@ -109,8 +109,10 @@ def _settle_step_plan(op: "_Operand", values: torch.Tensor, G: torch.Tensor, B: 
         # batched CSR (torch layout, equal nnz per item): the structured kernels see ONE block-diagonal problem (_pattern.flat_of);
         # the step plan describes that problem and keeps the batch shape of the tensors (one GPU's share of BASELINE configs[4] is
         # 0.14 ms of kernels per step: a Python host path of 0.08-0.26 ms would be what the sharded job waits for)
-        if B.dim() != 3 or not (B.is_contiguous() and G.is_contiguous()) or plan.core.flat is None:
-            return                          # (the flat view exists when the structured kernels have taken the batch; never made here)
+        if B.dim() != 3 or not (B.is_contiguous() and G.is_contiguous()):
+            return
+        if plan.core.flat is None:          # (the flat view exists when the structured kernels have looked at the batch; never made here)
+            return _settle_batched_plan_free(op, own, dtype, p, B, G)
         plan = plan.core.flat
     elif B.dim() != 2:
         return
@@ -138,7 +140,9 @@ def _settle_step_plan(op: "_Operand", values: torch.Tensor, G: torch.Tensor, B: 
             b = op.plan.batch
             sp.set_batch(b, op.plan.n_rows, op.plan.n_cols, op.plan.nnz)
     elif batched:
-        return                              # (batched operands off a lattice: the Python path)
+        if got is not None and any(g is not None for g in got):
+            return                          # (a lattice whose configurations are still being chosen)
+        return _settle_batched_plan_free(op, own, dtype, p, B, G)
     else:
         # no lattice: is the step on the plan-free kernels for good?  (not while a row-pair plan may still arrive)
         if got is not None and any(g is not None for g in got):
@@ -172,6 +176,42 @@ def _settle_step_plan(op: "_Operand", values: torch.Tensor, G: torch.Tensor, B: 
                              bool(_be.fused_backward_supported(dtype, p)))
     if op.layout != torch.sparse_csr:
         sp.set_coo(op.indices)
+    if plans is None:
+        plans = own["step_plans"] = {}
+    plans[key] = sp
+
+
+def _settle_batched_plan_free(op: "_Operand", own: dict, dtype, p: int, B: torch.Tensor, G: torch.Tensor) -> None:
+    """Batched CSR operands off a lattice (the reference's own batched benchmark shape: 128 items of 1024 x 1024 with 4096 random
+    entries, benchmarks/results/batched_sparse_mm_rand_results.csv:31 — 0.07 ms of kernels per step against 0.24-0.30 ms of Python):
+    once no structured plan can arrive any more, the step is the plan-free batched kernels + the per-item transposed pattern, issued
+    by csrc/host/step.cpp (reference sparse_matmul.py:151-153 assembles a block-diagonal matrix per call instead)."""
+    plan = op.plan
+    plans = own.get("step_plans")
+    key = _step_key(dtype, p)
+    if plans is not None and key in plans:
+        return
+    seen = own["step_settle_calls"] = own.get("step_settle_calls", 0) + 1
+    if dtype not in (torch.float32, torch.bfloat16, torch.float64) or seen <= _ops.PLAN_AFTER_USES + 2:
+        return
+    flat = plan.core.flat
+    t = plan.transposed
+    cores = [plan.core, t.core] + ([flat.core] + ([flat.core.t.core] if flat.core.t is not None else []) if flat is not None else [])
+    if any(not f.done() for c in cores for f in list(c.pending.values())):
+        return                              # (a row-pair plan of the block-diagonal problem is still being built)
+    if any(v is not None for c in cores for v in c.packs.values()):
+        return                              # (the Python path runs this batch on the row-pair kernels)
+    if flat is not None and _ops.ENABLE_LATTICE and flat.core.own.get("lattice") is not None:
+        return                              # (a lattice: settled by the caller once its configurations are final)
+    if not (plan.crow.is_contiguous() and plan.col.is_contiguous() and t.crow.is_contiguous() and t.col.is_contiguous()
+            and t.perm is not None and t.perm.is_contiguous()):
+        return
+    b, n, m, nnz = plan.batch, plan.n_rows, plan.n_cols, plan.nnz
+    none = (2, b"", 0)
+    sp = _host.StepPlan(plan.crow, plan.col, b * n, b * m, b * nnz, p, _be._VTYPE[dtype], plan.crow.device.index, none, none, none, [])
+    sp.set_plan_free(_be.itype_of(plan.crow), t.crow, t.col, t.perm, int(plan.max_row_nnz), int(t.max_row_nnz),
+                     bool(_be.fused_backward_supported(dtype, p)))
+    sp.set_batch(b, n, m, nnz)
     if plans is None:
         plans = own["step_plans"] = {}
     plans[key] = sp
