@@ -338,9 +338,10 @@ def patterns_leg(dev, steps, warmup, headline):
     from torchsparsegradutils_amd import _ops, _pattern, sparse_mm, wait_for_plans
     from torchsparsegradutils_amd.utils import synthetic
 
-    wire = {}
+    wire, roofs, roof_commit = {}, {}, None
     try:
-        wire = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json"))).get("patterns", {})
+        tj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
+        wire, roofs, roof_commit = tj.get("patterns", {}), tj.get("pattern_rooflines", {}), tj.get("commit")
     except Exception:  # noqa: BLE001
         wire = {}
     out = {"c2_27pt_periodic": headline}
@@ -407,6 +408,10 @@ def patterns_leg(dev, steps, warmup, headline):
                          "ms_per_step_device": round(ms_dev, 5), "frac_device": round(ab / (ms_dev * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                          "algorithmic_bytes_per_step": ab, "frac": round(ab / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                          "traffic": tr, "frac_wire": None if tr is None else round(tr / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            if name in roofs:
+                # the pattern's DOMINANT kernel: launch duration from the pattern's own rocprofv3 --stats pass, HBM bytes from its two
+                # PMC passes (tracked under profiles/, derived by tools/collect_profiles.py: durations of this run are the fields above)
+                out[name]["roofline"] = dict(roofs[name]["dominant"], source=roofs[name]["source"], commit=roof_commit)
             del A, B, G, crow, col, plan, lp
         except Exception as exc:  # noqa: BLE001  (never lose the headline line to a secondary leg)
             out[name] = {"what": what, "error": repr(exc)}

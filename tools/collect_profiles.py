@@ -13,7 +13,7 @@ import subprocess
 import sys
 from collections import defaultdict
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r06"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(root, "profiles")
@@ -94,15 +94,97 @@ def pattern_step_bytes(pdir):
     return total, [n.split("(")[0][:90] for n in per["fetch"][1]]
 
 
-patterns, pattern_kernels = {}, {}
+def kernel_kind(kname):
+    """forward / sddmm / transposed / fused_backward of a step's kernel, from its template arguments."""
+    args = kname.split("<", 1)[1].split(">")[0].replace(" ", "").split(",") if "<" in kname else []
+    if "march_kernel" in kname:
+        return {"0": "forward", "1": "sddmm", "2": "transposed"}.get(args[2])
+    if "lattice_kernel" in kname:
+        return {"0": "forward", "1": "sddmm", "2": "transposed"}.get(args[3])
+    if "tile_kernel" in kname:      # <V, CL, MODE, PERM, WIDE>
+        return "sddmm" if args[2] == "1" else ("transposed" if args[3] == "true" else "forward")
+    if "csr_mm_backward_kernel" in kname or ("csr_rowpack_kernel" in kname and args[4] == "1"):
+        return "fused_backward"
+    if "csr_sddmm_kernel" in kname or ("csr_rowpack_kernel" in kname and args[4] == "2"):
+        return "sddmm"
+    if "csr_spmm_kernel" in kname or "csr_rowpack_kernel" in kname:
+        return "transposed" if args[5] == "true" else "forward"
+    return None
+
+
+def pattern_roofline(pdir, key):
+    """Per kernel of a pattern's step: average launch duration (the pattern's own rocprofv3 --stats pass), HBM bytes per launch
+    (its two PMC passes, 2*FETCH_SIZE + WRITE_SIZE), algorithmic bytes (from the n / nnz / p the run printed) -> the
+    roofline block of the DOMINANT (longest) kernel and the list of all of them."""
+    geo = None
+    try:
+        for line in open(os.path.join(src, f"pat_{key}.stats.log")):
+            w = line.split()
+            if len(w) == 4 and w[0] == key and all(x.isdigit() for x in w[1:]):
+                geo = tuple(int(x) for x in w[1:])
+    except OSError:
+        return None
+    hits = glob.glob(os.path.join(pdir, "stats", "**", "*kernel_stats.csv"), recursive=True)
+    if geo is None or not hits:
+        return None
+    n, nnz, p = geo
+    idx, row_b = (n + 1) * 4 + nnz * 4, n * p * 4
+    alg = {"forward": idx + nnz * 4 + 2 * row_b, "transposed": idx + nnz * 4 + 2 * row_b, "sddmm": idx + 2 * row_b + nnz * 4,
+           "fused_backward": idx + nnz * 4 + 3 * row_b + nnz * 4}
+    stats = {r["Name"]: r for r in csv.DictReader(open(hits[0])) if "tsgu::" in r["Name"]}
+    pmc = defaultdict(lambda: defaultdict(list))
+    for kind, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+        for f in glob.glob(os.path.join(pdir, kind, "**", "*counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                if r["Counter_Name"] == counter:
+                    pmc[r["Kernel_Name"]][counter].append(float(r["Counter_Value"]))
+    kernels = []
+    for name, r in stats.items():
+        kind = kernel_kind(name)
+        calls = int(r["Calls"])
+        if kind is None or calls < 50:          # (first-sight / plan kernels of the warm-up are not the step)
+            continue
+        d = pmc.get(name, {})
+        traffic = None
+        if d.get("FETCH_SIZE") and d.get("WRITE_SIZE"):
+            # the launches of the last steps (the plan-free first steps launch other kernels; a kernel that serves both uses the later half)
+            fs, ws = d["FETCH_SIZE"], d["WRITE_SIZE"]
+            fs, ws = fs[len(fs) // 2:], ws[len(ws) // 2:]
+            traffic = int((2 * sum(fs) / len(fs) + sum(ws) / len(ws)) * 1024)
+        ms = float(r["AverageNs"]) / 1e6
+        kernels.append({"kernel": name.split("(")[0][:100], "kind": kind, "calls": calls, "avg_launch_ms": round(ms, 5),
+                        "algorithmic_bytes": alg[kind], "frac": round(alg[kind] / (ms * 1e-3) / 1e9 / 8000.0, 4), "traffic": traffic,
+                        "frac_wire": None if traffic is None else round(traffic / (ms * 1e-3) / 1e9 / 8000.0, 4)})
+    if not kernels:
+        return None
+    kernels.sort(key=lambda k: -k["avg_launch_ms"])
+    return {"n": n, "nnz": nnz, "rhs": p, "dominant": kernels[0], "kernels": kernels,
+            "source": f"profiles/{tag}_pattern_stats/{key}_kernel_stats.csv + profiles/{tag}_pmc_patterns/{key}_{{fetch,write}}.csv"}
+
+
+patterns, pattern_kernels, pattern_roof = {}, {}, {}
+os.makedirs(os.path.join(dst, f"{tag}_pmc_patterns"), exist_ok=True)
+os.makedirs(os.path.join(dst, f"{tag}_pattern_stats"), exist_ok=True)
 for pdir in sorted(glob.glob(os.path.join(src, "pat_*"))):
     if not os.path.isdir(pdir):
         continue
+    key = os.path.basename(pdir)[4:]
+    # the raw evidence, tracked: the pattern's two counter passes and its kernel statistics
+    for kind in ("fetch", "write"):
+        for f in glob.glob(os.path.join(pdir, kind, "**", "*counter_collection.csv"), recursive=True):
+            shutil.copy(f, os.path.join(dst, f"{tag}_pmc_patterns", f"{key}_{kind}.csv"))
+    for f in glob.glob(os.path.join(pdir, "stats", "**", "*kernel_stats.csv"), recursive=True):
+        rows = list(csv.reader(open(f)))
+        csv.writer(open(os.path.join(dst, f"{tag}_pattern_stats", f"{key}_kernel_stats.csv"), "w", newline="")).writerows(
+            [rows[0]] + [r for r in rows[1:] if any("tsgu::" in c for c in r)])
     got = pattern_step_bytes(pdir)
+    name = "c2_27pt_periodic" if key == "headline" else key
     if got is not None:
-        key = os.path.basename(pdir)[4:]
-        patterns["c2_27pt_periodic" if key == "headline" else key] = got[0]
+        patterns[name] = got[0]
         pattern_kernels[key] = got[1]
+    roof = pattern_roofline(pdir, key)
+    if roof is not None:
+        pattern_roof[name] = roof
 
 traffic, raw = {}, {}
 for k, d in acc.items():
@@ -135,6 +217,7 @@ if traffic or patterns:
         "plan_form": form,
         **traffic,
         "patterns": patterns,
+        "pattern_rooflines": pattern_roof,
         "_pattern_kernels": pattern_kernels,
         "_raw": raw,
         "_algorithmic": {"lattice_spmm": 476000004, "lattice_sddmm": 476000004, "lattice_spmm_t": 476000004, "forward": 476000004,
@@ -163,6 +246,9 @@ if os.path.exists(saved) and os.path.exists(os.path.join(dst, "hbm_traffic.json"
         if name in pats and "ms_per_step" in pats[name]:
             pats[name]["traffic"] = bytes_
             pats[name]["frac_wire"] = round(bytes_ / (pats[name]["ms_per_step"] * 1e-3) / 1e9 / peak, 4)
+    for name, roof_ in (tj.get("pattern_rooflines") or {}).items():
+        if name in pats and isinstance(pats[name], dict):
+            pats[name]["roofline"] = dict(roof_["dominant"], source=roof_["source"], commit=tj.get("commit"))
     if "c2_27pt_periodic" in (tj.get("patterns") or {}):
         line["step_traffic"] = tj["patterns"]["c2_27pt_periodic"]
         line["frac_of_hbm_peak_wire"] = round(line["step_traffic"] / (line["ms_per_step"] * 1e-3) / 1e9 / peak, 4)

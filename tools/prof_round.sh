@@ -5,7 +5,7 @@
 #   3. the un-profiled bench line and the secondary configurations               -> gpurun_out/prof_<tag>/*.json(l)
 # Copy the summaries into profiles/ with tools/collect_profiles.py afterwards.
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
@@ -19,6 +19,8 @@ for pass in "fetch FETCH_SIZE" "write WRITE_SIZE"; do
 done
 # per-pattern HBM bytes per step (bench.py's `patterns` block): the same two passes around a few steps of each pattern
 for pat in headline c2_7pt_periodic c2_27pt_truncated c2_27pt_truncated_lower mesh27_blocked cfd2_shaped cfd2_mesh; do
+  # (durations of the pattern's kernels: their own --stats pass, 100 steps — counters and timing never share a run)
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/pat_$pat/stats -o s -- python3 $ROOT/tools/pattern_steps.py $pat 100 > $OUT/pat_$pat.stats.log 2>&1
   for pass in "fetch FETCH_SIZE" "write WRITE_SIZE"; do
     set -- $pass
     timeout 600 rocprofv3 --kernel-trace --pmc $2 --kernel-include-regex "tsgu::" --output-format csv \
