@@ -10,6 +10,7 @@ the row-pair plans are translation-deduplicated, so items that share a pattern a
 from __future__ import annotations
 
 import os
+import threading
 
 import torch
 
@@ -52,6 +53,38 @@ ENABLE_LATTICE = os.environ.get("TSGU_ENABLE_LATTICE", "1") == "1"
 LATTICE_DTYPES = (torch.float32, torch.bfloat16, torch.float64)
 # measured launch configurations: every trial launch follows a 256 MB device copy (the cache state of a step, not of a back-to-back loop)
 TUNE_COLD = os.environ.get("TSGU_TUNE_COLD", "1") != "0"
+
+
+# ---- what a step launched ----------------------------------------------------------------------------------------------------------
+# The order of preference between the kernel families (lattice -> batched row pairs -> row-block tiles -> row pairs -> plan-free) is
+# written down ONCE, in spmm() / mm_backward() below.  The step's C++ host path (sparse_matmul._settle_step_plan) does not decide
+# anything a second time: the entry points NOTE what they launched — family and the plan objects — with the pattern, and the host
+# path is derived from notes that have stopped changing.  (Round 5 re-derived the decision there and a finished-but-unclaimed
+# row-pair future kept every tile pattern off the C++ path.)
+_CHOICE = threading.local()
+
+
+def _chose(family: str, *payload) -> None:
+    """What the product that is about to be launched runs on (read by mm_backward_separate right after the call, same thread)."""
+    _CHOICE.last = (family, payload)
+
+
+def _note(plan: RowGather, product: str, dense: torch.Tensor, family: str, *payload) -> None:
+    own = plan.core.own
+    sig = (dense.dtype, dense.size(-1))          # a pattern may be used with operands of several types and widths: a note is about ONE
+    prev = own.get("launched_" + product)
+    same = (prev is not None and prev[0] == family and prev[3] == sig and len(prev[1]) == len(payload)
+            and all(a is b for a, b in zip(prev[1], payload)))
+    own["launched_" + product] = (family, payload, (prev[2] + 1) if same else 1, sig)
+
+
+def launched(plan: RowGather, product: str, dtype=None, p: int = 0):
+    """(family, payload, consecutive steps with this very choice, (dtype, p)) of the last `product` ("fwd" / "bwd") on the pattern —
+    None when there is none or (dtype given) when it was made with operands of another type or width."""
+    got = plan.core.own.get("launched_" + product)
+    if got is not None and dtype is not None and got[3] != (dtype, p):
+        return None
+    return got
 
 
 def _lattice_plan(plan: RowGather, transposed: bool = False):
@@ -296,6 +329,7 @@ def _lattice_backward(plan: RowGather, values: torch.Tensor, G: torch.Tensor, B:
         return None
     ga = _be.csr_sddmm_lattice(fwd[0], fwd[1], Gf, Bf)
     gb = _be.csr_spmm_lattice(bwd[0], bwd[1], vals, Gf)
+    _note(plan, "bwd", G, "lattice", fwd[0], fwd[1], bwd[0], bwd[1])
     return ga.view(values.shape), gb.view(B.shape)
 
 
@@ -315,20 +349,25 @@ def mm_backward(plan: RowGather, values: torch.Tensor, G: torch.Tensor, B: torch
             rp = _pack_for(fplan.transposed, Gf, Bf)
             if rp is not None:
                 ga, gb = _be.csr_mm_backward_rowpack(fplan.transposed.crow, rp, values.reshape(-1), Gf, Bf, fplan.n_cols)
+                _note(plan, "bwd", G, "row pairs", rp)
                 return ga.view(values.shape), gb.view(B.shape)
     t = plan.transposed
     if same and plan.batch is None and plan.perm is None:
         # row-block tiles: the SDDMM in stored order + the transposed product on the transposed pattern's tiles (A's own values)
         tp, tt = _tile_for(plan, B, G), _tile_for(t, G)
         if tp is not None and tt is not None:
+            _note(plan, "bwd", G, "tiles", tp, tt)
             return _be.csr_sddmm_tile(tp, G, B), _be.csr_spmm_tile(tt, values, G)
     rp = _pack_for(t, G, B) if same else None
     if rp is not None and rp.srcstart is not None and plan.batch is None and plan.perm is None:
         # the transposed plan reached the dictionary form through row-relative value positions (mesh orderings): the SDDMM on the
         # stored-order plan + the transposed product beat the fused walk (mesh27_blocked: 124 + 208 us against 417 us)
+        _note(plan, "bwd", G, "row pairs", rp)
         return sddmm(plan, G, B), spmm(t, values, G, owner=plan)
     if rp is not None:
+        _note(plan, "bwd", G, "row pairs", rp)
         return _be.csr_mm_backward_rowpack(t.crow, rp, values, G, B, t.n_rows)
+    _note(plan, "bwd", G, "plan-free", t)
     return _be.csr_mm_backward(t, values, G, B, plan.n_rows, plan.n_cols)
 
 
@@ -350,6 +389,9 @@ def spmm(plan: RowGather, values: torch.Tensor, B: torch.Tensor, owner: RowGathe
                 got = _lattice_cfg(fsrc, _be.LAT_SPMM if stored else _be.LAT_SPMMT, Bf)
             if got is not None:
                 out = _be.csr_spmm_lattice(got[0], got[1], values.reshape(-1), Bf)
+                _chose("lattice", got[0], got[1])
+                if stored:
+                    _note(plan, "fwd", B, "lattice", got[0], got[1])
                 return out.view(B.shape[:-2] + (plan.n_rows, B.size(-1)))
         if plan.batch is not None and ENABLE_PACK:
             fl = _flat(plan, B)
@@ -358,13 +400,21 @@ def spmm(plan: RowGather, values: torch.Tensor, B: torch.Tensor, owner: RowGathe
                 rp = _pack_for(fplan, Bf)
                 if rp is not None:
                     out = _be.csr_spmm_rowpack(fplan.crow, values.reshape(-1), rp, Bf, fplan.n_rows)
+                    _chose("row pairs", rp)
+                    _note(plan, "fwd", B, "row pairs", rp)
                     return out.view(B.size(0), plan.n_rows, B.size(-1))
         tp = _tile_for(plan, B)
         if tp is not None:
+            _chose("tiles", tp)
+            _note(plan, "fwd", B, "tiles", tp)
             return _be.csr_spmm_tile(tp, values, B)
         rp = _pack_for(plan, B)
         if rp is not None:
+            _chose("row pairs", rp)
+            _note(plan, "fwd", B, "row pairs", rp)
             return _be.csr_spmm_rowpack(plan.crow, values, rp, B, plan.n_rows)
+    _chose("plan-free", plan)
+    _note(plan, "fwd", B, "plan-free")
     return _be.csr_spmm(plan.crow, plan.col, values, B, plan.n_rows, plan.n_cols, perm=plan.perm, max_row_nnz=plan.max_row_nnz)
 
 
@@ -381,6 +431,7 @@ def spmm_t(owner: RowGather, values: torch.Tensor, G: torch.Tensor) -> torch.Ten
         got = _lattice_cfg(fsrc, _be.LAT_SPMMT, Gf) if fsrc is not None else None
         if got is not None:
             out = _be.csr_spmm_lattice(got[0], got[1], values.reshape(-1), Gf)
+            _chose("lattice", got[0], got[1])
             return out.view(G.shape[:-2] + (owner.n_cols, G.size(-1)))
     return spmm(owner.transposed, values, G, owner=owner)
 
@@ -394,11 +445,27 @@ def sddmm(plan: RowGather, G: torch.Tensor, B: torch.Tensor, alpha: float = 1.0,
     if plan.perm is None and G.dtype == B.dtype:
         got = _lattice_cfg(plan, _be.LAT_SDDMM, gathered, rowop)
         if got is not None:
+            _chose("lattice", got[0], got[1])
             return _be.csr_sddmm_lattice(got[0], got[1], rowop, gathered, alpha=alpha)
         tp = _tile_for(plan, gathered, rowop)
         if tp is not None:
+            _chose("tiles", tp)
             return _be.csr_sddmm_tile(tp, rowop, gathered, alpha=alpha)
         rp = _pack_for(plan, gathered, rowop, need_plain_slots=True)
         if rp is not None and rp.upos is None:
+            _chose("row pairs", rp)
             return _be.csr_sddmm_rowpack(plan.crow, rp, rowop, gathered, plan.n_rows, alpha=alpha)
+    _chose("plan-free")
     return _be.csr_sddmm(plan.crow, plan.col, G, B, plan.n_rows, plan.n_cols, alpha=alpha, swap_roles=swap_roles)
+
+
+def mm_backward_separate(plan: RowGather, values: torch.Tensor, G: torch.Tensor, B: torch.Tensor):
+    """(gradA values in A's order, gradB) as TWO products — the SDDMM in stored order and Aᵀ·G — for operands the fused walk is not
+    compiled for (fp64, very wide rows).  Noted like mm_backward when both products ran on the same family."""
+    ga = sddmm(plan, G, B)
+    a = getattr(_CHOICE, "last", None)
+    gb = spmm_t(plan, values, G)
+    b = getattr(_CHOICE, "last", None)
+    if G.is_cuda and a is not None and b is not None and a[0] == b[0]:
+        _note(plan, "bwd", G, a[0], *(a[1] + b[1]))
+    return ga, gb

@@ -94,10 +94,17 @@ def _step_plan(A: torch.Tensor, B: torch.Tensor):
     return plans.get(_step_key(B.dtype, B.size(-1)))
 
 
+# consecutive steps a pattern has to launch the very same plans before the C++ host path takes the step over
+SETTLE_AFTER = 2
+
+
 def _settle_step_plan(op: "_Operand", values: torch.Tensor, G: torch.Tensor, B: torch.Tensor) -> None:
-    """After a step on the Python path (2-D operand, both gradients): when what the step launches is FINAL, describe it to the C++
-    host path — the three configurations of a lattice stencil (the StepPlan copies the plan structs and holds every device table
-    they point into), or the plan-free kernels with the cached transposed pattern once the row-pair plans are known not to apply."""
+    """After a step on the Python path (both gradients): when what the step launches has stopped changing, describe it to the C++ host
+    path (csrc/host/step.cpp).  Nothing is DECIDED here: `_ops.spmm` / `_ops.mm_backward` note the family and the plan objects they
+    launched with the pattern (`_ops.launched`); this function only waits until forward and backward have made the same choice
+    SETTLE_AFTER steps in a row with no plan build in flight, and then wraps exactly those objects — the three configurations of a
+    lattice stencil (the StepPlan copies the plan structs and holds every device table they point into), the two tile plans, or the
+    plan-free kernels with the cached transposed pattern."""
     plan = op.plan
     if (_host is None or not FAST_STEP or not B.is_cuda or not plan.crow.is_cuda or plan.perm is not None or op.flat_batch is not None
             or not (values.dtype == G.dtype == B.dtype) or (op.layout != torch.sparse_csr and op.indices is None)):
@@ -105,27 +112,33 @@ def _settle_step_plan(op: "_Operand", values: torch.Tensor, G: torch.Tensor, B: 
     dtype, p = G.dtype, G.size(-1)
     own = plan.core.own
     batched = plan.batch is not None
-    if batched:
-        # batched CSR (torch layout, equal nnz per item): the structured kernels see ONE block-diagonal problem (_pattern.flat_of);
-        # the step plan describes that problem and keeps the batch shape of the tensors (one GPU's share of BASELINE configs[4] is
-        # 0.14 ms of kernels per step: a Python host path of 0.08-0.26 ms would be what the sharded job waits for)
-        if B.dim() != 3 or not (B.is_contiguous() and G.is_contiguous()):
-            return
-        if plan.core.flat is None:          # (the flat view exists when the structured kernels have looked at the batch; never made here)
-            return _settle_batched_plan_free(op, own, dtype, p, B, G)
-        plan = plan.core.flat
-    elif B.dim() != 2:
+    if B.dim() != (3 if batched else 2) or not (B.is_contiguous() and G.is_contiguous()):
         return
     plans = own.get("step_plans")
     key = _step_key(dtype, p)
     if plans is not None and key in plans:
         return
+    fwd, bwd = _ops.launched(plan, "fwd", dtype, p), _ops.launched(plan, "bwd", dtype, p)       # (notes of THIS operand type and width only)
+    if fwd is None or bwd is None or fwd[0] != bwd[0] or min(fwd[2], bwd[2]) < SETTLE_AFTER:
+        return                              # (forward and backward on different families, or a choice that is still changing)
+    family = fwd[0]
+    flat = plan.core.flat if batched else plan
+    cores = [plan.core] + ([plan.core.t.core] if plan.core.t is not None else [])
+    if batched and flat is not None:
+        cores += [flat.core] + ([flat.core.t.core] if flat.core.t is not None else [])
+    if any(not f.done() for c in cores for f in list(c.pending.values())):
+        return                              # (a plan is still being built: the choice may change when it arrives)
     dev = plan.crow.device
-    memo = plan.core.own.get("lattice_memo") if _ops.ENABLE_LATTICE else None      # (of the flat problem when batched)
-    got = None if memo is None else [memo.get((mode, dtype, p, True, _ops._lt.ENABLE_MARCH)) for mode in (_be.LAT_SPMM, _be.LAT_SDDMM, _be.LAT_SPMMT)]
-    if got is not None and all(g is not None for g in got):
-        prods, tables = [], [plan.crow, plan.col]
-        for mode, (lp, cfg) in zip((_be.LAT_SPMM, _be.LAT_SDDMM, _be.LAT_SPMMT), got):
+    vt = _be._VTYPE[dtype]
+    if family == "lattice":
+        if flat is None:
+            return
+        (lpf, cf), (lps, cs, lpt, ct) = fwd[1], bwd[1]
+        if _ops._lt.TUNE and not torch.are_deterministic_algorithms_enabled() and not all(
+                getattr(c, "march", False) or c.tuned for c in (cf, cs, ct)):
+            return                          # (a sweep configuration that is still to be measured: _ops._lattice_cfg)
+        prods, tables = [], [flat.crow, flat.col]
+        for mode, lp, cfg in ((_be.LAT_SPMM, lpf, cf), (_be.LAT_SDDMM, lps, cs), (_be.LAT_SPMMT, lpt, ct)):
             blob = ctypes.string_at(cfg.struct_addr, ctypes.sizeof(cfg.struct))     # sizes + device pointers into the tables below
             if getattr(cfg, "march", False):
                 if cfg.col_tile != p:
@@ -134,84 +147,40 @@ def _settle_step_plan(op: "_Operand", values: torch.Tensor, G: torch.Tensor, B: 
             else:
                 prods.append((1, blob, 0))
             tables += _tensors_of(lp) + _tensors_of(cfg)
-        sp = _host.StepPlan(plan.crow, plan.col, plan.n_rows, plan.n_cols, plan.nnz, p, _be._VTYPE[dtype], dev.index,
-                            prods[0], prods[1], prods[2], tables)
+        sp = _host.StepPlan(flat.crow, flat.col, flat.n_rows, flat.n_cols, flat.nnz, p, vt, dev.index, prods[0], prods[1], prods[2], tables)
         if batched:
-            b = op.plan.batch
-            sp.set_batch(b, op.plan.n_rows, op.plan.n_cols, op.plan.nnz)
-    elif batched:
-        if got is not None and any(g is not None for g in got):
-            return                          # (a lattice whose configurations are still being chosen)
-        return _settle_batched_plan_free(op, own, dtype, p, B, G)
+            sp.set_batch(plan.batch, plan.n_rows, plan.n_cols, plan.nnz)
+    elif family == "tiles" and not batched:
+        # forward and SDDMM on the stored pattern's plan, Aᵀ·G on the transposed pattern's (its chunks read A's own values)
+        (tpf,), (tp, tt) = fwd[1], bwd[1]
+        if tpf is not tp:
+            return
+        blob = lambda q: ctypes.string_at(_be._tile_struct(q), ctypes.sizeof(_TilePlanStruct))      # noqa: E731
+        sp = _host.StepPlan(plan.crow, plan.col, plan.n_rows, plan.n_cols, plan.nnz, p, vt, dev.index,
+                            (3, blob(tp), 0), (3, blob(tp), 0), (3, blob(tt), 1), [plan.crow, plan.col] + _tensors_of(tp) + _tensors_of(tt))
+    elif family == "plan-free":
+        # the step is on the plan-free kernels for good only once every structured plan has been asked for and has not come: the
+        # pattern has to come back a few times (its row-pair / tile plans are requested on the way, _ops.PLAN_AFTER_USES)
+        if dtype not in (torch.float32, torch.bfloat16, torch.float64) or fwd[2] <= _ops.PLAN_AFTER_USES + 2:
+            return
+        (t,) = bwd[1]
+        if not (plan.crow.is_contiguous() and plan.col.is_contiguous() and t.crow.is_contiguous() and t.col.is_contiguous()
+                and t.perm is not None and t.perm.is_contiguous()):
+            return
+        none = (2, b"", 0)
+        b = plan.batch or 1
+        sp = _host.StepPlan(plan.crow, plan.col, b * plan.n_rows, b * plan.n_cols, b * plan.nnz, p, vt, dev.index, none, none, none, [])
+        sp.set_plan_free(_be.itype_of(plan.crow), t.crow, t.col, t.perm, int(plan.max_row_nnz), int(t.max_row_nnz),
+                         bool(_be.fused_backward_supported(dtype, p)))
+        if batched:
+            # (batched operands off a lattice — the reference's own batched benchmark shape, 128 items of 1024 x 1024 with 4096 random
+            # entries, benchmarks/results/batched_sparse_mm_rand_results.csv:31: 0.07 ms of kernels per step against 0.24-0.30 ms of Python;
+            # the kernels take the batch as it is: item strides, per-item transposed pattern)
+            sp.set_batch(plan.batch, plan.n_rows, plan.n_cols, plan.nnz)
     else:
-        # no lattice: is the step on the plan-free kernels for good?  (not while a row-pair plan may still arrive)
-        if got is not None and any(g is not None for g in got):
-            return                          # (a lattice whose configurations are still being chosen)
-        seen = own["step_settle_calls"] = own.get("step_settle_calls", 0) + 1
-        if dtype not in (torch.float32, torch.bfloat16, torch.float64) or seen <= _ops.PLAN_AFTER_USES + 2:
-            return                          # (the pattern has to come back a few times: its row-pair plans are asked for on the way)
-        if _ops.ENABLE_LATTICE and _ops._lattice_cfg(plan, _be.LAT_SPMM, B) is not None:
-            return
-        t = plan.transposed
-        if any(not f.done() for f in list(plan.core.pending.values()) + list(t.core.pending.values())):
-            return                          # (a plan is still being built; finished ones wait in `pending` until somebody asks for them)
-        tp, tt = _ops._tile_for(plan, B, G), _ops._tile_for(t, G)
-        if tp is not None and tt is not None:
-            # row-block tiles (what _ops.spmm / _ops.mm_backward launch for this pattern): forward and SDDMM on the stored pattern's
-            # plan, Aᵀ·G on the transposed pattern's (its `perm` reads A's own values)
-            if not (B.is_contiguous() and G.is_contiguous()):
-                return
-            blob = lambda q: ctypes.string_at(_be._tile_struct(q), ctypes.sizeof(_TilePlanStruct))      # noqa: E731
-            sp = _host.StepPlan(plan.crow, plan.col, plan.n_rows, plan.n_cols, plan.nnz, p, _be._VTYPE[dtype], dev.index,
-                                (3, blob(tp), 0), (3, blob(tp), 0), (3, blob(tt), 1), [plan.crow, plan.col] + _tensors_of(tp) + _tensors_of(tt))
-        elif tp is not None or tt is not None or _ops._pack_for(plan, B) is not None or _ops._pack_for(t, G, B) is not None:
-            return
-        else:
-            if not (B.is_contiguous() and G.is_contiguous() and plan.crow.is_contiguous() and plan.col.is_contiguous()
-                    and t.crow.is_contiguous() and t.col.is_contiguous() and t.perm is not None and t.perm.is_contiguous()):
-                return
-            none = (2, b"", 0)
-            sp = _host.StepPlan(plan.crow, plan.col, plan.n_rows, plan.n_cols, plan.nnz, p, _be._VTYPE[dtype], dev.index, none, none, none, [])
-            sp.set_plan_free(_be.itype_of(plan.crow), t.crow, t.col, t.perm, int(plan.max_row_nnz), int(t.max_row_nnz),
-                             bool(_be.fused_backward_supported(dtype, p)))
+        return                              # (row pairs: the Python path)
     if op.layout != torch.sparse_csr:
         sp.set_coo(op.indices)
-    if plans is None:
-        plans = own["step_plans"] = {}
-    plans[key] = sp
-
-
-def _settle_batched_plan_free(op: "_Operand", own: dict, dtype, p: int, B: torch.Tensor, G: torch.Tensor) -> None:
-    """Batched CSR operands off a lattice (the reference's own batched benchmark shape: 128 items of 1024 x 1024 with 4096 random
-    entries, benchmarks/results/batched_sparse_mm_rand_results.csv:31 — 0.07 ms of kernels per step against 0.24-0.30 ms of Python):
-    once no structured plan can arrive any more, the step is the plan-free batched kernels + the per-item transposed pattern, issued
-    by csrc/host/step.cpp (reference sparse_matmul.py:151-153 assembles a block-diagonal matrix per call instead)."""
-    plan = op.plan
-    plans = own.get("step_plans")
-    key = _step_key(dtype, p)
-    if plans is not None and key in plans:
-        return
-    seen = own["step_settle_calls"] = own.get("step_settle_calls", 0) + 1
-    if dtype not in (torch.float32, torch.bfloat16, torch.float64) or seen <= _ops.PLAN_AFTER_USES + 2:
-        return
-    flat = plan.core.flat
-    t = plan.transposed
-    cores = [plan.core, t.core] + ([flat.core] + ([flat.core.t.core] if flat.core.t is not None else []) if flat is not None else [])
-    if any(not f.done() for c in cores for f in list(c.pending.values())):
-        return                              # (a row-pair plan of the block-diagonal problem is still being built)
-    if any(v is not None for c in cores for v in c.packs.values()):
-        return                              # (the Python path runs this batch on the row-pair kernels)
-    if flat is not None and _ops.ENABLE_LATTICE and flat.core.own.get("lattice") is not None:
-        return                              # (a lattice: settled by the caller once its configurations are final)
-    if not (plan.crow.is_contiguous() and plan.col.is_contiguous() and t.crow.is_contiguous() and t.col.is_contiguous()
-            and t.perm is not None and t.perm.is_contiguous()):
-        return
-    b, n, m, nnz = plan.batch, plan.n_rows, plan.n_cols, plan.nnz
-    none = (2, b"", 0)
-    sp = _host.StepPlan(plan.crow, plan.col, b * n, b * m, b * nnz, p, _be._VTYPE[dtype], plan.crow.device.index, none, none, none, [])
-    sp.set_plan_free(_be.itype_of(plan.crow), t.crow, t.col, t.perm, int(plan.max_row_nnz), int(t.max_row_nnz),
-                     bool(_be.fused_backward_supported(dtype, p)))
-    sp.set_batch(b, n, m, nnz)
     if plans is None:
         plans = own["step_plans"] = {}
     plans[key] = sp
@@ -320,6 +289,16 @@ class SparseMatMul(torch.autograd.Function):
                 _settle_step_plan(op, values, G, B)
             return gradA, gradB
 
+        if need_a and need_b and plan.perm is None and G.dtype == B.dtype == values.dtype:
+            # both gradients as two products (operand types the fused walk is not compiled for: fp64, very wide rows)
+            gvals, gradB = _ops.mm_backward_separate(plan, values, G, B)
+            gradA = op.rebuild(gvals)
+            if ctx.batch_size is not None:
+                gradB = gradB.view(ctx.B_shape)
+            if op.flat_batch is None:
+                _settle_step_plan(op, values, G, B)
+            return gradA, gradB
+
         if need_a:
             # gradA[k] = <G[row k,:], B[col k,:]> at A's stored entries only (reference :172-205)
             if plan.perm is None:
@@ -334,6 +313,4 @@ class SparseMatMul(torch.autograd.Function):
             if ctx.batch_size is not None:
                 gradB = gradB.view(ctx.B_shape)
 
-        if need_a and need_b and op.flat_batch is None:
-            _settle_step_plan(op, values, G, B)
         return gradA, gradB
