@@ -252,11 +252,17 @@ int tsgu_csr_sddmm_rowpack(int vtype, int itype, int64_t n_rows, int64_t n_cols,
  * references — its tile — are copied to LDS by 16-byte LDS-DMA one block ahead of the walk (double buffer), next to the block's
  * slice of the value array and ONE BYTE per entry naming the entry's dense row inside the tile; the walk reads a byte, a value and
  * 16 bytes of LDS per entry and keeps the accumulators in registers.  Plan (value independent, built once per pattern):
- *   desc [n_blocks + 4][8] int32 {u0, U, e0, E, c0, NC, 0, 0}: block b's tile is ucol[u0 .. u0 + U) (ascending distinct columns, padded to
+ *   desc [n_blocks + 4][8] int32 {u0, U, e0, E, c0, NC, x0, X}: block b's tile is ucol[u0 .. u0 + U) (ascending distinct columns, padded to
  *                          a multiple of 8 by repeating the last one; u0 a multiple of 8), its entries are e0 .. e0 + E of the walked
  *                          pattern, its value chunks (below) c0 .. c0 + NC; four trailing all-zero descriptors (the pipeline reads ahead)
  *   ucol                   int32 column numbers, U <= max_union per block
- *   lidx [nnz + 16]        uint8: position of entry k's column inside its block's tile
+ *   lidx [nnz + 16]        uint8: position of entry k's column inside its block's tile (the SDDMM's walk)
+ *   ent, xrow              the same as RECORDS for the forward / Aᵀ·G walk: a row's entries as whole rounds of eight uint16 = position in
+ *                          the tile · 128 (the byte offset of the tile row), the last round padded with max_union · 128 (a row of zeros
+ *                          the kernel keeps behind the tile); ent is 16-byte aligned, block b's records are ent[x0 .. x0 + X) (16 bytes
+ *                          each, descriptor words 6, 7), row r's first record is x0 + xrow[r] (uint16; xrow is padded to whole blocks).
+ *                          One aligned 16-byte LDS read and eight half-word adds per round where the byte stream costs three reads,
+ *                          two byte shifts, eight extractions and eight shift-adds
  *   rptr [n_rows + 1]      int32 row pointer of the walked pattern
  *   cpos, cslot            optional (both or neither; NULL: values in walked order) — the plan of the TRANSPOSED pattern walks A's own
  *                          values (Aᵀ·G, sparse_matmul.py:229).  A block's values are fetched as CHUNKS of four consecutive values of
@@ -281,6 +287,8 @@ typedef struct tsgu_tile_plan {
     const void* rptr;
     const void* cpos;
     const void* cslot;
+    const void* ent;
+    const void* xrow;
 } tsgu_tile_plan;
 
 int tsgu_tile_geometry(int vtype, int64_t p, int* rows_per_block, int* max_union, int* max_entries);

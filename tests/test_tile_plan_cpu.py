@@ -27,6 +27,19 @@ def _check(crow, col, tp, R):
         lst = ucol[u0:u0 + U]
         assert (lst[:len(u)] == u).all() and (lst[len(u):] == u[-1]).all()
         assert (lst[lidx[e0:e0 + E]] == ents).all()
+        # the same entries as records: per row whole rounds of eight 16-bit tile offsets (position · 128), padded with max_union · 128
+        x0, X = desc[b][6:8]
+        ent = tp.ent.numpy().astype(np.int64).reshape(-1, 8) & 0xFFFF
+        xrow = tp.xrow.numpy().astype(np.int64) & 0xFFFF
+        pad, at = tp.max_union * 128, 0
+        for r in range(r0, r1):
+            ln = cr[r + 1] - cr[r]
+            nr = (ln + 7) // 8
+            assert xrow[r] == at
+            rec = ent[x0 + at:x0 + at + nr].reshape(-1)
+            assert (rec[:ln] == lidx[cr[r]:cr[r + 1]].astype(np.int64) * 128).all() and (rec[ln:] == pad).all()
+            at += nr
+        assert at == X
 
 
 def _check_chunks(tt, want):

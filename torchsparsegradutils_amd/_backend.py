@@ -448,7 +448,7 @@ def _tile_struct(tp):
         from ._tile import TilePlanStruct
 
         st = TilePlanStruct(tp.n_rows, tp.n_cols, tp.nnz, tp.n_blocks, tp.rows_per_block, tp.max_union, tp.max_entries, 0, _p(tp.desc),
-                            _p(tp.ucol), _p(tp.lidx), _p(tp.rptr), _p(tp.cpos), _p(tp.cslot))
+                            _p(tp.ucol), _p(tp.lidx), _p(tp.rptr), _p(tp.cpos), _p(tp.cslot), _p(tp.ent), _p(tp.xrow))
         tp._cstruct = st
     return ctypes.addressof(st)
 

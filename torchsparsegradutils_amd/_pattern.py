@@ -161,7 +161,7 @@ class RowGather:
         thread + side stream, None until it is ready (see rowpack_plan_async)."""
         key = ("tile",) + tuple(geo)
         if asynchronous:
-            return self._plan_async(key, lambda view: view._build_tile(geo), lambda plan: (plan.desc, plan.ucol, plan.lidx, plan.rptr, plan.cpos, plan.cslot))
+            return self._plan_async(key, lambda view: view._build_tile(geo), lambda plan: (plan.desc, plan.ucol, plan.lidx, plan.rptr, plan.cpos, plan.cslot, plan.ent, plan.xrow))
         packs = self.core.packs
         if key not in packs:
             fut = self.core.pending.get(key)

@@ -22,20 +22,22 @@ import torch
 REUSE_MIN = 2.0
 # value chunks per block the kernels can fetch (csrc/tile_impl.h: kTileCMax)
 MAX_CHUNKS = 1024
+# bytes of a tile row in LDS (a column tile of 32 fp32 columns): entry records hold the byte offset of their tile row
+TILE_ROW_BYTES = 128
 
 
 class TilePlan:
     """Device arrays of one ``tsgu_tile_plan`` (+ its ctypes image, cached by _backend)."""
 
     __slots__ = ("n_rows", "n_cols", "nnz", "n_blocks", "rows_per_block", "max_union", "max_entries", "desc", "ucol", "lidx", "rptr", "cpos",
-                 "cslot", "reuse", "_cstruct")
+                 "cslot", "ent", "xrow", "reuse", "_cstruct")
 
     def __init__(self, **kw):
         for k in self.__slots__:
             setattr(self, k, kw.get(k))
 
     def plan_bytes(self) -> int:
-        return sum(t.numel() * t.element_size() for t in (self.desc, self.ucol, self.lidx, self.rptr, self.cpos, self.cslot) if t is not None)
+        return sum(t.numel() * t.element_size() for t in (self.desc, self.ucol, self.lidx, self.rptr, self.cpos, self.cslot, self.ent, self.xrow) if t is not None)
 
 
 def build_tile_plan(crow: torch.Tensor, col: torch.Tensor, n_rows: int, n_cols: int, rows_per_block: int, max_union: int, max_entries: int,
@@ -43,7 +45,7 @@ def build_tile_plan(crow: torch.Tensor, col: torch.Tensor, n_rows: int, n_cols: 
     """TilePlan of the 2-D pattern (crow, col) or None when it does not qualify.  Tensor ops on the pattern's device: one sort of
     (block, column) keys + a few scans; the only host reads are the two limits and the reuse figure."""
     nnz = col.numel()
-    if n_rows <= 0 or nnz <= 0 or nnz >= 2**31 or n_rows >= 2**31 or n_cols >= 2**31:
+    if n_rows <= 0 or nnz <= 0 or nnz >= 2**31 or n_rows >= 2**31 or n_cols >= 2**31 or max_union * TILE_ROW_BYTES >= 2**15:
         return None
     dev = col.device
     R = rows_per_block
@@ -80,7 +82,23 @@ def build_tile_plan(crow: torch.Tensor, col: torch.Tensor, n_rows: int, n_cols: 
     ucol[pos] = ukey % n_cols
     lidx = torch.zeros(nnz + 16, dtype=torch.uint8, device=dev)
     lidx[:nnz] = (inv - first[blk]).to(torch.uint8)
+    # the forward / Aᵀ·G walk reads RECORDS: per row whole rounds of eight 16-bit tile offsets (position in the tile · the bytes of a
+    # tile row), the last round padded with the offset of the kernel's zero row (max_union · row bytes)
+    lens = crow64[1:n_rows + 1] - crow64[:n_rows]
+    rounds = (lens + 7) // 8
+    rcum = torch.zeros(n_rows + 1, dtype=torch.int64, device=dev)
+    rcum[1:] = torch.cumsum(rounds, 0)
+    x0 = rcum[0:n_rows:R]                                                # first record of every block
+    x1 = torch.cat((x0[1:], rcum[n_rows:n_rows + 1]))
+    nrec = int(rcum[-1])
+    xrow = torch.zeros(nb * R, dtype=torch.int64, device=dev)
+    xrow[:n_rows] = rcum[:n_rows] - torch.repeat_interleave(x0, R, output_size=nb * R)[:n_rows]
+    ent = torch.full((nrec + 8, 8), max_union * TILE_ROW_BYTES, dtype=torch.int64, device=dev)
+    q = torch.arange(nnz, device=dev, dtype=torch.int64) - crow64[rows.to(torch.int64)]      # position of every entry inside its row
+    ent[rcum[rows.to(torch.int64)] + q // 8, q % 8] = (inv - first[blk]) * TILE_ROW_BYTES
     desc = torch.zeros((nb + 4, 8), dtype=torch.int32, device=dev)
+    desc[:nb, 6] = x0.to(torch.int32)
+    desc[:nb, 7] = (x1 - x0).to(torch.int32)
     desc[:nb, 0] = u0[:-1].to(torch.int32)
     desc[:nb, 1] = padded.to(torch.int32)
     desc[:nb, 2] = e0.to(torch.int32)
@@ -124,7 +142,7 @@ def build_tile_plan(crow: torch.Tensor, col: torch.Tensor, n_rows: int, n_cols: 
         cslot = cs.to(torch.int16).contiguous()                          # [chunks][4] uint16 bit patterns
     return TilePlan(n_rows=n_rows, n_cols=n_cols, nnz=nnz, n_blocks=nb, rows_per_block=R, max_union=max_union, max_entries=max_entries,
                     desc=desc.contiguous(), ucol=ucol.to(torch.int32).contiguous(), lidx=lidx, rptr=crow.to(torch.int32).contiguous(),
-                    cpos=cpos, cslot=cslot, reuse=reuse, _cstruct=None)
+                    cpos=cpos, cslot=cslot, ent=ent.to(torch.int16).contiguous(), xrow=xrow.to(torch.int16).contiguous(), reuse=reuse, _cstruct=None)
 
 
 class TilePlanStruct(ctypes.Structure):
@@ -133,4 +151,4 @@ class TilePlanStruct(ctypes.Structure):
     _fields_ = [("n_rows", ctypes.c_int64), ("n_cols", ctypes.c_int64), ("nnz", ctypes.c_int64), ("n_blocks", ctypes.c_int64),
                 ("rows_per_block", ctypes.c_int32), ("max_union", ctypes.c_int32), ("max_entries", ctypes.c_int32), ("reserved", ctypes.c_int32),
                 ("desc", ctypes.c_void_p), ("ucol", ctypes.c_void_p), ("lidx", ctypes.c_void_p), ("rptr", ctypes.c_void_p), ("cpos", ctypes.c_void_p),
-                ("cslot", ctypes.c_void_p)]
+                ("cslot", ctypes.c_void_p), ("ent", ctypes.c_void_p), ("xrow", ctypes.c_void_p)]

@@ -19,8 +19,9 @@ int n_cu_of(int device) {
 
 int fill(TileParams& P, const tsgu_tile_plan* pl, int64_t p) {
     if (!pl || pl->n_rows < 0 || pl->n_cols < 0 || pl->nnz < 0 || pl->n_blocks < 0) return TSGU_ERR_BAD_ARG;
-    if (pl->rows_per_block != kTileRows || pl->max_union > kTileUMax || pl->max_entries > kTileEMax) return TSGU_ERR_BAD_ARG;
-    if (pl->n_blocks > 0 && (!pl->desc || !pl->ucol || !pl->lidx || !pl->rptr)) return TSGU_ERR_BAD_ARG;
+    // (max_union is also the tile row the padding of the entry records names — the kernel's zero row: it must be the kernel's own limit)
+    if (pl->rows_per_block != kTileRows || pl->max_union != kTileUMax || pl->max_entries > kTileEMax) return TSGU_ERR_BAD_ARG;
+    if (pl->n_blocks > 0 && (!pl->desc || !pl->ucol || !pl->lidx || !pl->rptr || !pl->ent || !pl->xrow)) return TSGU_ERR_BAD_ARG;
     if ((pl->cpos == nullptr) != (pl->cslot == nullptr)) return TSGU_ERR_BAD_ARG;       // (value chunks and their slots: both or neither)
     if (pl->cpos && pl->nnz > 0 && pl->nnz < 4) return TSGU_ERR_BAD_ARG;                // (a chunk is four values inside the value array)
     if (pl->n_rows > 0x7fffffffLL || pl->nnz > 0x7fffffffLL) return TSGU_ERR_TOO_LARGE;
@@ -33,6 +34,8 @@ int fill(TileParams& P, const tsgu_tile_plan* pl, int64_t p) {
     P.ucol = static_cast<const int*>(pl->ucol);
     P.lidx = static_cast<const unsigned char*>(pl->lidx);
     P.rptr = static_cast<const int*>(pl->rptr);
+    P.ent = static_cast<const uint4*>(pl->ent);
+    P.xrow = static_cast<const unsigned short*>(pl->xrow);
     P.cpos = static_cast<const int*>(pl->cpos);
     P.cslot = static_cast<const uint2*>(pl->cslot);
     P.ncol = (int)(p / 32);
@@ -99,7 +102,7 @@ int tsgu_csr_spmm_tile(int vtype, const tsgu_tile_plan* plan, const void* val, c
     if (const int rc = fill(P, plan, p)) return rc;
     if (P.n_rows == 0) return TSGU_OK;
     if (!B || !C || (P.nnz > 0 && !val) || ldb < p || ldc < p) return TSGU_ERR_BAD_ARG;
-    if (!aligned16(B) || !aligned16(C) || ldb % 4 || ldc % 4) return TSGU_ERR_BAD_ARG;
+    if (!aligned16(B) || !aligned16(C) || ldb % 4 || ldc % 4 || !aligned16(plan->ent)) return TSGU_ERR_BAD_ARG;
     if ((uint64_t)plan->n_cols * (uint64_t)ldb * 4u > 0xffffffffull || (uint64_t)P.nnz * 4u > 0xffffffffull) return TSGU_ERR_TOO_LARGE;
     if (plan->n_cols >= (1 << 24) || ldb * 4 >= (1 << 24)) return TSGU_ERR_TOO_LARGE;      // (tile row offsets are 24-bit products)
     if (const int rc = set_device(device)) return rc;

@@ -49,21 +49,28 @@ enum TileMode { kTileSpmm = 0, kTileSddmm = 1 };
 
 constexpr int kTileRows = 64;       // rows per block
 constexpr int kTileUMax = 224;      // distinct dense rows per block (multiple of 8)
-constexpr int kTileEMax = 2048;     // entries per block
+constexpr int kTileEMax = 1792;     // entries per block (28 per row on average; round 5: 2048 — the 16-bit entry records below take their LDS)
 constexpr int kTileThreads = 512;   // eight waves: with 8 lanes per row every wave owns 8 of the block's 64 rows
 constexpr int kTileCP = 2;                                 // value chunks (16 bytes) per thread: at most 1024 chunks per block
 constexpr int kTileCMax = kTileCP * kTileThreads;
 
+constexpr int kTileXMax = kTileEMax / 8 + kTileRows * 7 / 8;      // entry records (8 entries = 16 bytes) per block: every row padded to whole
+                                                                    // records (sum of ceil(len / 8) <= E / 8 + 7/8 per row)
+
 struct TileDesc {
     int u0, U, e0, E;
-    int c0, NC, pad0, pad1;      // value chunks of the block (plans with cpos / cslot): cpos[c0 .. c0 + NC)
+    int c0, NC;                  // value chunks of the block (plans with cpos / cslot): cpos[c0 .. c0 + NC)
+    int x0, X;                   // entry records of the block: ent[x0 .. x0 + X) (16 bytes each)
 };
 
 struct TileParams {
     int64_t n_rows, n_cols, nnz, n_blocks;
     const TileDesc* desc;        // [n_blocks + 4] (four trailing empty blocks: the pipeline reads ahead)
     const int* ucol;
-    const unsigned char* lidx;   // [nnz + 16]
+    const unsigned char* lidx;   // [nnz + 16] (the SDDMM's walk)
+    const uint4* ent;            // entry records (forward / Aᵀ·G walk): per row whole ROUNDS of eight 16-bit tile offsets (tile row · row bytes),
+                                 // padded with the offset of the zero row
+    const unsigned short* xrow;  // [n_rows rounded up to whole blocks] first record of every row inside its block
     const int* rptr;             // [n_rows + 1]
     const int* cpos;             // optional: per value chunk, the position of its first value in the value array …
     const uint2* cslot;          // … and the entries of the block its four values belong to (4 x uint16, 0xffff: none)
@@ -81,30 +88,37 @@ struct TileParams {
     int cyclic;                  // block of (workgroup w, step k): 0: w·blocks_per_wg + k (a run per workgroup); 1: k·workgroups + w
 };
 
-// LDS layout (bytes): two tile buffers (filled per pipeline step = per (block, column tile)), two plan buffers {values | entry bytes |
-// row pointer slice} (filled per block) and one zero row behind them
+// LDS layout (bytes): two tile buffers (filled per pipeline step = per (block, column tile); each followed by a ZERO ROW, the tile row
+// the padding of the entry records names) and two plan buffers {values | entry records or entry bytes | row pointer slice | first record
+// of every row} (filled per block)
 template <int RB>
 struct TileLds {
-    static constexpr int kTile = kTileUMax * RB;
-    static constexpr int kVals = kTileEMax * 4;
-    static constexpr int kLidx = kTileEMax + 16;
+    static constexpr int kTile = (kTileUMax + 1) * RB;
+    static constexpr int oZeroRow = kTileUMax * RB;           // inside a tile buffer (no DMA ever writes it: U <= kTileUMax)
+    static constexpr int kVals = kTileEMax * 4 + 16;
+    static constexpr int kEnt = kTileXMax * 16;               // (>= the kTileEMax + 16 entry bytes of the SDDMM)
     static constexpr int kRs = (kTileRows + 8) * 4;
-    static constexpr int kPlan = kVals + kLidx + kRs;
+    static constexpr int kXr = kTileRows * 2;
+    static constexpr int kPlan = kVals + kEnt + kRs + kXr;
     static constexpr int kTileStride = kTile, kPlanStride = kPlan;
     static constexpr int oPlan = 2 * kTile;
-    static constexpr int oVals = 0, oLidx = kVals, oRs = kVals + kLidx;      // inside a plan buffer
-    static constexpr int oZero = 2 * kTile + 2 * kPlan;
-    static constexpr int kTotal = oZero + RB;
+    static constexpr int oVals = 0, oLidx = kVals, oEnt = kVals, oRs = kVals + kEnt, oXr = kVals + kEnt + kRs;      // inside a plan buffer
+    static constexpr int kTotal = 2 * kTile + 2 * kPlan;
+    static_assert(kTotal <= 80 * 1024, "two workgroups per CU");
 };
 
 // wave-uniform copy of a descriptor (scalar registers: its fields go into lane predicates and M0-relative addresses)
-template <bool CHUNKS>
+template <bool CHUNKS, bool RECORDS>
 __device__ __forceinline__ TileDesc tile_uniform(const TileDesc d) {
     TileDesc u{__builtin_amdgcn_readfirstlane(d.u0), __builtin_amdgcn_readfirstlane(d.U), __builtin_amdgcn_readfirstlane(d.e0),
                __builtin_amdgcn_readfirstlane(d.E), 0, 0, 0, 0};
     if constexpr (CHUNKS) {
         u.c0 = __builtin_amdgcn_readfirstlane(d.c0);
         u.NC = __builtin_amdgcn_readfirstlane(d.NC);
+    }
+    if constexpr (RECORDS) {
+        u.x0 = __builtin_amdgcn_readfirstlane(d.x0);
+        u.X = __builtin_amdgcn_readfirstlane(d.X);
     }
     return u;
 }
@@ -159,11 +173,11 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(const TileParams 
         if (b > P.n_blocks) b = P.n_blocks;
         return desc_all[b];
     };
-    auto uni = [](const TileDesc d) { return tile_uniform<PERM>(d); };
+    auto uni = [](const TileDesc d) { return tile_uniform<PERM, MODE == kTileSpmm>(d); };
     const float* __restrict__ S = static_cast<const float*>(P.S);
     const uint32_t ld_bytes = (uint32_t)P.lds_ * 4u;
     const unsigned wave_piece = (unsigned)(wave * kWave);
-    if (t < RB / 4) reinterpret_cast<float*>(tile_lds + L::oZero)[t] = 0.f;       // the zero row (visible after the first step sync)
+    if (t < RB / 2) reinterpret_cast<float*>(tile_lds + (t / (RB / 4)) * L::kTileStride + L::oZeroRow)[t % (RB / 4)] = 0.f;      // the zero rows (visible after the first step sync)
 
     // Every compiler-visible global load of the loop below is FIRST USED behind the `s_waitcnt vmcnt(0)` that ends the step it was
     // issued in (hipcc's own wait for it is then free); a load consumed inside the same step would make hipcc drain the DMAs.
@@ -218,6 +232,7 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(const TileParams 
         }
         lat_pin(rawd.u0), lat_pin(rawd.U), lat_pin(rawd.e0), lat_pin(rawd.E);
         if constexpr (PERM) lat_pin(rawd.c0), lat_pin(rawd.NC);
+        if constexpr (MODE == kTileSpmm) lat_pin(rawd.x0), lat_pin(rawd.X);
         if constexpr (MODE == kTileSddmm) lat_pin(own_cur.x), lat_pin(own_cur.y), lat_pin(own_cur.z), lat_pin(own_cur.w);
     };
     auto set_offsets = [&]() {                           // `toff` of the block whose columns `ucolr` holds
@@ -264,7 +279,17 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(const TileParams 
                 }
             }
         }
-        {   // entry bytes: dwords from the 4-byte aligned address below e0 (the walk adds e0 & 3)
+        if constexpr (MODE == kTileSpmm) {
+            // entry records: 16-byte pieces (the block's records start on a 16-byte boundary), and the first record of every row
+            if (wave_e < d.X) {
+                const int q = t < d.X ? t : d.X - 1;
+                lat_dma16<true>(P.ent, (uint32_t)(d.x0 + q) * 16u, buf + L::oEnt + wave_piece * 16u);
+            }
+            if (wave == 2) {                                // (waves 0 and 1 issue the row pointer slice below)
+                const int64_t r0 = (b_first + (int64_t)k * b_step) * kTileRows;
+                if (lane < kTileRows / 2) lat_dma4<true>(P.xrow, (uint32_t)(r0 * 2 + lane * 4), buf + L::oXr);
+            }
+        } else {   // entry bytes: dwords from the 4-byte aligned address below e0 (the walk adds e0 & 3)
             const int a0 = d.e0 & ~3, nd = (d.e0 + d.E - a0 + 3) >> 2;
 #pragma unroll
             for (int i = 0; i < (kTileEMax / 4 + 1 + kTileThreads - 1) / kTileThreads; ++i) {
@@ -324,7 +349,6 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(const TileParams 
         };
         const int* rs = reinterpret_cast<const int*>(pbuf + L::oRs);
         const unsigned char* trow = tbuf + sub * 16;
-        const unsigned char* zrow = tile_lds + L::oZero + sub * 16;
         const int rl = wave * RPW + grp;
         const int64_t r = (b_first + (int64_t)k * b_step) * kTileRows + rl;
         const bool live = r < P.n_rows;
@@ -335,73 +359,82 @@ __global__ __launch_bounds__(kTileThreads, 4) void tile_kernel(const TileParams 
         const int nfull = len_lo >> 3;
         int kk = s;
         if constexpr (MODE == kTileSpmm) {
+            // Entry records: per row whole rounds of eight 16-bit tile offsets (tile row · row bytes, ready to be added to the lane's
+            // address: `v_add_u32_sdwa` takes the half-word — one instruction per entry where a byte stream cost an extraction, a
+            // shift-add and a share of two `v_alignbyte`), 16-byte aligned: ONE `ds_read_b128` per round.  A row's last record is padded
+            // with the offset of the zero row.
+            const uint4* recs = reinterpret_cast<const uint4*>(pbuf + L::oEnt) + (live ? reinterpret_cast<const unsigned short*>(pbuf + L::oXr)[rl] : 0);
+            const unsigned zoff = (unsigned)L::oZeroRow;
+            const int len = e - s;
+            const int nr = (len + 7) >> 3;                 // this row's records
+            const int nr_hi = (len_hi + 7) >> 3;
             float acc[4] = {0.f, 0.f, 0.f, 0.f};
-            unsigned li[8];
-            float v[8];
-            auto fetch = [&](int at) {                   // entry bytes and values of the round that starts at `at` (reads beyond a row's
-                unsigned lo, hi;                         // end stay inside the LDS buffer: harmless)
-                bytes8(at, lo, hi);
+            // A round: its values (requested FIRST: the LDS returns in order, so they are there when the rows are), its eight tile
+            // rows, then the NEXT round's record, then the sums.  (One set of value registers: with the values fetched a round ahead
+            // hipcc kept two, and the chunk variant spilled.)
+            auto values_of = [&](int t, float (&v)[8]) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = vals[s + 8 * t + j];      // (reads beyond a row's end stay inside the LDS buffer: masked below)
+            };
+            auto rows_of = [&](const uint4 rec, float4 (&bj)[8], int n) {
+                const unsigned ww[4] = {rec.x, rec.y, rec.z, rec.w};
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    li[j] = ((j < 4 ? lo : hi) >> (8 * (j & 3))) & 0xffu;
-                    v[j] = vals[at + j];
+                    if (j < n) {
+                        const unsigned off = (j & 1) ? ww[j >> 1] >> 16 : ww[j >> 1] & 0xffffu;
+                        bj[j] = *reinterpret_cast<const float4*>(trow + off);
+                    }
                 }
             };
-            fetch(kk);
-            for (int it = 0; it < nfull; ++it) {
-                float4 bj[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) bj[j] = *reinterpret_cast<const float4*>(trow + li[j] * RB);
-                float vv[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) vv[j] = v[j];
-                kk += 8;
-                fetch(kk);                               // the next round's bytes and values travel while this round is summed
+            auto add = [&](const float (&v)[8], const float4 (&bj)[8], int n) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    acc[0] = fmaf(vv[j], bj[j].x, acc[0]);
-                    acc[1] = fmaf(vv[j], bj[j].y, acc[1]);
-                    acc[2] = fmaf(vv[j], bj[j].z, acc[2]);
-                    acc[3] = fmaf(vv[j], bj[j].w, acc[3]);
-                }
-            }
-            // what is left of the rows.  Rows of ONE length (the common case): fewer than eight entries, a scalar count, no predicates …
-            if (len_lo == len_hi) {
-                const int rem = len_lo & 7;
-                float4 bj[7];
-#pragma unroll
-                for (int j = 0; j < 7; ++j)
-                    if (j < rem) bj[j] = *reinterpret_cast<const float4*>(trow + li[j] * RB);
-#pragma unroll
-                for (int j = 0; j < 7; ++j) {
-                    if (j < rem) {
+                    if (j < n) {
                         acc[0] = fmaf(v[j], bj[j].x, acc[0]);
                         acc[1] = fmaf(v[j], bj[j].y, acc[1]);
                         acc[2] = fmaf(v[j], bj[j].z, acc[2]);
                         acc[3] = fmaf(v[j], bj[j].w, acc[3]);
                     }
                 }
-                kk = e;
-            }
-            // … otherwise whole rounds in which a missing entry reads the zero row with a zero value: a row never touches a dense row
-            // it does not reference, 0·0 adds nothing
-            while (__any(kk < e)) {
+            };
+            uint4 w = recs[0];
+            int tr = 0;
+#pragma nounroll
+            for (; tr < nfull; ++tr) {                   // the rounds every row of the wave has in full: no predicates
+                float v[8];
                 float4 bj[8];
-                float vv[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const bool ok = kk + j < e;
-                    bj[j] = *reinterpret_cast<const float4*>(ok ? trow + li[j] * RB : zrow);
-                    vv[j] = ok ? v[j] : 0.f;
+                values_of(tr, v);
+                rows_of(w, bj, 8);
+                w = recs[tr + 1];
+                add(v, bj, 8);
+            }
+            if (len_lo == len_hi) {
+                // rows of ONE length (the common case): fewer than eight entries are left, a scalar count, no predicates
+                const int rem = len_lo & 7;
+                if (rem) {
+                    float v[8];
+                    float4 bj[8];
+                    values_of(tr, v);
+                    rows_of(w, bj, rem);
+                    add(v, bj, rem);
                 }
-                kk += 8;
-                if (__any(kk < e)) fetch(kk);
+            } else {
+                // … otherwise whole rounds: a row that has ended reads the zero row with zero values (its record is replaced: what lies
+                // behind its last record belongs to the next row), the padding of a last record names the zero row itself and only its
+                // values are cleared.  A row never touches a dense row it does not reference, 0·0 adds nothing
+#pragma nounroll
+                for (; tr < nr_hi; ++tr) {
+                    const bool in = tr < nr;
+                    const unsigned z2 = zoff | (zoff << 16);
+                    const uint4 rec = {in ? w.x : z2, in ? w.y : z2, in ? w.z : z2, in ? w.w : z2};
+                    float v[8];
+                    float4 bj[8];
+                    values_of(tr, v);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    acc[0] = fmaf(vv[j], bj[j].x, acc[0]);
-                    acc[1] = fmaf(vv[j], bj[j].y, acc[1]);
-                    acc[2] = fmaf(vv[j], bj[j].z, acc[2]);
-                    acc[3] = fmaf(vv[j], bj[j].w, acc[3]);
+                    for (int j = 0; j < 8; ++j) v[j] = 8 * tr + j < len ? v[j] : 0.f;
+                    rows_of(rec, bj, 8);
+                    w = recs[tr + 1];
+                    add(v, bj, 8);
                 }
             }
             if (live) store_vec<float, 4, true>(static_cast<float*>(P.out) + r * P.ldo + c * (RB / 4) + sub * 4, acc);
