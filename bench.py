@@ -1086,20 +1086,27 @@ def main():
             clones = [(crow2.clone(), col2.clone()) for _ in range(k2 + 2)]
             for cr, co in clones[:2]:          # (the first fresh step pays the one-time set-up of the host read: pinned buffer, event)
                 fstep(cr, co)
-            torch.cuda.synchronize(dev)
-            t0 = time.perf_counter()
-            for cr, co in clones[2:]:
-                fstep(cr, co)
-            torch.cuda.synchronize(dev)
-            ms_fresh = (time.perf_counter() - t0) / k2 * 1e3
+            loops_fresh = []
+            for _ in range(3):                 # (the median of three loops of 16 steps: one allocator stall is 1 ms in a 5 ms loop)
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                for cr, co in clones[2:]:
+                    fstep(cr, co)
+                torch.cuda.synchronize(dev)
+                loops_fresh.append((time.perf_counter() - t0) / k2 * 1e3)
+                del clones
+                clones = [(crow2.clone(), col2.clone()) for _ in range(k2 + 2)]      # (fresh storages again: new keys)
+            ms_fresh = sorted(loops_fresh)[1]
             t0 = time.perf_counter()
             for _ in range(k2):
                 fstep(crow2, col2)
             torch.cuda.synchronize(dev)
             ms_same = (time.perf_counter() - t0) / k2 * 1e3
             fresh = {"what": "the C2 step with crow.clone(), col.clone() on every step (fresh storages, known content)", "ms_per_step": round(ms_fresh, 5),
+                     "ms_per_step_loops": [round(x, 5) for x in loops_fresh],
                      "ms_per_step_same_tensors": round(ms_same, 5), "adopted": _pattern.STATS["adopted"], "steps": k2,
-                     "note": "timed from the third fresh step on"}
+                     "note": "timed from the third fresh step on; the median of three loops (plans adopted on an EXACT comparison with the cache's own "
+                             "copy of the index tensors: one pass over both, 216 MB, + one host read per step)"}
             del clones, crow2, col2, val2, B2, G2
             _pattern.clear_cache()
             torch.cuda.empty_cache()
