@@ -11,7 +11,7 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
 timeout 900 python3 $ROOT/bench.py > $OUT/bench.json 2> $OUT/bench.err
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python3 $ROOT/bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-c5 --no-patterns > $OUT/stats.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python3 $ROOT/bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-c5 > $OUT/stats.log 2>&1
 for pass in "fetch FETCH_SIZE" "write WRITE_SIZE"; do
   set -- $pass
   timeout 900 rocprofv3 --kernel-trace --pmc $2 --kernel-include-regex "tsgu::(march_kernel|lattice_kernel|tile_kernel|csr_(spmm|sddmm|rowpack|mm_backward))" --output-format csv \
