@@ -476,6 +476,19 @@ def published_shapes_leg(dev, steps, with_cpu):
         G = torch.randn(n, p, device=dev, generator=g)
         fwd = timed(lambda: sparse_triangular_solve(A.detach(), B.detach(), upper=False))
         fb = timed(lambda: torch.autograd.grad(sparse_triangular_solve(A, B, upper=False), (A, B), G))
+        # Every solve ends with a HOST READ of its error word before X is handed out (the default, TSGU_SPTRSM_CHECK=sync: a solve
+        # whose dependency wait timed out must not return silently): forward + backward contain two host reactions with the GPU idle
+        # (0.27-0.44 ms from run to run for ~0.25 ms of kernels).  The same step with the check deferred (TSGU_SPTRSM_CHECK=lazy:
+        # examined at the next solve / poll_errors()) is reported beside it.
+        from torchsparsegradutils_amd import _backend as _be_tri
+
+        keep_check = _be_tri._SYNC_CHECK
+        try:
+            _be_tri._SYNC_CHECK = False
+            fb_lazy = timed(lambda: torch.autograd.grad(sparse_triangular_solve(A, B, upper=False), (A, B), G))
+            _be_tri.poll_errors(block=True)
+        finally:
+            _be_tri._SYNC_CHECK = keep_check
         solve_b = (n + 1) * 4 + nnz * 8 + 2 * n * p * 4
         sddmm_b = (n + 1) * 4 + nnz * 4 + 2 * n * p * 4 + nnz * 4
         Ac, Bc, Gc = A.detach().cpu(), B.detach().cpu(), G.cpu()
@@ -484,6 +497,9 @@ def published_shapes_leg(dev, steps, with_cpu):
             "what": "lower CSR N=262144, nnz=524288 (diagonal + 262144 random strictly-lower entries, well conditioned), 8 RHS, fp32/int32",
             "reference_table": "benchmarks/results/sparse_triangular_solve_rand_results.csv:72 (sparse_triangular_solve, RTX 4090: fwd 701.7 us, bwd 1460.3 us)",
             "fwd_ms": fwd[0], "fwd_ms_device": fwd[1], "fwd_bwd_ms": fb[0], "fwd_bwd_ms_device": fb[1],
+            "fwd_bwd_ms_lazy_error_check": fb_lazy[0],
+            "error_check_note": "default: a host read of the solve's error word per solve (two per forward + backward, GPU idle while the host reacts); "
+                                "fwd_bwd_ms_lazy_error_check = TSGU_SPTRSM_CHECK=lazy (the word is examined at the next solve / poll_errors())",
             "algorithmic_bytes": {"fwd": solve_b, "fwd_bwd": 2 * solve_b + sddmm_b},
             "frac": {"fwd": frac(solve_b, fwd[1]), "fwd_bwd": frac(2 * solve_b + sddmm_b, fb[1])},
             "frac_note": "a dependency-bound solve: the fraction of the HBM roofline is reported for completeness, the time per dependency level is the figure of merit",

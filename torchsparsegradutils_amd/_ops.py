@@ -177,7 +177,8 @@ def _lattice_cfg(plan: RowGather, mode: int, dense: torch.Tensor, *others: torch
     # must not depend on a wall-clock trial; the ranked configuration stays.  TSGU_LATTICE_TUNE=0 does the same for a process)
     if _lt.TUNE and not cfg.tuned and not torch.are_deterministic_algorithms_enabled():
         cfg.uses += 1
-        if cfg.uses >= _lt.TUNE_AFTER_USES and not torch.cuda.is_current_stream_capturing():
+        # (never beside a plan build on the worker's side stream: its device sorts would be in the trial timings)
+        if cfg.uses >= _lt.TUNE_AFTER_USES and not torch.cuda.is_current_stream_capturing() and not _pt.plans_in_flight():
             try:
                 cfg = _measured_cfg(lp, mode, dense, cfg)
             except torch.cuda.OutOfMemoryError:

@@ -37,6 +37,12 @@ def _side_stream(dev: torch.device):
     return s
 
 
+def plans_in_flight() -> bool:
+    """True while an asynchronous plan build is running (its device work shares the GPU with whatever the caller times)."""
+    with _PENDING_LOCK:
+        return any(not f.done() for c in _PENDING_CORES for f in c.pending.values())
+
+
 def wait_for_plans() -> None:
     """Block until every asynchronous plan build submitted so far has finished (benchmarks call this at the end of
     their warm-up; a training loop never needs to).  The plans are picked up by the next call of the operator."""

@@ -138,11 +138,15 @@ def _sweep_width(pt: _pt.RowGather, lower: bool, unit: bool, rhs: torch.Tensor, 
     seen = memo[key] = (got or 0) - 1          # (negative: solves seen so far)
     if -seen <= SWEEP_TUNE_AFTER or torch.cuda.is_current_stream_capturing():
         return 1
+    if _pt.plans_in_flight():
+        # a plan build is running on the worker's side stream (device sorts): trial timings taken beside it picked 2 or 4 workgroups
+        # per CU where 8 is twice as fast (the published shape's backward: 0.27 ms or 0.44 ms from run to run) — try again next solve
+        return 1
     best, best_ms = 1, None
     for w in SWEEP_WIDTHS:
         run(w)
         ts = []
-        for _ in range(2):
+        for _ in range(3):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             run(w)
