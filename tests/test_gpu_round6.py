@@ -184,7 +184,7 @@ def test_cpp_host_path_of_a_batched_plan_free_step_equals_the_python_path(dt, p,
     from torchsparsegradutils_amd.utils import synthetic
 
     assert sm._host is not None
-    b, n, m, nnz = 5, 96, 80, 400
+    b, n, m, nnz = 5, 96, 800, 300          # (sparse enough that no block of 64 rows shares columns: no tile plan, no row pairs)
     crow, col = synthetic.rand_batched_csr(b, n, m, nnz, idt, DEV, seed=3)
     g = torch.Generator(device=DEV).manual_seed(22)
     val = torch.randn(b, nnz, device=DEV, generator=g).to(dt)
@@ -229,3 +229,53 @@ def test_cpp_host_path_of_a_batched_plan_free_step_equals_the_python_path(dt, p,
     finally:
         sm.FAST_STEP, _ops.PACK_MIN_NNZ = keep
         _pattern.clear_cache()
+
+
+# ---- batched operands whose items are meshes: the block-diagonal problem on the row-block tiles -------------------------------------
+
+
+def test_batched_mesh_operands_run_on_the_tiles_and_equal_the_items_one_by_one(monkeypatch):
+    """Batched CSR (torch layout) whose items are brick-numbered meshes with DIFFERENT values (and here the same pattern, as torch's
+    batched CSR of equal nnz usually is): forward and backward run on the row-block tile kernels over the block-diagonal problem —
+    bit-identical to the items stepped one at a time as 2-D operands on the same kernels, the gradient batched CSR with A's own index
+    tensors."""
+    from torchsparsegradutils_amd import _ops, _pattern, sparse_mm, wait_for_plans
+    from torchsparsegradutils_amd.utils import synthetic
+
+    monkeypatch.setattr(_ops, "PACK_MIN_NNZ", 1)
+    monkeypatch.setattr(_ops, "PLAN_ASYNC", False)
+    monkeypatch.setattr(_ops, "ENABLE_LATTICE", False)
+    b, p = 3, 32
+    crow1, col1 = synthetic.mesh27_blocked(8, 12, 16, 4, torch.int32, DEV)
+    n, nnz = crow1.numel() - 1, col1.numel()
+    g = torch.Generator(device=DEV).manual_seed(41)
+    val = torch.randn(b, nnz, device=DEV, generator=g)
+    B0 = torch.randn(b, n, p, device=DEV, generator=g)
+    Gd = torch.randn(b, n, p, device=DEV, generator=g)
+    _pattern.clear_cache()
+    A = torch.sparse_csr_tensor(crow1.unsqueeze(0).repeat(b, 1), col1.unsqueeze(0).repeat(b, 1), val, (b, n, n)).requires_grad_(True)
+    B = B0.clone().requires_grad_(True)
+    for _ in range(4):
+        C = sparse_mm(A, B)
+        gA, gB = torch.autograd.grad(C, (A, B), Gd)
+        wait_for_plans()
+    plan = _pattern.from_csr(A.detach())
+    assert _ops.launched(plan, "fwd")[0] == "tiles" and _ops.launched(plan, "bwd")[0] == "tiles"
+    assert gA.layout == torch.sparse_csr and gA.shape == (b, n, n) and gA.crow_indices().data_ptr() == A.crow_indices().data_ptr()
+    import torchsparsegradutils_amd.sparse_matmul as sm
+
+    if sm._host is not None and sm.FAST_STEP:       # … and the settled step through csrc/host/step.cpp: same launches, same bits
+        C2 = sparse_mm(A, B)
+        gA2, gB2 = torch.autograd.grad(C2, (A, B), Gd)
+        assert type(C2.grad_fn).__name__ != "SparseMatMulBackward", "the C++ host path was not reached"
+        assert torch.equal(C2, C) and torch.equal(gB2, gB) and torch.equal(gA2.values(), gA.values())
+    for i in range(b):
+        Ai = torch.sparse_csr_tensor(crow1, col1, val[i].clone(), (n, n)).requires_grad_(True)
+        Bi = B0[i].clone().requires_grad_(True)
+        for _ in range(4):
+            Ci = sparse_mm(Ai, Bi)
+            gAi, gBi = torch.autograd.grad(Ci, (Ai, Bi), Gd[i])
+            wait_for_plans()
+        assert _ops.launched(_pattern.from_csr(Ai.detach()), "bwd")[0] == "tiles"
+        assert torch.equal(C[i], Ci) and torch.equal(gB[i], gBi) and torch.equal(gA.values()[i], gAi.values()), i
+    _pattern.clear_cache()

@@ -343,6 +343,18 @@ def mm_backward(plan: RowGather, values: torch.Tensor, G: torch.Tensor, B: torch
         got = _lattice_backward(plan, values, G, B)
         if got is not None:
             return got
+    if same and plan.batch is not None and plan.perm is None and ENABLE_TILE:
+        # batched operands whose items are meshes: the block-diagonal problem on the row-block tiles (round 6; the tile plan of a
+        # block-diagonal pattern is the items' plans one after the other — a block of 64 rows never spans two items' columns unless
+        # n is not a multiple of 64, and then its tile simply lists both)
+        fl = _flat(plan, G, B)
+        if fl is not None:
+            fplan, (Gf, Bf) = fl
+            tp, tt = _tile_for(fplan, Bf, Gf), _tile_for(fplan.transposed, Gf)
+            if tp is not None and tt is not None:
+                _note(plan, "bwd", G, "tiles", tp, tt)
+                ga, gb = _be.csr_sddmm_tile(tp, Gf, Bf), _be.csr_spmm_tile(tt, values.reshape(-1), Gf)
+                return ga.view(values.shape), gb.view(B.shape)
     if same and plan.batch is not None and ENABLE_PACK:
         fl = _flat(plan, G, B)
         if fl is not None:
@@ -394,6 +406,15 @@ def spmm(plan: RowGather, values: torch.Tensor, B: torch.Tensor, owner: RowGathe
                 if stored:
                     _note(plan, "fwd", B, "lattice", got[0], got[1])
                 return out.view(B.shape[:-2] + (plan.n_rows, B.size(-1)))
+        if plan.batch is not None and stored and ENABLE_TILE:
+            fl = _flat(plan, B)
+            if fl is not None:
+                fplan, (Bf,) = fl
+                tp = _tile_for(fplan, Bf)
+                if tp is not None:
+                    _chose("tiles", tp)
+                    _note(plan, "fwd", B, "tiles", tp)
+                    return _be.csr_spmm_tile(tp, values.reshape(-1), Bf).view(B.size(0), plan.n_rows, B.size(-1))
         if plan.batch is not None and ENABLE_PACK:
             fl = _flat(plan, B)
             if fl is not None:

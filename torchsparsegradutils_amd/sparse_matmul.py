@@ -150,14 +150,17 @@ def _settle_step_plan(op: "_Operand", values: torch.Tensor, G: torch.Tensor, B: 
         sp = _host.StepPlan(flat.crow, flat.col, flat.n_rows, flat.n_cols, flat.nnz, p, vt, dev.index, prods[0], prods[1], prods[2], tables)
         if batched:
             sp.set_batch(plan.batch, plan.n_rows, plan.n_cols, plan.nnz)
-    elif family == "tiles" and not batched:
-        # forward and SDDMM on the stored pattern's plan, Aᵀ·G on the transposed pattern's (its chunks read A's own values)
+    elif family == "tiles":
+        # forward and SDDMM on the stored pattern's plan, Aᵀ·G on the transposed pattern's (its chunks read A's own values); batched
+        # operands: the plans of the block-diagonal problem, the tensors keep their batch shape
         (tpf,), (tp, tt) = fwd[1], bwd[1]
-        if tpf is not tp:
+        if tpf is not tp or flat is None:
             return
         blob = lambda q: ctypes.string_at(_be._tile_struct(q), ctypes.sizeof(_TilePlanStruct))      # noqa: E731
-        sp = _host.StepPlan(plan.crow, plan.col, plan.n_rows, plan.n_cols, plan.nnz, p, vt, dev.index,
-                            (3, blob(tp), 0), (3, blob(tp), 0), (3, blob(tt), 1), [plan.crow, plan.col] + _tensors_of(tp) + _tensors_of(tt))
+        sp = _host.StepPlan(flat.crow, flat.col, flat.n_rows, flat.n_cols, flat.nnz, p, vt, dev.index,
+                            (3, blob(tp), 0), (3, blob(tp), 0), (3, blob(tt), 1), [flat.crow, flat.col] + _tensors_of(tp) + _tensors_of(tt))
+        if batched:
+            sp.set_batch(plan.batch, plan.n_rows, plan.n_cols, plan.nnz)
     elif family == "plan-free":
         # the step is on the plan-free kernels for good only once every structured plan has been asked for and has not come: the
         # pattern has to come back a few times (its row-pair / tile plans are requested on the way, _ops.PLAN_AFTER_USES)
