@@ -758,6 +758,30 @@ STATS = {"adopted": 0, "fingerprints": 0, "volatile": 0, "verified": 0, "collisi
 _READ_BUFS = threading.local()
 
 
+def _read_words_begin(t: torch.Tensor):
+    """Queue the copy of a small int64 device tensor into pinned memory (behind everything the current stream holds NOW: what is
+    queued after this call does not delay the answer); _read_words_end waits for it."""
+    n = t.numel()
+    bufs = getattr(_READ_BUFS, "bufs", None)
+    if bufs is None:
+        bufs = _READ_BUFS.bufs = {}
+    dev = t.device
+    got = bufs.get(dev)
+    if got is None or got[0].numel() < n:
+        got = bufs[dev] = (torch.empty(max(n, 64), dtype=torch.int64, pin_memory=True), torch.cuda.Event())
+    host, ev = got
+    host[:n].copy_(t.reshape(-1), non_blocking=True)
+    ev.record(torch.cuda.current_stream(dev))
+    return host, ev, n
+
+
+def _read_words_end(handle) -> list:
+    host, ev, n = handle
+    while not ev.query():
+        pass
+    return host[:n].tolist()
+
+
 def _read_words(t: torch.Tensor) -> list:
     """The words of a small int64 device tensor as a flat list: asynchronous copy into pinned memory + a polled event.  `.cpu()` parks the thread in
     the runtime's blocking wait, whose wake-up took ~0.25 ms longer than the GPU needed (measured: 0.35 ms in `.cpu()` per step for
@@ -794,9 +818,9 @@ def _after_its_writer(core: _Core, stream) -> None:
         stream.wait_event(ev)
 
 
-def _match_candidates(tensors, uniq):
-    """(adopted core or None, fingerprint words of `tensors` as a flat host list).  One pass over the tensors + one host read when
-    they equal the most recently used candidate; one more pass + read per candidate the fingerprint selects otherwise."""
+def _launch_match(tensors, uniq):
+    """Queue the pass that fingerprints `tensors` and compares them with the most recently used candidate's copy; nothing is read
+    back.  Returns what _finish_match needs."""
     from . import _backend
 
     dev = tensors[0].device
@@ -809,9 +833,20 @@ def _match_candidates(tensors, uniq):
     missing = [c for c in uniq if "fp_host" not in c.own]
     for c in missing:
         _after_its_writer(c, cur)
-    k = len(tensors)
     stacked = torch.cat([out.reshape(-1)] + [c.fp.reshape(-1) for c in missing]) if missing else out.reshape(-1)
-    flat = _read_words(stacked)
+    return _read_words_begin(stacked), missing, uniq      # (the copy to the host is queued HERE: before anything a Speculation queues)
+
+
+def _finish_match(tensors, pending):
+    """(adopted core or None, fingerprint words of `tensors` as a flat host list): one host read when the tensors equal the most
+    recently used candidate; one more pass + read per candidate the fingerprint selects otherwise."""
+    from . import _backend
+
+    handle, missing, uniq = pending
+    first = uniq[0]
+    cur = torch.cuda.current_stream(tensors[0].device)
+    k = len(tensors)
+    flat = _read_words_end(handle)
     mine = flat[:3 * k]
     for i, c in enumerate(missing):
         c.own["fp_host"] = flat[3 * k + 2 * k * i:3 * k + 2 * k * (i + 1)]
@@ -833,7 +868,46 @@ def _match_candidates(tensors, uniq):
     return None, words
 
 
-def _core_for(kind: str, tensors, shape) -> _Core:
+def _candidates(geom):
+    with _CACHE_LOCK:
+        live = [c for c in _CACHE.values() if c.geom == geom and "index_copy" in c.own]
+    return live, list({id(c): c for c in reversed(live)}.values())          # most recently used first
+
+
+class Speculation:
+    """A cache miss whose answer has been ASKED FOR but not read: `candidate` is the most recently used pattern of the same geometry,
+    the pass that compares the fresh index tensors with its copy is queued.  The caller may queue work that assumes the answer is
+    "equal" (sparse_mm: the forward of the candidate's step plan) and must then call finish(): True = equal, the candidate's plans
+    are adopted under the new key and what was queued is valid; False = other content (the cache entry of the new pattern exists
+    now), what was queued must be DROPPED.  The host's reaction to the answer then overlaps the queued work instead of an idle GPU."""
+
+    __slots__ = ("kind", "tensors", "shape", "pending", "candidate")
+
+    def finish(self) -> bool:
+        return _core_for(self.kind, self.tensors, self.shape, pending=self.pending) is self.candidate
+
+
+def speculate_csr(A: torch.Tensor):
+    """Speculation for a CSR tensor whose index tensors miss the cache while a live pattern of the same geometry exists, else None."""
+    crow, col = A.crow_indices(), A.col_indices()
+    tensors = (crow, col)
+    key = _key("csr", tensors, A.shape)
+    with _CACHE_LOCK:
+        if key in _CACHE:
+            return None
+    if not _fingerprint_applies(tensors):
+        return None
+    geom = ("csr", tuple(A.shape)) + tuple((t.shape, t.dtype, t.device) for t in tensors)
+    _, uniq = _candidates(geom)
+    if not uniq:
+        return None
+    sp = Speculation()
+    sp.kind, sp.tensors, sp.shape, sp.candidate = "csr", tensors, A.shape, uniq[0]
+    sp.pending = _launch_match(tensors, uniq)
+    return sp
+
+
+def _core_for(kind: str, tensors, shape, pending=None) -> _Core:
     key = _key(kind, tensors, shape)
     with _CACHE_LOCK:
         core = _CACHE.get(key)
@@ -844,13 +918,14 @@ def _core_for(kind: str, tensors, shape) -> _Core:
             return core
     geom = (kind, tuple(shape)) + tuple((t.shape, t.dtype, t.device) for t in tensors)
     adopted, words, live = None, None, []
-    applies = _fingerprint_applies(tensors)
+    applies = pending is not None or _fingerprint_applies(tensors)
     if applies:
-        with _CACHE_LOCK:
-            live = [c for c in _CACHE.values() if c.geom == geom and "index_copy" in c.own]
-        uniq = list({id(c): c for c in reversed(live)}.values())          # most recently used first
-        if uniq:
-            adopted, words = _match_candidates(tensors, uniq)
+        live, uniq = _candidates(geom)
+        if pending is not None:            # (a Speculation: the comparison with pending's first candidate is queued already)
+            live = live or list(pending[2])
+            adopted, words = _finish_match(tensors, pending)
+        elif uniq:
+            adopted, words = _finish_match(tensors, _launch_match(tensors, uniq))
     if adopted is None:
         core = _Core()
         core.geom = geom

@@ -54,6 +54,10 @@ def sparse_mm(A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
         raise ValueError(f"Incompatible inner dimensions: A[..., {A.size(-1)}] vs B[..., {B.size(-2)}]")
 
     if _host is not None and FAST_STEP and B.is_cuda and (B.dim() == 2 or A.layout == torch.sparse_csr):
+        if SPECULATE and A.layout == torch.sparse_csr:
+            C = _speculative_step(A, B)
+            if C is not None:
+                return C
         plan = _step_plan(A, B)
         if plan is not None:
             return cast(torch.Tensor, _host.step(A, B, plan))
@@ -72,6 +76,33 @@ except ImportError:                          # (the Python path below is complet
     _host = None
 if os.environ.get("TSGU_LIB_PATH"):          # another build of the kernels is loaded (A/B experiments): _tsgu_host.so is linked against
     _host = None                             # csrc/libtsgu_hip.so and would launch THAT build's kernels
+
+
+# A caller that rebuilds its index tensors every step misses the pattern cache's identity key; whether the fresh tensors hold a known
+# pattern is one pass over them + one host read (`_pattern._core_for`).  With a live pattern of the same geometry that has a step
+# plan, the forward of THAT plan is queued right behind the comparison pass, before its answer is read: the host's reaction to the
+# answer (~50 us) then overlaps the forward kernel instead of an idle GPU.  Equal (the common case): the step was the right one.
+# Other content: the queued result is dropped — never returned — and the normal path runs on the new pattern.
+SPECULATE = os.environ.get("TSGU_SPECULATE_FRESH", "1") != "0"
+
+
+def _speculative_step(A: torch.Tensor, B: torch.Tensor):
+    spec = _pt.speculate_csr(A)
+    if spec is None:
+        return None
+    C = None
+    try:
+        if (A.dtype == B.dtype and A.device == B.device and B.is_contiguous() and B.data_ptr() % 16 == 0 and _be.KERNEL_EVENTS is None
+                and not torch.cuda.is_current_stream_capturing()):
+            plans = spec.candidate.own.get("step_plans")
+            sp = None if plans is None else plans.get(_step_key(B.dtype, B.size(-1)))
+            if sp is not None:
+                C = _host.step(A, B, sp)
+    except RuntimeError:
+        C = None                           # (the candidate's plan does not take these operands: the normal path decides)
+    finally:
+        same = spec.finish()               # (always: the cache entry of these tensors exists from here on, adopted or new)
+    return cast(torch.Tensor, C) if same and C is not None else None
 
 
 def _step_key(dtype, p: int):
