@@ -25,3 +25,17 @@ def _seed_everything():
     np.random.seed(42)
     torch.manual_seed(42)
     yield
+
+
+@pytest.fixture(autouse=True)
+def _fresh_pattern_cache():
+    """Every test starts with an empty pattern cache: the cache recognises index tensors by CONTENT and keeps the last patterns whose
+    tensors have died adoptable (`_pattern._RECENT`), so plans built under one test's switches would otherwise be adopted by the next
+    test that builds the same matrix."""
+    try:
+        from torchsparsegradutils_amd import _pattern
+    except Exception:  # noqa: BLE001  (tests of the oracle alone do not need the package)
+        yield
+        return
+    _pattern.clear_cache()
+    yield

@@ -279,3 +279,48 @@ def test_batched_mesh_operands_run_on_the_tiles_and_equal_the_items_one_by_one(m
         assert _ops.launched(_pattern.from_csr(Ai.detach()), "bwd")[0] == "tiles"
         assert torch.equal(C[i], Ci) and torch.equal(gB[i], gBi) and torch.equal(gA.values()[i], gAi.values()), i
     _pattern.clear_cache()
+
+
+def test_fresh_index_tensors_are_recognised_after_the_previous_ones_have_died():
+    """The loop a caller really writes: every step builds `torch.sparse_csr_tensor(crow.clone(), col.clone(), …)` and the previous
+    step's tensors are GONE by then.  Their cache entry dies with them — the pattern itself stays adoptable (`_pattern._RECENT`): every
+    step after the first adopts the plans (no second analysis), same bits as a step on the original tensors; `clear_cache()` and
+    TSGU_PLAN_CACHE_RECENT=0 release everything."""
+    import gc
+
+    from torchsparsegradutils_amd import _pattern, sparse_mm, wait_for_plans
+    from torchsparsegradutils_amd.utils import synthetic
+
+    crow, col = synthetic.stencil27_periodic(24, 24, 24, torch.int32, device=DEV)
+    n, nnz, p = crow.numel() - 1, col.numel(), 32
+    g = torch.Generator(device=DEV).manual_seed(8)
+    val = torch.randn(nnz, device=DEV, generator=g)
+    B = torch.randn(n, p, device=DEV, generator=g).requires_grad_(True)
+    Gd = torch.randn(n, p, device=DEV, generator=g)
+    _pattern.clear_cache()
+
+    def step(A):
+        C = sparse_mm(A, B)
+        gA, gB = torch.autograd.grad(C, (A, B), Gd)
+        return C.detach(), gA.values().detach(), gB.detach()
+
+    A = torch.sparse_csr_tensor(crow.clone(), col.clone(), val, (n, n)).requires_grad_(True)      # (`crow` / `col` themselves never enter the cache)
+    for _ in range(6):
+        ref = step(A)
+        wait_for_plans()
+    del A
+    gc.collect()
+    assert _pattern.cache_stats()[0] == 0 and len(_pattern._RECENT) == 1          # no key is left; the pattern is still adoptable
+    before = dict(_pattern.STATS)
+    for i in range(5):
+        A = torch.sparse_csr_tensor(crow.clone(), col.clone(), val, (n, n)).requires_grad_(True)      # (the previous A is dropped HERE …)
+        gc.collect()
+        got = step(A)                                                                                  # (… before the cache sees the new one)
+        assert all(torch.equal(a, b) for a, b in zip(got, ref)), i
+        del A
+        gc.collect()
+        assert _pattern.cache_stats()[0] == 0 and len(_pattern._RECENT) == 1
+    assert _pattern.STATS["adopted"] - before["adopted"] == 5
+    assert _pattern.STATS["fingerprints"] - before["fingerprints"] == 5          # (one comparison pass each, no fresh analysis)
+    _pattern.clear_cache()
+    assert _pattern.cache_stats() == (0, 0) and not _pattern._RECENT

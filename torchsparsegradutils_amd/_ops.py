@@ -343,7 +343,7 @@ def mm_backward(plan: RowGather, values: torch.Tensor, G: torch.Tensor, B: torch
         got = _lattice_backward(plan, values, G, B)
         if got is not None:
             return got
-    if same and plan.batch is not None and plan.perm is None and ENABLE_TILE:
+    if same and plan.batch is not None and plan.perm is None and ENABLE_TILE and _be.tile_geometry(B.dtype, B.size(-1)) is not None:
         # batched operands whose items are meshes: the block-diagonal problem on the row-block tiles (round 6; the tile plan of a
         # block-diagonal pattern is the items' plans one after the other — a block of 64 rows never spans two items' columns unless
         # n is not a multiple of 64, and then its tile simply lists both)
@@ -406,7 +406,7 @@ def spmm(plan: RowGather, values: torch.Tensor, B: torch.Tensor, owner: RowGathe
                 if stored:
                     _note(plan, "fwd", B, "lattice", got[0], got[1])
                 return out.view(B.shape[:-2] + (plan.n_rows, B.size(-1)))
-        if plan.batch is not None and stored and ENABLE_TILE:
+        if plan.batch is not None and stored and ENABLE_TILE and _be.tile_geometry(B.dtype, B.size(-1)) is not None:
             fl = _flat(plan, B)
             if fl is not None:
                 fplan, (Bf,) = fl

@@ -719,6 +719,9 @@ def _transpose(g: RowGather) -> RowGather:
 _CACHE: "OrderedDict[tuple, _Core]" = OrderedDict()
 _CACHE_LOCK = threading.RLock()  # backward runs on autograd threads; finalizers may run inside a locked region
 _CACHE_MAX = 16
+# patterns whose index tensors have all died, kept adoptable (see _evict); TSGU_PLAN_CACHE_RECENT=0: plans die with their tensors
+_RECENT: "OrderedDict[int, _Core]" = OrderedDict()
+RECENT_MAX = int(_os.environ.get("TSGU_PLAN_CACHE_RECENT", "2"))
 _CACHE_MAX_BYTES = int(_os.environ.get("TSGU_PLAN_CACHE_BYTES", str(8 << 30)))
 
 
@@ -731,7 +734,16 @@ def _key(kind: str, tensors, shape) -> tuple:
 
 def _evict(key) -> None:
     with _CACHE_LOCK:
-        _CACHE.pop(key, None)
+        core = _CACHE.pop(key, None)
+        # A caller that rebuilds its index tensors every step usually DROPS the previous ones before the next call: the entry of the
+        # old tensors dies here, one step before tensors with the same content arrive.  The last few patterns that lost their last key
+        # stay adoptable for a while (strong references, bounded in number and by the cache's byte budget): without this the
+        # recognition of fresh tensors only ever worked for callers that kept the old tensors alive (bench.py's and the tests' loops did).
+        if core is not None and "index_copy" in core.own and not any(c is core for c in _CACHE.values()):
+            _RECENT[id(core)] = core
+            _RECENT.move_to_end(id(core))
+            while len(_RECENT) > RECENT_MAX:
+                _RECENT.popitem(last=False)
 
 
 # A caller that rebuilds its index tensors every step (`torch.sparse_csr_tensor(crow.clone(), col.clone(), …)`) misses the identity
@@ -870,8 +882,8 @@ def _finish_match(tensors, pending):
 
 def _candidates(geom):
     with _CACHE_LOCK:
-        live = [c for c in _CACHE.values() if c.geom == geom and "index_copy" in c.own]
-    return live, list({id(c): c for c in reversed(live)}.values())          # most recently used first
+        live = [c for c in _RECENT.values() if c.geom == geom] + [c for c in _CACHE.values() if c.geom == geom and "index_copy" in c.own]
+    return live, list({id(c): c for c in reversed(live)}.values())          # most recently used first (then the recently orphaned)
 
 
 class Speculation:
@@ -949,6 +961,7 @@ def _core_for(kind: str, tensors, shape, pending=None) -> _Core:
     with _CACHE_LOCK:
         if adopted is not None:
             core = adopted
+            _RECENT.pop(id(core), None)       # (it has a key again)
             STATS["adopted"] += 1
             _FRESH.pop(geom, None)
         elif applies and live:
@@ -961,19 +974,22 @@ def _core_for(kind: str, tensors, shape, pending=None) -> _Core:
             weakref.finalize(t.untyped_storage(), _evict, key)
         while len(_CACHE) > _CACHE_MAX:
             _CACHE.popitem(last=False)
-        if len(_CACHE) > 1 and _cached_bytes() > _CACHE_MAX_BYTES:
+        if len(_CACHE) + len(_RECENT) > 1 and _cached_bytes() > _CACHE_MAX_BYTES:
+            while _RECENT and _cached_bytes() > _CACHE_MAX_BYTES:
+                _RECENT.popitem(last=False)
             while len(_CACHE) > 1 and _cached_bytes() > _CACHE_MAX_BYTES:
                 _CACHE.popitem(last=False)
     return core
 
 
 def _cached_bytes() -> int:
-    return sum(c.nbytes() for c in {id(c): c for c in _CACHE.values()}.values())      # (adopted cores sit under several keys)
+    return sum(c.nbytes() for c in {id(c): c for c in list(_CACHE.values()) + list(_RECENT.values())}.values())      # (adopted cores sit under several keys)
 
 
 def clear_cache() -> None:
     with _CACHE_LOCK:
         _CACHE.clear()
+        _RECENT.clear()
         _FRESH.clear()
 
 

@@ -26,6 +26,12 @@ MAX_CHUNKS = 1024
 TILE_ROW_BYTES = 128
 
 
+def _owned(t: torch.Tensor, source: torch.Tensor) -> torch.Tensor:
+    """`t`, or a copy when it IS the caller's tensor (an int32 contiguous row pointer converts to itself): a plan never holds the
+    caller's index tensors — the pattern cache drops an entry when they die and may keep the plans adoptable beyond that."""
+    return t.clone() if t.untyped_storage()._cdata == source.untyped_storage()._cdata else t
+
+
 class TilePlan:
     """Device arrays of one ``tsgu_tile_plan`` (+ its ctypes image, cached by _backend)."""
 
@@ -141,7 +147,7 @@ def build_tile_plan(crow: torch.Tensor, col: torch.Tensor, n_rows: int, n_cols: 
         cpos = start.to(torch.int32).contiguous()
         cslot = cs.to(torch.int16).contiguous()                          # [chunks][4] uint16 bit patterns
     return TilePlan(n_rows=n_rows, n_cols=n_cols, nnz=nnz, n_blocks=nb, rows_per_block=R, max_union=max_union, max_entries=max_entries,
-                    desc=desc.contiguous(), ucol=ucol.to(torch.int32).contiguous(), lidx=lidx, rptr=crow.to(torch.int32).contiguous(),
+                    desc=desc.contiguous(), ucol=ucol.to(torch.int32).contiguous(), lidx=lidx, rptr=_owned(crow.to(torch.int32).contiguous(), crow),
                     cpos=cpos, cslot=cslot, ent=ent.to(torch.int16).contiguous(), xrow=xrow.to(torch.int16).contiguous(), reuse=reuse, _cstruct=None)
 
 

@@ -168,7 +168,8 @@ def _settle_step_plan(op: "_Operand", values: torch.Tensor, G: torch.Tensor, B: 
         if _ops._lt.TUNE and not torch.are_deterministic_algorithms_enabled() and not all(
                 getattr(c, "march", False) or c.tuned for c in (cf, cs, ct)):
             return                          # (a sweep configuration that is still to be measured: _ops._lattice_cfg)
-        prods, tables = [], [flat.crow, flat.col]
+        icrow, icol = (flat.crow, flat.col) if batched else _own_indices(flat)      # (the block-diagonal arrays are the cache's own)
+        prods, tables = [], [icrow, icol]
         for mode, lp, cfg in ((_be.LAT_SPMM, lpf, cf), (_be.LAT_SDDMM, lps, cs), (_be.LAT_SPMMT, lpt, ct)):
             blob = ctypes.string_at(cfg.struct_addr, ctypes.sizeof(cfg.struct))     # sizes + device pointers into the tables below
             if getattr(cfg, "march", False):
@@ -178,7 +179,7 @@ def _settle_step_plan(op: "_Operand", values: torch.Tensor, G: torch.Tensor, B: 
             else:
                 prods.append((1, blob, 0))
             tables += _tensors_of(lp) + _tensors_of(cfg)
-        sp = _host.StepPlan(flat.crow, flat.col, flat.n_rows, flat.n_cols, flat.nnz, p, vt, dev.index, prods[0], prods[1], prods[2], tables)
+        sp = _host.StepPlan(icrow, icol, flat.n_rows, flat.n_cols, flat.nnz, p, vt, dev.index, prods[0], prods[1], prods[2], tables)
         if batched:
             sp.set_batch(plan.batch, plan.n_rows, plan.n_cols, plan.nnz)
     elif family == "tiles":
@@ -188,8 +189,9 @@ def _settle_step_plan(op: "_Operand", values: torch.Tensor, G: torch.Tensor, B: 
         if tpf is not tp or flat is None:
             return
         blob = lambda q: ctypes.string_at(_be._tile_struct(q), ctypes.sizeof(_TilePlanStruct))      # noqa: E731
-        sp = _host.StepPlan(flat.crow, flat.col, flat.n_rows, flat.n_cols, flat.nnz, p, vt, dev.index,
-                            (3, blob(tp), 0), (3, blob(tp), 0), (3, blob(tt), 1), [flat.crow, flat.col] + _tensors_of(tp) + _tensors_of(tt))
+        icrow, icol = (flat.crow, flat.col) if batched else _own_indices(flat)
+        sp = _host.StepPlan(icrow, icol, flat.n_rows, flat.n_cols, flat.nnz, p, vt, dev.index,
+                            (3, blob(tp), 0), (3, blob(tp), 0), (3, blob(tt), 1), [icrow, icol] + _tensors_of(tp) + _tensors_of(tt))
         if batched:
             sp.set_batch(plan.batch, plan.n_rows, plan.n_cols, plan.nnz)
     elif family == "plan-free":
@@ -203,7 +205,8 @@ def _settle_step_plan(op: "_Operand", values: torch.Tensor, G: torch.Tensor, B: 
             return
         none = (2, b"", 0)
         b = plan.batch or 1
-        sp = _host.StepPlan(plan.crow, plan.col, b * plan.n_rows, b * plan.n_cols, b * plan.nnz, p, vt, dev.index, none, none, none, [])
+        icrow, icol = _own_indices(plan)                # (the plan-free kernels READ these arrays: same content as the caller's)
+        sp = _host.StepPlan(icrow, icol, b * plan.n_rows, b * plan.n_cols, b * plan.nnz, p, vt, dev.index, none, none, none, [])
         sp.set_plan_free(_be.itype_of(plan.crow), t.crow, t.col, t.perm, int(plan.max_row_nnz), int(t.max_row_nnz),
                          bool(_be.fused_backward_supported(dtype, p)))
         if batched:
@@ -218,6 +221,22 @@ def _settle_step_plan(op: "_Operand", values: torch.Tensor, G: torch.Tensor, B: 
     if plans is None:
         plans = own["step_plans"] = {}
     plans[key] = sp
+
+
+def _own_indices(g) -> tuple:
+    """(crow, col) of the RowGather `g` as tensors the pattern cache OWNS (its index copy, or a copy made here once): a StepPlan lives in
+    the cache entry, and an entry that held the caller's index tensors would keep them — and itself — alive for ever."""
+    own = g.core.own
+    got = own.get("step_indices")
+    if got is None:
+        copy = own.get("index_copy")
+        if (copy is not None and len(copy) == 2 and copy[0].shape == g.crow.shape and copy[1].shape == g.col.shape
+                and copy[0].dtype == g.crow.dtype and copy[1].dtype == g.col.dtype):
+            got = copy                                   # (the CSR tensors the entry was built from, copied by the fingerprint pass)
+        else:
+            got = (g.crow.contiguous().clone(), g.col.contiguous().clone())
+        own["step_indices"] = got
+    return got
 
 
 def _tensors_of(obj, depth: int = 2):
