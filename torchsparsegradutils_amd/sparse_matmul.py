@@ -232,7 +232,8 @@ def _own_indices(g) -> tuple:
         copy = own.get("index_copy")
         if (copy is not None and len(copy) == 2 and copy[0].shape == g.crow.shape and copy[1].shape == g.col.shape
                 and copy[0].dtype == g.crow.dtype and copy[1].dtype == g.col.dtype):
-            got = copy                                   # (the CSR tensors the entry was built from, copied by the fingerprint pass)
+            got = copy                                   # (the CSR tensors the entry was built from, copied by the fingerprint pass …
+            _pt._after_its_writer(g.core, torch.cuda.current_stream(g.crow.device))     # … possibly on another stream: ordered behind it)
         else:
             got = (g.crow.contiguous().clone(), g.col.contiguous().clone())
         own["step_indices"] = got
