@@ -50,6 +50,8 @@ int tsgu_abi_version(void);
 const char* tsgu_status_string(int status);
 /* Fills name (<= cap bytes), compute-unit count and wavefront size of `device`. */
 int tsgu_device_info(int device, char* name, int cap, int* n_cu, int* wave_size);
+/* The compute-unit count alone, by attribute query (microseconds; tsgu_device_info reads the whole property structure: ~0.1 s on first use). */
+int tsgu_device_cu_count(int device, int* n_cu);
 /* Streaming device copy (16 bytes per lane, non-temporal): the HBM ceiling the measurements are compared with. */
 int tsgu_device_copy(const void* src, void* dst, int64_t bytes, int device, void* stream);
 

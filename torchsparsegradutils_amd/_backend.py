@@ -41,6 +41,7 @@ SIGNATURES = {
     "tsgu_status_string": (ctypes.c_char_p, [_int]),
     "tsgu_device_info": (_int, [_int, ctypes.c_char_p, _int, ctypes.POINTER(_int), ctypes.POINTER(_int)]),
     "tsgu_device_copy": (_int, [_ptr, _ptr, _i64, _int, _ptr]),
+    "tsgu_device_cu_count": (_int, [_int, ctypes.POINTER(_int)]),
     "tsgu_index_fingerprint": (_int, [_int, _i64, _ptr, _ptr, _int, _int, _ptr]),
     "tsgu_index_fingerprint_match": (_int, [_int, _i64, _ptr, _ptr, _ptr, _ptr, _int, _int, _ptr]),
     "tsgu_tile_geometry": (_int, [_int, _i64, ctypes.POINTER(_int), ctypes.POINTER(_int), ctypes.POINTER(_int)]),
@@ -933,6 +934,13 @@ def device_copy(src: torch.Tensor, dst: torch.Tensor) -> None:
         raise RuntimeError("device_copy: contiguous tensors of equal byte size expected")
     with torch.cuda.device(dev):
         check(lib.tsgu_device_copy(_p(src), _p(dst), nbytes, dev.index, _stream(dev)), "tsgu_device_copy")
+
+
+def device_cu_count(index: int = 0) -> int:
+    lib = load_library()
+    n = _int(0)
+    check(lib.tsgu_device_cu_count(index, ctypes.byref(n)), "tsgu_device_cu_count")
+    return n.value
 
 
 def device_info(index: int = 0):

@@ -40,7 +40,11 @@ def num_cu(device=None) -> int:
         n = 256
         if idx >= 0:
             try:
-                n = int(torch.cuda.get_device_properties(idx).multi_processor_count) or 256
+                # (an attribute query: torch.cuda.get_device_properties reads the whole property structure — 117 ms of a process'
+                # first sparse_mm step went there)
+                from . import _backend
+
+                n = int(_backend.device_cu_count(idx)) or 256
             except Exception:       # noqa: BLE001 - the count only steers a launch-configuration choice
                 n = 256
         _CU_COUNT[idx] = n

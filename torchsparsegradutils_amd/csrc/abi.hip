@@ -154,6 +154,15 @@ int tsgu_device_info(int device, char* name, int cap, int* n_cu, int* wave_size)
     return TSGU_OK;
 }
 
+int tsgu_device_cu_count(int device, int* n_cu) {
+    // (hipDeviceGetAttribute: microseconds; hipGetDeviceProperties — what tsgu_device_info and torch's get_device_properties call —
+    // took 117 ms of a process' first sparse_mm step)
+    int n = 0;
+    if (!n_cu || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) return TSGU_ERR_RUNTIME;
+    *n_cu = n;
+    return TSGU_OK;
+}
+
 // Streaming copy, 16 bytes per lane, grid-stride: the measured HBM ceiling a kernel of this library can be compared with
 // (bench.py reports it next to torch's copy_; MI355X_MICROARCH.md quotes 6.29 TB/s for a float4 copy kernel).
 __global__ __launch_bounds__(256) void tsgu_copy16_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, int64_t n16) {
