@@ -154,8 +154,8 @@ __global__ __launch_bounds__(kBlock) void csr_mm_backward_kernel(const BwdParams
                 d[u] = col_ok ? d[u] : (Acc)0;
             }
 #pragma unroll
-            for (int u = 0; u < U; ++u) d[u] = group_sum<Acc, CL>(d[u]);
-            if (cl == 0) {
+            for (int u = 0; u < U; ++u) d[u] = group_total<Acc, CL>(d[u]);      // (total in the lanes cl >= group_total_lane: no LDS round trip)
+            if (cl == group_total_lane<CL>()) {
 #pragma unroll
                 for (int u = 0; u < U; ++u) s_dot[i + u * EP] = d[u];
             }
@@ -172,8 +172,8 @@ __global__ __launch_bounds__(kBlock) void csr_mm_backward_kernel(const BwdParams
                 d = fma(own[v], g[v], d);
             }
             d = col_ok ? d : (Acc)0;
-            d = group_sum<Acc, CL>(d);
-            if (cl == 0) s_dot[i] = d;
+            d = group_total<Acc, CL>(d);
+            if (cl == group_total_lane<CL>()) s_dot[i] = d;
         }
         __syncthreads();
         // gradA[perm[k]] = <G[i,:], B[j,:]> : 4-byte scatter in the same row-transposed lane order

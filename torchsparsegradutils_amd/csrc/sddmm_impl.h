@@ -27,9 +27,10 @@ struct SddmmParams {
     int64_t col_tiles;
 };
 
+// (the dot of an entry: its total is needed by the ONE lane that stores it — cl == group_total_lane<CL>())
 template <typename Acc, int CL>
 __device__ __forceinline__ Acc reduce_cl(Acc x) {
-    return group_sum<Acc, CL>(x);
+    return group_total<Acc, CL>(x);
 }
 
 template <typename V, typename I, int VEC, int CL, int EP>
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(kBlock) void csr_sddmm_kernel(const SddmmParams P) 
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u) d[u] = reduce_cl<Acc, CL>(d[u]);
-                if (cl == 0) {
+                if (cl == group_total_lane<CL>()) {
 #pragma unroll
                     for (int u = 0; u < U; ++u) s_out[i + u * EP] = d[u];
                 }
@@ -139,7 +140,7 @@ __global__ __launch_bounds__(kBlock) void csr_sddmm_kernel(const SddmmParams P) 
                 for (int v = 0; v < VEC; ++v) d = fma(r0[v], b[v], d);
                 d = lane_ok0 ? d : (Acc)0;
                 d = reduce_cl<Acc, CL>(d);
-                if (cl == 0) s_out[i] = d;
+                if (cl == group_total_lane<CL>()) s_out[i] = d;
             }
         } else {
             // wide RHS (p > CL·VEC): walk the column tiles per entry; the row operand is
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(kBlock) void csr_sddmm_kernel(const SddmmParams P) 
                     }
                 }
                 d = reduce_cl<Acc, CL>(d);
-                if (cl == 0) s_out[i] = d;
+                if (cl == group_total_lane<CL>()) s_out[i] = d;
             }
         }
         __syncthreads();
@@ -211,7 +212,7 @@ __global__ __launch_bounds__(kBlock) void coo_sddmm_kernel(const CooSddmmParams 
             }
         }
         d = reduce_cl<Acc, CL>(d);
-        if (ok && cl == 0) out[e] = VT<V>::down(alpha * d);
+        if (ok && cl == group_total_lane<CL>()) out[e] = VT<V>::down(alpha * d);
     }
 }
 

@@ -195,6 +195,41 @@ __device__ __forceinline__ Acc group_sum(Acc x) {
     return x;
 }
 
+// The same sum for groups of 32 / 64 lanes WITHOUT the LDS round trip of `__shfl_xor` (ds_bpermute): the rows of 16 are reduced by
+// the butterfly above, then `row_bcast:15` adds lane 15 of rows 0 / 2 into every lane of rows 1 / 3 and (64 lanes) `row_bcast:31`
+// adds lane 31 into rows 2, 3.  NOT an all-reduce: the total is in the lanes cl >= group_total_lane<CL>() of the group only — enough
+// for a dot product that ONE lane stores.  Same association as the butterfly (S(row 0) + S(row 1)): the same bits.
+template <int CL>
+constexpr int group_total_lane() { return CL <= 16 ? 0 : (CL == 32 ? 16 : 48); }
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_rows_f32(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, ROW_MASK, 0xf, false));      // (rows outside the mask: 0)
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_rows_f64(double x) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ float dpp_bcast15(float x) { return dpp_rows_f32<0x142, 0xA>(x); }
+__device__ __forceinline__ double dpp_bcast15(double x) { return dpp_rows_f64<0x142, 0xA>(x); }
+__device__ __forceinline__ float dpp_bcast31(float x) { return dpp_rows_f32<0x143, 0xC>(x); }
+__device__ __forceinline__ double dpp_bcast31(double x) { return dpp_rows_f64<0x143, 0xC>(x); }
+
+template <typename Acc, int CL>
+__device__ __forceinline__ Acc group_total(Acc x) {
+    static_assert(CL >= 1 && CL <= 64 && (CL & (CL - 1)) == 0, "CL must be a power of two");
+    if constexpr (CL <= 16) {
+        return group_sum<Acc, CL>(x);
+    } else {
+        x = group_sum<Acc, 16>(x);
+        x += dpp_bcast15(x);
+        if constexpr (CL == 64) x += dpp_bcast31(x);
+        return x;
+    }
+}
+
 // Sum over the EP entry-lanes of a row group (lanes cl + CL*e, e < EP): xor strides CL, 2CL, ... below
 // CL*EP.  The geometries in use have 8-lane groups ((CL,EP) = (1,8), (2,4), (4,2)): strides 1 and 2 are
 // quad permutes, stride 4 is half-mirror followed by a quad reversal (i -> 7-i -> i^4); no LDS traffic.
