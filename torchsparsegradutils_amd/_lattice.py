@@ -556,6 +556,13 @@ _MARCH_CFG_ENV = os.environ.get("TSGU_MARCH_CFG", "")   # "ty,tz,nseg,threads" o
 MARCH_TAPS = 9
 MARCH_MAX_CLASSES = 64
 _MARCH_WAVES_PER_CU = {0: 20, 1: 20, 2: 16}     # resident waves per CU the segment count is planned for
+# SDDMM: x-segments = this factor times the ranked count (segments of at least 8 planes).  Measured INSIDE the step (rocprofv3 kernel
+# statistics of the C2 step, one box, us): 3 segments (ranked) 88.0, 5: 85.6, 6: 83.4-84.2, 7: 83.4, 8: 86.1, 10: 84.8, 12: 89.7 — the
+# forward at the same counts gets slower (74.8 -> 78.8 at 6).  A trial launch behind a device copy (the sweeps' way of choosing) ranks
+# them the other way round (104.7 against 108.5 us): in the step the SDDMM follows the forward and finds its operands in MALL / L2.
+# Only for rows of one length on the whole box (periodic lattices): same box, in the step, factor 1 / 2: periodic 84.6 / 81.1 us,
+# truncated box 87.3 / 87.5, its lower triangle 61.0 / 65.1.
+MARCH_SDDMM_SEGMENT_FACTOR = int(os.environ.get("TSGU_MARCH_SDDMM_SEGMENT_FACTOR", "2"))
 # workgroup sizes in order of preference: the first that fits the lattice is taken (measured at C2, same box, us:
 # forward 4x8/256: 80.8-85.5, 8x8/512: 88.1;  SDDMM 8x8/512: 87.4, 4x8/256: 94.6-101.7;  transposed 8x8/512: 102.4, 4x8/256: 99.5-103.0)
 # round 4 (three alternations per configuration in one process, C2, us): SDDMM 4x8/256 80.1-83.0 against 8x8/512 84.4-97.5 — the
@@ -689,6 +696,12 @@ def march_config_for(plan: LatticePlan, mode: int, vtype: int, p: int, lds_bytes
     cfg = None
     if best is not None:
         _, ty, tz, nseg, threads, lds = best
+        if mode == 1 and not _MARCH_CFG_ENV and MARCH_SDDMM_SEGMENT_FACTOR > 1 and mt.full and plan.uniform_len:
+            # rows of one length on the whole box (the kernel whose stores leave as aligned pieces of a wave's run): faster on MORE,
+            # shorter x-segments than the one-round ranking picks (see MARCH_SDDMM_SEGMENT_FACTOR)
+            want = nseg * MARCH_SDDMM_SEGMENT_FACTOR
+            if want <= 64 and -(-plan.nx // want) >= 8 and -(-plan.nx // want) * (want - 1) < plan.nx:
+                nseg = want
         cfg = MarchConfig()
         cfg.mode, cfg.ty, cfg.tz, cfg.nseg, cfg.threads, cfg.lds_bytes = mode, ty, tz, nseg, threads, lds
         cfg.ring, cfg.cpl, cfg.nloc, cfg.tables, cfg.col_tile = 2, 1, plan.ncls, mt, pt
