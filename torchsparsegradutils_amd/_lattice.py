@@ -553,6 +553,8 @@ def tune_config(plan: LatticePlan, mode: int, vtype: int, p: int, elem_bytes: in
 # ---- plane-march kernels (csrc/march_impl.h): full periodic box stencils --------------------------------------------
 ENABLE_MARCH = os.environ.get("TSGU_ENABLE_MARCH", "1") == "1"
 _MARCH_CFG_ENV = os.environ.get("TSGU_MARCH_CFG", "")   # "ty,tz,nseg,threads" overrides the choice (experiments)
+# … and per product (TSGU_MARCH_CFG_FWD / _SDDMM / _SPMMT): in-step probes of one kernel's configuration with the others unchanged
+_MARCH_CFG_MODE_ENV = {m: os.environ.get("TSGU_MARCH_CFG_" + n, "") for m, n in ((0, "FWD"), (1, "SDDMM"), (2, "SPMMT"))}
 MARCH_TAPS = 9
 MARCH_MAX_CLASSES = 64
 _MARCH_WAVES_PER_CU = {0: 20, 1: 20, 2: 16}     # resident waves per CU the segment count is planned for
@@ -655,8 +657,9 @@ def march_config_for(plan: LatticePlan, mode: int, vtype: int, p: int, lds_bytes
     pt = min(p, 64)                 # columns per launch
     cl = pt // 4
     best = None
-    if _MARCH_CFG_ENV:
-        v = [int(t) for t in _MARCH_CFG_ENV.split(",")]
+    pinned = _MARCH_CFG_MODE_ENV.get(mode) or _MARCH_CFG_ENV
+    if pinned:
+        v = [int(t) for t in pinned.split(",")]
         cands = [(v[0], v[1], min(v[2], plan.nx), v[3])]
         if supported_fn is not None and not supported_fn(mode, mt.mask, plan.uniform_len, v[3]):
             cands = []
@@ -696,7 +699,7 @@ def march_config_for(plan: LatticePlan, mode: int, vtype: int, p: int, lds_bytes
     cfg = None
     if best is not None:
         _, ty, tz, nseg, threads, lds = best
-        if mode == 1 and not _MARCH_CFG_ENV and MARCH_SDDMM_SEGMENT_FACTOR > 1 and mt.full and plan.uniform_len:
+        if mode == 1 and not pinned and MARCH_SDDMM_SEGMENT_FACTOR > 1 and mt.full and plan.uniform_len:
             # rows of one length on the whole box (the kernel whose stores leave as aligned pieces of a wave's run): faster on MORE,
             # shorter x-segments than the one-round ranking picks (see MARCH_SDDMM_SEGMENT_FACTOR)
             want = nseg * MARCH_SDDMM_SEGMENT_FACTOR
