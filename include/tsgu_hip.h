@@ -401,7 +401,14 @@ int tsgu_csr_sddmm_lattice(int vtype, const tsgu_lattice_plan* plan, int64_t n_r
  * kernels for rows that store their entries in ascending (dx, dy, dz) — all rows of a truncated lattice with sorted columns —
  * equal to rounding for rows that wrap around a face.  The transposed product needs no transposed pattern and no second plan:
  * entry (i -> j) is read from canonical slot (dx+1)·ntap + tap(dy, dz) of source row i's staged values.
- * fp32 only; p in {16, 32, 64} per call (wider operands: column tiles of 64 by the caller, the SDDMM with `accumulate`).
+ * fp32; p in {16, 32, 64} per call (wider operands: column tiles of 64 by the caller, the SDDMM with `accumulate`).
+ *
+ * bf16 (csrc/linemarch_impl.h, "whole-line march"): the products of a PERIODIC 27-point box stencil (mask = all 27 bits, periodic = 7,
+ * uniform_len = 27) at p = 16 whose tile is `ty` whole z-lines (tz = nz, nz a multiple of 8, threads = ty·nz·2 in {256, 512, 1024},
+ * ny a multiple of ty).  The value rows are staged raw (stored order) and the stored position of a displacement is computed —
+ * 9·rank_x + 3·rank_y + rank_z, the rank of the wrapped neighbour coordinate among the three of its dimension: rows with sorted
+ * columns — instead of read from kidx / rcls: the CALLER guarantees that this arithmetic describes every row (the Python side checks
+ * it against the plan's class tables once per pattern, _lattice.linemarch_ok).  fp32 accumulation, one rounding.
  */
 typedef struct tsgu_march_plan {
     int32_t nb, nx, ny, nz;   /* items, planes per item, lines per plane, points per line (each of nx, ny, nz >= 3) */

@@ -584,7 +584,11 @@ def march_config(lp, mode: int, dtype: torch.dtype, p: int):
     is not a full periodic box stencil / the operands are not covered (fp32, 32 or 64 columns)."""
     from . import _lattice
 
-    if dtype != torch.float32 or lp is None or lp.kind != 0:
+    if lp is None or lp.kind != 0:
+        return None
+    if dtype == torch.bfloat16:      # whole-line march (csrc/linemarch_impl.h): Aᵀ·G of a periodic 27-point stencil at 16 columns
+        return _lattice.linemarch_config_for(lp, mode, _VTYPE[dtype], p, march_lds_bytes)
+    if dtype != torch.float32:
         return None
     return _lattice.march_config_for(lp, mode, _VTYPE[dtype], p, march_lds_bytes, march_supported)
 

@@ -577,7 +577,7 @@ class MarchTables:
     """What the plane-march kernels need besides the lattice plan's `rcls` / `rstart`: the displacement set, the canonical class
     and the per-class map canonical slot -> stored position (include/tsgu_hip.h, tsgu_march_plan)."""
 
-    __slots__ = ("ident", "taps", "mask", "periodic", "full", "kidx_host", "kidx", "_cfg")
+    __slots__ = ("ident", "taps", "mask", "periodic", "full", "kidx_host", "kidx", "_cfg", "_line_ok")
 
 
 class MarchConfig:
@@ -714,5 +714,101 @@ def march_config_for(plan: LatticePlan, mode: int, vtype: int, p: int, lds_bytes
                                       ty, tz, nseg, threads, mt.mask, mt.periodic, plan.uniform_len, mt.kidx.data_ptr(),
                                       plan.rcls.data_ptr(), plan.rstart.data_ptr())
         cfg.struct_addr = ctypes.addressof(cfg.struct)
+    mt._cfg[key] = cfg
+    return cfg
+
+
+# ---- whole-line march (csrc/linemarch_impl.h): bf16, 16 columns, periodic 27-point box --------------------------------------
+ENABLE_LINEMARCH = os.environ.get("TSGU_ENABLE_LINEMARCH", "1") != "0"
+_LINEMARCH_CFG_ENV = os.environ.get("TSGU_LINEMARCH_CFG", "")      # "ty,nseg" pins the tile height and the x-segments (experiments)
+_LINE_RANK = ((2, 0, 1), (0, 1, 2), (1, 2, 0))      # rank of the neighbour at d = -1, 0, +1 for a point at the lower face / inside / at the upper face
+
+
+def linemarch_ok(plan: LatticePlan, mt: MarchTables) -> bool:
+    """The kernels compute the stored position of displacement (dx, dy, dz) in the row at (x, y, z) as 9·rank_x + 3·rank_y + rank_z
+    (sorted columns on a periodic lattice) instead of reading the plan's class tables: true when that arithmetic reproduces the
+    tables for every class AND every row's class is the one of its position.  Once per pattern (one device reduction, one host read)."""
+    hit = getattr(mt, "_line_ok", None)
+    if hit is not None:
+        return hit
+    ok = False
+    if plan.ncls == 27 and mt.full and mt.periodic == 7 and plan.uniform_len == 27:
+        kidx = mt.kidx_host[:, :27].tolist()
+        cls_of = {}
+        for sx in range(3):
+            for sy in range(3):
+                for sz in range(3):
+                    want = [9 * _LINE_RANK[sx][dx] + 3 * _LINE_RANK[sy][dy] + _LINE_RANK[sz][dz] for dx in range(3) for dy in range(3) for dz in range(3)]
+                    if want in kidx:
+                        cls_of[(sx, sy, sz)] = kidx.index(want)
+        if len(cls_of) == 27 and len(set(cls_of.values())) == 27:
+            dev = plan.rcls.device
+
+            def state(n):
+                s = torch.ones(n, dtype=torch.long, device=dev)
+                s[0], s[n - 1] = 0, 2
+                return s
+
+            tab = torch.tensor([[[cls_of[(a, b, c)] for c in range(3)] for b in range(3)] for a in range(3)], dtype=plan.rcls.dtype, device=dev)
+            want = tab[state(plan.nx)][:, state(plan.ny)][:, :, state(plan.nz)]
+            n_rows = plan.nb * plan.nx * plan.ny * plan.nz
+            ok = bool((plan.rcls[:n_rows].view(plan.nb, plan.nx, plan.ny, plan.nz) == want).all().item())
+    mt._line_ok = ok
+    return ok
+
+
+def linemarch_config_for(plan: LatticePlan, mode: int, vtype: int, p: int, lds_bytes_fn) -> Optional[MarchConfig]:
+    """Launch configuration of the whole-line march for a stored-order plan, or None: bf16, 16 columns, the transposed product of a
+    periodic 27-point box stencil whose z-lines are whole 16-byte pieces of values (nz a multiple of 8) and fit a workgroup."""
+    if not ENABLE_LINEMARCH or not ENABLE_MARCH or vtype != 2 or p != 16 or mode != 2:
+        return None
+    mt = march_tables(plan)
+    if mt is None or not mt.full or mt.periodic != 7 or plan.uniform_len != 27 or plan.nz % 8:
+        return None
+    key = ("line", mode, p)
+    if key in mt._cfg:
+        return mt._cfg[key]
+    cfg = None
+    if torch.cuda.is_current_stream_capturing():
+        return None          # (linemarch_ok reads a device reduction)
+    if linemarch_ok(plan, mt):
+        best = None
+        pinned = [int(t) for t in _LINEMARCH_CFG_ENV.split(",")] if _LINEMARCH_CFG_ENV else None
+        for threads in (512, 1024, 256):
+            if threads % (2 * plan.nz):
+                continue
+            ty = threads // (2 * plan.nz)
+            if pinned:
+                if ty != pinned[0]:
+                    continue
+            if ty > plan.ny or plan.ny % ty:
+                continue
+            lds = lds_bytes_fn(mode, vtype, p, ty, plan.nz, 1, 1, plan.ncls, threads)
+            if lds <= 0:
+                continue
+            per_cu = max(1, min(160 * 1024 // lds, 2048 // threads))
+            slots = num_cu(plan.rcls.device) * per_cu
+            base = plan.nb * (plan.ny // ty)
+            halo = (ty + 2) / ty
+            for ns_ in ([pinned[1]] if pinned else range(1, min(plan.nx, 64) + 1)):
+                seg_len = -(-plan.nx // ns_)
+                if seg_len * (ns_ - 1) >= plan.nx:
+                    continue
+                cost = -(-base * ns_ // slots) * (seg_len + 3) * threads * halo
+                if best is None or cost < best[0]:
+                    best = (cost, ty, ns_, threads, lds)
+            if best is not None and not pinned:
+                break
+        if best is not None:
+            _, ty, nseg, threads, lds = best
+            cfg = MarchConfig()
+            cfg.mode, cfg.ty, cfg.tz, cfg.nseg, cfg.threads, cfg.lds_bytes = mode, ty, plan.nz, nseg, threads, lds
+            cfg.ring, cfg.cpl, cfg.nloc, cfg.tables, cfg.col_tile = 2, 1, plan.ncls, mt, p
+            dy = (ctypes.c_int32 * 9)(*[t[0] for t in mt.taps])
+            dz = (ctypes.c_int32 * 9)(*[t[1] for t in mt.taps])
+            cfg.struct = _MarchPlanStruct(plan.nb, plan.nx, plan.ny, plan.nz, 1, 1, MARCH_TAPS, dy, dz, plan.ncls, mt.ident,
+                                          ty, plan.nz, nseg, threads, mt.mask, mt.periodic, plan.uniform_len, mt.kidx.data_ptr(),
+                                          plan.rcls.data_ptr(), plan.rstart.data_ptr())
+            cfg.struct_addr = ctypes.addressof(cfg.struct)
     mt._cfg[key] = cfg
     return cfg
