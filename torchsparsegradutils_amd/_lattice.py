@@ -720,6 +720,7 @@ def march_config_for(plan: LatticePlan, mode: int, vtype: int, p: int, lds_bytes
 
 # ---- whole-line march (csrc/linemarch_impl.h): bf16, 16 columns, periodic 27-point box --------------------------------------
 ENABLE_LINEMARCH = os.environ.get("TSGU_ENABLE_LINEMARCH", "1") != "0"
+LINEMARCH_MODES = tuple(int(t) for t in os.environ.get("TSGU_LINEMARCH_MODES", "0,1,2").split(",") if t)     # products it takes: 0 A·B, 1 SDDMM, 2 Aᵀ·G
 _LINEMARCH_CFG_ENV = os.environ.get("TSGU_LINEMARCH_CFG", "")      # "ty,nseg" pins the tile height and the x-segments (experiments)
 _LINE_RANK = ((2, 0, 1), (0, 1, 2), (1, 2, 0))      # rank of the neighbour at d = -1, 0, +1 for a point at the lower face / inside / at the upper face
 
@@ -758,13 +759,16 @@ def linemarch_ok(plan: LatticePlan, mt: MarchTables) -> bool:
 
 
 def linemarch_config_for(plan: LatticePlan, mode: int, vtype: int, p: int, lds_bytes_fn) -> Optional[MarchConfig]:
-    """Launch configuration of the whole-line march for a stored-order plan, or None: bf16, 16 columns, the transposed product of a
-    periodic 27-point box stencil whose z-lines are whole 16-byte pieces of values (nz a multiple of 8) and fit a workgroup."""
-    if not ENABLE_LINEMARCH or not ENABLE_MARCH or vtype != 2 or p != 16 or mode != 2:
+    """Launch configuration of the whole-line march for a stored-order plan, or None: bf16, 16 columns, the SDDMM (mode 1) or the
+    transposed product (mode 2) of a periodic 27-point box stencil whose z-lines are whole 16-byte pieces of values (nz a multiple
+    of 8) and fit a workgroup."""
+    if not ENABLE_LINEMARCH or not ENABLE_MARCH or vtype != 2 or p != 16 or mode not in LINEMARCH_MODES:
         return None
     mt = march_tables(plan)
     if mt is None or not mt.full or mt.periodic != 7 or plan.uniform_len != 27 or plan.nz % 8:
         return None
+    if mode == 1 and 32 % plan.nz:
+        return None          # (SDDMM: a wave's 32 rows must be whole z-lines)
     key = ("line", mode, p)
     if key in mt._cfg:
         return mt._cfg[key]

@@ -4,7 +4,7 @@
 namespace tsgu {
 
 // fills P from the plan (geometry, tile) and validates it; returns the dynamic LDS bytes or a negative status
-int linemarch_fill(LineParams& P, const tsgu_march_plan* pl, int64_t p, int64_t n_rows, int64_t nnz) {
+int linemarch_fill(LineParams& P, const tsgu_march_plan* pl, int mode, int64_t p, int64_t n_rows, int64_t nnz) {
     if (!pl || p != 16) return TSGU_ERR_BAD_DTYPE;
     if (pl->ntap != 9 || pl->ry != 1 || pl->rz != 1 || pl->mask != (1u << 27) - 1u || pl->periodic != 7 || pl->uniform_len != 27) return TSGU_ERR_BAD_ARG;
     if (pl->nb <= 0 || pl->nx < 3 || pl->ny < 3 || pl->nz < 3 || pl->nseg <= 0 || pl->nseg > pl->nx || pl->tz != pl->nz) return TSGU_ERR_BAD_ARG;
@@ -16,18 +16,32 @@ int linemarch_fill(LineParams& P, const tsgu_march_plan* pl, int64_t p, int64_t 
     P.nseg = pl->nseg;
     P.seg_len = (pl->nx + pl->nseg - 1) / pl->nseg;
     if ((int64_t)(P.nseg - 1) * P.seg_len >= pl->nx) return TSGU_ERR_BAD_ARG;
-    const int lds = linemarch_layout(P, pl->threads);
+    const int lds = linemarch_layout(P, pl->threads, mode);
     if (lds < 0) return lds;
     P.nblocks = (int64_t)P.nb * P.nseg * P.tiles_y;
     if (P.nblocks > 0x7fffffffLL) return TSGU_ERR_TOO_LARGE;
     return lds;
 }
 
-int linemarch_run_spmmt(const LineParams& P, int threads, hipStream_t stream) {
-    switch (threads) {
-        case 256: return linemarch_launch_t<256>(P, stream);
-        case 512: return linemarch_launch_t<512>(P, stream);
-        case 1024: return linemarch_launch_t<1024>(P, stream);
+int linemarch_run(int mode, const LineParams& P, int threads, hipStream_t stream) {
+    if (mode == kLatSpmmT) {
+        switch (threads) {
+            case 256: return linemarch_launch_t<256, kLatSpmmT>(P, stream);
+            case 512: return linemarch_launch_t<512, kLatSpmmT>(P, stream);
+            case 1024: return linemarch_launch_t<1024, kLatSpmmT>(P, stream);
+        }
+    } else if (mode == kLatSpmm) {
+        switch (threads) {
+            case 256: return linemarch_launch_t<256, kLatSpmm>(P, stream);
+            case 512: return linemarch_launch_t<512, kLatSpmm>(P, stream);
+            case 1024: return linemarch_launch_t<1024, kLatSpmm>(P, stream);
+        }
+    } else if (mode == kLatSddmm) {
+        switch (threads) {
+            case 256: return linemarch_launch_t<256, kLatSddmm>(P, stream);
+            case 512: return linemarch_launch_t<512, kLatSddmm>(P, stream);
+            case 1024: return linemarch_launch_t<1024, kLatSddmm>(P, stream);
+        }
     }
     return TSGU_ERR_BAD_ARG;
 }

@@ -5,8 +5,8 @@
 using namespace tsgu;
 
 namespace tsgu {
-int linemarch_fill(LineParams& P, const tsgu_march_plan* pl, int64_t p, int64_t n_rows, int64_t nnz);
-int linemarch_run_spmmt(const LineParams& P, int threads, hipStream_t stream);
+int linemarch_fill(LineParams& P, const tsgu_march_plan* pl, int mode, int64_t p, int64_t n_rows, int64_t nnz);
+int linemarch_run(int mode, const LineParams& P, int threads, hipStream_t stream);
 }  // namespace tsgu
 
 namespace {
@@ -86,10 +86,10 @@ int tsgu_march_supported(int mode, int mask, int uniform_len, int threads) {
 
 int tsgu_march_lds_bytes(int mode, int vtype, int64_t p, int ty, int tz, int ry, int rz, int ncls, int threads) {
     if (vtype == TSGU_BF16) {   // whole-line march (linemarch_impl.h): the transposed product at 16 columns; tz = the lattice's nz
-        if (mode != kLatSpmmT || p != 16 || ry != 1 || rz != 1) return TSGU_ERR_BAD_DTYPE;
+        if (mode < 0 || mode > kLatSpmmT || p != 16 || ry != 1 || rz != 1) return TSGU_ERR_BAD_DTYPE;
         LineParams L{};
         L.nz = tz, L.ty = ty, L.ny = ty;
-        return linemarch_layout(L, threads);
+        return linemarch_layout(L, threads, mode);
     }
     const int cl = march_lanes(vtype, p);
     if (cl == 0 || mode < 0 || mode > kLatSpmmT) return TSGU_ERR_BAD_DTYPE;
@@ -102,16 +102,15 @@ int tsgu_march_lds_bytes(int mode, int vtype, int64_t p, int ty, int tz, int ry,
 int tsgu_csr_spmm_march(int vtype, const tsgu_march_plan* plan, int transposed, int64_t n_rows, int64_t nnz, const void* val,
                         const void* B, int64_t ldb, void* C, int64_t ldc, int64_t p, int device, void* stream) {
     if (vtype == TSGU_BF16) {   // whole-line march: periodic 27-point box, 16 columns, Aᵀ·G
-        if (!transposed) return TSGU_ERR_BAD_DTYPE;
         LineParams L{};
-        const int lds = linemarch_fill(L, plan, p, n_rows, nnz);
+        const int lds = linemarch_fill(L, plan, transposed ? kLatSpmmT : kLatSpmm, p, n_rows, nnz);
         if (lds < 0) return lds;
         if (n_rows == 0) return TSGU_OK;
         if (!B || !C || !val || ldb < p || ldc < p || ldb % 8 || ldc % 8 || !aligned16(B) || !aligned16(C) || !aligned16(val)) return TSGU_ERR_BAD_ARG;
         if ((int64_t)plan->ny * plan->nz * ldb * 2 > 0x7fffffffLL) return TSGU_ERR_TOO_LARGE;
         if (const int rc = set_device(device)) return rc;
         L.val = val, L.S = B, L.lds_ = ldb, L.out = C, L.ldo = ldc;
-        return linemarch_run_spmmt(L, plan->threads, static_cast<hipStream_t>(stream));
+        return linemarch_run(transposed ? kLatSpmmT : kLatSpmm, L, plan->threads, static_cast<hipStream_t>(stream));
     }
     MarchParams P{};
     int cl = 0;
@@ -133,6 +132,18 @@ int tsgu_csr_spmm_march(int vtype, const tsgu_march_plan* plan, int transposed, 
 
 int tsgu_csr_sddmm_march(int vtype, const tsgu_march_plan* plan, int64_t n_rows, int64_t nnz, const void* R, int64_t ldr, const void* Cm,
                          int64_t ldc, void* out_vals, double alpha, int accumulate, int64_t p, int device, void* stream) {
+    if (vtype == TSGU_BF16) {   // whole-line march: periodic 27-point box, 16 columns
+        if (accumulate) return TSGU_ERR_BAD_ARG;
+        LineParams L{};
+        const int lds = linemarch_fill(L, plan, kLatSddmm, p, n_rows, nnz);
+        if (lds < 0) return lds;
+        if (n_rows == 0) return TSGU_OK;
+        if (!R || !Cm || !out_vals || ldr < p || ldc < p || ldr % 8 || ldc % 8 || !aligned16(R) || !aligned16(Cm) || !aligned16(out_vals)) return TSGU_ERR_BAD_ARG;
+        if ((int64_t)plan->ny * plan->nz * ldr * 2 > 0x7fffffffLL || (int64_t)plan->ny * plan->nz * ldc * 2 > 0x7fffffffLL) return TSGU_ERR_TOO_LARGE;
+        if (const int rc = set_device(device)) return rc;
+        L.Own = R, L.ldown = ldr, L.S = Cm, L.lds_ = ldc, L.gvals = out_vals, L.alpha = (float)alpha;
+        return linemarch_run(kLatSddmm, L, plan->threads, static_cast<hipStream_t>(stream));
+    }
     MarchParams P{};
     int cl = 0;
     if (const int rc = fill(P, plan, kLatSddmm, vtype, p, n_rows, nnz, cl)) return rc;
