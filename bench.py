@@ -222,9 +222,10 @@ def c5_leg(dev, world, rank, steps, warmup, barrier):
                     "allocates its own items only)",
         "resident_bytes_per_rank": int(val.numel() * 2 + 2 * B_loc.numel() * 2 + nloc * (crow1.numel() + col1.numel()) * 4),
         "algorithmic_bytes_fwd_whole_job": ab["spmm"],
-        "bytes_note": "algorithmic bytes are those of a CSR kernel (crow, col, values, B in, C out: SURVEY 8d); the plane sweeps this "
-                      "lattice pattern runs on read no column index (906 MB of the 1929 MB), so their HBM traffic is ~1.05 GB per "
-                      "forward launch (profiles/r03_pmc_c5/, 2*FETCH_SIZE + WRITE_SIZE) - GBps_whole_job above ~4 TB/s is algorithmic, not wire, rate",
+        "bytes_note": "algorithmic bytes are those of a CSR kernel (crow, col, values, B in, C out: SURVEY 8d); the whole-line march "
+                      "kernels this lattice pattern runs on read no column index and no row pointer (940 MB of the 1929 MB per product), "
+                      "so GBps_whole_job / frac_of_hbm_peak_per_gpu are algorithmic rates and can exceed the chip's copy rate; frac_wire "
+                      "(N = 1) = HBM bytes really moved per step (rocprofv3 PMC, profiles/hbm_traffic.json patterns.c5) / the same time / 8 TB/s",
         "fwd_compute_only": {"ms": round(ms_fwd, 4), "GBps_whole_job": round(ab["spmm"] / (ms_fwd * 1e-3) / 1e9, 1),
                              "frac_of_hbm_peak_per_gpu": round(ab["spmm"] / world / (ms_fwd * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
         "fwd_bwd_compute_only": {"ms": round(ms_fb, 4), "GBps_whole_job": round(ab["fwd_bwd"] / (ms_fb * 1e-3) / 1e9, 1),
@@ -232,6 +233,20 @@ def c5_leg(dev, world, rank, steps, warmup, barrier):
         "host_ms_per_step": {"fwd": round(host_ms.get("fwd_local", 0.0), 4), "fwd_bwd": round(host_ms.get("fwd_bwd_local", 0.0), 4),
                              "note": "time the host needs to queue one step (round 5: batched CSR steps go through csrc/host/step.cpp)"},
     }
+    if world == 1:
+        # wire rate and the dominant kernel's roofline from the committed counter passes of the same step (tools/prof_round.sh, pattern c5)
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
+            step_bytes = (tj.get("patterns") or {}).get("c5")
+            if step_bytes:
+                out["fwd_bwd_compute_only"]["traffic"] = int(step_bytes)
+                out["fwd_bwd_compute_only"]["frac_wire"] = round(step_bytes / (ms_fb * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            roof = (tj.get("pattern_rooflines") or {}).get("c5")
+            if roof:
+                out["roofline"] = dict(roof["dominant"], source=roof["source"], commit=tj.get("commit"))
+                out["kernels"] = [{k: kk[k] for k in ("kind", "avg_launch_ms", "frac", "traffic", "frac_wire")} for kk in roof["kernels"]]
+        except (OSError, ValueError):
+            pass
     if world == 1 and nloc >= 8:
         # one GPU's share of the 8-GPU job (8 items): what each rank of the sharded run steps — kernels and host time per step
         try:

@@ -101,6 +101,8 @@ def kernel_kind(kname):
         return {"0": "forward", "1": "sddmm", "2": "transposed"}.get(args[2])
     if "lattice_kernel" in kname:
         return {"0": "forward", "1": "sddmm", "2": "transposed"}.get(args[3])
+    if "linemarch_" in kname:
+        return "forward" if "linemarch_spmm_kernel" in kname else ("sddmm" if "linemarch_sddmm_kernel" in kname else "transposed")
     if "tile_kernel" in kname:      # <V, CL, MODE, PERM, WIDE>
         return "sddmm" if args[2] == "1" else ("transposed" if args[3] == "true" else "forward")
     if "csr_mm_backward_kernel" in kname or ("csr_rowpack_kernel" in kname and args[4] == "1"):
@@ -120,17 +122,18 @@ def pattern_roofline(pdir, key):
     try:
         for line in open(os.path.join(src, f"pat_{key}.stats.log")):
             w = line.split()
-            if len(w) == 4 and w[0] == key and all(x.isdigit() for x in w[1:]):
+            if len(w) in (4, 5) and w[0] == key and all(x.isdigit() for x in w[1:]):
                 geo = tuple(int(x) for x in w[1:])
     except OSError:
         return None
     hits = glob.glob(os.path.join(pdir, "stats", "**", "*kernel_stats.csv"), recursive=True)
     if geo is None or not hits:
         return None
-    n, nnz, p = geo
-    idx, row_b = (n + 1) * 4 + nnz * 4, n * p * 4
-    alg = {"forward": idx + nnz * 4 + 2 * row_b, "transposed": idx + nnz * 4 + 2 * row_b, "sddmm": idx + 2 * row_b + nnz * 4,
-           "fused_backward": idx + nnz * 4 + 3 * row_b + nnz * 4}
+    n, nnz, p = geo[:3]
+    eb = geo[3] if len(geo) > 3 else 4          # bytes per element of the values and the dense operands (indices: int32)
+    idx, row_b = (n + 1) * 4 + nnz * 4, n * p * eb
+    alg = {"forward": idx + nnz * eb + 2 * row_b, "transposed": idx + nnz * eb + 2 * row_b, "sddmm": idx + 2 * row_b + nnz * eb,
+           "fused_backward": idx + nnz * eb + 3 * row_b + nnz * eb}
     stats = {r["Name"]: r for r in csv.DictReader(open(hits[0])) if "tsgu::" in r["Name"]}
     pmc = defaultdict(lambda: defaultdict(list))
     for kind, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):

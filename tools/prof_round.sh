@@ -18,7 +18,7 @@ for pass in "fetch FETCH_SIZE" "write WRITE_SIZE"; do
      -d $OUT/$1 -o p -- python3 $ROOT/bench.py --steps 3 --warmup 3 --no-cpu-baseline --no-c5 --no-patterns > $OUT/$1.log 2>&1
 done
 # per-pattern HBM bytes per step (bench.py's `patterns` block): the same two passes around a few steps of each pattern
-for pat in headline c2_7pt_periodic c2_27pt_truncated c2_27pt_truncated_lower mesh27_blocked cfd2_shaped cfd2_mesh; do
+for pat in headline c2_7pt_periodic c2_27pt_truncated c2_27pt_truncated_lower mesh27_blocked cfd2_shaped cfd2_mesh c5; do
   # (durations of the pattern's kernels: their own --stats pass, 100 steps — counters and timing never share a run)
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/pat_$pat/stats -o s -- python3 $ROOT/tools/pattern_steps.py $pat 100 > $OUT/pat_$pat.stats.log 2>&1
   for pass in "fetch FETCH_SIZE" "write WRITE_SIZE"; do
