@@ -255,6 +255,22 @@ if os.path.exists(saved) and os.path.exists(os.path.join(dst, "hbm_traffic.json"
     if "c2_27pt_periodic" in (tj.get("patterns") or {}):
         line["step_traffic"] = tj["patterns"]["c2_27pt_periodic"]
         line["frac_of_hbm_peak_wire"] = round(line["step_traffic"] / (line["ms_per_step"] * 1e-3) / 1e9 / peak, 4)
+    c5 = line.get("c5")
+    if isinstance(c5, dict) and "fwd_bwd_compute_only" in c5:       # (the same derivation as bench.py's c5_leg, from this round's counters)
+        step_bytes, roof_ = (tj.get("patterns") or {}).get("c5"), (tj.get("pattern_rooflines") or {}).get("c5")
+        if step_bytes:
+            c5["fwd_bwd_compute_only"]["traffic"] = int(step_bytes)
+            c5["fwd_bwd_compute_only"]["frac_wire"] = round(step_bytes / (c5["fwd_bwd_compute_only"]["ms"] * 1e-3) / 1e9 / peak, 4)
+        if roof_:
+            d = roof_["dominant"]
+            c5["roofline"] = {"bound": "hbm", "kernel": d["kernel"], "kind": d["kind"], "avg_launch_ms": d["avg_launch_ms"],
+                              "achieved": round(d["traffic"] / (d["avg_launch_ms"] * 1e-3) / 1e9, 1) if d.get("traffic") else None,
+                              "peak": peak, "unit": "GB/s", "frac": d.get("frac_wire"), "traffic": d.get("traffic"),
+                              "algorithmic_bytes": d["algorithmic_bytes"], "frac_algorithmic": d["frac"],
+                              "note": "frac = HBM bytes really moved (2*FETCH_SIZE + WRITE_SIZE) / launch duration / peak",
+                              "source": roof_["source"], "commit": tj.get("commit")}
+            c5["kernels"] = [{"kind": kk["kind"], "avg_launch_ms": kk["avg_launch_ms"], "traffic": kk["traffic"], "frac_wire": kk["frac_wire"],
+                              "frac_algorithmic": kk["frac"]} for kk in roof_["kernels"]]
     if line.get("kernels_GBps_wire") is not None or True:
         wire = {}
         for kname, ms in (line.get("kernels_ms") or {}).items():
