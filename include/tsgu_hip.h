@@ -438,7 +438,7 @@ int tsgu_march_lds_bytes(int mode, int vtype, int64_t p, int ty, int tz, int ry,
 int tsgu_csr_spmm_march(int vtype, const tsgu_march_plan* plan, int transposed, int64_t n_rows, int64_t nnz, const void* val,
                         const void* B, int64_t ldb, void* C, int64_t ldc, int64_t p, int device, void* stream);
 /* out_vals[k] = alpha·<R[row k,:], Cm[col k,:]> in A's stored order (accumulate != 0: added to out_vals — the later column
- * tiles of operands wider than 64 columns).  bf16 (whole-line march, above): nz in {8, 16, 32}, accumulate == 0. */
+ * tiles of operands wider than 64 columns).  bf16 (whole-line march, above): accumulate == 0. */
 int tsgu_csr_sddmm_march(int vtype, const tsgu_march_plan* plan, int64_t n_rows, int64_t nnz, const void* R, int64_t ldr,
                          const void* Cm, int64_t ldc, void* out_vals, double alpha, int accumulate, int64_t p, int device,
                          void* stream);

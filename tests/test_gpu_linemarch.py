@@ -70,7 +70,7 @@ CASES = [
     (1, 3, 8, 32, True),        # three planes: every plane wraps in x or is the only interior one
     (3, 8, 8, 32, True),        # one y-tile: both halo lines are the tile's own lines (y wraps inside the tile)
     (2, 7, 32, 8, True),        # short lines: a wave holds four of them
-    (2, 4, 32, 64, False),      # lines of two waves: forward and transposed product only (a wave of the SDDMM flushes whole lines)
+    (2, 4, 32, 64, True),       # lines of two waves
     (1, 6, 16, 16, True),       # sixteen lines of sixteen points per workgroup
 ]
 
@@ -188,12 +188,12 @@ def test_abi_refuses_what_the_kernels_do_not_cover():
     from torchsparsegradutils_amd import _backend as be, _lattice as lt, _pattern
 
     lib = be.load_library()
-    # LDS bytes: whole lines only (threads = ty·nz·2), nz a multiple of 8, the SDDMM's waves hold whole lines
+    # LDS bytes: whole lines only (threads = ty·nz·2), nz a multiple of 8
     assert lib.tsgu_march_lds_bytes(2, 2, 16, 8, 32, 1, 1, 27, 512) > 0
     assert lib.tsgu_march_lds_bytes(0, 2, 16, 8, 32, 1, 1, 27, 512) > 0 and lib.tsgu_march_lds_bytes(1, 2, 16, 8, 32, 1, 1, 27, 512) > 0
     assert lib.tsgu_march_lds_bytes(2, 2, 16, 8, 32, 1, 1, 27, 256) < 0          # threads != ty·nz·2
     assert lib.tsgu_march_lds_bytes(2, 2, 16, 8, 12, 1, 1, 27, 192) < 0          # nz not a multiple of 8
-    assert lib.tsgu_march_lds_bytes(1, 2, 16, 4, 64, 1, 1, 27, 512) < 0          # SDDMM: a line longer than a wave's 32 rows
+    assert lib.tsgu_march_lds_bytes(1, 2, 16, 4, 64, 1, 1, 27, 512) > 0          # lines of two waves
     assert lib.tsgu_march_lds_bytes(2, 2, 32, 8, 32, 1, 1, 27, 512) < 0          # 32 columns
     nb, nx, ny, nz = 1, 4, 8, 32
     crow, col, val, B, Gd = _problem(nb, nx, ny, nz)

@@ -767,8 +767,6 @@ def linemarch_config_for(plan: LatticePlan, mode: int, vtype: int, p: int, lds_b
     mt = march_tables(plan)
     if mt is None or not mt.full or mt.periodic != 7 or plan.uniform_len != 27 or plan.nz % 8:
         return None
-    if mode == 1 and 32 % plan.nz:
-        return None          # (SDDMM: a wave's 32 rows must be whole z-lines)
     key = ("line", mode, p)
     if key in mt._cfg:
         return mt._cfg[key]

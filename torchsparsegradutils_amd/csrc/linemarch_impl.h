@@ -346,8 +346,9 @@ __global__ __launch_bounds__(NT, 4) void linemarch_spmm_kernel(const LineParams 
 // columns — no cross-lane sum — and both lanes the ninth), a dot is eight v_dot2_f32_bf16 on the packed pairs.  The stored
 // position of (dx, dy, dz) in the OWN row: 9·rank_x (wave-uniform per step and target) + 3·rank_y + rank_z (per-lane constants).
 // Results are staged as bf16 in the row's 54-byte slot of its target plane's stage (three planes: a target lives for three
-// steps); a wave's rows are whole z-lines (nz divides 32), so the wave itself flushes its 1728 contiguous bytes of a finished
-// target as aligned 16-byte pieces — no barrier between the last write and the flush, gradA leaves fully coalesced.
+// steps); the rows of a tile plane are consecutive in memory (whole z-lines), so a wave's 32 rows are 1728 contiguous bytes that
+// start on a 16-byte boundary: the wave itself flushes what it staged for a finished target as aligned 16-byte pieces — no barrier
+// between the last write and the flush, gradA leaves fully coalesced.
 template <int NT>
 __global__ __launch_bounds__(NT, 4) void linemarch_sddmm_kernel(const LineParams P) {
     typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
@@ -446,7 +447,7 @@ __global__ __launch_bounds__(NT, 4) void linemarch_sddmm_kernel(const LineParams
             *reinterpret_cast<unsigned short*>(sm + saddr[t] + uB) = (unsigned short)(pab >> 16);
             *reinterpret_cast<unsigned short*>(sm + saddr[t] + uC) = (unsigned short)pc;
         }
-        if (j >= 2) {   // target j - 2 is complete: this wave's rows (whole z-lines, written by this wave only) leave as 16-byte pieces
+        if (j >= 2) {   // target j - 2 is complete: this wave's 32 rows (written by this wave only) leave as 16-byte pieces
             const int64_t row0 = item_row0 + (int64_t)(x0 + j - 2) * plane_rows + y0 * P.nz + wave * (kWave / 2);
             char* const dst = static_cast<char*>(P.gvals) + row0 * kLineValB;
             const char* const src = sm + P.o_stage + slotA * P.stage_bytes + wave * (kWave / 2 * kLineValB);
@@ -472,7 +473,6 @@ inline int linemarch_layout(LineParams& P, int threads, int mode) {
         region = P.g_bytes + hl * P.nz * kLineValB;
         if (hl * (P.nz * kLineValB / 16) > kLineKV * threads) return TSGU_ERR_TOO_LARGE;
     } else if (mode == kLatSddmm) {
-        if (32 % P.nz) return TSGU_ERR_BAD_ARG;          // a wave's 32 rows are whole z-lines (it flushes what it staged)
         region = P.g_bytes + P.ty * P.nz * kLineRowB;    // + the row operand's plane (own rows only)
     } else if (mode == kLatSpmm) {
         region = P.g_bytes;
