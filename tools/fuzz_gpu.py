@@ -192,6 +192,54 @@ def case_lattice(g, i):
     return f"lattice {vd} dims={dims} p={p}", vd, errs
 
 
+def case_line(g, i):
+    """bf16 periodic 27-point stencils at 16 columns whose z-lines are whole 16-byte pieces of values (what the whole-line march,
+    csrc/linemarch_impl.h, takes): random tile-divisible sizes, 2-D or batched, faces in every dimension — against dense fp64 autograd."""
+    from torchsparsegradutils_amd.utils import synthetic
+
+    vd, p = torch.bfloat16, 16
+    nz = [8, 16, 32, 64][int(torch.randint(0, 4, (1,), generator=g))]
+    threads = [256, 512][int(torch.randint(0, 2, (1,), generator=g))]
+    ty = max(threads // (2 * nz), 1)
+    ny = ty * int(torch.randint(1, 4, (1,), generator=g))
+    if ny < 3:
+        ny = ty * 3
+    nx = int(torch.randint(3, 9, (1,), generator=g))
+    nb = int(torch.randint(0, 3, (1,), generator=g))          # 0: a 2-D operand
+    n = nx * ny * nz
+    if n > 7000:
+        nx = max(3, 7000 // (ny * nz))
+        n = nx * ny * nz
+    crow, col = synthetic.stencil27_periodic(nx, ny, nz, torch.int32, device=DEV)
+    items = max(nb, 1)
+    val = (torch.randn((items, col.numel()), dtype=torch.float64, generator=g) + 0.01).to(vd).to(DEV)
+    B = torch.randn((items, n, p), dtype=torch.float64, generator=g).to(vd).to(DEV)
+    G = torch.randn((items, n, p), dtype=torch.float64, generator=g).to(vd).to(DEV)
+    if nb:
+        A = torch.sparse_csr_tensor(crow.repeat(items, 1), col.repeat(items, 1), val, (items, n, n)).requires_grad_(True)
+        Bs, Gs = B.clone().requires_grad_(True), G
+    else:
+        A = torch.sparse_csr_tensor(crow, col, val[0], (n, n)).requires_grad_(True)
+        Bs, Gs = B[0].clone().requires_grad_(True), G[0]
+    for _ in range(REPEAT):
+        A.grad = Bs.grad = None
+        out = T.sparse_mm(A, Bs)
+        out.backward(Gs)
+        T.wait_for_plans()
+        CPP_STEPS[0] += type(out.grad_fn).__name__ != "SparseMatMulBackward"
+    rows = torch.repeat_interleave(torch.arange(n, device=DEV), crow.long().diff())
+    errs = [0.0, 0.0, 0.0]
+    for k in range(items):
+        Adg = torch.sparse_csr_tensor(crow, col, val[k].double(), (n, n)).to_dense().requires_grad_(True)
+        Bdg = B[k].double().clone().requires_grad_(True)
+        ref = Adg @ Bdg
+        ref.backward(G[k].double())
+        mine = (out[k], A.grad.values()[k], Bs.grad[k]) if nb else (out, A.grad.values(), Bs.grad)
+        for j, (a, b) in enumerate(zip(mine, (ref, Adg.grad[rows, col.long()], Bdg.grad))):
+            errs[j] = max(errs[j], nerr(a, b))
+    return f"line {vd} nb={nb} dims={[nx, ny, nz]} p={p}", vd, tuple(errs)
+
+
 def case_solve(g, i):
     """sparse_generic_solve with each Krylov solver on a random sparse SPD band matrix vs torch.linalg.solve."""
     from torchsparsegradutils_amd import utils as U
@@ -249,7 +297,7 @@ def main():
         _ops.PACK_MIN_NNZ = 0 if force else 1 << 16
         _ops.PLAN_AFTER_USES = 0 if force else 1
         _pattern.DEDUP_MODE = ["auto", "force", "off"][i % 3]
-        fn = case_tri if i % 5 == 4 else case_solve if i % 5 == 3 else case_lattice if i % 5 == 2 else case_mm
+        fn = case_tri if i % 5 == 4 else case_solve if i % 5 == 3 else (case_line if i % 20 == 7 else case_lattice) if i % 5 == 2 else case_mm
         try:
             r = fn(g, i)
         except Exception as exc:  # noqa: BLE001
