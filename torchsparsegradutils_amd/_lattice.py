@@ -765,7 +765,7 @@ def linemarch_config_for(plan: LatticePlan, mode: int, vtype: int, p: int, lds_b
     if not ENABLE_LINEMARCH or not ENABLE_MARCH or vtype != 2 or p != 16 or mode not in LINEMARCH_MODES:
         return None
     mt = march_tables(plan)
-    if mt is None or not mt.full or mt.periodic != 7 or plan.uniform_len != 27 or plan.nz % 8:
+    if mt is None or not mt.full or mt.periodic != 7 or plan.uniform_len != 27 or plan.nz not in (8, 16, 32, 64):      # (the kernels are compiled per line length)
         return None
     key = ("line", mode, p)
     if key in mt._cfg:

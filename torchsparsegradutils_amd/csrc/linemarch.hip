@@ -23,26 +23,31 @@ int linemarch_fill(LineParams& P, const tsgu_march_plan* pl, int mode, int64_t p
     return lds;
 }
 
-int linemarch_run(int mode, const LineParams& P, int threads, hipStream_t stream) {
-    if (mode == kLatSpmmT) {
-        switch (threads) {
-            case 256: return linemarch_launch_t<256, kLatSpmmT>(P, stream);
-            case 512: return linemarch_launch_t<512, kLatSpmmT>(P, stream);
-            case 1024: return linemarch_launch_t<1024, kLatSpmmT>(P, stream);
-        }
-    } else if (mode == kLatSpmm) {
-        switch (threads) {
-            case 256: return linemarch_launch_t<256, kLatSpmm>(P, stream);
-            case 512: return linemarch_launch_t<512, kLatSpmm>(P, stream);
-            case 1024: return linemarch_launch_t<1024, kLatSpmm>(P, stream);
-        }
-    } else if (mode == kLatSddmm) {
-        switch (threads) {
-            case 256: return linemarch_launch_t<256, kLatSddmm>(P, stream);
-            case 512: return linemarch_launch_t<512, kLatSddmm>(P, stream);
-            case 1024: return linemarch_launch_t<1024, kLatSddmm>(P, stream);
-        }
+template <int NT, int MODE>
+static int run_nz(const LineParams& P, hipStream_t stream) {
+    switch (P.nz) {
+        case 8: return linemarch_launch_t<NT, 8, MODE>(P, stream);
+        case 16: return linemarch_launch_t<NT, 16, MODE>(P, stream);
+        case 32: return linemarch_launch_t<NT, 32, MODE>(P, stream);
+        case 64: return linemarch_launch_t<NT, 64, MODE>(P, stream);
     }
+    return TSGU_ERR_BAD_ARG;
+}
+
+template <int MODE>
+static int run_nt(const LineParams& P, int threads, hipStream_t stream) {
+    switch (threads) {
+        case 256: return run_nz<256, MODE>(P, stream);
+        case 512: return run_nz<512, MODE>(P, stream);
+        case 1024: return run_nz<1024, MODE>(P, stream);
+    }
+    return TSGU_ERR_BAD_ARG;
+}
+
+int linemarch_run(int mode, const LineParams& P, int threads, hipStream_t stream) {
+    if (mode == kLatSpmmT) return run_nt<kLatSpmmT>(P, threads, stream);
+    if (mode == kLatSpmm) return run_nt<kLatSpmm>(P, threads, stream);
+    if (mode == kLatSddmm) return run_nt<kLatSddmm>(P, threads, stream);
     return TSGU_ERR_BAD_ARG;
 }
 
