@@ -404,7 +404,7 @@ int tsgu_csr_sddmm_lattice(int vtype, const tsgu_lattice_plan* plan, int64_t n_r
  * fp32; p in {16, 32, 64} per call (wider operands: column tiles of 64 by the caller, the SDDMM with `accumulate`).
  *
  * bf16 (csrc/linemarch_impl.h, "whole-line march"): the products of a PERIODIC 27-point box stencil (mask = all 27 bits, periodic = 7,
- * uniform_len = 27) at p = 16 whose tile is `ty` whole z-lines (tz = nz, nz a multiple of 8, threads = ty·nz·2 in {256, 512, 1024},
+ * uniform_len = 27) at p = 16 whose tile is `ty` whole z-lines (tz = nz, nz in {8, 16, 32, 64}, threads = ty·nz·2 in {256, 512, 1024},
  * ny a multiple of ty).  The value rows are staged raw (stored order) and the stored position of a displacement is computed —
  * 9·rank_x + 3·rank_y + rank_z, the rank of the wrapped neighbour coordinate among the three of its dimension: rows with sorted
  * columns — instead of read from kidx / rcls: the CALLER guarantees that this arithmetic describes every row (the Python side checks

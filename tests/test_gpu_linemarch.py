@@ -188,11 +188,11 @@ def test_abi_refuses_what_the_kernels_do_not_cover():
     from torchsparsegradutils_amd import _backend as be, _lattice as lt, _pattern
 
     lib = be.load_library()
-    # LDS bytes: whole lines only (threads = ty·nz·2), nz a multiple of 8
+    # LDS bytes: whole lines only (threads = ty·nz·2), nz one of 8 / 16 / 32 / 64
     assert lib.tsgu_march_lds_bytes(2, 2, 16, 8, 32, 1, 1, 27, 512) > 0
     assert lib.tsgu_march_lds_bytes(0, 2, 16, 8, 32, 1, 1, 27, 512) > 0 and lib.tsgu_march_lds_bytes(1, 2, 16, 8, 32, 1, 1, 27, 512) > 0
     assert lib.tsgu_march_lds_bytes(2, 2, 16, 8, 32, 1, 1, 27, 256) < 0          # threads != ty·nz·2
-    assert lib.tsgu_march_lds_bytes(2, 2, 16, 8, 12, 1, 1, 27, 192) < 0          # nz not a multiple of 8
+    assert lib.tsgu_march_lds_bytes(2, 2, 16, 8, 12, 1, 1, 27, 192) < 0          # a line length without kernels
     assert lib.tsgu_march_lds_bytes(1, 2, 16, 4, 64, 1, 1, 27, 512) > 0          # lines of two waves
     assert lib.tsgu_march_lds_bytes(2, 2, 32, 8, 32, 1, 1, 27, 512) < 0          # 32 columns
     nb, nx, ny, nz = 1, 4, 8, 32
