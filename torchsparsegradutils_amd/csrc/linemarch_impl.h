@@ -14,14 +14,21 @@
 // the row at (x, y, z) is 9·rank_x + 3·rank_y + rank_z, rank_d = rank of the (wrapped) neighbour coordinate among the three
 // of its dimension (checked against the lattice plan's class tables by the caller, `_lattice.linemarch_ok`).  A lane keeps
 // (y, z) for the whole march, so 3·rank_y + rank_z of its nine source rows are nine per-lane constants folded into the LDS
-// addresses; rank_x is the same for all rows of a source plane: the three values at +0 / +18 / +36 bytes belong to
-// dx = -1 / 0 / +1 in interior planes and are rotated at the two faces (a wave-uniform branch between three copies of the step).
+// addresses; rank_x is the same for all rows of a source plane: wave-uniform per step.
 // A tile is TY whole z-lines (the z wrap is inside the line: no z halo, folded into the per-lane addresses as well), two
 // planes of (TY + 2) lines are resident: 55 KB at TY = 8 — two workgroups of eight waves per CU, ALL of them computing.
 //
-// Sum per target row: source planes x-1, x, x+1 in that order (plane by plane as in march_impl.h), inside a plane the taps
-// in ascending (dy, dz) by pairs — two entries per v_dot2_f32_bf16, fp32 accumulation, one rounding at the end: every element
-// within one bf16 ulp of the exact result, like the sweep's (same tests), not bit-identical to it.
+// Instruction issue, not HBM, bounds these kernels (with the bookkeeping compiled out the forward runs at 6.9 TB/s), so:
+// the step loop is unrolled six times (TSGU_LINE_SIX_STEPS: register roles and plane buffer at compile time), the forward
+// and the SDDMM walk the nine STORED POSITIONS of an x-part (value offsets are immediates; per position the lane keeps the
+// dense-row address of the tap stored there), the kernels are compiled per line length (NZ: every LDS offset an immediate),
+// the schedule is pinned pair by pair (an empty asm on the accumulators), and accumulators written by v_dot2c are never
+// moved or converted by instructions the compiler cannot see (the dot pipeline needs wait states before an ordinary VALU read).
+//
+// Sum per target row: source planes x-1, x, x+1 in that order (plane by plane as in march_impl.h), inside a plane by pairs —
+// of taps in ascending (dy, dz) (transposed product) or of stored positions (forward) — two entries per v_dot2_f32_bf16, fp32
+// accumulation, one rounding at the end: every element within one bf16 ulp of the exact result, like the sweep's (same
+// tests), not bit-identical to it.
 #pragma once
 
 #include "lattice_impl.h"
