@@ -491,6 +491,16 @@ __global__ __launch_bounds__(NT, 4) void march_kernel(const MarchParams P) {    
     int tapb[NTAP];   // byte offset of tap i from the row's own position in a halo plane (wave-uniform)
 #pragma unroll
     for (int i = 0; i < NTAP; ++i) tapb[i] = P.tap_row[i] * RB;
+    // SDDMM of the whole box at eight lanes per row: tap i ^ c for register i (see XR below)
+    int tapx[8];
+    if constexpr (MODE == kLatSddmm && MASK == kBoxAll && CL == 8 && NTAP == 9) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            tapx[i] = tapb[0];
+#pragma unroll
+            for (int t = 1; t < 8; ++t) tapx[i] = (i ^ c) == t ? tapb[t] : tapx[i];
+        }
+    }
 
     auto as4 = [](const uint4& raw, float (&f)[4]) {
         f[0] = __uint_as_float(raw.x), f[1] = __uint_as_float(raw.y), f[2] = __uint_as_float(raw.z), f[3] = __uint_as_float(raw.w);
@@ -718,6 +728,13 @@ __global__ __launch_bounds__(NT, 4) void march_kernel(const MarchParams P) {    
         flush();   // target L (target L-1 left at the top of step L+1; with L = 1 nothing left earlier)
     } else {
         // ---- SDDMM -----------------------------------------------------------------------------------------------
+        // Whole box at eight lanes per row (XR): lane c walks the taps 0..7 in the order r ^ c (r = 0..7; per-lane tap offsets, no cost
+        // in the loop), so the partial dot of tap t sits in register t ^ c — then the eight-lane sums of eight taps need NO selects:
+        // recursive halving with fixed register pairs (R[2r] + xor1(R[2r+1]), …) leaves the total of tap c in lane c: 9 instructions
+        // per part instead of 21 (same summation tree as group_sum<float, 8>, operands commuted: the same bits).  A lane then keeps,
+        // per target, the dots of canonical slots 9·j + c (register j = part j) and — lanes 0..2, register 3 — the ninth tap's 9·c + 8.
+        constexpr bool XR = FULL && CL == 8 && NTAP == 9;
+        auto slot_of = [&](int j) -> int { return XR ? (j < 3 ? 9 * j + c : (c < 3 ? 9 * c + 8 : NS)) : j * CL + c; };
         struct Own {
             uint4 row;
             int cls, start;
@@ -733,7 +750,7 @@ __global__ __launch_bounds__(NT, 4) void march_kernel(const MarchParams P) {    
             for (int w = 0; w < (RJ + 3) / 4; ++w) kpk[w] = -1;
 #pragma unroll
             for (int j = 0; j < RJ; ++j) {
-                const int slot = j * CL + c;
+                const int slot = slot_of(j);
                 const int k = (slot < NS && has(slot)) ? (int)kidx_s[cm * 32 + slot] : 0xFF;
                 kpk[j / 4] = (kpk[j / 4] & ~(0xFF << (8 * (j % 4)))) | (k << (8 * (j % 4)));
             }
@@ -876,11 +893,13 @@ __global__ __launch_bounds__(NT, 4) void march_kernel(const MarchParams P) {    
                 if constexpr (FULL) {
                     uint4 b[NTAP];
                     constexpr int kAhead = 3;
+                    // (XR: register i < 8 takes tap i ^ c; the ninth tap is the same for all lanes)
+                    auto tap_at = [&](int i) -> int { return XR && i < 8 ? tapx[i] : tapb[i]; };
 #pragma unroll
-                    for (int i = 0; i < kAhead && i < NTAP; ++i) b[i] = *reinterpret_cast<const uint4*>(bb + tapb[i]);
+                    for (int i = 0; i < kAhead && i < NTAP; ++i) b[i] = *reinterpret_cast<const uint4*>(bb + tap_at(i));
 #pragma unroll
                     for (int i = 0; i < NTAP; ++i) {
-                        if (i + kAhead < NTAP) b[i + kAhead] = *reinterpret_cast<const uint4*>(bb + tapb[i + kAhead]);
+                        if (i + kAhead < NTAP) b[i + kAhead] = *reinterpret_cast<const uint4*>(bb + tap_at(i + kAhead));
                         asm volatile("" ::: "memory");
                         float f[4];
                         as4(b[i], f);
@@ -938,7 +957,25 @@ __global__ __launch_bounds__(NT, 4) void march_kernel(const MarchParams P) {    
                     }
                 }
                 // the 3·NTAP partial dots of this step, by canonical slot p·NTAP + i; slot j·CL + c belongs to lane c, register j
-                if constexpr (CL == 8) {
+                if constexpr (XR) {
+                    auto halve8 = [&](const float (&R)[NTAP]) -> float {       // registers 0..7: tap r ^ c;  -> the eight-lane total of tap c
+                        const float u0 = R[0] + dpp_move<0xB1>(R[1]), u1 = R[2] + dpp_move<0xB1>(R[3]);
+                        const float u2 = R[4] + dpp_move<0xB1>(R[5]), u3 = R[6] + dpp_move<0xB1>(R[7]);
+                        const float v0 = u0 + dpp_move<0x4E>(u1), v1 = u2 + dpp_move<0x4E>(u3);
+                        // lane c ^ 4: lanes 0..3 take lane + 4 (row_shl:4, banks 0 and 2), lanes 4..7 lane - 4 (row_shr:4, banks 1 and 3)
+                        int y = __builtin_amdgcn_update_dpp(0, __float_as_int(v1), 0x104, 0xF, 0x5, false);
+                        y = __builtin_amdgcn_update_dpp(y, __float_as_int(v1), 0x114, 0xF, 0xA, false);
+                        return v0 + __int_as_float(y);
+                    };
+                    rN[0] = halve8(pd[0]);
+                    rC[1] = halve8(pd[1]);
+                    rP[2] = halve8(pd[2]);
+                    // the ninth tap: lane 0 / 1 / 2 gets the total of part 0 / 1 / 2
+                    const float t8 = group_sum_t8<3>(pd[0][8], pd[1][8], pd[2][8], 0.f, 0.f, 0.f, 0.f, 0.f, c);
+                    rN[3] = c == 0 ? t8 : rN[3];
+                    rC[3] = c == 1 ? t8 : rC[3];
+                    rP[3] = c == 2 ? t8 : rP[3];
+                } else if constexpr (CL == 8) {
                     // eight slots at a time: the transposed reduction leaves the total of slot 8j + c in lane c
                     lat_static_for<0, RJ>([&](auto J) {
                         constexpr int j = decltype(J)::value;
@@ -983,7 +1020,7 @@ __global__ __launch_bounds__(NT, 4) void march_kernel(const MarchParams P) {    
                     const bool plain = FULL && oP.cls == P.ident;
 #pragma unroll
                     for (int j = 0; j < RJ; ++j) {
-                        const int slot = j * CL + c;
+                        const int slot = slot_of(j);
                         if (slot < NS && has(slot)) {
                             int k;
                             if (mid) k = (kpk[j / 4] >> (8 * (j % 4))) & 0xFF;
