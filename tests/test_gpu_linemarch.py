@@ -184,6 +184,38 @@ def test_rows_with_unsorted_columns_stay_on_the_general_sweep():
     assert float((C.float() - C1.float()).abs().max()) <= 2.0 ** -7 * float(C1.float().abs().max())
 
 
+def test_every_workgroup_size_and_segmentation_gives_the_same_bits():
+    """256 / 512 / 1024 threads (4 / 8 / 16 lines per tile at nz = 32) and 1 / 2 / 5 x-segments through the C ABI: a row's sum does not
+    depend on the tile it is in — all three products bit-identical across launch configurations."""
+    from torchsparsegradutils_amd import _backend as be, _lattice as lt, _pattern
+
+    lib = be.load_library()
+    nb, nx, ny, nz = 2, 5, 32, 32
+    crow, col, val, B, Gd = _problem(nb, nx, ny, nz, seed=77)
+    _pattern.clear_cache()
+    flat = _pattern.flat_of(_pattern.from_csr(_batched(crow, col, val)))
+    Bd, Gdd, vd = B.to(DEV).reshape(-1, 16), Gd.to(DEV).reshape(-1, 16), val.to(DEV).reshape(-1)
+    base = _line_cfgs(flat, Bd)[2]
+    assert base is not None
+    n, nnz = nb * nx * ny * nz, nb * col.numel()
+    ref = None
+    for threads, nseg in ((512, 1), (256, 1), (1024, 1), (512, 2), (256, 5), (1024, 5)):
+        st = lt._MarchPlanStruct.from_buffer_copy(base.struct)
+        st.threads, st.ty, st.nseg = threads, threads // (2 * nz), nseg
+        C, gB, gA = torch.empty_like(Bd), torch.empty_like(Bd), torch.empty_like(vd)
+        a = ctypes.addressof(st)
+        assert lib.tsgu_csr_spmm_march(2, a, 0, n, nnz, vd.data_ptr(), Bd.data_ptr(), 16, C.data_ptr(), 16, 16, 0, None) == 0
+        assert lib.tsgu_csr_spmm_march(2, a, 1, n, nnz, vd.data_ptr(), Gdd.data_ptr(), 16, gB.data_ptr(), 16, 16, 0, None) == 0
+        assert lib.tsgu_csr_sddmm_march(2, a, n, nnz, Gdd.data_ptr(), 16, Bd.data_ptr(), 16, gA.data_ptr(), 1.0, 0, 16, 0, None) == 0
+        torch.cuda.synchronize()
+        got = (C, gB, gA)
+        if ref is None:
+            ref = got
+        else:
+            for x, y, what in zip(got, ref, ("C", "gradB", "gradA")):
+                assert torch.equal(x.view(torch.int16), y.view(torch.int16)), (threads, nseg, what)
+
+
 def test_abi_refuses_what_the_kernels_do_not_cover():
     from torchsparsegradutils_amd import _backend as be, _lattice as lt, _pattern
 
