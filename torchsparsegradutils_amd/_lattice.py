@@ -759,9 +759,9 @@ def linemarch_ok(plan: LatticePlan, mt: MarchTables) -> bool:
 
 
 def linemarch_config_for(plan: LatticePlan, mode: int, vtype: int, p: int, lds_bytes_fn) -> Optional[MarchConfig]:
-    """Launch configuration of the whole-line march for a stored-order plan, or None: bf16, 16 columns, the SDDMM (mode 1) or the
-    transposed product (mode 2) of a periodic 27-point box stencil whose z-lines are whole 16-byte pieces of values (nz a multiple
-    of 8) and fit a workgroup."""
+    """Launch configuration of the whole-line march for a stored-order plan, or None: bf16, 16 columns, a product (mode 0 A·B, 1 SDDMM,
+    2 Aᵀ·G) of a periodic 27-point box stencil with sorted columns whose z-lines have one of the lengths the kernels are compiled for
+    (8 / 16 / 32 / 64) and whose tile height (threads / (2·nz) lines, 512 threads preferred) divides ny."""
     if not ENABLE_LINEMARCH or not ENABLE_MARCH or vtype != 2 or p != 16 or mode not in LINEMARCH_MODES:
         return None
     mt = march_tables(plan)
