@@ -420,7 +420,9 @@ typedef struct tsgu_march_plan {
     int32_t nseg;             /* x segments per item */
     int32_t threads;          /* workgroup size: 256 or 512 */
     uint32_t mask;            /* displacement set (27 bits) */
-    int32_t periodic;         /* bit 0: x, bit 1: y, bit 2: z */
+    int32_t periodic;         /* bit 0: x, bit 1: y, bit 2: z;  bit 3 (fp32, all three periodic, the whole box, uniform_len = 27): the caller has
+                                 checked that every row stores (dx, dy, dz) at 9·rank_x + 3·rank_y + rank_z (sorted columns) — SpMM / SpMMT then
+                                 stage value rows raw (plain 16-byte copies in every wave) and resolve the (y, z) order where values are read */
     int32_t uniform_len;      /* entries per row when all rows have the same number, else 0 */
     const void* kidx;
     const void* rcls;

@@ -552,6 +552,7 @@ def tune_config(plan: LatticePlan, mode: int, vtype: int, p: int, elem_bytes: in
 
 # ---- plane-march kernels (csrc/march_impl.h): full periodic box stencils --------------------------------------------
 ENABLE_MARCH = os.environ.get("TSGU_ENABLE_MARCH", "1") == "1"
+ENABLE_MARCH_RAW = os.environ.get("TSGU_MARCH_RAW", "1") != "0"      # periodic whole box: raw value rows (no gathers for the rows that wrap)
 _MARCH_CFG_ENV = os.environ.get("TSGU_MARCH_CFG", "")   # "ty,tz,nseg,threads" overrides the choice (experiments)
 # … and per product (TSGU_MARCH_CFG_FWD / _SDDMM / _SPMMT): in-step probes of one kernel's configuration with the others unchanged
 _MARCH_CFG_MODE_ENV = {m: os.environ.get("TSGU_MARCH_CFG_" + n, "") for m, n in ((0, "FWD"), (1, "SDDMM"), (2, "SPMMT"))}
@@ -710,8 +711,14 @@ def march_config_for(plan: LatticePlan, mode: int, vtype: int, p: int, lds_bytes
         cfg.ring, cfg.cpl, cfg.nloc, cfg.tables, cfg.col_tile = 2, 1, plan.ncls, mt, pt
         dy = (ctypes.c_int32 * 9)(*[t[0] for t in mt.taps])
         dz = (ctypes.c_int32 * 9)(*[t[1] for t in mt.taps])
+        # periodic whole box with sorted columns: the kernels may stage value rows RAW (bit 3 of `periodic`: the stored position of a
+        # displacement is 9·rank_x + 3·rank_y + rank_z — checked once per pattern, not while a stream is being captured)
+        periodic = mt.periodic
+        if (ENABLE_MARCH_RAW and plan.rcls.is_cuda and mt.full and mt.periodic == 7 and plan.uniform_len == 27
+                and (getattr(mt, "_line_ok", None) is not None or not torch.cuda.is_current_stream_capturing()) and linemarch_ok(plan, mt)):
+            periodic |= 8
         cfg.struct = _MarchPlanStruct(plan.nb, plan.nx, plan.ny, plan.nz, 1, 1, MARCH_TAPS, dy, dz, plan.ncls, mt.ident,
-                                      ty, tz, nseg, threads, mt.mask, mt.periodic, plan.uniform_len, mt.kidx.data_ptr(),
+                                      ty, tz, nseg, threads, mt.mask, periodic, plan.uniform_len, mt.kidx.data_ptr(),
                                       plan.rcls.data_ptr(), plan.rstart.data_ptr())
         cfg.struct_addr = ctypes.addressof(cfg.struct)
     mt._cfg[key] = cfg
@@ -762,7 +769,7 @@ def linemarch_config_for(plan: LatticePlan, mode: int, vtype: int, p: int, lds_b
     """Launch configuration of the whole-line march for a stored-order plan, or None: bf16, 16 columns, a product (mode 0 A·B, 1 SDDMM,
     2 Aᵀ·G) of a periodic 27-point box stencil with sorted columns whose z-lines have one of the lengths the kernels are compiled for
     (8 / 16 / 32 / 64) and whose tile height (threads / (2·nz) lines, 512 threads preferred) divides ny."""
-    if not ENABLE_LINEMARCH or not ENABLE_MARCH or vtype != 2 or p != 16 or mode not in LINEMARCH_MODES:
+    if not ENABLE_LINEMARCH or not ENABLE_MARCH or vtype != 2 or p != 16 or mode not in LINEMARCH_MODES or not plan.rcls.is_cuda:
         return None
     mt = march_tables(plan)
     if mt is None or not mt.full or mt.periodic != 7 or plan.uniform_len != 27 or plan.nz not in (8, 16, 32, 64):      # (the kernels are compiled per line length)

@@ -6,7 +6,7 @@ namespace tsgu {
 // fills P from the plan (geometry, tile) and validates it; returns the dynamic LDS bytes or a negative status
 int linemarch_fill(LineParams& P, const tsgu_march_plan* pl, int mode, int64_t p, int64_t n_rows, int64_t nnz) {
     if (!pl || p != 16) return TSGU_ERR_BAD_DTYPE;
-    if (pl->ntap != 9 || pl->ry != 1 || pl->rz != 1 || pl->mask != (1u << 27) - 1u || pl->periodic != 7 || pl->uniform_len != 27) return TSGU_ERR_BAD_ARG;
+    if (pl->ntap != 9 || pl->ry != 1 || pl->rz != 1 || pl->mask != (1u << 27) - 1u || (pl->periodic & 7) != 7 || pl->uniform_len != 27) return TSGU_ERR_BAD_ARG;
     if (pl->nb <= 0 || pl->nx < 3 || pl->ny < 3 || pl->nz < 3 || pl->nseg <= 0 || pl->nseg > pl->nx || pl->tz != pl->nz) return TSGU_ERR_BAD_ARG;
     if (n_rows >= 0 && ((int64_t)pl->nb * pl->nx * pl->ny * pl->nz != n_rows || 27 * n_rows != nnz)) return TSGU_ERR_BAD_ARG;
     if (nnz > 0x7fffffffLL || nnz * 2 + 16 > 0xffffffffLL) return TSGU_ERR_TOO_LARGE;

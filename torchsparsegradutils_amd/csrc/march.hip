@@ -46,6 +46,8 @@ int fill(MarchParams& P, const tsgu_march_plan* pl, int mode, int vtype, int64_t
     P.mask = pl->mask;
     P.per_x = pl->periodic & 1, P.per_y = pl->periodic >> 1 & 1, P.per_z = pl->periodic >> 2 & 1;
     P.uniform = pl->uniform_len;
+    // bit 3 of `periodic`: the caller has checked that rows store (dx, dy, dz) at 9·rank_x + 3·rank_y + rank_z — raw value rows
+    P.raw = (pl->periodic & 8) != 0 && (pl->periodic & 7) == 7 && pl->mask == kBoxAll && pl->uniform_len == 27;
     P.rstart = static_cast<const int*>(pl->rstart);
     const int hz = pl->tz + 2 * pl->rz;
     for (int i = 0; i < 9; ++i) {

@@ -51,6 +51,9 @@ struct MarchParams {
     int uniform;                 // > 0: every row stores this many entries (`rstart` is not read); 0: rows start at rstart[row]
     const int* rstart;           // [rows + 1] first value position of each row (A's row pointer as int32)
     int accumulate;              // SDDMM: add to gvals instead of overwriting (column tiles of wide dense operands)
+    int raw;                     // periodic whole box, rows with sorted columns (the stored position of (dx, dy, dz) is 9·rank_x + 3·rank_y +
+                                 // rank_z: checked by the caller): SpMM / SpMMT stage the value rows of interior planes RAW (plain 16-byte copies
+                                 // for every wave, no gathers for the rows that wrap in y / z) and resolve the (y, z) order where a value is read
     const unsigned char* kidx;   // [ncls][32] stored position of canonical slot s (0xff: the row has no such entry); byte 31: row length
     const unsigned char* rcls;   // [rows] class of each row
     const void* val;
@@ -136,11 +139,12 @@ __device__ __forceinline__ float group_sum_t8(float d0, float d1, float d2, floa
 // not reference (non-finite operands behave as in the reference).
 constexpr uint32_t kBoxAll = (1u << 27) - 1u;      // every displacement of the 3 x 3 x 3 box
 
-enum MarchRows { kRowsPointer = 0, kRowsUniform = 1, kRowsBox = 2 };
+enum MarchRows { kRowsPointer = 0, kRowsUniform = 1, kRowsBox = 2, kRowsRaw = 3 };     // kRowsRaw: kRowsUniform + raw value rows (SpMM / SpMMT of the periodic whole box)
 
 template <typename V, int CL, int MODE, int NT, int NTAP, uint32_t MASK, int ROWS>
 __global__ __launch_bounds__(NT, 4) void march_kernel(const MarchParams P) {     // 4 waves per SIMD: at most 128 VGPRs
-    constexpr bool PTR = ROWS == kRowsPointer, UNIF = ROWS == kRowsUniform, BOXA = ROWS == kRowsBox;
+    constexpr bool PTR = ROWS == kRowsPointer, RAWR = ROWS == kRowsRaw, UNIF = ROWS == kRowsUniform || RAWR, BOXA = ROWS == kRowsBox;
+    static_assert(!RAWR || (MASK == kBoxAll && MODE != kLatSddmm), "raw value rows: SpMM / SpMMT of the whole box");
     static_assert(!BOXA || MASK == kBoxAll, "row starts by box arithmetic: the whole box only");
     constexpr bool FULL = MASK == kBoxAll;     // the whole box
     static_assert(MASK != 0 && MASK <= kBoxAll, "a displacement set of the 3 x 3 x 3 box");
@@ -244,6 +248,15 @@ __global__ __launch_bounds__(NT, 4) void march_kernel(const MarchParams P) {    
     __syncthreads();
     const unsigned char* const kidx_s = reinterpret_cast<const unsigned char*>(sm + P.o_tab);
     const int* const rows_s = reinterpret_cast<const int*>(sm + P.o_rows);
+    // RAW value rows (periodic whole box, MarchParams::raw).  A row with sorted columns stores (dx, dy, dz) at position 9·t + q: t = the rank
+    // of its x-neighbour plane (= dx + 1 in interior planes, rotated at the two x faces: the same for all rows of a plane), q = 3·rank_y +
+    // rank_z (depends on the row's (y, z) only: a per-lane constant of the march).  Staged rows are "x-canonical, (y, z) as stored":
+    // interior planes by plain 16-byte copies in EVERY wave (with canonical rows the waves that hold a row wrapping in y / z gather 28
+    // values per row with 4-byte requests at every step — the tiles at the y / z faces, and a launch takes as long as its slowest
+    // workgroup: forward 73 -> 70 us, transposed product 80 -> 70 us at C2 with every wave on the plain copy); the two x-face planes by
+    // 4-byte requests that undo the rotation of the parts (arithmetic, no look-up).  The readers resolve q: see tapl / tvl below.
+    constexpr bool rawv = RAWR;
+    auto xrank = [&](int x, int d) -> int { return x == 0 ? (d < 0 ? 2 : d) : (x == P.nx - 1 ? (d > 0 ? 0 : d + 2) : d + 1); };
 
     // ---- per-thread descriptors ---------------------------------------------------------------------------------
     const uint32_t ldsb = (uint32_t)P.lds_ * 4u;
@@ -353,7 +366,7 @@ __global__ __launch_bounds__(NT, 4) void march_kernel(const MarchParams P) {    
     // with every wave on the plain copy (wrong results) 69 / 78 us.  Only the two x-face planes still look up per step.
     int mid_plain = 0;
     int gk[PTR ? 1 : NPASS][PTR ? 1 : NGI];
-    if constexpr (MODE != kLatSddmm && !PTR) {
+    if constexpr (MODE != kLatSddmm && !PTR && !RAWR) {
         const int prow_mid = row_of_x(1);
 #pragma unroll
         for (int q = 0; q < NPASS; ++q) {
@@ -392,15 +405,16 @@ __global__ __launch_bounds__(NT, 4) void march_kernel(const MarchParams P) {    
     // pointers) first value position of srow[q]
     // (pbase, pcx: plane_base / plane_cx of the plane — kept up to date by the march, below; unused with row pointers)
     // mid: an interior plane — no look-ups (above)
-    auto stage_vals = [&](int pbase, int pcx, bool mid, unsigned region, const int (&cls)[NPASS], const int (&stt)[NPASS]) {
+    auto stage_vals = [&](int pbase, int pcx, bool mid, int xv, unsigned region, const int (&cls)[NPASS], const int (&stt)[NPASS]) {
         if constexpr (MODE != kLatSddmm) {
 #pragma unroll
             for (int q = 0; q < NPASS; ++q) {
                 const int first = q * NG + wave * RPW;                       // wave-uniform
                 if (first < staged_rows) {
                     const unsigned wbase = sbase + region + (unsigned)(first * VP);
-                    const bool plain = FULL && (!PTR && mid ? (mid_plain >> q & 1) != 0
-                                                               : __builtin_amdgcn_ballot_w64(srow[q] >= 0 && cls[q] != P.ident) == 0);
+                    const bool plain = FULL && (rawv ? mid
+                                                     : (!PTR && mid ? (mid_plain >> q & 1) != 0
+                                                                    : __builtin_amdgcn_ballot_w64(srow[q] >= 0 && cls[q] != P.ident) == 0));
                     if (plain) {
                         // rows of the canonical class hold all NS values in canonical order: a plain copy
 #pragma unroll
@@ -428,7 +442,7 @@ __global__ __launch_bounds__(NT, 4) void march_kernel(const MarchParams P) {    
                                 }
                             }
                         }
-                    } else if (!PTR && mid) {
+                    } else if (!PTR && !rawv && mid) {
                         // an interior plane: every lane knows its source
 #pragma unroll
                         for (int n = 0; n < NGI; ++n) {
@@ -457,7 +471,8 @@ __global__ __launch_bounds__(NT, 4) void march_kernel(const MarchParams P) {    
                             else rs = pbase + pcx * (rr > 0 ? rr : 0);
                             // (a row at a face of a truncated lattice has no entry towards the neighbours beyond it: k = 0xff,
                             // nothing is requested — its slot was cleared once, below, or is never read)
-                            const int k = allid ? __builtin_popcount(mask & ((1u << (slot & 31)) - 1u)) : (int)kidx_s[rc * 32 + (slot & 31)];
+                            int k = allid ? __builtin_popcount(mask & ((1u << (slot & 31)) - 1u)) : (int)kidx_s[rc * 32 + (slot & 31)];
+                            if (rawv) k = NTAP * xrank(xv, slot / NTAP - 1) + slot % NTAP;      // (an x-face plane: only the parts are put in order)
                             if (rr >= 0 && slot < NS && has(slot) && (UNIF || k != 0xFF))
                                 lat_dma4<MODE == kLatSpmm>(valb, (uint32_t)rs * 4u + (uint32_t)k * 4u, wbase + (unsigned)(n * kWave * 4));
                         }
@@ -491,6 +506,33 @@ __global__ __launch_bounds__(NT, 4) void march_kernel(const MarchParams P) {    
     int tapb[NTAP];   // byte offset of tap i from the row's own position in a halo plane (wave-uniform)
 #pragma unroll
     for (int i = 0; i < NTAP; ++i) tapb[i] = P.tap_row[i] * RB;
+    // raw value rows — forward: register i of a part holds the value at STORED position i (the same vector reads as with canonical rows)
+    // and is multiplied with the dense row of the tap stored there (tapl[i]; canonical rows: tapb[i]);  transposed product: the value
+    // triple of tap i sits at position q of its SOURCE row's parts (tvq[i] = 4·q bytes; canonical rows: 4·(8 - i))
+    int tapl[NTAP], tvq[NTAP];
+#pragma unroll
+    for (int i = 0; i < NTAP; ++i) tapl[i] = tapb[i], tvq[i] = 4 * (NTAP - 1 - i);
+    if constexpr (RAWR) {
+        {
+            const int prow_mid = row_of_x(1);
+            if constexpr (MODE == kLatSpmm) {
+                const int cm = crow >= 0 ? (int)P.rcls[prow_mid + crow] : P.ident;
+#pragma unroll
+                for (int i = 0; i < NTAP; ++i) {
+                    const int q = (int)kidx_s[cm * 32 + NTAP + i] - NTAP;      // stored position of tap i inside the dx = 0 part
+#pragma unroll
+                    for (int t = 0; t < NTAP; ++t) tapl[t] = q == t ? tapb[i] : tapl[t];
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < NTAP; ++i) {
+                    const int sr = crow >= 0 ? rows_s[hrow + P.tap_row[i]] : -1;          // the source of tap i (a halo row)
+                    const int cs = sr >= 0 ? (int)P.rcls[prow_mid + sr] : P.ident;
+                    tvq[i] = 4 * ((int)kidx_s[cs * 32 + NTAP + (NTAP - 1 - i)] - NTAP);   // its entry towards this row: displacement -tap i
+                }
+            }
+        }
+    }
     // SDDMM of the whole box at eight lanes per row: tap i ^ c for register i (see XR below)
     int tapx[8];
     if constexpr (MODE == kLatSddmm && MASK == kBoxAll && CL == 8 && NTAP == 9) {
@@ -537,7 +579,7 @@ __global__ __launch_bounds__(NT, 4) void march_kernel(const MarchParams P) {    
             pin_cls(cls, stt);
         }
         if (x_ok(0)) dma_ring(row_of_x(x_ring), 0);
-        if (x_ok(first_val)) stage_vals(vbase, vcx, is_mid(x_val), (unsigned)(P.o_vals + (MODE == kLatSpmm ? 1 : 0) * vbuf), cls, stt);
+        if (x_ok(first_val)) stage_vals(vbase, vcx, is_mid(x_val), x_val, (unsigned)(P.o_vals + (MODE == kLatSpmm ? 1 : 0) * vbuf), cls, stt);
         x_ring = wrap(x_ring + 1, P.nx);
         next_val_plane();
         const int first_next = first_val + 1;                               // ring index of the next value plane
@@ -567,7 +609,7 @@ __global__ __launch_bounds__(NT, 4) void march_kernel(const MarchParams P) {    
             // 2. asynchronous fetches: the next halo plane, the next value plane
             if (s + 1 <= L + 1 && x_ok(s + 1)) dma_ring(row_of_x(x_ring), (s + 1) & 1);
             const int vnext = MODE == kLatSpmm ? s + 2 : s + 1;
-            if (vnext <= last_val && x_ok(vnext)) stage_vals(vbase, vcx, is_mid(x_val), (unsigned)(P.o_vals + (vnext & (VB - 1)) * vbuf), cls, stt);
+            if (vnext <= last_val && x_ok(vnext)) stage_vals(vbase, vcx, is_mid(x_val), x_val, (unsigned)(P.o_vals + (vnext & (VB - 1)) * vbuf), cls, stt);
             x_ring = wrap(x_ring + 1, P.nx);
             next_val_plane();
             // 3. class bytes for the next step
@@ -600,10 +642,10 @@ __global__ __launch_bounds__(NT, 4) void march_kernel(const MarchParams P) {    
                         uint4 b[NTAP];
                         constexpr int kAhead = 3;
 #pragma unroll
-                        for (int i = 0; i < kAhead && i < NTAP; ++i) b[i] = *reinterpret_cast<const uint4*>(bb + tapb[i]);
+                        for (int i = 0; i < kAhead && i < NTAP; ++i) b[i] = *reinterpret_cast<const uint4*>(bb + tapl[i]);
 #pragma unroll
                         for (int i = 0; i < NTAP; ++i) {
-                            if (i + kAhead < NTAP) b[i + kAhead] = *reinterpret_cast<const uint4*>(bb + tapb[i + kAhead]);
+                            if (i + kAhead < NTAP) b[i + kAhead] = *reinterpret_cast<const uint4*>(bb + tapl[i + kAhead]);
                             asm volatile("" ::: "memory");
                             float f[4];
                             as4(b[i], f);
@@ -649,18 +691,18 @@ __global__ __launch_bounds__(NT, 4) void march_kernel(const MarchParams P) {    
                     // transposed walk: the source through tap i is the halo row at own + tap i; its entry towards a target
                     // at dx sits at canonical slot (dx+1)·NTAP + (NTAP-1-i) of ITS value row
                     const char* const vb0 = sm + P.o_vals + (s & 1) * vbuf + hrow * VP;
-                    int tapv[NTAP];
+                    int tapv[NTAP], tvl[NTAP];      // value row of tap i's source (wave-uniform) / + the position of its triple (raw rows: per lane)
 #pragma unroll
-                    for (int i = 0; i < NTAP; ++i) tapv[i] = P.tap_row[i] * VP;
+                    for (int i = 0; i < NTAP; ++i) tapv[i] = P.tap_row[i] * VP, tvl[i] = tapv[i] + tvq[i];
                     if constexpr (FULL) {
                         uint4 b[NTAP];
                         float a[NTAP][3];
                         constexpr int kAhead = 2;
                         auto fetch = [&](int i) {
                             b[i] = *reinterpret_cast<const uint4*>(bb + tapb[i]);
-                            const char* const vr = vb0 + tapv[i];
+                            const char* const vr = vb0 + tvl[i];
 #pragma unroll
-                            for (int p = 0; p < 3; ++p) a[i][p] = *reinterpret_cast<const float*>(vr + ((2 - p) * NTAP + NTAP - 1 - i) * 4);
+                            for (int p = 0; p < 3; ++p) a[i][p] = *reinterpret_cast<const float*>(vr + (2 - p) * (NTAP * 4));
                         };
 #pragma unroll
                         for (int i = 0; i < kAhead && i < NTAP; ++i) fetch(i);

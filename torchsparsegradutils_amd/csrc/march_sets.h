@@ -58,8 +58,12 @@ int march_subset_sddmm(int cl, const MarchParams& P, hipStream_t s) {
 template <uint32_t MASK>
 int march_both_sizes(int mode, int cl, int threads, bool uni, const MarchParams& P, hipStream_t s) {
 #define TSGU_MARCH_CASE(M, T)                                                                   \
-    if (mode == M && threads == T)                                                              \
-        return uni ? march_by_lanes<M, T, MASK, kRowsUniform>(cl, P, s) : march_by_lanes<M, T, MASK, march_ragged_rows(MASK)>(cl, P, s);
+    if (mode == M && threads == T) {                                                            \
+        if constexpr (MASK == kBoxAll && M != kLatSddmm) {                                      \
+            if (uni && P.raw) return march_by_lanes<M, T, MASK, kRowsRaw>(cl, P, s);            \
+        }                                                                                       \
+        return uni ? march_by_lanes<M, T, MASK, kRowsUniform>(cl, P, s) : march_by_lanes<M, T, MASK, march_ragged_rows(MASK)>(cl, P, s); \
+    }
     TSGU_MARCH_CASE(kLatSpmm, 256)
     TSGU_MARCH_CASE(kLatSpmm, 512)
     TSGU_MARCH_CASE(kLatSddmm, 256)
