@@ -250,11 +250,13 @@ __global__ __launch_bounds__(NT, 4) void march_kernel(const MarchParams P) {    
     const int* const rows_s = reinterpret_cast<const int*>(sm + P.o_rows);
     // RAW value rows (periodic whole box, MarchParams::raw).  A row with sorted columns stores (dx, dy, dz) at position 9·t + q: t = the rank
     // of its x-neighbour plane (= dx + 1 in interior planes, rotated at the two x faces: the same for all rows of a plane), q = 3·rank_y +
-    // rank_z (depends on the row's (y, z) only: a per-lane constant of the march).  Staged rows are "x-canonical, (y, z) as stored":
-    // interior planes by plain 16-byte copies in EVERY wave (with canonical rows the waves that hold a row wrapping in y / z gather 28
-    // values per row with 4-byte requests at every step — the tiles at the y / z faces, and a launch takes as long as its slowest
-    // workgroup: forward 73 -> 70 us, transposed product 80 -> 70 us at C2 with every wave on the plain copy); the two x-face planes by
-    // 4-byte requests that undo the rotation of the parts (arithmetic, no look-up).  The readers resolve q: see tapl / tvl below.
+    // rank_z (depends on the row's (y, z) only: a per-lane constant of the march).  Rows are staged AS STORED, by plain 16-byte copies in
+    // EVERY wave (with canonical rows the waves that hold a row wrapping in y / z — the tiles at the y / z faces, at every step — gather
+    // 28 values per row with 4-byte requests, and a launch takes as long as its slowest workgroup: forward 73 -> 70 us, transposed
+    // product 80 -> 70 us at C2 with every wave on the plain copy).  The readers resolve q (tapl / tvl below).  The x-face planes (t
+    // rotated; two planes of nx): the forward has their parts put in order while they are staged (arithmetic 4-byte requests: one tap
+    // loop — a second copy with run-time offsets measured 4 us slower), the transposed product copies them plainly too and reads them
+    // through a second copy of its tap loop with run-time value offsets (3 us faster than gathering them).
     constexpr bool rawv = RAWR;
     auto xrank = [&](int x, int d) -> int { return x == 0 ? (d < 0 ? 2 : d) : (x == P.nx - 1 ? (d > 0 ? 0 : d + 2) : d + 1); };
 
@@ -412,7 +414,9 @@ __global__ __launch_bounds__(NT, 4) void march_kernel(const MarchParams P) {    
                 const int first = q * NG + wave * RPW;                       // wave-uniform
                 if (first < staged_rows) {
                     const unsigned wbase = sbase + region + (unsigned)(first * VP);
-                    const bool plain = FULL && (rawv ? mid
+                    // (raw rows: plain copies in every wave — the forward puts the parts of the two x-face planes in order while staging
+                    // them (arithmetic 4-byte requests below), the transposed product reads them rotated)
+                    const bool plain = FULL && (rawv ? (MODE == kLatSpmmT || mid)
                                                      : (!PTR && mid ? (mid_plain >> q & 1) != 0
                                                                     : __builtin_amdgcn_ballot_w64(srow[q] >= 0 && cls[q] != P.ident) == 0));
                     if (plain) {
@@ -472,7 +476,7 @@ __global__ __launch_bounds__(NT, 4) void march_kernel(const MarchParams P) {    
                             // (a row at a face of a truncated lattice has no entry towards the neighbours beyond it: k = 0xff,
                             // nothing is requested — its slot was cleared once, below, or is never read)
                             int k = allid ? __builtin_popcount(mask & ((1u << (slot & 31)) - 1u)) : (int)kidx_s[rc * 32 + (slot & 31)];
-                            if (rawv) k = NTAP * xrank(xv, slot / NTAP - 1) + slot % NTAP;      // (an x-face plane: only the parts are put in order)
+                            if (rawv) k = NTAP * xrank(xv, slot / NTAP - 1) + slot % NTAP;      // (raw rows, an x-face plane: only the parts are put in order)
                             if (rr >= 0 && slot < NS && has(slot) && (UNIF || k != 0xFF))
                                 lat_dma4<MODE == kLatSpmm>(valb, (uint32_t)rs * 4u + (uint32_t)k * 4u, wbase + (unsigned)(n * kWave * 4));
                         }
@@ -641,6 +645,7 @@ __global__ __launch_bounds__(NT, 4) void march_kernel(const MarchParams P) {    
                     if constexpr (FULL) {
                         uint4 b[NTAP];
                         constexpr int kAhead = 3;
+                        // (raw rows: register i = stored position i of each part, multiplied with the dense row of the tap stored there)
 #pragma unroll
                         for (int i = 0; i < kAhead && i < NTAP; ++i) b[i] = *reinterpret_cast<const uint4*>(bb + tapl[i]);
 #pragma unroll
@@ -695,32 +700,50 @@ __global__ __launch_bounds__(NT, 4) void march_kernel(const MarchParams P) {    
 #pragma unroll
                     for (int i = 0; i < NTAP; ++i) tapv[i] = P.tap_row[i] * VP, tvl[i] = tapv[i] + tvq[i];
                     if constexpr (FULL) {
-                        uint4 b[NTAP];
-                        float a[NTAP][3];
-                        constexpr int kAhead = 2;
-                        auto fetch = [&](int i) {
-                            b[i] = *reinterpret_cast<const uint4*>(bb + tapb[i]);
-                            const char* const vr = vb0 + tvl[i];
+                        // the part of target dx sits at x-position rank(dx) of the SOURCE plane: 2 / 1 / 0 for N / C / P — immediate offsets;
+                        // raw rows at an x-face source plane: rotated, run-time offsets in a second copy of the loop (ROT)
+                        auto taps = [&](auto rot, int oN, int oC, int oP) {
+                            constexpr bool ROT = decltype(rot)::value;
+                            uint4 b[NTAP];
+                            float a[NTAP][3];
+                            constexpr int kAhead = 2;
+                            auto fetch = [&](int i) {
+                                b[i] = *reinterpret_cast<const uint4*>(bb + tapb[i]);
+                                const char* const vr = vb0 + tvl[i];
+                                if constexpr (ROT) {
+                                    a[i][0] = *reinterpret_cast<const float*>(vr + oN), a[i][1] = *reinterpret_cast<const float*>(vr + oC);
+                                    a[i][2] = *reinterpret_cast<const float*>(vr + oP);
+                                } else {
 #pragma unroll
-                            for (int p = 0; p < 3; ++p) a[i][p] = *reinterpret_cast<const float*>(vr + (2 - p) * (NTAP * 4));
-                        };
+                                    for (int p = 0; p < 3; ++p) a[i][p] = *reinterpret_cast<const float*>(vr + (2 - p) * (NTAP * 4));
+                                }
+                            };
 #pragma unroll
-                        for (int i = 0; i < kAhead && i < NTAP; ++i) fetch(i);
+                            for (int i = 0; i < kAhead && i < NTAP; ++i) fetch(i);
 #pragma unroll
-                        for (int i = 0; i < NTAP; ++i) {
-                            if (i + kAhead < NTAP) fetch(i + kAhead);
-                            asm volatile("" ::: "memory");
-                            float f[4];
-                            as4(b[i], f);
-                            // part index here counts the TARGET: N = s+1 (dx = +1), C = s (dx = 0), P = s-1 (dx = -1)
-                            const float aN = a[i][0], aC = a[i][1], aP = a[i][2];
+                            for (int i = 0; i < NTAP; ++i) {
+                                if (i + kAhead < NTAP) fetch(i + kAhead);
+                                asm volatile("" ::: "memory");
+                                float f[4];
+                                as4(b[i], f);
+                                // part index here counts the TARGET: N = s+1 (dx = +1), C = s (dx = 0), P = s-1 (dx = -1)
+                                const float aN = a[i][0], aC = a[i][1], aP = a[i][2];
 #pragma unroll
-                            for (int v = 0; v < 4; ++v) {
-                                accN[v] = fmaf(aN, f[v], accN[v]);
-                                accC[v] = fmaf(aC, f[v], accC[v]);
-                                accP[v] = fmaf(aP, f[v], accP[v]);
+                                for (int v = 0; v < 4; ++v) {
+                                    accN[v] = fmaf(aN, f[v], accN[v]);
+                                    accC[v] = fmaf(aC, f[v], accC[v]);
+                                    accP[v] = fmaf(aP, f[v], accP[v]);
+                                }
                             }
+                        };
+                        bool face = false;
+                        if constexpr (RAWR) {
+                            int xsrc = xs - 1 + s;
+                            xsrc = xsrc < 0 ? xsrc + P.nx : (xsrc >= P.nx ? xsrc - P.nx : xsrc);
+                            face = xsrc == 0 || xsrc == P.nx - 1;
+                            if (face) taps(std::true_type{}, xrank(xsrc, 1) * (NTAP * 4), xrank(xsrc, 0) * (NTAP * 4), xrank(xsrc, -1) * (NTAP * 4));
                         }
+                        if (!face) taps(std::false_type{}, 0, 0, 0);
                     } else {
                         uint4 b[NTAP];
                         float a[NTAP][3];
