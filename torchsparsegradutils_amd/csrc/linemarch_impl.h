@@ -18,8 +18,7 @@
 // A tile is TY whole z-lines (the z wrap is inside the line: no z halo, folded into the per-lane addresses as well), two
 // planes of (TY + 2) lines are resident: 55 KB at TY = 8 — two workgroups of eight waves per CU, ALL of them computing.
 //
-// Launched back to back, instruction issue bounds these kernels, not memory (with the bookkeeping compiled out the forward
-// moves its 1.01 GB of L2 misses in 147 us; inside a step, with cold operands, they sit near the copy rate), so:
+// Launched back to back these kernels are bound by instruction issue rather than by memory, so:
 // the step loop is unrolled six times (TSGU_LINE_SIX_STEPS: register roles and plane buffer at compile time), the forward
 // and the SDDMM walk the nine STORED POSITIONS of an x-part (value offsets are immediates; per position the lane keeps the
 // dense-row address of the tap stored there), the kernels are compiled per line length (NZ: every LDS offset an immediate),
@@ -92,9 +91,8 @@ __device__ __forceinline__ int line_rank(int s, int d, int n) {
 // The step loop of all three kernels is unrolled six times: which of the three register sets holds the target that is completed /
 // continued / started in a step (period 3) and which of the two plane buffers is read (period 2) are then compile-time — no
 // register rotation (sixteen v_mov per step that each waited for the dot pipeline: an accumulator written by v_dot2c needs wait
-// states before an ordinary VALU instruction reads it) and no address toggling.  Measured on the forward kernel with the rotation
-// and the per-value address adds compiled out (wrong results, same traffic): 192 -> 147 us at C5 — these kernels are bound by
-// instruction issue when launched back to back (part of a repeated launch's L2 misses are MALL hits: not an HBM figure).
+// states before an ordinary VALU instruction reads it) and no address toggling.  Measured: forward 190 -> 165 us, SDDMM 198 -> 170 us,
+// transposed product 215 -> 192 us at C5 together with the stored-position walk and the per-line-length instantiation.
 #define TSGU_LINE_SIX_STEPS(run, last)                                                   \
     for (int j_ = 0;;) {                                                                 \
         run(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, j_);     \
