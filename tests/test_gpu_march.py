@@ -101,6 +101,49 @@ def test_march_kernels_match_oracle_and_plan_free_kernels(nb, nx, ny, nz, config
     mt._cfg.clear()
 
 
+@pytest.mark.parametrize("nb,nx,ny,nz", [(1, 9, 10, 12), (1, 3, 3, 3), (2, 5, 6, 8)])
+@pytest.mark.parametrize("p", [32, 64, 16])
+def test_raw_value_rows_equal_canonical_staging(nb, nx, ny, nz, p):
+    """Periodic lattices with sorted columns: the forward and the transposed product stage value rows as stored (`kRowsRaw`, bit 3 of
+    tsgu_march_plan.periodic, set after `_lattice.linemarch_ok`) instead of canonical rows with gathers for the rows that wrap.
+    Both forms against each other: bit-identical on the rows of the canonical class (same summation order), equal to rounding on
+    the rows that wrap (they walk their taps in stored order)."""
+    be, lt, pt = _mods()
+    dev = torch.device("cuda:0")
+    crow, col = _stencil_csr(nx, ny, nz, True, 27, False, nb)
+    n = nb * nx * ny * nz
+    g = torch.Generator().manual_seed(nx * 7 + p)
+    val, B, Gd = (torch.randn(s_, generator=g).to(dev) for s_ in ((col.numel(),), (n, p), (n, p)))
+    plan = pt.RowGather(crow.to(dev), col.to(dev), n, n)
+    lp = lt.build_lattice_plan_hip(plan, be, dims=(nb, nx, ny, nz))
+    mt = lt.march_tables(lp)
+    assert mt is not None and lt.linemarch_ok(lp, mt)
+    inner = (lp.rcls[:n] == mt.ident)
+    out = {}
+    keep = lt.ENABLE_MARCH_RAW
+    try:
+        for raw in (True, False):
+            lt.ENABLE_MARCH_RAW = raw
+            mt._cfg.clear()
+            lt._MARCH_CFG_ENV = "4,8,1,512" if p == 64 else "4,8,1,256"       # (a configuration each of these lattices takes at this width)
+            try:
+                c1 = be.march_config(lp, be.LAT_SPMM, torch.float32, p)
+                c3 = be.march_config(lp, be.LAT_SPMMT, torch.float32, p)
+            finally:
+                lt._MARCH_CFG_ENV = ""
+            assert c1 is not None and bool(c1.struct.periodic & 8) == raw
+            assert c3 is not None and bool(c3.struct.periodic & 8) == raw
+            out[raw] = (None if c1 is None else be.csr_spmm_lattice(lp, c1, val, B), be.csr_spmm_lattice(lp, c3, val, Gd))
+    finally:
+        lt.ENABLE_MARCH_RAW = keep
+        mt._cfg.clear()
+    for a, b in zip(out[True], out[False]):
+        if a is None:
+            continue
+        assert torch.equal(a[inner], b[inner])
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
+
+
 def test_alpha_and_leading_dimensions():
     """alpha scales gradA; dense operands that are column slices of wider arrays (leading dimension > p)."""
     be, lt, pt = _mods()
