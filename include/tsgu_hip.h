@@ -69,7 +69,8 @@ int tsgu_index_fingerprint(int itype, int64_t n, const void* x, void* out2, int 
  * count that is non-zero iff x[k] != ref[k] for some k; when `copy` is given, copy[k] = x[k].  The fingerprint only selects which
  * cached pattern a fresh index tensor is compared with — plans are adopted on out3[2] == 0, never on equal fingerprints alone
  * (a collision would silently compute with another matrix' pattern); `copy` is how the cache keeps the content it compares with
- * (it never holds the caller's tensors).  accumulate as above (0: the three words are zeroed first).
+ * (it never holds the caller's tensors).  accumulate bit 0 as above (0: the three words are zeroed first); bit 1 (with ref, without copy):
+ * COMPARE ONLY — the fingerprint words are left alone (equal tensors have their reference's fingerprint; the hashing is a third of the pass).
  */
 int tsgu_index_fingerprint_match(int itype, int64_t n, const void* x, const void* ref, void* copy, void* out3, int accumulate,
                                  int device, void* stream);

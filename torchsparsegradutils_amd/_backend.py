@@ -878,10 +878,11 @@ def index_fingerprint(*tensors: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def index_fingerprint_match(tensors, refs=None, copy: bool = False):
+def index_fingerprint_match(tensors, refs=None, copy: bool = False, hash: bool = True):
     """One pass per index tensor (see tsgu_index_fingerprint_match): returns (words, copies) — `words` a [len(tensors)][3] int64
     device tensor {fingerprint word 0, word 1, non-zero iff the tensor differs from its `refs` entry}, `copies` fresh contiguous
-    copies of the tensors (None unless `copy`).  Queued on the current stream, nothing is read back here."""
+    copies of the tensors (None unless `copy`).  `hash=False` (with `refs`, without `copy`): compare only — the fingerprint words stay 0
+    (equal tensors have their reference's fingerprint).  Queued on the current stream, nothing is read back here."""
     lib = load_library()
     dev = require_device(*tensors)
     out = torch.zeros((len(tensors), 3), dtype=torch.int64, device=dev)
@@ -896,7 +897,7 @@ def index_fingerprint_match(tensors, refs=None, copy: bool = False):
                     raise ValueError("index_fingerprint_match: a reference tensor does not have the geometry of its index tensor")
             c = torch.empty_like(t) if copy else None
             check(lib.tsgu_index_fingerprint_match(itype_of(t), t.numel(), _p(t), _p(r) if r is not None else None,
-                                                   _p(c) if c is not None else None, out[i].data_ptr(), 1, dev.index, _stream(dev)),
+                                                   _p(c) if c is not None else None, out[i].data_ptr(), 1 | (0 if hash or r is None or copy else 2), dev.index, _stream(dev)),
                   "tsgu_index_fingerprint_match")
             if copy:
                 copies.append(c)

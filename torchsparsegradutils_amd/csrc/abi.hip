@@ -24,7 +24,7 @@ using namespace tsgu;
 // only SELECTS a candidate pattern; what decides an adoption is the exact comparison (CMP: the number of elements that differ from
 // `ref` is added to out[2]) the same pass makes.  COPY: the pass also writes the array to `copy` (the cache's own copy, what later
 // comparisons read).
-template <typename I, bool CMP, bool COPY>
+template <typename I, bool CMP, bool COPY, bool HASH = true>
 __global__ __launch_bounds__(256) void tsgu_fingerprint_kernel(const I* __restrict__ x, const I* __restrict__ ref, I* __restrict__ copy,
                                                                 int64_t n, unsigned long long* __restrict__ out) {
     constexpr int V = 16 / (int)sizeof(I);               // indices per 16-byte load
@@ -36,6 +36,7 @@ __global__ __launch_bounds__(256) void tsgu_fingerprint_kernel(const I* __restri
     // position weights from 32-bit multiplicative hashes of the index (a 64-bit `%` costs ~100 instructions per element: the
     // first version of this kernel took 0.3 ms for C2's 27 M column indices)
     auto add = [&](int64_t k, I xv) {
+        if constexpr (!HASH) return;      // (compare only: the caller takes the fingerprint of the reference when the tensors are equal)
         const unsigned long long a = (unsigned long long)(long long)xv + 0x9e3779b97f4a7c15ull;
         const unsigned int kl = (unsigned int)k;
         const unsigned int w1 = (kl * 2654435761u) | 1u, w2 = ((kl ^ (kl >> 15)) * 2246822519u) | 1u;
@@ -100,8 +101,10 @@ __global__ __launch_bounds__(256) void tsgu_fingerprint_kernel(const I* __restri
     if ((threadIdx.x & 63) == 0) part[0][threadIdx.x >> 6] = h1, part[1][threadIdx.x >> 6] = h2, part[2][threadIdx.x >> 6] = wave_diff;
     __syncthreads();
     if (threadIdx.x == 0) {
-        atomicAdd(out, part[0][0] + part[0][1] + part[0][2] + part[0][3]);
-        atomicAdd(out + 1, part[1][0] + part[1][1] + part[1][2] + part[1][3]);
+        if (HASH) {
+            atomicAdd(out, part[0][0] + part[0][1] + part[0][2] + part[0][3]);
+            atomicAdd(out + 1, part[1][0] + part[1][1] + part[1][2] + part[1][3]);
+        }
         if (CMP) {
             const unsigned long long d = part[2][0] + part[2][1] + part[2][2] + part[2][3];
             if (d) atomicAdd(out + 2, d);
@@ -110,12 +113,14 @@ __global__ __launch_bounds__(256) void tsgu_fingerprint_kernel(const I* __restri
 }
 
 template <typename I>
-static void fingerprint_launch(unsigned blocks, hipStream_t s, const void* x, const void* ref, void* copy, int64_t n, void* out) {
+static void fingerprint_launch(unsigned blocks, hipStream_t s, const void* x, const void* ref, void* copy, int64_t n, void* out, bool hash) {
     const I* const xi = static_cast<const I*>(x);
     const I* const ri = static_cast<const I*>(ref);
     I* const ci = static_cast<I*>(copy);
     unsigned long long* const o = static_cast<unsigned long long*>(out);
-    if (ref && copy)
+    if (ref && !copy && !hash)
+        hipLaunchKernelGGL((tsgu_fingerprint_kernel<I, true, false, false>), dim3(blocks), dim3(256), 0, s, xi, ri, ci, n, o);
+    else if (ref && copy)
         hipLaunchKernelGGL((tsgu_fingerprint_kernel<I, true, true>), dim3(blocks), dim3(256), 0, s, xi, ri, ci, n, o);
     else if (ref)
         hipLaunchKernelGGL((tsgu_fingerprint_kernel<I, true, false>), dim3(blocks), dim3(256), 0, s, xi, ri, ci, n, o);
@@ -191,14 +196,15 @@ int tsgu_index_fingerprint_match(int itype, int64_t n, const void* x, const void
     if (itype != TSGU_I32 && itype != TSGU_I64) return TSGU_ERR_BAD_DTYPE;
     if (const int rc = set_device(device)) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (!accumulate && hipMemsetAsync(out3, 0, 24, s) != hipSuccess) return TSGU_ERR_RUNTIME;
+    const bool hash = (accumulate & 2) == 0;      // bit 1: compare only (ref given, no copy) — out3[0..1] are left alone
+    if (!(accumulate & 1) && hipMemsetAsync(out3, 0, 24, s) != hipSuccess) return TSGU_ERR_RUNTIME;
     if (n == 0) return TSGU_OK;
     const int64_t want = (n + 256 * 16 - 1) / (256 * 16);
     const unsigned blocks = (unsigned)(want < 512 ? want : 512);      // (two workgroups per CU: 64 bytes x 512 threads in flight on each)
     if (itype == TSGU_I32)
-        fingerprint_launch<int32_t>(blocks, s, x, ref, copy, n, out3);
+        fingerprint_launch<int32_t>(blocks, s, x, ref, copy, n, out3, hash);
     else
-        fingerprint_launch<int64_t>(blocks, s, x, ref, copy, n, out3);
+        fingerprint_launch<int64_t>(blocks, s, x, ref, copy, n, out3, hash);
     return check_launch();
 }
 
