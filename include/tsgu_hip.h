@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define TSGU_ABI_VERSION 6
+#define TSGU_ABI_VERSION 7
 
 typedef enum {
     TSGU_OK = 0,

@@ -157,7 +157,7 @@ def test_abi_library_exports_every_declared_symbol():
         assert hasattr(raw, name), f"{name} declared in include/tsgu_hip.h but not exported"
         assert name in _backend.SIGNATURES, f"{name} has no ctypes signature"
     assert set(_backend.SIGNATURES) <= declared
-    assert lib.tsgu_abi_version() == 6
+    assert lib.tsgu_abi_version() == 7
     # row-pair geometry: (rows per workgroup, entry lanes) per (value type, p); unsupported shapes are refused
     r, e = ctypes.c_int(0), ctypes.c_int(0)
     for vt, p_, want in ((_backend.TSGU_F32, 32, (64, 1)), (_backend.TSGU_F32, 64, (32, 1)), (_backend.TSGU_F32, 16, (64, 2)),

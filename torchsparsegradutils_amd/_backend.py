@@ -34,7 +34,7 @@ _ptr = ctypes.c_void_p
 _dbl = ctypes.c_double
 
 # name -> (restype, argtypes); must list every symbol declared in include/tsgu_hip.h
-ABI_VERSION = 6          # TSGU_ABI_VERSION of include/tsgu_hip.h this binding was written against
+ABI_VERSION = 7          # TSGU_ABI_VERSION of include/tsgu_hip.h this binding was written against
 
 SIGNATURES = {
     "tsgu_abi_version": (_int, []),
