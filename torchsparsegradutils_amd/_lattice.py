@@ -565,7 +565,9 @@ _MARCH_WAVES_PER_CU = {0: 20, 1: 20, 2: 16}     # resident waves per CU the segm
 # them the other way round (104.7 against 108.5 us): in the step the SDDMM follows the forward and finds its operands in MALL / L2.
 # Only for rows of one length on the whole box (periodic lattices): same box, in the step, factor 1 / 2: periodic 84.6 / 81.1 us,
 # truncated box 87.3 / 87.5, its lower triangle 61.0 / 65.1.
-MARCH_SDDMM_SEGMENT_FACTOR = int(os.environ.get("TSGU_MARCH_SDDMM_SEGMENT_FACTOR", "2"))
+# (late round 6: with the select-free eight-lane sums the SDDMM issues a quarter fewer instructions and the ranked count is the faster one
+# again — same box, in the step, three alternations: 3 segments 78.5-79.1 us, 6 segments 80.9-81.4 us — so the factor defaults to 1)
+MARCH_SDDMM_SEGMENT_FACTOR = int(os.environ.get("TSGU_MARCH_SDDMM_SEGMENT_FACTOR", "1"))
 # workgroup sizes in order of preference: the first that fits the lattice is taken (measured at C2, same box, us:
 # forward 4x8/256: 80.8-85.5, 8x8/512: 88.1;  SDDMM 8x8/512: 87.4, 4x8/256: 94.6-101.7;  transposed 8x8/512: 102.4, 4x8/256: 99.5-103.0)
 # round 4 (three alternations per configuration in one process, C2, us): SDDMM 4x8/256 80.1-83.0 against 8x8/512 84.4-97.5 — the
