@@ -46,11 +46,16 @@ def test_fingerprint_match_kernel_compares_exactly_and_copies():
             assert torch.equal(copies[0], x) and copies[0].data_ptr() != x.data_ptr()
             same, _ = be.index_fingerprint_match([x], refs=[copies[0]])
             assert torch.equal(same[0, :2], plain[0]) and int(same[0, 2]) == 0, (dtype, n)
+            # compare only (bit 1 of `accumulate`): no fingerprint words, the same verdict
+            only, _ = be.index_fingerprint_match([x], refs=[copies[0]], hash=False)
+            assert only[0].tolist() == [0, 0, 0], (dtype, n)
             for at in sorted({0, n - 1, n // 2, min(n - 1, 4096 * 3 + 5)}):
                 y = copies[0].clone()
                 y[at] += 1
                 diff, _ = be.index_fingerprint_match([x], refs=[y])
                 assert int(diff[0, 2]) != 0 and torch.equal(diff[0, :2], plain[0]), (dtype, n, at)
+                only, _ = be.index_fingerprint_match([x], refs=[y], hash=False)
+                assert int(only[0, 2]) != 0 and only[0, :2].tolist() == [0, 0], (dtype, n, at)
         # views that start 4 / 8 bytes into their storage (scalar path) against aligned references, and the other way round
         big = torch.randint(0, 1 << 30, (70001,), device=DEV, generator=g, dtype=dtype)
         ref = big[1:].clone()
